@@ -1,0 +1,40 @@
+"""Helpers shared by the oracle tests and the GPU parity tests."""
+import json
+import os
+
+import numpy as np
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load_cases(fname):
+    z = np.load(os.path.join(GOLDEN, fname))
+    meta = json.loads(bytes(z["meta_json"]).decode())
+    return z, meta
+
+
+def load_digests():
+    with open(os.path.join(GOLDEN, "digests.json")) as f:
+        return json.load(f)
+
+
+def ndim_of(kind):
+    return 2 if kind.endswith("2") else 1
+
+
+def swt_of(kind):
+    return 1 if "swt" in kind else 0
+
+
+def band_tol(level_index_1based, scale=255.0, base=3e-4):
+    """The reference's absolute rule (test/test_wavelets.py:103,235,247):
+    3e-4 * 2^level on 0..255-range data."""
+    return base * (2 ** level_index_1based) * (scale / 255.0)
+
+
+def rel_err(a, b):
+    """max|a-b| / max|b|  -- the north-star criterion (1e-4 relative per band)."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    den = max(np.abs(b).max(), 1e-30)
+    return np.abs(a - b).max() / den
