@@ -1,0 +1,166 @@
+/*
+ * pypwt_amd.h -- C ABI of the MI355X-native wavelet transform library
+ *                (libpypwt_amd.so, gfx950 HIP kernels).
+ *
+ * This is the drop-in boundary for the reference's hot path.  The reference's
+ * Cython module binds a C++ class directly (`cdef extern from "../pdwt/src/wt.h"`,
+ * reference src/pypwt.pyx:8-61; class Wavelets, reference pdwt/src/wt.h:20-76).
+ * Every method the Cython shim declares has exactly one entry point here, taking
+ * an opaque handle instead of `this`; plain pointers and sizes only, no C++ or
+ * torch types.  INTEGRATION.md shows the `cdef extern` block a pypwt maintainer
+ * would put in place of the C++ one.
+ *
+ * Conventions
+ *   - every function returns an int status: 0 (PDWT_OK) or a negative pdwt_status,
+ *     except the getters documented as returning an element count (like the
+ *     reference's get_image/get_coeff, pdwt/src/wt.cu:419-422, :473-506) and the
+ *     raw-pointer getters.  pdwt_last_error() gives the message of the last
+ *     failure on the calling thread.
+ *   - the plan owns all device memory; host buffers belong to the caller; device
+ *     pointers returned by pdwt_image_ptr / pdwt_coeff_ptr are borrowed and valid
+ *     while the plan lives (pdwt/src/wt.cu:658-665).
+ *   - kernels are enqueued asynchronously on the plan's HIP stream; device->host
+ *     getters synchronise that stream (the reference relies on blocking
+ *     cudaMemcpy on the default stream for the same effect).
+ *   - plans are independent: filter taps are per plan (the reference keeps them
+ *     in process-global __constant__ memory, pdwt/src/common.h:28-36), so plans
+ *     with different wavelets, devices and streams can coexist.  One plan must
+ *     not be used from two threads at once.
+ *   - coefficient index `num` (pdwt/src/wt.cu:479-502):
+ *       2D: 0 = A_L, 1 + 3(l-1) + {0,1,2} = H_l, V_l, D_l   (level 1 = finest)
+ *       1D: 0 = A_L, l = D_l
+ *     A batched plan (batch > 1) stores every band as [batch][rows][cols].
+ */
+#ifndef PYPWT_AMD_H
+#define PYPWT_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pdwt_plan* pdwt_handle;
+
+/* mirrors struct w_info (reference pdwt/src/utils.h:9-19) */
+typedef struct pdwt_info {
+    int ndims;   /* 1 or 2 (a 2D array with ndims == 1 is a batched 1D transform) */
+    int Nr;      /* rows (1 for plain 1D) */
+    int Nc;      /* columns */
+    int nlevels; /* after clamping, pdwt/src/wt.cu:155-165 */
+    int do_swt;  /* stationary (undecimated) transform */
+    int hlen;    /* filter length */
+} pdwt_info;
+
+/* mirrors enum w_state (reference pdwt/src/wt.h:8-17) */
+typedef enum pdwt_state {
+    PDWT_INIT = 0,
+    PDWT_FORWARD = 1,
+    PDWT_INVERSE = 2,
+    PDWT_THRESHOLD = 3,
+    PDWT_CREATION_ERROR = 4,
+    PDWT_FORWARD_ERROR = 5,
+    PDWT_INVERSE_ERROR = 6,
+    PDWT_THRESHOLD_ERROR = 7
+} pdwt_state;
+
+typedef enum pdwt_status {
+    PDWT_OK = 0,
+    PDWT_ERR_ARG = -1,          /* bad argument (null pointer, bad index, size) */
+    PDWT_ERR_WAVELET = -2,      /* unknown wavelet name (reference returns -2, separable.cu:42-45) */
+    PDWT_ERR_HIP = -3,          /* a HIP runtime call failed (reference -3, separable.cu:57-73) */
+    PDWT_ERR_STATE = -4,        /* refused by the state machine (e.g. coefficients after inverse) */
+    PDWT_ERR_FILTER_LEN = -5,   /* custom filter longer than PDWT_MAX_FILTER_WIDTH (reference -1) */
+    PDWT_ERR_MISMATCH = -6,     /* add_wavelet operands differ */
+    PDWT_ERR_UNSUPPORTED = -7,
+    PDWT_ERR_NOMEM = -8
+} pdwt_status;
+
+#define PDWT_MAX_FILTER_WIDTH 40 /* reference pdwt/src/common.h:15 */
+
+/* ---- construction (replaces Wavelets::Wavelets, pdwt/src/wt.cu:84-185, wt.h:42) ----
+ * img: Nr*Nc float32, row-major; host memory if mem_is_on_host else device memory;
+ * NULL = zero image.  Unknown wname -> PDWT_ERR_WAVELET (the reference stores -2 and
+ * later hangs in w_ilog2).  levels is clamped as the reference does.
+ * Uses the current HIP device and a private stream. */
+int pdwt_create(const float* img, int Nr, int Nc, const char* wname, int levels, int mem_is_on_host,
+                int do_separable, int do_cycle_spinning, int do_swt, int ndim, pdwt_handle* out);
+
+/* NEW (not in the reference): explicit device, caller stream (NULL = private stream)
+ * and a batch of `batch` independent images [batch][Nr][Nc] transformed by every call. */
+int pdwt_create_batched(const float* img, int batch, int Nr, int Nc, const char* wname, int levels,
+                        int mem_is_on_host, int do_separable, int do_cycle_spinning, int do_swt, int ndim,
+                        int device_id, void* hip_stream, pdwt_handle* out);
+
+/* deep copy (replaces the copy constructor, pdwt/src/wt.cu:191-222) */
+int pdwt_clone(pdwt_handle src, pdwt_handle* out);
+int pdwt_destroy(pdwt_handle h); /* ~Wavelets, pdwt/src/wt.cu:226-233 */
+
+/* ---- transforms (Wavelets::forward / inverse, pdwt/src/wt.cu:236-305) ---- */
+int pdwt_forward(pdwt_handle h);
+int pdwt_inverse(pdwt_handle h); /* second call in a row: PDWT_ERR_STATE, nothing done */
+
+/* ---- coefficient operators (pdwt/src/wt.cu:308-356, common.cu:219-371) ---- */
+int pdwt_soft_threshold(pdwt_handle h, float beta, int do_thresh_appcoeffs, int normalize);
+int pdwt_hard_threshold(pdwt_handle h, float beta, int do_thresh_appcoeffs, int normalize);
+int pdwt_group_soft_threshold(pdwt_handle h, float beta, int do_thresh_appcoeffs, int normalize);
+int pdwt_shrink(pdwt_handle h, float beta, int do_thresh_appcoeffs);
+int pdwt_proj_linf(pdwt_handle h, float beta, int do_thresh_appcoeffs);
+int pdwt_circshift(pdwt_handle h, int sr, int sc, int inplace); /* wt.cu:364-366 */
+int pdwt_norm1(pdwt_handle h, float* out);   /* wt.cu:396-416 */
+int pdwt_norm2sq(pdwt_handle h, float* out); /* wt.cu:368-393 (1D bug at :387 not reproduced) */
+/* dst += alpha * src ; returns 0, or the reference's codes -1..-4 / +1 (wt.cu:622-655) */
+int pdwt_add_wavelet(pdwt_handle dst, pdwt_handle src, float alpha);
+
+/* ---- data movement (pdwt/src/wt.cu:419-506) ---- */
+long long pdwt_get_image(pdwt_handle h, float* dst);          /* returns element count, <0 on error */
+long long pdwt_get_coeff(pdwt_handle h, float* dst, int num); /* 0 if refused after inverse */
+int pdwt_set_image(pdwt_handle h, const float* src, int mem_is_on_device);
+int pdwt_set_coeff(pdwt_handle h, const float* src, int num, int mem_is_on_device);
+long long pdwt_coeff_count(pdwt_handle h, int num, int* rows, int* cols); /* elements incl. batch */
+intptr_t pdwt_image_ptr(pdwt_handle h);                                   /* wt.cu:658-660 */
+intptr_t pdwt_coeff_ptr(pdwt_handle h, int num);                          /* wt.cu:663-665 */
+
+/* ---- custom filter banks (pdwt/src/wt.cu:558-600) ----
+ * separable plan: filter1 = low-pass, filter2 = high-pass (filter3/4 ignored)
+ * non-separable : filter1..4 = LL, LH, HL, HH, each len*len row-major */
+int pdwt_set_filters_forward(pdwt_handle h, const char* name, unsigned int len, const float* filter1,
+                             const float* filter2, const float* filter3, const float* filter4);
+int pdwt_set_filters_inverse(pdwt_handle h, const float* filter1, const float* filter2, const float* filter3,
+                             const float* filter4);
+
+/* ---- introspection ---- */
+int pdwt_get_info(pdwt_handle h, pdwt_info* info, int* do_separable, int* do_cycle_spinning, int* state,
+                  int* batch);
+int pdwt_print_info(pdwt_handle h);                       /* print_informations, wt.cu:511-550 */
+int pdwt_info_string(pdwt_handle h, char* buf, size_t n); /* same text into a buffer */
+int pdwt_current_shift(pdwt_handle h, int* sr, int* sc);
+const char* pdwt_last_error(void);
+const char* pdwt_version(void);
+
+/* ---- wavelet table ---- */
+int pdwt_wavelet_count(void);
+const char* pdwt_wavelet_name(int index);
+/* banks: 4*hlen floats = dec_lo, dec_hi, rec_lo, rec_hi ; returns hlen or PDWT_ERR_WAVELET */
+int pdwt_wavelet_filters(const char* wname, float* banks, int capacity);
+
+/* ---- stream / device plumbing (NEW) ---- */
+int pdwt_synchronize(pdwt_handle h);
+int pdwt_set_stream(pdwt_handle h, void* hip_stream); /* borrow a caller stream (e.g. torch's) */
+void* pdwt_get_stream(pdwt_handle h);
+int pdwt_device(pdwt_handle h);
+/* fill the plan image on the device with the deterministic test input
+ * x[i] = (lowbias32((i + index_offset) ^ seed) >> 8) * 2^-24 * scale (tests/golden, oracle, bench) */
+int pdwt_fill_image_hash(pdwt_handle h, uint32_t seed, float scale, long long index_offset);
+/* per-launch HIP-event timing: when enabled every kernel launch is bracketed by
+ * events on the plan's stream; pdwt_kernel_times returns (synchronising) the
+ * number of recorded launches and copies names/milliseconds of the first `cap`. */
+int pdwt_enable_kernel_timing(pdwt_handle h, int enable);
+int pdwt_kernel_times(pdwt_handle h, float* ms, char (*names)[48], int cap);
+int pdwt_reset_kernel_times(pdwt_handle h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PYPWT_AMD_H */

@@ -478,7 +478,7 @@ static float app_beta(float beta, int levels, int normalize) {
     if (normalize > 0) {
         const int n2 = levels / 2;
         beta /= (float)(1 << n2);
-        if (n2 * 2 != levels) beta /= (float)1.4142135623730951;
+        if (n2 * 2 != levels) beta = (float)(beta / 1.4142135623730951); /* SQRT_2 is a double, common.cu:8 */
     }
     return beta;
 }
@@ -498,7 +498,7 @@ API void oracle_threshold(float *coeffs, int Nr, int Nc, int ndim, int do_swt, i
     }
     const int per = ndim == 2 ? 3 : 1;
     for (int l = 1; l <= levels; l++) {
-        if (normalize > 0 && op != 2) beta /= (float)1.4142135623730951; /* common.cu:244 */
+        if (normalize > 0 && op != 2) beta = (float)(beta / 1.4142135623730951); /* common.cu:244 */
         for (int k = 0; k < per; k++) {
             const size_t off = oracle_band_offset(Nr, Nc, ndim, do_swt, levels, per * (l - 1) + 1 + k, &r, &c);
             float *b = coeffs + off;
@@ -516,7 +516,7 @@ API void oracle_group_soft_threshold(float *coeffs, int Nr, int Nc, int ndim, in
     const int per = ndim == 2 ? 3 : 1;
     int r, c;
     for (int l = 1; l <= levels; l++) {
-        if (normalize > 0) beta /= (float)1.4142135623730951;
+        if (normalize > 0) beta = (float)(beta / 1.4142135623730951);
         const size_t off = oracle_band_offset(Nr, Nc, ndim, do_swt, levels, per * (l - 1) + 1, &r, &c);
         const size_t n = (size_t)r * c;
         float *b = coeffs + off;

@@ -1,0 +1,11 @@
+"""pypwt_amd -- MI355X-native (gfx950) discrete wavelet transform, drop-in for pycudwt's `Wavelets`.
+
+    from pypwt_amd import Wavelets
+    W = Wavelets(img, "db2", 3); W.forward(); W.soft_threshold(10); W.inverse(); W.coeffs; W.image
+
+The compute path is the hand-written HIP library pypwt_amd/libpypwt_amd.so (C ABI in
+include/pypwt_amd.h, built by `python -m pypwt_amd.build`).  There is no CPU fallback.
+"""
+from .wavelets import BatchedWavelets, Wavelets  # noqa: F401
+
+__version__ = "0.1.0"

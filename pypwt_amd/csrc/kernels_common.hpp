@@ -1,0 +1,141 @@
+// kernels_common.hpp -- shared device helpers for the gfx950 wavelet kernels.
+//
+// Every kernel body is written as a "tile function"
+//     template<...> PDWT_DEVICE void xxx_tile(const Args&, int bx, int by, int bz, float* smem)
+// called from a thin __global__ wrapper with blockIdx and the dynamic-LDS base.
+// Work inside a tile is organised in barrier-separated phases; inside a phase a
+// thread only touches its own registers and LDS/global memory.  That discipline
+// lets tests/cpu_emu compile the SAME tile functions with g++ (PDWT_CPU_EMU: a
+// phase becomes a loop over thread ids, a barrier becomes nothing) and fuzz the
+// index math against the oracle in this GPU-less container; it is a sanitizer
+// build only and is never part of the shipped library.
+#pragma once
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef PDWT_CPU_EMU
+#include <math.h>
+#define PDWT_DEVICE inline
+#define PDWT_FOR_THREADS(tid, NT) for (int tid = 0; tid < (NT); ++tid)
+#define PDWT_SYNC() ((void)0)
+#define PDWT_RESTRICT
+struct pdwt_float2 { float x, y; };
+struct pdwt_float4 { float x, y, z, w; };
+typedef pdwt_float2 f32x2;
+typedef pdwt_float4 f32x4;
+static inline float pdwt_fma(float a, float b, float c) { return a * b + c; }
+#else
+#include <hip/hip_runtime.h>
+#define PDWT_DEVICE __device__ __forceinline__
+// one trip: the executing thread
+#define PDWT_FOR_THREADS(tid, NT) for (int tid = threadIdx.x, pdwt_once_ = 1; pdwt_once_; pdwt_once_ = 0)
+#define PDWT_SYNC() __syncthreads()
+#define PDWT_RESTRICT __restrict__
+typedef float2 f32x2;
+typedef float4 f32x4;
+static __device__ __forceinline__ float pdwt_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+#endif
+
+namespace pdwt {
+
+constexpr int kMaxTaps = 40;  // same limit as the reference (pdwt/src/common.h:15)
+
+// Per-launch filter taps, passed BY VALUE in the kernel-argument segment: with a
+// compile-time filter length every tap index is a constant after unrolling and
+// the taps are fetched with scalar loads (s_load) straight into SGPRs -- no
+// constant-memory bank shared by all plans (the reference's global __constant__
+// arrays, pdwt/src/common.h:28-36, make two live plans overwrite each other).
+struct FilterBank {
+    float lo[kMaxTaps];
+    float hi[kMaxTaps];
+};
+
+// ---- index helpers -------------------------------------------------------
+
+PDWT_DEVICE int true_mod(int i, int n) {
+    int m = i % n;
+    return m < 0 ? m + n : m;
+}
+
+// periodic index into [0, n): one conditional add/sub in the common case
+PDWT_DEVICE int wrap_periodic(int i, int n) {
+    int m = i;
+    if (m < 0) m += n;
+    else if (m >= n) m -= n;
+    if ((unsigned)m >= (unsigned)n) m = true_mod(i, n);  // tile larger than the signal
+    return m;
+}
+
+// analysis source index: the signal is extended to n + (n odd) samples by
+// repeating the last one, and that is periodized
+// (semantics of pdwt/src/separable.cu:114-121, restated as modulo + clamp)
+PDWT_DEVICE int wrap_analysis(int i, int n) {
+    const int np = n + (n & 1);
+    int m = wrap_periodic(i, np);
+    return m >= n ? n - 1 : m;
+}
+
+PDWT_DEVICE int analysis_centre(int hlen) { return (hlen & 1) ? hlen / 2 : hlen / 2 - 1; }
+
+// ---- argument blocks -----------------------------------------------------
+
+// one decimated 2D analysis level: in (Nr,Nc) -> A,H,V,D (Nr2,Nc2)
+struct Fwd2DArgs {
+    const float* in;
+    float *A, *H, *V, *D;
+    int Nr, Nc, Nr2, Nc2;
+    long long in_bstride, out_bstride;  // elements between consecutive images of a batch
+    int hlen;
+    FilterBank fb;  // dec_lo, dec_hi
+};
+
+// one decimated 2D synthesis level: A,H,V,D (Nrc,Ncc) -> out (Nr,Nc), Nr <= 2 Nrc
+struct Inv2DArgs {
+    const float *A, *H, *V, *D;
+    float* out;
+    int Nrc, Ncc, Nr, Nc;
+    long long in_bstride, out_bstride;
+    int hlen;
+    FilterBank fb;  // rec_lo, rec_hi
+};
+
+// one decimated 1D analysis level on `rows` independent rows: in (rows,Nc) -> L,H (rows,Nc2)
+struct Fwd1DArgs {
+    const float* in;
+    float *L, *H;
+    int rows, Nc, Nc2;
+    int hlen;
+    FilterBank fb;
+};
+
+struct Inv1DArgs {
+    const float *L, *H;
+    float* out;
+    int rows, Ncc, Nc;
+    int hlen;
+    FilterBank fb;
+};
+
+// one undecimated (a-trous) 2D level, dilation f = 2^(level-1)
+struct Swt2DArgs {
+    const float* in;          // forward: input plane; inverse: unused
+    float *A, *H, *V, *D;     // forward: outputs; inverse: inputs
+    float* out;               // inverse: output plane
+    int Nr, Nc, f;
+    long long bstride;
+    int hlen;
+    FilterBank fb;
+};
+
+struct Swt1DArgs {
+    const float* in;   // forward input / inverse approximation
+    const float* det;  // inverse: detail band
+    float *L, *H;      // forward outputs
+    float* out;        // inverse output
+    int rows, Nc, f;
+    int hlen;
+    FilterBank fb;
+};
+
+}  // namespace pdwt

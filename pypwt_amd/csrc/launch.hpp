@@ -1,0 +1,38 @@
+// launch.hpp -- host-side launch wrappers around the gfx950 kernels.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "kernels_common.hpp"
+#include "swt_kernels_args.hpp"
+
+namespace pdwt {
+
+// every even filter length of the built-in table gets its own fully unrolled instantiation
+#define PDWT_EVEN_HLENS(X) X(2) X(4) X(6) X(8) X(10) X(12) X(14) X(16) X(18) X(20) X(22) X(24) X(26) \
+    X(28) X(30) X(32) X(34) X(36) X(38) X(40)
+
+// element-wise operator codes of launch_ew
+enum EwOp { EW_SOFT = 0, EW_HARD = 1, EW_LINF = 2, EW_SCALE = 3 };
+
+hipError_t launch_dwt2_fwd(const Fwd2DArgs& a, int batch, hipStream_t s);
+hipError_t launch_dwt2_inv(const Inv2DArgs& a, int batch, hipStream_t s);
+hipError_t launch_dwt1_fwd(const Fwd1DArgs& a, hipStream_t s);
+hipError_t launch_dwt1_inv(const Inv1DArgs& a, hipStream_t s);
+// fused a-trous level; the host guarantees a.f divides a.Nr
+hipError_t launch_swt2_fwd(const Swt2DArgs& a, int batch, hipStream_t s);
+hipError_t launch_swt2_inv(const Swt2DArgs& a, int batch, hipStream_t s);
+hipError_t launch_swt_pass_fwd(const SwtPassArgs& a, hipStream_t s);
+hipError_t launch_swt_pass_inv(const SwtPassArgs& a, hipStream_t s);
+
+// streaming operators over a 16-B aligned range of n floats (n % 4 == 0)
+hipError_t launch_ew(int op, float* p, long long n, float b, hipStream_t s);
+hipError_t launch_group_soft(float* d0, float* d1, float* d2, float* ap, long long n, float beta, int nb,
+                             hipStream_t s);
+hipError_t launch_axpy(float* dst, const float* src, long long n, float alpha, hipStream_t s);
+hipError_t launch_norms(const float* p, long long n, double* out2, hipStream_t s);
+hipError_t launch_circshift(const float* in, float* out, int batch, int Nr, int Nc, int sr, int sc, hipStream_t s);
+hipError_t launch_fill_hash(float* x, long long n, uint32_t seed, float scale, long long index_offset,
+                            hipStream_t s);
+
+}  // namespace pdwt

@@ -1,0 +1,35 @@
+// launch_util.hpp -- small helpers shared by the launch_*.hip translation units.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+namespace pdwt {
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline long long cdivll(long long a, long long b) { return (a + b - 1) / b; }
+
+// Kernels that stage more than 64 KiB of dynamic LDS (long filters) must opt in once per
+// device; gfx950 has 160 KiB per CU.
+template <typename K>
+static inline hipError_t allow_big_lds(K kernel, size_t bytes, bool* done_per_device) {
+    if (bytes <= 64 * 1024) return hipSuccess;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= 64) dev = 0;
+    if (done_per_device[dev]) return hipSuccess;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024);
+    if (e == hipSuccess) done_per_device[dev] = true;
+    return e;
+}
+
+// grid for a grid-stride streaming kernel: enough workgroups to fill 256 CUs x 8
+static inline int stream_grid(long long work_items, int block) {
+    long long g = cdivll(work_items, block);
+    if (g > 2048) g = 2048;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+}  // namespace pdwt

@@ -1,0 +1,991 @@
+// plan.cpp -- C ABI (include/pypwt_amd.h) over the gfx950 kernels.
+//
+// Host-side counterpart of the reference's class Wavelets (pdwt/src/wt.cu) and its level-loop
+// drivers (pdwt/src/separable.cu:179-236, :332-395, :496-537, :629-672).  Each function cites
+// the reference member it replaces.  No CPU fallback exists: without a GPU every entry point
+// that touches data fails with PDWT_ERR_HIP.
+#include "plan.hpp"
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <strings.h>
+
+#include "launch.hpp"
+#include "wavelet_table.hpp"
+
+using namespace pdwt;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                               \
+    do {                                                                                            \
+        hipError_t e_ = (expr);                                                                     \
+        if (e_ != hipSuccess)                                                                       \
+            return fail(PDWT_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, \
+                        __LINE__);                                                                  \
+    } while (0)
+
+#define CHECK_HANDLE(h) \
+    if (!(h)) return fail(PDWT_ERR_ARG, "null plan handle")
+
+int div2(int n) { return (n + (n & 1)) / 2; }  // pdwt/src/utils.cu:24-27
+
+int ilog2(int i) {  // pdwt/src/utils.cu:14-20 (terminates for i <= 0 too)
+    int l = 0;
+    while (i > 1) {
+        i >>= 1;
+        ++l;
+    }
+    return l;
+}
+
+long long pad64(long long n) { return (n + 63) & ~63LL; }
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) { ok = false; return; }
+        if (prev != dev && hipSetDevice(dev) != hipSuccess) ok = false;
+    }
+    ~DeviceGuard() {
+        int cur = -1;
+        if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) (void)hipSetDevice(prev);
+    }
+};
+
+// brackets one kernel launch with events when per-kernel timing is on
+struct Stamp {
+    pdwt_plan* p;
+    int idx = -1;
+    Stamp(pdwt_plan* plan, const char* name) : p(plan) {
+        if (!p->timing) return;
+        KernelStamp s;
+        if (hipEventCreate(&s.start) != hipSuccess) return;
+        if (hipEventCreate(&s.stop) != hipSuccess) { (void)hipEventDestroy(s.start); return; }
+        snprintf(s.name, sizeof(s.name), "%s", name);
+        (void)hipEventRecord(s.start, p->stream);
+        p->stamps.push_back(s);
+        idx = (int)p->stamps.size() - 1;
+    }
+    ~Stamp() {
+        if (idx >= 0) (void)hipEventRecord(p->stamps[idx].stop, p->stream);
+    }
+};
+
+void clear_stamps(pdwt_plan* p) {
+    for (auto& s : p->stamps) {
+        (void)hipEventDestroy(s.start);
+        (void)hipEventDestroy(s.stop);
+    }
+    p->stamps.clear();
+}
+
+void set_bank(FilterBank& fb, const double* lo, const double* hi, int n) {
+    memset(&fb, 0, sizeof(fb));
+    for (int i = 0; i < n; i++) {
+        fb.lo[i] = (float)lo[i];
+        fb.hi[i] = (float)hi[i];
+    }
+}
+
+int ensure_tmp(pdwt_plan* p, long long elems) {
+    if (p->tmp_elems >= elems) return PDWT_OK;
+    if (p->tmp) {
+        HIP_TRY(hipStreamSynchronize(p->stream));
+        HIP_TRY(hipFree(p->tmp));
+        p->tmp = nullptr;
+        p->tmp_elems = 0;
+    }
+    HIP_TRY(hipMalloc((void**)&p->tmp, (size_t)elems * sizeof(float)));
+    p->tmp_elems = elems;
+    return PDWT_OK;
+}
+
+// number of coefficient bands (pdwt/src/common.cu:400-445)
+int num_bands(const pdwt_plan* p) { return p->info.ndims == 2 ? 3 * p->info.nlevels + 1 : p->info.nlevels + 1; }
+
+// Builds level dims, band table and arena layout; allocates and zeroes the arena.
+int build_layout(pdwt_plan* p) {
+    const int L = p->info.nlevels, B = p->batch;
+    const bool two_d = p->info.ndims == 2, swt = p->info.do_swt != 0;
+    p->lr.assign(L + 1, p->info.Nr);
+    p->lc.assign(L + 1, p->info.Nc);
+    for (int l = 1; l <= L; l++) {
+        p->lr[l] = (two_d && !swt) ? div2(p->lr[l - 1]) : p->lr[l - 1];
+        p->lc[l] = swt ? p->lc[l - 1] : div2(p->lc[l - 1]);
+    }
+    long long off = 0;
+    p->bands.clear();
+    p->bands.push_back({off, p->lr[L], p->lc[L]});
+    off += pad64((long long)B * p->lr[L] * p->lc[L]);
+    const int per = two_d ? 3 : 1;
+    for (int l = 1; l <= L; l++)
+        for (int k = 0; k < per; k++) {
+            p->bands.push_back({off, p->lr[l], p->lc[l]});
+            off += pad64((long long)B * p->lr[l] * p->lc[l]);
+        }
+    p->coeff_elems = off;
+    p->approx_off.clear();
+    if (!swt) {
+        p->approx_off.assign(L + 1, -1);
+        for (int l = 1; l < L; l++) {
+            p->approx_off[l] = off;
+            off += pad64((long long)B * p->lr[l] * p->lc[l]);
+        }
+    } else if (L >= 2) {
+        for (int k = 0; k < 2; k++) {
+            p->approx_off.push_back(off);
+            off += pad64((long long)B * p->info.Nr * p->info.Nc);
+        }
+    }
+    p->image_off = off;
+    off += pad64((long long)B * p->info.Nr * p->info.Nc);
+    p->arena_elems = off;
+    HIP_TRY(hipMalloc((void**)&p->arena, (size_t)off * sizeof(float)));
+    HIP_TRY(hipMemsetAsync(p->arena, 0, (size_t)off * sizeof(float), p->stream));
+    HIP_TRY(hipMalloc((void**)&p->d_red, 2 * sizeof(double)));
+    return PDWT_OK;
+}
+
+// outer products for the built-in non-separable banks.  Band naming follows the separable path
+// and pywt: H = high-pass along y (rows index), low-pass along x.  (The reference builds
+// LH = outer(lo, hi) with the row index on `lo`, pdwt/src/nonseparable.cu:70-74 "CHECKME",
+// which swaps H and V relative to its own separable path; not reproduced.)
+int upload_builtin_f2d(pdwt_plan* p) {
+    const int n = p->info.hlen;
+    std::vector<float> h((size_t)8 * n * n);
+    const float* flo[2] = {p->dec.lo, p->rec.lo};
+    const float* fhi[2] = {p->dec.hi, p->rec.hi};
+    for (int d = 0; d < 2; d++) {
+        float* LL = h.data() + (size_t)(4 * d + 0) * n * n;
+        float* LH = h.data() + (size_t)(4 * d + 1) * n * n;  // band H
+        float* HL = h.data() + (size_t)(4 * d + 2) * n * n;  // band V
+        float* HH = h.data() + (size_t)(4 * d + 3) * n * n;
+        for (int i = 0; i < n; i++)      // i: y tap
+            for (int j = 0; j < n; j++) {  // j: x tap
+                LL[i * n + j] = flo[d][i] * flo[d][j];
+                LH[i * n + j] = fhi[d][i] * flo[d][j];
+                HL[i * n + j] = flo[d][i] * fhi[d][j];
+                HH[i * n + j] = fhi[d][i] * fhi[d][j];
+            }
+    }
+    if (!p->d_f2d) HIP_TRY(hipMalloc((void**)&p->d_f2d, (size_t)8 * kMaxTaps * kMaxTaps * sizeof(float)));
+    HIP_TRY(hipMemcpyAsync(p->d_f2d, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    return PDWT_OK;
+}
+
+int create_impl(const float* img, int batch, int Nr, int Nc, const char* wname, int levels, int mem_is_on_host,
+                int do_separable, int do_cycle_spinning, int do_swt, int ndim, int device_id, void* stream,
+                pdwt_handle* out) {
+    if (!out) return fail(PDWT_ERR_ARG, "pdwt_create: out is null");
+    *out = nullptr;
+    if (Nr < 1 || Nc < 1 || batch < 1) return fail(PDWT_ERR_ARG, "pdwt_create: bad shape (%d, %d, %d)", batch, Nr, Nc);
+    if (!wname) return fail(PDWT_ERR_ARG, "pdwt_create: wname is null");
+    const WaveletEntry* w = find_wavelet(wname);
+    if (!w) return fail(PDWT_ERR_WAVELET, "unknown wavelet name %s", wname);
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return fail(PDWT_ERR_HIP, "no HIP device available (this library has no CPU path)");
+    if (device_id < 0) HIP_TRY(hipGetDevice(&device_id));
+    if (device_id >= ndev) return fail(PDWT_ERR_ARG, "device %d out of range (%d devices)", device_id, ndev);
+
+    pdwt_plan* p = new pdwt_plan();
+    p->device = device_id;
+    DeviceGuard guard(device_id);
+    if (!guard.ok) { delete p; return fail(PDWT_ERR_HIP, "cannot select device %d", device_id); }
+
+    p->batch = batch;
+    p->info.Nr = Nr;
+    p->info.Nc = Nc;
+    p->info.do_swt = do_swt ? 1 : 0;
+    p->do_separable = do_separable ? 1 : 0;
+    p->do_cycle_spinning = do_cycle_spinning ? 1 : 0;
+    p->state = PDWT_INIT;
+    snprintf(p->wname, sizeof(p->wname), "%s", wname);
+
+    // dimensions (wt.cu:133-142)
+    ndim = ndim < 2 ? 1 : 2;
+    if (Nr == 1) ndim = 1;
+    p->info.ndims = ndim;
+    if (ndim == 1 && !p->do_separable) {
+        puts("Warning: 1D DWT was requestred, which is incompatible with non-separable transform.");
+        puts("Ignoring the do_separable option.");
+        p->do_separable = 1;
+    }
+    // levels (wt.cu:111-114, 155-165)
+    if (levels < 1) {
+        puts("Warning: cannot initialize wavelet coefficients with nlevels < 1. Forcing nlevels = 1");
+        levels = 1;
+    }
+    p->info.hlen = w->hlen;
+    set_bank(p->dec, w->dec_lo, w->dec_hi, w->hlen);
+    set_bank(p->rec, w->rec_lo, w->rec_hi, w->hlen);
+    const int N = (ndim == 2) ? (Nr < Nc ? Nr : Nc) : Nc;
+    int wmaxlev = ilog2(N / (w->hlen - 1));
+    if (wmaxlev < 1) wmaxlev = 1;  // the reference would set 0 levels and index out of bounds
+    if (levels > wmaxlev) {
+        printf("Warning: required level (%d) is greater than the maximum possible level for %s (%d) on a %dx%d image.\n",
+               levels, wname, wmaxlev, Nc, Nr);
+        printf("Forcing nlevels = %d\n", wmaxlev);
+        levels = wmaxlev;
+    }
+    p->info.nlevels = levels;
+    if (p->do_cycle_spinning && p->info.do_swt)
+        puts("Warning: makes little sense to use Cycle spinning with stationary Wavelet transform");
+    if (p->do_cycle_spinning && ndim == 1) {  // wt.cu:179-183
+        delete p;
+        return fail(PDWT_ERR_UNSUPPORTED, "cycle spinning is not implemented for 1D. Use SWT instead.");
+    }
+
+    int rc = PDWT_OK;
+    auto bail = [&](int code) {
+        pdwt_destroy(p);
+        return code;
+    };
+    if (stream) {
+        p->stream = (hipStream_t)stream;
+        p->own_stream = false;
+    } else {
+        hipError_t e = hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) { delete p; return fail(PDWT_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
+        p->own_stream = true;
+    }
+    if ((rc = build_layout(p)) != PDWT_OK) return bail(rc);
+    if (img) {
+        hipError_t e = hipMemcpyAsync(p->image(), img, (size_t)batch * Nr * Nc * sizeof(float),
+                                      mem_is_on_host ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, p->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(p->stream);
+        if (e != hipSuccess) {
+            fail(PDWT_ERR_HIP, "image upload failed: %s", hipGetErrorString(e));
+            return bail(PDWT_ERR_HIP);
+        }
+    }
+    if (!p->do_separable && (rc = upload_builtin_f2d(p)) != PDWT_OK) return bail(rc);
+    *out = p;
+    return PDWT_OK;
+}
+
+// ---------------------------------------------------------------- level loops
+
+int forward_impl(pdwt_plan* p) {
+    const int L = p->info.nlevels, B = p->batch, hlen = p->info.hlen;
+    const bool swt = p->info.do_swt != 0;
+    const float* src = p->image();
+    if (p->info.ndims == 2) {
+        for (int l = 1; l <= L; l++) {
+            float* dstA = (l == L) ? p->band(0)
+                                   : p->arena + (swt ? p->approx_off[l & 1] : p->approx_off[l]);
+            float* H = p->band(3 * (l - 1) + 1);
+            float* V = p->band(3 * (l - 1) + 2);
+            float* D = p->band(3 * (l - 1) + 3);
+            if (!swt) {
+                Fwd2DArgs a;
+                a.in = src; a.A = dstA; a.H = H; a.V = V; a.D = D;
+                a.Nr = p->lr[l - 1]; a.Nc = p->lc[l - 1]; a.Nr2 = p->lr[l]; a.Nc2 = p->lc[l];
+                a.in_bstride = (long long)a.Nr * a.Nc;
+                a.out_bstride = (long long)a.Nr2 * a.Nc2;
+                a.hlen = hlen;
+                a.fb = p->dec;
+                Stamp st(p, "dwt2_fwd_level");
+                HIP_TRY(launch_dwt2_fwd(a, B, p->stream));
+            } else {
+                const int f = 1 << (l - 1);
+                const int Nr = p->info.Nr, Nc = p->info.Nc;
+                if (Nr % f == 0) {
+                    Swt2DArgs a;
+                    a.in = src; a.A = dstA; a.H = H; a.V = V; a.D = D; a.out = nullptr;
+                    a.Nr = Nr; a.Nc = Nc; a.f = f;
+                    a.bstride = (long long)Nr * Nc;
+                    a.hlen = hlen;
+                    a.fb = p->dec;
+                    Stamp st(p, "swt2_fwd_level");
+                    HIP_TRY(launch_swt2_fwd(a, B, p->stream));
+                } else {
+                    // dilation does not divide the row count: two direct passes through scratch
+                    const long long plane = (long long)Nr * Nc;
+                    int rc = ensure_tmp(p, 2 * plane);
+                    if (rc != PDWT_OK) return rc;
+                    for (int b = 0; b < B; b++) {
+                        SwtPassArgs r;
+                        r.in0 = src + b * plane; r.in1 = nullptr; r.out0 = p->tmp; r.out1 = p->tmp + plane;
+                        r.Nr = Nr; r.Nc = Nc; r.f = f; r.along_y = 0; r.hlen = hlen; r.fb = p->dec;
+                        Stamp st(p, "swt_pass_fwd");
+                        HIP_TRY(launch_swt_pass_fwd(r, p->stream));
+                        SwtPassArgs c1 = r;
+                        c1.in0 = p->tmp; c1.out0 = dstA + b * plane; c1.out1 = H + b * plane; c1.along_y = 1;
+                        HIP_TRY(launch_swt_pass_fwd(c1, p->stream));
+                        SwtPassArgs c2 = c1;
+                        c2.in0 = p->tmp + plane; c2.out0 = V + b * plane; c2.out1 = D + b * plane;
+                        HIP_TRY(launch_swt_pass_fwd(c2, p->stream));
+                    }
+                }
+            }
+            src = dstA;
+        }
+    } else {
+        const int rows = B * p->info.Nr;
+        for (int l = 1; l <= L; l++) {
+            float* dstA = (l == L) ? p->band(0)
+                                   : p->arena + (swt ? p->approx_off[l & 1] : p->approx_off[l]);
+            float* Dl = p->band(l);
+            if (!swt) {
+                Fwd1DArgs a;
+                a.in = src; a.L = dstA; a.H = Dl;
+                a.rows = rows; a.Nc = p->lc[l - 1]; a.Nc2 = p->lc[l];
+                a.hlen = hlen;
+                a.fb = p->dec;
+                Stamp st(p, "dwt1_fwd_level");
+                HIP_TRY(launch_dwt1_fwd(a, p->stream));
+            } else {
+                SwtPassArgs r;
+                r.in0 = src; r.in1 = nullptr; r.out0 = dstA; r.out1 = Dl;
+                r.Nr = rows; r.Nc = p->info.Nc; r.f = 1 << (l - 1); r.along_y = 0; r.hlen = hlen; r.fb = p->dec;
+                Stamp st(p, "swt1_fwd_level");
+                HIP_TRY(launch_swt_pass_fwd(r, p->stream));
+            }
+            src = dstA;
+        }
+    }
+    return PDWT_OK;
+}
+
+int inverse_impl(pdwt_plan* p) {
+    const int L = p->info.nlevels, B = p->batch, hlen = p->info.hlen;
+    const bool swt = p->info.do_swt != 0;
+    const float* cur = p->band(0);
+    if (p->info.ndims == 2) {
+        for (int l = L; l >= 1; l--) {
+            float* dst = (l == 1) ? p->image()
+                                  : p->arena + (swt ? p->approx_off[(l - 1) & 1] : p->approx_off[l - 1]);
+            const float* H = p->band(3 * (l - 1) + 1);
+            const float* V = p->band(3 * (l - 1) + 2);
+            const float* D = p->band(3 * (l - 1) + 3);
+            if (!swt) {
+                Inv2DArgs a;
+                a.A = cur; a.H = H; a.V = V; a.D = D; a.out = dst;
+                a.Nrc = p->lr[l]; a.Ncc = p->lc[l]; a.Nr = p->lr[l - 1]; a.Nc = p->lc[l - 1];
+                a.in_bstride = (long long)a.Nrc * a.Ncc;
+                a.out_bstride = (long long)a.Nr * a.Nc;
+                a.hlen = hlen;
+                a.fb = p->rec;
+                Stamp st(p, "dwt2_inv_level");
+                HIP_TRY(launch_dwt2_inv(a, B, p->stream));
+            } else {
+                const int f = 1 << (l - 1);
+                const int Nr = p->info.Nr, Nc = p->info.Nc;
+                if (Nr % f == 0) {
+                    Swt2DArgs a;
+                    a.in = nullptr;
+                    a.A = const_cast<float*>(cur); a.H = const_cast<float*>(H);
+                    a.V = const_cast<float*>(V); a.D = const_cast<float*>(D);
+                    a.out = dst;
+                    a.Nr = Nr; a.Nc = Nc; a.f = f;
+                    a.bstride = (long long)Nr * Nc;
+                    a.hlen = hlen;
+                    a.fb = p->rec;
+                    Stamp st(p, "swt2_inv_level");
+                    HIP_TRY(launch_swt2_inv(a, B, p->stream));
+                } else {
+                    const long long plane = (long long)Nr * Nc;
+                    int rc = ensure_tmp(p, 2 * plane);
+                    if (rc != PDWT_OK) return rc;
+                    for (int b = 0; b < B; b++) {
+                        SwtPassArgs c1;
+                        c1.in0 = cur + b * plane; c1.in1 = H + b * plane; c1.out0 = p->tmp; c1.out1 = nullptr;
+                        c1.Nr = Nr; c1.Nc = Nc; c1.f = f; c1.along_y = 1; c1.hlen = hlen; c1.fb = p->rec;
+                        Stamp st(p, "swt_pass_inv");
+                        HIP_TRY(launch_swt_pass_inv(c1, p->stream));
+                        SwtPassArgs c2 = c1;
+                        c2.in0 = V + b * plane; c2.in1 = D + b * plane; c2.out0 = p->tmp + plane;
+                        HIP_TRY(launch_swt_pass_inv(c2, p->stream));
+                        SwtPassArgs r = c1;
+                        r.in0 = p->tmp; r.in1 = p->tmp + plane; r.out0 = dst + b * plane; r.along_y = 0;
+                        HIP_TRY(launch_swt_pass_inv(r, p->stream));
+                    }
+                }
+            }
+            cur = dst;
+        }
+    } else {
+        const int rows = B * p->info.Nr;
+        for (int l = L; l >= 1; l--) {
+            float* dst = (l == 1) ? p->image()
+                                  : p->arena + (swt ? p->approx_off[(l - 1) & 1] : p->approx_off[l - 1]);
+            const float* Dl = p->band(l);
+            if (!swt) {
+                Inv1DArgs a;
+                a.L = cur; a.H = Dl; a.out = dst;
+                a.rows = rows; a.Ncc = p->lc[l]; a.Nc = p->lc[l - 1];
+                a.hlen = hlen;
+                a.fb = p->rec;
+                Stamp st(p, "dwt1_inv_level");
+                HIP_TRY(launch_dwt1_inv(a, p->stream));
+            } else {
+                SwtPassArgs r;
+                r.in0 = cur; r.in1 = Dl; r.out0 = dst; r.out1 = nullptr;
+                r.Nr = rows; r.Nc = p->info.Nc; r.f = 1 << (l - 1); r.along_y = 0; r.hlen = hlen; r.fb = p->rec;
+                Stamp st(p, "swt1_inv_level");
+                HIP_TRY(launch_swt_pass_inv(r, p->stream));
+            }
+            cur = dst;
+        }
+    }
+    return PDWT_OK;
+}
+
+int circshift_impl(pdwt_plan* p, int sr, int sc, int inplace) {
+    // pdwt/src/common.cu:378-396
+    const int Nr = p->info.Nr, Nc = p->info.Nc;
+    sr %= Nr; sc %= Nc;
+    if (sr < 0) sr += Nr;
+    if (sc < 0) sc += Nc;
+    if (p->info.ndims == 1) sr = 0;
+    const long long n = (long long)p->batch * Nr * Nc;
+    int rc = ensure_tmp(p, n);
+    if (rc != PDWT_OK) return rc;
+    Stamp st(p, "circshift");
+    if (inplace) {
+        HIP_TRY(hipMemcpyAsync(p->tmp, p->image(), (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, p->stream));
+        HIP_TRY(launch_circshift(p->tmp, p->image(), p->batch, Nr, Nc, sr, sc, p->stream));
+    } else {
+        HIP_TRY(launch_circshift(p->image(), p->tmp, p->batch, Nr, Nc, sr, sc, p->stream));
+    }
+    return PDWT_OK;
+}
+
+// beta / sqrt(2)^levels for the approximation band (pdwt/src/common.cu:229-236)
+float app_beta(float beta, int levels, int normalize) {
+    if (normalize > 0) {
+        const int n2 = levels / 2;
+        beta /= (float)(1 << n2);
+        if (n2 * 2 != levels) beta = (float)(beta / 1.4142135623730951);
+    }
+    return beta;
+}
+
+// soft / hard / proj_linf share one driver (pdwt/src/common.cu:219-308)
+int threshold_impl(pdwt_plan* p, int op, float beta, int do_app, int normalize, const char* what) {
+    if (p->state == PDWT_INVERSE)
+        return fail(PDWT_ERR_STATE, "%s: cannot threshold coefficients, as they were modified by inverse()", what);
+    const int L = p->info.nlevels, B = p->batch;
+    if (do_app) {
+        Stamp st(p, what);
+        HIP_TRY(launch_ew(op, p->band(0), pad64(p->bands[0].elems(B)), app_beta(beta, L, normalize), p->stream));
+    }
+    const int per = p->info.ndims == 2 ? 3 : 1;
+    if (normalize <= 0) {
+        // every detail band shares beta: ONE sweep over the contiguous detail region
+        Stamp st(p, what);
+        const long long first = p->bands[1].off;
+        HIP_TRY(launch_ew(op, p->arena + first, p->coeff_elems - first, beta, p->stream));
+    } else {
+        for (int l = 1; l <= L; l++) {
+            beta = (float)(beta / 1.4142135623730951);  // common.cu:244
+            const long long first = p->bands[per * (l - 1) + 1].off;
+            const long long last = (l == L) ? p->coeff_elems : p->bands[per * l + 1].off;
+            Stamp st(p, what);
+            HIP_TRY(launch_ew(op, p->arena + first, last - first, beta, p->stream));
+        }
+    }
+    return PDWT_OK;
+}
+
+std::string info_text(pdwt_plan* p) {
+    // same lines as Wavelets::print_informations (pdwt/src/wt.cu:511-550)
+    char buf[1024];
+    std::string s;
+    const char* yn[2] = {"no", "yes"};
+    s += "------------- Wavelet transform infos ------------\n";
+    if (p->info.ndims == 2) snprintf(buf, sizeof(buf), "Data dimensions : (%d, %d)\n", p->info.Nr, p->info.Nc);
+    else if (p->info.Nr == 1) snprintf(buf, sizeof(buf), "Data dimensions : %d\n", p->info.Nc);
+    else snprintf(buf, sizeof(buf), "Data dimensions : (%d, %d) [batched 1D transform]\n", p->info.Nr, p->info.Nc);
+    s += buf;
+    if (p->batch > 1) { snprintf(buf, sizeof(buf), "Batch : %d\n", p->batch); s += buf; }
+    snprintf(buf, sizeof(buf), "Wavelet name : %s\nNumber of levels : %d\nStationary WT : %s\nCycle spinning : %s\n"
+             "Separable transform : %s\n", p->wname, p->info.nlevels, yn[p->info.do_swt ? 1 : 0],
+             yn[p->do_cycle_spinning ? 1 : 0], yn[p->do_separable ? 1 : 0]);
+    s += buf;
+    snprintf(buf, sizeof(buf), "Estimated memory footprint : %.2f MB\n",
+             (double)(p->arena_elems + p->tmp_elems) * sizeof(float) / 1e6);
+    s += buf;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, p->device) == hipSuccess)
+        snprintf(buf, sizeof(buf), "Running on device : %s\n", prop.name);
+    else snprintf(buf, sizeof(buf), "Running on device : (unknown)\n");
+    s += buf;
+    s += "--------------------------------------------------\n";
+    return s;
+}
+
+}  // namespace
+
+// =============================================================================
+#pragma GCC visibility push(default)
+extern "C" {
+
+const char* pdwt_last_error(void) { return g_last_error.c_str(); }
+const char* pdwt_version(void) { return "pypwt_amd 0.1.0 (gfx950); API of pycudwt 1.0.3"; }
+
+int pdwt_create(const float* img, int Nr, int Nc, const char* wname, int levels, int mem_is_on_host,
+                int do_separable, int do_cycle_spinning, int do_swt, int ndim, pdwt_handle* out) {
+    return create_impl(img, 1, Nr, Nc, wname, levels, mem_is_on_host, do_separable, do_cycle_spinning, do_swt,
+                       ndim, -1, nullptr, out);
+}
+
+int pdwt_create_batched(const float* img, int batch, int Nr, int Nc, const char* wname, int levels,
+                        int mem_is_on_host, int do_separable, int do_cycle_spinning, int do_swt, int ndim,
+                        int device_id, void* hip_stream, pdwt_handle* out) {
+    return create_impl(img, batch, Nr, Nc, wname, levels, mem_is_on_host, do_separable, do_cycle_spinning, do_swt,
+                       ndim, device_id, hip_stream, out);
+}
+
+int pdwt_clone(pdwt_handle src, pdwt_handle* out) {
+    CHECK_HANDLE(src);
+    if (!out) return fail(PDWT_ERR_ARG, "pdwt_clone: out is null");
+    *out = nullptr;
+    DeviceGuard guard(src->device);
+    pdwt_plan* p = new pdwt_plan();
+    p->device = src->device;
+    p->batch = src->batch;
+    p->info = src->info;
+    p->do_separable = src->do_separable;
+    p->do_cycle_spinning = src->do_cycle_spinning;
+    p->state = src->state;
+    memcpy(p->wname, src->wname, sizeof(p->wname));
+    p->shift_r = src->shift_r;
+    p->shift_c = src->shift_c;
+    p->dec = src->dec;
+    p->rec = src->rec;
+    hipError_t e = hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete p; return fail(PDWT_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
+    p->own_stream = true;
+    int rc = build_layout(p);
+    if (rc != PDWT_OK) { pdwt_destroy(p); return rc; }
+    e = hipStreamSynchronize(src->stream);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(p->arena, src->arena, (size_t)p->arena_elems * sizeof(float), hipMemcpyDeviceToDevice,
+                           p->stream);
+    if (e == hipSuccess && src->d_f2d) {
+        e = hipMalloc((void**)&p->d_f2d, (size_t)8 * kMaxTaps * kMaxTaps * sizeof(float));
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(p->d_f2d, src->d_f2d, (size_t)8 * kMaxTaps * kMaxTaps * sizeof(float),
+                               hipMemcpyDeviceToDevice, p->stream);
+        p->f2d_custom = src->f2d_custom;
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(p->stream);
+    if (e != hipSuccess) { pdwt_destroy(p); return fail(PDWT_ERR_HIP, "clone copy: %s", hipGetErrorString(e)); }
+    *out = p;
+    return PDWT_OK;
+}
+
+int pdwt_destroy(pdwt_handle h) {
+    if (!h) return PDWT_OK;
+    DeviceGuard guard(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    clear_stamps(h);
+    if (h->arena) (void)hipFree(h->arena);
+    if (h->tmp) (void)hipFree(h->tmp);
+    if (h->d_red) (void)hipFree(h->d_red);
+    if (h->d_f2d) (void)hipFree(h->d_f2d);
+    if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return PDWT_OK;
+}
+
+int pdwt_forward(pdwt_handle h) {  // Wavelets::forward, wt.cu:236-269
+    CHECK_HANDLE(h);
+    if (h->state == PDWT_CREATION_ERROR)
+        return fail(PDWT_ERR_STATE, "forward transform not computed, as there was an error when creating the wavelets");
+    DeviceGuard guard(h->device);
+    if (!h->do_separable && h->info.ndims == 2 && h->f2d_custom)
+        return fail(PDWT_ERR_UNSUPPORTED, "custom non-separable filter banks: kernel not built yet");
+    if (h->do_cycle_spinning) {  // wt.cu:242-246
+        h->shift_r = rand() % h->info.Nr;
+        h->shift_c = rand() % h->info.Nc;
+        int rc = circshift_impl(h, h->shift_r, h->shift_c, 1);
+        if (rc != PDWT_OK) return rc;
+    }
+    int rc = forward_impl(h);
+    h->state = (rc == PDWT_OK) ? PDWT_FORWARD : PDWT_FORWARD_ERROR;
+    return rc;
+}
+
+int pdwt_inverse(pdwt_handle h) {  // Wavelets::inverse, wt.cu:271-305
+    CHECK_HANDLE(h);
+    if (h->state == PDWT_INVERSE)
+        return fail(PDWT_ERR_STATE, "W.inverse() has already been run. Inverse is available in W.get_image()");
+    if (h->state == PDWT_FORWARD_ERROR || h->state == PDWT_THRESHOLD_ERROR || h->state == PDWT_CREATION_ERROR)
+        return fail(PDWT_ERR_STATE, "inverse transform not computed, as there was an error in a previous stage");
+    DeviceGuard guard(h->device);
+    int rc = inverse_impl(h);
+    if (rc == PDWT_OK && h->do_cycle_spinning) rc = circshift_impl(h, -h->shift_r, -h->shift_c, 1);  // wt.cu:303
+    h->state = (rc == PDWT_OK) ? PDWT_INVERSE : PDWT_INVERSE_ERROR;
+    return rc;
+}
+
+int pdwt_soft_threshold(pdwt_handle h, float beta, int do_app, int normalize) {  // wt.cu:308-315
+    CHECK_HANDLE(h);
+    DeviceGuard guard(h->device);
+    return threshold_impl(h, EW_SOFT, beta, do_app, normalize, "soft_threshold");
+}
+
+int pdwt_hard_threshold(pdwt_handle h, float beta, int do_app, int normalize) {  // wt.cu:318-325
+    CHECK_HANDLE(h);
+    DeviceGuard guard(h->device);
+    return threshold_impl(h, EW_HARD, beta, do_app, normalize, "hard_threshold");
+}
+
+int pdwt_proj_linf(pdwt_handle h, float beta, int do_app) {  // wt.cu:349-356
+    CHECK_HANDLE(h);
+    DeviceGuard guard(h->device);
+    return threshold_impl(h, EW_LINF, beta, do_app, 0, "proj_linf");
+}
+
+int pdwt_group_soft_threshold(pdwt_handle h, float beta, int do_app, int normalize) {  // wt.cu:329-336
+    CHECK_HANDLE(h);
+    if (h->state == PDWT_INVERSE)
+        return fail(PDWT_ERR_STATE, "cannot threshold coefficients, as they were modified by inverse()");
+    DeviceGuard guard(h->device);
+    const int L = h->info.nlevels, B = h->batch;
+    const int per = h->info.ndims == 2 ? 3 : 1;
+    for (int l = 1; l <= L; l++) {  // common.cu:311-341
+        if (normalize > 0) beta = (float)(beta / 1.4142135623730951);
+        float* d0 = h->band(per * (l - 1) + 1);
+        float* d1 = per == 3 ? h->band(per * (l - 1) + 2) : nullptr;
+        float* d2 = per == 3 ? h->band(per * (l - 1) + 3) : nullptr;
+        float* ap = (do_app && l == L) ? h->band(0) : nullptr;
+        Stamp st(h, "group_soft_threshold");
+        HIP_TRY(launch_group_soft(d0, d1, d2, ap, h->bands[per * (l - 1) + 1].elems(B), beta, per, h->stream));
+    }
+    return PDWT_OK;
+}
+
+int pdwt_shrink(pdwt_handle h, float beta, int do_app) {  // wt.cu:340-347, common.cu:347-371
+    CHECK_HANDLE(h);
+    if (h->state == PDWT_INVERSE)
+        return fail(PDWT_ERR_STATE, "cannot threshold coefficients, as they were modified by inverse()");
+    DeviceGuard guard(h->device);
+    const long long first = do_app ? 0 : h->bands[1].off;
+    Stamp st(h, "shrink");
+    HIP_TRY(launch_ew(EW_SCALE, h->arena + first, h->coeff_elems - first, 1.0f / (1.0f + beta), h->stream));
+    return PDWT_OK;
+}
+
+int pdwt_circshift(pdwt_handle h, int sr, int sc, int inplace) {
+    CHECK_HANDLE(h);
+    DeviceGuard guard(h->device);
+    return circshift_impl(h, sr, sc, inplace);
+}
+
+static int norms_impl(pdwt_handle h, double out[2]) {
+    DeviceGuard guard(h->device);
+    HIP_TRY(hipMemsetAsync(h->d_red, 0, 2 * sizeof(double), h->stream));
+    {
+        Stamp st(h, "norms");
+        HIP_TRY(launch_norms(h->arena, h->coeff_elems, h->d_red, h->stream));
+    }
+    HIP_TRY(hipMemcpyAsync(out, h->d_red, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return PDWT_OK;
+}
+
+int pdwt_norm1(pdwt_handle h, float* out) {  // wt.cu:396-416
+    CHECK_HANDLE(h);
+    if (!out) return fail(PDWT_ERR_ARG, "pdwt_norm1: out is null");
+    double r[2];
+    int rc = norms_impl(h, r);
+    if (rc == PDWT_OK) *out = (float)r[0];
+    return rc;
+}
+
+int pdwt_norm2sq(pdwt_handle h, float* out) {  // wt.cu:368-393
+    CHECK_HANDLE(h);
+    if (!out) return fail(PDWT_ERR_ARG, "pdwt_norm2sq: out is null");
+    double r[2];
+    int rc = norms_impl(h, r);
+    if (rc == PDWT_OK) *out = (float)r[1];
+    return rc;
+}
+
+int pdwt_add_wavelet(pdwt_handle dst, pdwt_handle src, float alpha) {  // wt.cu:622-655
+    CHECK_HANDLE(dst);
+    CHECK_HANDLE(src);
+    if (dst->info.nlevels != src->info.nlevels || strcasecmp(dst->wname, src->wname)) {
+        fail(PDWT_ERR_MISMATCH, "add_wavelet(): right operand is not the same transform (wname, level)");
+        return -1;
+    }
+    if (dst->state == PDWT_INVERSE || src->state == PDWT_INVERSE) {
+        fail(PDWT_ERR_STATE, "add_wavelet(): this operation makes no sense when wavelet has just been inverted");
+        return 1;
+    }
+    if (dst->info.Nr != src->info.Nr || dst->info.Nc != src->info.Nc || dst->info.ndims != src->info.ndims ||
+        dst->batch != src->batch) {
+        fail(PDWT_ERR_MISMATCH, "add_wavelet(): operands do not have the same geometry");
+        return -2;
+    }
+    if ((dst->info.do_swt != 0) != (src->info.do_swt != 0)) {
+        fail(PDWT_ERR_MISMATCH, "add_wavelet(): operands should both use SWT or DWT");
+        return -3;
+    }
+    if (dst->do_cycle_spinning && src->do_cycle_spinning &&
+        (dst->shift_r != src->shift_r || dst->shift_c != src->shift_c)) {
+        fail(PDWT_ERR_MISMATCH, "add_wavelet(): operands do not have the same current shift");
+        return -4;
+    }
+    if (dst->device != src->device) {
+        fail(PDWT_ERR_MISMATCH, "add_wavelet(): operands live on different devices");
+        return -2;
+    }
+    DeviceGuard guard(dst->device);
+    if (src->stream != dst->stream) HIP_TRY(hipStreamSynchronize(src->stream));
+    Stamp st(dst, "add_wavelet");
+    HIP_TRY(launch_axpy(dst->arena, src->arena, dst->coeff_elems, alpha, dst->stream));
+    return PDWT_OK;
+}
+
+long long pdwt_get_image(pdwt_handle h, float* dst) {  // wt.cu:419-422
+    if (!h || !dst) return fail(PDWT_ERR_ARG, "pdwt_get_image: null argument");
+    DeviceGuard guard(h->device);
+    const long long n = (long long)h->batch * h->info.Nr * h->info.Nc;
+    HIP_TRY(hipMemcpyAsync(dst, h->image(), (size_t)n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return n;
+}
+
+long long pdwt_coeff_count(pdwt_handle h, int num, int* rows, int* cols) {
+    if (!h) return fail(PDWT_ERR_ARG, "null plan handle");
+    if (num < 0 || num >= (int)h->bands.size()) return fail(PDWT_ERR_ARG, "coefficient index %d out of range", num);
+    if (rows) *rows = h->bands[num].rows;
+    if (cols) *cols = h->bands[num].cols;
+    return h->bands[num].elems(h->batch);
+}
+
+long long pdwt_get_coeff(pdwt_handle h, float* dst, int num) {  // wt.cu:473-506
+    if (!h || !dst) return fail(PDWT_ERR_ARG, "pdwt_get_coeff: null argument");
+    if (num < 0 || num >= (int)h->bands.size()) return fail(PDWT_ERR_ARG, "coefficient index %d out of range", num);
+    if (h->state == PDWT_INVERSE) {
+        fail(PDWT_ERR_STATE, "get_coeff(): inverse() has been performed, the coefficients has been modified and do not make sense anymore.");
+        return 0;
+    }
+    DeviceGuard guard(h->device);
+    const long long n = h->bands[num].elems(h->batch);
+    HIP_TRY(hipMemcpyAsync(dst, h->band(num), (size_t)n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return n;
+}
+
+int pdwt_set_image(pdwt_handle h, const float* src, int mem_is_on_device) {  // wt.cu:425-431
+    CHECK_HANDLE(h);
+    if (!src) return fail(PDWT_ERR_ARG, "pdwt_set_image: src is null");
+    DeviceGuard guard(h->device);
+    const long long n = (long long)h->batch * h->info.Nr * h->info.Nc;
+    HIP_TRY(hipMemcpyAsync(h->image(), src, (size_t)n * sizeof(float),
+                           mem_is_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, h->stream));
+    if (!mem_is_on_device) HIP_TRY(hipStreamSynchronize(h->stream));  // the host buffer may be reused
+    h->state = PDWT_INIT;
+    return PDWT_OK;
+}
+
+int pdwt_set_coeff(pdwt_handle h, const float* src, int num, int mem_is_on_device) {  // wt.cu:435-466
+    CHECK_HANDLE(h);
+    if (!src) return fail(PDWT_ERR_ARG, "pdwt_set_coeff: src is null");
+    if (num < 0 || num >= (int)h->bands.size()) return fail(PDWT_ERR_ARG, "coefficient index %d out of range", num);
+    DeviceGuard guard(h->device);
+    const long long n = h->bands[num].elems(h->batch);
+    HIP_TRY(hipMemcpyAsync(h->band(num), src, (size_t)n * sizeof(float),
+                           mem_is_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, h->stream));
+    if (!mem_is_on_device) HIP_TRY(hipStreamSynchronize(h->stream));
+    return PDWT_OK;
+}
+
+intptr_t pdwt_image_ptr(pdwt_handle h) { return h ? (intptr_t)h->image() : 0; }
+
+intptr_t pdwt_coeff_ptr(pdwt_handle h, int num) {
+    if (!h || num < 0 || num >= (int)h->bands.size()) return 0;
+    return (intptr_t)h->band(num);
+}
+
+int pdwt_set_filters_forward(pdwt_handle h, const char* name, unsigned int len, const float* f1, const float* f2,
+                             const float* f3, const float* f4) {  // wt.cu:558-578
+    CHECK_HANDLE(h);
+    if (len > PDWT_MAX_FILTER_WIDTH || len < 1)
+        return fail(PDWT_ERR_FILTER_LEN, "set_filters_forward(): filter length (%u) exceeds the maximum size (%d)", len,
+                    PDWT_MAX_FILTER_WIDTH);
+    if (!f1 || !f2) return fail(PDWT_ERR_ARG, "set_filters_forward(): filter1/filter2 are required");
+    DeviceGuard guard(h->device);
+    if (h->do_separable) {
+        memset(&h->dec, 0, sizeof(h->dec));
+        memcpy(h->dec.lo, f1, len * sizeof(float));
+        memcpy(h->dec.hi, f2, len * sizeof(float));
+    } else {
+        if (!f3 || !f4)
+            return fail(PDWT_ERR_ARG, "set_filters_forward(): expected argument 4 and 5 for non-separable filtering");
+        if (!h->d_f2d) HIP_TRY(hipMalloc((void**)&h->d_f2d, (size_t)8 * kMaxTaps * kMaxTaps * sizeof(float)));
+        const float* f[4] = {f1, f2, f3, f4};
+        for (int k = 0; k < 4; k++)
+            HIP_TRY(hipMemcpyAsync(h->d_f2d + (size_t)k * len * len, f[k], (size_t)len * len * sizeof(float),
+                                   hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        h->f2d_custom = true;
+    }
+    h->info.hlen = (int)len;
+    if (name) snprintf(h->wname, sizeof(h->wname), "%s", name);
+    return PDWT_OK;
+}
+
+int pdwt_set_filters_inverse(pdwt_handle h, const float* f1, const float* f2, const float* f3,
+                             const float* f4) {  // wt.cu:583-600
+    CHECK_HANDLE(h);
+    if (!f1 || !f2) return fail(PDWT_ERR_ARG, "set_filters_inverse(): filter1/filter2 are required");
+    const unsigned len = (unsigned)h->info.hlen;
+    DeviceGuard guard(h->device);
+    if (h->do_separable) {
+        memset(&h->rec, 0, sizeof(h->rec));
+        memcpy(h->rec.lo, f1, len * sizeof(float));
+        memcpy(h->rec.hi, f2, len * sizeof(float));
+    } else {
+        if (!f3 || !f4)
+            return fail(PDWT_ERR_ARG, "set_filters_inverse(): expected argument 4 and 5 for non-separable filtering");
+        if (!h->d_f2d) HIP_TRY(hipMalloc((void**)&h->d_f2d, (size_t)8 * kMaxTaps * kMaxTaps * sizeof(float)));
+        const float* f[4] = {f1, f2, f3, f4};
+        for (int k = 0; k < 4; k++)
+            HIP_TRY(hipMemcpyAsync(h->d_f2d + (size_t)(4 + k) * len * len, f[k], (size_t)len * len * sizeof(float),
+                                   hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        h->f2d_custom = true;
+    }
+    return PDWT_OK;
+}
+
+int pdwt_get_info(pdwt_handle h, pdwt_info* info, int* do_separable, int* do_cycle_spinning, int* state,
+                  int* batch) {
+    CHECK_HANDLE(h);
+    if (info) *info = h->info;
+    if (do_separable) *do_separable = h->do_separable;
+    if (do_cycle_spinning) *do_cycle_spinning = h->do_cycle_spinning;
+    if (state) *state = h->state;
+    if (batch) *batch = h->batch;
+    return PDWT_OK;
+}
+
+int pdwt_print_info(pdwt_handle h) {
+    CHECK_HANDLE(h);
+    fputs(info_text(h).c_str(), stdout);
+    fflush(stdout);
+    return PDWT_OK;
+}
+
+int pdwt_info_string(pdwt_handle h, char* buf, size_t n) {
+    CHECK_HANDLE(h);
+    if (!buf || n == 0) return fail(PDWT_ERR_ARG, "pdwt_info_string: empty buffer");
+    snprintf(buf, n, "%s", info_text(h).c_str());
+    return PDWT_OK;
+}
+
+int pdwt_current_shift(pdwt_handle h, int* sr, int* sc) {
+    CHECK_HANDLE(h);
+    if (sr) *sr = h->shift_r;
+    if (sc) *sc = h->shift_c;
+    return PDWT_OK;
+}
+
+int pdwt_wavelet_count(void) { return wavelet_count(); }
+
+const char* pdwt_wavelet_name(int index) {
+    const WaveletEntry* w = wavelet_at(index);
+    return w ? w->name : nullptr;
+}
+
+int pdwt_wavelet_filters(const char* wname, float* banks, int capacity) {
+    const WaveletEntry* w = find_wavelet(wname);
+    if (!w) return fail(PDWT_ERR_WAVELET, "unknown wavelet name %s", wname ? wname : "(null)");
+    if (banks) {
+        if (capacity < 4 * w->hlen) return fail(PDWT_ERR_ARG, "pdwt_wavelet_filters: capacity %d < %d", capacity, 4 * w->hlen);
+        for (int i = 0; i < w->hlen; i++) {
+            banks[i] = (float)w->dec_lo[i];
+            banks[w->hlen + i] = (float)w->dec_hi[i];
+            banks[2 * w->hlen + i] = (float)w->rec_lo[i];
+            banks[3 * w->hlen + i] = (float)w->rec_hi[i];
+        }
+    }
+    return w->hlen;
+}
+
+int pdwt_synchronize(pdwt_handle h) {
+    CHECK_HANDLE(h);
+    DeviceGuard guard(h->device);
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return PDWT_OK;
+}
+
+int pdwt_set_stream(pdwt_handle h, void* hip_stream) {
+    CHECK_HANDLE(h);
+    DeviceGuard guard(h->device);
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (h->own_stream && h->stream) HIP_TRY(hipStreamDestroy(h->stream));
+    h->stream = (hipStream_t)hip_stream;
+    h->own_stream = false;
+    return PDWT_OK;
+}
+
+void* pdwt_get_stream(pdwt_handle h) { return h ? (void*)h->stream : nullptr; }
+int pdwt_device(pdwt_handle h) { return h ? h->device : -1; }
+
+int pdwt_fill_image_hash(pdwt_handle h, uint32_t seed, float scale, long long index_offset) {
+    CHECK_HANDLE(h);
+    DeviceGuard guard(h->device);
+    Stamp st(h, "fill_hash");
+    HIP_TRY(launch_fill_hash(h->image(), (long long)h->batch * h->info.Nr * h->info.Nc, seed, scale, index_offset,
+                             h->stream));
+    h->state = PDWT_INIT;
+    return PDWT_OK;
+}
+
+int pdwt_enable_kernel_timing(pdwt_handle h, int enable) {
+    CHECK_HANDLE(h);
+    h->timing = enable != 0;
+    return PDWT_OK;
+}
+
+int pdwt_reset_kernel_times(pdwt_handle h) {
+    CHECK_HANDLE(h);
+    DeviceGuard guard(h->device);
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    clear_stamps(h);
+    return PDWT_OK;
+}
+
+int pdwt_kernel_times(pdwt_handle h, float* ms, char (*names)[48], int cap) {
+    CHECK_HANDLE(h);
+    DeviceGuard guard(h->device);
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    const int n = (int)h->stamps.size();
+    for (int i = 0; i < n && i < cap; i++) {
+        float t = 0.f;
+        HIP_TRY(hipEventElapsedTime(&t, h->stamps[i].start, h->stamps[i].stop));
+        if (ms) ms[i] = t;
+        if (names) memcpy(names[i], h->stamps[i].name, 48);
+    }
+    return n;
+}
+
+}  // extern "C"
+#pragma GCC visibility pop

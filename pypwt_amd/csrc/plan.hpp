@@ -1,0 +1,76 @@
+// plan.hpp -- host-side transform plan (the MI355X counterpart of the reference's
+// C++ class Wavelets, pdwt/src/wt.h:20-76).
+//
+// A plan owns ONE device arena:
+//
+//   [ band 0 = A_L | band 1 | band 2 | ...  ]  coefficient region, reference order
+//   [ A_1 | A_2 | ... | A_{L-1} ]              intermediate approximations (DWT)
+//     or [ ping | pong ]                        two full-size planes (SWT, L >= 2)
+//   [ image ]
+//
+// Every band is [batch][rows][cols] float32, starts on a 256-B boundary and is
+// zero-padded to a multiple of 64 floats, so element-wise operators sweep whole
+// regions with 16-B accesses.  The forward transform writes A_l to its own slot
+// and the last level writes band 0 directly: there is no ping-pong fix-up copy
+// (reference: pdwt/src/separable.cu:234,389,535,667, haar.cu:83,112,186,214) and
+// the inverse does not overwrite band 0 (reference: wt.cu:272-275).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/pypwt_amd.h"
+#include "kernels_common.hpp"
+
+namespace pdwt {
+
+struct Band {
+    long long off;   // offset in floats from the arena base
+    int rows, cols;  // per image
+    long long elems(int batch) const { return (long long)batch * rows * cols; }
+};
+
+struct KernelStamp {
+    hipEvent_t start, stop;
+    char name[48];
+};
+
+}  // namespace pdwt
+
+struct pdwt_plan {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+
+    int batch = 1;
+    pdwt_info info{};  // ndims, Nr, Nc, nlevels, do_swt, hlen   (w_info, utils.h:9-19)
+    int do_separable = 1;
+    int do_cycle_spinning = 0;
+    int state = PDWT_INIT;
+    char wname[128] = {0};
+    int shift_r = 0, shift_c = 0;  // current cycle-spinning shift (wt.h:27-28)
+
+    float* arena = nullptr;
+    long long arena_elems = 0;
+    std::vector<pdwt::Band> bands;      // coefficient bands, index = `num`
+    long long coeff_elems = 0;          // size of the (padded) coefficient region
+    std::vector<long long> approx_off;  // DWT: [l] for 1 <= l < L ; SWT: [0], [1] ping-pong
+    long long image_off = 0;
+    std::vector<int> lr, lc;  // per-level image dims, lr[0] = Nr ... lr[L]
+
+    float* tmp = nullptr;  // lazily allocated scratch (circshift, SWT fallback)
+    long long tmp_elems = 0;
+    double* d_red = nullptr;  // two fp64 accumulators for the norms
+
+    pdwt::FilterBank dec{}, rec{};
+    float* d_f2d = nullptr;  // non-separable banks: fwd LL,LH,HL,HH then inv, each hlen*hlen
+    bool f2d_custom = false;
+
+    bool timing = false;
+    std::vector<pdwt::KernelStamp> stamps;
+
+    float* image() const { return arena + image_off; }
+    float* band(int num) const { return arena + bands[num].off; }
+};

@@ -1,0 +1,261 @@
+// swt_kernels.hpp -- undecimated (a-trous) wavelet level kernels for gfx950.
+//
+// Level l dilates the taps by f = 2^(l-1).  Rows y, y+f, y+2f, ... form f
+// independent "phase" sub-signals when f divides Nr, so the fused 2D kernels
+// tile the image as TX contiguous columns x TY rows OF ONE PHASE: the column
+// pass then needs a dense (hlen-1)-row halo whatever the dilation, and it runs
+// out of LDS.  The row pass reads its dilated taps straight from global memory
+// (each tap is a full coalesced row segment shifted by j*f; the re-reads hit
+// L1/L2), so no x-halo has to be staged.  Row and column pass are fused: the
+// intermediate low/high planes live only in LDS (the reference writes and
+// re-reads two full-size temporaries per level, pdwt/src/separable.cu:507-512
+// and :641-646).
+//
+// Semantics (restated in oracle/pdwt_oracle.c, pinned to pywt.swt/iswt):
+//   analysis   out[g] = sum_j x[(g + (j-c) f) mod N] * filt[hlen-1-j]
+//              (pdwt/src/separable.cu:409-493)
+//   synthesis  out[g] = 1/2 sum_j a[(g + (j-c') f) mod N] * rlo[hlen-1-j] + d[..] * rhi[hlen-1-j],
+//              c' = hlen/2   (pdwt/src/separable.cu:553-626)
+// The inverse applies the row (x) synthesis first and the column (y) synthesis
+// second; the two 1D operators commute, the reference runs them in the other
+// order (difference: fp32 rounding only).
+//
+// When f does not divide Nr (pywt cannot do these sizes; the reference can) the
+// host falls back to the direct one-pass kernels at the bottom, which are also
+// the (batched) 1D SWT.
+#pragma once
+
+#include "kernels_common.hpp"
+#include "swt_kernels_args.hpp"
+
+namespace pdwt {
+
+template <int TX, int TY>
+constexpr int swt2d_lds_floats(int hlen) {
+    return 2 * kMaxTaps + 2 * (TY + hlen - 1) * TX;
+}
+
+#define PDWT_STAGE_TAPS()                                   \
+    float* sTaps = smem;                                    \
+    const float* lo = a.fb.lo;                              \
+    const float* hi = a.fb.hi;                              \
+    if (HLEN == 0) {                                        \
+        PDWT_FOR_THREADS(tid, NT) {                         \
+            if (tid < kMaxTaps) {                           \
+                sTaps[tid] = a.fb.lo[tid];                  \
+                sTaps[kMaxTaps + tid] = a.fb.hi[tid];       \
+            }                                               \
+        }                                                   \
+        PDWT_SYNC();                                        \
+        lo = sTaps;                                         \
+        hi = sTaps + kMaxTaps;                              \
+    }
+
+// by enumerates (row tile, phase): ph = by % f, it = by / f
+template <int HLEN, int TX, int TY, int NT>
+PDWT_DEVICE void swt2_fwd_tile(const Swt2DArgs& a, int bx, int by, int bz, float* smem) {
+    static_assert(NT % TX == 0 && TY % (NT / TX) == 0, "tile/thread shape");
+    constexpr int NG = NT / TX;
+    constexpr int R = TY / NG;
+    const int hlen = HLEN ? HLEN : a.hlen;
+    const int c = analysis_centre(hlen);
+    const int f = a.f;
+    const int M = a.Nr / f;  // rows per phase (host guarantees f | Nr)
+    const int ph = by % f;
+    const int it = by / f;
+    const int RY = TY + hlen - 1;
+
+    PDWT_STAGE_TAPS();
+    float* tL = smem + 2 * kMaxTaps;
+    float* tH = tL + RY * TX;
+
+    const float* PDWT_RESTRICT in = a.in + (long long)bz * a.bstride;
+
+    // ---- phase 1: dilated row analysis straight from global -> tL, tH (RY x TX)
+    PDWT_FOR_THREADS(tid, NT) {
+        const int k = tid % TX;
+        const int x = bx * TX + k;
+        for (int r = tid / TX; r < RY; r += NG) {
+            float aL = 0.f, aH = 0.f;
+            if (x < a.Nc) {
+                const int i = wrap_periodic(it * TY - c + r, M);
+                const float* row = in + (long long)(ph + f * i) * a.Nc;
+#pragma unroll
+                for (int j = 0; j < (HLEN > 0 ? HLEN : hlen); ++j) {
+                    const float v = row[wrap_periodic(x + (j - c) * f, a.Nc)];
+                    aL = pdwt_fma(v, lo[hlen - 1 - j], aL);
+                    aH = pdwt_fma(v, hi[hlen - 1 - j], aH);
+                }
+            }
+            tL[r * TX + k] = aL;
+            tH[r * TX + k] = aH;
+        }
+    }
+    PDWT_SYNC();
+
+    // ---- phase 2: column analysis inside the phase, out of LDS
+    PDWT_FOR_THREADS(tid, NT) {
+        const int k = tid % TX;
+        const int ty0 = (tid / TX) * R;
+        const int x = bx * TX + k;
+        const long long boff = (long long)bz * a.bstride;
+        for (int i = 0; i < R; ++i) {
+            float rA = 0.f, rH = 0.f, rV = 0.f, rD = 0.f;
+#pragma unroll
+            for (int j = 0; j < (HLEN > 0 ? HLEN : hlen); ++j) {
+                const float l = tL[(ty0 + i + j) * TX + k];
+                const float h = tH[(ty0 + i + j) * TX + k];
+                const float tl = lo[hlen - 1 - j], th = hi[hlen - 1 - j];
+                rA = pdwt_fma(l, tl, rA);
+                rH = pdwt_fma(l, th, rH);
+                rV = pdwt_fma(h, tl, rV);
+                rD = pdwt_fma(h, th, rD);
+            }
+            const int si = it * TY + ty0 + i;
+            if (si < M && x < a.Nc) {
+                const long long o = boff + (long long)(ph + f * si) * a.Nc + x;
+                a.A[o] = rA;
+                a.H[o] = rH;
+                a.V[o] = rV;
+                a.D[o] = rD;
+            }
+        }
+    }
+}
+
+template <int HLEN, int TX, int TY, int NT>
+PDWT_DEVICE void swt2_inv_tile(const Swt2DArgs& a, int bx, int by, int bz, float* smem) {
+    static_assert(NT % TX == 0 && TY % (NT / TX) == 0, "tile/thread shape");
+    constexpr int NG = NT / TX;
+    constexpr int R = TY / NG;
+    const int hlen = HLEN ? HLEN : a.hlen;
+    const int c = hlen / 2;  // synthesis centre
+    const int f = a.f;
+    const int M = a.Nr / f;
+    const int ph = by % f;
+    const int it = by / f;
+    const int RY = TY + hlen - 1;
+
+    PDWT_STAGE_TAPS();
+    float* u1 = smem + 2 * kMaxTaps;
+    float* u2 = u1 + RY * TX;
+
+    const long long boff = (long long)bz * a.bstride;
+
+    // ---- phase 1: dilated row synthesis from global: u1 = Lx(A) + Hx(V), u2 = Lx(H) + Hx(D)
+    PDWT_FOR_THREADS(tid, NT) {
+        const int k = tid % TX;
+        const int x = bx * TX + k;
+        for (int r = tid / TX; r < RY; r += NG) {
+            float r1 = 0.f, r2 = 0.f;
+            if (x < a.Nc) {
+                const int i = wrap_periodic(it * TY - c + r, M);
+                const long long ro = boff + (long long)(ph + f * i) * a.Nc;
+#pragma unroll
+                for (int j = 0; j < (HLEN > 0 ? HLEN : hlen); ++j) {
+                    const long long o = ro + wrap_periodic(x + (j - c) * f, a.Nc);
+                    const float tl = lo[hlen - 1 - j], th = hi[hlen - 1 - j];
+                    r1 = pdwt_fma(a.A[o], tl, r1);
+                    r1 = pdwt_fma(a.V[o], th, r1);
+                    r2 = pdwt_fma(a.H[o], tl, r2);
+                    r2 = pdwt_fma(a.D[o], th, r2);
+                }
+            }
+            u1[r * TX + k] = 0.5f * r1;
+            u2[r * TX + k] = 0.5f * r2;
+        }
+    }
+    PDWT_SYNC();
+
+    // ---- phase 2: column synthesis inside the phase
+    PDWT_FOR_THREADS(tid, NT) {
+        const int k = tid % TX;
+        const int ty0 = (tid / TX) * R;
+        const int x = bx * TX + k;
+        for (int i = 0; i < R; ++i) {
+            float r = 0.f;
+#pragma unroll
+            for (int j = 0; j < (HLEN > 0 ? HLEN : hlen); ++j) {
+                r = pdwt_fma(u1[(ty0 + i + j) * TX + k], lo[hlen - 1 - j], r);
+                r = pdwt_fma(u2[(ty0 + i + j) * TX + k], hi[hlen - 1 - j], r);
+            }
+            const int si = it * TY + ty0 + i;
+            if (si < M && x < a.Nc) a.out[boff + (long long)(ph + f * si) * a.Nc + x] = 0.5f * r;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Direct one-pass kernels: one output sample per thread, taps read from global.
+// `along_y` selects the filtered axis.  Used for the (batched) 1D SWT and as the
+// 2D fallback when f does not divide Nr.
+// ---------------------------------------------------------------------------
+
+template <int NT>
+PDWT_DEVICE void swt_pass_fwd_tile(const SwtPassArgs& a, long long block, float* /*smem*/) {
+    PDWT_FOR_THREADS(tid, NT) {
+        const long long idx = block * NT + tid;
+        const long long total = (long long)a.Nr * a.Nc;
+        if (idx < total) {
+            const int y = (int)(idx / a.Nc);
+            const int x = (int)(idx - (long long)y * a.Nc);
+            const int c = analysis_centre(a.hlen);
+            float aL = 0.f, aH = 0.f;
+            for (int j = 0; j < a.hlen; ++j) {
+                long long src;
+                if (a.along_y) src = (long long)wrap_periodic(y + (j - c) * a.f, a.Nr) * a.Nc + x;
+                else src = (long long)y * a.Nc + wrap_periodic(x + (j - c) * a.f, a.Nc);
+                const float v = a.in0[src];
+                aL = pdwt_fma(v, a.fb.lo[a.hlen - 1 - j], aL);
+                aH = pdwt_fma(v, a.fb.hi[a.hlen - 1 - j], aH);
+            }
+            a.out0[idx] = aL;
+            a.out1[idx] = aH;
+        }
+    }
+}
+
+template <int NT>
+PDWT_DEVICE void swt_pass_inv_tile(const SwtPassArgs& a, long long block, float* /*smem*/) {
+    PDWT_FOR_THREADS(tid, NT) {
+        const long long idx = block * NT + tid;
+        const long long total = (long long)a.Nr * a.Nc;
+        if (idx < total) {
+            const int y = (int)(idx / a.Nc);
+            const int x = (int)(idx - (long long)y * a.Nc);
+            const int c = a.hlen / 2;
+            float r = 0.f;
+            for (int j = 0; j < a.hlen; ++j) {
+                long long src;
+                if (a.along_y) src = (long long)wrap_periodic(y + (j - c) * a.f, a.Nr) * a.Nc + x;
+                else src = (long long)y * a.Nc + wrap_periodic(x + (j - c) * a.f, a.Nc);
+                r = pdwt_fma(a.in0[src], a.fb.lo[a.hlen - 1 - j], r);
+                r = pdwt_fma(a.in1[src], a.fb.hi[a.hlen - 1 - j], r);
+            }
+            a.out0[idx] = 0.5f * r;
+        }
+    }
+}
+
+#ifndef PDWT_CPU_EMU
+template <int HLEN, int TX, int TY, int NT>
+__global__ void __launch_bounds__(NT) swt2_fwd_kernel(const Swt2DArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float pdwt_smem[];
+    swt2_fwd_tile<HLEN, TX, TY, NT>(a, blockIdx.x, blockIdx.y, blockIdx.z, pdwt_smem);
+}
+template <int HLEN, int TX, int TY, int NT>
+__global__ void __launch_bounds__(NT) swt2_inv_kernel(const Swt2DArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float pdwt_smem[];
+    swt2_inv_tile<HLEN, TX, TY, NT>(a, blockIdx.x, blockIdx.y, blockIdx.z, pdwt_smem);
+}
+template <int NT>
+__global__ void __launch_bounds__(NT) swt_pass_fwd_kernel(const SwtPassArgs a) {
+    swt_pass_fwd_tile<NT>(a, blockIdx.x, nullptr);
+}
+template <int NT>
+__global__ void __launch_bounds__(NT) swt_pass_inv_kernel(const SwtPassArgs a) {
+    swt_pass_inv_tile<NT>(a, blockIdx.x, nullptr);
+}
+#endif
+
+}  // namespace pdwt

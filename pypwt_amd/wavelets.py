@@ -1,0 +1,424 @@
+"""Python `Wavelets` class: drop-in for pycudwt / pypwt's Cython class.
+
+Mirrors the reference class member for member (reference src/pypwt.pyx:64-615): same
+constructor signature, read-only attributes, `coeffs` layout `[A, [H1, V1, D1], ...]`
+(2D) / `[A, D1, ...]` (1D, each of shape (Nr, Nc_l)), level clamping, state rules, and
+error behaviour -- but every method calls the gfx950 HIP library through the C ABI
+(include/pypwt_amd.h) instead of binding the C++ class.
+
+Deliberate differences from the reference (documented in DESIGN.md):
+  * unknown wavelet name -> ValueError (the reference hangs in w_ilog2)
+  * HIP errors raise instead of being printed and ignored
+  * filter banks are per instance (the reference shares one __constant__ bank per process)
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import PdwtInfo, check, f32p, handle_t
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _fptr(a):
+    return a.ctypes.data_as(f32p)
+
+
+class Wavelets(object):
+    """
+    Initializes the Wavelet transform from an image and given parameters.
+
+    img: 2D numpy.ndarray, float32
+        Input image
+    wname: string
+        Name of the wavelet
+    levels: int
+        Number of decomposition levels
+    do_separable: int
+        if not 0, perform a separable transform
+    do_cycle_spinning: int
+        if not 0, perform a random shift on the image
+        (useful for iterative algorithms)
+    do_swt: int
+        if not 0, perform a Stationary (non-decimated) wavelet transform
+    ndim: int
+        2 (default) or 1; a 2D array with ndim=1 is a batched 1D transform
+    """
+
+    def __init__(self, img, wname, levels, do_separable=1, do_cycle_spinning=0, do_swt=0, ndim=2, copy=None):
+        self._h = None
+        self._lib = _lib.load()
+        img = self._checkarray(np.asarray(img))
+
+        ndim = min(int(ndim), 2)  # src/pypwt.pyx:145
+        self.batched1d = 0
+        if img.ndim == 2:
+            self.Nr, self.Nc = int(img.shape[0]), int(img.shape[1])
+            if img.ndim != ndim:
+                self.batched1d = 1
+        elif img.ndim == 1:  # 1D: Nr = 1, Nc = len   (src/pypwt.pyx:152-154)
+            self.Nr, self.Nc = 1, int(img.shape[0])
+        else:
+            raise NotImplementedError("Wavelets(): Only 1D and 2D transforms are supported for now")
+        self.shape = tuple(int(s) for s in img.shape)
+        self.wname = str(wname)
+        self._wname = self.wname.encode("ASCII")
+        self.levels = int(levels)
+        self.do_separable = int(do_separable)
+        self.do_cycle_spinning = int(do_cycle_spinning)
+        self.do_swt = int(do_swt)
+        self.ndim = img.ndim
+
+        h = handle_t()
+        rc = self._lib.pdwt_create(_fptr(img), self.Nr, self.Nc, self._wname, self.levels, 1, self.do_separable,
+                                   self.do_cycle_spinning, self.do_swt, ndim, C.byref(h))
+        check(rc, "Wavelets()")
+        self._h = h
+        # read back what the library clamped (src/pypwt.pyx:181-183)
+        info, sep, cyc, st, b = PdwtInfo(), C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        check(self._lib.pdwt_get_info(self._h, C.byref(info), C.byref(sep), C.byref(cyc), C.byref(st), C.byref(b)))
+        self.levels = int(info.nlevels)
+        self.hlen = int(info.hlen)
+        self.do_separable = int(sep.value)
+        self.sizes = self._compute_sizes()
+
+        # host-side coefficient list (src/pypwt.pyx:187-205)
+        self._coeffs = [np.zeros(self.sizes[-1], dtype=np.float32)]
+        for i in range(self.levels):
+            if (self.ndim < 2) or self.batched1d:
+                self._coeffs.append(np.zeros(self.sizes[i], dtype=np.float32))
+            else:
+                self._coeffs.append([np.zeros(self.sizes[i], dtype=np.float32) for _ in range(3)])
+
+    # -- reference: info / __repr__ / __str__ (src/pypwt.pyx:209-221)
+    def info(self):
+        """Print some information on the current ``Wavelets`` instance."""
+        buf = C.create_string_buffer(2048)
+        check(self._lib.pdwt_info_string(self._h, buf, len(buf)))
+        print(buf.value.decode("utf-8", "replace"), end="")
+
+    def __repr__(self):
+        self.info()
+        return ""
+
+    def __str__(self):
+        self.info()
+        return ""
+
+    @staticmethod
+    def _checkarray(arr, shp=None):  # src/pypwt.pyx:224-235
+        res = arr
+        if arr.dtype != np.float32 or not arr.flags["C_CONTIGUOUS"]:
+            res = np.ascontiguousarray(arr, dtype=np.float32)
+        if shp is not None:
+            if arr.ndim != len(shp):
+                raise ValueError("Invalid number of dimensions (expected %d, got %d)" % (len(shp), arr.ndim))
+            for i in range(arr.ndim):
+                if arr.shape[i] != shp[i]:
+                    raise ValueError("The image does not have the correct shape (expected %s, got %s)"
+                                     % (str(shp), str(arr.shape)))
+        return res
+
+    @staticmethod
+    def div2(n):
+        """Returns (N + (N%2))/2: the image size at the next scale."""
+        return (n + (n & 1)) // 2
+
+    def _compute_sizes(self):  # src/pypwt.pyx:247-258
+        Nr, Nc = self.Nr, self.Nc
+        if self.do_swt:
+            return [(Nr, Nc)] * self.levels
+        res = []
+        for _ in range(self.levels):
+            Nc = self.div2(Nc)
+            if not self.batched1d:
+                Nr = self.div2(Nr)
+            res.append((Nr, Nc))
+        return res
+
+    def coeff_only(self, num):
+        """
+        Get only the coeff "num" from the device.
+
+        num : int
+            2D : [0: A, 1: H1, 2: V1, 3: D1,  4: H2, ...]
+            1D : [0: A, 1: D1, 2: D2, ...]
+        """
+        num = int(num)
+        if num == 0:
+            coeff_ref = self._coeffs[0]
+        elif (self.ndim == 2) and not self.batched1d:
+            coeff_ref = self._coeffs[(num - 1) // 3 + 1][(num - 1) % 3]
+        else:
+            coeff_ref = self._coeffs[num]
+        numc = self._lib.pdwt_get_coeff(self._h, _ptr(coeff_ref), num)
+        if numc != coeff_ref.size:  # src/pypwt.pyx:284-285 (0 when refused after inverse())
+            raise RuntimeError("Wavelets.coeff_only(): something went wrong when retrieving coefficients numbef %d, "
+                               "expected %d coeffs, got %d (%s)" % (num, coeff_ref.size, numc, _lib.last_error()))
+        return coeff_ref
+
+    @property
+    def coeffs(self):
+        """
+        Get all the coefficients from the device.
+        Returns the list [A, [H1, V1, D1], [H2, V2, D2], ...] (2D) or [A, D1, ...] (1D).
+        """
+        self.coeff_only(0)
+        i_end = 3 * self.levels if (self.ndim == 2 and not self.batched1d) else self.levels
+        for cnt in range(1, i_end + 1):
+            self.coeff_only(cnt)
+        return self._coeffs
+
+    @property
+    def image(self):
+        res = np.zeros((self.Nr, self.Nc), dtype=np.float32)
+        numc = self._lib.pdwt_get_image(self._h, _ptr(res))
+        if numc != res.size:
+            raise RuntimeError("Wavelets.image(): something went wrong when retrieving image, expected %d coeffs, "
+                               "got %d (%s)" % (res.size, numc, _lib.last_error()))
+        return res
+
+    def set_image(self, img):
+        """Replace the image (does not update the coefficients; run forward())."""
+        img = self._checkarray(np.asarray(img), (self.Nr, self.Nc))
+        check(self._lib.pdwt_set_image(self._h, _ptr(img), 0))
+
+    def forward(self, img=None):
+        """Forward wavelet transform of ``img`` if given, else of the current image."""
+        if img is not None:
+            img = self._checkarray(np.asarray(img), self.shape)
+            check(self._lib.pdwt_set_image(self._h, _ptr(img), 0))
+        check(self._lib.pdwt_forward(self._h), "forward")
+
+    def inverse(self):
+        """
+        Inverse transform: coefficients -> ``Wavelets.image``.
+
+        As in the reference, calling it twice in a row does nothing but warn, and the
+        coefficients cannot be read or thresholded afterwards until forward() is run again.
+        """
+        rc = self._lib.pdwt_inverse(self._h)
+        if rc == _lib.ERR_STATE:  # reference: puts() a warning and returns (wt.cu:272-279)
+            print("Warning: " + _lib.last_error())
+            return
+        check(rc, "inverse")
+
+    def _threshold(self, fn, beta, do_threshold_appcoeffs, normalize):
+        rc = fn(self._h, float(beta), int(do_threshold_appcoeffs), int(normalize))
+        if rc == _lib.ERR_STATE:  # wt.cu:309-312
+            print("Warning: Wavelets(): " + _lib.last_error())
+            return
+        check(rc)
+
+    def soft_threshold(self, beta, do_threshold_appcoeffs=0, normalize=0):
+        """ST(x, t) = (|x| - t)_+ . sign(x) on the detail (optionally approximation) coefficients;
+        ``normalize``: t is divided by sqrt(2) at each scale."""
+        self._threshold(self._lib.pdwt_soft_threshold, beta, do_threshold_appcoeffs, normalize)
+
+    def hard_threshold(self, beta, do_threshold_appcoeffs=0, normalize=0):
+        """HT(x, t) = x . 1_{|x| > t}"""
+        self._threshold(self._lib.pdwt_hard_threshold, beta, do_threshold_appcoeffs, normalize)
+
+    def group_soft_threshold(self, beta, do_threshold_appcoeffs=0, normalize=0):
+        """Per-pixel group shrinkage of (H, V, D[, A]) (C++-only in the reference, wt.cu:329-336)."""
+        self._threshold(self._lib.pdwt_group_soft_threshold, beta, do_threshold_appcoeffs, normalize)
+
+    def shrink(self, beta, do_threshold_appcoeffs=1):
+        """shrink(x, t) = x / (1 + t)"""
+        rc = self._lib.pdwt_shrink(self._h, float(beta), int(do_threshold_appcoeffs))
+        if rc == _lib.ERR_STATE:
+            print("Warning: Wavelets(): " + _lib.last_error())
+            return
+        check(rc)
+
+    def proj_linf(self, beta, do_threshold_appcoeffs=1):
+        """Projection onto the L-infinity ball of radius beta (C++-only in the reference, wt.cu:349-356)."""
+        rc = self._lib.pdwt_proj_linf(self._h, float(beta), int(do_threshold_appcoeffs))
+        if rc == _lib.ERR_STATE:
+            print("Warning: Wavelets(): " + _lib.last_error())
+            return
+        check(rc)
+
+    def norm1(self):
+        """L1 norm of all the wavelet coefficients."""
+        out = C.c_float()
+        check(self._lib.pdwt_norm1(self._h, C.byref(out)))
+        return out.value
+
+    def norm2sq(self):
+        """Squared L2 norm of all the wavelet coefficients."""
+        out = C.c_float()
+        check(self._lib.pdwt_norm2sq(self._h, C.byref(out)))
+        return out.value
+
+    def add_wavelet(self, W, alpha=1.0):
+        """coefficients += alpha * W.coefficients"""
+        rc = self._lib.pdwt_add_wavelet(self._h, W._h, float(alpha))
+        if rc != 0:  # the reference prints the reason and carries on (wt.cu:625-650)
+            print(("WARNING: " if rc > 0 else "ERROR: ") + _lib.last_error())
+        return rc
+
+    def set_coeff(self, coeff, num, check=False):
+        """Set coefficient band ``num`` (see coeff_only for the numbering)."""
+        coeff = self._checkarray(np.asarray(coeff))
+        if check:
+            dcoeff = self.coeff_only(num)
+            if dcoeff.shape != coeff.shape:
+                raise ValueError("set_coefInvalid coefficient shape : expected %s, got %s"
+                                 % (str(dcoeff.shape), str(coeff.shape)))
+        rows, cols = C.c_int(), C.c_int()
+        n = self._lib.pdwt_coeff_count(self._h, int(num), C.byref(rows), C.byref(cols))
+        _lib.check(int(n))
+        if coeff.size != n:  # the reference copies blindly (wt.cu:435 "There are no memory check !")
+            raise ValueError("set_coeff: expected %d elements for coefficient %d, got %d" % (n, num, coeff.size))
+        _lib.check(self._lib.pdwt_set_coeff(self._h, _ptr(coeff), int(num), 0))
+
+    def set_wavelets_filters(self, filter_name, lowpass, highpass, i_lowpass, i_highpass, LH=None, HL=None,
+                             i_LH=None, i_HL=None):
+        """
+        Set a custom filter bank. This re-defines the current wavelet transform.
+        Separable plans use (lowpass, highpass, i_lowpass, i_highpass); non-separable plans
+        additionally need the 2D LH, HL, i_LH, i_HL banks (lowpass = LL, highpass = HH).
+        """
+        arrs = [lowpass, highpass, i_lowpass, i_highpass, LH, HL, i_LH, i_HL]
+        if any(len(a) != len(lowpass) for a in arrs if a is not None):
+            raise ValueError("All filters must have the same length")
+        f = [None if a is None else self._checkarray(np.asarray(a)) for a in arrs]
+        name = filter_name.encode("ASCII")
+        flen = int(len(lowpass))
+        null = C.cast(None, f32p)
+        if self.do_separable:
+            check(self._lib.pdwt_set_filters_forward(self._h, name, flen, _fptr(f[0]), _fptr(f[1]), null, null))
+            check(self._lib.pdwt_set_filters_inverse(self._h, _fptr(f[2]), _fptr(f[3]), null, null))
+        else:
+            if LH is None or HL is None or i_LH is None or i_HL is None:
+                raise ValueError("Expected LH and HL filters for non-separable transform")
+            # argument order of the C side: (LL, LH, HL, HH)  (src/pypwt.pyx:557-575)
+            check(self._lib.pdwt_set_filters_forward(self._h, name, flen, _fptr(f[0]), _fptr(f[4]), _fptr(f[5]),
+                                                     _fptr(f[1])))
+            check(self._lib.pdwt_set_filters_inverse(self._h, _fptr(f[2]), _fptr(f[6]), _fptr(f[7]), _fptr(f[3])))
+        self.hlen = flen
+        self.wname = filter_name
+
+    def image_int_ptr(self):
+        """Address of the device image (borrowed; valid while the instance lives)."""
+        return int(self._lib.pdwt_image_ptr(self._h))
+
+    def coeff_int_ptr(self, num):
+        """Address of device coefficient band ``num``."""
+        return int(self._lib.pdwt_coeff_ptr(self._h, int(num)))
+
+    def synchronize(self):
+        """Wait for every kernel enqueued by this instance (new; the reference syncs implicitly)."""
+        check(self._lib.pdwt_synchronize(self._h))
+
+    def cleanup(self):  # should not be called manually
+        if getattr(self, "_h", None):
+            self._lib.pdwt_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.cleanup()
+        except Exception:
+            pass
+
+    @classmethod
+    def version(cls):
+        """Version of the pypwt API this class is a drop-in for."""
+        return "1.0.3"
+
+
+class BatchedWavelets(object):
+    """NEW (not in the reference): one plan over a batch of independent images [B][Nr][Nc].
+
+    Every call (forward / inverse / soft_threshold) processes all B images in the same kernel
+    launches; this is the unit that shards across GPUs in bench.py (one plan per rank, no
+    collective on the data path).  The image can be generated on the device
+    (``fill_hash``) so large batches never cross PCIe.
+    """
+
+    def __init__(self, batch, Nr, Nc, wname, levels, do_swt=0, ndim=2, device=-1, stream=None, img=None):
+        self._lib = _lib.load()
+        self._h = None
+        h = handle_t()
+        ptr = None
+        if img is not None:
+            img = Wavelets._checkarray(np.asarray(img), (batch, Nr, Nc))
+            ptr = _ptr(img)
+        rc = self._lib.pdwt_create_batched(ptr, int(batch), int(Nr), int(Nc), wname.encode("ASCII"), int(levels),
+                                           1, 1, 0, int(do_swt), int(ndim), int(device),
+                                           C.c_void_p(stream) if stream else None, C.byref(h))
+        check(rc, "BatchedWavelets()")
+        self._h = h
+        info, b = PdwtInfo(), C.c_int()
+        check(self._lib.pdwt_get_info(self._h, C.byref(info), None, None, None, C.byref(b)))
+        self.batch, self.Nr, self.Nc = int(b.value), int(info.Nr), int(info.Nc)
+        self.levels, self.hlen, self.ndims, self.do_swt = int(info.nlevels), int(info.hlen), int(info.ndims), int(info.do_swt)
+        self.nbands = 3 * self.levels + 1 if self.ndims == 2 else self.levels + 1
+
+    def fill_hash(self, seed, scale=255.0, index_offset=0):
+        check(self._lib.pdwt_fill_image_hash(self._h, seed & 0xFFFFFFFF, float(scale), int(index_offset)))
+
+    def forward(self):
+        check(self._lib.pdwt_forward(self._h), "forward")
+
+    def inverse(self):
+        check(self._lib.pdwt_inverse(self._h), "inverse")
+
+    def soft_threshold(self, beta, do_threshold_appcoeffs=0, normalize=0):
+        check(self._lib.pdwt_soft_threshold(self._h, float(beta), int(do_threshold_appcoeffs), int(normalize)))
+
+    def set_image(self, img):
+        img = Wavelets._checkarray(np.asarray(img), (self.batch, self.Nr, self.Nc))
+        check(self._lib.pdwt_set_image(self._h, _ptr(img), 0))
+
+    def coeff(self, num):
+        rows, cols = C.c_int(), C.c_int()
+        n = check(int(self._lib.pdwt_coeff_count(self._h, int(num), C.byref(rows), C.byref(cols))))
+        out = np.zeros((self.batch, rows.value, cols.value), dtype=np.float32)
+        got = self._lib.pdwt_get_coeff(self._h, _ptr(out), int(num))
+        if got != n:
+            raise RuntimeError("BatchedWavelets.coeff(%d): expected %d, got %d (%s)" % (num, n, got, _lib.last_error()))
+        return out
+
+    @property
+    def image(self):
+        out = np.zeros((self.batch, self.Nr, self.Nc), dtype=np.float32)
+        got = self._lib.pdwt_get_image(self._h, _ptr(out))
+        if got != out.size:
+            raise RuntimeError("BatchedWavelets.image: expected %d, got %d (%s)" % (out.size, got, _lib.last_error()))
+        return out
+
+    def synchronize(self):
+        check(self._lib.pdwt_synchronize(self._h))
+
+    def set_stream(self, stream_ptr):
+        check(self._lib.pdwt_set_stream(self._h, C.c_void_p(stream_ptr)))
+
+    def enable_kernel_timing(self, on=True):
+        check(self._lib.pdwt_enable_kernel_timing(self._h, 1 if on else 0))
+
+    def reset_kernel_times(self):
+        check(self._lib.pdwt_reset_kernel_times(self._h))
+
+    def kernel_times(self, cap=4096):
+        """[(name, milliseconds)] of every launch recorded since the last reset."""
+        ms = (C.c_float * cap)()
+        names = ((C.c_char * 48) * cap)()
+        n = check(self._lib.pdwt_kernel_times(self._h, ms, C.cast(names, C.c_void_p), cap))
+        return [(names[i].value.decode(), float(ms[i])) for i in range(min(n, cap))]
+
+    def cleanup(self):
+        if getattr(self, "_h", None):
+            self._lib.pdwt_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.cleanup()
+        except Exception:
+            pass

@@ -1,0 +1,171 @@
+// CPU emulation build of the gfx950 tile functions (sanitizer / index-math fuzz only).
+// Compiles pypwt_amd/csrc/*_kernels.hpp with PDWT_CPU_EMU: phases run as loops over
+// thread ids, blocks as loops over the grid.  Test infrastructure; never shipped.
+#define PDWT_CPU_EMU 1
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../pypwt_amd/csrc/dwt1_kernels.hpp"
+#include "../../pypwt_amd/csrc/dwt2_kernels.hpp"
+#include "../../pypwt_amd/csrc/swt_kernels.hpp"
+
+using namespace pdwt;
+
+#define EMU_API extern "C" __attribute__((visibility("default")))
+
+static void set_bank(FilterBank& fb, const float* lo, const float* hi, int hlen) {
+    std::memset(&fb, 0, sizeof(fb));
+    for (int i = 0; i < hlen; i++) { fb.lo[i] = lo[i]; fb.hi[i] = hi[i]; }
+}
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+#define EMU_EVEN_HLENS(X) X(2) X(4) X(6) X(8) X(10) X(12) X(14) X(16) X(18) X(20) X(22) X(24) X(26) \
+    X(28) X(30) X(32) X(34) X(36) X(38) X(40)
+
+template <int HLEN, int TX, int TY, int NT>
+static void run_fwd2d(const Fwd2DArgs& a, int batch) {
+    std::vector<float> smem(fwd2d_lds_floats<TX, TY>(a.hlen) + 64, -12345.f);
+    for (int bz = 0; bz < batch; bz++)
+        for (int by = 0; by < cdiv(a.Nr2, TY); by++)
+            for (int bx = 0; bx < cdiv(a.Nc2, TX); bx++)
+                dwt2_fwd_tile<HLEN, TX, TY, NT>(a, bx, by, bz, smem.data());
+}
+
+template <int HLEN, int TX, int TY, int NT>
+static void run_inv2d(const Inv2DArgs& a, int batch) {
+    std::vector<float> smem(inv2d_lds_floats<TX, TY>(a.hlen) + 64, -12345.f);
+    for (int bz = 0; bz < batch; bz++)
+        for (int by = 0; by < cdiv(a.Nr, 2 * TY); by++)
+            for (int bx = 0; bx < cdiv(a.Nc, 2 * TX); bx++)
+                dwt2_inv_tile<HLEN, TX, TY, NT>(a, bx, by, bz, smem.data());
+}
+
+// generic != 0 forces the runtime-length (HLEN = 0) instantiation
+EMU_API int emu_dwt2_fwd(const float* in, int batch, int Nr, int Nc, const float* lo, const float* hi, int hlen,
+                         int generic, int tile, float* A, float* H, float* V, float* D) {
+    Fwd2DArgs a;
+    a.in = in; a.A = A; a.H = H; a.V = V; a.D = D;
+    a.Nr = Nr; a.Nc = Nc; a.Nr2 = (Nr + 1) / 2; a.Nc2 = (Nc + 1) / 2;
+    a.in_bstride = (long long)Nr * Nc; a.out_bstride = (long long)a.Nr2 * a.Nc2;
+    a.hlen = hlen;
+    set_bank(a.fb, lo, hi, hlen);
+    if (generic || (hlen & 1)) {
+        if (tile == 0) run_fwd2d<0, 64, 16, 256>(a, batch); else run_fwd2d<0, 64, 32, 256>(a, batch);
+        return 0;
+    }
+    switch (hlen) {
+#define X(h) case h: if (tile == 0) run_fwd2d<h, 64, 16, 256>(a, batch); else run_fwd2d<h, 64, 32, 256>(a, batch); return 0;
+        EMU_EVEN_HLENS(X)
+#undef X
+    }
+    return -1;
+}
+
+EMU_API int emu_dwt2_inv(const float* A, const float* H, const float* V, const float* D, int batch, int Nrc, int Ncc,
+                         int Nr, int Nc, const float* lo, const float* hi, int hlen, int generic, int tile, float* out) {
+    Inv2DArgs a;
+    a.A = A; a.H = H; a.V = V; a.D = D; a.out = out;
+    a.Nrc = Nrc; a.Ncc = Ncc; a.Nr = Nr; a.Nc = Nc;
+    a.in_bstride = (long long)Nrc * Ncc; a.out_bstride = (long long)Nr * Nc;
+    a.hlen = hlen;
+    set_bank(a.fb, lo, hi, hlen);
+    if (generic || (hlen & 1)) {
+        if (tile == 0) run_inv2d<0, 64, 16, 256>(a, batch); else run_inv2d<0, 64, 32, 256>(a, batch);
+        return 0;
+    }
+    switch (hlen) {
+#define X(h) case h: if (tile == 0) run_inv2d<h, 64, 16, 256>(a, batch); else run_inv2d<h, 64, 32, 256>(a, batch); return 0;
+        EMU_EVEN_HLENS(X)
+#undef X
+    }
+    return -1;
+}
+
+// ------------------------------------------------------------------ 1D DWT
+template <int HLEN, int TXO, int NT>
+static void run_fwd1d(const Fwd1DArgs& a) {
+    std::vector<float> smem(fwd1d_lds_floats<TXO>(a.hlen) + 64, -12345.f);
+    for (int row = 0; row < a.rows; row++)
+        for (int bx = 0; bx < cdiv(a.Nc2, TXO); bx++) dwt1_fwd_tile<HLEN, TXO, NT>(a, bx, row, smem.data());
+}
+template <int HLEN, int TXO, int NT>
+static void run_inv1d(const Inv1DArgs& a) {
+    std::vector<float> smem(inv1d_lds_floats<TXO>(a.hlen) + 64, -12345.f);
+    for (int row = 0; row < a.rows; row++)
+        for (int bx = 0; bx < cdiv(a.Nc, 2 * TXO); bx++) dwt1_inv_tile<HLEN, TXO, NT>(a, bx, row, smem.data());
+}
+
+EMU_API int emu_dwt1_fwd(const float* in, int rows, int Nc, const float* lo, const float* hi, int hlen, int generic,
+                         int wide, float* L, float* H) {
+    Fwd1DArgs a;
+    a.in = in; a.L = L; a.H = H; a.rows = rows; a.Nc = Nc; a.Nc2 = (Nc + 1) / 2; a.hlen = hlen;
+    set_bank(a.fb, lo, hi, hlen);
+    if (generic || (hlen & 1)) { if (wide) run_fwd1d<0, 1024, 256>(a); else run_fwd1d<0, 256, 256>(a); return 0; }
+    switch (hlen) {
+#define X(h) case h: if (wide) run_fwd1d<h, 1024, 256>(a); else run_fwd1d<h, 256, 256>(a); return 0;
+        EMU_EVEN_HLENS(X)
+#undef X
+    }
+    return -1;
+}
+
+EMU_API int emu_dwt1_inv(const float* L, const float* H, int rows, int Ncc, int Nc, const float* lo, const float* hi,
+                         int hlen, int generic, int wide, float* out) {
+    Inv1DArgs a;
+    a.L = L; a.H = H; a.out = out; a.rows = rows; a.Ncc = Ncc; a.Nc = Nc; a.hlen = hlen;
+    set_bank(a.fb, lo, hi, hlen);
+    if (generic || (hlen & 1)) { if (wide) run_inv1d<0, 1024, 256>(a); else run_inv1d<0, 256, 256>(a); return 0; }
+    switch (hlen) {
+#define X(h) case h: if (wide) run_inv1d<h, 1024, 256>(a); else run_inv1d<h, 256, 256>(a); return 0;
+        EMU_EVEN_HLENS(X)
+#undef X
+    }
+    return -1;
+}
+
+// ------------------------------------------------------------------ SWT
+template <int HLEN, bool INV>
+static void run_swt2(const Swt2DArgs& a, int batch) {
+    constexpr int TX = 64, TY = 16, NT = 256;
+    std::vector<float> smem(swt2d_lds_floats<TX, TY>(a.hlen) + 64, -12345.f);
+    const int M = a.Nr / a.f;
+    for (int bz = 0; bz < batch; bz++)
+        for (int by = 0; by < cdiv(M, TY) * a.f; by++)
+            for (int bx = 0; bx < cdiv(a.Nc, TX); bx++) {
+                if (INV) swt2_inv_tile<HLEN, TX, TY, NT>(a, bx, by, bz, smem.data());
+                else swt2_fwd_tile<HLEN, TX, TY, NT>(a, bx, by, bz, smem.data());
+            }
+}
+
+// inverse != 0: A,H,V,D are inputs and io is the output plane; else io is the input plane
+EMU_API int emu_swt2(int inverse, float* io, int batch, int Nr, int Nc, int level, const float* lo, const float* hi,
+                     int hlen, int generic, float* A, float* H, float* V, float* D) {
+    Swt2DArgs a;
+    a.in = io; a.out = io; a.A = A; a.H = H; a.V = V; a.D = D;
+    a.Nr = Nr; a.Nc = Nc; a.f = 1 << (level - 1); a.bstride = (long long)Nr * Nc; a.hlen = hlen;
+    if (Nr % a.f) return -2;
+    set_bank(a.fb, lo, hi, hlen);
+    if (generic || (hlen & 1)) { if (inverse) run_swt2<0, true>(a, batch); else run_swt2<0, false>(a, batch); return 0; }
+    switch (hlen) {
+#define X(h) case h: if (inverse) run_swt2<h, true>(a, batch); else run_swt2<h, false>(a, batch); return 0;
+        EMU_EVEN_HLENS(X)
+#undef X
+    }
+    return -1;
+}
+
+EMU_API int emu_swt_pass(int inverse, const float* in0, const float* in1, int Nr, int Nc, int level, int along_y,
+                         const float* lo, const float* hi, int hlen, float* out0, float* out1) {
+    SwtPassArgs a;
+    a.in0 = in0; a.in1 = in1; a.out0 = out0; a.out1 = out1;
+    a.Nr = Nr; a.Nc = Nc; a.f = 1 << (level - 1); a.along_y = along_y; a.hlen = hlen;
+    set_bank(a.fb, lo, hi, hlen);
+    const long long total = (long long)Nr * Nc;
+    for (long long b = 0; b < (total + 255) / 256; b++) {
+        if (inverse) swt_pass_inv_tile<256>(a, b, nullptr);
+        else swt_pass_fwd_tile<256>(a, b, nullptr);
+    }
+    return 0;
+}

@@ -1,0 +1,117 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds, loads, and exports every
+symbol include/pypwt_amd.h declares; the built-in filter table equals the pywt vectors; argument
+errors are reported without a GPU; nothing in the product imports the oracle.  No compute calls."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from pypwt_amd.build import build_library
+    build_library(verbose=False)
+    from pypwt_amd import _lib
+    return _lib.load()
+
+
+def header_functions():
+    txt = open(os.path.join(ROOT, "include", "pypwt_amd.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(pdwt_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_header_symbol(lib):
+    names = header_functions()
+    assert len(names) >= 40
+    for n in names:
+        assert hasattr(lib, n), "libpypwt_amd.so does not export %s" % n
+
+
+def test_python_binding_covers_the_header(lib):
+    from pypwt_amd import _lib
+    assert sorted(_lib.SIGNATURES) == header_functions()
+
+
+def test_every_entry_point_cites_the_reference():
+    """include/*.h must cite the reference interface each entry point replaces (file:line)."""
+    txt = open(os.path.join(ROOT, "include", "pypwt_amd.h")).read()
+    assert txt.count("wt.cu:") >= 15 and "src/pypwt.pyx:8-61" in txt and "wt.h:20-76" in txt
+
+
+def test_filter_table_equals_pywt_vectors(lib):
+    from oracle import oracle
+    t = oracle.filter_table()
+    assert lib.pdwt_wavelet_count() == 72
+    names = [lib.pdwt_wavelet_name(i).decode() for i in range(72)]
+    assert names == t["order"]  # the reference's table order (filters.cpp:5919-6002)
+    buf = (C.c_float * 160)()
+    for w in names:
+        hlen = lib.pdwt_wavelet_filters(w.encode(), buf, 160)
+        e = t["filters"][w]
+        assert hlen == e["hlen"]
+        got = np.frombuffer(buf, dtype=np.float32, count=4 * hlen).reshape(4, hlen)
+        want = np.array([e["dec_lo"], e["dec_hi"], e["rec_lo"], e["rec_hi"]], dtype=np.float32)
+        assert np.array_equal(got, want), w
+    # Haar aliases (separable.cu:24-28) and case-insensitivity (strcasecmp, separable.cu:33)
+    for alias in (b"db1", b"bior1.1", b"rbior1.1", b"HAAR", b"Db4"):
+        assert lib.pdwt_wavelet_filters(alias, None, 0) in (2, 8)
+    assert lib.pdwt_wavelet_filters(b"nope", None, 0) == -2
+
+
+def test_argument_errors_without_gpu(lib):
+    from pypwt_amd import _lib
+    h = _lib.handle_t()
+    img = np.zeros((8, 8), dtype=np.float32)
+    p = img.ctypes.data_as(_lib.f32p)
+    assert lib.pdwt_create(p, 8, 8, b"nope", 1, 1, 1, 0, 0, 2, C.byref(h)) == _lib.ERR_WAVELET
+    assert b"unknown wavelet" in lib.pdwt_last_error()
+    assert lib.pdwt_create(p, 0, 8, b"db2", 1, 1, 1, 0, 0, 2, C.byref(h)) == _lib.ERR_ARG
+    assert lib.pdwt_forward(None) == _lib.ERR_ARG
+    assert lib.pdwt_destroy(None) == 0
+
+
+def test_no_gpu_means_loud_failure_not_fallback(lib):
+    """On a machine without a HIP device the product must FAIL, never compute on the CPU."""
+    import subprocess
+    import sys
+    code = ("import numpy as np, sys; sys.path.insert(0, %r)\n"
+            "from pypwt_amd import Wavelets\n"
+            "try:\n"
+            "    Wavelets(np.zeros((16,16),np.float32),'db2',1); print('CREATED')\n"
+            "except Exception as e: print('RAISED', type(e).__name__)\n" % ROOT)
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="-1", ROCR_VISIBLE_DEVICES="-1")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env).stdout
+    assert "RAISED PdwtError" in out
+
+
+def test_product_never_touches_the_oracle():
+    """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may use oracle/."""
+    pkg = os.path.join(ROOT, "pypwt_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hpp", ".hip", ".h", ".inc")):
+                src = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "import oracle" not in src and "from oracle" not in src, f
+                assert "pdwt_oracle" not in src or f.endswith((".hpp", ".hip", ".cpp", ".py")) and \
+                    all("oracle/pdwt_oracle.c" in line or "oracle_fill_hash" in line or "oracle" in line.split("//")[-1]
+                        for line in src.splitlines() if "pdwt_oracle" in line), f
+    for f in ("bench.py",):
+        src = open(os.path.join(ROOT, f)).read()
+        body = src.split("def cpu_baseline")[1].split("\ndef ")[0]
+        assert "oracle" in body
+        assert "oracle" not in src.replace(body, "").replace("the C oracle", "").replace("oracle/pdwt_oracle.c", "")
+
+
+def test_sources_are_gfx950_only():
+    """No CUDA shims, no dual CUDA/HIP paths, no Triton (north star)."""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "pypwt_amd")):
+        for f in files:
+            if f.endswith((".cpp", ".hpp", ".hip", ".py")):
+                src = open(os.path.join(dirpath, f), errors="replace").read()
+                for bad in ("__HIP_PLATFORM_AMD__", "__CUDACC__", "cuda_runtime", "import triton", "hipify"):
+                    assert bad not in src, (f, bad)

@@ -1,0 +1,57 @@
+"""The N>1 path of bench.py on CPU: world_size-2 gloo rendezvous, barrier, max-over-ranks and the
+single JSON line (no GPU work: --dry-run).  The data path itself has no collective (images shard
+one-per-rank), so this is everything multi-process about it."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def test_shard_images_partition():
+    import bench
+    for total in (1, 7, 8, 1024, 1027):
+        for world in (1, 2, 3, 8):
+            spans = [bench.shard_images(total, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            for a, b in zip(spans, spans[1:]):
+                assert a[1] == b[0]
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_algorithmic_bytes_match_baseline_md():
+    import bench
+    assert bench.algorithmic_bytes_per_sample(bench.CONFIGS["cfg2"]) == 16.0
+    assert bench.algorithmic_bytes_per_sample(bench.CONFIGS["cfg3"]) == 16.0
+    assert bench.algorithmic_bytes_per_sample(bench.CONFIGS["cfg4"]) == 256.0  # 68 + 120 + 68
+    # level-1 kernels move 8 B per input sample; each deeper 2D level a quarter of that
+    c = bench.CONFIGS["cfg2"]
+    assert bench.kernel_algorithmic_bytes("dwt2_fwd_level", 0, c, 1) == 8.0 * 4096 * 4096
+    assert bench.kernel_algorithmic_bytes("dwt2_fwd_level", 1, c, 1) == 2.0 * 4096 * 4096
+    assert bench.kernel_algorithmic_bytes("dwt2_inv_level", 3, c, 1) == 8.0 * 4096 * 4096
+
+
+def _run(cmd):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, env=env, timeout=240)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout  # exactly ONE json line, from rank 0
+    return json.loads(lines[0])
+
+
+def test_dry_run_world2_gloo():
+    out = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                "--master-addr", "127.0.0.1", "--master-port", "29533", "bench.py", "--gpus", "2",
+                "--steps", "4", "--warmup", "1", "--dry-run"])
+    assert out["n_gpus"] == 2 and out["steps"] == 4 and out["scaling"] == "weak"
+    # rank 1 sleeps 2 ms per step, rank 0 1 ms: the reported time is the MAX over ranks
+    assert out["ms_per_step"] >= 1.9
+
+
+def test_dry_run_single():
+    out = _run([sys.executable, "bench.py", "--steps", "3", "--dry-run"])
+    assert out["n_gpus"] == 1 and out["vs_baseline"] is None

@@ -1,0 +1,168 @@
+"""Index-math fuzz of the HIP tile functions, run through the CPU emulation build
+(tests/cpu_emu) against the oracle.  CPU only; the same tile functions are what the
+gfx950 kernels execute (parity proper is tests/test_gpu_*.py on the GPU box)."""
+import numpy as np
+import pytest
+
+from emu_util import P, f32, lib
+from oracle import oracle
+
+WNAMES = ["haar", "db2", "db3", "db4", "sym8", "coif2", "bior3.1", "db10", "db20"]
+SHAPES = [(64, 64), (61, 59), (32, 130), (129, 70), (6, 10), (2, 2), (1, 37), (200, 3)]
+
+
+def _tol(ref):
+    return 3e-6 * max(np.abs(ref).max(), 1.0)
+
+
+@pytest.mark.parametrize("wname", WNAMES)
+@pytest.mark.parametrize("generic", [0, 1])
+def test_emu_dwt2_fwd_level(wname, generic):
+    hlen, dlo, dhi, rlo, rhi = oracle.filters(wname)
+    for si, shape in enumerate(SHAPES):
+        if shape[0] == 1:
+            continue
+        x = oracle.hash_input(shape, 300 + si)
+        # force the generic separable path in the oracle (the Haar butterfly is a separate kernel)
+        ref = oracle.forward(x, wname, 1, ndim=2, filt=(hlen, dlo, dhi, rlo, rhi)) if hlen != 2 else None
+        if ref is None:
+            ref = oracle.forward(x, wname, 1, ndim=2)
+        r2, c2 = (shape[0] + 1) // 2, (shape[1] + 1) // 2
+        outs = [np.full((r2, c2), np.nan, dtype=np.float32) for _ in range(4)]
+        for tile in (0, 1):
+            rc = lib().emu_dwt2_fwd(P(x), 1, shape[0], shape[1], P(dlo), P(dhi), hlen, generic, tile,
+                                    *[P(o) for o in outs])
+            assert rc == 0
+            for got, want in zip(outs, ref):
+                assert np.isfinite(got).all()
+                assert np.abs(got - want).max() <= _tol(want), (wname, shape, tile)
+
+
+@pytest.mark.parametrize("wname", WNAMES)
+@pytest.mark.parametrize("generic", [0, 1])
+def test_emu_dwt2_inv_level(wname, generic):
+    hlen, dlo, dhi, rlo, rhi = oracle.filters(wname)
+    for si, shape in enumerate(SHAPES):
+        if shape[0] == 1:
+            continue
+        r2, c2 = (shape[0] + 1) // 2, (shape[1] + 1) // 2
+        bands = [oracle.hash_input((r2, c2), 900 + 7 * si + b, 2.0) - 1.0 for b in range(4)]
+        ref = oracle.inverse(bands, shape, wname, 1, ndim=2)
+        for tile in (0, 1):
+            out = np.full(shape, np.nan, dtype=np.float32)
+            rc = lib().emu_dwt2_inv(P(bands[0]), P(bands[1]), P(bands[2]), P(bands[3]), 1, r2, c2,
+                                    shape[0], shape[1], P(rlo), P(rhi), hlen, generic, tile, P(out))
+            assert rc == 0
+            assert np.isfinite(out).all()
+            assert np.abs(out - ref).max() <= _tol(ref), (wname, shape, tile)
+
+
+def test_emu_dwt2_batch():
+    hlen, dlo, dhi, rlo, rhi = oracle.filters("db4")
+    B, shape = 3, (40, 72)
+    x = oracle.hash_input((B,) + shape, 77)
+    outs = [np.zeros((B, 20, 36), dtype=np.float32) for _ in range(4)]
+    lib().emu_dwt2_fwd(P(x), B, shape[0], shape[1], P(dlo), P(dhi), hlen, 0, 0, *[P(o) for o in outs])
+    for b in range(B):
+        ref = oracle.forward(x[b], "db4", 1, ndim=2)
+        for got, want in zip(outs, ref):
+            assert np.abs(got[b] - want).max() <= _tol(want)
+    rec = np.zeros((B,) + shape, dtype=np.float32)
+    lib().emu_dwt2_inv(*[P(o) for o in outs], B, 20, 36, shape[0], shape[1], P(rlo), P(rhi), hlen, 0, 0, P(rec))
+    assert np.abs(rec - x).max() < 1e-3
+
+
+def test_emu_odd_length_custom_filter():
+    """Odd custom filter lengths go through the runtime-length (HLEN=0) path."""
+    rng = np.random.RandomState(5)
+    for hlen in (3, 5, 7):
+        lo = f32(rng.randn(hlen)); hi = f32(rng.randn(hlen))
+        shape = (34, 50)
+        x = oracle.hash_input(shape, 5 + hlen)
+        ref = oracle.forward(x, "custom", 1, ndim=2, filt=(hlen, lo, hi, lo, hi))
+        outs = [np.zeros((17, 25), dtype=np.float32) for _ in range(4)]
+        lib().emu_dwt2_fwd(P(x), 1, shape[0], shape[1], P(lo), P(hi), hlen, 1, 0, *[P(o) for o in outs])
+        for got, want in zip(outs, ref):
+            assert np.abs(got - want).max() <= _tol(want)
+        bands = ref
+        refi = oracle.inverse(bands, shape, "custom", 1, ndim=2, filt=(hlen, lo, hi, lo, hi))
+        out = np.zeros(shape, dtype=np.float32)
+        lib().emu_dwt2_inv(*[P(b) for b in bands], 1, 17, 25, shape[0], shape[1], P(lo), P(hi), hlen, 1, 0, P(out))
+        assert np.abs(out - refi).max() <= _tol(refi)
+
+
+# ----------------------------------------------------------------------------- 1D DWT tiles
+SHAPES_1D = [(1, 256), (1, 251), (3, 37), (2, 5000), (1, 4097), (4, 2)]
+
+
+@pytest.mark.parametrize("wname", WNAMES)
+@pytest.mark.parametrize("generic", [0, 1])
+def test_emu_dwt1_levels(wname, generic):
+    hlen, dlo, dhi, rlo, rhi = oracle.filters(wname)
+    for si, shape in enumerate(SHAPES_1D):
+        x = oracle.hash_input(shape, 1300 + si)
+        refA, refD = oracle.forward(x, wname, 1, ndim=1)
+        c2 = (shape[1] + 1) // 2
+        for wide in (0, 1):
+            L = np.full((shape[0], c2), np.nan, dtype=np.float32)
+            H = np.full((shape[0], c2), np.nan, dtype=np.float32)
+            assert lib().emu_dwt1_fwd(P(x), shape[0], shape[1], P(dlo), P(dhi), hlen, generic, wide, P(L), P(H)) == 0
+            assert np.abs(L - refA).max() <= _tol(refA) and np.abs(H - refD).max() <= _tol(refD), (wname, shape, wide)
+            a = oracle.hash_input((shape[0], c2), 77 + si, 2.0) - 1.0
+            d = oracle.hash_input((shape[0], c2), 78 + si, 2.0) - 1.0
+            ref = oracle.inverse([a, d], shape, wname, 1, ndim=1)
+            out = np.full(shape, np.nan, dtype=np.float32)
+            assert lib().emu_dwt1_inv(P(a), P(d), shape[0], c2, shape[1], P(rlo), P(rhi), hlen, generic, wide, P(out)) == 0
+            assert np.abs(out - ref).max() <= _tol(ref), (wname, shape, wide)
+
+
+# ----------------------------------------------------------------------------- SWT tiles
+@pytest.mark.parametrize("wname", ["haar", "db2", "db4", "sym8", "bior3.1"])
+@pytest.mark.parametrize("generic", [0, 1])
+def test_emu_swt2_levels(wname, generic):
+    hlen, dlo, dhi, rlo, rhi = oracle.filters(wname)
+    for si, (shape, level) in enumerate([((32, 32), 1), ((32, 48), 2), ((64, 70), 3), ((48, 33), 4), ((40, 20), 2)]):
+        x = oracle.hash_input(shape, 1700 + si)
+        # level-l analysis of an arbitrary plane == oracle analysis with dilation 2^(l-1)
+        lib_o = oracle.load()
+        t1 = np.zeros(shape, np.float32); t2 = np.zeros(shape, np.float32)
+        ref = [np.zeros(shape, np.float32) for _ in range(4)]
+        lib_o.oracle_swt_analysis_rows(P(x), shape[0], shape[1], P(dlo), P(dhi), hlen, level, P(t1), P(t2))
+        lib_o.oracle_swt_analysis_cols(P(t1), shape[0], shape[1], P(dlo), P(dhi), hlen, level, P(ref[0]), P(ref[1]))
+        lib_o.oracle_swt_analysis_cols(P(t2), shape[0], shape[1], P(dlo), P(dhi), hlen, level, P(ref[2]), P(ref[3]))
+        outs = [np.full(shape, np.nan, dtype=np.float32) for _ in range(4)]
+        xin = x.copy()
+        assert lib().emu_swt2(0, P(xin), 1, shape[0], shape[1], level, P(dlo), P(dhi), hlen, generic,
+                              *[P(o) for o in outs]) == 0
+        for g, r in zip(outs, ref):
+            assert np.abs(g - r).max() <= _tol(r), (wname, shape, level)
+        # synthesis
+        bands = [oracle.hash_input(shape, 50 + si * 4 + b, 2.0) - 1.0 for b in range(4)]
+        lib_o.oracle_swt_synthesis_cols(P(bands[0]), P(bands[1]), shape[0], shape[1], P(rlo), P(rhi), hlen, level, P(t1))
+        lib_o.oracle_swt_synthesis_cols(P(bands[2]), P(bands[3]), shape[0], shape[1], P(rlo), P(rhi), hlen, level, P(t2))
+        want = np.zeros(shape, np.float32)
+        lib_o.oracle_swt_synthesis_rows(P(t1), P(t2), shape[0], shape[1], P(rlo), P(rhi), hlen, level, P(want))
+        out = np.full(shape, np.nan, dtype=np.float32)
+        assert lib().emu_swt2(1, P(out), 1, shape[0], shape[1], level, P(rlo), P(rhi), hlen, generic,
+                              *[P(b) for b in bands]) == 0
+        assert np.abs(out - want).max() <= _tol(want), (wname, shape, level)
+
+
+@pytest.mark.parametrize("wname", ["haar", "db3", "sym8"])
+def test_emu_swt_direct_passes(wname):
+    hlen, dlo, dhi, rlo, rhi = oracle.filters(wname)
+    lib_o = oracle.load()
+    for shape, level in [((30, 44), 3), ((7, 100), 2), ((1, 128), 4)]:
+        x = oracle.hash_input(shape, 2100)
+        y = oracle.hash_input(shape, 2101)
+        for along_y in (0, 1):
+            r0 = np.zeros(shape, np.float32); r1 = np.zeros(shape, np.float32)
+            fa = lib_o.oracle_swt_analysis_cols if along_y else lib_o.oracle_swt_analysis_rows
+            fa(P(x), shape[0], shape[1], P(dlo), P(dhi), hlen, level, P(r0), P(r1))
+            o0 = np.full(shape, np.nan, np.float32); o1 = np.full(shape, np.nan, np.float32)
+            lib().emu_swt_pass(0, P(x), None, shape[0], shape[1], level, along_y, P(dlo), P(dhi), hlen, P(o0), P(o1))
+            assert np.abs(o0 - r0).max() <= _tol(r0) and np.abs(o1 - r1).max() <= _tol(r1)
+            fs = lib_o.oracle_swt_synthesis_cols if along_y else lib_o.oracle_swt_synthesis_rows
+            fs(P(x), P(y), shape[0], shape[1], P(rlo), P(rhi), hlen, level, P(r0))
+            lib().emu_swt_pass(1, P(x), P(y), shape[0], shape[1], level, along_y, P(rlo), P(rhi), hlen, P(o0), None)
+            assert np.abs(o0 - r0).max() <= _tol(r0)

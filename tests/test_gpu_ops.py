@@ -1,0 +1,247 @@
+"""GPU tests of the coefficient operators and of the drop-in API behaviour (`pytest -m gpu`).
+
+The reference has NO tests for thresholds, norms, add_wavelet, set_coeff, custom filters or cycle
+spinning; these pin them to the oracle's restatement of pdwt/src/common.cu and
+to pywt.threshold vectors.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from golden_util import GOLDEN
+from oracle import oracle
+from test_gpu_parity import flat_coeffs
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def W():
+    oracle.build()
+    from pypwt_amd import Wavelets
+    return Wavelets
+
+
+CASES = [((96, 80), 2, 0, "db3", 3), ((61, 59), 2, 0, "db2", 2), ((64, 64), 2, 1, "haar", 3),
+         ((1, 300), 1, 0, "sym4", 3), ((5, 128), 1, 0, "db2", 2), ((4, 64), 1, 1, "db2", 2)]
+
+
+def _mk(W, case, seed=1):
+    shape, nd, swt, wname, lv = case
+    x = oracle.hash_input(shape, seed, 100.0) - 50.0
+    w = W(x[0] if shape[0] == 1 else x, wname, lv, do_swt=swt, ndim=nd)
+    w.forward()
+    bands = [b.copy() for b in flat_coeffs(w)]
+    return w, x, bands
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("op", ["soft", "hard"])
+@pytest.mark.parametrize("do_app,normalize", [(0, 0), (1, 0), (0, 1), (1, 1)])
+def test_thresholds_vs_oracle(W, case, op, do_app, normalize):
+    shape, nd, swt, wname, lv = case
+    w, x, bands = _mk(W, case)
+    beta = 7.5
+    getattr(w, op + "_threshold")(beta, do_app, normalize)
+    ref = oracle.threshold(bands, shape, lv, op, beta, do_app, normalize, ndim=nd, do_swt=swt)
+    for g, r in zip(flat_coeffs(w), ref):
+        assert np.abs(g - r).max() <= 2e-6 * max(np.abs(r).max(), 1.0)
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_shrink_linf_group_vs_oracle(W, case):
+    shape, nd, swt, wname, lv = case
+    for do_app in (0, 1):
+        w, x, bands = _mk(W, case)
+        w.shrink(0.25, do_app)
+        ref = oracle.shrink(bands, shape, lv, 0.25, do_app, ndim=nd, do_swt=swt)
+        for g, r in zip(flat_coeffs(w), ref):
+            assert np.abs(g - r).max() <= 2e-6 * max(np.abs(r).max(), 1.0)
+        w, x, bands = _mk(W, case)
+        w.proj_linf(3.0, do_app)
+        ref = oracle.threshold(bands, shape, lv, "linf", 3.0, do_app, 0, ndim=nd, do_swt=swt)
+        for g, r in zip(flat_coeffs(w), ref):
+            assert np.array_equal(g, r)
+        if swt or not do_app:  # A has the detail shape only for SWT (common.cu:145-150)
+            for normalize in (0, 1):
+                w, x, bands = _mk(W, case)
+                w.group_soft_threshold(20.0, do_app, normalize)
+                ref = oracle.threshold(bands, shape, lv, "group", 20.0, do_app, normalize, ndim=nd, do_swt=swt)
+                for g, r in zip(flat_coeffs(w), ref):
+                    assert np.abs(g - r).max() <= 5e-6 * max(np.abs(r).max(), 1.0)
+
+
+def test_soft_threshold_pywt_vectors(W):
+    """pywt.threshold(mode='soft'/'hard') vectors through set_coeff -> threshold -> coeffs."""
+    z = np.load(os.path.join(GOLDEN, "threshold.npz"))
+    x = z["x"]
+    n = x.size // 2
+    for k in range(3):
+        beta = float(z["beta%d" % k])
+        for op in ("soft", "hard"):
+            w = W(np.zeros(2 * n, dtype=np.float32), "haar", 1, ndim=1)
+            w.forward()
+            w.set_coeff(x[:n].reshape(1, n), 0)
+            w.set_coeff(x[n:].reshape(1, n), 1)
+            getattr(w, op + "_threshold")(beta, 1, 0)
+            got = np.concatenate([c.ravel() for c in flat_coeffs(w)])
+            assert np.allclose(got, z["%s%d" % (op, k)], rtol=0, atol=2e-6)
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_norms_and_add_wavelet(W, case):
+    shape, nd, swt, wname, lv = case
+    w, x, bands = _mk(W, case, seed=3)
+    n1, n2 = oracle.norms(bands, shape, lv, ndim=nd, do_swt=swt)
+    assert abs(w.norm1() - n1) <= 1e-5 * n1
+    assert abs(w.norm2sq() - n2) <= 1e-5 * n2
+    w2, x2, bands2 = _mk(W, case, seed=4)
+    assert w.add_wavelet(w2, 0.5) == 0
+    for g, a, b in zip(flat_coeffs(w), bands, bands2):
+        assert np.abs(g - (a + np.float32(0.5) * b)).max() <= 2e-6 * max(np.abs(a).max(), 1.0)
+    # mismatching operands are refused with the reference's codes (wt.cu:625-640)
+    other = W(np.zeros((96, 80), dtype=np.float32), "db4", 1)
+    assert w.add_wavelet(other) in (-1, -2, -3)
+
+
+def test_state_machine_and_errors(W):
+    x = oracle.hash_input((64, 64), 5)
+    w = W(x, "db2", 2)
+    w.forward()
+    w.inverse()
+    w.inverse()  # second inverse: warning, no-op (wt.cu:272-275)
+    with pytest.raises(RuntimeError):
+        _ = w.coeffs  # refused after inverse (wt.cu:474-477, pypwt.pyx:284-285)
+    w.soft_threshold(1.0)  # refused with a warning, no exception (wt.cu:309-312)
+    assert np.abs(w.image - x).max() < 7e-4
+    w.forward()
+    assert len(w.coeffs) == 3
+    with pytest.raises(ValueError):
+        W(x, "not_a_wavelet", 2)
+    with pytest.raises(NotImplementedError):
+        W(np.zeros((2, 2, 2), dtype=np.float32), "haar", 1)
+    with pytest.raises(ValueError):
+        w.set_image(np.zeros((3, 3), dtype=np.float32))
+    with pytest.raises(ValueError):
+        w.forward(np.zeros((64, 63), dtype=np.float32))
+
+
+def test_level_clamp_and_attributes(W):
+    x = oracle.hash_input((512, 512), 6)
+    w = W(x, "db2", 99)
+    assert w.levels == 7  # floor(log2(512/3)), wt.cu:155-165
+    assert w.sizes[0] == (256, 256) and w.sizes[-1] == (4, 4)
+    assert (w.Nr, w.Nc, w.ndim, w.batched1d, w.do_swt, w.do_separable) == (512, 512, 2, 0, 0, 1)
+    assert W.version() == "1.0.3"
+    w = W(x, "DB2", 0)  # case-insensitive name (separable.cu:33); levels < 1 -> 1 (wt.cu:111-114)
+    assert w.levels == 1
+    w = W(x[0], "haar", 3, ndim=1)
+    assert (w.Nr, w.Nc, w.ndim) == (1, 512, 1)
+    w.forward()
+    assert [c.shape for c in w.coeffs] == [(1, 64), (1, 256), (1, 128), (1, 64)]  # (1, n) shapes, pypwt.pyx:152-154
+    w = W(x, "haar", 3, do_swt=1)
+    assert w.sizes == [(512, 512)] * 3
+    for alias in ("db1", "bior1.1", "rbior1.1"):  # separable.cu:24-28
+        assert W(x, alias, 1).hlen == 2
+    w.info()
+    assert int(w.image_int_ptr()) != 0 and int(w.coeff_int_ptr(1)) != 0
+
+
+def test_coeffs_are_cached_arrays(W):
+    x = oracle.hash_input((32, 32), 7)
+    w = W(x, "db2", 1)
+    w.forward()
+    c1 = w.coeffs
+    c2 = w.coeffs
+    assert c1 is c2 and c1[1][0] is c2[1][0]  # same numpy objects every call (pypwt.pyx:298-305)
+    a = w.coeff_only(0)
+    assert a is c1[0]
+
+
+def test_set_coeff_roundtrip_and_forward_img(W):
+    x = oracle.hash_input((48, 40), 8)
+    w = W(x, "sym4", 2)
+    w.forward()
+    co = [c.copy() for c in flat_coeffs(w)]
+    w2 = W(np.zeros_like(x), "sym4", 2)
+    w2.forward()
+    for num, c in enumerate(co):
+        w2.set_coeff(c, num, check=True)
+    w2.inverse()
+    assert np.abs(w2.image - x).max() < 7e-4
+    with pytest.raises(ValueError):
+        w.set_coeff(np.zeros((3, 3), dtype=np.float32), 1)
+    y = oracle.hash_input((48, 40), 9)
+    w.forward(y)
+    ora = oracle.forward(y, "sym4", 2)
+    for g, r in zip(flat_coeffs(w), ora):
+        assert np.abs(g - r).max() <= 3e-6 * max(np.abs(r).max(), 1.0)
+
+
+def test_circshift_and_cycle_spinning(W):
+    from pypwt_amd import _lib
+    x = oracle.hash_input((37, 50), 10)
+    w = W(x, "db2", 2)
+    lib = _lib.load()
+    _lib.check(lib.pdwt_circshift(w._h, 5, -7, 1))
+    assert np.array_equal(w.image, oracle.circshift(x, 5, -7))
+    # cycle spinning: forward shifts by a random amount, inverse undoes it (wt.cu:242-246,303)
+    w = W(x, "db2", 2, do_cycle_spinning=1)
+    w.forward()
+    w.inverse()
+    assert np.abs(w.image - x).max() < 7e-4
+
+
+def test_custom_separable_filters(W):
+    """set_wavelets_filters with pywt's db3 taps on a db2 plan == a db3 plan; odd-length bank runs the
+    runtime-length kernels."""
+    x = oracle.hash_input((64, 72), 11)
+    hlen, dlo, dhi, rlo, rhi = oracle.filters("db3")
+    w = W(x, "db2", 2)
+    w.set_wavelets_filters("mydb3", dlo, dhi, rlo, rhi)
+    w.forward()
+    ora = oracle.forward(x, "db3", 2)
+    for g, r in zip(flat_coeffs(w), ora):
+        assert np.abs(g - r).max() <= 3e-6 * max(np.abs(r).max(), 1.0)
+    w.inverse()
+    assert np.abs(w.image - x).max() < 7e-4
+    rng = np.random.RandomState(0)
+    lo, hi = rng.randn(5).astype(np.float32), rng.randn(5).astype(np.float32)
+    w = W(x, "db2", 1)
+    w.set_wavelets_filters("odd5", lo, hi, lo, hi)
+    w.forward()
+    ora = oracle.forward(x, "odd5", 1, filt=(5, lo, hi, lo, hi))
+    for g, r in zip(flat_coeffs(w), ora):
+        assert np.abs(g - r).max() <= 3e-6 * max(np.abs(r).max(), 1.0)
+    with pytest.raises(ValueError):
+        w.set_wavelets_filters("bad", lo, hi[:4], lo, hi)
+
+
+def test_two_live_plans_do_not_share_filters(W):
+    """The reference keeps ONE filter bank in __constant__ memory per process (separable.cu:48-51):
+    creating a second Wavelets silently changes the first one's filters.  Plans here are independent."""
+    x = oracle.hash_input((64, 64), 12)
+    wa = W(x, "db2", 2)
+    wb = W(x, "sym8", 1)  # would overwrite the reference's global bank
+    wa.forward()
+    wb.forward()
+    for g, r in zip(flat_coeffs(wa), oracle.forward(x, "db2", 2)):
+        assert np.abs(g - r).max() <= 3e-6 * max(np.abs(r).max(), 1.0)
+    for g, r in zip(flat_coeffs(wb), oracle.forward(x, "sym8", 1)):
+        assert np.abs(g - r).max() <= 3e-6 * max(np.abs(r).max(), 1.0)
+
+
+def test_nonseparable_flag_matches_separable(W):
+    """do_separable=0 with a built-in wavelet must give the separable result (the
+    non-separable path is pinned to the separable one)."""
+    x = oracle.hash_input((64, 80), 13)
+    for wname, swt in (("db2", 0), ("db3", 0), ("haar", 1)):
+        w = W(x, wname, 2, do_separable=0, do_swt=swt)
+        assert w.do_separable == 0
+        w.forward()
+        ora = oracle.forward(x, wname, 2, do_swt=swt)
+        for g, r in zip(flat_coeffs(w), ora):
+            assert np.abs(g - r).max() <= 1e-5 * max(np.abs(r).max(), 1.0)
+        w.inverse()
+        assert np.abs(w.image - x).max() < 7e-4
