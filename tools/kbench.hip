@@ -1,0 +1,148 @@
+// kbench.hip -- kernel micro-benchmark for tuning (developer tool, not part of the library).
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I pypwt_amd/csrc tools/kbench.hip -o build/kbench
+// Times variants of the level kernels at a given size with HIP events, next to plain streaming
+// kernels (copy / read / write) that calibrate what this GPU sustains at the same footprint.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <string>
+#include <vector>
+
+#include "dwt2_kernels.hpp"
+
+using namespace pdwt;
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
+
+__global__ void copy4(const float4* __restrict__ a, float4* __restrict__ b, long long n4) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) b[i] = a[i];
+}
+__global__ void read4(const float4* __restrict__ a, float* __restrict__ sink, long long n4) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    float s = 0.f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 v = a[i];
+        s += v.x + v.y + v.z + v.w;
+    }
+    if (s == 123.456f) sink[0] = s;
+}
+__global__ void write4(float4* __restrict__ b, long long n4) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride)
+        b[i] = make_float4(1.f, 2.f, 3.f, 4.f);
+}
+
+static float time_it(const std::function<void()>& fn, int reps = 30, int warm = 5) {
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    for (int i = 0; i < warm; i++) fn();
+    CK(hipDeviceSynchronize());
+    std::vector<float> t;
+    // back-to-back launches bracketed once: average kernel time incl. launch gaps
+    CK(hipEventRecord(e0));
+    for (int i = 0; i < reps; i++) fn();
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms = 0;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    CK(hipEventDestroy(e0));
+    CK(hipEventDestroy(e1));
+    return ms * 1e3f / reps;
+}
+
+static const float DB4_LO[8] = {-0.010597401784997278f, 0.032883011666982945f, 0.030841381835986965f, -0.18703481171888114f,
+                                -0.02798376941698385f, 0.6308807679295904f, 0.7148465705525415f, 0.23037781330885523f};
+static const float DB4_HI[8] = {-0.23037781330885523f, 0.7148465705525415f, -0.6308807679295904f, -0.02798376941698385f,
+                                0.18703481171888114f, 0.030841381835986965f, -0.032883011666982945f, -0.010597401784997278f};
+
+template <int HLEN, int TX, int TY, int NT>
+static void bench_fwd(const char* tag, const float* in, float* out4, int N, int batch) {
+    Fwd2DArgs a;
+    a.in = in;
+    const long long q = (long long)batch * (N / 2) * (N / 2);
+    a.A = out4; a.H = out4 + q; a.V = out4 + 2 * q; a.D = out4 + 3 * q;
+    a.Nr = N; a.Nc = N; a.Nr2 = N / 2; a.Nc2 = N / 2;
+    a.in_bstride = (long long)N * N; a.out_bstride = (long long)(N / 2) * (N / 2);
+    a.hlen = HLEN;
+    memset(&a.fb, 0, sizeof(a.fb));
+    for (int i = 0; i < 8; i++) { a.fb.lo[i] = DB4_LO[i]; a.fb.hi[i] = DB4_HI[i]; }
+    const size_t lds = (size_t)fwd2d_lds_floats<TX, TY>(HLEN) * sizeof(float);
+    if (lds > 64 * 1024)
+        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(dwt2_fwd_kernel<HLEN, TX, TY, NT>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    dim3 grid((N / 2 + TX - 1) / TX, (N / 2 + TY - 1) / TY, batch);
+    float us = time_it([&] { hipLaunchKernelGGL((dwt2_fwd_kernel<HLEN, TX, TY, NT>), grid, dim3(NT), lds, 0, a); });
+    const double bytes = 8.0 * batch * N * N;
+    printf("%-34s N=%d B=%d lds=%6zu  %8.2f us  %7.1f GB/s (algorithmic)\n", tag, N, batch, lds, us, bytes / us / 1e3);
+}
+
+template <int HLEN, int TX, int TY, int NT>
+static void bench_inv(const char* tag, const float* in4, float* out, int N, int batch) {
+    Inv2DArgs a;
+    const long long q = (long long)batch * (N / 2) * (N / 2);
+    a.A = in4; a.H = in4 + q; a.V = in4 + 2 * q; a.D = in4 + 3 * q; a.out = out;
+    a.Nrc = N / 2; a.Ncc = N / 2; a.Nr = N; a.Nc = N;
+    a.in_bstride = (long long)(N / 2) * (N / 2); a.out_bstride = (long long)N * N;
+    a.hlen = HLEN;
+    memset(&a.fb, 0, sizeof(a.fb));
+    for (int i = 0; i < 8; i++) { a.fb.lo[i] = DB4_LO[7 - i]; a.fb.hi[i] = DB4_HI[7 - i]; }
+    const size_t lds = (size_t)inv2d_lds_floats<TX, TY>(HLEN) * sizeof(float);
+    if (lds > 64 * 1024)
+        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(dwt2_inv_kernel<HLEN, TX, TY, NT>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    dim3 grid((N + 2 * TX - 1) / (2 * TX), (N + 2 * TY - 1) / (2 * TY), batch);
+    float us = time_it([&] { hipLaunchKernelGGL((dwt2_inv_kernel<HLEN, TX, TY, NT>), grid, dim3(NT), lds, 0, a); });
+    const double bytes = 8.0 * batch * N * N;
+    printf("%-34s N=%d B=%d lds=%6zu  %8.2f us  %7.1f GB/s (algorithmic)\n", tag, N, batch, lds, us, bytes / us / 1e3);
+}
+
+int main(int argc, char** argv) {
+    const int N = argc > 1 ? atoi(argv[1]) : 4096;
+    const int B = argc > 2 ? atoi(argv[2]) : 1;
+    const long long n = (long long)B * N * N;
+    float *a, *b;
+    CK(hipMalloc((void**)&a, n * sizeof(float)));
+    CK(hipMalloc((void**)&b, n * sizeof(float)));
+    CK(hipMemset(a, 0, n * sizeof(float)));
+    CK(hipMemset(b, 0, n * sizeof(float)));
+    {
+        std::vector<float> h((size_t)N * N);
+        for (size_t i = 0; i < h.size(); i++) h[i] = (float)((i * 2654435761u) >> 8 & 0xffff) / 257.0f;
+        for (int i = 0; i < B; i++) CK(hipMemcpy(a + (long long)i * N * N, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+    hipDeviceProp_t prop;
+    CK(hipGetDeviceProperties(&prop, 0));
+    printf("device %s, %d CUs, clock %d MHz\n", prop.name, prop.multiProcessorCount, prop.clockRate / 1000);
+    const long long n4 = n / 4;
+    for (int grid : {1024, 2048, 8192}) {
+        float us = time_it([&] { hipLaunchKernelGGL(copy4, dim3(grid), dim3(256), 0, 0, (const float4*)a, (float4*)b, n4); });
+        printf("copy4  grid=%5d                    %8.2f us  %7.1f GB/s (r+w)\n", grid, us, 8.0 * n / us / 1e3);
+    }
+    {
+        float us = time_it([&] { hipLaunchKernelGGL(read4, dim3(2048), dim3(256), 0, 0, (const float4*)a, b, n4); });
+        printf("read4  grid= 2048                    %8.2f us  %7.1f GB/s (r)\n", us, 4.0 * n / us / 1e3);
+        us = time_it([&] { hipLaunchKernelGGL(write4, dim3(2048), dim3(256), 0, 0, (float4*)b, n4); });
+        printf("write4 grid= 2048                    %8.2f us  %7.1f GB/s (w)\n", us, 4.0 * n / us / 1e3);
+    }
+    bench_fwd<8, 64, 16, 256>("fwd db4 TX64 TY16 NT256", a, b, N, B);
+    bench_fwd<8, 64, 32, 256>("fwd db4 TX64 TY32 NT256", a, b, N, B);
+    bench_fwd<8, 64, 8, 256>("fwd db4 TX64 TY8  NT256", a, b, N, B);
+    bench_fwd<8, 128, 16, 256>("fwd db4 TX128 TY16 NT256", a, b, N, B);
+    bench_fwd<8, 64, 16, 128>("fwd db4 TX64 TY16 NT128", a, b, N, B);
+    bench_fwd<8, 64, 32, 512>("fwd db4 TX64 TY32 NT512", a, b, N, B);
+    bench_fwd<8, 32, 32, 256>("fwd db4 TX32 TY32 NT256", a, b, N, B);
+    bench_fwd<2, 64, 16, 256>("fwd haar(taps of db4) TX64 TY16", a, b, N, B);
+    bench_inv<8, 64, 16, 256>("inv db4 TX64 TY16 NT256", b, a, N, B);
+    bench_inv<8, 64, 32, 256>("inv db4 TX64 TY32 NT256", b, a, N, B);
+    bench_inv<8, 64, 8, 256>("inv db4 TX64 TY8  NT256", b, a, N, B);
+    bench_inv<8, 128, 16, 256>("inv db4 TX128 TY16 NT256", b, a, N, B);
+    bench_inv<8, 32, 32, 256>("inv db4 TX32 TY32 NT256", b, a, N, B);
+    CK(hipFree(a));
+    CK(hipFree(b));
+    return 0;
+}
