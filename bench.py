@@ -149,7 +149,7 @@ def cpu_baseline(cfg):
     from oracle import oracle
     oracle.build()
     Nr, Nc, wname, L, swt, ndim, beta, desc = cfg
-    cores = oracle.set_threads(0)
+    cores = oracle.set_threads(oracle.usable_cpus())
     x = oracle.hash_input((Nr, Nc), 20242)
     best = None
     reps = 3 if not swt else 1

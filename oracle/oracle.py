@@ -27,6 +27,19 @@ def build():
     subprocess.check_call(["make", "-s", "-C", HERE])
 
 
+def usable_cpus():
+    """CPUs this process may actually use: affinity mask capped by the cgroup quota (the GPU box
+    shows 256 CPUs but grants 16; 256 OpenMP threads on 16 cores is 10x slower than 16)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
 def _ptr(a):
     return a.ctypes.data_as(f32p)
 
@@ -66,6 +79,8 @@ def load(double=False):
     lib.oracle_div2.argtypes = [i]
     lib.oracle_set_threads.argtypes = [i]
     assert bool(lib.oracle_real_is_double()) == bool(double)
+    if "OMP_NUM_THREADS" not in os.environ:
+        lib.oracle_set_threads(usable_cpus())
     _LIBS[key] = lib
     return lib
 

@@ -17,6 +17,9 @@ enum EwOp { EW_SOFT = 0, EW_HARD = 1, EW_LINF = 2, EW_SCALE = 3 };
 
 hipError_t launch_dwt2_fwd(const Fwd2DArgs& a, int batch, hipStream_t s);
 hipError_t launch_dwt2_inv(const Inv2DArgs& a, int batch, hipStream_t s);
+// tuned kernels; hipErrorNotSupported = preconditions not met, use the generic launcher
+hipError_t try_launch_dwt2_fwd_fast(const Fwd2DArgs& a, int batch, hipStream_t s);
+hipError_t try_launch_dwt2_inv_fast(const Inv2DArgs& a, int batch, hipStream_t s);
 hipError_t launch_dwt1_fwd(const Fwd1DArgs& a, hipStream_t s);
 hipError_t launch_dwt1_inv(const Inv1DArgs& a, hipStream_t s);
 // fused a-trous level; the host guarantees a.f divides a.Nr

@@ -33,6 +33,10 @@ static hipError_t run_inv(const Inv2DArgs& a, int batch, hipStream_t s) {
 }
 
 hipError_t launch_dwt2_fwd(const Fwd2DArgs& a, int batch, hipStream_t s) {
+    {
+        const hipError_t e = try_launch_dwt2_fwd_fast(a, batch, s);
+        if (e != hipErrorNotSupported) return e;
+    }
     if (a.hlen & 1) return run_fwd<0, 64, 16, 256>(a, batch, s);
     switch (a.hlen) {
 #define X(h)                                                       \
@@ -47,6 +51,10 @@ hipError_t launch_dwt2_fwd(const Fwd2DArgs& a, int batch, hipStream_t s) {
 }
 
 hipError_t launch_dwt2_inv(const Inv2DArgs& a, int batch, hipStream_t s) {
+    {
+        const hipError_t e = try_launch_dwt2_inv_fast(a, batch, s);
+        if (e != hipErrorNotSupported) return e;
+    }
     if (a.hlen & 1) return run_inv<0, 64, 16, 256>(a, batch, s);
     switch (a.hlen) {
 #define X(h)                                                       \

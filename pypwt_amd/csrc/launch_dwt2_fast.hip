@@ -1,0 +1,93 @@
+// launch_dwt2_fast.hip -- instantiations + launchers of the tuned 2D DWT level kernels (gfx950).
+//
+// try_launch_* return hipErrorNotSupported when the level does not meet the fast kernels'
+// preconditions (even compile-time filter length, row length multiple of 4, 16-B aligned rows);
+// the caller then uses the generic kernels of launch_dwt2.hip.
+//
+// Tile shape per filter length (kbench on MI355X, profiles/r01b_kbench_*.txt): 64 output columns;
+// short filters want SMALL tiles (8 output rows, ~23 KB LDS, 6 workgroups per CU): occupancy beats
+// the larger halo; longer filters amortise their halo over 16 / 32 rows.
+#include "dwt2_fast_kernels.hpp"
+#include "launch.hpp"
+#include "launch_util.hpp"
+
+namespace pdwt {
+
+static void interleave(FilterBankI& o, const FilterBank& fb) {
+    for (int i = 0; i < kMaxTaps; i++) {
+        o.t[i].x = fb.lo[i];
+        o.t[i].y = fb.hi[i];
+    }
+}
+
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+template <int HLEN, int TX, int TY, int NT>
+static hipError_t run_fwd_fast(const Fwd2DArgs& g, int batch, hipStream_t s) {
+    static bool big[64] = {};
+    constexpr size_t lds = (size_t)fwd2d_fast_lds_floats<HLEN, TX, TY>() * sizeof(float);
+    hipError_t e = allow_big_lds(dwt2_fwd_fast_kernel<HLEN, TX, TY, NT>, lds, big);
+    if (e != hipSuccess) return e;
+    Fwd2DFastArgs a;
+    a.in = g.in; a.A = g.A; a.H = g.H; a.V = g.V; a.D = g.D;
+    a.Nr = g.Nr; a.Nc = g.Nc; a.Nr2 = g.Nr2; a.Nc2 = g.Nc2;
+    a.in_bstride = g.in_bstride; a.out_bstride = g.out_bstride;
+    a.tiles_x = cdiv(g.Nc2, TX); a.tiles_y = cdiv(g.Nr2, TY);
+    interleave(a.fb, g.fb);
+    const int chunk = (a.tiles_x * a.tiles_y + 7) / 8;
+    hipLaunchKernelGGL((dwt2_fwd_fast_kernel<HLEN, TX, TY, NT>), dim3(8 * chunk, batch), dim3(NT), lds, s, a);
+    return hipGetLastError();
+}
+
+template <int HLEN, int TX, int TY, int NT>
+static hipError_t run_inv_fast(const Inv2DArgs& g, int batch, hipStream_t s) {
+    static bool big[64] = {};
+    constexpr size_t lds = (size_t)inv2d_fast_lds_floats<HLEN, TX, TY>() * sizeof(float);
+    hipError_t e = allow_big_lds(dwt2_inv_fast_kernel<HLEN, TX, TY, NT>, lds, big);
+    if (e != hipSuccess) return e;
+    Inv2DFastArgs a;
+    a.A = g.A; a.H = g.H; a.V = g.V; a.D = g.D; a.out = g.out;
+    a.Nrc = g.Nrc; a.Ncc = g.Ncc; a.Nr = g.Nr; a.Nc = g.Nc;
+    a.in_bstride = g.in_bstride; a.out_bstride = g.out_bstride;
+    a.tiles_x = cdiv(g.Nc, 2 * TX); a.tiles_y = cdiv(g.Nr, 2 * TY);
+    interleave(a.fb, g.fb);
+    const int chunk = (a.tiles_x * a.tiles_y + 7) / 8;
+    hipLaunchKernelGGL((dwt2_inv_fast_kernel<HLEN, TX, TY, NT>), dim3(8 * chunk, batch), dim3(NT), lds, s, a);
+    return hipGetLastError();
+}
+
+hipError_t try_launch_dwt2_fwd_fast(const Fwd2DArgs& a, int batch, hipStream_t s) {
+    if ((a.hlen & 1) || a.hlen < 2 || a.hlen > kMaxTaps) return hipErrorNotSupported;
+    if ((a.Nc & 3) || (a.in_bstride & 3) || (a.out_bstride & 1)) return hipErrorNotSupported;
+    if (!aligned16(a.in) || !aligned16(a.A) || !aligned16(a.H) || !aligned16(a.V) || !aligned16(a.D))
+        return hipErrorNotSupported;
+    switch (a.hlen) {
+#define X(h)                                                                \
+    case h:                                                                 \
+        if constexpr (h <= 8) return run_fwd_fast<h, 64, 8, 256>(a, batch, s);   \
+        else if constexpr (h <= 20) return run_fwd_fast<h, 64, 16, 256>(a, batch, s); \
+        else return run_fwd_fast<h, 64, 32, 256>(a, batch, s);
+        PDWT_EVEN_HLENS(X)
+#undef X
+    }
+    return hipErrorNotSupported;
+}
+
+hipError_t try_launch_dwt2_inv_fast(const Inv2DArgs& a, int batch, hipStream_t s) {
+    if ((a.hlen & 1) || a.hlen < 2 || a.hlen > kMaxTaps) return hipErrorNotSupported;
+    if ((a.Ncc & 3) || a.Nc != 2 * a.Ncc || (a.in_bstride & 3) || (a.out_bstride & 3)) return hipErrorNotSupported;
+    if (!aligned16(a.out) || !aligned16(a.A) || !aligned16(a.H) || !aligned16(a.V) || !aligned16(a.D))
+        return hipErrorNotSupported;
+    switch (a.hlen) {
+#define X(h)                                                                \
+    case h:                                                                 \
+        if constexpr (h <= 8) return run_inv_fast<h, 64, 8, 256>(a, batch, s);   \
+        else if constexpr (h <= 20) return run_inv_fast<h, 64, 16, 256>(a, batch, s); \
+        else return run_inv_fast<h, 64, 32, 256>(a, batch, s);
+        PDWT_EVEN_HLENS(X)
+#undef X
+    }
+    return hipErrorNotSupported;
+}
+
+}  // namespace pdwt

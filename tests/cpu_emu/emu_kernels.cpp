@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "../../pypwt_amd/csrc/dwt1_kernels.hpp"
+#include "../../pypwt_amd/csrc/dwt2_fast_kernels.hpp"
 #include "../../pypwt_amd/csrc/dwt2_kernels.hpp"
 #include "../../pypwt_amd/csrc/swt_kernels.hpp"
 
@@ -168,4 +169,71 @@ EMU_API int emu_swt_pass(int inverse, const float* in0, const float* in1, int Nr
         else swt_pass_fwd_tile<256>(a, b, nullptr);
     }
     return 0;
+}
+
+// ------------------------------------------------------------------ tuned 2D kernels
+static void set_bank_i(FilterBankI& fb, const float* lo, const float* hi, int hlen) {
+    std::memset(&fb, 0, sizeof(fb));
+    for (int i = 0; i < hlen; i++) { fb.t[i].x = lo[i]; fb.t[i].y = hi[i]; }
+}
+
+template <int HLEN, int TX, int TY, int NT>
+static void run_fwd2d_fast(Fwd2DFastArgs a, int batch) {
+    std::vector<float> smem(fwd2d_fast_lds_floats<HLEN, TX, TY>() + 64, -12345.f);
+    a.tiles_x = cdiv(a.Nc2, TX); a.tiles_y = cdiv(a.Nr2, TY);
+    const int chunk = (a.tiles_x * a.tiles_y + 7) / 8;
+    std::vector<int> seen(a.tiles_x * a.tiles_y, 0);
+    for (int bz = 0; bz < batch; bz++)
+        for (int b = 0; b < 8 * chunk; b++) {
+            int bx, by;
+            if (!xcd_tile(b, a.tiles_x, a.tiles_y, bx, by)) continue;
+            if (bz == 0) seen[by * a.tiles_x + bx]++;
+            dwt2_fwd_fast_tile<HLEN, TX, TY, NT>(a, bx, by, bz, smem.data());
+        }
+    for (int v : seen) if (v != 1) std::abort();  // the XCD renumbering must be a bijection
+}
+
+template <int HLEN, int TX, int TY, int NT>
+static void run_inv2d_fast(Inv2DFastArgs a, int batch) {
+    std::vector<float> smem(inv2d_fast_lds_floats<HLEN, TX, TY>() + 64, -12345.f);
+    a.tiles_x = cdiv(a.Nc, 2 * TX); a.tiles_y = cdiv(a.Nr, 2 * TY);
+    const int chunk = (a.tiles_x * a.tiles_y + 7) / 8;
+    for (int bz = 0; bz < batch; bz++)
+        for (int b = 0; b < 8 * chunk; b++) {
+            int bx, by;
+            if (!xcd_tile(b, a.tiles_x, a.tiles_y, bx, by)) continue;
+            dwt2_inv_fast_tile<HLEN, TX, TY, NT>(a, bx, by, bz, smem.data());
+        }
+}
+
+EMU_API int emu_dwt2_fwd_fast(const float* in, int batch, int Nr, int Nc, const float* lo, const float* hi, int hlen,
+                              int tile, float* A, float* H, float* V, float* D) {
+    if ((hlen & 1) || (Nc & 3)) return -2;
+    Fwd2DFastArgs a;
+    a.in = in; a.A = A; a.H = H; a.V = V; a.D = D;
+    a.Nr = Nr; a.Nc = Nc; a.Nr2 = (Nr + 1) / 2; a.Nc2 = Nc / 2;
+    a.in_bstride = (long long)Nr * Nc; a.out_bstride = (long long)a.Nr2 * a.Nc2;
+    set_bank_i(a.fb, lo, hi, hlen);
+    switch (hlen) {
+#define X(h) case h: if (tile == 0) run_fwd2d_fast<h, 64, 16, 256>(a, batch); else if (tile == 1) run_fwd2d_fast<h, 64, 32, 512>(a, batch); else run_fwd2d_fast<h, 64, 32, 256>(a, batch); return 0;
+        EMU_EVEN_HLENS(X)
+#undef X
+    }
+    return -1;
+}
+
+EMU_API int emu_dwt2_inv_fast(const float* A, const float* H, const float* V, const float* D, int batch, int Nrc,
+                              int Ncc, int Nr, int Nc, const float* lo, const float* hi, int hlen, int tile, float* out) {
+    if ((hlen & 1) || (Ncc & 3) || Nc != 2 * Ncc) return -2;
+    Inv2DFastArgs a;
+    a.A = A; a.H = H; a.V = V; a.D = D; a.out = out;
+    a.Nrc = Nrc; a.Ncc = Ncc; a.Nr = Nr; a.Nc = Nc;
+    a.in_bstride = (long long)Nrc * Ncc; a.out_bstride = (long long)Nr * Nc;
+    set_bank_i(a.fb, lo, hi, hlen);
+    switch (hlen) {
+#define X(h) case h: if (tile == 0) run_inv2d_fast<h, 64, 16, 256>(a, batch); else if (tile == 1) run_inv2d_fast<h, 64, 8, 256>(a, batch); else run_inv2d_fast<h, 64, 32, 512>(a, batch); return 0;
+        EMU_EVEN_HLENS(X)
+#undef X
+    }
+    return -1;
 }

@@ -166,3 +166,47 @@ def test_emu_swt_direct_passes(wname):
             fs(P(x), P(y), shape[0], shape[1], P(rlo), P(rhi), hlen, level, P(r0))
             lib().emu_swt_pass(1, P(x), P(y), shape[0], shape[1], level, along_y, P(rlo), P(rhi), hlen, P(o0), None)
             assert np.abs(o0 - r0).max() <= _tol(r0)
+
+
+# ----------------------------------------------------------------------------- tuned 2D tiles
+FAST_SHAPES = [(64, 64), (61, 72), (32, 136), (129, 8), (6, 12), (2, 4), (200, 260)]
+
+
+@pytest.mark.parametrize("wname", WNAMES + ["db5", "db6", "db7", "sym20"])
+def test_emu_dwt2_fast_tiles(wname):
+    hlen, dlo, dhi, rlo, rhi = oracle.filters(wname)
+    for si, shape in enumerate(FAST_SHAPES):
+        x = oracle.hash_input(shape, 3300 + si)
+        ref = oracle.forward(x, wname, 1, ndim=2)
+        r2, c2 = (shape[0] + 1) // 2, shape[1] // 2
+        for tile in (0, 1, 2):
+            outs = [np.full((r2, c2), np.nan, dtype=np.float32) for _ in range(4)]
+            rc = lib().emu_dwt2_fwd_fast(P(x), 1, shape[0], shape[1], P(dlo), P(dhi), hlen, tile, *[P(o) for o in outs])
+            assert rc == 0
+            for got, want in zip(outs, ref):
+                assert np.isfinite(got).all()
+                assert np.abs(got - want).max() <= _tol(want), (wname, shape, tile)
+        if c2 % 4 == 0 and shape[0] % 2 == 0 or c2 % 4 == 0:
+            bands = [oracle.hash_input((r2, c2), 3900 + 7 * si + b, 2.0) - 1.0 for b in range(4)]
+            refi = oracle.inverse(bands, shape, wname, 1, ndim=2)
+            for tile in (0, 1, 2):
+                out = np.full(shape, np.nan, dtype=np.float32)
+                rc = lib().emu_dwt2_inv_fast(*[P(b) for b in bands], 1, r2, c2, shape[0], shape[1], P(rlo), P(rhi),
+                                             hlen, tile, P(out))
+                assert rc == 0
+                assert np.isfinite(out).all()
+                assert np.abs(out - refi).max() <= _tol(refi), (wname, shape, tile)
+
+
+def test_emu_dwt2_fast_batch():
+    hlen, dlo, dhi, rlo, rhi = oracle.filters("db4")
+    B, shape = 2, (48, 136)
+    x = oracle.hash_input((B,) + shape, 78)
+    outs = [np.zeros((B, 24, 68), dtype=np.float32) for _ in range(4)]
+    assert lib().emu_dwt2_fwd_fast(P(x), B, shape[0], shape[1], P(dlo), P(dhi), hlen, 0, *[P(o) for o in outs]) == 0
+    for b in range(B):
+        for got, want in zip(outs, oracle.forward(x[b], "db4", 1, ndim=2)):
+            assert np.abs(got[b] - want).max() <= _tol(want)
+    rec = np.zeros((B,) + shape, dtype=np.float32)
+    assert lib().emu_dwt2_inv_fast(*[P(o) for o in outs], B, 24, 68, shape[0], shape[1], P(rlo), P(rhi), hlen, 0, P(rec)) == 0
+    assert np.abs(rec - x).max() < 1e-3

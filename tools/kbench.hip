@@ -11,6 +11,7 @@
 #include <string>
 #include <vector>
 
+#include "dwt2_fast_kernels.hpp"
 #include "dwt2_kernels.hpp"
 
 using namespace pdwt;
@@ -101,6 +102,49 @@ static void bench_inv(const char* tag, const float* in4, float* out, int N, int 
     printf("%-34s N=%d B=%d lds=%6zu  %8.2f us  %7.1f GB/s (algorithmic)\n", tag, N, batch, lds, us, bytes / us / 1e3);
 }
 
+template <int HLEN, int TX, int TY, int NT>
+static void bench_fwd_fast(const char* tag, const float* in, float* out4, int N, int batch) {
+    Fwd2DFastArgs a;
+    a.in = in;
+    const long long q = (long long)batch * (N / 2) * (N / 2);
+    a.A = out4; a.H = out4 + q; a.V = out4 + 2 * q; a.D = out4 + 3 * q;
+    a.Nr = N; a.Nc = N; a.Nr2 = N / 2; a.Nc2 = N / 2;
+    a.in_bstride = (long long)N * N; a.out_bstride = (long long)(N / 2) * (N / 2);
+    a.tiles_x = (N / 2 + TX - 1) / TX; a.tiles_y = (N / 2 + TY - 1) / TY;
+    memset(&a.fb, 0, sizeof(a.fb));
+    for (int i = 0; i < 8; i++) { a.fb.t[i].x = DB4_LO[i]; a.fb.t[i].y = DB4_HI[i]; }
+    const size_t lds = (size_t)fwd2d_fast_lds_floats<HLEN, TX, TY>() * sizeof(float);
+    if (lds > 64 * 1024)
+        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(dwt2_fwd_fast_kernel<HLEN, TX, TY, NT>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    const int chunk = (a.tiles_x * a.tiles_y + 7) / 8;
+    dim3 grid(8 * chunk, batch);
+    float us = time_it([&] { hipLaunchKernelGGL((dwt2_fwd_fast_kernel<HLEN, TX, TY, NT>), grid, dim3(NT), lds, 0, a); });
+    const double bytes = 8.0 * batch * N * N;
+    printf("%-34s N=%d B=%d lds=%6zu  %8.2f us  %7.1f GB/s (algorithmic)\n", tag, N, batch, lds, us, bytes / us / 1e3);
+}
+
+template <int HLEN, int TX, int TY, int NT>
+static void bench_inv_fast(const char* tag, const float* in4, float* out, int N, int batch) {
+    Inv2DFastArgs a;
+    const long long q = (long long)batch * (N / 2) * (N / 2);
+    a.A = in4; a.H = in4 + q; a.V = in4 + 2 * q; a.D = in4 + 3 * q; a.out = out;
+    a.Nrc = N / 2; a.Ncc = N / 2; a.Nr = N; a.Nc = N;
+    a.in_bstride = (long long)(N / 2) * (N / 2); a.out_bstride = (long long)N * N;
+    a.tiles_x = (N + 2 * TX - 1) / (2 * TX); a.tiles_y = (N + 2 * TY - 1) / (2 * TY);
+    memset(&a.fb, 0, sizeof(a.fb));
+    for (int i = 0; i < 8; i++) { a.fb.t[i].x = DB4_LO[7 - i]; a.fb.t[i].y = DB4_HI[7 - i]; }
+    const size_t lds = (size_t)inv2d_fast_lds_floats<HLEN, TX, TY>() * sizeof(float);
+    if (lds > 64 * 1024)
+        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(dwt2_inv_fast_kernel<HLEN, TX, TY, NT>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    const int chunk = (a.tiles_x * a.tiles_y + 7) / 8;
+    dim3 grid(8 * chunk, batch);
+    float us = time_it([&] { hipLaunchKernelGGL((dwt2_inv_fast_kernel<HLEN, TX, TY, NT>), grid, dim3(NT), lds, 0, a); });
+    const double bytes = 8.0 * batch * N * N;
+    printf("%-34s N=%d B=%d lds=%6zu  %8.2f us  %7.1f GB/s (algorithmic)\n", tag, N, batch, lds, us, bytes / us / 1e3);
+}
+
 int main(int argc, char** argv) {
     const int N = argc > 1 ? atoi(argv[1]) : 4096;
     const int B = argc > 2 ? atoi(argv[2]) : 1;
@@ -129,6 +173,21 @@ int main(int argc, char** argv) {
         us = time_it([&] { hipLaunchKernelGGL(write4, dim3(2048), dim3(256), 0, 0, (float4*)b, n4); });
         printf("write4 grid= 2048                    %8.2f us  %7.1f GB/s (w)\n", us, 4.0 * n / us / 1e3);
     }
+    bench_fwd_fast<8, 64, 16, 256>("FAST fwd db4 TX64 TY16 NT256", a, b, N, B);
+    bench_fwd_fast<8, 64, 32, 256>("FAST fwd db4 TX64 TY32 NT256", a, b, N, B);
+    bench_fwd_fast<8, 64, 32, 512>("FAST fwd db4 TX64 TY32 NT512", a, b, N, B);
+    bench_fwd_fast<8, 64, 8, 256>("FAST fwd db4 TX64 TY8  NT256", a, b, N, B);
+    bench_fwd_fast<8, 64, 8, 128>("FAST fwd db4 TX64 TY8  NT128", a, b, N, B);
+    bench_fwd_fast<8, 128, 16, 512>("FAST fwd db4 TX128 TY16 NT512", a, b, N, B);
+    bench_fwd_fast<8, 32, 16, 128>("FAST fwd db4 TX32 TY16 NT128", a, b, N, B);
+    bench_fwd_fast<2, 64, 16, 256>("FAST fwd hlen2 TX64 TY16 NT256", a, b, N, B);
+    bench_inv_fast<8, 64, 16, 256>("FAST inv db4 TX64 TY16 NT256", b, a, N, B);
+    bench_inv_fast<8, 64, 8, 256>("FAST inv db4 TX64 TY8  NT256", b, a, N, B);
+    bench_inv_fast<8, 64, 32, 256>("FAST inv db4 TX64 TY32 NT256", b, a, N, B);
+    bench_inv_fast<8, 64, 32, 512>("FAST inv db4 TX64 TY32 NT512", b, a, N, B);
+    bench_inv_fast<8, 128, 16, 512>("FAST inv db4 TX128 TY16 NT512", b, a, N, B);
+    bench_inv_fast<8, 32, 16, 128>("FAST inv db4 TX32 TY16 NT128", b, a, N, B);
+    bench_inv_fast<2, 64, 16, 256>("FAST inv hlen2 TX64 TY16 NT256", b, a, N, B);
     bench_fwd<8, 64, 16, 256>("fwd db4 TX64 TY16 NT256", a, b, N, B);
     bench_fwd<8, 64, 32, 256>("fwd db4 TX64 TY32 NT256", a, b, N, B);
     bench_fwd<8, 64, 8, 256>("fwd db4 TX64 TY8  NT256", a, b, N, B);
