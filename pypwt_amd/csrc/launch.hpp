@@ -28,6 +28,10 @@ hipError_t launch_swt2_inv(const Swt2DArgs& a, int batch, hipStream_t s);
 hipError_t launch_swt_pass_fwd(const SwtPassArgs& a, hipStream_t s);
 hipError_t launch_swt_pass_inv(const SwtPassArgs& a, hipStream_t s);
 
+struct NonsepArgs;
+hipError_t launch_nonsep_fwd(const NonsepArgs& a, int batch, hipStream_t s);
+hipError_t launch_nonsep_inv(const NonsepArgs& a, int batch, hipStream_t s);
+
 // streaming operators over a 16-B aligned range of n floats (n % 4 == 0)
 hipError_t launch_ew(int op, float* p, long long n, float b, hipStream_t s);
 hipError_t launch_group_soft(float* d0, float* d1, float* d2, float* ap, long long n, float beta, int nb,

@@ -14,6 +14,7 @@
 #include <strings.h>
 
 #include "launch.hpp"
+#include "nonsep_kernels.hpp"
 #include "wavelet_table.hpp"
 
 using namespace pdwt;
@@ -296,7 +297,17 @@ int forward_impl(pdwt_plan* p) {
             float* H = p->band(3 * (l - 1) + 1);
             float* V = p->band(3 * (l - 1) + 2);
             float* D = p->band(3 * (l - 1) + 3);
-            if (!swt) {
+            if (!p->do_separable) {
+                NonsepArgs a;
+                a.in = src; a.A = dstA; a.H = H; a.V = V; a.D = D; a.out = nullptr;
+                a.filt = p->d_f2d;  // forward banks
+                a.Nr = p->lr[l - 1]; a.Nc = p->lc[l - 1]; a.Nrc = p->lr[l]; a.Ncc = p->lc[l];
+                a.f = 1 << (l - 1); a.do_swt = swt ? 1 : 0;
+                a.img_bstride = (long long)a.Nr * a.Nc; a.coef_bstride = (long long)a.Nrc * a.Ncc;
+                a.hlen = hlen;
+                Stamp st(p, "nonsep_fwd_level");
+                HIP_TRY(launch_nonsep_fwd(a, B, p->stream));
+            } else if (!swt) {
                 Fwd2DArgs a;
                 a.in = src; a.A = dstA; a.H = H; a.V = V; a.D = D;
                 a.Nr = p->lr[l - 1]; a.Nc = p->lc[l - 1]; a.Nr2 = p->lr[l]; a.Nc2 = p->lc[l];
@@ -378,7 +389,20 @@ int inverse_impl(pdwt_plan* p) {
             const float* H = p->band(3 * (l - 1) + 1);
             const float* V = p->band(3 * (l - 1) + 2);
             const float* D = p->band(3 * (l - 1) + 3);
-            if (!swt) {
+            if (!p->do_separable) {
+                NonsepArgs a;
+                a.in = nullptr;
+                a.A = const_cast<float*>(cur); a.H = const_cast<float*>(H);
+                a.V = const_cast<float*>(V); a.D = const_cast<float*>(D);
+                a.out = dst;
+                a.filt = p->d_f2d + (size_t)4 * hlen * hlen;  // inverse banks
+                a.Nr = p->lr[l - 1]; a.Nc = p->lc[l - 1]; a.Nrc = p->lr[l]; a.Ncc = p->lc[l];
+                a.f = 1 << (l - 1); a.do_swt = swt ? 1 : 0;
+                a.img_bstride = (long long)a.Nr * a.Nc; a.coef_bstride = (long long)a.Nrc * a.Ncc;
+                a.hlen = hlen;
+                Stamp st(p, "nonsep_inv_level");
+                HIP_TRY(launch_nonsep_inv(a, B, p->stream));
+            } else if (!swt) {
                 Inv2DArgs a;
                 a.A = cur; a.H = H; a.V = V; a.D = D; a.out = dst;
                 a.Nrc = p->lr[l]; a.Ncc = p->lc[l]; a.Nr = p->lr[l - 1]; a.Nc = p->lc[l - 1];
@@ -615,8 +639,6 @@ int pdwt_forward(pdwt_handle h) {  // Wavelets::forward, wt.cu:236-269
     if (h->state == PDWT_CREATION_ERROR)
         return fail(PDWT_ERR_STATE, "forward transform not computed, as there was an error when creating the wavelets");
     DeviceGuard guard(h->device);
-    if (!h->do_separable && h->info.ndims == 2 && h->f2d_custom)
-        return fail(PDWT_ERR_UNSUPPORTED, "custom non-separable filter banks: kernel not built yet");
     if (h->do_cycle_spinning) {  // wt.cu:242-246
         h->shift_r = rand() % h->info.Nr;
         h->shift_c = rand() % h->info.Nc;

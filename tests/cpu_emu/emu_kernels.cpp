@@ -9,6 +9,7 @@
 #include "../../pypwt_amd/csrc/dwt1_kernels.hpp"
 #include "../../pypwt_amd/csrc/dwt2_fast_kernels.hpp"
 #include "../../pypwt_amd/csrc/dwt2_kernels.hpp"
+#include "../../pypwt_amd/csrc/nonsep_kernels.hpp"
 #include "../../pypwt_amd/csrc/swt_kernels.hpp"
 
 using namespace pdwt;
@@ -236,4 +237,23 @@ EMU_API int emu_dwt2_inv_fast(const float* A, const float* H, const float* V, co
 #undef X
     }
     return -1;
+}
+
+// ------------------------------------------------------------------ non-separable
+// filt: 4 banks of hlen*hlen ; inverse != 0: A..D inputs, io output
+EMU_API int emu_nonsep(int inverse, float* io, int batch, int Nr, int Nc, int do_swt, int level, const float* filt,
+                       int hlen, float* A, float* H, float* V, float* D) {
+    NonsepArgs a;
+    a.in = io; a.out = io; a.A = A; a.H = H; a.V = V; a.D = D; a.filt = filt;
+    a.Nr = Nr; a.Nc = Nc; a.Nrc = do_swt ? Nr : (Nr + 1) / 2; a.Ncc = do_swt ? Nc : (Nc + 1) / 2;
+    a.f = 1 << (level - 1); a.do_swt = do_swt;
+    a.img_bstride = (long long)Nr * Nc; a.coef_bstride = (long long)a.Nrc * a.Ncc; a.hlen = hlen;
+    std::vector<float> smem(nonsep_lds_floats(hlen) + 16, -1.f);
+    const long long total = inverse ? (long long)Nr * Nc : (long long)a.Nrc * a.Ncc;
+    for (int bz = 0; bz < batch; bz++)
+        for (long long b = 0; b < (total + 255) / 256; b++) {
+            if (inverse) nonsep_inv_tile<256>(a, b, bz, smem.data());
+            else nonsep_fwd_tile<256>(a, b, bz, smem.data());
+        }
+    return 0;
 }

@@ -210,3 +210,36 @@ def test_emu_dwt2_fast_batch():
     rec = np.zeros((B,) + shape, dtype=np.float32)
     assert lib().emu_dwt2_inv_fast(*[P(o) for o in outs], B, 24, 68, shape[0], shape[1], P(rlo), P(rhi), hlen, 0, P(rec)) == 0
     assert np.abs(rec - x).max() < 1e-3
+
+
+# ----------------------------------------------------------------------------- non-separable tiles
+def _banks2d(lo, hi):
+    """(A,H,V,D) banks with the separable path's band naming: H = high along y, low along x."""
+    return np.concatenate([np.outer(lo, lo).ravel(), np.outer(hi, lo).ravel(), np.outer(lo, hi).ravel(),
+                           np.outer(hi, hi).ravel()]).astype(np.float32)
+
+
+@pytest.mark.parametrize("wname", ["haar", "db2", "db3", "sym4", "bior3.1"])
+def test_emu_nonsep_equals_separable(wname):
+    hlen, dlo, dhi, rlo, rhi = oracle.filters(wname)
+    fwd, inv = _banks2d(dlo, dhi), _banks2d(rlo, rhi)
+    for si, (shape, swt, level) in enumerate([((32, 40), 0, 1), ((31, 29), 0, 1), ((32, 32), 1, 1), ((32, 48), 1, 2)]):
+        x = oracle.hash_input(shape, 5100 + si)
+        r2, c2 = (shape if swt else ((shape[0] + 1) // 2, (shape[1] + 1) // 2))
+        outs = [np.full((r2, c2), np.nan, dtype=np.float32) for _ in range(4)]
+        assert lib().emu_nonsep(0, P(x.copy()), 1, shape[0], shape[1], swt, level, P(fwd), hlen, *[P(o) for o in outs]) == 0
+        # oracle: explicit non-separable restatement AND the separable path (identical for built-in banks)
+        n2 = hlen * hlen
+        ref_ns = oracle.nonsep_forward_level(x, fwd[:n2], fwd[n2:2 * n2], fwd[2 * n2:3 * n2], fwd[3 * n2:], hlen,
+                                             do_swt=swt, level=level)
+        for g, r in zip(outs, ref_ns):
+            assert np.abs(g - r).max() <= _tol(r) * 4, (wname, shape, swt)
+        if level == 1:
+            ref_sep = oracle.forward(x, wname, 1, ndim=2, do_swt=swt)
+            for g, r in zip(outs, ref_sep):
+                assert np.abs(g - r).max() <= 2e-5 * max(np.abs(r).max(), 1.0), (wname, shape, swt)
+            bands = [oracle.hash_input((r2, c2), 5200 + 4 * si + b, 2.0) - 1.0 for b in range(4)]
+            want = oracle.inverse(bands, shape, wname, 1, ndim=2, do_swt=swt)
+            out = np.full(shape, np.nan, dtype=np.float32)
+            assert lib().emu_nonsep(1, P(out), 1, shape[0], shape[1], swt, 1, P(inv), hlen, *[P(b) for b in bands]) == 0
+            assert np.abs(out - want).max() <= 2e-5 * max(np.abs(want).max(), 1.0), (wname, shape, swt)

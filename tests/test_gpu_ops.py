@@ -245,3 +245,34 @@ def test_nonseparable_flag_matches_separable(W):
             assert np.abs(g - r).max() <= 1e-5 * max(np.abs(r).max(), 1.0)
         w.inverse()
         assert np.abs(w.image - x).max() < 7e-4
+
+
+def test_custom_nonseparable_filter_bank(W):
+    """set_wavelets_filters on a non-separable plan with 2D banks (LL, LH, HL, HH): a genuinely
+    non-separable bank (random perturbation) against the oracle's non-separable restatement, and the
+    outer-product bank of db3 against the separable result."""
+    x = oracle.hash_input((48, 56), 14)
+    hlen, dlo, dhi, rlo, rhi = oracle.filters("db3")
+
+    def banks(lo, hi):
+        return [np.outer(lo, lo), np.outer(hi, lo), np.outer(lo, hi), np.outer(hi, hi)]  # A, H, V, D
+
+    f, i = banks(dlo, dhi), banks(rlo, rhi)
+    w = W(x, "db2", 1, do_separable=0)
+    w.set_wavelets_filters("db3-2d", f[0], f[3], i[0], i[3], LH=f[1], HL=f[2], i_LH=i[1], i_HL=i[2])
+    assert w.hlen == 6
+    w.forward()
+    for g, r in zip(flat_coeffs(w), oracle.forward(x, "db3", 1)):
+        assert np.abs(g - r).max() <= 2e-5 * max(np.abs(r).max(), 1.0)
+    w.inverse()
+    assert np.abs(w.image - x).max() < 2e-3
+    rng = np.random.RandomState(3)
+    g4 = [(b + 0.05 * rng.randn(*b.shape)).astype(np.float32) for b in f]
+    w = W(x, "db2", 1, do_separable=0)
+    w.set_wavelets_filters("rand-2d", g4[0], g4[3], i[0], i[3], LH=g4[1], HL=g4[2], i_LH=i[1], i_HL=i[2])
+    w.forward()
+    ref = oracle.nonsep_forward_level(x, g4[0].ravel(), g4[1].ravel(), g4[2].ravel(), g4[3].ravel(), 6)
+    for g, r in zip(flat_coeffs(w), ref):
+        assert np.abs(g - r).max() <= 2e-5 * max(np.abs(r).max(), 1.0)
+    with pytest.raises(ValueError):
+        w.set_wavelets_filters("missing", g4[0], g4[3], i[0], i[3])

@@ -194,16 +194,21 @@ def test_reference_suites_on_ascent(W):
 def test_iswt_linear_operator_golden(W):
     """Arbitrary coefficients -> inverse == pywt.iswt2 / iswt, via set_coeff."""
     z, meta = load_cases("iswt_cases.npz")
+    done = 0
     for m in meta:
         nd = 2 if m["kind"] == "iswt2" else 1
         shape = tuple(m["shape"])
         w = W(np.zeros(shape if nd == 2 else shape[1], dtype=np.float32), m["wname"], m["levels"], do_swt=1, ndim=nd)
+        if w.levels != m["levels"]:
+            continue  # the reference clamps levels to floor(log2(N/(hlen-1))) (wt.cu:155-165); pywt does not
+        done += 1
         w.forward()
         for b in range(m["nbands"]):
             w.set_coeff(z["%s_b%d" % (m["key"], b)], b)
         w.inverse()
         ref = z[m["key"] + "_rec"]
         assert rel_err(w.image, ref) < 1e-5, m
+    assert done >= 16
 
 
 def test_fill_hash_matches_oracle():
