@@ -103,6 +103,84 @@ constexpr int fwd2d_fast_lds_floats() {
     return (2 * TY + HLEN - 2) * (FwdFastGeom<HLEN, TX>::RXA + 2 * TX);
 }
 
+// row analysis of the staged tile: two adjacent outputs per thread, packed (L,H) accumulators
+template <int HLEN, int TX, int TY, int NT>
+PDWT_DEVICE void fwd_fast_row_pass(int tid, const float* sIn, v2f* tLH, const FilterBankI& fb) {
+    using G = FwdFastGeom<HLEN, TX>;
+    constexpr int PADL = G::PADL, RXA = G::RXA, NV = G::NV;
+    constexpr int RY = 2 * TY + HLEN - 2;
+    constexpr int HT = TX / 2;
+    const int t = tid % HT;
+    for (int r = tid / HT; r < RY; r += NT / HT) {
+        float v[NV];
+        const float* p4 = sIn + r * RXA + 4 * t;
+#pragma unroll
+        for (int q = 0; q < NV / 4; ++q) {
+            const v4f w = lds_read16(p4 + 4 * q);
+            v[4 * q + 0] = w.x;
+            v[4 * q + 1] = w.y;
+            v[4 * q + 2] = w.z;
+            v[4 * q + 3] = w.w;
+        }
+        v2f acc0 = mk2(0.f, 0.f), acc1 = mk2(0.f, 0.f);
+#pragma unroll
+        for (int j = 0; j < HLEN; ++j) {
+            const v2f tap = fb.t[HLEN - 1 - j];
+            acc0 = fma2(bc(v[PADL + j]), tap, acc0);
+            acc1 = fma2(bc(v[PADL + 2 + j]), tap, acc1);
+        }
+        f32x4 o;
+        o.x = acc0.x;
+        o.y = acc0.y;
+        o.z = acc1.x;
+        o.w = acc1.y;
+        *reinterpret_cast<f32x4*>(&tLH[r * TX + 2 * t]) = o;
+    }
+}
+
+// column analysis; (L,H) pair x tap -> (A,V) with lo, (H,D) with hi.  Each thread owns two adjacent
+// columns (one ds_read_b128 per staged row, 8-B stores).
+template <int HLEN, int TX, int TY, int NT>
+PDWT_DEVICE void fwd_fast_col_pass(int tid, const v2f* tLH, const Fwd2DFastArgs& a, int bx, int by, int bz) {
+    constexpr int HT = TX / 2;
+    constexpr int R = TY / (NT / HT);
+    const int t = tid % HT;
+    const int ty0 = (tid / HT) * R;
+    const int ox = bx * TX + 2 * t;
+    v2f accAV[R][2], accHD[R][2];
+#pragma unroll
+    for (int i = 0; i < R; ++i) accAV[i][0] = accAV[i][1] = accHD[i][0] = accHD[i][1] = mk2(0.f, 0.f);
+#pragma unroll
+    for (int r = 0; r < 2 * R + HLEN - 2; ++r) {
+        const v4f w = lds_read16(&tLH[(2 * ty0 + r) * TX + 2 * t]);
+        const v2f lh0 = mk2(w.x, w.y), lh1 = mk2(w.z, w.w);
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            const int j = r - 2 * i;
+            if (j >= 0 && j < HLEN) {
+                const v2f tap = a.fb.t[HLEN - 1 - j];
+                accAV[i][0] = fma2(lh0, bc(tap.x), accAV[i][0]);
+                accHD[i][0] = fma2(lh0, bc(tap.y), accHD[i][0]);
+                accAV[i][1] = fma2(lh1, bc(tap.x), accAV[i][1]);
+                accHD[i][1] = fma2(lh1, bc(tap.y), accHD[i][1]);
+            }
+        }
+    }
+    const long long boff = (long long)bz * a.out_bstride;
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        const int oy = by * TY + ty0 + i;
+        if (oy < a.Nr2 && ox < a.Nc2) {  // Nc2 is even: ox + 1 is inside too
+            const long long o = boff + (long long)oy * a.Nc2 + ox;
+            f32x2 v;
+            v.x = accAV[i][0].x; v.y = accAV[i][1].x; *reinterpret_cast<f32x2*>(a.A + o) = v;
+            v.x = accAV[i][0].y; v.y = accAV[i][1].y; *reinterpret_cast<f32x2*>(a.V + o) = v;
+            v.x = accHD[i][0].x; v.y = accHD[i][1].x; *reinterpret_cast<f32x2*>(a.H + o) = v;
+            v.x = accHD[i][0].y; v.y = accHD[i][1].y; *reinterpret_cast<f32x2*>(a.D + o) = v;
+        }
+    }
+}
+
 // Requirements (checked by the host): HLEN even, Nc % 4 == 0, 16-B aligned image rows.
 template <int HLEN, int TX, int TY, int NT>
 PDWT_DEVICE void dwt2_fwd_fast_tile(const Fwd2DFastArgs& a, int bx, int by, int bz, float* smem) {
@@ -137,75 +215,110 @@ PDWT_DEVICE void dwt2_fwd_fast_tile(const Fwd2DFastArgs& a, int bx, int by, int 
     }
     PDWT_SYNC();
 
-    // ---- phase 2: row analysis, two adjacent outputs per thread, packed (L,H) accumulators
-    PDWT_FOR_THREADS(tid, NT) {
-        const int t = tid % HT;
-        for (int r = tid / HT; r < RY; r += NT / HT) {
-            float v[NV];
-            const float* p4 = sIn + r * RXA + 4 * t;
-#pragma unroll
-            for (int q = 0; q < NV / 4; ++q) {
-                const v4f w = lds_read16(p4 + 4 * q);
-                v[4 * q + 0] = w.x;
-                v[4 * q + 1] = w.y;
-                v[4 * q + 2] = w.z;
-                v[4 * q + 3] = w.w;
-            }
-            v2f acc0 = mk2(0.f, 0.f), acc1 = mk2(0.f, 0.f);
-#pragma unroll
-            for (int j = 0; j < HLEN; ++j) {
-                const v2f tap = a.fb.t[HLEN - 1 - j];
-                acc0 = fma2(bc(v[PADL + j]), tap, acc0);
-                acc1 = fma2(bc(v[PADL + 2 + j]), tap, acc1);
-            }
-            f32x4 o;
-            o.x = acc0.x;
-            o.y = acc0.y;
-            o.z = acc1.x;
-            o.w = acc1.y;
-            *reinterpret_cast<f32x4*>(&tLH[r * TX + 2 * t]) = o;
-        }
-    }
+    // ---- phase 2: row analysis -> interleaved (L,H) pairs in LDS
+    PDWT_FOR_THREADS(tid, NT) { fwd_fast_row_pass<HLEN, TX, TY, NT>(tid, sIn, tLH, a.fb); }
     PDWT_SYNC();
 
-    // ---- phase 3: column analysis; (L,H) pair x tap -> (A,V) with lo, (H,D) with hi.
-    // Each thread owns two adjacent columns (one ds_read_b128 per staged row, 8-B stores).
-    PDWT_FOR_THREADS(tid, NT) {
-        const int t = tid % HT;
-        const int ty0 = (tid / HT) * R;
-        const int ox = bx * TX + 2 * t;
-        v2f accAV[R][2], accHD[R][2];
+    // ---- phase 3: column analysis -> A, H, V, D
+    PDWT_FOR_THREADS(tid, NT) { fwd_fast_col_pass<HLEN, TX, TY, NT>(tid, tLH, a, bx, by, bz); }
+}
+
+// Streaming variant: a workgroup walks over several tiles of its XCD's band and issues the 16-B
+// global loads of tile i+1 into registers BEFORE it computes tile i (row + column pass), so the
+// HBM/L2 latency of the next tile hides behind the arithmetic of the current one.  The one-tile
+// kernel above is latency-bound (occupancy x bytes in flight / latency ~ 4 TB/s of reads+writes,
+// profiles/r01b_*); this one keeps every resident workgroup's loads in flight all the time.
+// Position q of a workgroup's walk -> (image, tile).  One XCD's share of the work is the sequence
+// q = 0 .. batch*chunk-1 : image q / chunk, tile xcd*chunk + q % chunk of that image.  All workgroups
+// advance through the images TOGETHER, so at any time the chip streams through one image (a few
+// bands per XCD) rather than through `batch` of them at once (which measured 20 % slower on the
+// inverse: too many concurrent DRAM streams).
+PDWT_DEVICE bool stream_pos(int q, int xcd, int chunk, int total, int batch, int tiles_x, int& bx, int& by,
+                            int& bz) {
+    if (q >= batch * chunk) return false;
+    bz = q / chunk;
+    const int tile = xcd * chunk + (q - bz * chunk);
+    if (tile >= total) return false;
+    by = tile / tiles_x;
+    bx = tile - by * tiles_x;
+    return true;
+}
+
+template <int HLEN, int TX, int TY, int NT>
+PDWT_DEVICE void dwt2_fwd_fast_stream(const Fwd2DFastArgs& a, int wg, int nwg, int batch, float* smem) {
+    using G = FwdFastGeom<HLEN, TX>;
+    constexpr int C = G::C, PADL = G::PADL, RXA = G::RXA;
+    constexpr int RY = 2 * TY + HLEN - 2;
+    constexpr int V4 = RXA / 4;
+    constexpr int NLD = (RY * V4 + NT - 1) / NT;  // float4 loads per thread per tile
+
+    float* sIn = smem;
+    v2f* tLH = reinterpret_cast<v2f*>(smem + RY * RXA);
+
+    const int total = a.tiles_x * a.tiles_y;
+    const int chunk = (total + 7) >> 3;
+    const int xcd = wg & 7;       // ids b and b+8 share an XCD (speed only)
+    const int stride = nwg >> 3;  // workgroups per XCD
+    const int limit = batch * chunk;
+
+    PDWT_PER_THREAD(v4f, stage, NLD, NT);
+
+    int q = wg >> 3;
+    int bx = 0, by = 0, bz = 0;
+    while (q < limit && !stream_pos(q, xcd, chunk, total, batch, a.tiles_x, bx, by, bz)) q += stride;
+    bool have = q < limit;
+    if (have) {
+        PDWT_FOR_THREADS(tid, NT) {
+            const float* PDWT_RESTRICT in = a.in + (long long)bz * a.in_bstride;
+            const int xa = 2 * bx * TX - C - PADL, y0 = 2 * by * TY - C;
 #pragma unroll
-        for (int i = 0; i < R; ++i) accAV[i][0] = accAV[i][1] = accHD[i][0] = accHD[i][1] = mk2(0.f, 0.f);
+            for (int i = 0; i < NLD; ++i) {
+                // lanes past the end of the tile reload its last group (branch-free: the staging
+                // registers must stay in VGPRs; a divergent conditional load sends them to scratch)
+                const int idx = (tid + i * NT < RY * V4) ? tid + i * NT : RY * V4 - 1;
+                const int r = idx / V4, g = idx - r * V4;
+                const int sy = wrap_analysis(y0 + r, a.Nr);
+                const int sx = wrap_periodic(xa + 4 * g, a.Nc);
+                PDWT_MINE(stage, tid)[i] = *reinterpret_cast<const v4f*>(in + (long long)sy * a.Nc + sx);
+            }
+        }
+    }
+    while (have) {
+        PDWT_FOR_THREADS(tid, NT) {
 #pragma unroll
-        for (int r = 0; r < 2 * R + HLEN - 2; ++r) {
-            const v4f w = lds_read16(&tLH[(2 * ty0 + r) * TX + 2 * t]);
-            const v2f lh0 = mk2(w.x, w.y), lh1 = mk2(w.z, w.w);
+            for (int i = 0; i < NLD; ++i) {
+                const int idx = tid + i * NT;
+                if (idx < RY * V4) *reinterpret_cast<v4f*>(sIn + 4 * idx) = PDWT_MINE(stage, tid)[i];
+            }
+        }
+        PDWT_SYNC();
+        // prefetch the next tile of this workgroup
+        int qn = q + stride;
+        int nbx = 0, nby = 0, nbz = 0;
+        while (qn < limit && !stream_pos(qn, xcd, chunk, total, batch, a.tiles_x, nbx, nby, nbz)) qn += stride;
+        const bool have_next = qn < limit;
+        if (have_next) {
+            PDWT_FOR_THREADS(tid, NT) {
+                const float* PDWT_RESTRICT in = a.in + (long long)nbz * a.in_bstride;
+                const int xa = 2 * nbx * TX - C - PADL, y0 = 2 * nby * TY - C;
 #pragma unroll
-            for (int i = 0; i < R; ++i) {
-                const int j = r - 2 * i;
-                if (j >= 0 && j < HLEN) {
-                    const v2f tap = a.fb.t[HLEN - 1 - j];
-                    accAV[i][0] = fma2(lh0, bc(tap.x), accAV[i][0]);
-                    accHD[i][0] = fma2(lh0, bc(tap.y), accHD[i][0]);
-                    accAV[i][1] = fma2(lh1, bc(tap.x), accAV[i][1]);
-                    accHD[i][1] = fma2(lh1, bc(tap.y), accHD[i][1]);
+                for (int i = 0; i < NLD; ++i) {
+                    const int idx = (tid + i * NT < RY * V4) ? tid + i * NT : RY * V4 - 1;
+                    const int r = idx / V4, g = idx - r * V4;
+                    const int sy = wrap_analysis(y0 + r, a.Nr);
+                    const int sx = wrap_periodic(xa + 4 * g, a.Nc);
+                    PDWT_MINE(stage, tid)[i] = *reinterpret_cast<const v4f*>(in + (long long)sy * a.Nc + sx);
                 }
             }
         }
-        const long long boff = (long long)bz * a.out_bstride;
-#pragma unroll
-        for (int i = 0; i < R; ++i) {
-            const int oy = by * TY + ty0 + i;
-            if (oy < a.Nr2 && ox < a.Nc2) {  // Nc2 is even: ox + 1 is inside too
-                const long long o = boff + (long long)oy * a.Nc2 + ox;
-                f32x2 v;
-                v.x = accAV[i][0].x; v.y = accAV[i][1].x; *reinterpret_cast<f32x2*>(a.A + o) = v;
-                v.x = accAV[i][0].y; v.y = accAV[i][1].y; *reinterpret_cast<f32x2*>(a.V + o) = v;
-                v.x = accHD[i][0].x; v.y = accHD[i][1].x; *reinterpret_cast<f32x2*>(a.H + o) = v;
-                v.x = accHD[i][0].y; v.y = accHD[i][1].y; *reinterpret_cast<f32x2*>(a.D + o) = v;
-            }
-        }
+        PDWT_FOR_THREADS(tid, NT) { fwd_fast_row_pass<HLEN, TX, TY, NT>(tid, sIn, tLH, a.fb); }
+        PDWT_SYNC();
+        PDWT_FOR_THREADS(tid, NT) { fwd_fast_col_pass<HLEN, TX, TY, NT>(tid, tLH, a, bx, by, bz); }
+        bx = nbx;
+        by = nby;
+        bz = nbz;
+        q = qn;
+        have = have_next;
     }
 }
 
@@ -227,19 +340,121 @@ constexpr int inv2d_fast_lds_floats() {
     return 4 * (TY + G::H2 + 1) * G::CXA + 2 * (2 * TY) * G::CXA;
 }
 
-// Requirements: HLEN even, Ncc % 4 == 0 (so Nc = 2*Ncc or 2*Ncc-1 ... the host requires Nc == 2*Ncc),
-// 16-B aligned coefficient rows.
+// column synthesis.  Work item = (m, column pair): the two output rows p = 2m, 2m+1 (p = gy + S)
+// share the coefficient rows m .. m+H2-1 (local); even taps feed p odd, odd taps feed p even.
+template <int HLEN, int TX, int TY, int NT>
+PDWT_DEVICE void inv_fast_col_pass(int tid, const v2f* sAV, const v2f* sHD, v2f* tt, const FilterBankI& fb) {
+    using G = InvFastGeom<HLEN, TX>;
+    constexpr int H2 = G::H2, S = G::S, CXA = G::CXA;
+    constexpr int OY = 2 * TY;
+    constexpr int NM = TY + S;  // m = 0 .. TY-1+S
+    constexpr int Q2 = CXA / 2;
+    for (int idx = tid; idx < NM * Q2; idx += NT) {
+        const int m = idx / Q2;
+        const int q = 2 * (idx - m * Q2);
+        v2f e0 = mk2(0.f, 0.f), o0 = e0, e1 = e0, o1 = e0;  // p even / p odd, columns q / q+1
+#pragma unroll
+        for (int j = 0; j < H2; ++j) {
+            const v4f wav = lds_read16(&sAV[(m + j) * CXA + q]);
+            const v4f whd = lds_read16(&sHD[(m + j) * CXA + q]);
+            const v2f te = fb.t[HLEN - 2 - 2 * j];  // p even: par = 1
+            const v2f to = fb.t[HLEN - 1 - 2 * j];  // p odd : par = 0
+            const v2f av0 = mk2(wav.x, wav.y), av1 = mk2(wav.z, wav.w);
+            const v2f hd0 = mk2(whd.x, whd.y), hd1 = mk2(whd.z, whd.w);
+            e0 = fma2(av0, bc(te.x), e0); e0 = fma2(hd0, bc(te.y), e0);
+            o0 = fma2(av0, bc(to.x), o0); o0 = fma2(hd0, bc(to.y), o0);
+            e1 = fma2(av1, bc(te.x), e1); e1 = fma2(hd1, bc(te.y), e1);
+            o1 = fma2(av1, bc(to.x), o1); o1 = fma2(hd1, bc(to.y), o1);
+        }
+        const int ge = 2 * m - S, go = 2 * m + 1 - S;  // local output rows
+        f32x4 w;
+        if (ge >= 0 && ge < OY) {
+            w.x = e0.x; w.y = e0.y; w.z = e1.x; w.w = e1.y;
+            *reinterpret_cast<f32x4*>(&tt[ge * CXA + q]) = w;
+        }
+        if (go >= 0 && go < OY) {
+            w.x = o0.x; w.y = o0.y; w.z = o1.x; w.w = o1.y;
+            *reinterpret_cast<f32x4*>(&tt[go * CXA + q]) = w;
+        }
+    }
+}
+
+// row synthesis, four adjacent samples per thread, 16-B stores
+template <int HLEN, int TX, int TY, int NT>
+PDWT_DEVICE void inv_fast_row_pass(int tid, const v2f* tt, const Inv2DFastArgs& a, int bx, int by, int bz) {
+    using G = InvFastGeom<HLEN, TX>;
+    constexpr int H2 = G::H2, S = G::S, PADL = G::PADL, CXA = G::CXA;
+    constexpr int OY = 2 * TY;
+    constexpr int HT = TX / 2;
+    constexpr int PE = PADL & 1;                // read origin rounded down to an even pair index
+    constexpr int NP = (PE + H2 + 2 + 1) & ~1;  // (t1,t2) pairs read per thread
+    float* PDWT_RESTRICT out = a.out + (long long)bz * a.out_bstride;
+    for (int idx = tid; idx < OY * HT; idx += NT) {
+        const int gy = idx / HT;
+        const int k = 2 * (idx - gy * HT);
+        v2f u[NP];
+        const v2f* base = tt + gy * CXA + (PADL - PE) + k;
+#pragma unroll
+        for (int q = 0; q < NP / 2; ++q) {
+            const v4f w = lds_read16(base + 2 * q);
+            u[2 * q] = mk2(w.x, w.y);
+            u[2 * q + 1] = mk2(w.z, w.w);
+        }
+        float res[4];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {  // coefficient column k + kk -> samples 2(k+kk), 2(k+kk)+1
+            v2f r0 = mk2(0.f, 0.f), r1 = mk2(0.f, 0.f);
+            if (S == 0) {
+#pragma unroll
+                for (int j = 0; j < H2; ++j) {
+                    const v2f w = u[PE + kk + j];
+                    r0 = fma2(w, a.fb.t[HLEN - 2 - 2 * j], r0);  // p even
+                    r1 = fma2(w, a.fb.t[HLEN - 1 - 2 * j], r1);  // p odd
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < H2 + 1; ++j) {
+                    const v2f w = u[PE + kk + j];
+                    if (j < H2) r0 = fma2(w, a.fb.t[HLEN - 1 - 2 * j], r0);        // p = 2k+1 (odd), base k
+                    if (j >= 1) r1 = fma2(w, a.fb.t[HLEN - 2 - 2 * (j - 1)], r1);  // p = 2k+2 (even), base k+1
+                }
+            }
+            res[2 * kk] = r0.x + r0.y;
+            res[2 * kk + 1] = r1.x + r1.y;
+        }
+        const int oy = 2 * by * TY + gy;
+        const int ox = 2 * (bx * TX + k);
+        if (oy < a.Nr && ox < a.Nc) {  // Nc % 8 == 0 (Ncc % 4 == 0): the float4 is inside and aligned
+            f32x4 v;
+            v.x = res[0]; v.y = res[1]; v.z = res[2]; v.w = res[3];
+            *reinterpret_cast<f32x4*>(out + (long long)oy * a.Nc + ox) = v;
+        }
+    }
+}
+
+// interleave one float4 of A,V and of H,D into the (A,V) / (H,D) pair planes
+PDWT_DEVICE void inv_fast_interleave(v2f* sAV, v2f* sHD, int pair_index, const v4f& vA, const v4f& vV,
+                                     const v4f& vH, const v4f& vD) {
+    f32x4 w;
+    f32x4* dAV = reinterpret_cast<f32x4*>(sAV + pair_index);
+    f32x4* dHD = reinterpret_cast<f32x4*>(sHD + pair_index);
+    w.x = vA.x; w.y = vV.x; w.z = vA.y; w.w = vV.y; dAV[0] = w;
+    w.x = vA.z; w.y = vV.z; w.z = vA.w; w.w = vV.w; dAV[1] = w;
+    w.x = vH.x; w.y = vD.x; w.z = vH.y; w.w = vD.y; dHD[0] = w;
+    w.x = vH.z; w.y = vD.z; w.z = vH.w; w.w = vD.w; dHD[1] = w;
+}
+
+// Requirements: HLEN even, Ncc % 4 == 0, Nc == 2*Ncc, 16-B aligned coefficient rows.
 template <int HLEN, int TX, int TY, int NT>
 PDWT_DEVICE void dwt2_inv_fast_tile(const Inv2DFastArgs& a, int bx, int by, int bz, float* smem) {
     using G = InvFastGeom<HLEN, TX>;
-    constexpr int H2 = G::H2, C = G::C, S = G::S, PADL = G::PADL, CXA = G::CXA;
+    constexpr int H2 = G::H2, C = G::C, PADL = G::PADL, CXA = G::CXA;
     constexpr int CR = TY + H2 + 1;
     constexpr int V4 = CXA / 4;
-    constexpr int OY = 2 * TY;
 
     v2f* sAV = reinterpret_cast<v2f*>(smem);  // CR x CXA (A,V) pairs
     v2f* sHD = sAV + CR * CXA;                // CR x CXA (H,D) pairs
-    v2f* tt = sHD + CR * CXA;                 // OY x CXA (t1,t2) pairs
+    v2f* tt = sHD + CR * CXA;                 // 2TY x CXA (t1,t2) pairs
 
     const long long boff = (long long)bz * a.in_bstride;
     const int cy0 = by * TY - C;
@@ -253,104 +468,105 @@ PDWT_DEVICE void dwt2_inv_fast_tile(const Inv2DFastArgs& a, int bx, int by, int 
             const int sy = wrap_periodic(cy0 + r, a.Nrc);
             const int sx = wrap_periodic(cxa + 4 * g, a.Ncc);
             const long long o = boff + (long long)sy * a.Ncc + sx;
-            const f32x4 vA = *reinterpret_cast<const f32x4*>(a.A + o);
-            const f32x4 vV = *reinterpret_cast<const f32x4*>(a.V + o);
-            const f32x4 vH = *reinterpret_cast<const f32x4*>(a.H + o);
-            const f32x4 vD = *reinterpret_cast<const f32x4*>(a.D + o);
-            f32x4 w;
-            f32x4* dAV = reinterpret_cast<f32x4*>(sAV + r * CXA + 4 * g);
-            f32x4* dHD = reinterpret_cast<f32x4*>(sHD + r * CXA + 4 * g);
-            w.x = vA.x; w.y = vV.x; w.z = vA.y; w.w = vV.y; dAV[0] = w;
-            w.x = vA.z; w.y = vV.z; w.z = vA.w; w.w = vV.w; dAV[1] = w;
-            w.x = vH.x; w.y = vD.x; w.z = vH.y; w.w = vD.y; dHD[0] = w;
-            w.x = vH.z; w.y = vD.z; w.z = vH.w; w.w = vD.w; dHD[1] = w;
+            const v4f vA = *reinterpret_cast<const v4f*>(a.A + o);
+            const v4f vV = *reinterpret_cast<const v4f*>(a.V + o);
+            const v4f vH = *reinterpret_cast<const v4f*>(a.H + o);
+            const v4f vD = *reinterpret_cast<const v4f*>(a.D + o);
+            inv_fast_interleave(sAV, sHD, r * CXA + 4 * g, vA, vV, vH, vD);
         }
     }
     PDWT_SYNC();
+    PDWT_FOR_THREADS(tid, NT) { inv_fast_col_pass<HLEN, TX, TY, NT>(tid, sAV, sHD, tt, a.fb); }
+    PDWT_SYNC();
+    PDWT_FOR_THREADS(tid, NT) { inv_fast_row_pass<HLEN, TX, TY, NT>(tid, tt, a, bx, by, bz); }
+}
 
-    // ---- phase 2: column synthesis.  Work item = (m, column pair): the two output rows p = 2m, 2m+1
-    // (p = gy + S) share the coefficient rows m .. m+H2-1 (local); even taps feed p odd, odd taps p even.
-    PDWT_FOR_THREADS(tid, NT) {
-        constexpr int NM = TY + S;  // m = 0 .. TY-1+S
-        constexpr int Q2 = CXA / 2;
-        for (int idx = tid; idx < NM * Q2; idx += NT) {
-            const int m = idx / Q2;
-            const int q = 2 * (idx - m * Q2);
-            v2f e0 = mk2(0.f, 0.f), o0 = e0, e1 = e0, o1 = e0;  // p even / p odd, columns q / q+1
+// Streaming variant (see dwt2_fwd_fast_stream): the four coefficient float4 of the NEXT tile are in
+// flight while the current tile is synthesised.
+template <int HLEN, int TX, int TY, int NT>
+PDWT_DEVICE void dwt2_inv_fast_stream(const Inv2DFastArgs& a, int wg, int nwg, int batch, float* smem) {
+    using G = InvFastGeom<HLEN, TX>;
+    constexpr int H2 = G::H2, C = G::C, PADL = G::PADL, CXA = G::CXA;
+    constexpr int CR = TY + H2 + 1;
+    constexpr int V4 = CXA / 4;
+    constexpr int NLD = (CR * V4 + NT - 1) / NT;
+
+    v2f* sAV = reinterpret_cast<v2f*>(smem);
+    v2f* sHD = sAV + CR * CXA;
+    v2f* tt = sHD + CR * CXA;
+
+    const int total = a.tiles_x * a.tiles_y;
+    const int chunk = (total + 7) >> 3;
+    const int xcd = wg & 7;
+    const int stride = nwg >> 3;
+    const int limit = batch * chunk;
+
+    PDWT_PER_THREAD(v4f, stA, NLD, NT);
+    PDWT_PER_THREAD(v4f, stV, NLD, NT);
+    PDWT_PER_THREAD(v4f, stH, NLD, NT);
+    PDWT_PER_THREAD(v4f, stD, NLD, NT);
+
+    int q = wg >> 3;
+    int bx = 0, by = 0, bz = 0;
+    while (q < limit && !stream_pos(q, xcd, chunk, total, batch, a.tiles_x, bx, by, bz)) q += stride;
+    bool have = q < limit;
+    if (have) {
+        PDWT_FOR_THREADS(tid, NT) {
+            const long long boff = (long long)bz * a.in_bstride;
+            const int cy0 = by * TY - C, cxa = bx * TX - C - PADL;
 #pragma unroll
-            for (int j = 0; j < H2; ++j) {
-                const v4f wav = lds_read16(&sAV[(m + j) * CXA + q]);
-                const v4f whd = lds_read16(&sHD[(m + j) * CXA + q]);
-                const v2f te = a.fb.t[HLEN - 2 - 2 * j];  // p even: par = 1
-                const v2f to = a.fb.t[HLEN - 1 - 2 * j];  // p odd : par = 0
-                const v2f av0 = mk2(wav.x, wav.y), av1 = mk2(wav.z, wav.w);
-                const v2f hd0 = mk2(whd.x, whd.y), hd1 = mk2(whd.z, whd.w);
-                e0 = fma2(av0, bc(te.x), e0); e0 = fma2(hd0, bc(te.y), e0);
-                o0 = fma2(av0, bc(to.x), o0); o0 = fma2(hd0, bc(to.y), o0);
-                e1 = fma2(av1, bc(te.x), e1); e1 = fma2(hd1, bc(te.y), e1);
-                o1 = fma2(av1, bc(to.x), o1); o1 = fma2(hd1, bc(to.y), o1);
-            }
-            const int ge = 2 * m - S, go = 2 * m + 1 - S;  // local output rows
-            f32x4 w;
-            if (ge >= 0 && ge < OY) {
-                w.x = e0.x; w.y = e0.y; w.z = e1.x; w.w = e1.y;
-                *reinterpret_cast<f32x4*>(&tt[ge * CXA + q]) = w;
-            }
-            if (go >= 0 && go < OY) {
-                w.x = o0.x; w.y = o0.y; w.z = o1.x; w.w = o1.y;
-                *reinterpret_cast<f32x4*>(&tt[go * CXA + q]) = w;
+            for (int i = 0; i < NLD; ++i) {
+                const int idx = (tid + i * NT < CR * V4) ? tid + i * NT : CR * V4 - 1;
+                const int r = idx / V4, g = idx - r * V4;
+                const long long o = boff + (long long)wrap_periodic(cy0 + r, a.Nrc) * a.Ncc +
+                                    wrap_periodic(cxa + 4 * g, a.Ncc);
+                PDWT_MINE(stA, tid)[i] = *reinterpret_cast<const v4f*>(a.A + o);
+                PDWT_MINE(stV, tid)[i] = *reinterpret_cast<const v4f*>(a.V + o);
+                PDWT_MINE(stH, tid)[i] = *reinterpret_cast<const v4f*>(a.H + o);
+                PDWT_MINE(stD, tid)[i] = *reinterpret_cast<const v4f*>(a.D + o);
             }
         }
     }
-    PDWT_SYNC();
-
-    // ---- phase 3: row synthesis, four adjacent samples per thread, 16-B stores
-    PDWT_FOR_THREADS(tid, NT) {
-        float* PDWT_RESTRICT out = a.out + (long long)bz * a.out_bstride;
-        constexpr int HT = TX / 2;
-        constexpr int PE = PADL & 1;                    // read origin rounded down to an even pair index
-        constexpr int NP = (PE + H2 + 2 + 1) & ~1;      // (t1,t2) pairs read per thread
-        for (int idx = tid; idx < OY * HT; idx += NT) {
-            const int gy = idx / HT;
-            const int k = 2 * (idx - gy * HT);
-            v2f u[NP];
-            const v2f* base = tt + gy * CXA + (PADL - PE) + k;
+    while (have) {
+        PDWT_FOR_THREADS(tid, NT) {
 #pragma unroll
-            for (int q = 0; q < NP / 2; ++q) {
-                const v4f w = lds_read16(base + 2 * q);
-                u[2 * q] = mk2(w.x, w.y);
-                u[2 * q + 1] = mk2(w.z, w.w);
+            for (int i = 0; i < NLD; ++i) {
+                const int idx = tid + i * NT;
+                if (idx < CR * V4)
+                    inv_fast_interleave(sAV, sHD, 4 * idx, PDWT_MINE(stA, tid)[i], PDWT_MINE(stV, tid)[i],
+                                        PDWT_MINE(stH, tid)[i], PDWT_MINE(stD, tid)[i]);
             }
-            float res[4];
+        }
+        PDWT_SYNC();
+        int qn = q + stride;
+        int nbx = 0, nby = 0, nbz = 0;
+        while (qn < limit && !stream_pos(qn, xcd, chunk, total, batch, a.tiles_x, nbx, nby, nbz)) qn += stride;
+        const bool have_next = qn < limit;
+        if (have_next) {
+            PDWT_FOR_THREADS(tid, NT) {
+                const long long boff = (long long)nbz * a.in_bstride;
+                const int cy0 = nby * TY - C, cxa = nbx * TX - C - PADL;
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {  // coefficient column k + kk -> samples 2(k+kk), 2(k+kk)+1
-                v2f r0 = mk2(0.f, 0.f), r1 = mk2(0.f, 0.f);
-                if (S == 0) {
-#pragma unroll
-                    for (int j = 0; j < H2; ++j) {
-                        const v2f w = u[PE + kk + j];
-                        r0 = fma2(w, a.fb.t[HLEN - 2 - 2 * j], r0);  // p even
-                        r1 = fma2(w, a.fb.t[HLEN - 1 - 2 * j], r1);  // p odd
-                    }
-                } else {
-#pragma unroll
-                    for (int j = 0; j < H2 + 1; ++j) {
-                        const v2f w = u[PE + kk + j];
-                        if (j < H2) r0 = fma2(w, a.fb.t[HLEN - 1 - 2 * j], r0);        // p = 2k+1 (odd), base k
-                        if (j >= 1) r1 = fma2(w, a.fb.t[HLEN - 2 - 2 * (j - 1)], r1);  // p = 2k+2 (even), base k+1
-                    }
+                for (int i = 0; i < NLD; ++i) {
+                    const int idx = (tid + i * NT < CR * V4) ? tid + i * NT : CR * V4 - 1;
+                    const int r = idx / V4, g = idx - r * V4;
+                    const long long o = boff + (long long)wrap_periodic(cy0 + r, a.Nrc) * a.Ncc +
+                                        wrap_periodic(cxa + 4 * g, a.Ncc);
+                    PDWT_MINE(stA, tid)[i] = *reinterpret_cast<const v4f*>(a.A + o);
+                    PDWT_MINE(stV, tid)[i] = *reinterpret_cast<const v4f*>(a.V + o);
+                    PDWT_MINE(stH, tid)[i] = *reinterpret_cast<const v4f*>(a.H + o);
+                    PDWT_MINE(stD, tid)[i] = *reinterpret_cast<const v4f*>(a.D + o);
                 }
-                res[2 * kk] = r0.x + r0.y;
-                res[2 * kk + 1] = r1.x + r1.y;
-            }
-            const int oy = 2 * by * TY + gy;
-            const int ox = 2 * (bx * TX + k);
-            if (oy < a.Nr && ox < a.Nc) {  // Nc % 8 == 0 (Ncc % 4 == 0): the float4 is inside and aligned
-                f32x4 v;
-                v.x = res[0]; v.y = res[1]; v.z = res[2]; v.w = res[3];
-                *reinterpret_cast<f32x4*>(out + (long long)oy * a.Nc + ox) = v;
             }
         }
+        PDWT_FOR_THREADS(tid, NT) { inv_fast_col_pass<HLEN, TX, TY, NT>(tid, sAV, sHD, tt, a.fb); }
+        PDWT_SYNC();
+        PDWT_FOR_THREADS(tid, NT) { inv_fast_row_pass<HLEN, TX, TY, NT>(tid, tt, a, bx, by, bz); }
+        bx = nbx;
+        by = nby;
+        bz = nbz;
+        q = qn;
+        have = have_next;
     }
 }
 
@@ -361,6 +577,18 @@ __global__ void __launch_bounds__(NT) dwt2_fwd_fast_kernel(const Fwd2DFastArgs a
     int bx, by;
     if (!xcd_tile(blockIdx.x, a.tiles_x, a.tiles_y, bx, by)) return;
     dwt2_fwd_fast_tile<HLEN, TX, TY, NT>(a, bx, by, blockIdx.y, pdwt_smem);
+}
+
+template <int HLEN, int TX, int TY, int NT>
+__global__ void __launch_bounds__(NT) dwt2_fwd_fast_stream_kernel(const Fwd2DFastArgs a, int batch) {
+    extern __shared__ __attribute__((aligned(16))) float pdwt_smem[];
+    dwt2_fwd_fast_stream<HLEN, TX, TY, NT>(a, blockIdx.x, gridDim.x, batch, pdwt_smem);
+}
+
+template <int HLEN, int TX, int TY, int NT>
+__global__ void __launch_bounds__(NT) dwt2_inv_fast_stream_kernel(const Inv2DFastArgs a, int batch) {
+    extern __shared__ __attribute__((aligned(16))) float pdwt_smem[];
+    dwt2_inv_fast_stream<HLEN, TX, TY, NT>(a, blockIdx.x, gridDim.x, batch, pdwt_smem);
 }
 
 template <int HLEN, int TX, int TY, int NT>

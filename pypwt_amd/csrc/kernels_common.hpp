@@ -19,6 +19,9 @@
 #define PDWT_DEVICE inline
 #define PDWT_FOR_THREADS(tid, NT) for (int tid = 0; tid < (NT); ++tid)
 #define PDWT_SYNC() ((void)0)
+// registers that live across phases: one copy per emulated thread
+#define PDWT_PER_THREAD(type, name, count, NT) type name##_store[(NT)][(count)]
+#define PDWT_MINE(name, tid) name##_store[tid]
 #define PDWT_RESTRICT
 struct pdwt_float2 { float x, y; };
 struct pdwt_float4 { float x, y, z, w; };
@@ -31,6 +34,8 @@ static inline float pdwt_fma(float a, float b, float c) { return a * b + c; }
 // one trip: the executing thread
 #define PDWT_FOR_THREADS(tid, NT) for (int tid = threadIdx.x, pdwt_once_ = 1; pdwt_once_; pdwt_once_ = 0)
 #define PDWT_SYNC() __syncthreads()
+#define PDWT_PER_THREAD(type, name, count, NT) type name##_store[(count)]
+#define PDWT_MINE(name, tid) name##_store
 #define PDWT_RESTRICT __restrict__
 typedef float2 f32x2;
 typedef float4 f32x4;

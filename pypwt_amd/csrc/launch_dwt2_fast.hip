@@ -20,13 +20,28 @@ static void interleave(FilterBankI& o, const FilterBank& fb) {
     }
 }
 
+// Workgroups per image for the streaming kernels: as many as stay RESIDENT on the 256 CUs (LDS-limited,
+// at most 6 per CU: measured optimum, profiles/r01c_kbench_stream.txt), never more than
+// there are (image, tile) pairs; a multiple of 8 (one share per XCD).  Each workgroup then
+// walks over tiles/workgroups tiles and prefetches the next one while it computes.
+static int stream_workgroups(int tiles, int batch, size_t lds_bytes) {
+    int per_cu = (int)((160 * 1024) / (lds_bytes ? lds_bytes : 1));
+    if (per_cu > 6) per_cu = 6;
+    if (per_cu < 1) per_cu = 1;
+    int n = 256 * per_cu;
+    const long long work = (long long)((tiles + 7) / 8) * 8 * (batch > 0 ? batch : 1);
+    if (n > work) n = (int)work;
+    n = (n + 7) & ~7;
+    return n < 8 ? 8 : n;
+}
+
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 template <int HLEN, int TX, int TY, int NT>
 static hipError_t run_fwd_fast(const Fwd2DArgs& g, int batch, hipStream_t s) {
     static bool big[64] = {};
     constexpr size_t lds = (size_t)fwd2d_fast_lds_floats<HLEN, TX, TY>() * sizeof(float);
-    hipError_t e = allow_big_lds(dwt2_fwd_fast_kernel<HLEN, TX, TY, NT>, lds, big);
+    hipError_t e = allow_big_lds(dwt2_fwd_fast_stream_kernel<HLEN, TX, TY, NT>, lds, big);
     if (e != hipSuccess) return e;
     Fwd2DFastArgs a;
     a.in = g.in; a.A = g.A; a.H = g.H; a.V = g.V; a.D = g.D;
@@ -34,8 +49,8 @@ static hipError_t run_fwd_fast(const Fwd2DArgs& g, int batch, hipStream_t s) {
     a.in_bstride = g.in_bstride; a.out_bstride = g.out_bstride;
     a.tiles_x = cdiv(g.Nc2, TX); a.tiles_y = cdiv(g.Nr2, TY);
     interleave(a.fb, g.fb);
-    const int chunk = (a.tiles_x * a.tiles_y + 7) / 8;
-    hipLaunchKernelGGL((dwt2_fwd_fast_kernel<HLEN, TX, TY, NT>), dim3(8 * chunk, batch), dim3(NT), lds, s, a);
+    hipLaunchKernelGGL((dwt2_fwd_fast_stream_kernel<HLEN, TX, TY, NT>),
+                       dim3(stream_workgroups(a.tiles_x * a.tiles_y, batch, lds)), dim3(NT), lds, s, a, batch);
     return hipGetLastError();
 }
 
@@ -51,6 +66,10 @@ static hipError_t run_inv_fast(const Inv2DArgs& g, int batch, hipStream_t s) {
     a.in_bstride = g.in_bstride; a.out_bstride = g.out_bstride;
     a.tiles_x = cdiv(g.Nc, 2 * TX); a.tiles_y = cdiv(g.Nr, 2 * TY);
     interleave(a.fb, g.fb);
+    // One tile per workgroup.  The streaming (persistent + prefetch) form of this kernel,
+    // dwt2_inv_fast_stream, measured SLOWER (25.4 vs 23.5 us at 4096^2, 280 vs 220 us for a batch of 8;
+    // profiles/r01c_kbench_stream.txt): workgroups that start together stay in phase and alternate
+    // read bursts with write bursts, while hardware dispatch naturally staggers them.
     const int chunk = (a.tiles_x * a.tiles_y + 7) / 8;
     hipLaunchKernelGGL((dwt2_inv_fast_kernel<HLEN, TX, TY, NT>), dim3(8 * chunk, batch), dim3(NT), lds, s, a);
     return hipGetLastError();

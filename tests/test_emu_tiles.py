@@ -243,3 +243,53 @@ def test_emu_nonsep_equals_separable(wname):
             out = np.full(shape, np.nan, dtype=np.float32)
             assert lib().emu_nonsep(1, P(out), 1, shape[0], shape[1], swt, 1, P(inv), hlen, *[P(b) for b in bands]) == 0
             assert np.abs(out - want).max() <= 2e-5 * max(np.abs(want).max(), 1.0), (wname, shape, swt)
+
+
+@pytest.mark.parametrize("wname", ["haar", "db2", "db4", "sym8", "db20"])
+def test_emu_dwt2_fwd_stream(wname):
+    """Persistent/prefetching variant: any number of workgroups must cover every tile exactly once."""
+    hlen, dlo, dhi, rlo, rhi = oracle.filters(wname)
+    for si, shape in enumerate([(64, 64), (61, 72), (200, 260), (6, 12), (300, 136)]):
+        x = oracle.hash_input(shape, 6300 + si)
+        ref = oracle.forward(x, wname, 1, ndim=2)
+        r2, c2 = (shape[0] + 1) // 2, shape[1] // 2
+        for nwg in (8, 16, 24, 64, 1024):
+            outs = [np.full((r2, c2), np.nan, dtype=np.float32) for _ in range(4)]
+            assert lib().emu_dwt2_fwd_stream(P(x), 1, shape[0], shape[1], P(dlo), P(dhi), hlen, nwg,
+                                             *[P(o) for o in outs]) == 0
+            for got, want in zip(outs, ref):
+                assert np.isfinite(got).all(), (wname, shape, nwg)
+                assert np.abs(got - want).max() <= _tol(want), (wname, shape, nwg)
+
+
+@pytest.mark.parametrize("wname", ["haar", "db2", "db4", "sym8", "db20"])
+def test_emu_dwt2_inv_stream(wname):
+    hlen, dlo, dhi, rlo, rhi = oracle.filters(wname)
+    for si, shape in enumerate([(64, 64), (61, 72), (200, 264), (6, 8), (300, 136)]):
+        r2, c2 = (shape[0] + 1) // 2, shape[1] // 2
+        bands = [oracle.hash_input((r2, c2), 6900 + 7 * si + b, 2.0) - 1.0 for b in range(4)]
+        ref = oracle.inverse(bands, shape, wname, 1, ndim=2)
+        for nwg in (8, 16, 64, 1024):
+            out = np.full(shape, np.nan, dtype=np.float32)
+            assert lib().emu_dwt2_inv_stream(*[P(b) for b in bands], 1, r2, c2, shape[0], shape[1], P(rlo), P(rhi),
+                                             hlen, nwg, P(out)) == 0
+            assert np.isfinite(out).all(), (wname, shape, nwg)
+            assert np.abs(out - ref).max() <= _tol(ref), (wname, shape, nwg)
+
+
+def test_emu_dwt2_stream_batch():
+    """The streaming kernels walk over (image, tile) pairs: every image of a batch must come out right
+    for any workgroup count."""
+    hlen, dlo, dhi, rlo, rhi = oracle.filters("db4")
+    B, shape = 3, (48, 136)
+    x = oracle.hash_input((B,) + shape, 79)
+    for nwg in (8, 24, 40, 512):
+        outs = [np.full((B, 24, 68), np.nan, dtype=np.float32) for _ in range(4)]
+        assert lib().emu_dwt2_fwd_stream(P(x), B, shape[0], shape[1], P(dlo), P(dhi), hlen, nwg, *[P(o) for o in outs]) == 0
+        for b in range(B):
+            for got, want in zip(outs, oracle.forward(x[b], "db4", 1, ndim=2)):
+                assert np.abs(got[b] - want).max() <= _tol(want), (nwg, b)
+        rec = np.full((B,) + shape, np.nan, dtype=np.float32)
+        assert lib().emu_dwt2_inv_stream(*[P(o) for o in outs], B, 24, 68, shape[0], shape[1], P(rlo), P(rhi), hlen,
+                                         nwg, P(rec)) == 0
+        assert np.abs(rec - x).max() < 1e-3, nwg

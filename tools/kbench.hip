@@ -125,6 +125,48 @@ static void bench_fwd_fast(const char* tag, const float* in, float* out4, int N,
 }
 
 template <int HLEN, int TX, int TY, int NT>
+static void bench_fwd_stream(const char* tag, const float* in, float* out4, int N, int batch, int wg_per_cu) {
+    Fwd2DFastArgs a;
+    a.in = in;
+    const long long q = (long long)batch * (N / 2) * (N / 2);
+    a.A = out4; a.H = out4 + q; a.V = out4 + 2 * q; a.D = out4 + 3 * q;
+    a.Nr = N; a.Nc = N; a.Nr2 = N / 2; a.Nc2 = N / 2;
+    a.in_bstride = (long long)N * N; a.out_bstride = (long long)(N / 2) * (N / 2);
+    a.tiles_x = (N / 2 + TX - 1) / TX; a.tiles_y = (N / 2 + TY - 1) / TY;
+    memset(&a.fb, 0, sizeof(a.fb));
+    for (int i = 0; i < 8; i++) { a.fb.t[i].x = DB4_LO[i]; a.fb.t[i].y = DB4_HI[i]; }
+    const size_t lds = (size_t)fwd2d_fast_lds_floats<HLEN, TX, TY>() * sizeof(float);
+    const int chunk = (a.tiles_x * a.tiles_y + 7) / 8;
+    int nwg = 256 * wg_per_cu;
+    if (nwg > 8 * chunk * batch) nwg = 8 * chunk * batch;
+    nwg = (nwg + 7) & ~7;
+    dim3 grid(nwg);
+    float us = time_it([&] { hipLaunchKernelGGL((dwt2_fwd_fast_stream_kernel<HLEN, TX, TY, NT>), grid, dim3(NT), lds, 0, a, batch); });
+    const double bytes = 8.0 * batch * N * N;
+    printf("%-30s wg/cu=%d N=%d B=%d lds=%6zu  %8.2f us  %7.1f GB/s (algorithmic)\n", tag, wg_per_cu, N, batch, lds, us, bytes / us / 1e3);
+}
+
+template <int HLEN, int TX, int TY, int NT>
+static void bench_inv_stream(const char* tag, const float* in4, float* out, int N, int batch, int wg_per_cu) {
+    Inv2DFastArgs a;
+    const long long q = (long long)batch * (N / 2) * (N / 2);
+    a.A = in4; a.H = in4 + q; a.V = in4 + 2 * q; a.D = in4 + 3 * q; a.out = out;
+    a.Nrc = N / 2; a.Ncc = N / 2; a.Nr = N; a.Nc = N;
+    a.in_bstride = (long long)(N / 2) * (N / 2); a.out_bstride = (long long)N * N;
+    a.tiles_x = (N + 2 * TX - 1) / (2 * TX); a.tiles_y = (N + 2 * TY - 1) / (2 * TY);
+    memset(&a.fb, 0, sizeof(a.fb));
+    for (int i = 0; i < 8; i++) { a.fb.t[i].x = DB4_LO[7 - i]; a.fb.t[i].y = DB4_HI[7 - i]; }
+    const size_t lds = (size_t)inv2d_fast_lds_floats<HLEN, TX, TY>() * sizeof(float);
+    const int chunk = (a.tiles_x * a.tiles_y + 7) / 8;
+    int nwg = 256 * wg_per_cu;
+    if (nwg > 8 * chunk * batch) nwg = 8 * chunk * batch;
+    nwg = (nwg + 7) & ~7;
+    float us = time_it([&] { hipLaunchKernelGGL((dwt2_inv_fast_stream_kernel<HLEN, TX, TY, NT>), dim3(nwg), dim3(NT), lds, 0, a, batch); });
+    const double bytes = 8.0 * batch * N * N;
+    printf("%-30s wg/cu=%d N=%d B=%d lds=%6zu  %8.2f us  %7.1f GB/s (algorithmic)\n", tag, wg_per_cu, N, batch, lds, us, bytes / us / 1e3);
+}
+
+template <int HLEN, int TX, int TY, int NT>
 static void bench_inv_fast(const char* tag, const float* in4, float* out, int N, int batch) {
     Inv2DFastArgs a;
     const long long q = (long long)batch * (N / 2) * (N / 2);
@@ -173,6 +215,11 @@ int main(int argc, char** argv) {
         us = time_it([&] { hipLaunchKernelGGL(write4, dim3(2048), dim3(256), 0, 0, (float4*)b, n4); });
         printf("write4 grid= 2048                    %8.2f us  %7.1f GB/s (w)\n", us, 4.0 * n / us / 1e3);
     }
+    for (int w : {2, 4, 6, 8, 12}) bench_fwd_stream<8, 64, 8, 256>("STREAM fwd db4 TX64 TY8 NT256", a, b, N, B, w);
+    for (int w : {2, 4, 6, 8}) bench_fwd_stream<8, 64, 16, 256>("STREAM fwd db4 TX64 TY16 NT256", a, b, N, B, w);
+    for (int w : {2, 4, 8}) bench_fwd_stream<8, 64, 4, 128>("STREAM fwd db4 TX64 TY4 NT128", a, b, N, B, w);
+    for (int w : {4, 6, 8}) bench_inv_stream<8, 64, 8, 256>("STREAM inv db4 TX64 TY8 NT256", b, a, N, B, w);
+    for (int w : {2, 4}) bench_inv_stream<8, 64, 16, 256>("STREAM inv db4 TX64 TY16 NT256", b, a, N, B, w);
     bench_fwd_fast<8, 64, 16, 256>("FAST fwd db4 TX64 TY16 NT256", a, b, N, B);
     bench_fwd_fast<8, 64, 32, 256>("FAST fwd db4 TX64 TY32 NT256", a, b, N, B);
     bench_fwd_fast<8, 64, 32, 512>("FAST fwd db4 TX64 TY32 NT512", a, b, N, B);
