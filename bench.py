@@ -61,6 +61,10 @@ def kernel_algorithmic_bytes(name, occurrence, cfg, batch):
         lvl = L - occurrence
     else:
         lvl = None
+    if name in ("dwt1_fwd_fused", "dwt1_inv_fused"):
+        # all levels of one direction in one launch: input read once, every band written once.
+        # (a second fused launch only exists for > 6 levels and works on 1/64 of the samples)
+        return 8.0 * samples if occurrence == 0 else 0.0
     if name.startswith("dwt2"):
         return 8.0 * samples / (4 ** (lvl - 1))
     if name.startswith("dwt1"):

@@ -22,6 +22,7 @@ SOURCES = [
     "launch_dwt2.hip",
     "launch_dwt2_fast.hip",
     "launch_dwt1.hip",
+    "launch_dwt1_fused.hip",
     "launch_swt.hip",
     "launch_ops.hip",
     "launch_nonsep.hip",

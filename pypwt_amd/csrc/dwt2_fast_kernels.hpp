@@ -17,46 +17,9 @@
 #pragma once
 
 #include "kernels_common.hpp"
+#include "packed_math.hpp"
 
 namespace pdwt {
-
-#ifdef PDWT_CPU_EMU
-struct v2f {
-    float x, y;
-};
-static inline v2f mk2(float a, float b) { return v2f{a, b}; }
-static inline v2f fma2(v2f a, v2f b, v2f c) { return v2f{a.x * b.x + c.x, a.y * b.y + c.y}; }
-#else
-typedef float v2f __attribute__((ext_vector_type(2)));
-static __device__ __forceinline__ v2f mk2(float a, float b) {
-    v2f r;
-    r.x = a;
-    r.y = b;
-    return r;
-}
-static __device__ __forceinline__ v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
-#endif
-static PDWT_DEVICE v2f bc(float a) { return mk2(a, a); }
-
-// Reads 16 B from LDS as ONE ds_read_b128 (256 B/clk) even when only some components are used
-// afterwards; without the barrier hipcc narrows it to ds_read2_b32 / ds_read2_b64 pairs, which
-// run at half the LDS rate (MI355X_MICROARCH.md, LDS table).
-#ifdef PDWT_CPU_EMU
-typedef f32x4 v4f;
-static inline v4f lds_read16(const void* p) { return *reinterpret_cast<const v4f*>(p); }
-#else
-typedef float v4f __attribute__((ext_vector_type(4)));
-static __device__ __forceinline__ v4f lds_read16(const void* p) {
-    v4f w = *reinterpret_cast<const v4f*>(p);
-    asm volatile("" : "+v"(w));
-    return w;
-}
-#endif
-
-// taps interleaved as (lo[j], hi[j]) pairs
-struct FilterBankI {
-    v2f t[kMaxTaps];
-};
 
 struct Fwd2DFastArgs {
     const float* in;
@@ -228,6 +191,40 @@ PDWT_DEVICE void dwt2_fwd_fast_tile(const Fwd2DFastArgs& a, int bx, int by, int 
 // HBM/L2 latency of the next tile hides behind the arithmetic of the current one.  The one-tile
 // kernel above is latency-bound (occupancy x bytes in flight / latency ~ 4 TB/s of reads+writes,
 // profiles/r01b_*); this one keeps every resident workgroup's loads in flight all the time.
+// Issue the 16-B loads of one forward tile into the staging registers.  Interior tiles (no
+// periodic wrap in either direction: all but the border ring) skip the wrap arithmetic, which was
+// ~30 % of the kernel's vector instructions.
+template <int HLEN, int TX, int TY, int NT, int NLD>
+PDWT_DEVICE void fwd_fast_issue_loads(int tid, const Fwd2DFastArgs& a, int bx, int by, int bz, v4f* st) {
+    using G = FwdFastGeom<HLEN, TX>;
+    constexpr int C = G::C, PADL = G::PADL, RXA = G::RXA;
+    constexpr int RY = 2 * TY + HLEN - 2;
+    constexpr int V4 = RXA / 4;
+    const float* PDWT_RESTRICT in = a.in + (long long)bz * a.in_bstride;
+    const int xa = 2 * bx * TX - C - PADL, y0 = 2 * by * TY - C;
+    const bool interior = xa >= 0 && xa + RXA <= a.Nc && y0 >= 0 && y0 + RY <= a.Nr;
+    if (interior) {
+        const float* base = in + (long long)y0 * a.Nc + xa;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int idx = (tid + i * NT < RY * V4) ? tid + i * NT : RY * V4 - 1;
+            const int r = idx / V4, g = idx - r * V4;
+            st[i] = *reinterpret_cast<const v4f*>(base + (long long)r * a.Nc + 4 * g);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            // lanes past the end of the tile reload its last group (branch-free: the staging
+            // registers must stay in VGPRs; a divergent conditional load sends them to scratch)
+            const int idx = (tid + i * NT < RY * V4) ? tid + i * NT : RY * V4 - 1;
+            const int r = idx / V4, g = idx - r * V4;
+            const int sy = wrap_analysis(y0 + r, a.Nr);
+            const int sx = wrap_periodic(xa + 4 * g, a.Nc);  // Nc % 4 == 0: a group never straddles
+            st[i] = *reinterpret_cast<const v4f*>(in + (long long)sy * a.Nc + sx);
+        }
+    }
+}
+
 // Position q of a workgroup's walk -> (image, tile).  One XCD's share of the work is the sequence
 // q = 0 .. batch*chunk-1 : image q / chunk, tile xcd*chunk + q % chunk of that image.  All workgroups
 // advance through the images TOGETHER, so at any time the chip streams through one image (a few
@@ -269,18 +266,7 @@ PDWT_DEVICE void dwt2_fwd_fast_stream(const Fwd2DFastArgs& a, int wg, int nwg, i
     bool have = q < limit;
     if (have) {
         PDWT_FOR_THREADS(tid, NT) {
-            const float* PDWT_RESTRICT in = a.in + (long long)bz * a.in_bstride;
-            const int xa = 2 * bx * TX - C - PADL, y0 = 2 * by * TY - C;
-#pragma unroll
-            for (int i = 0; i < NLD; ++i) {
-                // lanes past the end of the tile reload its last group (branch-free: the staging
-                // registers must stay in VGPRs; a divergent conditional load sends them to scratch)
-                const int idx = (tid + i * NT < RY * V4) ? tid + i * NT : RY * V4 - 1;
-                const int r = idx / V4, g = idx - r * V4;
-                const int sy = wrap_analysis(y0 + r, a.Nr);
-                const int sx = wrap_periodic(xa + 4 * g, a.Nc);
-                PDWT_MINE(stage, tid)[i] = *reinterpret_cast<const v4f*>(in + (long long)sy * a.Nc + sx);
-            }
+            fwd_fast_issue_loads<HLEN, TX, TY, NT, NLD>(tid, a, bx, by, bz, PDWT_MINE(stage, tid));
         }
     }
     while (have) {
@@ -299,16 +285,7 @@ PDWT_DEVICE void dwt2_fwd_fast_stream(const Fwd2DFastArgs& a, int wg, int nwg, i
         const bool have_next = qn < limit;
         if (have_next) {
             PDWT_FOR_THREADS(tid, NT) {
-                const float* PDWT_RESTRICT in = a.in + (long long)nbz * a.in_bstride;
-                const int xa = 2 * nbx * TX - C - PADL, y0 = 2 * nby * TY - C;
-#pragma unroll
-                for (int i = 0; i < NLD; ++i) {
-                    const int idx = (tid + i * NT < RY * V4) ? tid + i * NT : RY * V4 - 1;
-                    const int r = idx / V4, g = idx - r * V4;
-                    const int sy = wrap_analysis(y0 + r, a.Nr);
-                    const int sx = wrap_periodic(xa + 4 * g, a.Nc);
-                    PDWT_MINE(stage, tid)[i] = *reinterpret_cast<const v4f*>(in + (long long)sy * a.Nc + sx);
-                }
+                fwd_fast_issue_loads<HLEN, TX, TY, NT, NLD>(tid, a, nbx, nby, nbz, PDWT_MINE(stage, tid));
             }
         }
         PDWT_FOR_THREADS(tid, NT) { fwd_fast_row_pass<HLEN, TX, TY, NT>(tid, sIn, tLH, a.fb); }
@@ -461,18 +438,29 @@ PDWT_DEVICE void dwt2_inv_fast_tile(const Inv2DFastArgs& a, int bx, int by, int 
     const int cxa = bx * TX - C - PADL;  // multiple of 4
 
     // ---- phase 1: stage the four coefficient tiles, interleaved as (A,V) and (H,D)
+    // interior tiles (all but the border ring) skip the periodic-wrap arithmetic (a uniform branch)
+    const bool interior = cxa >= 0 && cxa + CXA <= a.Ncc && cy0 >= 0 && cy0 + CR <= a.Nrc;
     PDWT_FOR_THREADS(tid, NT) {
-        for (int idx = tid; idx < CR * V4; idx += NT) {
-            const int r = idx / V4;
-            const int g = idx - r * V4;
-            const int sy = wrap_periodic(cy0 + r, a.Nrc);
-            const int sx = wrap_periodic(cxa + 4 * g, a.Ncc);
-            const long long o = boff + (long long)sy * a.Ncc + sx;
-            const v4f vA = *reinterpret_cast<const v4f*>(a.A + o);
-            const v4f vV = *reinterpret_cast<const v4f*>(a.V + o);
-            const v4f vH = *reinterpret_cast<const v4f*>(a.H + o);
-            const v4f vD = *reinterpret_cast<const v4f*>(a.D + o);
-            inv_fast_interleave(sAV, sHD, r * CXA + 4 * g, vA, vV, vH, vD);
+        if (interior) {
+            const long long o0 = boff + (long long)cy0 * a.Ncc + cxa;
+            for (int idx = tid; idx < CR * V4; idx += NT) {
+                const int r = idx / V4;
+                const int g = idx - r * V4;
+                const long long o = o0 + (long long)r * a.Ncc + 4 * g;
+                inv_fast_interleave(sAV, sHD, r * CXA + 4 * g, *reinterpret_cast<const v4f*>(a.A + o),
+                                    *reinterpret_cast<const v4f*>(a.V + o), *reinterpret_cast<const v4f*>(a.H + o),
+                                    *reinterpret_cast<const v4f*>(a.D + o));
+            }
+        } else {
+            for (int idx = tid; idx < CR * V4; idx += NT) {
+                const int r = idx / V4;
+                const int g = idx - r * V4;
+                const long long o = boff + (long long)wrap_periodic(cy0 + r, a.Nrc) * a.Ncc +
+                                    wrap_periodic(cxa + 4 * g, a.Ncc);
+                inv_fast_interleave(sAV, sHD, r * CXA + 4 * g, *reinterpret_cast<const v4f*>(a.A + o),
+                                    *reinterpret_cast<const v4f*>(a.V + o), *reinterpret_cast<const v4f*>(a.H + o),
+                                    *reinterpret_cast<const v4f*>(a.D + o));
+            }
         }
     }
     PDWT_SYNC();

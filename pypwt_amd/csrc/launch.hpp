@@ -22,6 +22,12 @@ hipError_t try_launch_dwt2_fwd_fast(const Fwd2DArgs& a, int batch, hipStream_t s
 hipError_t try_launch_dwt2_inv_fast(const Inv2DArgs& a, int batch, hipStream_t s);
 hipError_t launch_dwt1_fwd(const Fwd1DArgs& a, hipStream_t s);
 hipError_t launch_dwt1_inv(const Inv1DArgs& a, hipStream_t s);
+// K consecutive 1D levels in one launch (2^K must divide N0, even hlen); hipErrorNotSupported otherwise
+int dwt1_fused_max_levels(int hlen);
+hipError_t launch_dwt1_fwd_fused(const float* in, float* const* det, float* app, int rows, int N0, int K, int hlen,
+                                 const FilterBank& fb, hipStream_t s);
+hipError_t launch_dwt1_inv_fused(const float* app, const float* const* det, float* out, int rows, int N0, int K,
+                                 int hlen, const FilterBank& fb, hipStream_t s);
 // fused a-trous level; the host guarantees a.f divides a.Nr
 hipError_t launch_swt2_fwd(const Swt2DArgs& a, int batch, hipStream_t s);
 hipError_t launch_swt2_inv(const Swt2DArgs& a, int batch, hipStream_t s);

@@ -1,0 +1,79 @@
+// launch_dwt1_fused.hip -- launchers of the multi-level fused 1D DWT kernels (gfx950).
+#include "dwt1_fused_kernels.hpp"
+#include "launch.hpp"
+#include "launch_util.hpp"
+
+#include <cstdlib>
+
+namespace pdwt {
+
+static void interleave(FilterBankI& o, const FilterBank& fb) {
+    for (int i = 0; i < kMaxTaps; i++) {
+        o.t[i].x = fb.lo[i];
+        o.t[i].y = fb.hi[i];
+    }
+}
+
+// Largest number of levels one forward launch may fuse for this filter length so that the two
+// ping-pong LDS buffers of a TF = 64 workgroup stay within ~48 KB (>= 3 workgroups per CU).
+int dwt1_fused_max_levels(int hlen) {
+    int best = 1;
+    for (int k = 2; k <= kMaxFusedLevels; ++k)
+        if ((size_t)fwd1d_fused_lds_floats(64, hlen, k) * sizeof(float) <= 48 * 1024) best = k;
+    return best;
+}
+
+template <int HLEN, int TF>
+static hipError_t run_fwd(const Fwd1DFusedArgs& a, hipStream_t s) {
+    const size_t lds = (size_t)fwd1d_fused_lds_floats(TF, HLEN, a.K) * sizeof(float);
+    const int tiles = cdiv(a.N0 >> a.K, TF);
+    hipLaunchKernelGGL((dwt1_fwd_fused_kernel<HLEN, TF, 256>), dim3((unsigned)((long long)tiles * a.rows)), dim3(256),
+                       lds, s, a, tiles);
+    return hipGetLastError();
+}
+
+template <int HLEN, int T0>
+static hipError_t run_inv(const Inv1DFusedArgs& a, hipStream_t s) {
+    const size_t lds = (size_t)inv1d_fused_lds_floats(T0, HLEN, a.K) * sizeof(float);
+    const int tiles = cdiv(a.N0, T0);
+    hipLaunchKernelGGL((dwt1_inv_fused_kernel<HLEN, T0, 256>), dim3((unsigned)((long long)tiles * a.rows)), dim3(256),
+                       lds, s, a, tiles);
+    return hipGetLastError();
+}
+
+// levels: K >= 1 consecutive levels starting from `in` of length N0 per row; 2^(K+2) must divide N0
+// (every level length even, every band row 16-B aligned)
+hipError_t launch_dwt1_fwd_fused(const float* in, float* const* det, float* app, int rows, int N0, int K, int hlen,
+                                 const FilterBank& fb, hipStream_t s) {
+    if ((hlen & 1) || K < 1 || K > kMaxFusedLevels || (N0 % (1 << (K + 2))) || N0 >= (1 << 30)) return hipErrorNotSupported;
+    Fwd1DFusedArgs a;
+    a.in = in; a.app = app; a.rows = rows; a.N0 = N0; a.K = K;
+    for (int k = 0; k < kMaxFusedLevels; k++) a.det[k] = k < K ? det[k] : nullptr;
+    interleave(a.fb, fb);
+    // TF = 64 final-level outputs per workgroup (TF = 128 measured 25 % slower on 2^24 sym8 L6:
+    // 55 KB of LDS leaves 2 workgroups per CU)
+    switch (hlen) {
+#define X(h) case h: return run_fwd<h, 64>(a, s);
+        PDWT_EVEN_HLENS(X)
+#undef X
+    }
+    return hipErrorNotSupported;
+}
+
+hipError_t launch_dwt1_inv_fused(const float* app, const float* const* det, float* out, int rows, int N0, int K,
+                                 int hlen, const FilterBank& fb, hipStream_t s) {
+    if ((hlen & 1) || K < 1 || K > kMaxFusedLevels || (N0 % (1 << (K + 2))) || N0 >= (1 << 30)) return hipErrorNotSupported;
+    Inv1DFusedArgs a;
+    a.app = app; a.out = out; a.rows = rows; a.N0 = N0; a.K = K;
+    for (int k = 0; k < kMaxFusedLevels; k++) a.det[k] = k < K ? det[k] : nullptr;
+    interleave(a.fb, fb);
+    // 4096 output samples per workgroup (2048: 73 us, 4096: 58 us, 8192: 61 us on 2^24 sym8 L6)
+    switch (hlen) {
+#define X(h) case h: return run_inv<h, 4096>(a, s);
+        PDWT_EVEN_HLENS(X)
+#undef X
+    }
+    return hipErrorNotSupported;
+}
+
+}  // namespace pdwt

@@ -1,0 +1,50 @@
+// packed_math.hpp -- 2-wide fp32 helpers shared by the tuned kernels.
+//
+// gfx950 executes v_pk_fma_f32 on (x,y) register pairs; keeping the low/high filter outputs (or the
+// (A,V)/(H,D) band pairs) interleaved makes every multiply-add of the transform one packed
+// instruction with the (lo,hi) tap pair coming from SGPRs.
+#pragma once
+
+#include "kernels_common.hpp"
+
+namespace pdwt {
+
+#ifdef PDWT_CPU_EMU
+struct v2f {
+    float x, y;
+};
+static inline v2f mk2(float a, float b) { return v2f{a, b}; }
+static inline v2f fma2(v2f a, v2f b, v2f c) { return v2f{a.x * b.x + c.x, a.y * b.y + c.y}; }
+#else
+typedef float v2f __attribute__((ext_vector_type(2)));
+static __device__ __forceinline__ v2f mk2(float a, float b) {
+    v2f r;
+    r.x = a;
+    r.y = b;
+    return r;
+}
+static __device__ __forceinline__ v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+#endif
+static PDWT_DEVICE v2f bc(float a) { return mk2(a, a); }
+
+// Reads 16 B from LDS as ONE ds_read_b128 (256 B/clk) even when only some components are used
+// afterwards; without the barrier hipcc narrows it to ds_read2_b32 / ds_read2_b64 pairs, which
+// run at half the LDS rate (MI355X_MICROARCH.md, LDS table).
+#ifdef PDWT_CPU_EMU
+typedef f32x4 v4f;
+static inline v4f lds_read16(const void* p) { return *reinterpret_cast<const v4f*>(p); }
+#else
+typedef float v4f __attribute__((ext_vector_type(4)));
+static __device__ __forceinline__ v4f lds_read16(const void* p) {
+    v4f w = *reinterpret_cast<const v4f*>(p);
+    asm volatile("" : "+v"(w));
+    return w;
+}
+#endif
+
+// taps interleaved as (lo[j], hi[j]) pairs
+struct FilterBankI {
+    v2f t[kMaxTaps];
+};
+
+}  // namespace pdwt

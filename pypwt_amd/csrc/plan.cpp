@@ -11,6 +11,9 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+
+#include <utility>
+#include <vector>
 #include <strings.h>
 
 #include "launch.hpp"
@@ -286,6 +289,31 @@ int create_impl(const float* img, int batch, int Nr, int Nc, const char* wname, 
 
 // ---------------------------------------------------------------- level loops
 
+constexpr int kMaxFusedLevelsHost = 10;  // == kMaxFusedLevels of dwt1_fused_kernels.hpp
+
+// Partition of the 1D levels into runs handled by ONE fused launch: (first level - 1, K) with K >= 2,
+// 2^K dividing the run's input length (every level length even, see dwt1_fused_kernels.hpp) and K
+// within the LDS budget of the filter length.  Levels not covered run through the per-level kernels.
+std::vector<std::pair<int, int>> fused_groups_1d(const pdwt_plan* p) {
+    std::vector<std::pair<int, int>> g;
+    const int L = p->info.nlevels, hlen = p->info.hlen;
+    if ((hlen & 1) || hlen > kMaxTaps || getenv("PDWT_NO_FUSED_1D")) return g;
+    const int cap = dwt1_fused_max_levels(hlen);
+    int l = 0;
+    while (l < L) {
+        int K = L - l < cap ? L - l : cap;
+        // 2^K | N makes every level length even (exactness); 4 | N >> K keeps every band row 16-B aligned
+        while (K >= 2 && (p->lc[l] % (1 << (K + 2))) != 0) --K;
+        if (K >= 2) {
+            g.push_back({l, K});
+            l += K;
+        } else {
+            ++l;
+        }
+    }
+    return g;
+}
+
 int forward_impl(pdwt_plan* p) {
     const int L = p->info.nlevels, B = p->batch, hlen = p->info.hlen;
     const bool swt = p->info.do_swt != 0;
@@ -353,7 +381,22 @@ int forward_impl(pdwt_plan* p) {
         }
     } else {
         const int rows = B * p->info.Nr;
+        std::vector<std::pair<int, int>> groups = swt ? std::vector<std::pair<int, int>>() : fused_groups_1d(p);
+        size_t gi = 0;
         for (int l = 1; l <= L; l++) {
+            if (gi < groups.size() && groups[gi].first == l - 1) {
+                // levels l .. l+K-1 in ONE launch (dwt1_fused_kernels.hpp)
+                const int K = groups[gi].second;
+                float* det[kMaxFusedLevelsHost] = {};
+                for (int k = 0; k < K; k++) det[k] = p->band(l + k);
+                float* app = (l + K - 1 == L) ? p->band(0) : p->arena + p->approx_off[l + K - 1];
+                Stamp st(p, "dwt1_fwd_fused");
+                HIP_TRY(launch_dwt1_fwd_fused(src, det, app, rows, p->lc[l - 1], K, hlen, p->dec, p->stream));
+                src = app;
+                l += K - 1;
+                gi++;
+                continue;
+            }
             float* dstA = (l == L) ? p->band(0)
                                    : p->arena + (swt ? p->approx_off[l & 1] : p->approx_off[l]);
             float* Dl = p->band(l);
@@ -450,7 +493,22 @@ int inverse_impl(pdwt_plan* p) {
         }
     } else {
         const int rows = B * p->info.Nr;
+        std::vector<std::pair<int, int>> groups = swt ? std::vector<std::pair<int, int>>() : fused_groups_1d(p);
+        int gi = (int)groups.size() - 1;
         for (int l = L; l >= 1; l--) {
+            if (gi >= 0 && groups[gi].first + groups[gi].second == l) {
+                // levels l-K+1 .. l undone in ONE launch
+                const int K = groups[gi].second, l0 = groups[gi].first;  // l0 = level of the output (0 = image)
+                const float* det[kMaxFusedLevelsHost] = {};
+                for (int k = 0; k < K; k++) det[k] = p->band(l0 + 1 + k);
+                float* dst = (l0 == 0) ? p->image() : p->arena + p->approx_off[l0];
+                Stamp st(p, "dwt1_inv_fused");
+                HIP_TRY(launch_dwt1_inv_fused(cur, det, dst, rows, p->lc[l0], K, hlen, p->rec, p->stream));
+                cur = dst;
+                l = l0 + 1;
+                gi--;
+                continue;
+            }
             float* dst = (l == 1) ? p->image()
                                   : p->arena + (swt ? p->approx_off[(l - 1) & 1] : p->approx_off[l - 1]);
             const float* Dl = p->band(l);

@@ -2,10 +2,12 @@
 // Compiles pypwt_amd/csrc/*_kernels.hpp with PDWT_CPU_EMU: phases run as loops over
 // thread ids, blocks as loops over the grid.  Test infrastructure; never shipped.
 #define PDWT_CPU_EMU 1
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
 
+#include "../../pypwt_amd/csrc/dwt1_fused_kernels.hpp"
 #include "../../pypwt_amd/csrc/dwt1_kernels.hpp"
 #include "../../pypwt_amd/csrc/dwt2_fast_kernels.hpp"
 #include "../../pypwt_amd/csrc/dwt2_kernels.hpp"
@@ -303,4 +305,51 @@ EMU_API int emu_nonsep(int inverse, float* io, int batch, int Nr, int Nc, int do
             else nonsep_fwd_tile<256>(a, b, bz, smem.data());
         }
     return 0;
+}
+
+// ------------------------------------------------------------------ fused multi-level 1D
+// outputs: det = K row-major planes concatenated in level order (each rows x (N0>>k)), app = rows x (N0>>K)
+template <int HLEN, int TF, int NT>
+static void run_fwd1d_fused(Fwd1DFusedArgs a) {
+    std::vector<float> smem(fwd1d_fused_lds_floats(TF, HLEN, a.K) + 64, NAN);
+    const int tiles = cdiv(a.N0 >> a.K, TF);
+    for (int row = 0; row < a.rows; row++)
+        for (int bx = 0; bx < tiles; bx++) dwt1_fwd_fused_tile<HLEN, TF, NT>(a, bx, row, smem.data());
+}
+template <int HLEN, int T0, int NT>
+static void run_inv1d_fused(Inv1DFusedArgs a) {
+    std::vector<float> smem(inv1d_fused_lds_floats(T0, HLEN, a.K) + 64, NAN);
+    const int tiles = cdiv(a.N0, T0);
+    for (int row = 0; row < a.rows; row++)
+        for (int bx = 0; bx < tiles; bx++) dwt1_inv_fused_tile<HLEN, T0, NT>(a, bx, row, smem.data());
+}
+
+EMU_API int emu_dwt1_fused(int inverse, float* io, int rows, int N0, int K, const float* lo, const float* hi, int hlen,
+                           int small, float* det, float* app) {
+    if ((hlen & 1) || (N0 % (1 << (K + 2))) || K > kMaxFusedLevels) return -2;
+    float* dptr[kMaxFusedLevels] = {};
+    size_t off = 0;
+    for (int k = 1; k <= K; k++) { dptr[k - 1] = det + off; off += (size_t)rows * (N0 >> k); }
+    if (!inverse) {
+        Fwd1DFusedArgs a;
+        a.in = io; a.app = app; a.rows = rows; a.N0 = N0; a.K = K;
+        for (int k = 0; k < kMaxFusedLevels; k++) a.det[k] = dptr[k];
+        set_bank_i(a.fb, lo, hi, hlen);
+        switch (hlen) {
+#define X(h) case h: if (small) run_fwd1d_fused<h, 16, 256>(a); else run_fwd1d_fused<h, 128, 256>(a); return 0;
+            EMU_EVEN_HLENS(X)
+#undef X
+        }
+    } else {
+        Inv1DFusedArgs a;
+        a.out = io; a.app = app; a.rows = rows; a.N0 = N0; a.K = K;
+        for (int k = 0; k < kMaxFusedLevels; k++) a.det[k] = dptr[k];
+        set_bank_i(a.fb, lo, hi, hlen);
+        switch (hlen) {
+#define X(h) case h: if (small) run_inv1d_fused<h, 1024, 256>(a); else run_inv1d_fused<h, 8192, 256>(a); return 0;
+            EMU_EVEN_HLENS(X)
+#undef X
+        }
+    }
+    return -1;
 }

@@ -293,3 +293,35 @@ def test_emu_dwt2_stream_batch():
         assert lib().emu_dwt2_inv_stream(*[P(o) for o in outs], B, 24, 68, shape[0], shape[1], P(rlo), P(rhi), hlen,
                                          nwg, P(rec)) == 0
         assert np.abs(rec - x).max() < 1e-3, nwg
+
+
+# ----------------------------------------------------------------------------- fused multi-level 1D
+@pytest.mark.parametrize("wname", ["haar", "db2", "db4", "sym8", "db10", "db20"])
+def test_emu_dwt1_fused_pyramid(wname):
+    hlen, dlo, dhi, rlo, rhi = oracle.filters(wname)
+    for si, (rows, N0, K) in enumerate([(1, 4096, 1), (2, 4096, 3), (1, 16384, 6), (3, 1536, 4), (1, 64, 2), (1, 24576, 5)]):
+        if N0 % (1 << (K + 2)):
+            continue
+        x = oracle.hash_input((rows, N0), 7100 + si)
+        ref = oracle.forward(x, wname, K, ndim=1)  # [A_K, D_1, ..., D_K]
+        ndet = sum(rows * (N0 >> k) for k in range(1, K + 1))
+        for small in (0, 1):
+            det = np.full(ndet, np.nan, dtype=np.float32)
+            app = np.full((rows, N0 >> K), np.nan, dtype=np.float32)
+            assert lib().emu_dwt1_fused(0, P(x.copy()), rows, N0, K, P(dlo), P(dhi), hlen, small, P(det), P(app)) == 0
+            assert np.abs(app - ref[0]).max() <= _tol(ref[0]) * (1 + K), (wname, rows, N0, K, small)
+            off = 0
+            for k in range(1, K + 1):
+                n = rows * (N0 >> k)
+                got = det[off:off + n].reshape(rows, N0 >> k)
+                off += n
+                assert np.isfinite(got).all(), (wname, N0, K, k, small)
+                assert np.abs(got - ref[k]).max() <= _tol(ref[k]) * (1 + K), (wname, rows, N0, K, k, small)
+            # inverse of arbitrary coefficients
+            bands = [oracle.hash_input(b.shape, 7200 + 9 * si + i, 2.0) - 1.0 for i, b in enumerate(ref)]
+            want = oracle.inverse(bands, (rows, N0), wname, K, ndim=1)
+            det_in = np.concatenate([b.ravel() for b in bands[1:]]).astype(np.float32)
+            out = np.full((rows, N0), np.nan, dtype=np.float32)
+            assert lib().emu_dwt1_fused(1, P(out), rows, N0, K, P(rlo), P(rhi), hlen, small, P(det_in), P(bands[0])) == 0
+            assert np.isfinite(out).all(), (wname, N0, K, small)
+            assert np.abs(out - want).max() <= _tol(want) * (1 + K), (wname, rows, N0, K, small)
