@@ -83,6 +83,13 @@ PDWT_DEVICE int wrap_analysis(int i, int n) {
 
 PDWT_DEVICE int analysis_centre(int hlen) { return (hlen & 1) ? hlen / 2 : hlen / 2 - 1; }
 
+// soft threshold sign(x) max(|x|-b, 0) written as x - clamp(x, -b, b): the same value for every
+// finite x (b >= 0), the identity for b == 0, two instructions (v_med3_f32 + v_sub_f32)
+PDWT_DEVICE float soft_shrink(float x, float b) {
+    const float c = x < -b ? -b : (x > b ? b : x);
+    return x - c;
+}
+
 // ---- argument blocks -----------------------------------------------------
 
 // one decimated 2D analysis level: in (Nr,Nc) -> A,H,V,D (Nr2,Nc2)
@@ -130,6 +137,7 @@ struct Swt2DArgs {
     int Nr, Nc, f;
     long long bstride;
     int hlen;
+    float soft_beta;          // inverse: soft-threshold applied to H,V,D as they are loaded (0 = none)
     FilterBank fb;
 };
 

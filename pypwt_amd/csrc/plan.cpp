@@ -354,6 +354,7 @@ int forward_impl(pdwt_plan* p) {
                     a.Nr = Nr; a.Nc = Nc; a.f = f;
                     a.bstride = (long long)Nr * Nc;
                     a.hlen = hlen;
+                    a.soft_beta = 0.f;
                     a.fb = p->dec;
                     Stamp st(p, "swt2_fwd_level");
                     HIP_TRY(launch_swt2_fwd(a, B, p->stream));
@@ -467,8 +468,15 @@ int inverse_impl(pdwt_plan* p) {
                     a.Nr = Nr; a.Nc = Nc; a.f = f;
                     a.bstride = (long long)Nr * Nc;
                     a.hlen = hlen;
+                    a.soft_beta = 0.f;
+                    if (p->pend_soft) {  // deferred soft_threshold: beta (/ sqrt(2)^l when normalised)
+                        float b = p->pend_beta;
+                        if (p->pend_normalize > 0)
+                            for (int i = 0; i < l; i++) b = (float)(b / 1.4142135623730951);
+                        a.soft_beta = b;
+                    }
                     a.fb = p->rec;
-                    Stamp st(p, "swt2_inv_level");
+                    Stamp st(p, p->pend_soft ? "swt2_inv_level+soft" : "swt2_inv_level");
                     HIP_TRY(launch_swt2_inv(a, B, p->stream));
                 } else {
                     const long long plane = (long long)Nr * Nc;
@@ -563,10 +571,30 @@ float app_beta(float beta, int levels, int normalize) {
     return beta;
 }
 
+int threshold_impl(pdwt_plan* p, int op, float beta, int do_app, int normalize, const char* what);
+
+// apply a deferred soft_threshold now (every consumer of the coefficients other than the fused SWT
+// inverse calls this first)
+int materialize_pending(pdwt_plan* p) {
+    if (!p->pend_soft) return PDWT_OK;
+    p->pend_soft = false;
+    return threshold_impl(p, EW_SOFT, p->pend_beta, 0, p->pend_normalize, "soft_threshold");
+}
+
+// can the inverse of this plan apply a soft threshold on the fly?  (fused 2D SWT kernels on every level)
+bool can_defer_soft(const pdwt_plan* p) {
+    if (!p->info.do_swt || p->info.ndims != 2 || !p->do_separable || getenv("PDWT_NO_LAZY_THRESHOLD")) return false;
+    return p->info.Nr % (1 << (p->info.nlevels - 1)) == 0;
+}
+
 // soft / hard / proj_linf share one driver (pdwt/src/common.cu:219-308)
 int threshold_impl(pdwt_plan* p, int op, float beta, int do_app, int normalize, const char* what) {
     if (p->state == PDWT_INVERSE)
         return fail(PDWT_ERR_STATE, "%s: cannot threshold coefficients, as they were modified by inverse()", what);
+    {
+        const int rc = materialize_pending(p);
+        if (rc != PDWT_OK) return rc;
+    }
     const int L = p->info.nlevels, B = p->batch;
     if (do_app) {
         Stamp st(p, what);
@@ -644,6 +672,10 @@ int pdwt_clone(pdwt_handle src, pdwt_handle* out) {
     if (!out) return fail(PDWT_ERR_ARG, "pdwt_clone: out is null");
     *out = nullptr;
     DeviceGuard guard(src->device);
+    {
+        const int rc0 = materialize_pending(src);
+        if (rc0 != PDWT_OK) return rc0;
+    }
     pdwt_plan* p = new pdwt_plan();
     p->device = src->device;
     p->batch = src->batch;
@@ -697,6 +729,7 @@ int pdwt_forward(pdwt_handle h) {  // Wavelets::forward, wt.cu:236-269
     if (h->state == PDWT_CREATION_ERROR)
         return fail(PDWT_ERR_STATE, "forward transform not computed, as there was an error when creating the wavelets");
     DeviceGuard guard(h->device);
+    h->pend_soft = false;  // the coefficients a deferred threshold referred to are about to be overwritten
     if (h->do_cycle_spinning) {  // wt.cu:242-246
         h->shift_r = rand() % h->info.Nr;
         h->shift_c = rand() % h->info.Nc;
@@ -716,6 +749,7 @@ int pdwt_inverse(pdwt_handle h) {  // Wavelets::inverse, wt.cu:271-305
         return fail(PDWT_ERR_STATE, "inverse transform not computed, as there was an error in a previous stage");
     DeviceGuard guard(h->device);
     int rc = inverse_impl(h);
+    h->pend_soft = false;  // consumed by the fused kernels
     if (rc == PDWT_OK && h->do_cycle_spinning) rc = circshift_impl(h, -h->shift_r, -h->shift_c, 1);  // wt.cu:303
     h->state = (rc == PDWT_OK) ? PDWT_INVERSE : PDWT_INVERSE_ERROR;
     return rc;
@@ -724,6 +758,14 @@ int pdwt_inverse(pdwt_handle h) {  // Wavelets::inverse, wt.cu:271-305
 int pdwt_soft_threshold(pdwt_handle h, float beta, int do_app, int normalize) {  // wt.cu:308-315
     CHECK_HANDLE(h);
     DeviceGuard guard(h->device);
+    if (h->state != PDWT_INVERSE && !do_app && beta >= 0.f && can_defer_soft(h)) {
+        const int rc = materialize_pending(h);  // an earlier pending threshold composes: apply it first
+        if (rc != PDWT_OK) return rc;
+        h->pend_soft = true;
+        h->pend_beta = beta;
+        h->pend_normalize = normalize;
+        return PDWT_OK;
+    }
     return threshold_impl(h, EW_SOFT, beta, do_app, normalize, "soft_threshold");
 }
 
@@ -744,6 +786,10 @@ int pdwt_group_soft_threshold(pdwt_handle h, float beta, int do_app, int normali
     if (h->state == PDWT_INVERSE)
         return fail(PDWT_ERR_STATE, "cannot threshold coefficients, as they were modified by inverse()");
     DeviceGuard guard(h->device);
+    {
+        const int rc0 = materialize_pending(h);
+        if (rc0 != PDWT_OK) return rc0;
+    }
     const int L = h->info.nlevels, B = h->batch;
     const int per = h->info.ndims == 2 ? 3 : 1;
     for (int l = 1; l <= L; l++) {  // common.cu:311-341
@@ -763,6 +809,10 @@ int pdwt_shrink(pdwt_handle h, float beta, int do_app) {  // wt.cu:340-347, comm
     if (h->state == PDWT_INVERSE)
         return fail(PDWT_ERR_STATE, "cannot threshold coefficients, as they were modified by inverse()");
     DeviceGuard guard(h->device);
+    {
+        const int rc0 = materialize_pending(h);
+        if (rc0 != PDWT_OK) return rc0;
+    }
     const long long first = do_app ? 0 : h->bands[1].off;
     Stamp st(h, "shrink");
     HIP_TRY(launch_ew(EW_SCALE, h->arena + first, h->coeff_elems - first, 1.0f / (1.0f + beta), h->stream));
@@ -777,6 +827,10 @@ int pdwt_circshift(pdwt_handle h, int sr, int sc, int inplace) {
 
 static int norms_impl(pdwt_handle h, double out[2]) {
     DeviceGuard guard(h->device);
+    {
+        const int rc0 = materialize_pending(h);
+        if (rc0 != PDWT_OK) return rc0;
+    }
     HIP_TRY(hipMemsetAsync(h->d_red, 0, 2 * sizeof(double), h->stream));
     {
         Stamp st(h, "norms");
@@ -835,6 +889,11 @@ int pdwt_add_wavelet(pdwt_handle dst, pdwt_handle src, float alpha) {  // wt.cu:
         return -2;
     }
     DeviceGuard guard(dst->device);
+    {
+        int rc0 = materialize_pending(dst);
+        if (rc0 == PDWT_OK) rc0 = materialize_pending(src);
+        if (rc0 != PDWT_OK) return rc0;
+    }
     if (src->stream != dst->stream) HIP_TRY(hipStreamSynchronize(src->stream));
     Stamp st(dst, "add_wavelet");
     HIP_TRY(launch_axpy(dst->arena, src->arena, dst->coeff_elems, alpha, dst->stream));
@@ -866,6 +925,10 @@ long long pdwt_get_coeff(pdwt_handle h, float* dst, int num) {  // wt.cu:473-506
         return 0;
     }
     DeviceGuard guard(h->device);
+    {
+        const int rc0 = materialize_pending(h);
+        if (rc0 != PDWT_OK) return rc0;
+    }
     const long long n = h->bands[num].elems(h->batch);
     HIP_TRY(hipMemcpyAsync(dst, h->band(num), (size_t)n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
@@ -889,6 +952,10 @@ int pdwt_set_coeff(pdwt_handle h, const float* src, int num, int mem_is_on_devic
     if (!src) return fail(PDWT_ERR_ARG, "pdwt_set_coeff: src is null");
     if (num < 0 || num >= (int)h->bands.size()) return fail(PDWT_ERR_ARG, "coefficient index %d out of range", num);
     DeviceGuard guard(h->device);
+    {
+        const int rc0 = materialize_pending(h);  // a deferred threshold applies to the OLD contents only
+        if (rc0 != PDWT_OK) return rc0;
+    }
     const long long n = h->bands[num].elems(h->batch);
     HIP_TRY(hipMemcpyAsync(h->band(num), src, (size_t)n * sizeof(float),
                            mem_is_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, h->stream));
@@ -900,6 +967,10 @@ intptr_t pdwt_image_ptr(pdwt_handle h) { return h ? (intptr_t)h->image() : 0; }
 
 intptr_t pdwt_coeff_ptr(pdwt_handle h, int num) {
     if (!h || num < 0 || num >= (int)h->bands.size()) return 0;
+    {
+        DeviceGuard guard(h->device);
+        if (materialize_pending(h) != PDWT_OK) return 0;  // the caller will read device memory directly
+    }
     return (intptr_t)h->band(num);
 }
 

@@ -68,6 +68,13 @@ struct pdwt_plan {
     float* d_f2d = nullptr;  // non-separable banks: fwd LL,LH,HL,HH then inv, each hlen*hlen
     bool f2d_custom = false;
 
+    // A soft_threshold that has been requested but not yet applied: the fused SWT inverse applies
+    // it while it loads the detail bands (saves one read+write sweep of 3L full-size planes); any
+    // other consumer of the coefficients materialises it first (plan.cpp: materialize_pending).
+    bool pend_soft = false;
+    float pend_beta = 0.f;
+    int pend_normalize = 0;
+
     bool timing = false;
     std::vector<pdwt::KernelStamp> stamps;
 

@@ -155,10 +155,12 @@ PDWT_DEVICE void swt2_inv_tile(const Swt2DArgs& a, int bx, int by, int bz, float
                 for (int j = 0; j < (HLEN > 0 ? HLEN : hlen); ++j) {
                     const long long o = ro + wrap_periodic(x + (j - c) * f, a.Nc);
                     const float tl = lo[hlen - 1 - j], th = hi[hlen - 1 - j];
+                    // a pending soft_threshold of the plan is applied here, on the fly, to the detail
+                    // bands (never to A): the thresholded coefficients are not written back
                     r1 = pdwt_fma(a.A[o], tl, r1);
-                    r1 = pdwt_fma(a.V[o], th, r1);
-                    r2 = pdwt_fma(a.H[o], tl, r2);
-                    r2 = pdwt_fma(a.D[o], th, r2);
+                    r1 = pdwt_fma(soft_shrink(a.V[o], a.soft_beta), th, r1);
+                    r2 = pdwt_fma(soft_shrink(a.H[o], a.soft_beta), tl, r2);
+                    r2 = pdwt_fma(soft_shrink(a.D[o], a.soft_beta), th, r2);
                 }
             }
             u1[r * TX + k] = 0.5f * r1;

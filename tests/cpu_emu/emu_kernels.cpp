@@ -148,7 +148,7 @@ EMU_API int emu_swt2(int inverse, float* io, int batch, int Nr, int Nc, int leve
                      int hlen, int generic, float* A, float* H, float* V, float* D) {
     Swt2DArgs a;
     a.in = io; a.out = io; a.A = A; a.H = H; a.V = V; a.D = D;
-    a.Nr = Nr; a.Nc = Nc; a.f = 1 << (level - 1); a.bstride = (long long)Nr * Nc; a.hlen = hlen;
+    a.Nr = Nr; a.Nc = Nc; a.f = 1 << (level - 1); a.bstride = (long long)Nr * Nc; a.hlen = hlen; a.soft_beta = 0.f;
     if (Nr % a.f) return -2;
     set_bank(a.fb, lo, hi, hlen);
     if (generic || (hlen & 1)) { if (inverse) run_swt2<0, true>(a, batch); else run_swt2<0, false>(a, batch); return 0; }

@@ -276,3 +276,52 @@ def test_custom_nonseparable_filter_bank(W):
         assert np.abs(g - r).max() <= 2e-5 * max(np.abs(r).max(), 1.0)
     with pytest.raises(ValueError):
         w.set_wavelets_filters("missing", g4[0], g4[3], i[0], i[3])
+
+
+def test_deferred_soft_threshold_fused_into_swt_inverse(W):
+    """On a 2D SWT plan soft_threshold() is deferred and applied by the fused inverse kernels while they
+    load the detail bands.  Every observable result must equal the eager semantics: reconstruction vs the
+    oracle (threshold then inverse), coefficients read after the threshold, composition of two thresholds,
+    a later set_coeff, and a forward() that discards the pending threshold."""
+    x = oracle.hash_input((64, 96), 21, 100.0) - 50.0
+    for wname, lv, normalize in (("haar", 3, 0), ("db2", 2, 1), ("sym4", 2, 0)):
+        ora = oracle.forward(x, wname, lv, do_swt=1)
+        thr = oracle.threshold(ora, x.shape, lv, "soft", 6.0, 0, normalize, do_swt=1)
+        want = oracle.inverse(thr, x.shape, wname, lv, do_swt=1)
+        # 1. threshold -> inverse directly (the fused path)
+        w = W(x, wname, lv, do_swt=1)
+        w.forward()
+        w.soft_threshold(6.0, 0, normalize)
+        w.inverse()
+        assert np.abs(w.image - want).max() <= 3e-5 * max(np.abs(want).max(), 1.0), wname  # (inverse() overwrote the image: pass x again below)
+        # 2. threshold -> read coefficients (materialised) -> inverse
+        w.forward(x)
+        w.soft_threshold(6.0, 0, normalize)
+        for g, r in zip(flat_coeffs(w), thr):
+            assert np.abs(g - r).max() <= 2e-6 * max(np.abs(r).max(), 1.0)
+        w.inverse()
+        assert np.abs(w.image - want).max() <= 3e-5 * max(np.abs(want).max(), 1.0)
+        # 3. two thresholds compose: soft(soft(x, a), b) == soft(x, a + b)
+        thr2 = oracle.threshold(thr, x.shape, lv, "soft", 2.5, 0, normalize, do_swt=1)
+        want2 = oracle.inverse(thr2, x.shape, wname, lv, do_swt=1)
+        w.forward(x)
+        w.soft_threshold(6.0, 0, normalize)
+        w.soft_threshold(2.5, 0, normalize)
+        w.inverse()
+        assert np.abs(w.image - want2).max() <= 3e-5 * max(np.abs(want2).max(), 1.0)
+        # 4. set_coeff after a pending threshold must not be thresholded; norms see thresholded values
+        w.forward(x)
+        w.soft_threshold(6.0, 0, normalize)
+        n1, _ = oracle.norms(thr, x.shape, lv, do_swt=1)
+        assert abs(w.norm1() - n1) <= 1e-5 * n1
+        w.forward(x)
+        w.soft_threshold(6.0, 0, normalize)
+        newH = oracle.hash_input(x.shape, 22, 10.0)
+        w.set_coeff(newH, 1)
+        assert np.array_equal(w.coeff_only(1), newH)
+        # 5. forward() discards a pending threshold
+        w.forward(x)
+        w.soft_threshold(1e9)
+        w.forward(x)
+        w.inverse()
+        assert np.abs(w.image - x).max() < 7e-4

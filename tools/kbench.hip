@@ -218,6 +218,16 @@ int main(int argc, char** argv) {
     for (int w : {2, 4, 6, 8, 12}) bench_fwd_stream<8, 64, 8, 256>("STREAM fwd db4 TX64 TY8 NT256", a, b, N, B, w);
     for (int w : {2, 4, 6, 8}) bench_fwd_stream<8, 64, 16, 256>("STREAM fwd db4 TX64 TY16 NT256", a, b, N, B, w);
     for (int w : {2, 4, 8}) bench_fwd_stream<8, 64, 4, 128>("STREAM fwd db4 TX64 TY4 NT128", a, b, N, B, w);
+    bench_fwd_fast<8, 64, 16, 512>("FAST fwd db4 TX64 TY16 NT512", a, b, N, B);
+    bench_fwd_fast<8, 128, 8, 512>("FAST fwd db4 TX128 TY8 NT512", a, b, N, B);
+    bench_fwd_fast<8, 64, 4, 128>("FAST fwd db4 TX64 TY4 NT128", a, b, N, B);
+    bench_fwd_fast<8, 32, 8, 128>("FAST fwd db4 TX32 TY8 NT128", a, b, N, B);
+    bench_inv_fast<8, 64, 16, 512>("FAST inv db4 TX64 TY16 NT512", b, a, N, B);
+    bench_inv_fast<8, 64, 8, 512>("FAST inv db4 TX64 TY8 NT512", b, a, N, B);
+    bench_inv_fast<8, 64, 4, 128>("FAST inv db4 TX64 TY4 NT128", b, a, N, B);
+    bench_inv_fast<8, 64, 4, 256>("FAST inv db4 TX64 TY4 NT256", b, a, N, B);
+    bench_inv_fast<8, 32, 8, 128>("FAST inv db4 TX32 TY8 NT128", b, a, N, B);
+    bench_inv_fast<8, 128, 8, 256>("FAST inv db4 TX128 TY8 NT256", b, a, N, B);
     for (int w : {4, 6, 8}) bench_inv_stream<8, 64, 8, 256>("STREAM inv db4 TX64 TY8 NT256", b, a, N, B, w);
     for (int w : {2, 4}) bench_inv_stream<8, 64, 16, 256>("STREAM inv db4 TX64 TY16 NT256", b, a, N, B, w);
     bench_fwd_fast<8, 64, 16, 256>("FAST fwd db4 TX64 TY16 NT256", a, b, N, B);
