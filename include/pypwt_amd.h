@@ -159,6 +159,12 @@ int pdwt_fill_image_hash(pdwt_handle h, uint32_t seed, float scale, long long in
 int pdwt_enable_kernel_timing(pdwt_handle h, int enable);
 int pdwt_kernel_times(pdwt_handle h, float* ms, char (*names)[48], int cap);
 int pdwt_reset_kernel_times(pdwt_handle h);
+/* micro-benchmark of ONE level: the launch(es) of level `level` (1 = finest; for fused multi-level
+ * 1D launches: the first level of the group) of the forward (inverse = 0) or inverse transform are
+ * enqueued `reps` times back to back between two HIP events on the plan's stream; returns the mean
+ * milliseconds per repetition.  The data the level reads is whatever the buffers hold (run a
+ * forward first); nothing else of the plan's state changes. */
+int pdwt_time_level(pdwt_handle h, int level, int inverse, int reps, float* ms_per_launch);
 
 #ifdef __cplusplus
 }

@@ -71,6 +71,7 @@ SIGNATURES = {
     "pdwt_enable_kernel_timing": (C.c_int, [handle_t, C.c_int]),
     "pdwt_kernel_times": (C.c_int, [handle_t, f32p, C.c_void_p, C.c_int]),
     "pdwt_reset_kernel_times": (C.c_int, [handle_t]),
+    "pdwt_time_level": (C.c_int, [handle_t, C.c_int, C.c_int, C.c_int, f32p]),
 }
 
 _lib = None

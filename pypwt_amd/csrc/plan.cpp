@@ -73,29 +73,26 @@ struct DeviceGuard {
     }
 };
 
-// brackets one kernel launch with events when per-kernel timing is on
+// Per-kernel timing: ONE event is recorded on the plan's stream in front of every launch; a
+// launch's duration is the distance to the next event (the next launch's, or the closing event
+// recorded by pdwt_kernel_times).  One event per launch instead of a start/stop pair halves the
+// perturbation (an event costs about 1 us of stream time on MI355X).
 struct Stamp {
-    pdwt_plan* p;
-    int idx = -1;
-    Stamp(pdwt_plan* plan, const char* name) : p(plan) {
+    Stamp(pdwt_plan* p, const char* name) {
         if (!p->timing) return;
         KernelStamp s;
+        s.stop = nullptr;
         if (hipEventCreate(&s.start) != hipSuccess) return;
-        if (hipEventCreate(&s.stop) != hipSuccess) { (void)hipEventDestroy(s.start); return; }
         snprintf(s.name, sizeof(s.name), "%s", name);
         (void)hipEventRecord(s.start, p->stream);
         p->stamps.push_back(s);
-        idx = (int)p->stamps.size() - 1;
-    }
-    ~Stamp() {
-        if (idx >= 0) (void)hipEventRecord(p->stamps[idx].stop, p->stream);
     }
 };
 
 void clear_stamps(pdwt_plan* p) {
     for (auto& s : p->stamps) {
         (void)hipEventDestroy(s.start);
-        (void)hipEventDestroy(s.stop);
+        if (s.stop) (void)hipEventDestroy(s.stop);
     }
     p->stamps.clear();
 }
@@ -314,12 +311,14 @@ std::vector<std::pair<int, int>> fused_groups_1d(const pdwt_plan* p) {
     return g;
 }
 
-int forward_impl(pdwt_plan* p) {
+// only == 0: every level; only == l: just the launch(es) of level l (pdwt_time_level)
+int forward_impl(pdwt_plan* p, int only = 0) {
     const int L = p->info.nlevels, B = p->batch, hlen = p->info.hlen;
     const bool swt = p->info.do_swt != 0;
     const float* src = p->image();
     if (p->info.ndims == 2) {
         for (int l = 1; l <= L; l++) {
+            const bool run = (only == 0 || only == l);
             float* dstA = (l == L) ? p->band(0)
                                    : p->arena + (swt ? p->approx_off[l & 1] : p->approx_off[l]);
             float* H = p->band(3 * (l - 1) + 1);
@@ -334,7 +333,7 @@ int forward_impl(pdwt_plan* p) {
                 a.img_bstride = (long long)a.Nr * a.Nc; a.coef_bstride = (long long)a.Nrc * a.Ncc;
                 a.hlen = hlen;
                 Stamp st(p, "nonsep_fwd_level");
-                HIP_TRY(launch_nonsep_fwd(a, B, p->stream));
+                if (run) HIP_TRY(launch_nonsep_fwd(a, B, p->stream));
             } else if (!swt) {
                 Fwd2DArgs a;
                 a.in = src; a.A = dstA; a.H = H; a.V = V; a.D = D;
@@ -344,7 +343,7 @@ int forward_impl(pdwt_plan* p) {
                 a.hlen = hlen;
                 a.fb = p->dec;
                 Stamp st(p, "dwt2_fwd_level");
-                HIP_TRY(launch_dwt2_fwd(a, B, p->stream));
+                if (run) HIP_TRY(launch_dwt2_fwd(a, B, p->stream));
             } else {
                 const int f = 1 << (l - 1);
                 const int Nr = p->info.Nr, Nc = p->info.Nc;
@@ -357,7 +356,7 @@ int forward_impl(pdwt_plan* p) {
                     a.soft_beta = 0.f;
                     a.fb = p->dec;
                     Stamp st(p, "swt2_fwd_level");
-                    HIP_TRY(launch_swt2_fwd(a, B, p->stream));
+                    if (run) HIP_TRY(launch_swt2_fwd(a, B, p->stream));
                 } else {
                     // dilation does not divide the row count: two direct passes through scratch
                     const long long plane = (long long)Nr * Nc;
@@ -368,13 +367,13 @@ int forward_impl(pdwt_plan* p) {
                         r.in0 = src + b * plane; r.in1 = nullptr; r.out0 = p->tmp; r.out1 = p->tmp + plane;
                         r.Nr = Nr; r.Nc = Nc; r.f = f; r.along_y = 0; r.hlen = hlen; r.fb = p->dec;
                         Stamp st(p, "swt_pass_fwd");
-                        HIP_TRY(launch_swt_pass_fwd(r, p->stream));
+                        if (run) HIP_TRY(launch_swt_pass_fwd(r, p->stream));
                         SwtPassArgs c1 = r;
                         c1.in0 = p->tmp; c1.out0 = dstA + b * plane; c1.out1 = H + b * plane; c1.along_y = 1;
-                        HIP_TRY(launch_swt_pass_fwd(c1, p->stream));
+                        if (run) HIP_TRY(launch_swt_pass_fwd(c1, p->stream));
                         SwtPassArgs c2 = c1;
                         c2.in0 = p->tmp + plane; c2.out0 = V + b * plane; c2.out1 = D + b * plane;
-                        HIP_TRY(launch_swt_pass_fwd(c2, p->stream));
+                        if (run) HIP_TRY(launch_swt_pass_fwd(c2, p->stream));
                     }
                 }
             }
@@ -385,6 +384,7 @@ int forward_impl(pdwt_plan* p) {
         std::vector<std::pair<int, int>> groups = swt ? std::vector<std::pair<int, int>>() : fused_groups_1d(p);
         size_t gi = 0;
         for (int l = 1; l <= L; l++) {
+            const bool run = (only == 0 || only == l);
             if (gi < groups.size() && groups[gi].first == l - 1) {
                 // levels l .. l+K-1 in ONE launch (dwt1_fused_kernels.hpp)
                 const int K = groups[gi].second;
@@ -392,7 +392,7 @@ int forward_impl(pdwt_plan* p) {
                 for (int k = 0; k < K; k++) det[k] = p->band(l + k);
                 float* app = (l + K - 1 == L) ? p->band(0) : p->arena + p->approx_off[l + K - 1];
                 Stamp st(p, "dwt1_fwd_fused");
-                HIP_TRY(launch_dwt1_fwd_fused(src, det, app, rows, p->lc[l - 1], K, hlen, p->dec, p->stream));
+                if (run) HIP_TRY(launch_dwt1_fwd_fused(src, det, app, rows, p->lc[l - 1], K, hlen, p->dec, p->stream));
                 src = app;
                 l += K - 1;
                 gi++;
@@ -408,13 +408,13 @@ int forward_impl(pdwt_plan* p) {
                 a.hlen = hlen;
                 a.fb = p->dec;
                 Stamp st(p, "dwt1_fwd_level");
-                HIP_TRY(launch_dwt1_fwd(a, p->stream));
+                if (run) HIP_TRY(launch_dwt1_fwd(a, p->stream));
             } else {
                 SwtPassArgs r;
                 r.in0 = src; r.in1 = nullptr; r.out0 = dstA; r.out1 = Dl;
                 r.Nr = rows; r.Nc = p->info.Nc; r.f = 1 << (l - 1); r.along_y = 0; r.hlen = hlen; r.fb = p->dec;
                 Stamp st(p, "swt1_fwd_level");
-                HIP_TRY(launch_swt_pass_fwd(r, p->stream));
+                if (run) HIP_TRY(launch_swt_pass_fwd(r, p->stream));
             }
             src = dstA;
         }
@@ -422,12 +422,13 @@ int forward_impl(pdwt_plan* p) {
     return PDWT_OK;
 }
 
-int inverse_impl(pdwt_plan* p) {
+int inverse_impl(pdwt_plan* p, int only = 0) {
     const int L = p->info.nlevels, B = p->batch, hlen = p->info.hlen;
     const bool swt = p->info.do_swt != 0;
     const float* cur = p->band(0);
     if (p->info.ndims == 2) {
         for (int l = L; l >= 1; l--) {
+            const bool run = (only == 0 || only == l);
             float* dst = (l == 1) ? p->image()
                                   : p->arena + (swt ? p->approx_off[(l - 1) & 1] : p->approx_off[l - 1]);
             const float* H = p->band(3 * (l - 1) + 1);
@@ -445,7 +446,7 @@ int inverse_impl(pdwt_plan* p) {
                 a.img_bstride = (long long)a.Nr * a.Nc; a.coef_bstride = (long long)a.Nrc * a.Ncc;
                 a.hlen = hlen;
                 Stamp st(p, "nonsep_inv_level");
-                HIP_TRY(launch_nonsep_inv(a, B, p->stream));
+                if (run) HIP_TRY(launch_nonsep_inv(a, B, p->stream));
             } else if (!swt) {
                 Inv2DArgs a;
                 a.A = cur; a.H = H; a.V = V; a.D = D; a.out = dst;
@@ -455,7 +456,7 @@ int inverse_impl(pdwt_plan* p) {
                 a.hlen = hlen;
                 a.fb = p->rec;
                 Stamp st(p, "dwt2_inv_level");
-                HIP_TRY(launch_dwt2_inv(a, B, p->stream));
+                if (run) HIP_TRY(launch_dwt2_inv(a, B, p->stream));
             } else {
                 const int f = 1 << (l - 1);
                 const int Nr = p->info.Nr, Nc = p->info.Nc;
@@ -477,7 +478,7 @@ int inverse_impl(pdwt_plan* p) {
                     }
                     a.fb = p->rec;
                     Stamp st(p, p->pend_soft ? "swt2_inv_level+soft" : "swt2_inv_level");
-                    HIP_TRY(launch_swt2_inv(a, B, p->stream));
+                    if (run) HIP_TRY(launch_swt2_inv(a, B, p->stream));
                 } else {
                     const long long plane = (long long)Nr * Nc;
                     int rc = ensure_tmp(p, 2 * plane);
@@ -487,13 +488,13 @@ int inverse_impl(pdwt_plan* p) {
                         c1.in0 = cur + b * plane; c1.in1 = H + b * plane; c1.out0 = p->tmp; c1.out1 = nullptr;
                         c1.Nr = Nr; c1.Nc = Nc; c1.f = f; c1.along_y = 1; c1.hlen = hlen; c1.fb = p->rec;
                         Stamp st(p, "swt_pass_inv");
-                        HIP_TRY(launch_swt_pass_inv(c1, p->stream));
+                        if (run) HIP_TRY(launch_swt_pass_inv(c1, p->stream));
                         SwtPassArgs c2 = c1;
                         c2.in0 = V + b * plane; c2.in1 = D + b * plane; c2.out0 = p->tmp + plane;
-                        HIP_TRY(launch_swt_pass_inv(c2, p->stream));
+                        if (run) HIP_TRY(launch_swt_pass_inv(c2, p->stream));
                         SwtPassArgs r = c1;
                         r.in0 = p->tmp; r.in1 = p->tmp + plane; r.out0 = dst + b * plane; r.along_y = 0;
-                        HIP_TRY(launch_swt_pass_inv(r, p->stream));
+                        if (run) HIP_TRY(launch_swt_pass_inv(r, p->stream));
                     }
                 }
             }
@@ -504,6 +505,7 @@ int inverse_impl(pdwt_plan* p) {
         std::vector<std::pair<int, int>> groups = swt ? std::vector<std::pair<int, int>>() : fused_groups_1d(p);
         int gi = (int)groups.size() - 1;
         for (int l = L; l >= 1; l--) {
+            const bool run = (only == 0 || only == l);
             if (gi >= 0 && groups[gi].first + groups[gi].second == l) {
                 // levels l-K+1 .. l undone in ONE launch
                 const int K = groups[gi].second, l0 = groups[gi].first;  // l0 = level of the output (0 = image)
@@ -511,7 +513,7 @@ int inverse_impl(pdwt_plan* p) {
                 for (int k = 0; k < K; k++) det[k] = p->band(l0 + 1 + k);
                 float* dst = (l0 == 0) ? p->image() : p->arena + p->approx_off[l0];
                 Stamp st(p, "dwt1_inv_fused");
-                HIP_TRY(launch_dwt1_inv_fused(cur, det, dst, rows, p->lc[l0], K, hlen, p->rec, p->stream));
+                if (only == 0 || only == l0 + 1) HIP_TRY(launch_dwt1_inv_fused(cur, det, dst, rows, p->lc[l0], K, hlen, p->rec, p->stream));
                 cur = dst;
                 l = l0 + 1;
                 gi--;
@@ -527,13 +529,13 @@ int inverse_impl(pdwt_plan* p) {
                 a.hlen = hlen;
                 a.fb = p->rec;
                 Stamp st(p, "dwt1_inv_level");
-                HIP_TRY(launch_dwt1_inv(a, p->stream));
+                if (run) HIP_TRY(launch_dwt1_inv(a, p->stream));
             } else {
                 SwtPassArgs r;
                 r.in0 = cur; r.in1 = Dl; r.out0 = dst; r.out1 = nullptr;
                 r.Nr = rows; r.Nc = p->info.Nc; r.f = 1 << (l - 1); r.along_y = 0; r.hlen = hlen; r.fb = p->rec;
                 Stamp st(p, "swt1_inv_level");
-                HIP_TRY(launch_swt_pass_inv(r, p->stream));
+                if (run) HIP_TRY(launch_swt_pass_inv(r, p->stream));
             }
             cur = dst;
         }
@@ -1110,6 +1112,32 @@ int pdwt_fill_image_hash(pdwt_handle h, uint32_t seed, float scale, long long in
     return PDWT_OK;
 }
 
+int pdwt_time_level(pdwt_handle h, int level, int inverse, int reps, float* ms_per_launch) {
+    CHECK_HANDLE(h);
+    if (!ms_per_launch || reps < 1 || level < 1 || level > h->info.nlevels)
+        return fail(PDWT_ERR_ARG, "pdwt_time_level: bad arguments");
+    DeviceGuard guard(h->device);
+    const bool was_timing = h->timing;
+    h->timing = false;
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    int rc = PDWT_OK;
+    for (int i = 0; i < 3 && rc == PDWT_OK; i++) rc = inverse ? inverse_impl(h, level) : forward_impl(h, level);
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipEventRecord(e0, h->stream));
+    for (int i = 0; i < reps && rc == PDWT_OK; i++) rc = inverse ? inverse_impl(h, level) : forward_impl(h, level);
+    HIP_TRY(hipEventRecord(e1, h->stream));
+    HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    h->timing = was_timing;
+    *ms_per_launch = ms / (float)reps;
+    return rc;
+}
+
 int pdwt_enable_kernel_timing(pdwt_handle h, int enable) {
     CHECK_HANDLE(h);
     h->timing = enable != 0;
@@ -1127,11 +1155,16 @@ int pdwt_reset_kernel_times(pdwt_handle h) {
 int pdwt_kernel_times(pdwt_handle h, float* ms, char (*names)[48], int cap) {
     CHECK_HANDLE(h);
     DeviceGuard guard(h->device);
-    HIP_TRY(hipStreamSynchronize(h->stream));
     const int n = (int)h->stamps.size();
+    if (n > 0 && !h->stamps[n - 1].stop) {  // closing event for the last launch
+        HIP_TRY(hipEventCreate(&h->stamps[n - 1].stop));
+        HIP_TRY(hipEventRecord(h->stamps[n - 1].stop, h->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(h->stream));
     for (int i = 0; i < n && i < cap; i++) {
         float t = 0.f;
-        HIP_TRY(hipEventElapsedTime(&t, h->stamps[i].start, h->stamps[i].stop));
+        hipEvent_t end = (i + 1 < n) ? h->stamps[i + 1].start : h->stamps[i].stop;
+        HIP_TRY(hipEventElapsedTime(&t, h->stamps[i].start, end));
         if (ms) ms[i] = t;
         if (names) memcpy(names[i], h->stamps[i].name, 48);
     }

@@ -405,6 +405,13 @@ class BatchedWavelets(object):
     def reset_kernel_times(self):
         check(self._lib.pdwt_reset_kernel_times(self._h))
 
+    def time_level(self, level, inverse=False, reps=50):
+        """Mean microseconds of the level-`level` launch: `reps` launches back to back between two HIP
+        events on the plan's stream (pdwt_time_level)."""
+        ms = C.c_float()
+        check(self._lib.pdwt_time_level(self._h, int(level), 1 if inverse else 0, int(reps), C.byref(ms)))
+        return ms.value * 1e3
+
     def kernel_times(self, cap=4096):
         """[(name, milliseconds)] of every launch recorded since the last reset."""
         ms = (C.c_float * cap)()
