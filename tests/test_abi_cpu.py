@@ -115,3 +115,15 @@ def test_sources_are_gfx950_only():
                 src = open(os.path.join(dirpath, f), errors="replace").read()
                 for bad in ("__HIP_PLATFORM_AMD__", "__CUDACC__", "cuda_runtime", "import triton", "hipify"):
                     assert bad not in src, (f, bad)
+
+
+def test_plain_c_program_links_against_the_abi(lib, tmp_path):
+    """The boundary is a C ABI: a C99 translation unit including only include/pypwt_amd.h must compile
+    with gcc and link against libpypwt_amd.so (it runs on the GPU box in tests/test_gpu_ops.py)."""
+    import subprocess
+    exe = str(tmp_path / "roundtrip")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "c_abi", "roundtrip.c"), "-L", os.path.join(ROOT, "pypwt_amd"),
+                           "-lpypwt_amd", "-Wl,-rpath," + os.path.join(ROOT, "pypwt_amd"), "-lm", "-o", exe])
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode in (0, 77), r.stdout  # 77: no HIP device here; unknown-wavelet check already ran

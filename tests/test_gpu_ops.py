@@ -325,3 +325,51 @@ def test_deferred_soft_threshold_fused_into_swt_inverse(W):
         w.forward(x)
         w.inverse()
         assert np.abs(w.image - x).max() < 7e-4
+
+
+def test_plain_c_program_round_trip(tmp_path):
+    """tests/c_abi/roundtrip.c: a C99 program using only include/pypwt_amd.h (create, forward, get_coeff,
+    norm2sq, soft_threshold, inverse, state refusals, get_image)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "roundtrip")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "tests", "c_abi", "roundtrip.c"), "-L", os.path.join(root, "pypwt_amd"),
+                           "-lpypwt_amd", "-Wl,-rpath," + os.path.join(root, "pypwt_amd"), "-lm", "-o", exe])
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "C ABI round trip: ok" in r.stdout
+
+
+@pytest.mark.parametrize("wname,shape,lv", [("db10", (1030, 1040), 2), ("db20", (1040, 1024), 2), ("sym20", (520, 2080), 3),
+                                              ("coif3", (1026, 1022), 3), ("bior6.8", (768, 1280), 4), ("db4", (4100, 1028), 2)])
+def test_large_shapes_long_filters(W, wname, shape, lv):
+    """Many tiles per launch for every tile shape of the tuned kernels (TY = 8 / 16 / 32 by filter length),
+    plus shapes whose rows are not a multiple of 4 (generic kernels) and mixed levels (tuned at level 1,
+    generic deeper)."""
+    x = oracle.hash_input(shape, 31)
+    w = W(x, wname, lv)
+    assert w.levels == lv
+    w.forward()
+    for g, r in zip(flat_coeffs(w), oracle.forward(x, wname, lv)):
+        assert g.shape == r.shape
+        assert np.abs(g - r).max() <= 1.5e-6 * (1 + lv) * max(np.abs(r).max(), 1.0), (wname, shape)
+    w.inverse()
+    assert np.abs(w.image - x).max() < (7e-4 if wname not in ("db20", "sym20") else 5e-3)
+
+
+@pytest.mark.parametrize("wname,n,lv", [("haar", 1 << 18, 9), ("db2", 1 << 18, 8), ("sym8", 3 << 16, 6), ("db20", 1 << 17, 5),
+                                        ("db4", 100000, 5), ("coif2", (1 << 16) + 2, 4)])
+def test_long_rows_1d_fused_and_unfused(W, wname, n, lv):
+    """1D rows long enough for many workgroups: fused multi-level launches when 2^(K+2) divides the length,
+    per-level kernels otherwise (and for the remainder levels), batched rows included."""
+    x = oracle.hash_input((3, n), 33)
+    for data in (x[0], x):
+        w = W(data, wname, lv, ndim=1)
+        assert w.levels == lv
+        w.forward()
+        ref = oracle.forward(np.atleast_2d(data), wname, lv, ndim=1)
+        for g, r in zip(flat_coeffs(w), ref):
+            assert np.abs(g - r).max() <= 1.5e-6 * (1 + lv) * max(np.abs(r).max(), 1.0), (wname, n)
+        w.inverse()
+        assert np.abs(w.image - np.atleast_2d(data)).max() < 2e-3
