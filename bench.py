@@ -50,22 +50,20 @@ def algorithmic_bytes_per_sample(cfg):
     return b
 
 
-def kernel_algorithmic_bytes(name, occurrence, cfg, batch):
-    """Algorithmic bytes of ONE launch of a level kernel: its input read once + its outputs
-    written once (DESIGN.md 'Kernels').  occurrence = index of this kernel within the step."""
+def kernel_algorithmic_bytes(label, cfg, batch):
+    """Algorithmic bytes of ONE launch: its input read once + its outputs written once (DESIGN.md
+    'Kernels').  label = 'name[Ll]' from label_step_kernels."""
     Nr, Nc, wname, L, swt, ndim, beta, _ = cfg
     samples = batch * Nr * Nc
+    name, lvl = label[:-1].split("[")
     name = name.replace("+soft", "")  # SWT inverse level with the deferred soft-threshold folded in
-    if name in ("dwt2_fwd_level", "dwt1_fwd_level"):
-        lvl = occurrence + 1
-    elif name in ("dwt2_inv_level", "dwt1_inv_level"):
-        lvl = L - occurrence
-    else:
-        lvl = None
+    lvl = None if lvl == "-" else int(lvl[1:])
     if name in ("dwt1_fwd_fused", "dwt1_inv_fused"):
-        # all levels of one direction in one launch: input read once, every band written once.
-        # (a second fused launch only exists for > 6 levels and works on 1/64 of the samples)
-        return 8.0 * samples if occurrence == 0 else 0.0
+        return 8.0 * samples / (2 ** (lvl - 1))  # all remaining levels: input once, every band once
+    if name in ("dwt2_fwd_pyr2", "dwt2_inv_pyr2"):
+        # two levels in one launch: the pair's input read once, details of the first and all four bands
+        # of the second level written once = 8 B per sample entering the pair
+        return 8.0 * samples / (4 ** (lvl - 1))
     if name.startswith("dwt2"):
         return 8.0 * samples / (4 ** (lvl - 1))
     if name.startswith("dwt1"):
@@ -80,17 +78,38 @@ def kernel_algorithmic_bytes(name, occurrence, cfg, batch):
     return 0.0
 
 
+def label_step_kernels(names, L):
+    """Launch names of ONE step, in order -> labels 'name[Ll]' with l = the (first) transform level the
+    launch works on.  Forward launches count levels up from 1, inverse launches down from L; a pyramid
+    launch covers two levels, a fused 1D launch all remaining ones."""
+    out = []
+    f, i = 1, L
+    for n in names:
+        base = n.replace("+soft", "")
+        if base in ("dwt2_fwd_level", "dwt1_fwd_level", "swt2_fwd_level", "swt1_fwd_level", "nonsep_fwd_level"):
+            out.append("%s[L%d]" % (n, f)); f += 1
+        elif base == "dwt2_fwd_pyr2":
+            out.append("%s[L%d]" % (n, f)); f += 2
+        elif base == "dwt1_fwd_fused":
+            out.append("%s[L%d]" % (n, f)); f = L + 1
+        elif base in ("dwt2_inv_level", "dwt1_inv_level", "swt2_inv_level", "swt1_inv_level", "nonsep_inv_level"):
+            out.append("%s[L%d]" % (n, i)); i -= 1
+        elif base == "dwt2_inv_pyr2":
+            out.append("%s[L%d]" % (n, i - 1)); i -= 2
+        elif base == "dwt1_inv_fused":
+            out.append("%s[L%d]" % (n, 1)); i = 0
+        else:
+            out.append("%s[-]" % n)
+    return out
+
+
 def level_of_kernel(kernel, L):
-    """'dwt2_inv_level[3]' -> (level, is_inverse) for pdwt_time_level; None for non-level kernels."""
-    name, occ = kernel[:-1].split("[")
-    occ = int(occ)
-    if name in ("dwt1_fwd_fused", "dwt1_inv_fused"):
-        return (1, name == "dwt1_inv_fused") if occ == 0 else None
-    if name.endswith("fwd_level"):
-        return occ + 1, False
-    if name.endswith("inv_level") or name.endswith("inv_level+soft"):
-        return L - occ, True
-    return None
+    """'dwt2_inv_level[L1]' -> (level, is_inverse) for pdwt_time_level; None when the launch is not a
+    single-level one that pdwt_time_level can repeat."""
+    name, lvl = kernel[:-1].split("[")
+    if lvl == "-":
+        return None
+    return int(lvl[1:]), ("_inv_" in name)
 
 
 def parse_args():
@@ -264,18 +283,15 @@ def main():
     plan.enable_kernel_timing(False)
     plan.reset_kernel_times()
     per_step = len(times) // args.steps
+    labels = label_step_kernels([n for n, _ in times[:per_step]], L)
     agg = {}
     for i, (name, ms) in enumerate(times):
-        pos = i % per_step
-        occ = sum(1 for j in range(pos) if times[j][0] == name)
-        key = (name, occ)
-        agg.setdefault(key, []).append(ms)
+        agg.setdefault(labels[i % per_step], []).append(ms)
     kernels = []
-    for (name, occ), v in agg.items():
+    for label, v in agg.items():
         avg_ms = sum(v) / len(v)
-        abytes = kernel_algorithmic_bytes(name, occ, cfg, B)
-        kernels.append({"kernel": "%s[%d]" % (name, occ), "avg_us": avg_ms * 1e3,
-                        "algorithmic_bytes": abytes,
+        abytes = kernel_algorithmic_bytes(label, cfg, B)
+        kernels.append({"kernel": label, "avg_us": avg_ms * 1e3, "algorithmic_bytes": abytes,
                         "GBps": abytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0})
     kernels.sort(key=lambda k: -k["avg_us"])
     dom = kernels[0]

@@ -21,6 +21,7 @@ LIB = os.path.join(HERE, "libpypwt_amd.so")
 SOURCES = [
     "launch_dwt2.hip",
     "launch_dwt2_fast.hip",
+    "launch_dwt2_pyramid.hip",
     "launch_dwt1.hip",
     "launch_dwt1_fused.hip",
     "launch_swt.hip",

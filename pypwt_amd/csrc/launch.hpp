@@ -20,6 +20,12 @@ hipError_t launch_dwt2_inv(const Inv2DArgs& a, int batch, hipStream_t s);
 // tuned kernels; hipErrorNotSupported = preconditions not met, use the generic launcher
 hipError_t try_launch_dwt2_fwd_fast(const Fwd2DArgs& a, int batch, hipStream_t s);
 hipError_t try_launch_dwt2_inv_fast(const Inv2DArgs& a, int batch, hipStream_t s);
+// two consecutive 2D levels in one launch (small levels only, see launch_dwt2_pyramid.hip)
+bool dwt2_pyramid_supported(int hlen, int N0r, int N0c);
+hipError_t launch_dwt2_fwd_pyr2(const float* in, float* const det1[3], float* const band2[4], int N0r, int N0c,
+                                int hlen, const FilterBank& fb, int batch, hipStream_t s);
+hipError_t launch_dwt2_inv_pyr2(const float* const band2[4], const float* const det1[3], float* out, int N0r, int N0c,
+                                int hlen, const FilterBank& fb, int batch, hipStream_t s);
 hipError_t launch_dwt1_fwd(const Fwd1DArgs& a, hipStream_t s);
 hipError_t launch_dwt1_inv(const Inv1DArgs& a, hipStream_t s);
 // K consecutive 1D levels in one launch (2^K must divide N0, even hlen); hipErrorNotSupported otherwise

@@ -1,0 +1,102 @@
+// launch_dwt2_pyramid.hip -- launchers of the two-levels-per-launch 2D DWT kernels (gfx950).
+//
+// Used by the host only for SMALL level pairs (plan.cpp: pyramid_pairs), where a launch's fixed cost
+// dominates: kbench on MI355X, db4, one image (profiles/r01e_kbench_pyramid.txt):
+//     level input   two launches   one pyramid launch
+//       512^2         8.8 us            5.4 us   (forward)      8.4 -> 5.3 us (inverse)
+//      1024^2         9.3 us            5.5 us                   9.0 -> 6.2 us
+//      2048^2        13.8 us           12.2 us                  14.4 -> 12.7 us
+//      4096^2        33.6 us           40.3 us  (slower: 1.9x recomputed halo, half the occupancy)
+#include "dwt2_pyramid_kernels.hpp"
+#include "launch.hpp"
+#include "launch_util.hpp"
+
+namespace pdwt {
+
+static void interleave(FilterBankI& o, const FilterBank& fb) {
+    for (int i = 0; i < kMaxTaps; i++) {
+        o.t[i].x = fb.lo[i];
+        o.t[i].y = fb.hi[i];
+    }
+}
+
+static bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+bool dwt2_pyramid_supported(int hlen, int N0r, int N0c) {
+    // even sizes at both levels (exact periodization), 16-B aligned rows at level l+1
+    return (hlen == 2 || hlen == 4 || hlen == 6 || hlen == 8) && (N0r % 4) == 0 && (N0c % 16) == 0 && N0r >= 4 &&
+           N0c >= 16;
+}
+
+template <int HLEN>
+static hipError_t run_fwd(FwdPyr2Args& a, int batch, hipStream_t s) {
+    constexpr int TX2 = 32, TY2 = 8, NT = 512;
+    constexpr size_t lds = (size_t)Pyr2Geom<HLEN, TX2, TY2>::LDS_FLOATS * sizeof(float);
+    static_assert(lds <= 64 * 1024, "fits the default dynamic-LDS limit");
+    a.tiles_x = cdiv(a.N0c / 4, TX2);
+    a.tiles_y = cdiv(a.N0r / 4, TY2);
+    const int chunk = (a.tiles_x * a.tiles_y + 7) / 8;
+    hipLaunchKernelGGL((dwt2_fwd_pyr2_kernel<HLEN, TX2, TY2, NT>), dim3(8 * chunk, batch), dim3(NT), lds, s, a);
+    return hipGetLastError();
+}
+
+template <int HLEN>
+static hipError_t run_inv(InvPyr2Args& a, int batch, hipStream_t s) {
+    constexpr int TX = 64, TY = 8, NT = 256;
+    constexpr size_t lds = (size_t)InvPyr2Geom<HLEN, TX, TY>::LDS_FLOATS * sizeof(float);
+    static_assert(lds <= 64 * 1024, "fits the default dynamic-LDS limit");
+    a.tiles_x = cdiv(a.N0c, 2 * TX);
+    a.tiles_y = cdiv(a.N0r, 2 * TY);
+    const int chunk = (a.tiles_x * a.tiles_y + 7) / 8;
+    hipLaunchKernelGGL((dwt2_inv_pyr2_kernel<HLEN, TX, TY, NT>), dim3(8 * chunk, batch), dim3(NT), lds, s, a);
+    return hipGetLastError();
+}
+
+// in (N0r,N0c) -> details of level l (det1 = H,V,D) and all four bands of level l+1 (band2 = A,H,V,D)
+hipError_t launch_dwt2_fwd_pyr2(const float* in, float* const det1[3], float* const band2[4], int N0r, int N0c,
+                                int hlen, const FilterBank& fb, int batch, hipStream_t s) {
+    if (!dwt2_pyramid_supported(hlen, N0r, N0c)) return hipErrorNotSupported;
+    if (!al16(in) || !al16(det1[0]) || !al16(det1[1]) || !al16(det1[2]) || !al16(band2[0]) || !al16(band2[1]) ||
+        !al16(band2[2]) || !al16(band2[3]))
+        return hipErrorNotSupported;
+    FwdPyr2Args a;
+    a.in = in; a.H1 = det1[0]; a.V1 = det1[1]; a.D1 = det1[2];
+    a.A2 = band2[0]; a.H2 = band2[1]; a.V2 = band2[2]; a.D2 = band2[3];
+    a.N0r = N0r; a.N0c = N0c;
+    a.in_bstride = (long long)N0r * N0c;
+    a.l1_bstride = (long long)(N0r / 2) * (N0c / 2);
+    a.l2_bstride = (long long)(N0r / 4) * (N0c / 4);
+    interleave(a.fb, fb);
+    switch (hlen) {
+        case 2: return run_fwd<2>(a, batch, s);
+        case 4: return run_fwd<4>(a, batch, s);
+        case 6: return run_fwd<6>(a, batch, s);
+        case 8: return run_fwd<8>(a, batch, s);
+    }
+    return hipErrorNotSupported;
+}
+
+hipError_t launch_dwt2_inv_pyr2(const float* const band2[4], const float* const det1[3], float* out, int N0r, int N0c,
+                                int hlen, const FilterBank& fb, int batch, hipStream_t s) {
+    if (!dwt2_pyramid_supported(hlen, N0r, N0c)) return hipErrorNotSupported;
+    if (!al16(out) || !al16(det1[0]) || !al16(det1[1]) || !al16(det1[2]) || !al16(band2[0]) || !al16(band2[1]) ||
+        !al16(band2[2]) || !al16(band2[3]))
+        return hipErrorNotSupported;
+    InvPyr2Args a;
+    a.A2 = band2[0]; a.H2 = band2[1]; a.V2 = band2[2]; a.D2 = band2[3];
+    a.H1 = det1[0]; a.V1 = det1[1]; a.D1 = det1[2];
+    a.out = out; a.N0r = N0r; a.N0c = N0c;
+    a.out_bstride = (long long)N0r * N0c;
+    a.l1_bstride = (long long)(N0r / 2) * (N0c / 2);
+    a.l2_bstride = (long long)(N0r / 4) * (N0c / 4);
+    interleave(a.fb, fb);
+    switch (hlen) {
+        case 2: return run_inv<2>(a, batch, s);
+        case 4: return run_inv<4>(a, batch, s);
+        case 6: return run_inv<6>(a, batch, s);
+        case 8: return run_inv<8>(a, batch, s);
+    }
+    return hipErrorNotSupported;
+}
+
+}  // namespace pdwt

@@ -286,6 +286,29 @@ int create_impl(const float* img, int batch, int Nr, int Nc, const char* wname, 
 
 // ---------------------------------------------------------------- level loops
 
+// First levels l of the 2D level pairs (l, l+1) that run as ONE pyramid launch: separable DWT, short even
+// filters, even / aligned sizes, and SMALL levels only -- at most 2^20 samples enter the pair, where the
+// fixed cost of a launch (not bandwidth) is what the level costs (launch_dwt2_pyramid.hip has the numbers).
+std::vector<int> pyramid_pairs(const pdwt_plan* p) {
+    std::vector<int> v;
+    if (p->info.ndims != 2 || p->info.do_swt || !p->do_separable || getenv("PDWT_NO_PYRAMID")) return v;
+    const int L = p->info.nlevels;
+    for (int l = 1; l + 1 <= L; l++) {
+        const long long samples = (long long)p->batch * p->lr[l - 1] * p->lc[l - 1];
+        if (samples <= (1LL << 20) && dwt2_pyramid_supported(p->info.hlen, p->lr[l - 1], p->lc[l - 1])) {
+            v.push_back(l);
+            l++;  // level l+1 is consumed by the pair
+        }
+    }
+    return v;
+}
+
+bool in_list(const std::vector<int>& v, int x) {
+    for (int e : v)
+        if (e == x) return true;
+    return false;
+}
+
 constexpr int kMaxFusedLevelsHost = 10;  // == kMaxFusedLevels of dwt1_fused_kernels.hpp
 
 // Partition of the 1D levels into runs handled by ONE fused launch: (first level - 1, K) with K >= 2,
@@ -317,8 +340,21 @@ int forward_impl(pdwt_plan* p, int only = 0) {
     const bool swt = p->info.do_swt != 0;
     const float* src = p->image();
     if (p->info.ndims == 2) {
+        const std::vector<int> pyr = pyramid_pairs(p);
         for (int l = 1; l <= L; l++) {
             const bool run = (only == 0 || only == l);
+            if (in_list(pyr, l)) {
+                // levels l and l+1 in one launch; A_l never leaves LDS
+                float* det1[3] = {p->band(3 * (l - 1) + 1), p->band(3 * (l - 1) + 2), p->band(3 * (l - 1) + 3)};
+                float* A2 = (l + 1 == L) ? p->band(0) : p->arena + p->approx_off[l + 1];
+                float* band2[4] = {A2, p->band(3 * l + 1), p->band(3 * l + 2), p->band(3 * l + 3)};
+                Stamp st(p, "dwt2_fwd_pyr2");
+                if (run) HIP_TRY(launch_dwt2_fwd_pyr2(src, det1, band2, p->lr[l - 1], p->lc[l - 1], hlen, p->dec, B,
+                                                      p->stream));
+                src = A2;
+                l++;
+                continue;
+            }
             float* dstA = (l == L) ? p->band(0)
                                    : p->arena + (swt ? p->approx_off[l & 1] : p->approx_off[l]);
             float* H = p->band(3 * (l - 1) + 1);
@@ -427,7 +463,22 @@ int inverse_impl(pdwt_plan* p, int only = 0) {
     const bool swt = p->info.do_swt != 0;
     const float* cur = p->band(0);
     if (p->info.ndims == 2) {
+        const std::vector<int> pyr = pyramid_pairs(p);
         for (int l = L; l >= 1; l--) {
+            if (l >= 2 && in_list(pyr, l - 1)) {
+                // levels l and l-1 undone in one launch: A_{l-1} is synthesised in LDS
+                const int l1 = l - 1;
+                const float* band2[4] = {cur, p->band(3 * (l - 1) + 1), p->band(3 * (l - 1) + 2), p->band(3 * (l - 1) + 3)};
+                const float* det1[3] = {p->band(3 * (l1 - 1) + 1), p->band(3 * (l1 - 1) + 2), p->band(3 * (l1 - 1) + 3)};
+                float* dst = (l1 == 1) ? p->image() : p->arena + p->approx_off[l1 - 1];
+                Stamp st(p, "dwt2_inv_pyr2");
+                if (only == 0 || only == l1)
+                    HIP_TRY(launch_dwt2_inv_pyr2(band2, det1, dst, p->lr[l1 - 1], p->lc[l1 - 1], hlen, p->rec, B,
+                                                 p->stream));
+                cur = dst;
+                l--;
+                continue;
+            }
             const bool run = (only == 0 || only == l);
             float* dst = (l == 1) ? p->image()
                                   : p->arena + (swt ? p->approx_off[(l - 1) & 1] : p->approx_off[l - 1]);

@@ -11,6 +11,7 @@
 #include "../../pypwt_amd/csrc/dwt1_kernels.hpp"
 #include "../../pypwt_amd/csrc/dwt2_fast_kernels.hpp"
 #include "../../pypwt_amd/csrc/dwt2_kernels.hpp"
+#include "../../pypwt_amd/csrc/dwt2_pyramid_kernels.hpp"
 #include "../../pypwt_amd/csrc/nonsep_kernels.hpp"
 #include "../../pypwt_amd/csrc/swt_kernels.hpp"
 
@@ -350,6 +351,65 @@ EMU_API int emu_dwt1_fused(int inverse, float* io, int rows, int N0, int K, cons
             EMU_EVEN_HLENS(X)
 #undef X
         }
+    }
+    return -1;
+}
+
+// ------------------------------------------------------------------ two-level pyramid (forward)
+template <int HLEN, int TX2, int TY2, int NT>
+static void run_fwd_pyr2(FwdPyr2Args a, int batch) {
+    std::vector<float> smem(Pyr2Geom<HLEN, TX2, TY2>::LDS_FLOATS + 64, NAN);
+    a.tiles_x = cdiv(a.N0c / 4, TX2); a.tiles_y = cdiv(a.N0r / 4, TY2);
+    for (int bz = 0; bz < batch; bz++)
+        for (int by = 0; by < a.tiles_y; by++)
+            for (int bx = 0; bx < a.tiles_x; bx++) dwt2_fwd_pyr2_tile<HLEN, TX2, TY2, NT>(a, bx, by, bz, smem.data());
+}
+
+// l1: H,V,D planes of the first level (3 x batch x N0r/2 x N0c/2), l2: A,H,V,D of the second (4 x ...)
+EMU_API int emu_dwt2_fwd_pyr2(const float* in, int batch, int N0r, int N0c, const float* lo, const float* hi, int hlen,
+                              int tile, float* l1, float* l2) {
+    if ((hlen & 1) || hlen > 8 || (N0c & 7) || (N0r & 3)) return -2;
+    FwdPyr2Args a;
+    const long long n1 = (long long)batch * (N0r / 2) * (N0c / 2), n2 = (long long)batch * (N0r / 4) * (N0c / 4);
+    a.in = in; a.H1 = l1; a.V1 = l1 + n1; a.D1 = l1 + 2 * n1;
+    a.A2 = l2; a.H2 = l2 + n2; a.V2 = l2 + 2 * n2; a.D2 = l2 + 3 * n2;
+    a.N0r = N0r; a.N0c = N0c;
+    a.in_bstride = (long long)N0r * N0c; a.l1_bstride = (long long)(N0r / 2) * (N0c / 2);
+    a.l2_bstride = (long long)(N0r / 4) * (N0c / 4);
+    set_bank_i(a.fb, lo, hi, hlen);
+    switch (hlen) {
+#define X(h) case h: if (tile == 0) run_fwd_pyr2<h, 32, 4, 256>(a, batch); else run_fwd_pyr2<h, 32, 8, 256>(a, batch); return 0;
+        X(2) X(4) X(6) X(8)
+#undef X
+    }
+    return -1;
+}
+
+// ------------------------------------------------------------------ two-level pyramid (inverse)
+template <int HLEN, int TX, int TY, int NT>
+static void run_inv_pyr2(InvPyr2Args a, int batch) {
+    std::vector<float> smem(InvPyr2Geom<HLEN, TX, TY>::LDS_FLOATS + 64, NAN);
+    a.tiles_x = cdiv(a.N0c, 2 * TX); a.tiles_y = cdiv(a.N0r, 2 * TY);
+    for (int bz = 0; bz < batch; bz++)
+        for (int by = 0; by < a.tiles_y; by++)
+            for (int bx = 0; bx < a.tiles_x; bx++) dwt2_inv_pyr2_tile<HLEN, TX, TY, NT>(a, bx, by, bz, smem.data());
+}
+
+EMU_API int emu_dwt2_inv_pyr2(const float* l1, const float* l2, int batch, int N0r, int N0c, const float* lo,
+                              const float* hi, int hlen, int tile, float* out) {
+    if ((hlen & 1) || hlen > 8 || (N0c & 15) || (N0r & 3)) return -2;
+    InvPyr2Args a;
+    const long long n1 = (long long)batch * (N0r / 2) * (N0c / 2), n2 = (long long)batch * (N0r / 4) * (N0c / 4);
+    a.H1 = l1; a.V1 = l1 + n1; a.D1 = l1 + 2 * n1;
+    a.A2 = l2; a.H2 = l2 + n2; a.V2 = l2 + 2 * n2; a.D2 = l2 + 3 * n2;
+    a.out = out; a.N0r = N0r; a.N0c = N0c;
+    a.out_bstride = (long long)N0r * N0c; a.l1_bstride = (long long)(N0r / 2) * (N0c / 2);
+    a.l2_bstride = (long long)(N0r / 4) * (N0c / 4);
+    set_bank_i(a.fb, lo, hi, hlen);
+    switch (hlen) {
+#define X(h) case h: if (tile == 0) run_inv_pyr2<h, 64, 8, 256>(a, batch); else run_inv_pyr2<h, 64, 16, 256>(a, batch); return 0;
+        X(2) X(4) X(6) X(8)
+#undef X
     }
     return -1;
 }

@@ -29,9 +29,15 @@ def test_algorithmic_bytes_match_baseline_md():
     assert bench.algorithmic_bytes_per_sample(bench.CONFIGS["cfg4"]) == 256.0  # 68 + 120 + 68
     # level-1 kernels move 8 B per input sample; each deeper 2D level a quarter of that
     c = bench.CONFIGS["cfg2"]
-    assert bench.kernel_algorithmic_bytes("dwt2_fwd_level", 0, c, 1) == 8.0 * 4096 * 4096
-    assert bench.kernel_algorithmic_bytes("dwt2_fwd_level", 1, c, 1) == 2.0 * 4096 * 4096
-    assert bench.kernel_algorithmic_bytes("dwt2_inv_level", 3, c, 1) == 8.0 * 4096 * 4096
+    assert bench.kernel_algorithmic_bytes("dwt2_fwd_level[L1]", c, 1) == 8.0 * 4096 * 4096
+    assert bench.kernel_algorithmic_bytes("dwt2_fwd_level[L2]", c, 1) == 2.0 * 4096 * 4096
+    assert bench.kernel_algorithmic_bytes("dwt2_inv_level[L1]", c, 1) == 8.0 * 4096 * 4096
+    # one step of the 4-level benchmark: levels 3+4 run as one pyramid launch per direction
+    names = ["dwt2_fwd_level", "dwt2_fwd_level", "dwt2_fwd_pyr2", "dwt2_inv_pyr2", "dwt2_inv_level", "dwt2_inv_level"]
+    assert bench.label_step_kernels(names, 4) == ["dwt2_fwd_level[L1]", "dwt2_fwd_level[L2]", "dwt2_fwd_pyr2[L3]",
+                                                   "dwt2_inv_pyr2[L3]", "dwt2_inv_level[L2]", "dwt2_inv_level[L1]"]
+    assert bench.level_of_kernel("dwt2_inv_level[L1]", 4) == (1, True)
+    assert bench.kernel_algorithmic_bytes("dwt2_fwd_pyr2[L3]", c, 1) == 8.0 * 1024 * 1024
 
 
 def _run(cmd):

@@ -325,3 +325,41 @@ def test_emu_dwt1_fused_pyramid(wname):
             assert lib().emu_dwt1_fused(1, P(out), rows, N0, K, P(rlo), P(rhi), hlen, small, P(det_in), P(bands[0])) == 0
             assert np.isfinite(out).all(), (wname, N0, K, small)
             assert np.abs(out - want).max() <= _tol(want) * (1 + K), (wname, rows, N0, K, small)
+
+
+# ----------------------------------------------------------------------------- two-level pyramid
+@pytest.mark.parametrize("wname", ["haar", "db2", "db3", "db4", "sym4", "bior3.1"])
+def test_emu_dwt2_fwd_pyramid(wname):
+    hlen, dlo, dhi, rlo, rhi = oracle.filters(wname)
+    for si, (B, shape) in enumerate([(1, (64, 64)), (1, (32, 136)), (2, (40, 72)), (1, (128, 512)), (1, (4, 8)), (1, (260, 264))]):
+        x = oracle.hash_input((B,) + shape, 8100 + si)
+        n1 = (shape[0] // 2, shape[1] // 2)
+        n2 = (shape[0] // 4, shape[1] // 4)
+        for tile in (0, 1):
+            l1 = np.full((3, B) + n1, np.nan, dtype=np.float32)
+            l2 = np.full((4, B) + n2, np.nan, dtype=np.float32)
+            assert lib().emu_dwt2_fwd_pyr2(P(x), B, shape[0], shape[1], P(dlo), P(dhi), hlen, tile, P(l1), P(l2)) == 0
+            for b in range(B):
+                ref = oracle.forward(x[b], wname, 2, ndim=2)  # [A2, H1,V1,D1, H2,V2,D2]
+                got = [l2[0, b], l1[0, b], l1[1, b], l1[2, b], l2[1, b], l2[2, b], l2[3, b]]
+                for k, (g, r) in enumerate(zip(got, ref)):
+                    assert np.isfinite(g).all(), (wname, shape, tile, k)
+                    assert np.abs(g - r).max() <= 2 * _tol(r), (wname, shape, tile, k)
+
+
+@pytest.mark.parametrize("wname", ["haar", "db2", "db3", "db4", "sym4", "bior3.1"])
+def test_emu_dwt2_inv_pyramid(wname):
+    hlen, dlo, dhi, rlo, rhi = oracle.filters(wname)
+    for si, (B, shape) in enumerate([(1, (64, 64)), (1, (32, 144)), (2, (40, 80)), (1, (128, 512)), (1, (4, 16)), (1, (260, 272))]):
+        n1 = (shape[0] // 2, shape[1] // 2)
+        n2 = (shape[0] // 4, shape[1] // 4)
+        l1 = np.stack([oracle.hash_input((B,) + n1, 8500 + 10 * si + k, 2.0) - 1.0 for k in range(3)])  # H1,V1,D1
+        l2 = np.stack([oracle.hash_input((B,) + n2, 8600 + 10 * si + k, 2.0) - 1.0 for k in range(4)])  # A2,H2,V2,D2
+        for tile in (0, 1):
+            out = np.full((B,) + shape, np.nan, dtype=np.float32)
+            assert lib().emu_dwt2_inv_pyr2(P(l1), P(l2), B, shape[0], shape[1], P(rlo), P(rhi), hlen, tile, P(out)) == 0
+            for b in range(B):
+                bands = [l2[0, b], l1[0, b], l1[1, b], l1[2, b], l2[1, b], l2[2, b], l2[3, b]]
+                want = oracle.inverse(bands, shape, wname, 2, ndim=2)
+                assert np.isfinite(out[b]).all(), (wname, shape, tile)
+                assert np.abs(out[b] - want).max() <= 3 * _tol(want), (wname, shape, tile)

@@ -13,6 +13,7 @@
 
 #include "dwt2_fast_kernels.hpp"
 #include "dwt2_kernels.hpp"
+#include "dwt2_pyramid_kernels.hpp"
 
 using namespace pdwt;
 
@@ -187,6 +188,48 @@ static void bench_inv_fast(const char* tag, const float* in4, float* out, int N,
     printf("%-34s N=%d B=%d lds=%6zu  %8.2f us  %7.1f GB/s (algorithmic)\n", tag, N, batch, lds, us, bytes / us / 1e3);
 }
 
+template <int HLEN, int TX2, int TY2, int NT>
+static void bench_fwd_pyr2(const char* tag, const float* in, float* out, int N, int batch) {
+    FwdPyr2Args a;
+    const long long n1 = (long long)batch * (N / 2) * (N / 2), n2 = (long long)batch * (N / 4) * (N / 4);
+    a.in = in; a.H1 = out; a.V1 = out + n1; a.D1 = out + 2 * n1;
+    float* l2 = out + 3 * n1;
+    a.A2 = l2; a.H2 = l2 + n2; a.V2 = l2 + 2 * n2; a.D2 = l2 + 3 * n2;
+    a.N0r = N; a.N0c = N;
+    a.in_bstride = (long long)N * N; a.l1_bstride = (long long)(N / 2) * (N / 2); a.l2_bstride = (long long)(N / 4) * (N / 4);
+    a.tiles_x = (N / 4 + TX2 - 1) / TX2; a.tiles_y = (N / 4 + TY2 - 1) / TY2;
+    memset(&a.fb, 0, sizeof(a.fb));
+    for (int i = 0; i < 8; i++) { a.fb.t[i].x = DB4_LO[i]; a.fb.t[i].y = DB4_HI[i]; }
+    const size_t lds = (size_t)Pyr2Geom<HLEN, TX2, TY2>::LDS_FLOATS * sizeof(float);
+    if (lds > 64 * 1024)
+        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(dwt2_fwd_pyr2_kernel<HLEN, TX2, TY2, NT>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    const int chunk = (a.tiles_x * a.tiles_y + 7) / 8;
+    float us = time_it([&] { hipLaunchKernelGGL((dwt2_fwd_pyr2_kernel<HLEN, TX2, TY2, NT>), dim3(8 * chunk, batch), dim3(NT), lds, 0, a); });
+    printf("%-34s N=%d B=%d lds=%6zu  %8.2f us  (two levels in one launch)\n", tag, N, batch, lds, us);
+}
+
+template <int HLEN, int TX, int TY, int NT>
+static void bench_inv_pyr2(const char* tag, const float* in, float* out, int N, int batch) {
+    InvPyr2Args a;
+    const long long n1 = (long long)batch * (N / 2) * (N / 2), n2 = (long long)batch * (N / 4) * (N / 4);
+    a.H1 = in; a.V1 = in + n1; a.D1 = in + 2 * n1;
+    const float* l2 = in + 3 * n1;
+    a.A2 = l2; a.H2 = l2 + n2; a.V2 = l2 + 2 * n2; a.D2 = l2 + 3 * n2;
+    a.out = out; a.N0r = N; a.N0c = N;
+    a.out_bstride = (long long)N * N; a.l1_bstride = (long long)(N / 2) * (N / 2); a.l2_bstride = (long long)(N / 4) * (N / 4);
+    a.tiles_x = (N + 2 * TX - 1) / (2 * TX); a.tiles_y = (N + 2 * TY - 1) / (2 * TY);
+    memset(&a.fb, 0, sizeof(a.fb));
+    for (int i = 0; i < 8; i++) { a.fb.t[i].x = DB4_LO[7 - i]; a.fb.t[i].y = DB4_HI[7 - i]; }
+    const size_t lds = (size_t)InvPyr2Geom<HLEN, TX, TY>::LDS_FLOATS * sizeof(float);
+    if (lds > 64 * 1024)
+        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(dwt2_inv_pyr2_kernel<HLEN, TX, TY, NT>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    const int chunk = (a.tiles_x * a.tiles_y + 7) / 8;
+    float us = time_it([&] { hipLaunchKernelGGL((dwt2_inv_pyr2_kernel<HLEN, TX, TY, NT>), dim3(8 * chunk, batch), dim3(NT), lds, 0, a); });
+    printf("%-34s N=%d B=%d lds=%6zu  %8.2f us  (two levels in one launch)\n", tag, N, batch, lds, us);
+}
+
 int main(int argc, char** argv) {
     const int N = argc > 1 ? atoi(argv[1]) : 4096;
     const int B = argc > 2 ? atoi(argv[2]) : 1;
@@ -218,6 +261,13 @@ int main(int argc, char** argv) {
     for (int w : {2, 4, 6, 8, 12}) bench_fwd_stream<8, 64, 8, 256>("STREAM fwd db4 TX64 TY8 NT256", a, b, N, B, w);
     for (int w : {2, 4, 6, 8}) bench_fwd_stream<8, 64, 16, 256>("STREAM fwd db4 TX64 TY16 NT256", a, b, N, B, w);
     for (int w : {2, 4, 8}) bench_fwd_stream<8, 64, 4, 128>("STREAM fwd db4 TX64 TY4 NT128", a, b, N, B, w);
+    bench_fwd_pyr2<8, 32, 4, 256>("PYR2 fwd db4 TX2=32 TY2=4 NT256", a, b, N, B);
+    bench_fwd_pyr2<8, 32, 8, 256>("PYR2 fwd db4 TX2=32 TY2=8 NT256", a, b, N, B);
+    bench_fwd_pyr2<8, 32, 8, 512>("PYR2 fwd db4 TX2=32 TY2=8 NT512", a, b, N, B);
+    bench_fwd_pyr2<8, 64, 4, 256>("PYR2 fwd db4 TX2=64 TY2=4 NT256", a, b, N, B);
+    bench_inv_pyr2<8, 64, 8, 256>("PYR2 inv db4 TX=64 TY=8 NT256", b, a, N, B);
+    bench_inv_pyr2<8, 64, 16, 256>("PYR2 inv db4 TX=64 TY=16 NT256", b, a, N, B);
+    bench_inv_pyr2<8, 64, 16, 512>("PYR2 inv db4 TX=64 TY=16 NT512", b, a, N, B);
     bench_fwd_fast<8, 64, 16, 512>("FAST fwd db4 TX64 TY16 NT512", a, b, N, B);
     bench_fwd_fast<8, 128, 8, 512>("FAST fwd db4 TX128 TY8 NT512", a, b, N, B);
     bench_fwd_fast<8, 64, 4, 128>("FAST fwd db4 TX64 TY4 NT128", a, b, N, B);
