@@ -136,14 +136,17 @@ PDWT_DEVICE void dwt1_fwd_fused_tile(const Fwd1DFusedArgs& a, int bx, int row, f
             float* PDWT_RESTRICT outA = a.app + (long long)row * Nk;
             for (int t = tid; 2 * t < nk; t += NT) {
                 float v[NV];
+v4f w[NV / 4];
 #pragma unroll
-                for (int q = 0; q < NV / 4; ++q) {
-                    const v4f w = lds_read16(src + 4 * t + 4 * q);
-                    v[4 * q + 0] = w.x;
-                    v[4 * q + 1] = w.y;
-                    v[4 * q + 2] = w.z;
-                    v[4 * q + 3] = w.w;
-                }
+for (int q = 0; q < NV / 4; ++q) w[q] = lds_load16(src + 4 * t + 4 * q);
+#pragma unroll
+for (int q = 0; q < NV / 4; ++q) {
+    lds_pin(w[q]);
+                    v[4 * q + 0] = w[q].x;
+                    v[4 * q + 1] = w[q].y;
+                    v[4 * q + 2] = w[q].z;
+                    v[4 * q + 3] = w[q].w;
+}
                 v2f acc0 = mk2(0.f, 0.f), acc1 = mk2(0.f, 0.f);  // (A, D) of outputs 2t and 2t+1
 #pragma unroll
                 for (int j = 0; j < HLEN; ++j) {

@@ -77,13 +77,16 @@ PDWT_DEVICE void fwd_fast_row_pass(int tid, const float* sIn, v2f* tLH, const Fi
     for (int r = tid / HT; r < RY; r += NT / HT) {
         float v[NV];
         const float* p4 = sIn + r * RXA + 4 * t;
+        v4f w[NV / 4];
+#pragma unroll
+        for (int q = 0; q < NV / 4; ++q) w[q] = lds_load16(p4 + 4 * q);
 #pragma unroll
         for (int q = 0; q < NV / 4; ++q) {
-            const v4f w = lds_read16(p4 + 4 * q);
-            v[4 * q + 0] = w.x;
-            v[4 * q + 1] = w.y;
-            v[4 * q + 2] = w.z;
-            v[4 * q + 3] = w.w;
+            lds_pin(w[q]);
+            v[4 * q + 0] = w[q].x;
+            v[4 * q + 1] = w[q].y;
+            v[4 * q + 2] = w[q].z;
+            v[4 * q + 3] = w[q].w;
         }
         v2f acc0 = mk2(0.f, 0.f), acc1 = mk2(0.f, 0.f);
 #pragma unroll
@@ -113,19 +116,30 @@ PDWT_DEVICE void fwd_fast_col_pass(int tid, const v2f* tLH, const Fwd2DFastArgs&
     v2f accAV[R][2], accHD[R][2];
 #pragma unroll
     for (int i = 0; i < R; ++i) accAV[i][0] = accAV[i][1] = accHD[i][0] = accHD[i][1] = mk2(0.f, 0.f);
+    constexpr int NRW = 2 * R + HLEN - 2, GB = 12;  // LDS loads are issued GB at a time, then consumed
 #pragma unroll
-    for (int r = 0; r < 2 * R + HLEN - 2; ++r) {
-        const v4f w = lds_read16(&tLH[(2 * ty0 + r) * TX + 2 * t]);
-        const v2f lh0 = mk2(w.x, w.y), lh1 = mk2(w.z, w.w);
+    for (int r0 = 0; r0 < NRW; r0 += GB) {
+        v4f w[GB];
 #pragma unroll
-        for (int i = 0; i < R; ++i) {
-            const int j = r - 2 * i;
-            if (j >= 0 && j < HLEN) {
-                const v2f tap = a.fb.t[HLEN - 1 - j];
-                accAV[i][0] = fma2(lh0, bc(tap.x), accAV[i][0]);
-                accHD[i][0] = fma2(lh0, bc(tap.y), accHD[i][0]);
-                accAV[i][1] = fma2(lh1, bc(tap.x), accAV[i][1]);
-                accHD[i][1] = fma2(lh1, bc(tap.y), accHD[i][1]);
+        for (int g = 0; g < GB; ++g)
+            if (r0 + g < NRW) w[g] = lds_load16(&tLH[(2 * ty0 + r0 + g) * TX + 2 * t]);
+#pragma unroll
+        for (int g = 0; g < GB; ++g) {
+            const int r = r0 + g;
+            if (r < NRW) {
+                lds_pin(w[g]);
+                const v2f lh0 = mk2(w[g].x, w[g].y), lh1 = mk2(w[g].z, w[g].w);
+#pragma unroll
+                for (int i = 0; i < R; ++i) {
+                    const int j = r - 2 * i;
+                    if (j >= 0 && j < HLEN) {
+                        const v2f tap = a.fb.t[HLEN - 1 - j];
+                        accAV[i][0] = fma2(lh0, bc(tap.x), accAV[i][0]);
+                        accHD[i][0] = fma2(lh0, bc(tap.y), accHD[i][0]);
+                        accAV[i][1] = fma2(lh1, bc(tap.x), accAV[i][1]);
+                        accHD[i][1] = fma2(lh1, bc(tap.y), accHD[i][1]);
+                    }
+                }
             }
         }
     }
@@ -330,18 +344,32 @@ PDWT_DEVICE void inv_fast_col_pass(int tid, const v2f* sAV, const v2f* sHD, v2f*
         const int m = idx / Q2;
         const int q = 2 * (idx - m * Q2);
         v2f e0 = mk2(0.f, 0.f), o0 = e0, e1 = e0, o1 = e0;  // p even / p odd, columns q / q+1
+        constexpr int GB = 6;  // 2 GB LDS loads are issued, then consumed
 #pragma unroll
-        for (int j = 0; j < H2; ++j) {
-            const v4f wav = lds_read16(&sAV[(m + j) * CXA + q]);
-            const v4f whd = lds_read16(&sHD[(m + j) * CXA + q]);
-            const v2f te = fb.t[HLEN - 2 - 2 * j];  // p even: par = 1
-            const v2f to = fb.t[HLEN - 1 - 2 * j];  // p odd : par = 0
-            const v2f av0 = mk2(wav.x, wav.y), av1 = mk2(wav.z, wav.w);
-            const v2f hd0 = mk2(whd.x, whd.y), hd1 = mk2(whd.z, whd.w);
-            e0 = fma2(av0, bc(te.x), e0); e0 = fma2(hd0, bc(te.y), e0);
-            o0 = fma2(av0, bc(to.x), o0); o0 = fma2(hd0, bc(to.y), o0);
-            e1 = fma2(av1, bc(te.x), e1); e1 = fma2(hd1, bc(te.y), e1);
-            o1 = fma2(av1, bc(to.x), o1); o1 = fma2(hd1, bc(to.y), o1);
+        for (int j0 = 0; j0 < H2; j0 += GB) {
+            v4f wav[GB], whd[GB];
+#pragma unroll
+            for (int g = 0; g < GB; ++g)
+                if (j0 + g < H2) {
+                    wav[g] = lds_load16(&sAV[(m + j0 + g) * CXA + q]);
+                    whd[g] = lds_load16(&sHD[(m + j0 + g) * CXA + q]);
+                }
+#pragma unroll
+            for (int g = 0; g < GB; ++g) {
+                const int j = j0 + g;
+                if (j < H2) {
+                    lds_pin(wav[g]);
+                    lds_pin(whd[g]);
+                    const v2f te = fb.t[HLEN - 2 - 2 * j];  // p even: par = 1
+                    const v2f to = fb.t[HLEN - 1 - 2 * j];  // p odd : par = 0
+                    const v2f av0 = mk2(wav[g].x, wav[g].y), av1 = mk2(wav[g].z, wav[g].w);
+                    const v2f hd0 = mk2(whd[g].x, whd[g].y), hd1 = mk2(whd[g].z, whd[g].w);
+                    e0 = fma2(av0, bc(te.x), e0); e0 = fma2(hd0, bc(te.y), e0);
+                    o0 = fma2(av0, bc(to.x), o0); o0 = fma2(hd0, bc(to.y), o0);
+                    e1 = fma2(av1, bc(te.x), e1); e1 = fma2(hd1, bc(te.y), e1);
+                    o1 = fma2(av1, bc(to.x), o1); o1 = fma2(hd1, bc(to.y), o1);
+                }
+            }
         }
         const int ge = 2 * m - S, go = 2 * m + 1 - S;  // local output rows
         f32x4 w;
@@ -371,11 +399,14 @@ PDWT_DEVICE void inv_fast_row_pass(int tid, const v2f* tt, const Inv2DFastArgs& 
         const int k = 2 * (idx - gy * HT);
         v2f u[NP];
         const v2f* base = tt + gy * CXA + (PADL - PE) + k;
+        v4f w[NP / 2];
+#pragma unroll
+        for (int q = 0; q < NP / 2; ++q) w[q] = lds_load16(base + 2 * q);
 #pragma unroll
         for (int q = 0; q < NP / 2; ++q) {
-            const v4f w = lds_read16(base + 2 * q);
-            u[2 * q] = mk2(w.x, w.y);
-            u[2 * q + 1] = mk2(w.z, w.w);
+            lds_pin(w[q]);
+            u[2 * q] = mk2(w[q].x, w[q].y);
+            u[2 * q + 1] = mk2(w[q].z, w[q].w);
         }
         float res[4];
 #pragma unroll

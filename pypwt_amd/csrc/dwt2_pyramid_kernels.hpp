@@ -103,11 +103,14 @@ PDWT_DEVICE void dwt2_fwd_pyr2_tile(const FwdPyr2Args& a, int bx, int by, int bz
         for (int idx = tid; idx < R0Y * HT; idx += NT) {
             const int r = idx / HT, t = idx - r * HT;
             float v[NV1];
+v4f w[NV1 / 4];
 #pragma unroll
-            for (int q = 0; q < NV1 / 4; ++q) {
-                const v4f w = lds_read16(sIn + r * RXA + 4 * t + 4 * q);
-                v[4 * q + 0] = w.x; v[4 * q + 1] = w.y; v[4 * q + 2] = w.z; v[4 * q + 3] = w.w;
-            }
+for (int q = 0; q < NV1 / 4; ++q) w[q] = lds_load16(sIn + r * RXA + 4 * t + 4 * q);
+#pragma unroll
+for (int q = 0; q < NV1 / 4; ++q) {
+    lds_pin(w[q]);
+                v[4 * q + 0] = w[q].x; v[4 * q + 1] = w[q].y; v[4 * q + 2] = w[q].z; v[4 * q + 3] = w[q].w;
+}
             v2f acc0 = mk2(0.f, 0.f), acc1 = mk2(0.f, 0.f);
 #pragma unroll
             for (int j = 0; j < H; ++j) {
@@ -131,10 +134,13 @@ PDWT_DEVICE void dwt2_fwd_pyr2_tile(const FwdPyr2Args& a, int bx, int by, int bz
             v2f accAV[2][2], accHD[2][2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) accAV[i][0] = accAV[i][1] = accHD[i][0] = accHD[i][1] = mk2(0.f, 0.f);
+            v4f w[H + 2];
+#pragma unroll
+            for (int r = 0; r < H + 2; ++r) w[r] = lds_load16(&tLH1[(4 * i2 + r) * R1X + 2 * t]);
 #pragma unroll
             for (int r = 0; r < H + 2; ++r) {
-                const v4f w = lds_read16(&tLH1[(4 * i2 + r) * R1X + 2 * t]);
-                const v2f lh0 = mk2(w.x, w.y), lh1 = mk2(w.z, w.w);
+                lds_pin(w[r]);
+                const v2f lh0 = mk2(w[r].x, w[r].y), lh1 = mk2(w[r].z, w[r].w);
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     const int j = r - 2 * i;
@@ -173,11 +179,14 @@ PDWT_DEVICE void dwt2_fwd_pyr2_tile(const FwdPyr2Args& a, int bx, int by, int bz
         for (int idx = tid; idx < R1Y * HT; idx += NT) {
             const int r = idx / HT, t = idx - r * HT;
             float v[NV2];
+v4f w[NV2 / 4];
 #pragma unroll
-            for (int q = 0; q < NV2 / 4; ++q) {
-                const v4f w = lds_read16(sA1 + r * S1 + 4 * t + 4 * q);
-                v[4 * q + 0] = w.x; v[4 * q + 1] = w.y; v[4 * q + 2] = w.z; v[4 * q + 3] = w.w;
-            }
+for (int q = 0; q < NV2 / 4; ++q) w[q] = lds_load16(sA1 + r * S1 + 4 * t + 4 * q);
+#pragma unroll
+for (int q = 0; q < NV2 / 4; ++q) {
+    lds_pin(w[q]);
+                v[4 * q + 0] = w[q].x; v[4 * q + 1] = w[q].y; v[4 * q + 2] = w[q].z; v[4 * q + 3] = w[q].w;
+}
             v2f acc0 = mk2(0.f, 0.f), acc1 = mk2(0.f, 0.f);
 #pragma unroll
             for (int j = 0; j < H; ++j) {
@@ -199,10 +208,13 @@ PDWT_DEVICE void dwt2_fwd_pyr2_tile(const FwdPyr2Args& a, int bx, int by, int bz
         for (int idx = tid; idx < TY2 * HT; idx += NT) {
             const int i = idx / HT, t = idx - i * HT;
             v2f aAV0 = mk2(0.f, 0.f), aAV1 = aAV0, aHD0 = aAV0, aHD1 = aAV0;
+            v4f w[H];
+#pragma unroll
+            for (int j = 0; j < H; ++j) w[j] = lds_load16(&tLH2[(2 * i + j) * TX2 + 2 * t]);
 #pragma unroll
             for (int j = 0; j < H; ++j) {
-                const v4f w = lds_read16(&tLH2[(2 * i + j) * TX2 + 2 * t]);
-                const v2f lh0 = mk2(w.x, w.y), lh1 = mk2(w.z, w.w);
+                lds_pin(w[j]);
+                const v2f lh0 = mk2(w[j].x, w[j].y), lh1 = mk2(w[j].z, w[j].w);
                 const v2f tap = a.fb.t[H - 1 - j];
                 aAV0 = fma2(lh0, bc(tap.x), aAV0);
                 aHD0 = fma2(lh0, bc(tap.y), aHD0);
@@ -337,10 +349,17 @@ PDWT_DEVICE void dwt2_inv_pyr2_tile(const InvPyr2Args& a, int bx, int by, int bz
             const int kk = ky_lo + ki;
             const int r0 = kk - C2 - c2y0;
             v2f e0 = mk2(0.f, 0.f), o0 = e0, e1 = e0, o1 = e0;
+            v4f wavs[H2], whds[H2];
 #pragma unroll
             for (int j = 0; j < H2; ++j) {
-                const v4f wav = lds_read16(&sAV2[(r0 + j) * W2 + q]);
-                const v4f whd = lds_read16(&sHD2[(r0 + j) * W2 + q]);
+                wavs[j] = lds_load16(&sAV2[(r0 + j) * W2 + q]);
+                whds[j] = lds_load16(&sHD2[(r0 + j) * W2 + q]);
+            }
+#pragma unroll
+            for (int j = 0; j < H2; ++j) {
+                lds_pin(wavs[j]);
+                lds_pin(whds[j]);
+                const v4f wav = wavs[j], whd = whds[j];
                 const v2f te = a.fb.t[H - 2 - 2 * j], to = a.fb.t[H - 1 - 2 * j];
                 const v2f av0 = mk2(wav.x, wav.y), av1 = mk2(wav.z, wav.w);
                 const v2f hd0 = mk2(whd.x, whd.y), hd1 = mk2(whd.z, whd.w);

@@ -12,6 +12,7 @@
 #include "../../pypwt_amd/csrc/dwt2_fast_kernels.hpp"
 #include "../../pypwt_amd/csrc/dwt2_kernels.hpp"
 #include "../../pypwt_amd/csrc/dwt2_pyramid_kernels.hpp"
+#include "../../pypwt_amd/csrc/dwt2_strip_kernels.hpp"
 #include "../../pypwt_amd/csrc/nonsep_kernels.hpp"
 #include "../../pypwt_amd/csrc/swt_kernels.hpp"
 
@@ -408,6 +409,35 @@ EMU_API int emu_dwt2_inv_pyr2(const float* l1, const float* l2, int batch, int N
     set_bank_i(a.fb, lo, hi, hlen);
     switch (hlen) {
 #define X(h) case h: if (tile == 0) run_inv_pyr2<h, 64, 8, 256>(a, batch); else run_inv_pyr2<h, 64, 16, 256>(a, batch); return 0;
+        X(2) X(4) X(6) X(8)
+#undef X
+    }
+    return -1;
+}
+
+// ------------------------------------------------------------------ two-level streaming strips (forward)
+template <int HLEN, int TX2, int NT>
+static void run_fwd_strip2(FwdStrip2Args a, int batch) {
+    std::vector<float> smem(Strip2Geom<HLEN, TX2>::LDS_FLOATS + 64, NAN);
+    a.strips = cdiv(a.N0c / 4, TX2); a.segs = cdiv(a.N0r / 4, a.seg2);
+    for (int bz = 0; bz < batch; bz++)
+        for (int sg = 0; sg < a.segs; sg++)
+            for (int st = 0; st < a.strips; st++) dwt2_fwd_strip2_wg<HLEN, TX2, NT>(a, st, sg, bz, smem.data());
+}
+
+EMU_API int emu_dwt2_fwd_strip2(const float* in, int batch, int N0r, int N0c, const float* lo, const float* hi, int hlen,
+                                int seg2, float* l1, float* l2) {
+    if ((hlen & 1) || hlen > 8 || (N0c & 7) || (N0r & 3)) return -2;
+    FwdStrip2Args a;
+    const long long n1 = (long long)batch * (N0r / 2) * (N0c / 2), n2 = (long long)batch * (N0r / 4) * (N0c / 4);
+    a.in = in; a.H1 = l1; a.V1 = l1 + n1; a.D1 = l1 + 2 * n1;
+    a.A2 = l2; a.H2 = l2 + n2; a.V2 = l2 + 2 * n2; a.D2 = l2 + 3 * n2;
+    a.N0r = N0r; a.N0c = N0c; a.seg2 = seg2;
+    a.in_bstride = (long long)N0r * N0c; a.l1_bstride = (long long)(N0r / 2) * (N0c / 2);
+    a.l2_bstride = (long long)(N0r / 4) * (N0c / 4);
+    set_bank_i(a.fb, lo, hi, hlen);
+    switch (hlen) {
+#define X(h) case h: run_fwd_strip2<h, 32, 256>(a, batch); return 0;
         X(2) X(4) X(6) X(8)
 #undef X
     }

@@ -363,3 +363,23 @@ def test_emu_dwt2_inv_pyramid(wname):
                 want = oracle.inverse(bands, shape, wname, 2, ndim=2)
                 assert np.isfinite(out[b]).all(), (wname, shape, tile)
                 assert np.abs(out[b] - want).max() <= 3 * _tol(want), (wname, shape, tile)
+
+
+@pytest.mark.parametrize("wname", ["haar", "db2", "db3", "db4", "sym4", "bior3.1"])
+def test_emu_dwt2_fwd_strip_streaming(wname):
+    """Two levels per launch, streaming down column strips with carried (L,H) rows."""
+    hlen, dlo, dhi, rlo, rhi = oracle.filters(wname)
+    for si, (B, shape) in enumerate([(1, (64, 64)), (1, (32, 136)), (2, (40, 72)), (1, (128, 512)), (1, (4, 8)), (1, (260, 264)), (1, (512, 128))]):
+        x = oracle.hash_input((B,) + shape, 9100 + si)
+        n1 = (shape[0] // 2, shape[1] // 2)
+        n2 = (shape[0] // 4, shape[1] // 4)
+        for seg2 in (4, 16, 32, 1000):
+            l1 = np.full((3, B) + n1, np.nan, dtype=np.float32)
+            l2 = np.full((4, B) + n2, np.nan, dtype=np.float32)
+            assert lib().emu_dwt2_fwd_strip2(P(x), B, shape[0], shape[1], P(dlo), P(dhi), hlen, seg2, P(l1), P(l2)) == 0
+            for b in range(B):
+                ref = oracle.forward(x[b], wname, 2, ndim=2)  # [A2, H1,V1,D1, H2,V2,D2]
+                got = [l2[0, b], l1[0, b], l1[1, b], l1[2, b], l2[1, b], l2[2, b], l2[3, b]]
+                for k, (g, r) in enumerate(zip(got, ref)):
+                    assert np.isfinite(g).all(), (wname, shape, seg2, k)
+                    assert np.abs(g - r).max() <= 2 * _tol(r), (wname, shape, seg2, k)

@@ -14,9 +14,12 @@
 #include "dwt2_fast_kernels.hpp"
 #include "dwt2_kernels.hpp"
 #include "dwt2_pyramid_kernels.hpp"
+#include "dwt2_strip_kernels.hpp"
 
 using namespace pdwt;
 
+static const char* g_only = nullptr;
+static bool skip(const char* tag) { return g_only && !strstr(tag, g_only); }
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
 
 __global__ void copy4(const float4* __restrict__ a, float4* __restrict__ b, long long n4) {
@@ -64,6 +67,7 @@ static const float DB4_HI[8] = {-0.23037781330885523f, 0.7148465705525415f, -0.6
 
 template <int HLEN, int TX, int TY, int NT>
 static void bench_fwd(const char* tag, const float* in, float* out4, int N, int batch) {
+    if (skip(tag)) return;
     Fwd2DArgs a;
     a.in = in;
     const long long q = (long long)batch * (N / 2) * (N / 2);
@@ -85,6 +89,7 @@ static void bench_fwd(const char* tag, const float* in, float* out4, int N, int 
 
 template <int HLEN, int TX, int TY, int NT>
 static void bench_inv(const char* tag, const float* in4, float* out, int N, int batch) {
+    if (skip(tag)) return;
     Inv2DArgs a;
     const long long q = (long long)batch * (N / 2) * (N / 2);
     a.A = in4; a.H = in4 + q; a.V = in4 + 2 * q; a.D = in4 + 3 * q; a.out = out;
@@ -105,6 +110,7 @@ static void bench_inv(const char* tag, const float* in4, float* out, int N, int 
 
 template <int HLEN, int TX, int TY, int NT>
 static void bench_fwd_fast(const char* tag, const float* in, float* out4, int N, int batch) {
+    if (skip(tag)) return;
     Fwd2DFastArgs a;
     a.in = in;
     const long long q = (long long)batch * (N / 2) * (N / 2);
@@ -127,6 +133,7 @@ static void bench_fwd_fast(const char* tag, const float* in, float* out4, int N,
 
 template <int HLEN, int TX, int TY, int NT>
 static void bench_fwd_stream(const char* tag, const float* in, float* out4, int N, int batch, int wg_per_cu) {
+    if (skip(tag)) return;
     Fwd2DFastArgs a;
     a.in = in;
     const long long q = (long long)batch * (N / 2) * (N / 2);
@@ -149,6 +156,7 @@ static void bench_fwd_stream(const char* tag, const float* in, float* out4, int 
 
 template <int HLEN, int TX, int TY, int NT>
 static void bench_inv_stream(const char* tag, const float* in4, float* out, int N, int batch, int wg_per_cu) {
+    if (skip(tag)) return;
     Inv2DFastArgs a;
     const long long q = (long long)batch * (N / 2) * (N / 2);
     a.A = in4; a.H = in4 + q; a.V = in4 + 2 * q; a.D = in4 + 3 * q; a.out = out;
@@ -169,6 +177,7 @@ static void bench_inv_stream(const char* tag, const float* in4, float* out, int 
 
 template <int HLEN, int TX, int TY, int NT>
 static void bench_inv_fast(const char* tag, const float* in4, float* out, int N, int batch) {
+    if (skip(tag)) return;
     Inv2DFastArgs a;
     const long long q = (long long)batch * (N / 2) * (N / 2);
     a.A = in4; a.H = in4 + q; a.V = in4 + 2 * q; a.D = in4 + 3 * q; a.out = out;
@@ -190,6 +199,7 @@ static void bench_inv_fast(const char* tag, const float* in4, float* out, int N,
 
 template <int HLEN, int TX2, int TY2, int NT>
 static void bench_fwd_pyr2(const char* tag, const float* in, float* out, int N, int batch) {
+    if (skip(tag)) return;
     FwdPyr2Args a;
     const long long n1 = (long long)batch * (N / 2) * (N / 2), n2 = (long long)batch * (N / 4) * (N / 4);
     a.in = in; a.H1 = out; a.V1 = out + n1; a.D1 = out + 2 * n1;
@@ -211,6 +221,7 @@ static void bench_fwd_pyr2(const char* tag, const float* in, float* out, int N, 
 
 template <int HLEN, int TX, int TY, int NT>
 static void bench_inv_pyr2(const char* tag, const float* in, float* out, int N, int batch) {
+    if (skip(tag)) return;
     InvPyr2Args a;
     const long long n1 = (long long)batch * (N / 2) * (N / 2), n2 = (long long)batch * (N / 4) * (N / 4);
     a.H1 = in; a.V1 = in + n1; a.D1 = in + 2 * n1;
@@ -230,9 +241,28 @@ static void bench_inv_pyr2(const char* tag, const float* in, float* out, int N, 
     printf("%-34s N=%d B=%d lds=%6zu  %8.2f us  (two levels in one launch)\n", tag, N, batch, lds, us);
 }
 
+template <int HLEN, int TX2, int NT, int PF>
+static void bench_fwd_strip2(const char* tag, const float* in, float* out, int N, int batch, int seg2) {
+    if (skip(tag)) return;
+    FwdStrip2Args a;
+    const long long n1 = (long long)batch * (N / 2) * (N / 2), n2 = (long long)batch * (N / 4) * (N / 4);
+    a.in = in; a.H1 = out; a.V1 = out + n1; a.D1 = out + 2 * n1;
+    float* l2 = out + 3 * n1;
+    a.A2 = l2; a.H2 = l2 + n2; a.V2 = l2 + 2 * n2; a.D2 = l2 + 3 * n2;
+    a.N0r = N; a.N0c = N; a.seg2 = seg2;
+    a.in_bstride = (long long)N * N; a.l1_bstride = (long long)(N / 2) * (N / 2); a.l2_bstride = (long long)(N / 4) * (N / 4);
+    a.strips = (N / 4 + TX2 - 1) / TX2; a.segs = (N / 4 + seg2 - 1) / seg2;
+    memset(&a.fb, 0, sizeof(a.fb));
+    for (int i = 0; i < 8; i++) { a.fb.t[i].x = DB4_LO[i]; a.fb.t[i].y = DB4_HI[i]; }
+    const size_t lds = (size_t)Strip2Geom<HLEN, TX2>::LDS_FLOATS * sizeof(float);
+    float us = time_it([&] { hipLaunchKernelGGL((dwt2_fwd_strip2_kernel<HLEN, TX2, NT, PF>), dim3(a.strips * a.segs, batch), dim3(NT), lds, 0, a); });
+    printf("%-24s PF=%d seg2=%3d wgs=%5d N=%d B=%d lds=%6zu  %8.2f us  (two levels in one launch)\n", tag, PF, seg2, a.strips * a.segs, N, batch, lds, us);
+}
+
 int main(int argc, char** argv) {
     const int N = argc > 1 ? atoi(argv[1]) : 4096;
     const int B = argc > 2 ? atoi(argv[2]) : 1;
+    if (argc > 3) g_only = argv[3];
     const long long n = (long long)B * N * N;
     float *a, *b;
     CK(hipMalloc((void**)&a, n * sizeof(float)));
@@ -261,6 +291,11 @@ int main(int argc, char** argv) {
     for (int w : {2, 4, 6, 8, 12}) bench_fwd_stream<8, 64, 8, 256>("STREAM fwd db4 TX64 TY8 NT256", a, b, N, B, w);
     for (int w : {2, 4, 6, 8}) bench_fwd_stream<8, 64, 16, 256>("STREAM fwd db4 TX64 TY16 NT256", a, b, N, B, w);
     for (int w : {2, 4, 8}) bench_fwd_stream<8, 64, 4, 128>("STREAM fwd db4 TX64 TY4 NT128", a, b, N, B, w);
+    for (int sg : {16, 32, 64, 128}) bench_fwd_strip2<8, 32, 256, 1>("STRIP2 fwd db4 TX2=32 NT256", a, b, N, B, sg);
+    for (int sg : {16, 32, 64, 128}) bench_fwd_strip2<8, 32, 256, 2>("STRIP2 fwd db4 TX2=32 NT256", a, b, N, B, sg);
+    for (int sg : {16, 32, 64, 128}) bench_fwd_strip2<8, 32, 256, 3>("STRIP2 fwd db4 TX2=32 NT256", a, b, N, B, sg);
+    for (int sg : {16, 32, 64}) bench_fwd_strip2<8, 64, 512, 2>("STRIP2 fwd db4 TX2=64 NT512", a, b, N, B, sg);
+    for (int sg : {16, 32, 64}) bench_fwd_strip2<8, 64, 256, 2>("STRIP2 fwd db4 TX2=64 NT256", a, b, N, B, sg);
     bench_fwd_pyr2<8, 32, 4, 256>("PYR2 fwd db4 TX2=32 TY2=4 NT256", a, b, N, B);
     bench_fwd_pyr2<8, 32, 8, 256>("PYR2 fwd db4 TX2=32 TY2=8 NT256", a, b, N, B);
     bench_fwd_pyr2<8, 32, 8, 512>("PYR2 fwd db4 TX2=32 TY2=8 NT512", a, b, N, B);
