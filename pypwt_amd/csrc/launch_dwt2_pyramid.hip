@@ -8,6 +8,7 @@
 //      2048^2        13.8 us           12.2 us                  14.4 -> 12.7 us
 //      4096^2        33.6 us           40.3 us  (slower: 1.9x recomputed halo, half the occupancy)
 #include "dwt2_pyramid_kernels.hpp"
+#include "dwt2_strip_kernels.hpp"
 #include "launch.hpp"
 #include "launch_util.hpp"
 
@@ -72,6 +73,48 @@ hipError_t launch_dwt2_fwd_pyr2(const float* in, float* const det1[3], float* co
         case 4: return run_fwd<4>(a, batch, s);
         case 6: return run_fwd<6>(a, batch, s);
         case 8: return run_fwd<8>(a, batch, s);
+    }
+    return hipErrorNotSupported;
+}
+
+// Streaming strips (dwt2_strip_kernels.hpp): same contract as launch_dwt2_fwd_pyr2, for LARGE inputs.
+// kbench, MI355X, db4, 8 images of 4096^2 (profiles/r02a_kbench_strip.txt): levels 1+2 as two launches
+// 284 us, as one strip launch 232 us (A_1 never goes to HBM); one image: 32 us vs 36 us (slower: the
+// launch then has too few workgroups for its longer per-workgroup critical path), so the host only uses it
+// when at least 2^26 samples enter the pair (plan.cpp: strip_pairs_fwd).
+template <int HLEN>
+static hipError_t run_fwd_strip(FwdStrip2Args& a, int batch, hipStream_t s) {
+    constexpr int TX2 = 32, NT = 256, PF = 2;
+    constexpr size_t lds = (size_t)Strip2Geom<HLEN, TX2>::LDS_FLOATS * sizeof(float);
+    static_assert(lds <= 64 * 1024, "fits the default dynamic-LDS limit");
+    a.strips = cdiv(a.N0c / 4, TX2);
+    int seg2 = 128;  // longer segments amortise the 3(hlen-2)-row warm-up; keep >= 4 workgroups per CU
+    while (seg2 > 16 && (long long)a.strips * cdiv(a.N0r / 4, seg2) * batch < 1024) seg2 >>= 1;
+    a.seg2 = seg2;
+    a.segs = cdiv(a.N0r / 4, seg2);
+    hipLaunchKernelGGL((dwt2_fwd_strip2_kernel<HLEN, TX2, NT, PF>), dim3(a.strips * a.segs, batch), dim3(NT), lds, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_dwt2_fwd_strip2(const float* in, float* const det1[3], float* const band2[4], int N0r, int N0c,
+                                  int hlen, const FilterBank& fb, int batch, hipStream_t s) {
+    if (!dwt2_pyramid_supported(hlen, N0r, N0c)) return hipErrorNotSupported;
+    if (!al16(in) || !al16(det1[0]) || !al16(det1[1]) || !al16(det1[2]) || !al16(band2[0]) || !al16(band2[1]) ||
+        !al16(band2[2]) || !al16(band2[3]))
+        return hipErrorNotSupported;
+    FwdStrip2Args a;
+    a.in = in; a.H1 = det1[0]; a.V1 = det1[1]; a.D1 = det1[2];
+    a.A2 = band2[0]; a.H2 = band2[1]; a.V2 = band2[2]; a.D2 = band2[3];
+    a.N0r = N0r; a.N0c = N0c;
+    a.in_bstride = (long long)N0r * N0c;
+    a.l1_bstride = (long long)(N0r / 2) * (N0c / 2);
+    a.l2_bstride = (long long)(N0r / 4) * (N0c / 4);
+    interleave(a.fb, fb);
+    switch (hlen) {
+        case 2: return run_fwd_strip<2>(a, batch, s);
+        case 4: return run_fwd_strip<4>(a, batch, s);
+        case 6: return run_fwd_strip<6>(a, batch, s);
+        case 8: return run_fwd_strip<8>(a, batch, s);
     }
     return hipErrorNotSupported;
 }

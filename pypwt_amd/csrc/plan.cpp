@@ -303,6 +303,25 @@ std::vector<int> pyramid_pairs(const pdwt_plan* p) {
     return v;
 }
 
+// First levels l of the FORWARD level pairs that run as one streaming-strip launch (dwt2_strip_kernels.hpp):
+// the opposite regime -- at least 2^26 samples enter the pair (a batch of large images), where the level
+// is bandwidth-bound and not writing + re-reading A_l is what pays.  PDWT_FORCE_STRIP=1 drops the size
+// threshold (tests), PDWT_NO_STRIP=1 disables the path.
+std::vector<int> strip_pairs_fwd(const pdwt_plan* p) {
+    std::vector<int> v;
+    if (p->info.ndims != 2 || p->info.do_swt || !p->do_separable || getenv("PDWT_NO_STRIP")) return v;
+    const long long min_samples = getenv("PDWT_FORCE_STRIP") ? 0 : (1LL << 26);
+    const int L = p->info.nlevels;
+    for (int l = 1; l + 1 <= L; l++) {
+        const long long samples = (long long)p->batch * p->lr[l - 1] * p->lc[l - 1];
+        if (samples >= min_samples && dwt2_pyramid_supported(p->info.hlen, p->lr[l - 1], p->lc[l - 1])) {
+            v.push_back(l);
+            l++;
+        }
+    }
+    return v;
+}
+
 bool in_list(const std::vector<int>& v, int x) {
     for (int e : v)
         if (e == x) return true;
@@ -340,10 +359,22 @@ int forward_impl(pdwt_plan* p, int only = 0) {
     const bool swt = p->info.do_swt != 0;
     const float* src = p->image();
     if (p->info.ndims == 2) {
-        const std::vector<int> pyr = pyramid_pairs(p);
+        const std::vector<int> strips = strip_pairs_fwd(p);
+        std::vector<int> pyr = pyramid_pairs(p);
         for (int l = 1; l <= L; l++) {
             const bool run = (only == 0 || only == l);
-            if (in_list(pyr, l)) {
+            if (in_list(strips, l)) {
+                float* det1[3] = {p->band(3 * (l - 1) + 1), p->band(3 * (l - 1) + 2), p->band(3 * (l - 1) + 3)};
+                float* A2 = (l + 1 == L) ? p->band(0) : p->arena + p->approx_off[l + 1];
+                float* band2[4] = {A2, p->band(3 * l + 1), p->band(3 * l + 2), p->band(3 * l + 3)};
+                Stamp st(p, "dwt2_fwd_strip2");
+                if (run) HIP_TRY(launch_dwt2_fwd_strip2(src, det1, band2, p->lr[l - 1], p->lc[l - 1], hlen, p->dec, B,
+                                                        p->stream));
+                src = A2;
+                l++;
+                continue;
+            }
+            if (in_list(pyr, l) && !in_list(strips, l + 1)) {
                 // levels l and l+1 in one launch; A_l never leaves LDS
                 float* det1[3] = {p->band(3 * (l - 1) + 1), p->band(3 * (l - 1) + 2), p->band(3 * (l - 1) + 3)};
                 float* A2 = (l + 1 == L) ? p->band(0) : p->arena + p->approx_off[l + 1];

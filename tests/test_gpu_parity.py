@@ -298,3 +298,32 @@ def test_cfg4_swt_2048_haar_L5_soft_threshold_full_size(W):
         _check_digest(g, ref, ("cfg4 soft", b))
     w.inverse()
     _check_digest(w.image, c["rec_soft"], "cfg4 rec")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("wname", ["haar", "db2", "db3", "db4"])
+def test_strip_forward_path_matches_oracle(wname, monkeypatch):
+    """The streaming-strip forward (two levels per launch, used for batches of large images) forced on
+    small inputs: coefficients must equal the oracle's and the per-level path's."""
+    from pypwt_amd import BatchedWavelets
+    monkeypatch.setenv("PDWT_FORCE_STRIP", "1")
+    B, shape, L = 3, (136, 272), 3
+    x = oracle.hash_input((B,) + shape, 4242, scale=255.0)
+    w = BatchedWavelets(B, shape[0], shape[1], wname, L, img=x)
+    w.enable_kernel_timing(True)
+    w.forward()
+    assert "dwt2_fwd_strip2" in [n for n, _ in w.kernel_times()]
+    w.enable_kernel_timing(False)
+    got = [w.coeff(i) for i in range(3 * w.levels + 1)]
+    monkeypatch.delenv("PDWT_FORCE_STRIP")
+    monkeypatch.setenv("PDWT_NO_STRIP", "1")
+    w2 = BatchedWavelets(B, shape[0], shape[1], wname, L, img=x)
+    w2.forward()
+    for b in range(B):
+        ref = oracle.forward(x[b], wname, w.levels, ndim=2)
+        for k, r in enumerate(ref):
+            tol = 1.5e-6 * (1 + w.levels) * max(1.0, float(np.abs(r).max()))
+            assert np.abs(got[k][b] - r).max() <= tol, (wname, b, k)
+            assert np.abs(got[k][b] - w2.coeff(k)[b]).max() <= tol, (wname, b, k)
+    w.inverse()
+    assert np.abs(w.image - x).max() <= 2e-3
