@@ -19,6 +19,7 @@
 //   synthesis  polyphase form of separable.cu:293-328, see dwt2_kernels.hpp.
 #pragma once
 
+#include "dwt2_fast_kernels.hpp"  // inv_row_synth4
 #include "kernels_common.hpp"
 #include "packed_math.hpp"
 
@@ -136,17 +137,17 @@ PDWT_DEVICE void dwt1_fwd_fused_tile(const Fwd1DFusedArgs& a, int bx, int row, f
             float* PDWT_RESTRICT outA = a.app + (long long)row * Nk;
             for (int t = tid; 2 * t < nk; t += NT) {
                 float v[NV];
-v4f w[NV / 4];
+                v4f w[NV / 4];
 #pragma unroll
-for (int q = 0; q < NV / 4; ++q) w[q] = lds_load16(src + 4 * t + 4 * q);
+                for (int q = 0; q < NV / 4; ++q) w[q] = lds_load16(src + 4 * t + 4 * q);
 #pragma unroll
-for (int q = 0; q < NV / 4; ++q) {
-    lds_pin(w[q]);
+                for (int q = 0; q < NV / 4; ++q) {
+                    lds_pin(w[q]);
                     v[4 * q + 0] = w[q].x;
                     v[4 * q + 1] = w[q].y;
                     v[4 * q + 2] = w[q].z;
                     v[4 * q + 3] = w[q].w;
-}
+                }
                 v2f acc0 = mk2(0.f, 0.f), acc1 = mk2(0.f, 0.f);  // (A, D) of outputs 2t and 2t+1
 #pragma unroll
                 for (int j = 0; j < HLEN; ++j) {
@@ -194,30 +195,44 @@ constexpr int inv1d_fused_lds_floats(int T0, int hlen, int K) {
     const int H2 = hlen / 2;
     const int m1 = T0 / 2 + 2 * H2 + 8;   // generous bound on the level-1 coefficient count
     const int m2 = T0 / 4 + 3 * H2 + 8;
-    return 2 * (m1 + m2) + 32;
+    // + 8 pairs in front (the 4-sample synthesis blocks read a little outside their range) + the range table
+    return 2 * (m1 + m2) + 32 + 16 + 32;
 }
 
 template <int HLEN, int T0, int NT>
 PDWT_DEVICE void dwt1_inv_fused_tile(const Inv1DFusedArgs& a, int bx, int row, float* smem) {
-    constexpr int H2 = HLEN / 2, C2 = H2 / 2, S = (H2 & 1) ? 0 : 1;
+    constexpr int H2 = HLEN / 2, C2 = H2 / 2;
     const int K = a.K;
     constexpr int M1 = T0 / 2 + 2 * H2 + 8;
-    v2f* bufP = reinterpret_cast<v2f*>(smem);           // (a,d) pairs of the odd levels 1,3,5..
-    v2f* bufQ = reinterpret_cast<v2f*>(smem) + M1 + 8;  // even levels 2,4,6..
+    constexpr int M2 = T0 / 4 + 3 * H2 + 8;
+    v2f* bufP = reinterpret_cast<v2f*>(smem) + 8;  // (a,d) pairs of the odd levels 1,3,5.. (8 pairs of front slack)
+    v2f* bufQ = bufP + M1 + 8;                     // even levels 2,4,6..
+    int* rng = reinterpret_cast<int*>(smem + 2 * (M1 + M2) + 32 + 16);  // [2k], [2k+1] = range of level k
 
-    // coefficient range of level k, recomputed from the owned output range (K <= 10 scalar steps;
-    // a runtime-indexed array would live in scratch)
+    // coefficient range of every level, from the owned output range: computed once (a per-level
+    // recomputation is O(K^2) scalar work per wave and showed up as 2x more SALU than VALU instructions),
+    // kept in LDS because a runtime-indexed register array would live in scratch
     const int lo0 = bx * T0;
     const int hi0 = (lo0 + T0 > a.N0) ? a.N0 : lo0 + T0;
-    auto range_of = [&](int level, int& l, int& h) {
-        l = lo0;
-        h = hi0;
-        for (int k = 1; k <= level; ++k) {
-            int cl, ch;
-            inv1d_fused_range(l, h, H2, cl, ch);
-            l = cl;
-            h = ch;
+    PDWT_FOR_THREADS(tid, NT) {
+        if (tid == 0) {
+            int l = lo0, h = hi0;
+            rng[0] = l;
+            rng[1] = h;
+            for (int k = 1; k <= K; ++k) {
+                int cl, ch;
+                inv1d_fused_range(l, h, H2, cl, ch);
+                l = cl;
+                h = ch;
+                rng[2 * k] = l;
+                rng[2 * k + 1] = h;
+            }
         }
+    }
+    PDWT_SYNC();
+    auto range_of = [&](int level, int& l, int& h) {
+        l = rng[2 * level];
+        h = rng[2 * level + 1];
     };
 
     // ---- approximation A_K -> .x of level K's buffer
@@ -245,32 +260,29 @@ PDWT_DEVICE void dwt1_inv_fused_tile(const Inv1DFusedArgs& a, int bx, int row, f
             stage_periodic_f4<NT, 4, 2>(tid, gD, Nk, lok, m, reinterpret_cast<float*>(cur), 1);
         }
         PDWT_SYNC();
-        // synthesis of level k-1 samples [lo[k-1], hi[k-1]): work item = coefficient index kk, which
-        // yields the two samples p = 2kk (even taps) and p = 2kk+1 (odd taps), p = g + S, from the
-        // same H2 (a,d) pairs -- no parity divergence inside a wavefront
+        // synthesis of level k-1 samples [lom, him): work item = the 4-aligned block of samples 4b .. 4b+3,
+        // i.e. coefficient indices 2b and 2b+1 (inv_row_synth4: 16-B LDS reads, all four results from
+        // one window of pairs, 16-B stores at the last level); samples outside [lom, him) are dropped
         PDWT_FOR_THREADS(tid, NT) {
             float* PDWT_RESTRICT out = a.out + (long long)row * a.N0;
-            const int kk_lo = (lom + S) >> 1;
-            const int kk_hi = (him - 1 + S) >> 1;
-            const int cnt = kk_hi - kk_lo + 1;
-            for (int i = tid; i < cnt; i += NT) {
-                const int kk = kk_lo + i;
-                const v2f* u = cur + (kk - C2 - lok);
-                v2f re = mk2(0.f, 0.f), ro = mk2(0.f, 0.f);
+            const int b_lo = lom >> 2, b_hi = (him - 1) >> 2;  // arithmetic shifts: floor, lom may be negative
+            const int pe = (C2 + lok) & 1;                      // parity that makes the window origin 16-B aligned
+            for (int i = tid; i <= b_hi - b_lo; i += NT) {
+                const int kk = 2 * (b_lo + i);
+                const v2f* base = cur + (kk - C2 - lok - pe);
+                float res[4];
+                if (pe) inv_row_synth4<HLEN, 1>(base, a.fb, res);
+                else inv_row_synth4<HLEN, 0>(base, a.fb, res);
+                const int g0 = 2 * kk;
+                if (k > 1) {
 #pragma unroll
-                for (int j = 0; j < H2; ++j) {
-                    const v2f w = u[j];
-                    re = fma2(w, a.fb.t[HLEN - 2 - 2 * j], re);  // p even: par = 1
-                    ro = fma2(w, a.fb.t[HLEN - 1 - 2 * j], ro);  // p odd : par = 0
-                }
-                const int ge = 2 * kk - S, go = 2 * kk + 1 - S;
-                if (ge >= lom && ge < him) {
-                    if (k > 1) nxt[ge - lom].x = re.x + re.y;
-                    else out[ge] = re.x + re.y;  // level 0: inside [0, N0) by construction
-                }
-                if (go >= lom && go < him) {
-                    if (k > 1) nxt[go - lom].x = ro.x + ro.y;
-                    else out[go] = ro.x + ro.y;
+                    for (int c = 0; c < 4; ++c)
+                        if (g0 + c >= lom && g0 + c < him) nxt[g0 + c - lom].x = res[c];
+                } else {
+                    // level 0: [lom, him) = [bx T0, min(.., N0)) is a union of whole blocks inside [0, N0)
+                    f32x4 v;
+                    v.x = res[0]; v.y = res[1]; v.z = res[2]; v.w = res[3];
+                    *reinterpret_cast<f32x4*>(out + g0) = v;
                 }
             }
         }

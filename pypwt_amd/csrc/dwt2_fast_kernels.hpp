@@ -331,6 +331,83 @@ constexpr int inv2d_fast_lds_floats() {
     return 4 * (TY + G::H2 + 1) * G::CXA + 2 * (2 * TY) * G::CXA;
 }
 
+// Column synthesis core: H2 consecutive coefficient rows (row stride `stride` pairs) of two adjacent
+// columns, given as (A,V) and (H,D) pairs -> the (t1,t2) pairs of output rows p even (e) / p odd (o).
+template <int HLEN>
+PDWT_DEVICE void inv_col_synth2(const v2f* pAV, const v2f* pHD, int stride, const FilterBankI& fb, v2f& e0, v2f& o0,
+                                v2f& e1, v2f& o1) {
+    constexpr int H2 = HLEN / 2;
+    e0 = mk2(0.f, 0.f);
+    o0 = e0; e1 = e0; o1 = e0;
+    constexpr int GB = 6;  // 2 GB LDS loads are issued, then consumed
+#pragma unroll
+    for (int j0 = 0; j0 < H2; j0 += GB) {
+        v4f wav[GB], whd[GB];
+#pragma unroll
+        for (int g = 0; g < GB; ++g)
+            if (j0 + g < H2) {
+                wav[g] = lds_load16(pAV + (j0 + g) * stride);
+                whd[g] = lds_load16(pHD + (j0 + g) * stride);
+            }
+#pragma unroll
+        for (int g = 0; g < GB; ++g) {
+            const int j = j0 + g;
+            if (j < H2) {
+                lds_pin(wav[g]);
+                lds_pin(whd[g]);
+                const v2f te = fb.t[HLEN - 2 - 2 * j];  // p even: par = 1
+                const v2f to = fb.t[HLEN - 1 - 2 * j];  // p odd : par = 0
+                const v2f av0 = mk2(wav[g].x, wav[g].y), av1 = mk2(wav[g].z, wav[g].w);
+                const v2f hd0 = mk2(whd[g].x, whd[g].y), hd1 = mk2(whd[g].z, whd[g].w);
+                e0 = fma2(av0, bc(te.x), e0); e0 = fma2(hd0, bc(te.y), e0);
+                o0 = fma2(av0, bc(to.x), o0); o0 = fma2(hd0, bc(to.y), o0);
+                e1 = fma2(av1, bc(te.x), e1); e1 = fma2(hd1, bc(te.y), e1);
+                o1 = fma2(av1, bc(to.x), o1); o1 = fma2(hd1, bc(to.y), o1);
+            }
+        }
+    }
+}
+
+// Row synthesis core: the (t1,t2) pairs from `base` (16-B aligned, PE = PADL & 1 pairs before the first
+// one used) -> the four samples 2k .. 2k+3 of coefficient columns k, k+1.
+template <int HLEN, int PADL>
+PDWT_DEVICE void inv_row_synth4(const v2f* base, const FilterBankI& fb, float res[4]) {
+    constexpr int H2 = HLEN / 2, S = (H2 & 1) ? 0 : 1;
+    constexpr int PE = PADL & 1;
+    constexpr int NP = (PE + H2 + 2 + 1) & ~1;
+    v2f u[NP];
+    v4f w[NP / 2];
+#pragma unroll
+    for (int q = 0; q < NP / 2; ++q) w[q] = lds_load16(base + 2 * q);
+#pragma unroll
+    for (int q = 0; q < NP / 2; ++q) {
+        lds_pin(w[q]);
+        u[2 * q] = mk2(w[q].x, w[q].y);
+        u[2 * q + 1] = mk2(w[q].z, w[q].w);
+    }
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {  // coefficient column k + kk -> samples 2(k+kk), 2(k+kk)+1
+        v2f r0 = mk2(0.f, 0.f), r1 = mk2(0.f, 0.f);
+        if (S == 0) {
+#pragma unroll
+            for (int j = 0; j < H2; ++j) {
+                const v2f x = u[PE + kk + j];
+                r0 = fma2(x, fb.t[HLEN - 2 - 2 * j], r0);  // p even
+                r1 = fma2(x, fb.t[HLEN - 1 - 2 * j], r1);  // p odd
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < H2 + 1; ++j) {
+                const v2f x = u[PE + kk + j];
+                if (j < H2) r0 = fma2(x, fb.t[HLEN - 1 - 2 * j], r0);        // p = 2k+1 (odd), base k
+                if (j >= 1) r1 = fma2(x, fb.t[HLEN - 2 - 2 * (j - 1)], r1);  // p = 2k+2 (even), base k+1
+            }
+        }
+        res[2 * kk] = r0.x + r0.y;
+        res[2 * kk + 1] = r1.x + r1.y;
+    }
+}
+
 // column synthesis.  Work item = (m, column pair): the two output rows p = 2m, 2m+1 (p = gy + S)
 // share the coefficient rows m .. m+H2-1 (local); even taps feed p odd, odd taps feed p even.
 template <int HLEN, int TX, int TY, int NT>
@@ -343,34 +420,8 @@ PDWT_DEVICE void inv_fast_col_pass(int tid, const v2f* sAV, const v2f* sHD, v2f*
     for (int idx = tid; idx < NM * Q2; idx += NT) {
         const int m = idx / Q2;
         const int q = 2 * (idx - m * Q2);
-        v2f e0 = mk2(0.f, 0.f), o0 = e0, e1 = e0, o1 = e0;  // p even / p odd, columns q / q+1
-        constexpr int GB = 6;  // 2 GB LDS loads are issued, then consumed
-#pragma unroll
-        for (int j0 = 0; j0 < H2; j0 += GB) {
-            v4f wav[GB], whd[GB];
-#pragma unroll
-            for (int g = 0; g < GB; ++g)
-                if (j0 + g < H2) {
-                    wav[g] = lds_load16(&sAV[(m + j0 + g) * CXA + q]);
-                    whd[g] = lds_load16(&sHD[(m + j0 + g) * CXA + q]);
-                }
-#pragma unroll
-            for (int g = 0; g < GB; ++g) {
-                const int j = j0 + g;
-                if (j < H2) {
-                    lds_pin(wav[g]);
-                    lds_pin(whd[g]);
-                    const v2f te = fb.t[HLEN - 2 - 2 * j];  // p even: par = 1
-                    const v2f to = fb.t[HLEN - 1 - 2 * j];  // p odd : par = 0
-                    const v2f av0 = mk2(wav[g].x, wav[g].y), av1 = mk2(wav[g].z, wav[g].w);
-                    const v2f hd0 = mk2(whd[g].x, whd[g].y), hd1 = mk2(whd[g].z, whd[g].w);
-                    e0 = fma2(av0, bc(te.x), e0); e0 = fma2(hd0, bc(te.y), e0);
-                    o0 = fma2(av0, bc(to.x), o0); o0 = fma2(hd0, bc(to.y), o0);
-                    e1 = fma2(av1, bc(te.x), e1); e1 = fma2(hd1, bc(te.y), e1);
-                    o1 = fma2(av1, bc(to.x), o1); o1 = fma2(hd1, bc(to.y), o1);
-                }
-            }
-        }
+        v2f e0, o0, e1, o1;  // p even / p odd, columns q / q+1
+        inv_col_synth2<HLEN>(&sAV[m * CXA + q], &sHD[m * CXA + q], CXA, fb, e0, o0, e1, o1);
         const int ge = 2 * m - S, go = 2 * m + 1 - S;  // local output rows
         f32x4 w;
         if (ge >= 0 && ge < OY) {
@@ -397,39 +448,8 @@ PDWT_DEVICE void inv_fast_row_pass(int tid, const v2f* tt, const Inv2DFastArgs& 
     for (int idx = tid; idx < OY * HT; idx += NT) {
         const int gy = idx / HT;
         const int k = 2 * (idx - gy * HT);
-        v2f u[NP];
-        const v2f* base = tt + gy * CXA + (PADL - PE) + k;
-        v4f w[NP / 2];
-#pragma unroll
-        for (int q = 0; q < NP / 2; ++q) w[q] = lds_load16(base + 2 * q);
-#pragma unroll
-        for (int q = 0; q < NP / 2; ++q) {
-            lds_pin(w[q]);
-            u[2 * q] = mk2(w[q].x, w[q].y);
-            u[2 * q + 1] = mk2(w[q].z, w[q].w);
-        }
         float res[4];
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {  // coefficient column k + kk -> samples 2(k+kk), 2(k+kk)+1
-            v2f r0 = mk2(0.f, 0.f), r1 = mk2(0.f, 0.f);
-            if (S == 0) {
-#pragma unroll
-                for (int j = 0; j < H2; ++j) {
-                    const v2f w = u[PE + kk + j];
-                    r0 = fma2(w, a.fb.t[HLEN - 2 - 2 * j], r0);  // p even
-                    r1 = fma2(w, a.fb.t[HLEN - 1 - 2 * j], r1);  // p odd
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < H2 + 1; ++j) {
-                    const v2f w = u[PE + kk + j];
-                    if (j < H2) r0 = fma2(w, a.fb.t[HLEN - 1 - 2 * j], r0);        // p = 2k+1 (odd), base k
-                    if (j >= 1) r1 = fma2(w, a.fb.t[HLEN - 2 - 2 * (j - 1)], r1);  // p = 2k+2 (even), base k+1
-                }
-            }
-            res[2 * kk] = r0.x + r0.y;
-            res[2 * kk + 1] = r1.x + r1.y;
-        }
+        inv_row_synth4<HLEN, PADL>(tt + gy * CXA + (PADL - PE) + k, a.fb, res);
         const int oy = 2 * by * TY + gy;
         const int ox = 2 * (bx * TX + k);
         if (oy < a.Nr && ox < a.Nc) {  // Nc % 8 == 0 (Ncc % 4 == 0): the float4 is inside and aligned

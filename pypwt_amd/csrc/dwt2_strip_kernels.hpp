@@ -262,4 +262,228 @@ __global__ void __launch_bounds__(NT) dwt2_fwd_strip2_kernel(const FwdStrip2Args
 }
 #endif
 
+// ===========================================================================================
+// Inverse strips: levels l+1 and l undone in one launch, streaming down strips of 2*TX output columns.
+// Per chunk a workgroup reads 4 coefficient rows of level l+1 (four bands) and 8 detail rows of
+// level l (three bands), synthesises 8 rows of A_l in LDS and from them 16 output rows.  The H2-1 =
+// hlen/2-1 coefficient rows a synthesis window shares with the previous chunk stay in LDS (carry
+// rows of the two ring buffers); A_l is never in HBM.  Loads of the next chunk are in flight (one
+// work item per thread: a 4-column group of one row, three or four bands) while this one is computed.
+//
+// Row bookkeeping (C = H2/2, S = 1 if H2 even): coefficient index kk yields outputs p = 2kk, 2kk+1 at
+// position g = p - S from coefficient rows kk-C .. kk-C+H2-1.  Chunk t stages level-(l+1) rows
+// [c2b+4t, +4), synthesises the 4 items whose window ends in them = level-l rows [a1+8t, +8),
+// a1 = 2(c2b+C-H2+1)-S, stages the level-l details of those rows, and synthesises the 8 items whose
+// window ends in them = output rows [o0+16t, +16), o0 = 2(a1+C-H2+1)-S.  c2b is chosen so that
+// o0 + 16 WARM <= first owned row < o0 + 16 WARM + 4; chunk 0 is a warm-up (fills the level-l carry
+// rows) when the filter has carry rows at all.
+// ===========================================================================================
+struct InvStrip2Args {
+    const float *A2, *H2, *V2, *D2;  // level l+1: (N0r/4, N0c/4)
+    const float *H1, *V1, *D1;       // level l  : (N0r/2, N0c/2)
+    float* out;                      // level l-1: (N0r, N0c)
+    int N0r, N0c;
+    long long l2_bstride, l1_bstride, out_bstride;
+    int strips;    // strips of TX level-l coefficient columns (2 TX output columns)
+    int segs;      // row segments
+    int seg_rows;  // output rows per segment
+    FilterBankI fb;  // (rec_lo, rec_hi)
+};
+
+template <int HLEN, int TX>
+struct InvStrip2Geom {
+    using G1 = InvFastGeom<HLEN, TX>;
+    static constexpr int H2 = G1::H2, C = G1::C, S = G1::S, PADL = G1::PADL, CXA = G1::CXA;
+    static constexpr int K = H2 - 1;                 // carry rows of both rings
+    static constexpr int WARM = K > 0 ? 1 : 0;
+    static constexpr int R2 = K + 4, R1 = K + 8;     // ring rows
+    static constexpr int W2 = ((CXA / 2 + H2 + 2 + 3 + 3) & ~3);   // level-(l+1) pair columns incl. alignment slack
+    static constexpr int NK = (CXA - 1 + S) / 2 + 1;                // level-(l+1) row-synthesis items per row
+    static constexpr int LDS_FLOATS = 2 * (2 * R2 * W2 + 8 * W2 + 2 * R1 * CXA + 16 * CXA) + 16;
+    static_assert(K <= 4, "carry copy of the level-(l+1) ring must not overlap its source");
+};
+
+template <int HLEN, int TX, int NT>
+PDWT_DEVICE void dwt2_inv_strip2_wg(const InvStrip2Args& a, int bx, int sg, int bz, float* smem) {
+    using G = InvStrip2Geom<HLEN, TX>;
+    constexpr int H2 = G::H2, C = G::C, S = G::S, PADL = G::PADL, CXA = G::CXA, K = G::K, WARM = G::WARM, R2 = G::R2,
+                  R1 = G::R1, W2 = G::W2, NK = G::NK;
+    constexpr int V4 = CXA / 4;
+    constexpr int N1I = 8 * V4;           // level-l load items per chunk (row, 4-column group)
+    static_assert(N1I + 4 * (W2 / 4) <= NT, "one load item per thread");
+
+    v2f* sAV2 = reinterpret_cast<v2f*>(smem);  // R2 x W2
+    v2f* sHD2 = sAV2 + R2 * W2;
+    v2f* tt2 = sHD2 + R2 * W2;                 // 8 x W2
+    v2f* sAV1 = tt2 + 8 * W2;                  // R1 x CXA
+    v2f* sHD1 = sAV1 + R1 * CXA;
+    v2f* tt1 = sHD1 + R1 * CXA;                // 16 x CXA
+
+    const int N1r = a.N0r >> 1, N1c = a.N0c >> 1, N2r = a.N0r >> 2, N2c = a.N0c >> 2;
+    const int oy = sg * a.seg_rows;
+    const int oy_end = (oy + a.seg_rows < a.N0r) ? oy + a.seg_rows : a.N0r;
+    const int X = oy - 6 * (C - H2 + 1) + 3 * S;
+    const int c2b = (X >> 2) - 4 * WARM;             // arithmetic shift = floor
+    const int a1 = 2 * (c2b + C - H2 + 1) - S;
+    const int o0 = 2 * (a1 + C - H2 + 1) - S;
+    const int T = (oy_end - o0 + 15) >> 4;           // chunks 0 .. T-1
+
+    const int cxa = bx * TX - C - PADL;              // level-l column origin, multiple of 4
+    const int kx_lo = (cxa + S) >> 1;
+    const int c2xa = (kx_lo - C) & ~3;               // level-(l+1) column origin, multiple of 4
+    const int nc2 = ((((cxa + CXA - 1 + S) >> 1) - C + H2 - c2xa) + 3) & ~3;  // <= W2
+    const int g42 = nc2 >> 2;
+    const int N2I = 4 * g42;
+
+    const long long b2 = (long long)bz * a.l2_bstride, b1 = (long long)bz * a.l1_bstride;
+    float* PDWT_RESTRICT out = a.out + (long long)bz * a.out_bstride;
+
+    // ---- prologue: carry rows of the level-(l+1) ring = rows [c2b-K, c2b)
+    PDWT_FOR_THREADS(tid, NT) {
+        for (int idx = tid; idx < K * g42; idx += NT) {
+            const int r = idx / g42, g = idx - r * g42;
+            const long long o = b2 + (long long)wrap_periodic(c2b - K + r, N2r) * N2c + wrap_periodic(c2xa + 4 * g, N2c);
+            inv_fast_interleave(sAV2, sHD2, r * W2 + 4 * g, *reinterpret_cast<const v4f*>(a.A2 + o),
+                                *reinterpret_cast<const v4f*>(a.V2 + o), *reinterpret_cast<const v4f*>(a.H2 + o),
+                                *reinterpret_cast<const v4f*>(a.D2 + o));
+        }
+    }
+
+    PDWT_PER_THREAD(v4f, stage, 4, NT);
+    // one load item per thread: tid < N1I: level-l (row r, group g): V,H,D ; next N2I threads: level-(l+1)
+    // (row r, group g): A,V,H,D ; the rest reload a valid address (branch-free: staging stays in VGPRs)
+    auto issue = [&](int tid, int t) {
+        const bool l2 = tid >= N1I;
+        int i2 = tid - N1I;
+        if (i2 >= N2I) i2 = N2I - 1;
+        const int r = l2 ? i2 / g42 : tid / V4;
+        const int g = l2 ? i2 - r * g42 : tid - r * V4;
+        const int row = l2 ? wrap_periodic(c2b + 4 * t + r, N2r) : wrap_periodic(a1 + 8 * t + r, N1r);
+        const int col = l2 ? wrap_periodic(c2xa + 4 * g, N2c) : wrap_periodic(cxa + 4 * g, N1c);
+        const long long o = l2 ? b2 + (long long)row * N2c + col : b1 + (long long)row * N1c + col;
+        const float* p0 = l2 ? a.A2 : a.V1;
+        const float* p1 = l2 ? a.V2 : a.H1;
+        const float* p2 = l2 ? a.H2 : a.D1;
+        const float* p3 = l2 ? a.D2 : a.D1;
+        PDWT_MINE(stage, tid)[0] = *reinterpret_cast<const v4f*>(p0 + o);
+        PDWT_MINE(stage, tid)[1] = *reinterpret_cast<const v4f*>(p1 + o);
+        PDWT_MINE(stage, tid)[2] = *reinterpret_cast<const v4f*>(p2 + o);
+        PDWT_MINE(stage, tid)[3] = *reinterpret_cast<const v4f*>(p3 + o);
+    };
+    PDWT_FOR_THREADS(tid, NT) { issue(tid, 0); }
+
+    for (int t = 0; t < T; ++t) {
+        // ---- P1: staged loads -> the new rows of the two rings
+        PDWT_FOR_THREADS(tid, NT) {
+            const v4f s0 = PDWT_MINE(stage, tid)[0], s1 = PDWT_MINE(stage, tid)[1], s2 = PDWT_MINE(stage, tid)[2],
+                      s3 = PDWT_MINE(stage, tid)[3];
+            if (tid < N1I) {
+                const int r = tid / V4, g = tid - r * V4;
+                v2f* dAV = sAV1 + (K + r) * CXA + 4 * g;
+                dAV[0].y = s0.x; dAV[1].y = s0.y; dAV[2].y = s0.z; dAV[3].y = s0.w;
+                f32x4 w;
+                f32x4* dHD = reinterpret_cast<f32x4*>(sHD1 + (K + r) * CXA + 4 * g);
+                w.x = s1.x; w.y = s2.x; w.z = s1.y; w.w = s2.y; dHD[0] = w;
+                w.x = s1.z; w.y = s2.z; w.z = s1.w; w.w = s2.w; dHD[1] = w;
+            } else if (tid - N1I < N2I) {
+                const int i2 = tid - N1I;
+                const int r = i2 / g42, g = i2 - r * g42;
+                inv_fast_interleave(sAV2, sHD2, (K + r) * W2 + 4 * g, s0, s1, s2, s3);
+            }
+        }
+        PDWT_SYNC();
+        if (t + 1 < T) {
+            PDWT_FOR_THREADS(tid, NT) { issue(tid, t + 1); }
+        }
+        // ---- P2: level-(l+1) column synthesis: item i uses ring rows i .. i+H2-1 -> tt2 rows 2i, 2i+1
+        PDWT_FOR_THREADS(tid, NT) {
+            const int q2n = nc2 >> 1;
+            for (int idx = tid; idx < 4 * q2n; idx += NT) {
+                const int i = idx / q2n, q = 2 * (idx - i * q2n);
+                v2f e0, o0v, e1, o1v;
+                inv_col_synth2<HLEN>(&sAV2[i * W2 + q], &sHD2[i * W2 + q], W2, a.fb, e0, o0v, e1, o1v);
+                f32x4 w;
+                w.x = e0.x; w.y = e0.y; w.z = e1.x; w.w = e1.y;
+                *reinterpret_cast<f32x4*>(&tt2[(2 * i) * W2 + q]) = w;
+                w.x = o0v.x; w.y = o0v.y; w.z = o1v.x; w.w = o1v.y;
+                *reinterpret_cast<f32x4*>(&tt2[(2 * i + 1) * W2 + q]) = w;
+            }
+        }
+        PDWT_SYNC();
+        // ---- P3: level-(l+1) row synthesis -> A_l into the .x lanes of the new level-l ring rows ;
+        //          carry the level-(l+1) ring
+        PDWT_FOR_THREADS(tid, NT) {
+            for (int idx = tid; idx < 8 * NK; idx += NT) {
+                const int r = idx / NK, kk = kx_lo + (idx - r * NK);
+                const v2f* u = tt2 + r * W2 + (kk - C - c2xa);
+                v2f re = mk2(0.f, 0.f), ro = mk2(0.f, 0.f);
+#pragma unroll
+                for (int j = 0; j < H2; ++j) {
+                    const v2f w = u[j];
+                    re = fma2(w, a.fb.t[HLEN - 2 - 2 * j], re);
+                    ro = fma2(w, a.fb.t[HLEN - 1 - 2 * j], ro);
+                }
+                const int ge = 2 * kk - S - cxa, go = ge + 1;  // local level-l columns
+                if (ge >= 0 && ge < CXA) sAV1[(K + r) * CXA + ge].x = re.x + re.y;
+                if (go >= 0 && go < CXA) sAV1[(K + r) * CXA + go].x = ro.x + ro.y;
+            }
+            for (int idx = tid; idx < K * W2; idx += NT) {
+                sAV2[idx] = sAV2[4 * W2 + idx];
+                sHD2[idx] = sHD2[4 * W2 + idx];
+            }
+        }
+        PDWT_SYNC();
+        if (t >= WARM) {
+            // ---- P4: level-l column synthesis: item i uses ring rows i .. i+H2-1 -> tt1 rows 2i, 2i+1
+            PDWT_FOR_THREADS(tid, NT) {
+                constexpr int Q2 = CXA / 2;
+                for (int idx = tid; idx < 8 * Q2; idx += NT) {
+                    const int i = idx / Q2, q = 2 * (idx - i * Q2);
+                    v2f e0, o0v, e1, o1v;
+                    inv_col_synth2<HLEN>(&sAV1[i * CXA + q], &sHD1[i * CXA + q], CXA, a.fb, e0, o0v, e1, o1v);
+                    f32x4 w;
+                    w.x = e0.x; w.y = e0.y; w.z = e1.x; w.w = e1.y;
+                    *reinterpret_cast<f32x4*>(&tt1[(2 * i) * CXA + q]) = w;
+                    w.x = o0v.x; w.y = o0v.y; w.z = o1v.x; w.w = o1v.y;
+                    *reinterpret_cast<f32x4*>(&tt1[(2 * i + 1) * CXA + q]) = w;
+                }
+            }
+            PDWT_SYNC();
+        }
+        // ---- P5: level-l row synthesis, 16-B stores of the owned rows ; carry the level-l ring
+        PDWT_FOR_THREADS(tid, NT) {
+            if (t >= WARM) {
+                constexpr int HT = TX / 2;
+                constexpr int PE = PADL & 1;
+                for (int idx = tid; idx < 16 * HT; idx += NT) {
+                    const int gy = idx / HT, k = 2 * (idx - gy * HT);
+                    float res[4];
+                    inv_row_synth4<HLEN, PADL>(tt1 + gy * CXA + (PADL - PE) + k, a.fb, res);
+                    const int y = o0 + 16 * t + gy;
+                    const int x = 2 * (bx * TX + k);
+                    if (y >= oy && y < oy_end && x < a.N0c) {
+                        f32x4 v;
+                        v.x = res[0]; v.y = res[1]; v.z = res[2]; v.w = res[3];
+                        *reinterpret_cast<f32x4*>(out + (long long)y * a.N0c + x) = v;
+                    }
+                }
+            }
+            for (int idx = tid; idx < K * CXA; idx += NT) {
+                sAV1[idx] = sAV1[8 * CXA + idx];
+                sHD1[idx] = sHD1[8 * CXA + idx];
+            }
+        }
+        PDWT_SYNC();
+    }
+}
+
+#ifndef PDWT_CPU_EMU
+template <int HLEN, int TX, int NT>
+__global__ void __launch_bounds__(NT) dwt2_inv_strip2_kernel(const InvStrip2Args a) {
+    extern __shared__ __attribute__((aligned(16))) float pdwt_smem[];
+    const int sg = blockIdx.x / a.strips;
+    dwt2_inv_strip2_wg<HLEN, TX, NT>(a, blockIdx.x - sg * a.strips, sg, blockIdx.y, pdwt_smem);
+}
+#endif
+
 }  // namespace pdwt

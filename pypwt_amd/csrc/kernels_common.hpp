@@ -56,6 +56,22 @@ struct FilterBank {
     float hi[kMaxTaps];
 };
 
+// ---- asynchronous global -> LDS copy (gfx950 global_load_lds_dwordx4) ----------------------------
+// Each active lane copies 16 B from ITS OWN global address to lds_lane0 + 16 * lane: the LDS image of
+// one wave instruction is lane-linear from a wave-uniform base (active lanes must be a prefix of the
+// wave).  No VGPR destination and no wait at the issue point: many copies can be put in flight back
+// to back; the next PDWT_SYNC() (s_waitcnt vmcnt(0) + s_barrier) retires them.
+#ifdef PDWT_CPU_EMU
+static inline void pdwt_glds16(const float* gsrc, float* lds_lane0, int lane) {
+    for (int c = 0; c < 4; ++c) lds_lane0[4 * lane + c] = gsrc[c];
+}
+#else
+static __device__ __forceinline__ void pdwt_glds16(const float* gsrc, float* lds_lane0, int /*lane*/) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_lane0, 16, 0, 0);
+}
+#endif
+
 // ---- index helpers -------------------------------------------------------
 
 PDWT_DEVICE int true_mod(int i, int n) {

@@ -27,6 +27,8 @@ hipError_t launch_dwt2_fwd_pyr2(const float* in, float* const det1[3], float* co
 // same contract, streaming-strip kernel for large inputs (forward only)
 hipError_t launch_dwt2_fwd_strip2(const float* in, float* const det1[3], float* const band2[4], int N0r, int N0c,
                                   int hlen, const FilterBank& fb, int batch, hipStream_t s);
+hipError_t launch_dwt2_inv_strip2(const float* const band2[4], const float* const det1[3], float* out, int N0r,
+                                  int N0c, int hlen, const FilterBank& fb, int batch, hipStream_t s);
 hipError_t launch_dwt2_inv_pyr2(const float* const band2[4], const float* const det1[3], float* out, int N0r, int N0c,
                                 int hlen, const FilterBank& fb, int batch, hipStream_t s);
 hipError_t launch_dwt1_fwd(const Fwd1DArgs& a, hipStream_t s);

@@ -119,6 +119,44 @@ hipError_t launch_dwt2_fwd_strip2(const float* in, float* const det1[3], float* 
     return hipErrorNotSupported;
 }
 
+template <int HLEN>
+static hipError_t run_inv_strip(InvStrip2Args& a, int batch, hipStream_t s) {
+    constexpr int TX = 64, NT = 256;
+    constexpr size_t lds = (size_t)InvStrip2Geom<HLEN, TX>::LDS_FLOATS * sizeof(float);
+    static_assert(lds <= 64 * 1024, "fits the default dynamic-LDS limit");
+    a.strips = cdiv(a.N0c / 2, TX);
+    int seg = 512;  // output rows per workgroup; one 16-row warm-up chunk per segment
+    while (seg > 64 && (long long)a.strips * cdiv(a.N0r, seg) * batch < 1024) seg >>= 1;
+    a.seg_rows = seg;
+    a.segs = cdiv(a.N0r, seg);
+    hipLaunchKernelGGL((dwt2_inv_strip2_kernel<HLEN, TX, NT>), dim3(a.strips * a.segs, batch), dim3(NT), lds, s, a);
+    return hipGetLastError();
+}
+
+// same contract as launch_dwt2_inv_pyr2, streaming-strip kernel for large inputs
+hipError_t launch_dwt2_inv_strip2(const float* const band2[4], const float* const det1[3], float* out, int N0r,
+                                  int N0c, int hlen, const FilterBank& fb, int batch, hipStream_t s) {
+    if (!dwt2_pyramid_supported(hlen, N0r, N0c)) return hipErrorNotSupported;
+    if (!al16(out) || !al16(det1[0]) || !al16(det1[1]) || !al16(det1[2]) || !al16(band2[0]) || !al16(band2[1]) ||
+        !al16(band2[2]) || !al16(band2[3]))
+        return hipErrorNotSupported;
+    InvStrip2Args a;
+    a.A2 = band2[0]; a.H2 = band2[1]; a.V2 = band2[2]; a.D2 = band2[3];
+    a.H1 = det1[0]; a.V1 = det1[1]; a.D1 = det1[2];
+    a.out = out; a.N0r = N0r; a.N0c = N0c;
+    a.out_bstride = (long long)N0r * N0c;
+    a.l1_bstride = (long long)(N0r / 2) * (N0c / 2);
+    a.l2_bstride = (long long)(N0r / 4) * (N0c / 4);
+    interleave(a.fb, fb);
+    switch (hlen) {
+        case 2: return run_inv_strip<2>(a, batch, s);
+        case 4: return run_inv_strip<4>(a, batch, s);
+        case 6: return run_inv_strip<6>(a, batch, s);
+        case 8: return run_inv_strip<8>(a, batch, s);
+    }
+    return hipErrorNotSupported;
+}
+
 hipError_t launch_dwt2_inv_pyr2(const float* const band2[4], const float* const det1[3], float* out, int N0r, int N0c,
                                 int hlen, const FilterBank& fb, int batch, hipStream_t s) {
     if (!dwt2_pyramid_supported(hlen, N0r, N0c)) return hipErrorNotSupported;

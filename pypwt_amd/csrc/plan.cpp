@@ -303,14 +303,19 @@ std::vector<int> pyramid_pairs(const pdwt_plan* p) {
     return v;
 }
 
-// First levels l of the FORWARD level pairs that run as one streaming-strip launch (dwt2_strip_kernels.hpp):
-// the opposite regime -- at least 2^26 samples enter the pair (a batch of large images), where the level
-// is bandwidth-bound and not writing + re-reading A_l is what pays.  PDWT_FORCE_STRIP=1 drops the size
-// threshold (tests), PDWT_NO_STRIP=1 disables the path.
-std::vector<int> strip_pairs_fwd(const pdwt_plan* p) {
+// First levels l of the level pairs (l, l+1) that run as one streaming-strip launch (dwt2_strip_kernels.hpp):
+// the opposite regime of the tile pyramid -- at least 2^26 samples enter the pair (a batch of large
+// images), where the level is bandwidth-bound and not writing + re-reading A_l is what pays.
+// Measured (MI355X, db4, 8 x 4096^2, profiles/r01f_kbench_strip.txt): forward 284 -> 232 us; the INVERSE
+// strip kernel is no faster than two launches (292 vs 290 us: it reads seven bands at once), so it
+// only runs when PDWT_FORCE_STRIP=1 (tests); that variable also drops the size threshold.
+// PDWT_NO_STRIP=1 disables the path.
+std::vector<int> strip_pairs(const pdwt_plan* p, bool inverse) {
     std::vector<int> v;
     if (p->info.ndims != 2 || p->info.do_swt || !p->do_separable || getenv("PDWT_NO_STRIP")) return v;
-    const long long min_samples = getenv("PDWT_FORCE_STRIP") ? 0 : (1LL << 26);
+    const bool force = getenv("PDWT_FORCE_STRIP") != nullptr;
+    if (inverse && !force) return v;
+    const long long min_samples = force ? 0 : (1LL << 26);
     const int L = p->info.nlevels;
     for (int l = 1; l + 1 <= L; l++) {
         const long long samples = (long long)p->batch * p->lr[l - 1] * p->lc[l - 1];
@@ -359,7 +364,7 @@ int forward_impl(pdwt_plan* p, int only = 0) {
     const bool swt = p->info.do_swt != 0;
     const float* src = p->image();
     if (p->info.ndims == 2) {
-        const std::vector<int> strips = strip_pairs_fwd(p);
+        const std::vector<int> strips = strip_pairs(p, false);
         std::vector<int> pyr = pyramid_pairs(p);
         for (int l = 1; l <= L; l++) {
             const bool run = (only == 0 || only == l);
@@ -495,8 +500,22 @@ int inverse_impl(pdwt_plan* p, int only = 0) {
     const float* cur = p->band(0);
     if (p->info.ndims == 2) {
         const std::vector<int> pyr = pyramid_pairs(p);
+        const std::vector<int> strips = strip_pairs(p, true);
         for (int l = L; l >= 1; l--) {
-            if (l >= 2 && in_list(pyr, l - 1)) {
+            if (l >= 2 && in_list(strips, l - 1)) {
+                const int l1 = l - 1;
+                const float* band2[4] = {cur, p->band(3 * (l - 1) + 1), p->band(3 * (l - 1) + 2), p->band(3 * (l - 1) + 3)};
+                const float* det1[3] = {p->band(3 * (l1 - 1) + 1), p->band(3 * (l1 - 1) + 2), p->band(3 * (l1 - 1) + 3)};
+                float* dst = (l1 == 1) ? p->image() : p->arena + p->approx_off[l1 - 1];
+                Stamp st(p, "dwt2_inv_strip2");
+                if (only == 0 || only == l1)
+                    HIP_TRY(launch_dwt2_inv_strip2(band2, det1, dst, p->lr[l1 - 1], p->lc[l1 - 1], hlen, p->rec, B,
+                                                   p->stream));
+                cur = dst;
+                l--;
+                continue;
+            }
+            if (l >= 2 && in_list(pyr, l - 1) && !in_list(strips, l)) {
                 // levels l and l-1 undone in one launch: A_{l-1} is synthesised in LDS
                 const int l1 = l - 1;
                 const float* band2[4] = {cur, p->band(3 * (l - 1) + 1), p->band(3 * (l - 1) + 2), p->band(3 * (l - 1) + 3)};

@@ -443,3 +443,31 @@ EMU_API int emu_dwt2_fwd_strip2(const float* in, int batch, int N0r, int N0c, co
     }
     return -1;
 }
+
+template <int HLEN, int TX, int NT>
+static void run_inv_strip2(InvStrip2Args a, int batch) {
+    std::vector<float> smem(InvStrip2Geom<HLEN, TX>::LDS_FLOATS + 64, NAN);
+    a.strips = cdiv(a.N0c / 2, TX); a.segs = cdiv(a.N0r, a.seg_rows);
+    for (int bz = 0; bz < batch; bz++)
+        for (int sg = 0; sg < a.segs; sg++)
+            for (int st = 0; st < a.strips; st++) dwt2_inv_strip2_wg<HLEN, TX, NT>(a, st, sg, bz, smem.data());
+}
+
+EMU_API int emu_dwt2_inv_strip2(const float* l1, const float* l2, int batch, int N0r, int N0c, const float* lo,
+                                const float* hi, int hlen, int seg_rows, float* out) {
+    if ((hlen & 1) || hlen > 8 || (N0c & 15) || (N0r & 3)) return -2;
+    InvStrip2Args a;
+    const long long n1 = (long long)batch * (N0r / 2) * (N0c / 2), n2 = (long long)batch * (N0r / 4) * (N0c / 4);
+    a.H1 = l1; a.V1 = l1 + n1; a.D1 = l1 + 2 * n1;
+    a.A2 = l2; a.H2 = l2 + n2; a.V2 = l2 + 2 * n2; a.D2 = l2 + 3 * n2;
+    a.out = out; a.N0r = N0r; a.N0c = N0c; a.seg_rows = seg_rows;
+    a.out_bstride = (long long)N0r * N0c; a.l1_bstride = (long long)(N0r / 2) * (N0c / 2);
+    a.l2_bstride = (long long)(N0r / 4) * (N0c / 4);
+    set_bank_i(a.fb, lo, hi, hlen);
+    switch (hlen) {
+#define X(h) case h: run_inv_strip2<h, 64, 256>(a, batch); return 0;
+        X(2) X(4) X(6) X(8)
+#undef X
+    }
+    return -1;
+}

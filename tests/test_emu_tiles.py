@@ -383,3 +383,22 @@ def test_emu_dwt2_fwd_strip_streaming(wname):
                 for k, (g, r) in enumerate(zip(got, ref)):
                     assert np.isfinite(g).all(), (wname, shape, seg2, k)
                     assert np.abs(g - r).max() <= 2 * _tol(r), (wname, shape, seg2, k)
+
+
+@pytest.mark.parametrize("wname", ["haar", "db2", "db3", "db4", "sym4", "bior3.1"])
+def test_emu_dwt2_inv_strip_streaming(wname):
+    """Inverse of two levels per launch, streaming down strips with carried coefficient rows."""
+    hlen, dlo, dhi, rlo, rhi = oracle.filters(wname)
+    for si, (B, shape) in enumerate([(1, (64, 64)), (1, (32, 144)), (2, (40, 80)), (1, (128, 512)), (1, (4, 16)), (1, (260, 272)), (1, (512, 128))]):
+        n1 = (shape[0] // 2, shape[1] // 2)
+        n2 = (shape[0] // 4, shape[1] // 4)
+        l1 = np.stack([oracle.hash_input((B,) + n1, 8700 + 10 * si + k, 2.0) - 1.0 for k in range(3)])  # H1,V1,D1
+        l2 = np.stack([oracle.hash_input((B,) + n2, 8800 + 10 * si + k, 2.0) - 1.0 for k in range(4)])  # A2,H2,V2,D2
+        for seg_rows in (16, 48, 64, 128, 4000):
+            out = np.full((B,) + shape, np.nan, dtype=np.float32)
+            assert lib().emu_dwt2_inv_strip2(P(l1), P(l2), B, shape[0], shape[1], P(rlo), P(rhi), hlen, seg_rows, P(out)) == 0
+            for b in range(B):
+                bands = [l2[0, b], l1[0, b], l1[1, b], l1[2, b], l2[1, b], l2[2, b], l2[3, b]]
+                want = oracle.inverse(bands, shape, wname, 2, ndim=2)
+                assert np.isfinite(out[b]).all(), (wname, shape, seg_rows)
+                assert np.abs(out[b] - want).max() <= 3 * _tol(want), (wname, shape, seg_rows)

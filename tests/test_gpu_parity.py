@@ -302,9 +302,9 @@ def test_cfg4_swt_2048_haar_L5_soft_threshold_full_size(W):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("wname", ["haar", "db2", "db3", "db4"])
-def test_strip_forward_path_matches_oracle(wname, monkeypatch):
-    """The streaming-strip forward (two levels per launch, used for batches of large images) forced on
-    small inputs: coefficients must equal the oracle's and the per-level path's."""
+def test_strip_paths_match_oracle(wname, monkeypatch):
+    """The streaming-strip kernels (two levels per launch, used for batches of large images) forced on
+    small inputs: coefficients and reconstruction must equal the oracle's and the per-level path's."""
     from pypwt_amd import BatchedWavelets
     monkeypatch.setenv("PDWT_FORCE_STRIP", "1")
     B, shape, L = 3, (136, 272), 3
@@ -312,9 +312,11 @@ def test_strip_forward_path_matches_oracle(wname, monkeypatch):
     w = BatchedWavelets(B, shape[0], shape[1], wname, L, img=x)
     w.enable_kernel_timing(True)
     w.forward()
-    assert "dwt2_fwd_strip2" in [n for n, _ in w.kernel_times()]
-    w.enable_kernel_timing(False)
     got = [w.coeff(i) for i in range(3 * w.levels + 1)]
+    w.inverse()
+    names = [n for n, _ in w.kernel_times()]
+    assert "dwt2_fwd_strip2" in names and "dwt2_inv_strip2" in names, names
+    rec = w.image
     monkeypatch.delenv("PDWT_FORCE_STRIP")
     monkeypatch.setenv("PDWT_NO_STRIP", "1")
     w2 = BatchedWavelets(B, shape[0], shape[1], wname, L, img=x)
@@ -325,5 +327,6 @@ def test_strip_forward_path_matches_oracle(wname, monkeypatch):
             tol = 1.5e-6 * (1 + w.levels) * max(1.0, float(np.abs(r).max()))
             assert np.abs(got[k][b] - r).max() <= tol, (wname, b, k)
             assert np.abs(got[k][b] - w2.coeff(k)[b]).max() <= tol, (wname, b, k)
-    w.inverse()
-    assert np.abs(w.image - x).max() <= 2e-3
+    w2.inverse()
+    assert np.abs(rec - x).max() <= 2e-3
+    assert np.abs(rec - w2.image).max() <= 1e-3

@@ -259,6 +259,24 @@ static void bench_fwd_strip2(const char* tag, const float* in, float* out, int N
     printf("%-24s PF=%d seg2=%3d wgs=%5d N=%d B=%d lds=%6zu  %8.2f us  (two levels in one launch)\n", tag, PF, seg2, a.strips * a.segs, N, batch, lds, us);
 }
 
+template <int HLEN, int TX, int NT>
+static void bench_inv_strip2(const char* tag, const float* in, float* out, int N, int batch, int seg_rows) {
+    if (skip(tag)) return;
+    InvStrip2Args a;
+    const long long n1 = (long long)batch * (N / 2) * (N / 2), n2 = (long long)batch * (N / 4) * (N / 4);
+    a.H1 = in; a.V1 = in + n1; a.D1 = in + 2 * n1;
+    const float* l2 = in + 3 * n1;
+    a.A2 = l2; a.H2 = l2 + n2; a.V2 = l2 + 2 * n2; a.D2 = l2 + 3 * n2;
+    a.out = out; a.N0r = N; a.N0c = N; a.seg_rows = seg_rows;
+    a.out_bstride = (long long)N * N; a.l1_bstride = (long long)(N / 2) * (N / 2); a.l2_bstride = (long long)(N / 4) * (N / 4);
+    a.strips = (N / 2 + TX - 1) / TX; a.segs = (N + seg_rows - 1) / seg_rows;
+    memset(&a.fb, 0, sizeof(a.fb));
+    for (int i = 0; i < 8; i++) { a.fb.t[i].x = DB4_LO[7 - i]; a.fb.t[i].y = DB4_HI[7 - i]; }
+    const size_t lds = (size_t)InvStrip2Geom<HLEN, TX>::LDS_FLOATS * sizeof(float);
+    float us = time_it([&] { hipLaunchKernelGGL((dwt2_inv_strip2_kernel<HLEN, TX, NT>), dim3(a.strips * a.segs, batch), dim3(NT), lds, 0, a); });
+    printf("%-24s seg_rows=%4d wgs=%5d N=%d B=%d lds=%6zu  %8.2f us  (two levels in one launch)\n", tag, seg_rows, a.strips * a.segs, N, batch, lds, us);
+}
+
 int main(int argc, char** argv) {
     const int N = argc > 1 ? atoi(argv[1]) : 4096;
     const int B = argc > 2 ? atoi(argv[2]) : 1;
@@ -296,6 +314,12 @@ int main(int argc, char** argv) {
     for (int sg : {16, 32, 64, 128}) bench_fwd_strip2<8, 32, 256, 3>("STRIP2 fwd db4 TX2=32 NT256", a, b, N, B, sg);
     for (int sg : {16, 32, 64}) bench_fwd_strip2<8, 64, 512, 2>("STRIP2 fwd db4 TX2=64 NT512", a, b, N, B, sg);
     for (int sg : {16, 32, 64}) bench_fwd_strip2<8, 64, 256, 2>("STRIP2 fwd db4 TX2=64 NT256", a, b, N, B, sg);
+    for (int sg : {128, 256, 512}) bench_inv_strip2<8, 64, 256>("STRIP2 inv db4 TX=64 NT256", b, a, N, B, sg);
+    for (int sg : {128, 256, 512}) bench_inv_strip2<8, 64, 512>("STRIP2 inv db4 TX=64 NT512", b, a, N, B, sg);
+    for (int sg : {128, 256, 512}) bench_inv_strip2<8, 56, 256>("STRIP2 inv db4 TX=56 NT256", b, a, N, B, sg);
+    for (int sg : {128, 256, 512}) bench_inv_strip2<8, 120, 512>("STRIP2 inv db4 TX=120 NT512", b, a, N, B, sg);
+    for (int sg : {32, 64, 128}) bench_fwd_strip2<8, 28, 256, 2>("STRIP2 fwd db4 TX2=28 NT256", a, b, N, B, sg);
+    for (int sg : {32, 64, 128}) bench_fwd_strip2<8, 60, 512, 2>("STRIP2 fwd db4 TX2=60 NT512", a, b, N, B, sg);
     bench_fwd_pyr2<8, 32, 4, 256>("PYR2 fwd db4 TX2=32 TY2=4 NT256", a, b, N, B);
     bench_fwd_pyr2<8, 32, 8, 256>("PYR2 fwd db4 TX2=32 TY2=8 NT256", a, b, N, B);
     bench_fwd_pyr2<8, 32, 8, 512>("PYR2 fwd db4 TX2=32 TY2=8 NT512", a, b, N, B);
