@@ -43,6 +43,16 @@ extern "C" {
 
 typedef struct pdwt_plan* pdwt_handle;
 
+/* Sample / coefficient / scalar type of the library.  libpypwt_amd.so is the fp32 build (the reference's
+ * default, and the only type its Python class accepts); libpypwt_amd_f64.so is the same source built with
+ * -DPDWT_DOUBLE (the reference's DOUBLEPRECISION make switch, pdwt/src/filters.h:16-30) and exports the
+ * same symbols with pdwt_real = double.  Compile a client of the fp64 library with -DPDWT_DOUBLE. */
+#ifdef PDWT_DOUBLE
+typedef double pdwt_real;
+#else
+typedef float pdwt_real;
+#endif
+
 /* mirrors struct w_info (reference pdwt/src/utils.h:9-19) */
 typedef struct pdwt_info {
     int ndims;   /* 1 or 2 (a 2D array with ndims == 1 is a batched 1D transform) */
@@ -80,16 +90,16 @@ typedef enum pdwt_status {
 #define PDWT_MAX_FILTER_WIDTH 40 /* reference pdwt/src/common.h:15 */
 
 /* ---- construction (replaces Wavelets::Wavelets, pdwt/src/wt.cu:84-185, wt.h:42) ----
- * img: Nr*Nc float32, row-major; host memory if mem_is_on_host else device memory;
+ * img: Nr*Nc pdwt_real, row-major; host memory if mem_is_on_host else device memory;
  * NULL = zero image.  Unknown wname -> PDWT_ERR_WAVELET (the reference stores -2 and
  * later hangs in w_ilog2).  levels is clamped as the reference does.
  * Uses the current HIP device and a private stream. */
-int pdwt_create(const float* img, int Nr, int Nc, const char* wname, int levels, int mem_is_on_host,
+int pdwt_create(const pdwt_real* img, int Nr, int Nc, const char* wname, int levels, int mem_is_on_host,
                 int do_separable, int do_cycle_spinning, int do_swt, int ndim, pdwt_handle* out);
 
 /* NEW (not in the reference): explicit device, caller stream (NULL = private stream)
  * and a batch of `batch` independent images [batch][Nr][Nc] transformed by every call. */
-int pdwt_create_batched(const float* img, int batch, int Nr, int Nc, const char* wname, int levels,
+int pdwt_create_batched(const pdwt_real* img, int batch, int Nr, int Nc, const char* wname, int levels,
                         int mem_is_on_host, int do_separable, int do_cycle_spinning, int do_swt, int ndim,
                         int device_id, void* hip_stream, pdwt_handle* out);
 
@@ -102,22 +112,22 @@ int pdwt_forward(pdwt_handle h);
 int pdwt_inverse(pdwt_handle h); /* second call in a row: PDWT_ERR_STATE, nothing done */
 
 /* ---- coefficient operators (pdwt/src/wt.cu:308-356, common.cu:219-371) ---- */
-int pdwt_soft_threshold(pdwt_handle h, float beta, int do_thresh_appcoeffs, int normalize);
-int pdwt_hard_threshold(pdwt_handle h, float beta, int do_thresh_appcoeffs, int normalize);
-int pdwt_group_soft_threshold(pdwt_handle h, float beta, int do_thresh_appcoeffs, int normalize);
-int pdwt_shrink(pdwt_handle h, float beta, int do_thresh_appcoeffs);
-int pdwt_proj_linf(pdwt_handle h, float beta, int do_thresh_appcoeffs);
+int pdwt_soft_threshold(pdwt_handle h, pdwt_real beta, int do_thresh_appcoeffs, int normalize);
+int pdwt_hard_threshold(pdwt_handle h, pdwt_real beta, int do_thresh_appcoeffs, int normalize);
+int pdwt_group_soft_threshold(pdwt_handle h, pdwt_real beta, int do_thresh_appcoeffs, int normalize);
+int pdwt_shrink(pdwt_handle h, pdwt_real beta, int do_thresh_appcoeffs);
+int pdwt_proj_linf(pdwt_handle h, pdwt_real beta, int do_thresh_appcoeffs);
 int pdwt_circshift(pdwt_handle h, int sr, int sc, int inplace); /* wt.cu:364-366 */
-int pdwt_norm1(pdwt_handle h, float* out);   /* wt.cu:396-416 */
-int pdwt_norm2sq(pdwt_handle h, float* out); /* wt.cu:368-393 (1D bug at :387 not reproduced) */
+int pdwt_norm1(pdwt_handle h, pdwt_real* out);   /* wt.cu:396-416 */
+int pdwt_norm2sq(pdwt_handle h, pdwt_real* out); /* wt.cu:368-393 (1D bug at :387 not reproduced) */
 /* dst += alpha * src ; returns 0, or the reference's codes -1..-4 / +1 (wt.cu:622-655) */
-int pdwt_add_wavelet(pdwt_handle dst, pdwt_handle src, float alpha);
+int pdwt_add_wavelet(pdwt_handle dst, pdwt_handle src, pdwt_real alpha);
 
 /* ---- data movement (pdwt/src/wt.cu:419-506) ---- */
-long long pdwt_get_image(pdwt_handle h, float* dst);          /* returns element count, <0 on error */
-long long pdwt_get_coeff(pdwt_handle h, float* dst, int num); /* 0 if refused after inverse */
-int pdwt_set_image(pdwt_handle h, const float* src, int mem_is_on_device);
-int pdwt_set_coeff(pdwt_handle h, const float* src, int num, int mem_is_on_device);
+long long pdwt_get_image(pdwt_handle h, pdwt_real* dst);          /* returns element count, <0 on error */
+long long pdwt_get_coeff(pdwt_handle h, pdwt_real* dst, int num); /* 0 if refused after inverse */
+int pdwt_set_image(pdwt_handle h, const pdwt_real* src, int mem_is_on_device);
+int pdwt_set_coeff(pdwt_handle h, const pdwt_real* src, int num, int mem_is_on_device);
 long long pdwt_coeff_count(pdwt_handle h, int num, int* rows, int* cols); /* elements incl. batch */
 intptr_t pdwt_image_ptr(pdwt_handle h);                                   /* wt.cu:658-660 */
 intptr_t pdwt_coeff_ptr(pdwt_handle h, int num);                          /* wt.cu:663-665 */
@@ -125,10 +135,10 @@ intptr_t pdwt_coeff_ptr(pdwt_handle h, int num);                          /* wt.
 /* ---- custom filter banks (pdwt/src/wt.cu:558-600) ----
  * separable plan: filter1 = low-pass, filter2 = high-pass (filter3/4 ignored)
  * non-separable : filter1..4 = LL, LH, HL, HH, each len*len row-major */
-int pdwt_set_filters_forward(pdwt_handle h, const char* name, unsigned int len, const float* filter1,
-                             const float* filter2, const float* filter3, const float* filter4);
-int pdwt_set_filters_inverse(pdwt_handle h, const float* filter1, const float* filter2, const float* filter3,
-                             const float* filter4);
+int pdwt_set_filters_forward(pdwt_handle h, const char* name, unsigned int len, const pdwt_real* filter1,
+                             const pdwt_real* filter2, const pdwt_real* filter3, const pdwt_real* filter4);
+int pdwt_set_filters_inverse(pdwt_handle h, const pdwt_real* filter1, const pdwt_real* filter2, const pdwt_real* filter3,
+                             const pdwt_real* filter4);
 
 /* ---- introspection ---- */
 int pdwt_get_info(pdwt_handle h, pdwt_info* info, int* do_separable, int* do_cycle_spinning, int* state,
@@ -143,7 +153,7 @@ const char* pdwt_version(void);
 int pdwt_wavelet_count(void);
 const char* pdwt_wavelet_name(int index);
 /* banks: 4*hlen floats = dec_lo, dec_hi, rec_lo, rec_hi ; returns hlen or PDWT_ERR_WAVELET */
-int pdwt_wavelet_filters(const char* wname, float* banks, int capacity);
+int pdwt_wavelet_filters(const char* wname, pdwt_real* banks, int capacity);
 
 /* ---- stream / device plumbing (NEW) ---- */
 int pdwt_synchronize(pdwt_handle h);
@@ -152,7 +162,7 @@ void* pdwt_get_stream(pdwt_handle h);
 int pdwt_device(pdwt_handle h);
 /* fill the plan image on the device with the deterministic test input
  * x[i] = (lowbias32((i + index_offset) ^ seed) >> 8) * 2^-24 * scale (tests/golden, oracle, bench) */
-int pdwt_fill_image_hash(pdwt_handle h, uint32_t seed, float scale, long long index_offset);
+int pdwt_fill_image_hash(pdwt_handle h, uint32_t seed, pdwt_real scale, long long index_offset);
 /* per-launch HIP-event timing: when enabled every kernel launch is bracketed by
  * events on the plan's stream; pdwt_kernel_times returns (synchronising) the
  * number of recorded launches and copies names/milliseconds of the first `cap`. */

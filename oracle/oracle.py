@@ -41,23 +41,34 @@ def usable_cpus():
 
 
 def _ptr(a):
-    return a.ctypes.data_as(f32p)
+    return a.ctypes.data_as(C.c_void_p)
 
 
 def _f32(a):
     return np.ascontiguousarray(a, dtype=np.float32)
 
 
+def _kind(double):
+    """double: False -> fp32 arithmetic and data; True -> fp64 accumulation, fp32 data (pins the index math
+    against pywt); "full" -> fp64 arithmetic AND data (the checker of the product's fp64 build)."""
+    return {False: "f32", True: "f64", "full": "d64"}[double]
+
+
+def _dt(double):
+    return np.float64 if double == "full" else np.float32
+
+
 def load(double=False):
-    key = "f64" if double else "f32"
+    key = _kind(double)
     if key in _LIBS:
         return _LIBS[key]
     path = os.path.join(HERE, "libpdwt_oracle_%s.so" % key)
     if not os.path.exists(path):
         build()
     lib = C.CDLL(path)
-    i, f, sz = C.c_int, C.c_float, C.c_size_t
+    i, f, sz = C.c_int, (C.c_double if key == "d64" else C.c_float), C.c_size_t
     ip = C.POINTER(C.c_int)
+    f32p = C.c_void_p  # DATA*: float32 arrays, float64 for the d64 library
     lib.oracle_forward.argtypes = [f32p, i, i, i, i, i, f32p, f32p, i, f32p]
     lib.oracle_inverse.argtypes = [f32p, i, i, i, i, i, f32p, f32p, i, f32p]
     lib.oracle_coeff_count.argtypes = [i, i, i, i, i]
@@ -79,6 +90,7 @@ def load(double=False):
     lib.oracle_div2.argtypes = [i]
     lib.oracle_set_threads.argtypes = [i]
     assert bool(lib.oracle_real_is_double()) == bool(double)
+    assert bool(lib.oracle_data_is_double()) == (key == "d64")
     if "OMP_NUM_THREADS" not in os.environ:
         lib.oracle_set_threads(usable_cpus())
     _LIBS[key] = lib
@@ -96,8 +108,8 @@ def filter_table():
 HAAR_ALIASES = ("haar", "db1", "bior1.1", "rbio1.1", "rbior1.1")
 
 
-def filters(wname):
-    """(hlen, dec_lo, dec_hi, rec_lo, rec_hi) as float32 arrays."""
+def filters(wname, dtype=np.float32):
+    """(hlen, dec_lo, dec_hi, rec_lo, rec_hi) as float32 (or `dtype`) arrays."""
     t = filter_table()["filters"]
     key = wname.lower()
     if key in HAAR_ALIASES:
@@ -105,7 +117,7 @@ def filters(wname):
     if key not in t:
         raise ValueError("unknown wavelet %r" % wname)
     e = t[key]
-    return (e["hlen"],) + tuple(np.asarray(e[k], dtype=np.float32)
+    return (e["hlen"],) + tuple(np.asarray(e[k], dtype=dtype)
                                 for k in ("dec_lo", "dec_hi", "rec_lo", "rec_hi"))
 
 
@@ -137,15 +149,15 @@ class Geometry:
     def split(self, flat):
         return [flat[o:o + r * c].reshape(r, c) for (o, r, c) in self.bands]
 
-    def join(self, bands):
-        flat = np.empty(self.count, dtype=np.float32)
+    def join(self, bands, dtype=np.float32):
+        flat = np.empty(self.count, dtype=dtype)
         for (o, r, c), b in zip(self.bands, bands):
-            flat[o:o + r * c] = np.asarray(b, dtype=np.float32).ravel()
+            flat[o:o + r * c] = np.asarray(b, dtype=dtype).ravel()
         return flat
 
 
-def _shape2(x, ndim):
-    x = _f32(x)
+def _shape2(x, ndim, dtype=np.float32):
+    x = np.ascontiguousarray(x, dtype=dtype)
     if x.ndim == 1:
         x = x[None, :]
     Nr, Nc = x.shape
@@ -155,10 +167,11 @@ def _shape2(x, ndim):
 
 def forward(x, wname, levels, ndim=2, do_swt=0, double=False, filt=None):
     """Flat list of bands [A, H1, V1, D1, ...] (2D) or [A, D1, ...] (1D)."""
-    x, Nr, Nc, nd = _shape2(x, ndim)
-    hlen, dlo, dhi, rlo, rhi = filt if filt is not None else filters(wname)
+    dt = _dt(double)
+    x, Nr, Nc, nd = _shape2(x, ndim, dt)
+    hlen, dlo, dhi, rlo, rhi = filt if filt is not None else filters(wname, dt)
     g = Geometry(Nr, Nc, nd, do_swt, levels, double)
-    flat = np.zeros(g.count, dtype=np.float32)
+    flat = np.zeros(g.count, dtype=dt)
     rc = load(double).oracle_forward(_ptr(x), Nr, Nc, nd, int(do_swt), levels, _ptr(dlo), _ptr(dhi),
                                      hlen, _ptr(flat))
     if rc != 0:
@@ -169,10 +182,11 @@ def forward(x, wname, levels, ndim=2, do_swt=0, double=False, filt=None):
 def inverse(bands, shape, wname, levels, ndim=2, do_swt=0, double=False, filt=None):
     Nr, Nc = (1, shape[0]) if len(shape) == 1 else shape
     nd = 1 if (ndim == 1 or Nr == 1) else 2
-    hlen, dlo, dhi, rlo, rhi = filt if filt is not None else filters(wname)
+    dt = _dt(double)
+    hlen, dlo, dhi, rlo, rhi = filt if filt is not None else filters(wname, dt)
     g = Geometry(Nr, Nc, nd, do_swt, levels, double)
-    flat = g.join(bands)
-    img = np.zeros((Nr, Nc), dtype=np.float32)
+    flat = g.join(bands, dt)
+    img = np.zeros((Nr, Nc), dtype=dt)
     rc = load(double).oracle_inverse(_ptr(flat), Nr, Nc, nd, int(do_swt), levels, _ptr(rlo), _ptr(rhi),
                                      hlen, _ptr(img))
     if rc != 0:

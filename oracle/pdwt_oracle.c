@@ -26,13 +26,15 @@
  * The arithmetic type is REAL: float (default; what the reference computes in,
  * DTYPE at pdwt/src/filters.h:16-30) or double (-DORACLE_DOUBLE; used to pin
  * the index math against pywt's float64 without fp32 noise).  Data in and out
- * is always float32.
+ * is DATA: float32, or float64 with -DORACLE_STORE_DOUBLE (the checker of the
+ * product's fp64 build, libpypwt_amd_f64.so).
  *
  * The code is written as plain loops over output samples; it is not a copy of
  * the CUDA kernels: boundary handling is one true-modulo function, synthesis is
  * one polyphase formula, and level loops write each band once.
  */
 #include <math.h>
+#include <tgmath.h> /* fabs, fmax, copysign, sqrt resolve to the f-suffixed functions for float DATA */
 #include <stddef.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -46,6 +48,11 @@
 typedef double REAL;
 #else
 typedef float REAL;
+#endif
+#ifdef ORACLE_STORE_DOUBLE
+typedef double DATA;
+#else
+typedef float DATA;
 #endif
 
 #define API __attribute__((visibility("default")))
@@ -69,6 +76,7 @@ API int oracle_max_level(int N, int hlen) {
 }
 
 API int oracle_real_is_double(void) { return sizeof(REAL) == 8; }
+API int oracle_data_is_double(void) { return sizeof(DATA) == 8; }
 
 /* Periodized source index for the analysis passes (separable.cu:114-121):
  * the signal of length N is extended to Np = N + (N odd) by repeating the
@@ -93,12 +101,12 @@ static inline int ana_centre(int hlen) { return (hlen & 1) ? hlen / 2 : hlen / 2
 
 /* rows: in (Nr,Nc) -> outL,outH (Nr, ceil(Nc/2))   [separable.cu:91-131]
  * out[k] = sum_j x[per(2k - c + j)] * f[hlen-1-j]                          */
-API void oracle_analysis_rows(const float *in, int Nr, int Nc, const float *lo, const float *hi,
-                              int hlen, float *outL, float *outH) {
+API void oracle_analysis_rows(const DATA *in, int Nr, int Nc, const DATA *lo, const DATA *hi,
+                              int hlen, DATA *outL, DATA *outH) {
     const int Nc2 = oracle_div2(Nc), c = ana_centre(hlen);
 #pragma omp parallel for schedule(static)
     for (int y = 0; y < Nr; y++) {
-        const float *row = in + (size_t)y * Nc;
+        const DATA *row = in + (size_t)y * Nc;
         for (int k = 0; k < Nc2; k++) {
             REAL aL = 0, aH = 0;
             for (int j = 0; j < hlen; j++) {
@@ -106,15 +114,15 @@ API void oracle_analysis_rows(const float *in, int Nr, int Nc, const float *lo, 
                 aL += v * (REAL)lo[hlen - 1 - j];
                 aH += v * (REAL)hi[hlen - 1 - j];
             }
-            outL[(size_t)y * Nc2 + k] = (float)aL;
-            outH[(size_t)y * Nc2 + k] = (float)aH;
+            outL[(size_t)y * Nc2 + k] = (DATA)aL;
+            outH[(size_t)y * Nc2 + k] = (DATA)aH;
         }
     }
 }
 
 /* columns: in (Nr,Nc) -> outL,outH (ceil(Nr/2), Nc)   [separable.cu:135-176] */
-API void oracle_analysis_cols(const float *in, int Nr, int Nc, const float *lo, const float *hi,
-                              int hlen, float *outL, float *outH) {
+API void oracle_analysis_cols(const DATA *in, int Nr, int Nc, const DATA *lo, const DATA *hi,
+                              int hlen, DATA *outL, DATA *outH) {
     const int Nr2 = oracle_div2(Nr), c = ana_centre(hlen);
 #pragma omp parallel for schedule(static)
     for (int k = 0; k < Nr2; k++) {
@@ -125,8 +133,8 @@ API void oracle_analysis_cols(const float *in, int Nr, int Nc, const float *lo, 
                 aL += v * (REAL)lo[hlen - 1 - j];
                 aH += v * (REAL)hi[hlen - 1 - j];
             }
-            outL[(size_t)k * Nc + x] = (float)aL;
-            outH[(size_t)k * Nc + x] = (float)aH;
+            outL[(size_t)k * Nc + x] = (DATA)aL;
+            outH[(size_t)k * Nc + x] = (DATA)aH;
         }
     }
 }
@@ -145,8 +153,8 @@ static inline void syn_params(int hlen, int *h2, int *c, int *shift) {
     *shift = ((*h2) & 1) ? 0 : 1;
 }
 
-API void oracle_synthesis_cols(const float *a, const float *d, int Nin, int Nc, int Nout,
-                               const float *rlo, const float *rhi, int hlen, float *out) {
+API void oracle_synthesis_cols(const DATA *a, const DATA *d, int Nin, int Nc, int Nout,
+                               const DATA *rlo, const DATA *rhi, int hlen, DATA *out) {
     int h2, c, s;
     syn_params(hlen, &h2, &c, &s);
 #pragma omp parallel for schedule(static)
@@ -161,18 +169,18 @@ API void oracle_synthesis_cols(const float *a, const float *d, int Nin, int Nc, 
                 ra += (REAL)a[src] * (REAL)rlo[t];
                 rd += (REAL)d[src] * (REAL)rhi[t];
             }
-            out[(size_t)g * Nc + x] = (float)(ra + rd);
+            out[(size_t)g * Nc + x] = (DATA)(ra + rd);
         }
     }
 }
 
-API void oracle_synthesis_rows(const float *a, const float *d, int Nr, int Nin, int Nout,
-                               const float *rlo, const float *rhi, int hlen, float *out) {
+API void oracle_synthesis_rows(const DATA *a, const DATA *d, int Nr, int Nin, int Nout,
+                               const DATA *rlo, const DATA *rhi, int hlen, DATA *out) {
     int h2, c, s;
     syn_params(hlen, &h2, &c, &s);
 #pragma omp parallel for schedule(static)
     for (int y = 0; y < Nr; y++) {
-        const float *ar = a + (size_t)y * Nin, *dr = d + (size_t)y * Nin;
+        const DATA *ar = a + (size_t)y * Nin, *dr = d + (size_t)y * Nin;
         for (int g = 0; g < Nout; g++) {
             const int p = g + s, base = p / 2 - c, par = 1 - (p & 1);
             REAL ra = 0, rd = 0;
@@ -183,7 +191,7 @@ API void oracle_synthesis_rows(const float *a, const float *d, int Nr, int Nin, 
                 ra += (REAL)ar[src] * (REAL)rlo[t];
                 rd += (REAL)dr[src] * (REAL)rhi[t];
             }
-            out[(size_t)y * Nout + g] = (float)(ra + rd);
+            out[(size_t)y * Nout + g] = (DATA)(ra + rd);
         }
     }
 }
@@ -191,12 +199,12 @@ API void oracle_synthesis_rows(const float *a, const float *d, int Nr, int Nin, 
 /* ------------------------------------------------- undecimated analysis (SWT)
  * out[g] = sum_j x[(g + (j - c) f) mod N] * filt[hlen-1-j],  f = 2^(level-1)
  * (separable.cu:409-448 rows, :452-493 columns)                              */
-API void oracle_swt_analysis_rows(const float *in, int Nr, int Nc, const float *lo, const float *hi,
-                                  int hlen, int level, float *outL, float *outH) {
+API void oracle_swt_analysis_rows(const DATA *in, int Nr, int Nc, const DATA *lo, const DATA *hi,
+                                  int hlen, int level, DATA *outL, DATA *outH) {
     const int f = 1 << (level - 1), c = ana_centre(hlen);
 #pragma omp parallel for schedule(static)
     for (int y = 0; y < Nr; y++) {
-        const float *row = in + (size_t)y * Nc;
+        const DATA *row = in + (size_t)y * Nc;
         for (int g = 0; g < Nc; g++) {
             REAL aL = 0, aH = 0;
             for (int j = 0; j < hlen; j++) {
@@ -204,14 +212,14 @@ API void oracle_swt_analysis_rows(const float *in, int Nr, int Nc, const float *
                 aL += v * (REAL)lo[hlen - 1 - j];
                 aH += v * (REAL)hi[hlen - 1 - j];
             }
-            outL[(size_t)y * Nc + g] = (float)aL;
-            outH[(size_t)y * Nc + g] = (float)aH;
+            outL[(size_t)y * Nc + g] = (DATA)aL;
+            outH[(size_t)y * Nc + g] = (DATA)aH;
         }
     }
 }
 
-API void oracle_swt_analysis_cols(const float *in, int Nr, int Nc, const float *lo, const float *hi,
-                                  int hlen, int level, float *outL, float *outH) {
+API void oracle_swt_analysis_cols(const DATA *in, int Nr, int Nc, const DATA *lo, const DATA *hi,
+                                  int hlen, int level, DATA *outL, DATA *outH) {
     const int f = 1 << (level - 1), c = ana_centre(hlen);
 #pragma omp parallel for schedule(static)
     for (int g = 0; g < Nr; g++) {
@@ -222,8 +230,8 @@ API void oracle_swt_analysis_cols(const float *in, int Nr, int Nc, const float *
                 aL += v * (REAL)lo[hlen - 1 - j];
                 aH += v * (REAL)hi[hlen - 1 - j];
             }
-            outL[(size_t)g * Nc + x] = (float)aL;
-            outH[(size_t)g * Nc + x] = (float)aH;
+            outL[(size_t)g * Nc + x] = (DATA)aL;
+            outH[(size_t)g * Nc + x] = (DATA)aH;
         }
     }
 }
@@ -233,8 +241,8 @@ API void oracle_swt_analysis_cols(const float *in, int Nr, int Nc, const float *
  *                    + d[(g - c f + j f) mod N] rhi[hlen-1-j] ),  c = hlen/2
  * (separable.cu:553-589 columns, :593-626 rows; the 1/2 sits inside the MAC
  *  at :581-584 and :621-622)                                                  */
-API void oracle_swt_synthesis_cols(const float *a, const float *d, int Nr, int Nc, const float *rlo,
-                                   const float *rhi, int hlen, int level, float *out) {
+API void oracle_swt_synthesis_cols(const DATA *a, const DATA *d, int Nr, int Nc, const DATA *rlo,
+                                   const DATA *rhi, int hlen, int level, DATA *out) {
     const int f = 1 << (level - 1), c = hlen / 2;
 #pragma omp parallel for schedule(static)
     for (int g = 0; g < Nr; g++) {
@@ -245,17 +253,17 @@ API void oracle_swt_synthesis_cols(const float *a, const float *d, int Nr, int N
                 ra += (REAL)a[src] * (REAL)rlo[hlen - 1 - j] / 2;
                 rd += (REAL)d[src] * (REAL)rhi[hlen - 1 - j] / 2;
             }
-            out[(size_t)g * Nc + x] = (float)(ra + rd);
+            out[(size_t)g * Nc + x] = (DATA)(ra + rd);
         }
     }
 }
 
-API void oracle_swt_synthesis_rows(const float *a, const float *d, int Nr, int Nc, const float *rlo,
-                                   const float *rhi, int hlen, int level, float *out) {
+API void oracle_swt_synthesis_rows(const DATA *a, const DATA *d, int Nr, int Nc, const DATA *rlo,
+                                   const DATA *rhi, int hlen, int level, DATA *out) {
     const int f = 1 << (level - 1), c = hlen / 2;
 #pragma omp parallel for schedule(static)
     for (int y = 0; y < Nr; y++) {
-        const float *ar = a + (size_t)y * Nc, *dr = d + (size_t)y * Nc;
+        const DATA *ar = a + (size_t)y * Nc, *dr = d + (size_t)y * Nc;
         for (int g = 0; g < Nc; g++) {
             REAL ra = 0, rd = 0;
             for (int j = 0; j < hlen; j++) {
@@ -263,7 +271,7 @@ API void oracle_swt_synthesis_rows(const float *a, const float *d, int Nr, int N
                 ra += (REAL)ar[src] * (REAL)rlo[hlen - 1 - j] / 2;
                 rd += (REAL)dr[src] * (REAL)rhi[hlen - 1 - j] / 2;
             }
-            out[(size_t)y * Nc + g] = (float)(ra + rd);
+            out[(size_t)y * Nc + g] = (DATA)(ra + rd);
         }
     }
 }
@@ -271,7 +279,7 @@ API void oracle_swt_synthesis_rows(const float *a, const float *d, int Nr, int N
 /* ------------------------------------------------------- Haar (haar.cu:10-160)
  * Selected by the reference when hlen == 2 and the transform is decimated
  * (wt.cu:248,255,282,289). */
-API void oracle_haar2d_fwd(const float *img, int Nr, int Nc, float *A, float *H, float *V, float *D) {
+API void oracle_haar2d_fwd(const DATA *img, int Nr, int Nc, DATA *A, DATA *H, DATA *V, DATA *D) {
     const int Nr2 = oracle_div2(Nr), Nc2 = oracle_div2(Nc);
 #pragma omp parallel for schedule(static)
     for (int y = 0; y < Nr2; y++) {
@@ -283,16 +291,16 @@ API void oracle_haar2d_fwd(const float *img, int Nr, int Nc, float *A, float *H,
             REAL a = img[(size_t)y0 * Nc + x0], b = img[(size_t)y0 * Nc + x1];
             REAL c = img[(size_t)y1 * Nc + x0], d = img[(size_t)y1 * Nc + x1];
             const size_t o = (size_t)y * Nc2 + x;
-            A[o] = (float)((REAL)0.5 * ((a + c) + (b + d)));
-            V[o] = (float)((REAL)0.5 * ((a + c) - (b + d)));
-            H[o] = (float)((REAL)0.5 * ((a - c) + (b - d)));
-            D[o] = (float)((REAL)0.5 * ((a - c) - (b - d)));
+            A[o] = (DATA)((REAL)0.5 * ((a + c) + (b + d)));
+            V[o] = (DATA)((REAL)0.5 * ((a + c) - (b + d)));
+            H[o] = (DATA)((REAL)0.5 * ((a - c) + (b - d)));
+            D[o] = (DATA)((REAL)0.5 * ((a - c) - (b - d)));
         }
     }
 }
 
 /* coefficients (Nrc,Ncc) -> image (Nr,Nc), Nr <= 2 Nrc  (haar.cu:41-58) */
-API void oracle_haar2d_inv(float *img, const float *A, const float *H, const float *V, const float *D,
+API void oracle_haar2d_inv(DATA *img, const DATA *A, const DATA *H, const DATA *V, const DATA *D,
                            int Nrc, int Ncc, int Nr, int Nc) {
     (void)Nrc;
 #pragma omp parallel for schedule(static)
@@ -305,14 +313,14 @@ API void oracle_haar2d_inv(float *img, const float *A, const float *H, const flo
             else if (gx && !gy) r = (REAL)0.5 * ((a + c) - (b + d));
             else if (!gx && gy) r = (REAL)0.5 * ((a - c) + (b - d));
             else r = (REAL)0.5 * ((a - c) - (b - d));
-            img[(size_t)y * Nc + x] = (float)r;
+            img[(size_t)y * Nc + x] = (DATA)r;
         }
     }
 }
 
 #define ORACLE_ONE_SQRT2 0.70710678118654746
 
-API void oracle_haar1d_fwd(const float *img, int Nr, int Nc, float *A, float *D) {
+API void oracle_haar1d_fwd(const DATA *img, int Nr, int Nc, DATA *A, DATA *D) {
     const int Nc2 = oracle_div2(Nc);
 #pragma omp parallel for schedule(static)
     for (int y = 0; y < Nr; y++)
@@ -320,17 +328,17 @@ API void oracle_haar1d_fwd(const float *img, int Nr, int Nc, float *A, float *D)
             int x1 = 2 * x + 1;
             if (x1 == Nc) x1--;
             REAL a = img[(size_t)y * Nc + 2 * x], b = img[(size_t)y * Nc + x1];
-            A[(size_t)y * Nc2 + x] = (float)((REAL)ORACLE_ONE_SQRT2 * (a + b));
-            D[(size_t)y * Nc2 + x] = (float)((REAL)ORACLE_ONE_SQRT2 * (a - b));
+            A[(size_t)y * Nc2 + x] = (DATA)((REAL)ORACLE_ONE_SQRT2 * (a + b));
+            D[(size_t)y * Nc2 + x] = (DATA)((REAL)ORACLE_ONE_SQRT2 * (a - b));
         }
 }
 
-API void oracle_haar1d_inv(float *img, const float *A, const float *D, int Nr, int Ncc, int Nc) {
+API void oracle_haar1d_inv(DATA *img, const DATA *A, const DATA *D, int Nr, int Ncc, int Nc) {
 #pragma omp parallel for schedule(static)
     for (int y = 0; y < Nr; y++)
         for (int x = 0; x < Nc; x++) {
             REAL a = A[(size_t)y * Ncc + x / 2], b = D[(size_t)y * Ncc + x / 2];
-            img[(size_t)y * Nc + x] = (float)((REAL)ORACLE_ONE_SQRT2 * ((x & 1) ? (a - b) : (a + b)));
+            img[(size_t)y * Nc + x] = (DATA)((REAL)ORACLE_ONE_SQRT2 * ((x & 1) ? (a - b) : (a + b)));
         }
 }
 
@@ -377,16 +385,16 @@ API size_t oracle_coeff_count(int Nr, int Nc, int ndim, int do_swt, int levels) 
 /* ------------------------------------------------------------- level loops */
 
 /* filters = { dec_lo, dec_hi, rec_lo, rec_hi }.  Returns 0, or <0 on bad args. */
-API int oracle_forward(const float *img, int Nr, int Nc, int ndim, int do_swt, int levels,
-                       const float *dec_lo, const float *dec_hi, int hlen, float *coeffs) {
+API int oracle_forward(const DATA *img, int Nr, int Nc, int ndim, int do_swt, int levels,
+                       const DATA *dec_lo, const DATA *dec_hi, int hlen, DATA *coeffs) {
     if (levels < 1 || hlen < 1 || Nr < 1 || Nc < 1 || (ndim != 1 && ndim != 2)) return -1;
     const size_t n = (size_t)Nr * Nc;
-    float *cur = (float *)malloc(n * sizeof(float));
-    float *nxt = (float *)malloc(n * sizeof(float));
-    float *t1 = (float *)malloc(n * sizeof(float));
-    float *t2 = (float *)malloc(n * sizeof(float));
+    DATA *cur = (DATA *)malloc(n * sizeof(DATA));
+    DATA *nxt = (DATA *)malloc(n * sizeof(DATA));
+    DATA *t1 = (DATA *)malloc(n * sizeof(DATA));
+    DATA *t2 = (DATA *)malloc(n * sizeof(DATA));
     if (!cur || !nxt || !t1 || !t2) { free(cur); free(nxt); free(t1); free(t2); return -2; }
-    memcpy(cur, img, n * sizeof(float));
+    memcpy(cur, img, n * sizeof(DATA));
     int r = Nr, c = Nc;
     const int per = ndim == 2 ? 3 : 1;
     const int haar = (hlen == 2 && !do_swt); /* wt.cu:248,255 */
@@ -394,7 +402,7 @@ API int oracle_forward(const float *img, int Nr, int Nc, int ndim, int do_swt, i
         int br, bc, dummy_r, dummy_c;
         const size_t off = oracle_band_offset(Nr, Nc, ndim, do_swt, levels, per * (l - 1) + 1, &br, &bc);
         (void)dummy_r; (void)dummy_c;
-        float *b0 = coeffs + off, *b1 = b0 + (size_t)br * bc, *b2 = b1 + (size_t)br * bc;
+        DATA *b0 = coeffs + off, *b1 = b0 + (size_t)br * bc, *b2 = b1 + (size_t)br * bc;
         if (ndim == 2) {
             if (haar) {
                 oracle_haar2d_fwd(cur, r, c, nxt, b0, b1, b2);
@@ -415,32 +423,32 @@ API int oracle_forward(const float *img, int Nr, int Nc, int ndim, int do_swt, i
             else oracle_swt_analysis_rows(cur, r, c, dec_lo, dec_hi, hlen, l, nxt, b0);
         }
         r = br; c = bc;
-        float *sw = cur; cur = nxt; nxt = sw;
+        DATA *sw = cur; cur = nxt; nxt = sw;
     }
-    memcpy(coeffs, cur, (size_t)r * c * sizeof(float));
+    memcpy(coeffs, cur, (size_t)r * c * sizeof(DATA));
     free(cur); free(nxt); free(t1); free(t2);
     return 0;
 }
 
-API int oracle_inverse(const float *coeffs, int Nr, int Nc, int ndim, int do_swt, int levels,
-                       const float *rec_lo, const float *rec_hi, int hlen, float *img) {
+API int oracle_inverse(const DATA *coeffs, int Nr, int Nc, int ndim, int do_swt, int levels,
+                       const DATA *rec_lo, const DATA *rec_hi, int hlen, DATA *img) {
     if (levels < 1 || hlen < 1 || Nr < 1 || Nc < 1 || (ndim != 1 && ndim != 2)) return -1;
     const size_t n = (size_t)Nr * Nc;
-    float *cur = (float *)malloc(n * sizeof(float));
-    float *nxt = (float *)malloc(n * sizeof(float));
-    float *t1 = (float *)malloc(n * sizeof(float));
-    float *t2 = (float *)malloc(n * sizeof(float));
+    DATA *cur = (DATA *)malloc(n * sizeof(DATA));
+    DATA *nxt = (DATA *)malloc(n * sizeof(DATA));
+    DATA *t1 = (DATA *)malloc(n * sizeof(DATA));
+    DATA *t2 = (DATA *)malloc(n * sizeof(DATA));
     if (!cur || !nxt || !t1 || !t2) { free(cur); free(nxt); free(t1); free(t2); return -2; }
     int r, c;
     oracle_level_shape(Nr, Nc, ndim, do_swt, levels, &r, &c);
-    memcpy(cur, coeffs, (size_t)r * c * sizeof(float));
+    memcpy(cur, coeffs, (size_t)r * c * sizeof(DATA));
     const int per = ndim == 2 ? 3 : 1;
     const int haar = (hlen == 2 && !do_swt);
     for (int l = levels; l >= 1; l--) {
         int br, bc, orr, oc;
         const size_t off = oracle_band_offset(Nr, Nc, ndim, do_swt, levels, per * (l - 1) + 1, &br, &bc);
         oracle_level_shape(Nr, Nc, ndim, do_swt, l - 1, &orr, &oc);
-        const float *b0 = coeffs + off, *b1 = b0 + (size_t)br * bc, *b2 = b1 + (size_t)br * bc;
+        const DATA *b0 = coeffs + off, *b1 = b0 + (size_t)br * bc, *b2 = b1 + (size_t)br * bc;
         if (ndim == 2) {
             if (haar) {
                 oracle_haar2d_inv(nxt, cur, b0, b1, b2, br, bc, orr, oc);
@@ -459,26 +467,26 @@ API int oracle_inverse(const float *coeffs, int Nr, int Nc, int ndim, int do_swt
             else if (!do_swt) oracle_synthesis_rows(cur, b0, br, bc, oc, rec_lo, rec_hi, hlen, nxt);
             else oracle_swt_synthesis_rows(cur, b0, br, bc, rec_lo, rec_hi, hlen, l, nxt);
         }
-        float *sw = cur; cur = nxt; nxt = sw;
+        DATA *sw = cur; cur = nxt; nxt = sw;
     }
-    memcpy(img, cur, n * sizeof(float));
+    memcpy(img, cur, n * sizeof(DATA));
     free(cur); free(nxt); free(t1); free(t2);
     return 0;
 }
 
 /* --------------------------------------------------- coefficient operators */
 
-static inline float soft1(float x, float b) { return copysignf(fmaxf(fabsf(x) - b, 0.0f), x); }
-static inline float hard1(float x, float b) { return (fabsf(x) - b > 0.0f) ? x : 0.0f; }
-static inline float linf1(float x, float b) { return copysignf(fminf(fabsf(x), b), x); }
+static inline DATA soft1(DATA x, DATA b) { return copysign(fmax(fabs(x) - b, (DATA)0), x); }
+static inline DATA hard1(DATA x, DATA b) { return (fabs(x) - b > (DATA)0) ? x : (DATA)0; }
+static inline DATA linf1(DATA x, DATA b) { return copysign(fmin(fabs(x), b), x); }
 
 /* beta for the approximation band when `normalize` (common.cu:229-236):
  * beta / sqrt(2)^levels computed as a shift plus one optional 1/sqrt(2) */
-static float app_beta(float beta, int levels, int normalize) {
+static DATA app_beta(DATA beta, int levels, int normalize) {
     if (normalize > 0) {
         const int n2 = levels / 2;
-        beta /= (float)(1 << n2);
-        if (n2 * 2 != levels) beta = (float)(beta / 1.4142135623730951); /* SQRT_2 is a double, common.cu:8 */
+        beta /= (DATA)(1 << n2);
+        if (n2 * 2 != levels) beta = (DATA)(beta / 1.4142135623730951); /* SQRT_2 is a double, common.cu:8 */
     }
     return beta;
 }
@@ -487,21 +495,21 @@ static float app_beta(float beta, int levels, int normalize) {
  * passes beta instead of beta2 to the approximation band at :270 -- restated
  * here WITH the normalised beta2, the documented intent), 2 proj_linf
  * (:101-137,285-308; no normalize) */
-API void oracle_threshold(float *coeffs, int Nr, int Nc, int ndim, int do_swt, int levels, int op,
-                          float beta, int do_app, int normalize) {
+API void oracle_threshold(DATA *coeffs, int Nr, int Nc, int ndim, int do_swt, int levels, int op,
+                          DATA beta, int do_app, int normalize) {
     int r, c;
     if (do_app) {
         oracle_band_offset(Nr, Nc, ndim, do_swt, levels, 0, &r, &c);
-        const float b2 = (op == 2) ? beta : app_beta(beta, levels, normalize);
+        const DATA b2 = (op == 2) ? beta : app_beta(beta, levels, normalize);
         for (size_t i = 0; i < (size_t)r * c; i++)
             coeffs[i] = op == 0 ? soft1(coeffs[i], b2) : op == 1 ? hard1(coeffs[i], b2) : linf1(coeffs[i], b2);
     }
     const int per = ndim == 2 ? 3 : 1;
     for (int l = 1; l <= levels; l++) {
-        if (normalize > 0 && op != 2) beta = (float)(beta / 1.4142135623730951); /* common.cu:244 */
+        if (normalize > 0 && op != 2) beta = (DATA)(beta / 1.4142135623730951); /* common.cu:244 */
         for (int k = 0; k < per; k++) {
             const size_t off = oracle_band_offset(Nr, Nc, ndim, do_swt, levels, per * (l - 1) + 1 + k, &r, &c);
-            float *b = coeffs + off;
+            DATA *b = coeffs + off;
             for (size_t i = 0; i < (size_t)r * c; i++)
                 b[i] = op == 0 ? soft1(b[i], beta) : op == 1 ? hard1(b[i], beta) : linf1(b[i], beta);
         }
@@ -511,22 +519,22 @@ API void oracle_threshold(float *coeffs, int Nr, int Nc, int ndim, int do_swt, i
 /* group soft threshold (common.cu:145-198, 311-341): per pixel, the detail
  * bands of one level (plus A at the last level when do_app) shrink by
  * max(1 - beta/||.||_2, 0) */
-API void oracle_group_soft_threshold(float *coeffs, int Nr, int Nc, int ndim, int do_swt, int levels,
-                                     float beta, int do_app, int normalize) {
+API void oracle_group_soft_threshold(DATA *coeffs, int Nr, int Nc, int ndim, int do_swt, int levels,
+                                     DATA beta, int do_app, int normalize) {
     const int per = ndim == 2 ? 3 : 1;
     int r, c;
     for (int l = 1; l <= levels; l++) {
-        if (normalize > 0) beta = (float)(beta / 1.4142135623730951);
+        if (normalize > 0) beta = (DATA)(beta / 1.4142135623730951);
         const size_t off = oracle_band_offset(Nr, Nc, ndim, do_swt, levels, per * (l - 1) + 1, &r, &c);
         const size_t n = (size_t)r * c;
-        float *b = coeffs + off;
-        float *a = (do_app && l == levels) ? coeffs : NULL;
+        DATA *b = coeffs + off;
+        DATA *a = (do_app && l == levels) ? coeffs : NULL;
         for (size_t i = 0; i < n; i++) {
-            float nrm = 0;
+            DATA nrm = 0;
             for (int k = 0; k < per; k++) nrm += b[k * n + i] * b[k * n + i];
             if (a) nrm += a[i] * a[i];
-            nrm = sqrtf(nrm);
-            const float res = (nrm == 0) ? 0.0f : fmaxf(1.0f - beta / nrm, 0.0f);
+            nrm = sqrt(nrm);
+            const DATA res = (nrm == 0) ? (DATA)0 : fmax(1.0f - beta / nrm, (DATA)0);
             for (int k = 0; k < per; k++) b[k * n + i] *= res;
             if (a) a[i] *= res;
         }
@@ -535,26 +543,26 @@ API void oracle_group_soft_threshold(float *coeffs, int Nr, int Nc, int ndim, in
 
 /* shrink: x / (1 + beta) on every detail band, and on A when do_app
  * (common.cu:347-371) */
-API void oracle_shrink(float *coeffs, int Nr, int Nc, int ndim, int do_swt, int levels, float beta,
+API void oracle_shrink(DATA *coeffs, int Nr, int Nc, int ndim, int do_swt, int levels, DATA beta,
                        int do_app) {
     const size_t total = oracle_coeff_count(Nr, Nc, ndim, do_swt, levels);
     int r, c;
     oracle_band_offset(Nr, Nc, ndim, do_swt, levels, 0, &r, &c);
-    const float s = 1.0f / (1.0f + beta);
+    const DATA s = 1.0f / (1.0f + beta);
     for (size_t i = do_app ? 0 : (size_t)r * c; i < total; i++) coeffs[i] *= s;
 }
 
 /* norms over ALL bands (wt.cu:368-416).  The reference's 1D norm2sq sums
  * |x| instead of x^2 for detail bands (wt.cu:387); restated as the documented
  * squared L2 norm. */
-API double oracle_norm1(const float *coeffs, int Nr, int Nc, int ndim, int do_swt, int levels) {
+API double oracle_norm1(const DATA *coeffs, int Nr, int Nc, int ndim, int do_swt, int levels) {
     const size_t total = oracle_coeff_count(Nr, Nc, ndim, do_swt, levels);
     double s = 0;
     for (size_t i = 0; i < total; i++) s += fabs((double)coeffs[i]);
     return s;
 }
 
-API double oracle_norm2sq(const float *coeffs, int Nr, int Nc, int ndim, int do_swt, int levels) {
+API double oracle_norm2sq(const DATA *coeffs, int Nr, int Nc, int ndim, int do_swt, int levels) {
     const size_t total = oracle_coeff_count(Nr, Nc, ndim, do_swt, levels);
     double s = 0;
     for (size_t i = 0; i < total; i++) s += (double)coeffs[i] * coeffs[i];
@@ -562,7 +570,7 @@ API double oracle_norm2sq(const float *coeffs, int Nr, int Nc, int ndim, int do_
 }
 
 /* circular shift (common.cu:202-211, 378-396): out[y,x] = in[(y-sr) mod Nr, (x-sc) mod Nc] */
-API void oracle_circshift(const float *in, float *out, int Nr, int Nc, int sr, int sc) {
+API void oracle_circshift(const DATA *in, DATA *out, int Nr, int Nc, int sr, int sc) {
     for (int y = 0; y < Nr; y++)
         for (int x = 0; x < Nc; x++)
             out[(size_t)y * Nc + x] = in[(size_t)mod_n(y - sr, Nr) * Nc + mod_n(x - sc, Nc)];
@@ -574,9 +582,9 @@ API void oracle_circshift(const float *in, float *out, int Nr, int Nc, int sr, i
  * nonseparable.cu:70-74), indexed [jy][jx]; A,H,V,D use LL,LH,HL,HH with
  * out = sum_{jy,jx} x[per(2y-c+jy), per(2x-c+jx)] * F[(hlen-1-jy)*hlen + (hlen-1-jx)].
  * Filters are passed explicitly so user-supplied non-separable banks work too. */
-API void oracle_nonsep_fwd_level(const float *in, int Nr, int Nc, const float *FA, const float *FH,
-                                 const float *FV, const float *FD, int hlen, int do_swt, int level,
-                                 float *A, float *H, float *V, float *D) {
+API void oracle_nonsep_fwd_level(const DATA *in, int Nr, int Nc, const DATA *FA, const DATA *FH,
+                                 const DATA *FV, const DATA *FD, int hlen, int do_swt, int level,
+                                 DATA *A, DATA *H, DATA *V, DATA *D) {
     const int c = ana_centre(hlen);
     const int f = do_swt ? (1 << (level - 1)) : 1;
     const int Nr2 = do_swt ? Nr : oracle_div2(Nr), Nc2 = do_swt ? Nc : oracle_div2(Nc);
@@ -595,7 +603,7 @@ API void oracle_nonsep_fwd_level(const float *in, int Nr, int Nc, const float *F
                 }
             }
             const size_t o = (size_t)y * Nc2 + x;
-            A[o] = (float)ra; H[o] = (float)rh; V[o] = (float)rv; D[o] = (float)rd;
+            A[o] = (DATA)ra; H[o] = (DATA)rh; V[o] = (DATA)rv; D[o] = (DATA)rd;
         }
 }
 
@@ -603,14 +611,14 @@ API void oracle_nonsep_fwd_level(const float *in, int Nr, int Nc, const float *F
 
 /* Counter-based generator shared with tests/golden/make_golden.py:hash_input
  * and the HIP fill kernel: lowbias32(i ^ seed) >> 8, scaled to [0, scale). */
-API void oracle_fill_hash(float *x, size_t n, uint32_t seed, float scale) {
+API void oracle_fill_hash(DATA *x, size_t n, uint32_t seed, DATA scale) {
 #pragma omp parallel for schedule(static)
     for (size_t i = 0; i < n; i++) {
         uint32_t h = (uint32_t)i ^ seed;
         h ^= h >> 16; h *= 0x7FEB352Du;
         h ^= h >> 15; h *= 0x846CA68Bu;
         h ^= h >> 16;
-        x[i] = (float)((double)(h >> 8) * (1.0 / 16777216.0) * (double)scale);
+        x[i] = (DATA)((double)(h >> 8) * (1.0 / 16777216.0) * (double)scale);
     }
 }
 

@@ -4,8 +4,9 @@
     W = Wavelets(img, "db2", 3); W.forward(); W.soft_threshold(10); W.inverse(); W.coeffs; W.image
 
 The compute path is the hand-written HIP library pypwt_amd/libpypwt_amd.so (C ABI in
-include/pypwt_amd.h, built by `python -m pypwt_amd.build`).  There is no CPU fallback.
+include/pypwt_amd.h, built by `python -m pypwt_amd.build`; `Wavelets64` binds the fp64 build
+libpypwt_amd_f64.so).  There is no CPU fallback.
 """
-from .wavelets import BatchedWavelets, Wavelets  # noqa: F401
+from .wavelets import BatchedWavelets, Wavelets, Wavelets64  # noqa: F401
 
 __version__ = "0.1.0"

@@ -1,4 +1,5 @@
-"""Builds pypwt_amd/libpypwt_amd.so for gfx950 with hipcc (cross-compiles without a GPU).
+"""Builds pypwt_amd/libpypwt_amd.so (fp32) and pypwt_amd/libpypwt_amd_f64.so (fp64, -DPDWT_DOUBLE) for
+gfx950 with hipcc (cross-compiles without a GPU).
 
     python -m pypwt_amd.build [--force]
 
@@ -17,6 +18,14 @@ CSRC = os.path.join(HERE, "csrc")
 ROOT = os.path.dirname(HERE)
 OBJ = os.path.join(ROOT, "build", "obj")
 LIB = os.path.join(HERE, "libpypwt_amd.so")
+LIB_F64 = os.path.join(HERE, "libpypwt_amd_f64.so")
+# (object directory, library, extra flags, sources left out) per variant; the fp64 build has no
+# packed-fp32 fast paths
+VARIANTS = {
+    "f32": (OBJ, LIB, [], ()),
+    "f64": (os.path.join(ROOT, "build", "obj_f64"), LIB_F64, ["-DPDWT_DOUBLE"],
+            ("launch_dwt2_fast.hip", "launch_dwt2_pyramid.hip", "launch_dwt1_fused.hip")),
+}
 
 SOURCES = [
     "launch_dwt2.hip",
@@ -51,36 +60,42 @@ def _deps_mtime():
     return latest
 
 
-def _compile(src):
-    obj = os.path.join(OBJ, src.rsplit(".", 1)[0] + ".o")
+def _compile(job):
+    src, objdir, extra = job
+    obj = os.path.join(objdir, src.rsplit(".", 1)[0] + ".o")
     path = os.path.join(CSRC, src)
     if os.path.exists(obj) and os.path.getmtime(obj) >= _deps_mtime():
         return obj
-    cmd = [hipcc()] + FLAGS + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", path, "-o", obj]
+    cmd = [hipcc()] + FLAGS + extra + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", path, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed on %s:\n%s" % (src, r.stderr[-4000:]))
     return obj
 
 
-def build_library(force=False, verbose=True):
-    os.makedirs(OBJ, exist_ok=True)
-    srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= _deps_mtime():
-        return LIB
+def build_library(force=False, verbose=True, variant="f32"):
+    objdir, lib, extra, skip = VARIANTS[variant]
+    os.makedirs(objdir, exist_ok=True)
+    srcs = [s for s in SOURCES if s not in skip and os.path.exists(os.path.join(CSRC, s))]
+    if not force and os.path.exists(lib) and os.path.getmtime(lib) >= _deps_mtime():
+        return lib
     if force:
-        for f in os.listdir(OBJ):
-            os.remove(os.path.join(OBJ, f))
+        for f in os.listdir(objdir):
+            os.remove(os.path.join(objdir, f))
     with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
-        objs = list(ex.map(_compile, srcs))
-    cmd = [hipcc(), "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", LIB] + objs
+        objs = list(ex.map(_compile, [(s, objdir, extra) for s in srcs]))
+    cmd = [hipcc(), "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", lib] + objs
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n%s" % r.stderr[-4000:])
     if verbose:
-        print("built", LIB, "(%d KiB)" % (os.path.getsize(LIB) // 1024))
-    return LIB
+        print("built", lib, "(%d KiB)" % (os.path.getsize(lib) // 1024))
+    return lib
+
+
+def build_all(force=False, verbose=True):
+    return [build_library(force, verbose, v) for v in ("f32", "f64")]
 
 
 if __name__ == "__main__":
-    build_library(force="--force" in sys.argv)
+    build_all(force="--force" in sys.argv)

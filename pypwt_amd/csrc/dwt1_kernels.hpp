@@ -21,16 +21,16 @@ constexpr int fwd1d_lds_floats(int hlen) {
 }
 
 template <int HLEN, int TXO, int NT>
-PDWT_DEVICE void dwt1_fwd_tile(const Fwd1DArgs& a, int bx, int row, float* smem) {
+PDWT_DEVICE void dwt1_fwd_tile(const Fwd1DArgs& a, int bx, int row, real_t* smem) {
     static_assert(TXO % NT == 0, "outputs per thread must be integral");
     const int hlen = HLEN ? HLEN : a.hlen;
     const int c = analysis_centre(hlen);
     const int RX = (2 * TXO + hlen - 2 + 1) & ~1;
 
-    float* sTaps = smem;
-    float* sIn = smem + 2 * kMaxTaps;
-    const float* lo = a.fb.lo;
-    const float* hi = a.fb.hi;
+    real_t* sTaps = smem;
+    real_t* sIn = smem + 2 * kMaxTaps;
+    const real_t* lo = a.fb.lo;
+    const real_t* hi = a.fb.hi;
     if (HLEN == 0) {
         PDWT_FOR_THREADS(tid, NT) {
             if (tid < kMaxTaps) {
@@ -42,7 +42,7 @@ PDWT_DEVICE void dwt1_fwd_tile(const Fwd1DArgs& a, int bx, int row, float* smem)
         hi = sTaps + kMaxTaps;
     }
 
-    const float* PDWT_RESTRICT in = a.in + (long long)row * a.Nc;
+    const real_t* PDWT_RESTRICT in = a.in + (long long)row * a.Nc;
     const int x0 = 2 * bx * TXO - c;
 
     PDWT_FOR_THREADS(tid, NT) {
@@ -51,18 +51,18 @@ PDWT_DEVICE void dwt1_fwd_tile(const Fwd1DArgs& a, int bx, int row, float* smem)
     PDWT_SYNC();
 
     PDWT_FOR_THREADS(tid, NT) {
-        float* PDWT_RESTRICT oL = a.L + (long long)row * a.Nc2;
-        float* PDWT_RESTRICT oH = a.H + (long long)row * a.Nc2;
+        real_t* PDWT_RESTRICT oL = a.L + (long long)row * a.Nc2;
+        real_t* PDWT_RESTRICT oH = a.H + (long long)row * a.Nc2;
 #pragma unroll
         for (int i = 0; i < TXO / NT; ++i) {
             const int k = tid + i * NT;
-            const float* p = sIn + 2 * k;
-            float aL = 0.f, aH = 0.f;
+            const real_t* p = sIn + 2 * k;
+            real_t aL = 0.f, aH = 0.f;
             if (HLEN > 0 && (HLEN % 2) == 0) {
-                const f32x2* p2 = reinterpret_cast<const f32x2*>(p);
+                const real2_t* p2 = reinterpret_cast<const real2_t*>(p);
 #pragma unroll
                 for (int m = 0; m < (HLEN > 0 ? HLEN / 2 : 1); ++m) {
-                    const f32x2 v = p2[m];
+                    const real2_t v = p2[m];
                     aL = pdwt_fma(v.x, lo[hlen - 1 - 2 * m], aL);
                     aH = pdwt_fma(v.x, hi[hlen - 1 - 2 * m], aH);
                     aL = pdwt_fma(v.y, lo[hlen - 2 - 2 * m], aL);
@@ -70,7 +70,7 @@ PDWT_DEVICE void dwt1_fwd_tile(const Fwd1DArgs& a, int bx, int row, float* smem)
                 }
             } else {
                 for (int j = 0; j < hlen; ++j) {
-                    const float v = p[j];
+                    const real_t v = p[j];
                     aL = pdwt_fma(v, lo[hlen - 1 - j], aL);
                     aH = pdwt_fma(v, hi[hlen - 1 - j], aH);
                 }
@@ -91,7 +91,7 @@ constexpr int inv1d_lds_floats(int hlen) {
 
 // produces 2*TXO consecutive samples of one row from TXO (+halo) coefficients
 template <int HLEN, int TXO, int NT>
-PDWT_DEVICE void dwt1_inv_tile(const Inv1DArgs& a, int bx, int row, float* smem) {
+PDWT_DEVICE void dwt1_inv_tile(const Inv1DArgs& a, int bx, int row, real_t* smem) {
     static_assert(TXO % NT == 0, "outputs per thread must be integral");
     const int hlen = HLEN ? HLEN : a.hlen;
     const int h2 = hlen / 2;
@@ -99,11 +99,11 @@ PDWT_DEVICE void dwt1_inv_tile(const Inv1DArgs& a, int bx, int row, float* smem)
     const int s = (h2 & 1) ? 0 : 1;
     const int CX = TXO + h2 + 1;
 
-    float* sTaps = smem;
-    float* sL = smem + 2 * kMaxTaps;
-    float* sH = sL + CX;
-    const float* lo = a.fb.lo;
-    const float* hi = a.fb.hi;
+    real_t* sTaps = smem;
+    real_t* sL = smem + 2 * kMaxTaps;
+    real_t* sH = sL + CX;
+    const real_t* lo = a.fb.lo;
+    const real_t* hi = a.fb.hi;
     if (HLEN == 0) {
         PDWT_FOR_THREADS(tid, NT) {
             if (tid < kMaxTaps) {
@@ -115,8 +115,8 @@ PDWT_DEVICE void dwt1_inv_tile(const Inv1DArgs& a, int bx, int row, float* smem)
         hi = sTaps + kMaxTaps;
     }
 
-    const float* PDWT_RESTRICT gL = a.L + (long long)row * a.Ncc;
-    const float* PDWT_RESTRICT gH = a.H + (long long)row * a.Ncc;
+    const real_t* PDWT_RESTRICT gL = a.L + (long long)row * a.Ncc;
+    const real_t* PDWT_RESTRICT gH = a.H + (long long)row * a.Ncc;
     const int cx0 = bx * TXO - c;
 
     PDWT_FOR_THREADS(tid, NT) {
@@ -129,18 +129,18 @@ PDWT_DEVICE void dwt1_inv_tile(const Inv1DArgs& a, int bx, int row, float* smem)
     PDWT_SYNC();
 
     PDWT_FOR_THREADS(tid, NT) {
-        float* PDWT_RESTRICT out = a.out + (long long)row * a.Nc;
+        real_t* PDWT_RESTRICT out = a.out + (long long)row * a.Nc;
         const bool vec_ok = ((a.Nc & 1) == 0);
 #pragma unroll
         for (int i = 0; i < TXO / NT; ++i) {
             const int k = tid + i * NT;
-            float res[2];
+            real_t res[2];
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 const int p = 2 * k + e + s;
                 const int q0 = p >> 1;
                 const int par = 1 - (p & 1);
-                float r = 0.f;
+                real_t r = 0.f;
 #pragma unroll
                 for (int j = 0; j < (HLEN > 0 ? HLEN / 2 : h2); ++j) {
                     const int t = hlen - 1 - (2 * j + par);
@@ -151,12 +151,12 @@ PDWT_DEVICE void dwt1_inv_tile(const Inv1DArgs& a, int bx, int row, float* smem)
                 res[e] = r;
             }
             const int ox = 2 * (bx * TXO + k);
-            float* dst = out + ox;
+            real_t* dst = out + ox;
             if (vec_ok && ox + 1 < a.Nc) {
-                f32x2 v;
+                real2_t v;
                 v.x = res[0];
                 v.y = res[1];
-                *reinterpret_cast<f32x2*>(dst) = v;
+                *reinterpret_cast<real2_t*>(dst) = v;
             } else {
                 if (ox < a.Nc) dst[0] = res[0];
                 if (ox + 1 < a.Nc) dst[1] = res[1];
@@ -168,7 +168,7 @@ PDWT_DEVICE void dwt1_inv_tile(const Inv1DArgs& a, int bx, int row, float* smem)
 #ifndef PDWT_CPU_EMU
 template <int HLEN, int TXO, int NT>
 __global__ void __launch_bounds__(NT) dwt1_fwd_kernel(const Fwd1DArgs a, int tiles_x) {
-    extern __shared__ __attribute__((aligned(16))) float pdwt_smem[];
+    extern __shared__ __attribute__((aligned(16))) real_t pdwt_smem[];
     const int row = blockIdx.x / tiles_x;
     const int bx = blockIdx.x - row * tiles_x;
     dwt1_fwd_tile<HLEN, TXO, NT>(a, bx, row, pdwt_smem);
@@ -176,7 +176,7 @@ __global__ void __launch_bounds__(NT) dwt1_fwd_kernel(const Fwd1DArgs a, int til
 
 template <int HLEN, int TXO, int NT>
 __global__ void __launch_bounds__(NT) dwt1_inv_kernel(const Inv1DArgs a, int tiles_x) {
-    extern __shared__ __attribute__((aligned(16))) float pdwt_smem[];
+    extern __shared__ __attribute__((aligned(16))) real_t pdwt_smem[];
     const int row = blockIdx.x / tiles_x;
     const int bx = blockIdx.x - row * tiles_x;
     dwt1_inv_tile<HLEN, TXO, NT>(a, bx, row, pdwt_smem);

@@ -31,7 +31,7 @@ constexpr int fwd2d_lds_floats(int hlen) {
 }
 
 template <int HLEN, int TX, int TY, int NT>
-PDWT_DEVICE void dwt2_fwd_tile(const Fwd2DArgs& a, int bx, int by, int bz, float* smem) {
+PDWT_DEVICE void dwt2_fwd_tile(const Fwd2DArgs& a, int bx, int by, int bz, real_t* smem) {
     static_assert(NT % TX == 0, "a wavefront row must cover the tile width");
     constexpr int NG = NT / TX;  // thread groups stacked along y
     static_assert(TY % NG == 0, "tile height must split over the thread groups");
@@ -42,13 +42,13 @@ PDWT_DEVICE void dwt2_fwd_tile(const Fwd2DArgs& a, int bx, int by, int bz, float
     const int RY = 2 * TY + hlen - 2;          // input rows staged
     const int RXp = (2 * TX + hlen - 2 + 1) & ~1;  // input cols staged (even stride: 8-B aligned pairs)
 
-    float* sTaps = smem;
-    float* sIn = smem + 2 * kMaxTaps;
-    float* tL = sIn + RY * RXp;
-    float* tH = tL + RY * TX;
+    real_t* sTaps = smem;
+    real_t* sIn = smem + 2 * kMaxTaps;
+    real_t* tL = sIn + RY * RXp;
+    real_t* tH = tL + RY * TX;
 
-    const float* lo = a.fb.lo;
-    const float* hi = a.fb.hi;
+    const real_t* lo = a.fb.lo;
+    const real_t* hi = a.fb.hi;
     if (HLEN == 0) {
         PDWT_FOR_THREADS(tid, NT) {
             if (tid < kMaxTaps) {
@@ -60,7 +60,7 @@ PDWT_DEVICE void dwt2_fwd_tile(const Fwd2DArgs& a, int bx, int by, int bz, float
         hi = sTaps + kMaxTaps;
     }
 
-    const float* PDWT_RESTRICT in = a.in + (long long)bz * a.in_bstride;
+    const real_t* PDWT_RESTRICT in = a.in + (long long)bz * a.in_bstride;
     const int x0 = 2 * bx * TX - c;
     const int y0 = 2 * by * TY - c;
 
@@ -81,13 +81,13 @@ PDWT_DEVICE void dwt2_fwd_tile(const Fwd2DArgs& a, int bx, int by, int bz, float
     PDWT_FOR_THREADS(tid, NT) {
         const int k = tid % TX;
         for (int r = tid / TX; r < RY; r += NG) {
-            const float* p = sIn + r * RXp + 2 * k;
-            float aL = 0.f, aH = 0.f;
+            const real_t* p = sIn + r * RXp + 2 * k;
+            real_t aL = 0.f, aH = 0.f;
             if (HLEN > 0 && (HLEN % 2) == 0) {
-                const f32x2* p2 = reinterpret_cast<const f32x2*>(p);
+                const real2_t* p2 = reinterpret_cast<const real2_t*>(p);
 #pragma unroll
                 for (int m = 0; m < (HLEN > 0 ? HLEN / 2 : 1); ++m) {
-                    const f32x2 v = p2[m];
+                    const real2_t v = p2[m];
                     aL = pdwt_fma(v.x, lo[hlen - 1 - 2 * m], aL);
                     aH = pdwt_fma(v.x, hi[hlen - 1 - 2 * m], aH);
                     aL = pdwt_fma(v.y, lo[hlen - 2 - 2 * m], aL);
@@ -95,7 +95,7 @@ PDWT_DEVICE void dwt2_fwd_tile(const Fwd2DArgs& a, int bx, int by, int bz, float
                 }
             } else {
                 for (int j = 0; j < hlen; ++j) {
-                    const float v = p[j];
+                    const real_t v = p[j];
                     aL = pdwt_fma(v, lo[hlen - 1 - j], aL);
                     aH = pdwt_fma(v, hi[hlen - 1 - j], aH);
                 }
@@ -111,25 +111,25 @@ PDWT_DEVICE void dwt2_fwd_tile(const Fwd2DArgs& a, int bx, int by, int bz, float
         const int k = tid % TX;
         const int ty0 = (tid / TX) * R;
         const int ox = bx * TX + k;
-        float* PDWT_RESTRICT oA = a.A + (long long)bz * a.out_bstride;
-        float* PDWT_RESTRICT oH = a.H + (long long)bz * a.out_bstride;
-        float* PDWT_RESTRICT oV = a.V + (long long)bz * a.out_bstride;
-        float* PDWT_RESTRICT oD = a.D + (long long)bz * a.out_bstride;
+        real_t* PDWT_RESTRICT oA = a.A + (long long)bz * a.out_bstride;
+        real_t* PDWT_RESTRICT oH = a.H + (long long)bz * a.out_bstride;
+        real_t* PDWT_RESTRICT oV = a.V + (long long)bz * a.out_bstride;
+        real_t* PDWT_RESTRICT oD = a.D + (long long)bz * a.out_bstride;
         if (HLEN > 0) {
             // sliding window: each staged row is read once and feeds every output
             // row whose support covers it
-            float accA[R], accH[R], accV[R], accD[R];
+            real_t accA[R], accH[R], accV[R], accD[R];
 #pragma unroll
             for (int i = 0; i < R; ++i) accA[i] = accH[i] = accV[i] = accD[i] = 0.f;
 #pragma unroll
             for (int r = 0; r < 2 * R + (HLEN > 0 ? HLEN : 2) - 2; ++r) {
-                const float l = tL[(2 * ty0 + r) * TX + k];
-                const float h = tH[(2 * ty0 + r) * TX + k];
+                const real_t l = tL[(2 * ty0 + r) * TX + k];
+                const real_t h = tH[(2 * ty0 + r) * TX + k];
 #pragma unroll
                 for (int i = 0; i < R; ++i) {
                     const int j = r - 2 * i;
                     if (j >= 0 && j < hlen) {
-                        const float tl = lo[hlen - 1 - j], th = hi[hlen - 1 - j];
+                        const real_t tl = lo[hlen - 1 - j], th = hi[hlen - 1 - j];
                         accA[i] = pdwt_fma(l, tl, accA[i]);
                         accH[i] = pdwt_fma(l, th, accH[i]);
                         accV[i] = pdwt_fma(h, tl, accV[i]);
@@ -150,11 +150,11 @@ PDWT_DEVICE void dwt2_fwd_tile(const Fwd2DArgs& a, int bx, int by, int bz, float
             }
         } else {
             for (int i = 0; i < R; ++i) {
-                float rA = 0.f, rH = 0.f, rV = 0.f, rD = 0.f;
+                real_t rA = 0.f, rH = 0.f, rV = 0.f, rD = 0.f;
                 for (int j = 0; j < hlen; ++j) {
-                    const float l = tL[(2 * (ty0 + i) + j) * TX + k];
-                    const float h = tH[(2 * (ty0 + i) + j) * TX + k];
-                    const float tl = lo[hlen - 1 - j], th = hi[hlen - 1 - j];
+                    const real_t l = tL[(2 * (ty0 + i) + j) * TX + k];
+                    const real_t h = tH[(2 * (ty0 + i) + j) * TX + k];
+                    const real_t tl = lo[hlen - 1 - j], th = hi[hlen - 1 - j];
                     rA = pdwt_fma(l, tl, rA);
                     rH = pdwt_fma(l, th, rH);
                     rV = pdwt_fma(h, tl, rV);
@@ -190,7 +190,7 @@ constexpr int inv2d_lds_floats(int hlen) {
 }
 
 template <int HLEN, int TX, int TY, int NT>
-PDWT_DEVICE void dwt2_inv_tile(const Inv2DArgs& a, int bx, int by, int bz, float* smem) {
+PDWT_DEVICE void dwt2_inv_tile(const Inv2DArgs& a, int bx, int by, int bz, real_t* smem) {
     const int hlen = HLEN ? HLEN : a.hlen;
     const int h2 = hlen / 2;
     const int c = h2 / 2;
@@ -199,16 +199,16 @@ PDWT_DEVICE void dwt2_inv_tile(const Inv2DArgs& a, int bx, int by, int bz, float
     const int CXp = TX + h2 + 1;  // coefficient cols staged
     const int OY = 2 * TY;
 
-    float* sTaps = smem;
-    float* sA = smem + 2 * kMaxTaps;
-    float* sH = sA + CR * CXp;
-    float* sV = sH + CR * CXp;
-    float* sD = sV + CR * CXp;
-    float* t1 = sD + CR * CXp;  // OY x CXp
-    float* t2 = t1 + OY * CXp;
+    real_t* sTaps = smem;
+    real_t* sA = smem + 2 * kMaxTaps;
+    real_t* sH = sA + CR * CXp;
+    real_t* sV = sH + CR * CXp;
+    real_t* sD = sV + CR * CXp;
+    real_t* t1 = sD + CR * CXp;  // OY x CXp
+    real_t* t2 = t1 + OY * CXp;
 
-    const float* lo = a.fb.lo;
-    const float* hi = a.fb.hi;
+    const real_t* lo = a.fb.lo;
+    const real_t* hi = a.fb.hi;
     if (HLEN == 0) {
         PDWT_FOR_THREADS(tid, NT) {
             if (tid < kMaxTaps) {
@@ -221,10 +221,10 @@ PDWT_DEVICE void dwt2_inv_tile(const Inv2DArgs& a, int bx, int by, int bz, float
     }
 
     const long long boff = (long long)bz * a.in_bstride;
-    const float* PDWT_RESTRICT gA = a.A + boff;
-    const float* PDWT_RESTRICT gH = a.H + boff;
-    const float* PDWT_RESTRICT gV = a.V + boff;
-    const float* PDWT_RESTRICT gD = a.D + boff;
+    const real_t* PDWT_RESTRICT gA = a.A + boff;
+    const real_t* PDWT_RESTRICT gH = a.H + boff;
+    const real_t* PDWT_RESTRICT gV = a.V + boff;
+    const real_t* PDWT_RESTRICT gD = a.D + boff;
 
     const int cy0 = by * TY - c;  // first coefficient row staged
     const int cx0 = bx * TX - c;
@@ -255,13 +255,13 @@ PDWT_DEVICE void dwt2_inv_tile(const Inv2DArgs& a, int bx, int by, int bz, float
             const int p = gy + s;  // tile origin 2*by*TY is even: parity of p is local
             const int r0 = p >> 1;
             const int par = 1 - (p & 1);
-            float r1 = 0.f, r2 = 0.f;
+            real_t r1 = 0.f, r2 = 0.f;
 #pragma unroll
             for (int j = 0; j < (HLEN > 0 ? HLEN / 2 : h2); ++j) {
                 const int t = hlen - 1 - (2 * j + par);
                 if (HLEN == 0 && t < 0) continue;
                 const int o = (r0 + j) * CXp + q;
-                const float tl = lo[t], th = hi[t];
+                const real_t tl = lo[t], th = hi[t];
                 r1 = pdwt_fma(sA[o], tl, r1);
                 r1 = pdwt_fma(sH[o], th, r1);
                 r2 = pdwt_fma(sV[o], tl, r2);
@@ -275,7 +275,7 @@ PDWT_DEVICE void dwt2_inv_tile(const Inv2DArgs& a, int bx, int by, int bz, float
 
     // ---- phase 3: row synthesis -> image tile, two adjacent samples per thread
     PDWT_FOR_THREADS(tid, NT) {
-        float* PDWT_RESTRICT out = a.out + (long long)bz * a.out_bstride;
+        real_t* PDWT_RESTRICT out = a.out + (long long)bz * a.out_bstride;
         const int total = OY * TX;
         const bool vec_ok = ((a.Nc & 1) == 0);
         for (int idx = tid; idx < total; idx += NT) {
@@ -283,15 +283,15 @@ PDWT_DEVICE void dwt2_inv_tile(const Inv2DArgs& a, int bx, int by, int bz, float
             const int k = idx - gy * TX;
             const int oy = 2 * by * TY + gy;
             const int ox = 2 * (bx * TX + k);
-            const float* u1 = t1 + gy * CXp;
-            const float* u2 = t2 + gy * CXp;
-            float res[2];
+            const real_t* u1 = t1 + gy * CXp;
+            const real_t* u2 = t2 + gy * CXp;
+            real_t res[2];
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 const int p = 2 * k + e + s;
                 const int q0 = p >> 1;
                 const int par = 1 - (p & 1);
-                float r = 0.f;
+                real_t r = 0.f;
 #pragma unroll
                 for (int j = 0; j < (HLEN > 0 ? HLEN / 2 : h2); ++j) {
                     const int t = hlen - 1 - (2 * j + par);
@@ -302,12 +302,12 @@ PDWT_DEVICE void dwt2_inv_tile(const Inv2DArgs& a, int bx, int by, int bz, float
                 res[e] = r;
             }
             if (oy < a.Nr) {
-                float* dst = out + (long long)oy * a.Nc + ox;
+                real_t* dst = out + (long long)oy * a.Nc + ox;
                 if (vec_ok && ox + 1 < a.Nc) {
-                    f32x2 v;
+                    real2_t v;
                     v.x = res[0];
                     v.y = res[1];
-                    *reinterpret_cast<f32x2*>(dst) = v;
+                    *reinterpret_cast<real2_t*>(dst) = v;
                 } else {
                     if (ox < a.Nc) dst[0] = res[0];
                     if (ox + 1 < a.Nc) dst[1] = res[1];
@@ -320,13 +320,13 @@ PDWT_DEVICE void dwt2_inv_tile(const Inv2DArgs& a, int bx, int by, int bz, float
 #ifndef PDWT_CPU_EMU
 template <int HLEN, int TX, int TY, int NT>
 __global__ void __launch_bounds__(NT) dwt2_fwd_kernel(const Fwd2DArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float pdwt_smem[];
+    extern __shared__ __attribute__((aligned(16))) real_t pdwt_smem[];
     dwt2_fwd_tile<HLEN, TX, TY, NT>(a, blockIdx.x, blockIdx.y, blockIdx.z, pdwt_smem);
 }
 
 template <int HLEN, int TX, int TY, int NT>
 __global__ void __launch_bounds__(NT) dwt2_inv_kernel(const Inv2DArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float pdwt_smem[];
+    extern __shared__ __attribute__((aligned(16))) real_t pdwt_smem[];
     dwt2_inv_tile<HLEN, TX, TY, NT>(a, blockIdx.x, blockIdx.y, blockIdx.z, pdwt_smem);
 }
 #endif

@@ -14,6 +14,16 @@
 #include <stddef.h>
 #include <stdint.h>
 
+// Arithmetic / storage type of the library.  The default build is fp32 (the reference's default and
+// the only type its Python class accepts); -DPDWT_DOUBLE builds the fp64 variant (the reference's
+// DOUBLEPRECISION compile-time switch, pdwt/src/filters.h:16-30): same sources, the generic kernels
+// only -- the packed-fp32 fast paths are compiled out.
+#ifdef PDWT_DOUBLE
+typedef double real_t;
+#else
+typedef float real_t;
+#endif
+
 #ifdef PDWT_CPU_EMU
 #include <math.h>
 #define PDWT_DEVICE inline
@@ -28,6 +38,11 @@ struct pdwt_float4 { float x, y, z, w; };
 typedef pdwt_float2 f32x2;
 typedef pdwt_float4 f32x4;
 static inline float pdwt_fma(float a, float b, float c) { return a * b + c; }
+static inline double pdwt_fma(double a, double b, double c) { return a * b + c; }
+struct pdwt_real2 { real_t x, y; };
+struct pdwt_real4 { real_t x, y, z, w; };
+typedef pdwt_real2 real2_t;
+typedef pdwt_real4 real4_t;
 #else
 #include <hip/hip_runtime.h>
 #define PDWT_DEVICE __device__ __forceinline__
@@ -40,6 +55,14 @@ static inline float pdwt_fma(float a, float b, float c) { return a * b + c; }
 typedef float2 f32x2;
 typedef float4 f32x4;
 static __device__ __forceinline__ float pdwt_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+static __device__ __forceinline__ double pdwt_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+#ifdef PDWT_DOUBLE
+typedef double2 real2_t;
+typedef double4 real4_t;
+#else
+typedef float2 real2_t;
+typedef float4 real4_t;
+#endif
 #endif
 
 namespace pdwt {
@@ -52,25 +75,9 @@ constexpr int kMaxTaps = 40;  // same limit as the reference (pdwt/src/common.h:
 // constant-memory bank shared by all plans (the reference's global __constant__
 // arrays, pdwt/src/common.h:28-36, make two live plans overwrite each other).
 struct FilterBank {
-    float lo[kMaxTaps];
-    float hi[kMaxTaps];
+    real_t lo[kMaxTaps];
+    real_t hi[kMaxTaps];
 };
-
-// ---- asynchronous global -> LDS copy (gfx950 global_load_lds_dwordx4) ----------------------------
-// Each active lane copies 16 B from ITS OWN global address to lds_lane0 + 16 * lane: the LDS image of
-// one wave instruction is lane-linear from a wave-uniform base (active lanes must be a prefix of the
-// wave).  No VGPR destination and no wait at the issue point: many copies can be put in flight back
-// to back; the next PDWT_SYNC() (s_waitcnt vmcnt(0) + s_barrier) retires them.
-#ifdef PDWT_CPU_EMU
-static inline void pdwt_glds16(const float* gsrc, float* lds_lane0, int lane) {
-    for (int c = 0; c < 4; ++c) lds_lane0[4 * lane + c] = gsrc[c];
-}
-#else
-static __device__ __forceinline__ void pdwt_glds16(const float* gsrc, float* lds_lane0, int /*lane*/) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                     (__attribute__((address_space(3))) void*)lds_lane0, 16, 0, 0);
-}
-#endif
 
 // ---- index helpers -------------------------------------------------------
 
@@ -101,8 +108,8 @@ PDWT_DEVICE int analysis_centre(int hlen) { return (hlen & 1) ? hlen / 2 : hlen 
 
 // soft threshold sign(x) max(|x|-b, 0) written as x - clamp(x, -b, b): the same value for every
 // finite x (b >= 0), the identity for b == 0, two instructions (v_med3_f32 + v_sub_f32)
-PDWT_DEVICE float soft_shrink(float x, float b) {
-    const float c = x < -b ? -b : (x > b ? b : x);
+PDWT_DEVICE real_t soft_shrink(real_t x, real_t b) {
+    const real_t c = x < -b ? -b : (x > b ? b : x);
     return x - c;
 }
 
@@ -110,8 +117,8 @@ PDWT_DEVICE float soft_shrink(float x, float b) {
 
 // one decimated 2D analysis level: in (Nr,Nc) -> A,H,V,D (Nr2,Nc2)
 struct Fwd2DArgs {
-    const float* in;
-    float *A, *H, *V, *D;
+    const real_t* in;
+    real_t *A, *H, *V, *D;
     int Nr, Nc, Nr2, Nc2;
     long long in_bstride, out_bstride;  // elements between consecutive images of a batch
     int hlen;
@@ -120,8 +127,8 @@ struct Fwd2DArgs {
 
 // one decimated 2D synthesis level: A,H,V,D (Nrc,Ncc) -> out (Nr,Nc), Nr <= 2 Nrc
 struct Inv2DArgs {
-    const float *A, *H, *V, *D;
-    float* out;
+    const real_t *A, *H, *V, *D;
+    real_t* out;
     int Nrc, Ncc, Nr, Nc;
     long long in_bstride, out_bstride;
     int hlen;
@@ -130,16 +137,16 @@ struct Inv2DArgs {
 
 // one decimated 1D analysis level on `rows` independent rows: in (rows,Nc) -> L,H (rows,Nc2)
 struct Fwd1DArgs {
-    const float* in;
-    float *L, *H;
+    const real_t* in;
+    real_t *L, *H;
     int rows, Nc, Nc2;
     int hlen;
     FilterBank fb;
 };
 
 struct Inv1DArgs {
-    const float *L, *H;
-    float* out;
+    const real_t *L, *H;
+    real_t* out;
     int rows, Ncc, Nc;
     int hlen;
     FilterBank fb;
@@ -147,21 +154,21 @@ struct Inv1DArgs {
 
 // one undecimated (a-trous) 2D level, dilation f = 2^(level-1)
 struct Swt2DArgs {
-    const float* in;          // forward: input plane; inverse: unused
-    float *A, *H, *V, *D;     // forward: outputs; inverse: inputs
-    float* out;               // inverse: output plane
+    const real_t* in;          // forward: input plane; inverse: unused
+    real_t *A, *H, *V, *D;     // forward: outputs; inverse: inputs
+    real_t* out;               // inverse: output plane
     int Nr, Nc, f;
     long long bstride;
     int hlen;
-    float soft_beta;          // inverse: soft-threshold applied to H,V,D as they are loaded (0 = none)
+    real_t soft_beta;          // inverse: soft-threshold applied to H,V,D as they are loaded (0 = none)
     FilterBank fb;
 };
 
 struct Swt1DArgs {
-    const float* in;   // forward input / inverse approximation
-    const float* det;  // inverse: detail band
-    float *L, *H;      // forward outputs
-    float* out;        // inverse output
+    const real_t* in;   // forward input / inverse approximation
+    const real_t* det;  // inverse: detail band
+    real_t *L, *H;      // forward outputs
+    real_t* out;        // inverse output
     int rows, Nc, f;
     int hlen;
     FilterBank fb;

@@ -22,22 +22,22 @@ hipError_t try_launch_dwt2_fwd_fast(const Fwd2DArgs& a, int batch, hipStream_t s
 hipError_t try_launch_dwt2_inv_fast(const Inv2DArgs& a, int batch, hipStream_t s);
 // two consecutive 2D levels in one launch (small levels only, see launch_dwt2_pyramid.hip)
 bool dwt2_pyramid_supported(int hlen, int N0r, int N0c);
-hipError_t launch_dwt2_fwd_pyr2(const float* in, float* const det1[3], float* const band2[4], int N0r, int N0c,
+hipError_t launch_dwt2_fwd_pyr2(const real_t* in, real_t* const det1[3], real_t* const band2[4], int N0r, int N0c,
                                 int hlen, const FilterBank& fb, int batch, hipStream_t s);
 // same contract, streaming-strip kernel for large inputs (forward only)
-hipError_t launch_dwt2_fwd_strip2(const float* in, float* const det1[3], float* const band2[4], int N0r, int N0c,
+hipError_t launch_dwt2_fwd_strip2(const real_t* in, real_t* const det1[3], real_t* const band2[4], int N0r, int N0c,
                                   int hlen, const FilterBank& fb, int batch, hipStream_t s);
-hipError_t launch_dwt2_inv_strip2(const float* const band2[4], const float* const det1[3], float* out, int N0r,
+hipError_t launch_dwt2_inv_strip2(const real_t* const band2[4], const real_t* const det1[3], real_t* out, int N0r,
                                   int N0c, int hlen, const FilterBank& fb, int batch, hipStream_t s);
-hipError_t launch_dwt2_inv_pyr2(const float* const band2[4], const float* const det1[3], float* out, int N0r, int N0c,
+hipError_t launch_dwt2_inv_pyr2(const real_t* const band2[4], const real_t* const det1[3], real_t* out, int N0r, int N0c,
                                 int hlen, const FilterBank& fb, int batch, hipStream_t s);
 hipError_t launch_dwt1_fwd(const Fwd1DArgs& a, hipStream_t s);
 hipError_t launch_dwt1_inv(const Inv1DArgs& a, hipStream_t s);
 // K consecutive 1D levels in one launch (2^K must divide N0, even hlen); hipErrorNotSupported otherwise
 int dwt1_fused_max_levels(int hlen);
-hipError_t launch_dwt1_fwd_fused(const float* in, float* const* det, float* app, int rows, int N0, int K, int hlen,
+hipError_t launch_dwt1_fwd_fused(const real_t* in, real_t* const* det, real_t* app, int rows, int N0, int K, int hlen,
                                  const FilterBank& fb, hipStream_t s);
-hipError_t launch_dwt1_inv_fused(const float* app, const float* const* det, float* out, int rows, int N0, int K,
+hipError_t launch_dwt1_inv_fused(const real_t* app, const real_t* const* det, real_t* out, int rows, int N0, int K,
                                  int hlen, const FilterBank& fb, hipStream_t s);
 // fused a-trous level; the host guarantees a.f divides a.Nr
 hipError_t launch_swt2_fwd(const Swt2DArgs& a, int batch, hipStream_t s);
@@ -50,13 +50,13 @@ hipError_t launch_nonsep_fwd(const NonsepArgs& a, int batch, hipStream_t s);
 hipError_t launch_nonsep_inv(const NonsepArgs& a, int batch, hipStream_t s);
 
 // streaming operators over a 16-B aligned range of n floats (n % 4 == 0)
-hipError_t launch_ew(int op, float* p, long long n, float b, hipStream_t s);
-hipError_t launch_group_soft(float* d0, float* d1, float* d2, float* ap, long long n, float beta, int nb,
+hipError_t launch_ew(int op, real_t* p, long long n, real_t b, hipStream_t s);
+hipError_t launch_group_soft(real_t* d0, real_t* d1, real_t* d2, real_t* ap, long long n, real_t beta, int nb,
                              hipStream_t s);
-hipError_t launch_axpy(float* dst, const float* src, long long n, float alpha, hipStream_t s);
-hipError_t launch_norms(const float* p, long long n, double* out2, hipStream_t s);
-hipError_t launch_circshift(const float* in, float* out, int batch, int Nr, int Nc, int sr, int sc, hipStream_t s);
-hipError_t launch_fill_hash(float* x, long long n, uint32_t seed, float scale, long long index_offset,
+hipError_t launch_axpy(real_t* dst, const real_t* src, long long n, real_t alpha, hipStream_t s);
+hipError_t launch_norms(const real_t* p, long long n, double* out2, hipStream_t s);
+hipError_t launch_circshift(const real_t* in, real_t* out, int batch, int Nr, int Nc, int sr, int sc, hipStream_t s);
+hipError_t launch_fill_hash(real_t* x, long long n, uint32_t seed, real_t scale, long long index_offset,
                             hipStream_t s);
 
 }  // namespace pdwt

@@ -11,7 +11,7 @@ namespace pdwt {
 template <int HLEN, int TXO, int NT>
 static hipError_t run_fwd(const Fwd1DArgs& a, hipStream_t s) {
     const int tiles = cdiv(a.Nc2, TXO);
-    const size_t lds = (size_t)fwd1d_lds_floats<TXO>(a.hlen) * sizeof(float);
+    const size_t lds = (size_t)fwd1d_lds_floats<TXO>(a.hlen) * sizeof(real_t);
     hipLaunchKernelGGL((dwt1_fwd_kernel<HLEN, TXO, NT>), dim3((unsigned)((long long)tiles * a.rows)), dim3(NT),
                        lds, s, a, tiles);
     return hipGetLastError();
@@ -20,7 +20,7 @@ static hipError_t run_fwd(const Fwd1DArgs& a, hipStream_t s) {
 template <int HLEN, int TXO, int NT>
 static hipError_t run_inv(const Inv1DArgs& a, hipStream_t s) {
     const int tiles = cdiv(a.Nc, 2 * TXO);
-    const size_t lds = (size_t)inv1d_lds_floats<TXO>(a.hlen) * sizeof(float);
+    const size_t lds = (size_t)inv1d_lds_floats<TXO>(a.hlen) * sizeof(real_t);
     hipLaunchKernelGGL((dwt1_inv_kernel<HLEN, TXO, NT>), dim3((unsigned)((long long)tiles * a.rows)), dim3(NT),
                        lds, s, a, tiles);
     return hipGetLastError();

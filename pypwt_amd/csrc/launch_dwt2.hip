@@ -11,10 +11,10 @@ namespace pdwt {
 template <int HLEN, int TX, int TY, int NT>
 static hipError_t run_fwd(const Fwd2DArgs& a, int batch, hipStream_t s) {
     static bool big[64] = {};
-    const size_t lds = (size_t)fwd2d_lds_floats<TX, TY>(HLEN ? HLEN : kMaxTaps) * sizeof(float);
+    const size_t lds = (size_t)fwd2d_lds_floats<TX, TY>(HLEN ? HLEN : kMaxTaps) * sizeof(real_t);
     hipError_t e = allow_big_lds(dwt2_fwd_kernel<HLEN, TX, TY, NT>, lds, big);
     if (e != hipSuccess) return e;
-    const size_t use = (size_t)fwd2d_lds_floats<TX, TY>(a.hlen) * sizeof(float);
+    const size_t use = (size_t)fwd2d_lds_floats<TX, TY>(a.hlen) * sizeof(real_t);
     dim3 grid(cdiv(a.Nc2, TX), cdiv(a.Nr2, TY), batch);
     hipLaunchKernelGGL((dwt2_fwd_kernel<HLEN, TX, TY, NT>), grid, dim3(NT), use, s, a);
     return hipGetLastError();
@@ -23,30 +23,54 @@ static hipError_t run_fwd(const Fwd2DArgs& a, int batch, hipStream_t s) {
 template <int HLEN, int TX, int TY, int NT>
 static hipError_t run_inv(const Inv2DArgs& a, int batch, hipStream_t s) {
     static bool big[64] = {};
-    const size_t lds = (size_t)inv2d_lds_floats<TX, TY>(HLEN ? HLEN : kMaxTaps) * sizeof(float);
+    const size_t lds = (size_t)inv2d_lds_floats<TX, TY>(HLEN ? HLEN : kMaxTaps) * sizeof(real_t);
     hipError_t e = allow_big_lds(dwt2_inv_kernel<HLEN, TX, TY, NT>, lds, big);
     if (e != hipSuccess) return e;
-    const size_t use = (size_t)inv2d_lds_floats<TX, TY>(a.hlen) * sizeof(float);
+    const size_t use = (size_t)inv2d_lds_floats<TX, TY>(a.hlen) * sizeof(real_t);
     dim3 grid(cdiv(a.Nc, 2 * TX), cdiv(a.Nr, 2 * TY), batch);
     hipLaunchKernelGGL((dwt2_inv_kernel<HLEN, TX, TY, NT>), grid, dim3(NT), use, s, a);
     return hipGetLastError();
 }
+
+#ifdef PDWT_DOUBLE
+// fp64 build: the packed-fp32 kernels (tuned single-level, tile pyramid, streaming strips, fused 1D
+// pyramids) are not compiled; every level runs through the generic kernels of this file / launch_dwt1.hip
+hipError_t try_launch_dwt2_fwd_fast(const Fwd2DArgs&, int, hipStream_t) { return hipErrorNotSupported; }
+hipError_t try_launch_dwt2_inv_fast(const Inv2DArgs&, int, hipStream_t) { return hipErrorNotSupported; }
+bool dwt2_pyramid_supported(int, int, int) { return false; }
+hipError_t launch_dwt2_fwd_pyr2(const real_t*, real_t* const[3], real_t* const[4], int, int, int, const FilterBank&, int,
+                                hipStream_t) { return hipErrorNotSupported; }
+hipError_t launch_dwt2_fwd_strip2(const real_t*, real_t* const[3], real_t* const[4], int, int, int, const FilterBank&,
+                                  int, hipStream_t) { return hipErrorNotSupported; }
+hipError_t launch_dwt2_inv_strip2(const real_t* const[4], const real_t* const[3], real_t*, int, int, int,
+                                  const FilterBank&, int, hipStream_t) { return hipErrorNotSupported; }
+hipError_t launch_dwt2_inv_pyr2(const real_t* const[4], const real_t* const[3], real_t*, int, int, int,
+                                const FilterBank&, int, hipStream_t) { return hipErrorNotSupported; }
+int dwt1_fused_max_levels(int) { return 1; }
+hipError_t launch_dwt1_fwd_fused(const real_t*, real_t* const*, real_t*, int, int, int, int, const FilterBank&,
+                                 hipStream_t) { return hipErrorNotSupported; }
+hipError_t launch_dwt1_inv_fused(const real_t*, const real_t* const*, real_t*, int, int, int, int, const FilterBank&,
+                                 hipStream_t) { return hipErrorNotSupported; }
+constexpr int kTyLong = 8;   // long filters: a 32-row tile of doubles would not fit the 160 KB of LDS
+#else
+constexpr int kTyLong = 32;
+#endif
 
 hipError_t launch_dwt2_fwd(const Fwd2DArgs& a, int batch, hipStream_t s) {
     {
         const hipError_t e = try_launch_dwt2_fwd_fast(a, batch, s);
         if (e != hipErrorNotSupported) return e;
     }
-    if (a.hlen & 1) return run_fwd<0, 64, 16, 256>(a, batch, s);
+    if (a.hlen & 1) return run_fwd<0, 64, kTyLong < 16 ? kTyLong : 16, 256>(a, batch, s);
     switch (a.hlen) {
 #define X(h)                                                       \
     case h:                                                        \
         if constexpr (h <= 12) return run_fwd<h, 64, 16, 256>(a, batch, s);  \
-        else return run_fwd<h, 64, 32, 256>(a, batch, s);
+        else return run_fwd<h, 64, kTyLong, 256>(a, batch, s);
         PDWT_EVEN_HLENS(X)
 #undef X
         default:
-            return run_fwd<0, 64, 16, 256>(a, batch, s);
+            return run_fwd<0, 64, kTyLong < 16 ? kTyLong : 16, 256>(a, batch, s);
     }
 }
 
@@ -55,16 +79,16 @@ hipError_t launch_dwt2_inv(const Inv2DArgs& a, int batch, hipStream_t s) {
         const hipError_t e = try_launch_dwt2_inv_fast(a, batch, s);
         if (e != hipErrorNotSupported) return e;
     }
-    if (a.hlen & 1) return run_inv<0, 64, 16, 256>(a, batch, s);
+    if (a.hlen & 1) return run_inv<0, 64, kTyLong < 16 ? kTyLong : 16, 256>(a, batch, s);
     switch (a.hlen) {
 #define X(h)                                                       \
     case h:                                                        \
         if constexpr (h <= 12) return run_inv<h, 64, 16, 256>(a, batch, s);  \
-        else return run_inv<h, 64, 32, 256>(a, batch, s);
+        else return run_inv<h, 64, kTyLong, 256>(a, batch, s);
         PDWT_EVEN_HLENS(X)
 #undef X
         default:
-            return run_inv<0, 64, 16, 256>(a, batch, s);
+            return run_inv<0, 64, kTyLong < 16 ? kTyLong : 16, 256>(a, batch, s);
     }
 }
 

@@ -10,10 +10,10 @@ namespace pdwt {
 template <int HLEN, int TX, int TY, int NT>
 static hipError_t run_fwd(const Swt2DArgs& a, int batch, hipStream_t s) {
     static bool big[64] = {};
-    const size_t lds = (size_t)swt2d_lds_floats<TX, TY>(HLEN ? HLEN : kMaxTaps) * sizeof(float);
+    const size_t lds = (size_t)swt2d_lds_floats<TX, TY>(HLEN ? HLEN : kMaxTaps) * sizeof(real_t);
     hipError_t e = allow_big_lds(swt2_fwd_kernel<HLEN, TX, TY, NT>, lds, big);
     if (e != hipSuccess) return e;
-    const size_t use = (size_t)swt2d_lds_floats<TX, TY>(a.hlen) * sizeof(float);
+    const size_t use = (size_t)swt2d_lds_floats<TX, TY>(a.hlen) * sizeof(real_t);
     const int M = a.Nr / a.f;
     dim3 grid(cdiv(a.Nc, TX), cdiv(M, TY) * a.f, batch);
     hipLaunchKernelGGL((swt2_fwd_kernel<HLEN, TX, TY, NT>), grid, dim3(NT), use, s, a);
@@ -23,10 +23,10 @@ static hipError_t run_fwd(const Swt2DArgs& a, int batch, hipStream_t s) {
 template <int HLEN, int TX, int TY, int NT>
 static hipError_t run_inv(const Swt2DArgs& a, int batch, hipStream_t s) {
     static bool big[64] = {};
-    const size_t lds = (size_t)swt2d_lds_floats<TX, TY>(HLEN ? HLEN : kMaxTaps) * sizeof(float);
+    const size_t lds = (size_t)swt2d_lds_floats<TX, TY>(HLEN ? HLEN : kMaxTaps) * sizeof(real_t);
     hipError_t e = allow_big_lds(swt2_inv_kernel<HLEN, TX, TY, NT>, lds, big);
     if (e != hipSuccess) return e;
-    const size_t use = (size_t)swt2d_lds_floats<TX, TY>(a.hlen) * sizeof(float);
+    const size_t use = (size_t)swt2d_lds_floats<TX, TY>(a.hlen) * sizeof(real_t);
     const int M = a.Nr / a.f;
     dim3 grid(cdiv(a.Nc, TX), cdiv(M, TY) * a.f, batch);
     hipLaunchKernelGGL((swt2_inv_kernel<HLEN, TX, TY, NT>), grid, dim3(NT), use, s, a);

@@ -17,10 +17,10 @@
 namespace pdwt {
 
 struct NonsepArgs {
-    const float* in;       // forward: image plane
-    float *A, *H, *V, *D;  // forward: outputs ; inverse: inputs
-    float* out;            // inverse: output plane
-    const float* filt;     // device memory: 4 banks of hlen*hlen (already the right direction)
+    const real_t* in;       // forward: image plane
+    real_t *A, *H, *V, *D;  // forward: outputs ; inverse: inputs
+    real_t* out;            // inverse: output plane
+    const real_t* filt;     // device memory: 4 banks of hlen*hlen (already the right direction)
     int Nr, Nc;            // image dims of this level
     int Nrc, Ncc;          // coefficient dims of this level (== Nr,Nc for SWT)
     int f;                 // SWT dilation (1 for DWT)
@@ -32,7 +32,7 @@ struct NonsepArgs {
 constexpr int nonsep_lds_floats(int hlen) { return 4 * hlen * hlen; }
 
 template <int NT>
-PDWT_DEVICE void nonsep_fwd_tile(const NonsepArgs& a, long long block, int bz, float* smem) {
+PDWT_DEVICE void nonsep_fwd_tile(const NonsepArgs& a, long long block, int bz, real_t* smem) {
     const int hlen = a.hlen, n2 = hlen * hlen;
     PDWT_FOR_THREADS(tid, NT) {
         for (int i = tid; i < 4 * n2; i += NT) smem[i] = a.filt[i];
@@ -44,14 +44,14 @@ PDWT_DEVICE void nonsep_fwd_tile(const NonsepArgs& a, long long block, int bz, f
         if (idx < total) {
             const int y = (int)(idx / a.Ncc), x = (int)(idx - (long long)y * a.Ncc);
             const int c = analysis_centre(hlen);
-            const float* in = a.in + (long long)bz * a.img_bstride;
-            float rA = 0.f, rH = 0.f, rV = 0.f, rD = 0.f;
+            const real_t* in = a.in + (long long)bz * a.img_bstride;
+            real_t rA = 0.f, rH = 0.f, rV = 0.f, rD = 0.f;
             for (int jy = 0; jy < hlen; ++jy) {
                 const int sy = a.do_swt ? wrap_periodic(y + (jy - c) * a.f, a.Nr) : wrap_analysis(2 * y - c + jy, a.Nr);
-                const float* row = in + (long long)sy * a.Nc;
+                const real_t* row = in + (long long)sy * a.Nc;
                 for (int jx = 0; jx < hlen; ++jx) {
                     const int sx = a.do_swt ? wrap_periodic(x + (jx - c) * a.f, a.Nc) : wrap_analysis(2 * x - c + jx, a.Nc);
-                    const float v = row[sx];
+                    const real_t v = row[sx];
                     const int t = (hlen - 1 - jy) * hlen + (hlen - 1 - jx);
                     rA = pdwt_fma(v, smem[t], rA);
                     rH = pdwt_fma(v, smem[n2 + t], rH);
@@ -69,7 +69,7 @@ PDWT_DEVICE void nonsep_fwd_tile(const NonsepArgs& a, long long block, int bz, f
 }
 
 template <int NT>
-PDWT_DEVICE void nonsep_inv_tile(const NonsepArgs& a, long long block, int bz, float* smem) {
+PDWT_DEVICE void nonsep_inv_tile(const NonsepArgs& a, long long block, int bz, real_t* smem) {
     const int hlen = a.hlen, n2 = hlen * hlen;
     PDWT_FOR_THREADS(tid, NT) {
         for (int i = tid; i < 4 * n2; i += NT) smem[i] = a.filt[i];
@@ -81,7 +81,7 @@ PDWT_DEVICE void nonsep_inv_tile(const NonsepArgs& a, long long block, int bz, f
         if (idx < total) {
             const int gy = (int)(idx / a.Nc), gx = (int)(idx - (long long)gy * a.Nc);
             const long long cb = (long long)bz * a.coef_bstride;
-            float r = 0.f;
+            real_t r = 0.f;
             if (!a.do_swt) {
                 const int h2 = hlen / 2, c = h2 / 2, s = (h2 & 1) ? 0 : 1;
                 const int py = gy + s, px = gx + s;
@@ -125,12 +125,12 @@ PDWT_DEVICE void nonsep_inv_tile(const NonsepArgs& a, long long block, int bz, f
 #ifndef PDWT_CPU_EMU
 template <int NT>
 __global__ void __launch_bounds__(NT) nonsep_fwd_kernel(const NonsepArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float pdwt_smem[];
+    extern __shared__ __attribute__((aligned(16))) real_t pdwt_smem[];
     nonsep_fwd_tile<NT>(a, blockIdx.x, blockIdx.y, pdwt_smem);
 }
 template <int NT>
 __global__ void __launch_bounds__(NT) nonsep_inv_kernel(const NonsepArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float pdwt_smem[];
+    extern __shared__ __attribute__((aligned(16))) real_t pdwt_smem[];
     nonsep_inv_tile<NT>(a, blockIdx.x, blockIdx.y, pdwt_smem);
 }
 #endif

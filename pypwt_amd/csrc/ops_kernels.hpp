@@ -2,7 +2,7 @@
 //
 // All bands of a plan live in one arena with 256-B aligned, zero-padded bands, so
 // an operator that treats every band alike sweeps ONE contiguous range with
-// float4 loads/stores (the reference launches one 16x16-thread kernel per level
+// real4_t loads/stores (the reference launches one 16x16-thread kernel per level
 // or one cuBLAS-v1 call per band, pdwt/src/common.cu:219-371, wt.cu:368-416).
 // Padding is zero and every operator here maps 0 -> 0.
 //
@@ -25,19 +25,19 @@
 namespace pdwt {
 
 template <int OP>
-__device__ __forceinline__ float ew_apply(float x, float b) {
-    if (OP == EW_SOFT) return copysignf(fmaxf(fabsf(x) - b, 0.0f), x);
-    if (OP == EW_HARD) return (fabsf(x) - b > 0.0f) ? x : 0.0f;
-    if (OP == EW_LINF) return copysignf(fminf(fabsf(x), b), x);
+__device__ __forceinline__ real_t ew_apply(real_t x, real_t b) {
+    if (OP == EW_SOFT) return copysign(fmax(fabs(x) - b, real_t(0)), x);
+    if (OP == EW_HARD) return (fabs(x) - b > real_t(0)) ? x : real_t(0);
+    if (OP == EW_LINF) return copysign(fmin(fabs(x), b), x);
     return x * b;
 }
 
-// n4 = number of float4 groups; the host only passes 16-B aligned, padded ranges
+// n4 = number of real4_t groups; the host only passes 16-B aligned, padded ranges
 template <int OP>
-__global__ void __launch_bounds__(256) ew_kernel(float4* __restrict__ p, long long n4, float b) {
+__global__ void __launch_bounds__(256) ew_kernel(real4_t* __restrict__ p, long long n4, real_t b) {
     const long long stride = (long long)gridDim.x * blockDim.x;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-        float4 v = p[i];
+        real4_t v = p[i];
         v.x = ew_apply<OP>(v.x, b);
         v.y = ew_apply<OP>(v.y, b);
         v.z = ew_apply<OP>(v.z, b);
@@ -47,17 +47,17 @@ __global__ void __launch_bounds__(256) ew_kernel(float4* __restrict__ p, long lo
 }
 
 // nb detail bands (1 or 3) of one level, optional approximation band
-__global__ void __launch_bounds__(256) group_soft_kernel(float* __restrict__ d0, float* __restrict__ d1,
-                                                         float* __restrict__ d2, float* __restrict__ ap,
-                                                         long long n, float beta, int nb) {
+__global__ void __launch_bounds__(256) group_soft_kernel(real_t* __restrict__ d0, real_t* __restrict__ d1,
+                                                         real_t* __restrict__ d2, real_t* __restrict__ ap,
+                                                         long long n, real_t beta, int nb) {
     const long long stride = (long long)gridDim.x * blockDim.x;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const float a = d0[i];
-        const float b = nb > 1 ? d1[i] : 0.f;
-        const float c = nb > 1 ? d2[i] : 0.f;
-        const float e = ap ? ap[i] : 0.f;
-        const float nrm = sqrtf(a * a + b * b + c * c + e * e);
-        const float res = (nrm == 0.f) ? 0.f : fmaxf(1.0f - beta / nrm, 0.0f);
+        const real_t a = d0[i];
+        const real_t b = nb > 1 ? d1[i] : real_t(0);
+        const real_t c = nb > 1 ? d2[i] : real_t(0);
+        const real_t e = ap ? ap[i] : real_t(0);
+        const real_t nrm = sqrt(a * a + b * b + c * c + e * e);
+        const real_t res = (nrm == real_t(0)) ? real_t(0) : fmax(real_t(1) - beta / nrm, real_t(0));
         d0[i] = a * res;
         if (nb > 1) {
             d1[i] = b * res;
@@ -67,29 +67,29 @@ __global__ void __launch_bounds__(256) group_soft_kernel(float* __restrict__ d0,
     }
 }
 
-__global__ void __launch_bounds__(256) axpy_kernel(float4* __restrict__ dst, const float4* __restrict__ src,
-                                                   long long n4, float alpha) {
+__global__ void __launch_bounds__(256) axpy_kernel(real4_t* __restrict__ dst, const real4_t* __restrict__ src,
+                                                   long long n4, real_t alpha) {
     const long long stride = (long long)gridDim.x * blockDim.x;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-        float4 d = dst[i];
-        const float4 s = src[i];
-        d.x = fmaf(alpha, s.x, d.x);
-        d.y = fmaf(alpha, s.y, d.y);
-        d.z = fmaf(alpha, s.z, d.z);
-        d.w = fmaf(alpha, s.w, d.w);
+        real4_t d = dst[i];
+        const real4_t s = src[i];
+        d.x = pdwt_fma(alpha, s.x, d.x);
+        d.y = pdwt_fma(alpha, s.y, d.y);
+        d.z = pdwt_fma(alpha, s.z, d.z);
+        d.w = pdwt_fma(alpha, s.w, d.w);
         dst[i] = d;
     }
 }
 
 // out[0] += sum|x| ; out[1] += sum x^2   (fp64 accumulation: one wave-shuffle
 // reduction per wavefront, one LDS step per block, two atomics per block)
-__global__ void __launch_bounds__(256) norms_kernel(const float4* __restrict__ p, long long n4,
+__global__ void __launch_bounds__(256) norms_kernel(const real4_t* __restrict__ p, long long n4,
                                                     double* __restrict__ out) {
     double s1 = 0.0, s2 = 0.0;
     const long long stride = (long long)gridDim.x * blockDim.x;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-        const float4 v = p[i];
-        s1 += (double)fabsf(v.x) + (double)fabsf(v.y) + (double)fabsf(v.z) + (double)fabsf(v.w);
+        const real4_t v = p[i];
+        s1 += (double)fabs(v.x) + (double)fabs(v.y) + (double)fabs(v.z) + (double)fabs(v.w);
         s2 += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
     }
 #pragma unroll
@@ -111,7 +111,7 @@ __global__ void __launch_bounds__(256) norms_kernel(const float4* __restrict__ p
 }
 
 // out[b][y][x] = in[b][(y - sr) mod Nr][(x - sc) mod Nc],  0 <= sr < Nr, 0 <= sc < Nc
-__global__ void __launch_bounds__(256) circshift_kernel(const float* __restrict__ in, float* __restrict__ out,
+__global__ void __launch_bounds__(256) circshift_kernel(const real_t* __restrict__ in, real_t* __restrict__ out,
                                                         int Nr, int Nc, int sr, int sc) {
     const long long plane = (long long)Nr * Nc;
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -127,8 +127,8 @@ __global__ void __launch_bounds__(256) circshift_kernel(const float* __restrict_
 
 // deterministic test/bench input, identical to oracle_fill_hash and
 // tests/golden/make_golden.py:hash_input
-__global__ void __launch_bounds__(256) fill_hash_kernel(float* __restrict__ x, long long n, uint32_t seed,
-                                                        float scale, long long index_offset) {
+__global__ void __launch_bounds__(256) fill_hash_kernel(real_t* __restrict__ x, long long n, uint32_t seed,
+                                                        real_t scale, long long index_offset) {
     const long long stride = (long long)gridDim.x * blockDim.x;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         uint32_t h = (uint32_t)(i + index_offset) ^ seed;
@@ -137,7 +137,7 @@ __global__ void __launch_bounds__(256) fill_hash_kernel(float* __restrict__ x, l
         h ^= h >> 15;
         h *= 0x846CA68Bu;
         h ^= h >> 16;
-        x[i] = (float)(h >> 8) * (1.0f / 16777216.0f) * scale;
+        x[i] = (real_t)((float)(h >> 8) * (1.0f / 16777216.0f)) * scale;  // 24-bit value, exact in fp32
     }
 }
 

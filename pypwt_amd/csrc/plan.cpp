@@ -100,8 +100,8 @@ void clear_stamps(pdwt_plan* p) {
 void set_bank(FilterBank& fb, const double* lo, const double* hi, int n) {
     memset(&fb, 0, sizeof(fb));
     for (int i = 0; i < n; i++) {
-        fb.lo[i] = (float)lo[i];
-        fb.hi[i] = (float)hi[i];
+        fb.lo[i] = (real_t)lo[i];
+        fb.hi[i] = (real_t)hi[i];
     }
 }
 
@@ -113,7 +113,7 @@ int ensure_tmp(pdwt_plan* p, long long elems) {
         p->tmp = nullptr;
         p->tmp_elems = 0;
     }
-    HIP_TRY(hipMalloc((void**)&p->tmp, (size_t)elems * sizeof(float)));
+    HIP_TRY(hipMalloc((void**)&p->tmp, (size_t)elems * sizeof(real_t)));
     p->tmp_elems = elems;
     return PDWT_OK;
 }
@@ -158,8 +158,8 @@ int build_layout(pdwt_plan* p) {
     p->image_off = off;
     off += pad64((long long)B * p->info.Nr * p->info.Nc);
     p->arena_elems = off;
-    HIP_TRY(hipMalloc((void**)&p->arena, (size_t)off * sizeof(float)));
-    HIP_TRY(hipMemsetAsync(p->arena, 0, (size_t)off * sizeof(float), p->stream));
+    HIP_TRY(hipMalloc((void**)&p->arena, (size_t)off * sizeof(real_t)));
+    HIP_TRY(hipMemsetAsync(p->arena, 0, (size_t)off * sizeof(real_t), p->stream));
     HIP_TRY(hipMalloc((void**)&p->d_red, 2 * sizeof(double)));
     return PDWT_OK;
 }
@@ -170,14 +170,14 @@ int build_layout(pdwt_plan* p) {
 // which swaps H and V relative to its own separable path; not reproduced.)
 int upload_builtin_f2d(pdwt_plan* p) {
     const int n = p->info.hlen;
-    std::vector<float> h((size_t)8 * n * n);
-    const float* flo[2] = {p->dec.lo, p->rec.lo};
-    const float* fhi[2] = {p->dec.hi, p->rec.hi};
+    std::vector<real_t> h((size_t)8 * n * n);
+    const real_t* flo[2] = {p->dec.lo, p->rec.lo};
+    const real_t* fhi[2] = {p->dec.hi, p->rec.hi};
     for (int d = 0; d < 2; d++) {
-        float* LL = h.data() + (size_t)(4 * d + 0) * n * n;
-        float* LH = h.data() + (size_t)(4 * d + 1) * n * n;  // band H
-        float* HL = h.data() + (size_t)(4 * d + 2) * n * n;  // band V
-        float* HH = h.data() + (size_t)(4 * d + 3) * n * n;
+        real_t* LL = h.data() + (size_t)(4 * d + 0) * n * n;
+        real_t* LH = h.data() + (size_t)(4 * d + 1) * n * n;  // band H
+        real_t* HL = h.data() + (size_t)(4 * d + 2) * n * n;  // band V
+        real_t* HH = h.data() + (size_t)(4 * d + 3) * n * n;
         for (int i = 0; i < n; i++)      // i: y tap
             for (int j = 0; j < n; j++) {  // j: x tap
                 LL[i * n + j] = flo[d][i] * flo[d][j];
@@ -186,13 +186,13 @@ int upload_builtin_f2d(pdwt_plan* p) {
                 HH[i * n + j] = fhi[d][i] * fhi[d][j];
             }
     }
-    if (!p->d_f2d) HIP_TRY(hipMalloc((void**)&p->d_f2d, (size_t)8 * kMaxTaps * kMaxTaps * sizeof(float)));
-    HIP_TRY(hipMemcpyAsync(p->d_f2d, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice, p->stream));
+    if (!p->d_f2d) HIP_TRY(hipMalloc((void**)&p->d_f2d, (size_t)8 * kMaxTaps * kMaxTaps * sizeof(real_t)));
+    HIP_TRY(hipMemcpyAsync(p->d_f2d, h.data(), h.size() * sizeof(real_t), hipMemcpyHostToDevice, p->stream));
     HIP_TRY(hipStreamSynchronize(p->stream));
     return PDWT_OK;
 }
 
-int create_impl(const float* img, int batch, int Nr, int Nc, const char* wname, int levels, int mem_is_on_host,
+int create_impl(const real_t* img, int batch, int Nr, int Nc, const char* wname, int levels, int mem_is_on_host,
                 int do_separable, int do_cycle_spinning, int do_swt, int ndim, int device_id, void* stream,
                 pdwt_handle* out) {
     if (!out) return fail(PDWT_ERR_ARG, "pdwt_create: out is null");
@@ -271,7 +271,7 @@ int create_impl(const float* img, int batch, int Nr, int Nc, const char* wname, 
     }
     if ((rc = build_layout(p)) != PDWT_OK) return bail(rc);
     if (img) {
-        hipError_t e = hipMemcpyAsync(p->image(), img, (size_t)batch * Nr * Nc * sizeof(float),
+        hipError_t e = hipMemcpyAsync(p->image(), img, (size_t)batch * Nr * Nc * sizeof(real_t),
                                       mem_is_on_host ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, p->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(p->stream);
         if (e != hipSuccess) {
@@ -362,16 +362,16 @@ std::vector<std::pair<int, int>> fused_groups_1d(const pdwt_plan* p) {
 int forward_impl(pdwt_plan* p, int only = 0) {
     const int L = p->info.nlevels, B = p->batch, hlen = p->info.hlen;
     const bool swt = p->info.do_swt != 0;
-    const float* src = p->image();
+    const real_t* src = p->image();
     if (p->info.ndims == 2) {
         const std::vector<int> strips = strip_pairs(p, false);
         std::vector<int> pyr = pyramid_pairs(p);
         for (int l = 1; l <= L; l++) {
             const bool run = (only == 0 || only == l);
             if (in_list(strips, l)) {
-                float* det1[3] = {p->band(3 * (l - 1) + 1), p->band(3 * (l - 1) + 2), p->band(3 * (l - 1) + 3)};
-                float* A2 = (l + 1 == L) ? p->band(0) : p->arena + p->approx_off[l + 1];
-                float* band2[4] = {A2, p->band(3 * l + 1), p->band(3 * l + 2), p->band(3 * l + 3)};
+                real_t* det1[3] = {p->band(3 * (l - 1) + 1), p->band(3 * (l - 1) + 2), p->band(3 * (l - 1) + 3)};
+                real_t* A2 = (l + 1 == L) ? p->band(0) : p->arena + p->approx_off[l + 1];
+                real_t* band2[4] = {A2, p->band(3 * l + 1), p->band(3 * l + 2), p->band(3 * l + 3)};
                 Stamp st(p, "dwt2_fwd_strip2");
                 if (run) HIP_TRY(launch_dwt2_fwd_strip2(src, det1, band2, p->lr[l - 1], p->lc[l - 1], hlen, p->dec, B,
                                                         p->stream));
@@ -381,9 +381,9 @@ int forward_impl(pdwt_plan* p, int only = 0) {
             }
             if (in_list(pyr, l) && !in_list(strips, l + 1)) {
                 // levels l and l+1 in one launch; A_l never leaves LDS
-                float* det1[3] = {p->band(3 * (l - 1) + 1), p->band(3 * (l - 1) + 2), p->band(3 * (l - 1) + 3)};
-                float* A2 = (l + 1 == L) ? p->band(0) : p->arena + p->approx_off[l + 1];
-                float* band2[4] = {A2, p->band(3 * l + 1), p->band(3 * l + 2), p->band(3 * l + 3)};
+                real_t* det1[3] = {p->band(3 * (l - 1) + 1), p->band(3 * (l - 1) + 2), p->band(3 * (l - 1) + 3)};
+                real_t* A2 = (l + 1 == L) ? p->band(0) : p->arena + p->approx_off[l + 1];
+                real_t* band2[4] = {A2, p->band(3 * l + 1), p->band(3 * l + 2), p->band(3 * l + 3)};
                 Stamp st(p, "dwt2_fwd_pyr2");
                 if (run) HIP_TRY(launch_dwt2_fwd_pyr2(src, det1, band2, p->lr[l - 1], p->lc[l - 1], hlen, p->dec, B,
                                                       p->stream));
@@ -391,11 +391,11 @@ int forward_impl(pdwt_plan* p, int only = 0) {
                 l++;
                 continue;
             }
-            float* dstA = (l == L) ? p->band(0)
+            real_t* dstA = (l == L) ? p->band(0)
                                    : p->arena + (swt ? p->approx_off[l & 1] : p->approx_off[l]);
-            float* H = p->band(3 * (l - 1) + 1);
-            float* V = p->band(3 * (l - 1) + 2);
-            float* D = p->band(3 * (l - 1) + 3);
+            real_t* H = p->band(3 * (l - 1) + 1);
+            real_t* V = p->band(3 * (l - 1) + 2);
+            real_t* D = p->band(3 * (l - 1) + 3);
             if (!p->do_separable) {
                 NonsepArgs a;
                 a.in = src; a.A = dstA; a.H = H; a.V = V; a.D = D; a.out = nullptr;
@@ -460,9 +460,9 @@ int forward_impl(pdwt_plan* p, int only = 0) {
             if (gi < groups.size() && groups[gi].first == l - 1) {
                 // levels l .. l+K-1 in ONE launch (dwt1_fused_kernels.hpp)
                 const int K = groups[gi].second;
-                float* det[kMaxFusedLevelsHost] = {};
+                real_t* det[kMaxFusedLevelsHost] = {};
                 for (int k = 0; k < K; k++) det[k] = p->band(l + k);
-                float* app = (l + K - 1 == L) ? p->band(0) : p->arena + p->approx_off[l + K - 1];
+                real_t* app = (l + K - 1 == L) ? p->band(0) : p->arena + p->approx_off[l + K - 1];
                 Stamp st(p, "dwt1_fwd_fused");
                 if (run) HIP_TRY(launch_dwt1_fwd_fused(src, det, app, rows, p->lc[l - 1], K, hlen, p->dec, p->stream));
                 src = app;
@@ -470,9 +470,9 @@ int forward_impl(pdwt_plan* p, int only = 0) {
                 gi++;
                 continue;
             }
-            float* dstA = (l == L) ? p->band(0)
+            real_t* dstA = (l == L) ? p->band(0)
                                    : p->arena + (swt ? p->approx_off[l & 1] : p->approx_off[l]);
-            float* Dl = p->band(l);
+            real_t* Dl = p->band(l);
             if (!swt) {
                 Fwd1DArgs a;
                 a.in = src; a.L = dstA; a.H = Dl;
@@ -497,16 +497,16 @@ int forward_impl(pdwt_plan* p, int only = 0) {
 int inverse_impl(pdwt_plan* p, int only = 0) {
     const int L = p->info.nlevels, B = p->batch, hlen = p->info.hlen;
     const bool swt = p->info.do_swt != 0;
-    const float* cur = p->band(0);
+    const real_t* cur = p->band(0);
     if (p->info.ndims == 2) {
         const std::vector<int> pyr = pyramid_pairs(p);
         const std::vector<int> strips = strip_pairs(p, true);
         for (int l = L; l >= 1; l--) {
             if (l >= 2 && in_list(strips, l - 1)) {
                 const int l1 = l - 1;
-                const float* band2[4] = {cur, p->band(3 * (l - 1) + 1), p->band(3 * (l - 1) + 2), p->band(3 * (l - 1) + 3)};
-                const float* det1[3] = {p->band(3 * (l1 - 1) + 1), p->band(3 * (l1 - 1) + 2), p->band(3 * (l1 - 1) + 3)};
-                float* dst = (l1 == 1) ? p->image() : p->arena + p->approx_off[l1 - 1];
+                const real_t* band2[4] = {cur, p->band(3 * (l - 1) + 1), p->band(3 * (l - 1) + 2), p->band(3 * (l - 1) + 3)};
+                const real_t* det1[3] = {p->band(3 * (l1 - 1) + 1), p->band(3 * (l1 - 1) + 2), p->band(3 * (l1 - 1) + 3)};
+                real_t* dst = (l1 == 1) ? p->image() : p->arena + p->approx_off[l1 - 1];
                 Stamp st(p, "dwt2_inv_strip2");
                 if (only == 0 || only == l1)
                     HIP_TRY(launch_dwt2_inv_strip2(band2, det1, dst, p->lr[l1 - 1], p->lc[l1 - 1], hlen, p->rec, B,
@@ -518,9 +518,9 @@ int inverse_impl(pdwt_plan* p, int only = 0) {
             if (l >= 2 && in_list(pyr, l - 1) && !in_list(strips, l)) {
                 // levels l and l-1 undone in one launch: A_{l-1} is synthesised in LDS
                 const int l1 = l - 1;
-                const float* band2[4] = {cur, p->band(3 * (l - 1) + 1), p->band(3 * (l - 1) + 2), p->band(3 * (l - 1) + 3)};
-                const float* det1[3] = {p->band(3 * (l1 - 1) + 1), p->band(3 * (l1 - 1) + 2), p->band(3 * (l1 - 1) + 3)};
-                float* dst = (l1 == 1) ? p->image() : p->arena + p->approx_off[l1 - 1];
+                const real_t* band2[4] = {cur, p->band(3 * (l - 1) + 1), p->band(3 * (l - 1) + 2), p->band(3 * (l - 1) + 3)};
+                const real_t* det1[3] = {p->band(3 * (l1 - 1) + 1), p->band(3 * (l1 - 1) + 2), p->band(3 * (l1 - 1) + 3)};
+                real_t* dst = (l1 == 1) ? p->image() : p->arena + p->approx_off[l1 - 1];
                 Stamp st(p, "dwt2_inv_pyr2");
                 if (only == 0 || only == l1)
                     HIP_TRY(launch_dwt2_inv_pyr2(band2, det1, dst, p->lr[l1 - 1], p->lc[l1 - 1], hlen, p->rec, B,
@@ -530,16 +530,16 @@ int inverse_impl(pdwt_plan* p, int only = 0) {
                 continue;
             }
             const bool run = (only == 0 || only == l);
-            float* dst = (l == 1) ? p->image()
+            real_t* dst = (l == 1) ? p->image()
                                   : p->arena + (swt ? p->approx_off[(l - 1) & 1] : p->approx_off[l - 1]);
-            const float* H = p->band(3 * (l - 1) + 1);
-            const float* V = p->band(3 * (l - 1) + 2);
-            const float* D = p->band(3 * (l - 1) + 3);
+            const real_t* H = p->band(3 * (l - 1) + 1);
+            const real_t* V = p->band(3 * (l - 1) + 2);
+            const real_t* D = p->band(3 * (l - 1) + 3);
             if (!p->do_separable) {
                 NonsepArgs a;
                 a.in = nullptr;
-                a.A = const_cast<float*>(cur); a.H = const_cast<float*>(H);
-                a.V = const_cast<float*>(V); a.D = const_cast<float*>(D);
+                a.A = const_cast<real_t*>(cur); a.H = const_cast<real_t*>(H);
+                a.V = const_cast<real_t*>(V); a.D = const_cast<real_t*>(D);
                 a.out = dst;
                 a.filt = p->d_f2d + (size_t)4 * hlen * hlen;  // inverse banks
                 a.Nr = p->lr[l - 1]; a.Nc = p->lc[l - 1]; a.Nrc = p->lr[l]; a.Ncc = p->lc[l];
@@ -564,17 +564,17 @@ int inverse_impl(pdwt_plan* p, int only = 0) {
                 if (Nr % f == 0) {
                     Swt2DArgs a;
                     a.in = nullptr;
-                    a.A = const_cast<float*>(cur); a.H = const_cast<float*>(H);
-                    a.V = const_cast<float*>(V); a.D = const_cast<float*>(D);
+                    a.A = const_cast<real_t*>(cur); a.H = const_cast<real_t*>(H);
+                    a.V = const_cast<real_t*>(V); a.D = const_cast<real_t*>(D);
                     a.out = dst;
                     a.Nr = Nr; a.Nc = Nc; a.f = f;
                     a.bstride = (long long)Nr * Nc;
                     a.hlen = hlen;
                     a.soft_beta = 0.f;
                     if (p->pend_soft) {  // deferred soft_threshold: beta (/ sqrt(2)^l when normalised)
-                        float b = p->pend_beta;
+                        real_t b = p->pend_beta;
                         if (p->pend_normalize > 0)
-                            for (int i = 0; i < l; i++) b = (float)(b / 1.4142135623730951);
+                            for (int i = 0; i < l; i++) b = (real_t)(b / 1.4142135623730951);
                         a.soft_beta = b;
                     }
                     a.fb = p->rec;
@@ -610,9 +610,9 @@ int inverse_impl(pdwt_plan* p, int only = 0) {
             if (gi >= 0 && groups[gi].first + groups[gi].second == l) {
                 // levels l-K+1 .. l undone in ONE launch
                 const int K = groups[gi].second, l0 = groups[gi].first;  // l0 = level of the output (0 = image)
-                const float* det[kMaxFusedLevelsHost] = {};
+                const real_t* det[kMaxFusedLevelsHost] = {};
                 for (int k = 0; k < K; k++) det[k] = p->band(l0 + 1 + k);
-                float* dst = (l0 == 0) ? p->image() : p->arena + p->approx_off[l0];
+                real_t* dst = (l0 == 0) ? p->image() : p->arena + p->approx_off[l0];
                 Stamp st(p, "dwt1_inv_fused");
                 if (only == 0 || only == l0 + 1) HIP_TRY(launch_dwt1_inv_fused(cur, det, dst, rows, p->lc[l0], K, hlen, p->rec, p->stream));
                 cur = dst;
@@ -620,9 +620,9 @@ int inverse_impl(pdwt_plan* p, int only = 0) {
                 gi--;
                 continue;
             }
-            float* dst = (l == 1) ? p->image()
+            real_t* dst = (l == 1) ? p->image()
                                   : p->arena + (swt ? p->approx_off[(l - 1) & 1] : p->approx_off[l - 1]);
-            const float* Dl = p->band(l);
+            const real_t* Dl = p->band(l);
             if (!swt) {
                 Inv1DArgs a;
                 a.L = cur; a.H = Dl; a.out = dst;
@@ -656,7 +656,7 @@ int circshift_impl(pdwt_plan* p, int sr, int sc, int inplace) {
     if (rc != PDWT_OK) return rc;
     Stamp st(p, "circshift");
     if (inplace) {
-        HIP_TRY(hipMemcpyAsync(p->tmp, p->image(), (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, p->stream));
+        HIP_TRY(hipMemcpyAsync(p->tmp, p->image(), (size_t)n * sizeof(real_t), hipMemcpyDeviceToDevice, p->stream));
         HIP_TRY(launch_circshift(p->tmp, p->image(), p->batch, Nr, Nc, sr, sc, p->stream));
     } else {
         HIP_TRY(launch_circshift(p->image(), p->tmp, p->batch, Nr, Nc, sr, sc, p->stream));
@@ -665,16 +665,16 @@ int circshift_impl(pdwt_plan* p, int sr, int sc, int inplace) {
 }
 
 // beta / sqrt(2)^levels for the approximation band (pdwt/src/common.cu:229-236)
-float app_beta(float beta, int levels, int normalize) {
+real_t app_beta(real_t beta, int levels, int normalize) {
     if (normalize > 0) {
         const int n2 = levels / 2;
-        beta /= (float)(1 << n2);
-        if (n2 * 2 != levels) beta = (float)(beta / 1.4142135623730951);
+        beta /= (real_t)(1 << n2);
+        if (n2 * 2 != levels) beta = (real_t)(beta / 1.4142135623730951);
     }
     return beta;
 }
 
-int threshold_impl(pdwt_plan* p, int op, float beta, int do_app, int normalize, const char* what);
+int threshold_impl(pdwt_plan* p, int op, real_t beta, int do_app, int normalize, const char* what);
 
 // apply a deferred soft_threshold now (every consumer of the coefficients other than the fused SWT
 // inverse calls this first)
@@ -691,7 +691,7 @@ bool can_defer_soft(const pdwt_plan* p) {
 }
 
 // soft / hard / proj_linf share one driver (pdwt/src/common.cu:219-308)
-int threshold_impl(pdwt_plan* p, int op, float beta, int do_app, int normalize, const char* what) {
+int threshold_impl(pdwt_plan* p, int op, real_t beta, int do_app, int normalize, const char* what) {
     if (p->state == PDWT_INVERSE)
         return fail(PDWT_ERR_STATE, "%s: cannot threshold coefficients, as they were modified by inverse()", what);
     {
@@ -711,7 +711,7 @@ int threshold_impl(pdwt_plan* p, int op, float beta, int do_app, int normalize, 
         HIP_TRY(launch_ew(op, p->arena + first, p->coeff_elems - first, beta, p->stream));
     } else {
         for (int l = 1; l <= L; l++) {
-            beta = (float)(beta / 1.4142135623730951);  // common.cu:244
+            beta = (real_t)(beta / 1.4142135623730951);  // common.cu:244
             const long long first = p->bands[per * (l - 1) + 1].off;
             const long long last = (l == L) ? p->coeff_elems : p->bands[per * l + 1].off;
             Stamp st(p, what);
@@ -737,7 +737,7 @@ std::string info_text(pdwt_plan* p) {
              yn[p->do_cycle_spinning ? 1 : 0], yn[p->do_separable ? 1 : 0]);
     s += buf;
     snprintf(buf, sizeof(buf), "Estimated memory footprint : %.2f MB\n",
-             (double)(p->arena_elems + p->tmp_elems) * sizeof(float) / 1e6);
+             (double)(p->arena_elems + p->tmp_elems) * sizeof(real_t) / 1e6);
     s += buf;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, p->device) == hipSuccess)
@@ -757,13 +757,13 @@ extern "C" {
 const char* pdwt_last_error(void) { return g_last_error.c_str(); }
 const char* pdwt_version(void) { return "pypwt_amd 0.1.0 (gfx950); API of pycudwt 1.0.3"; }
 
-int pdwt_create(const float* img, int Nr, int Nc, const char* wname, int levels, int mem_is_on_host,
+int pdwt_create(const real_t* img, int Nr, int Nc, const char* wname, int levels, int mem_is_on_host,
                 int do_separable, int do_cycle_spinning, int do_swt, int ndim, pdwt_handle* out) {
     return create_impl(img, 1, Nr, Nc, wname, levels, mem_is_on_host, do_separable, do_cycle_spinning, do_swt,
                        ndim, -1, nullptr, out);
 }
 
-int pdwt_create_batched(const float* img, int batch, int Nr, int Nc, const char* wname, int levels,
+int pdwt_create_batched(const real_t* img, int batch, int Nr, int Nc, const char* wname, int levels,
                         int mem_is_on_host, int do_separable, int do_cycle_spinning, int do_swt, int ndim,
                         int device_id, void* hip_stream, pdwt_handle* out) {
     return create_impl(img, batch, Nr, Nc, wname, levels, mem_is_on_host, do_separable, do_cycle_spinning, do_swt,
@@ -798,12 +798,12 @@ int pdwt_clone(pdwt_handle src, pdwt_handle* out) {
     if (rc != PDWT_OK) { pdwt_destroy(p); return rc; }
     e = hipStreamSynchronize(src->stream);
     if (e == hipSuccess)
-        e = hipMemcpyAsync(p->arena, src->arena, (size_t)p->arena_elems * sizeof(float), hipMemcpyDeviceToDevice,
+        e = hipMemcpyAsync(p->arena, src->arena, (size_t)p->arena_elems * sizeof(real_t), hipMemcpyDeviceToDevice,
                            p->stream);
     if (e == hipSuccess && src->d_f2d) {
-        e = hipMalloc((void**)&p->d_f2d, (size_t)8 * kMaxTaps * kMaxTaps * sizeof(float));
+        e = hipMalloc((void**)&p->d_f2d, (size_t)8 * kMaxTaps * kMaxTaps * sizeof(real_t));
         if (e == hipSuccess)
-            e = hipMemcpyAsync(p->d_f2d, src->d_f2d, (size_t)8 * kMaxTaps * kMaxTaps * sizeof(float),
+            e = hipMemcpyAsync(p->d_f2d, src->d_f2d, (size_t)8 * kMaxTaps * kMaxTaps * sizeof(real_t),
                                hipMemcpyDeviceToDevice, p->stream);
         p->f2d_custom = src->f2d_custom;
     }
@@ -858,7 +858,7 @@ int pdwt_inverse(pdwt_handle h) {  // Wavelets::inverse, wt.cu:271-305
     return rc;
 }
 
-int pdwt_soft_threshold(pdwt_handle h, float beta, int do_app, int normalize) {  // wt.cu:308-315
+int pdwt_soft_threshold(pdwt_handle h, real_t beta, int do_app, int normalize) {  // wt.cu:308-315
     CHECK_HANDLE(h);
     DeviceGuard guard(h->device);
     if (h->state != PDWT_INVERSE && !do_app && beta >= 0.f && can_defer_soft(h)) {
@@ -872,19 +872,19 @@ int pdwt_soft_threshold(pdwt_handle h, float beta, int do_app, int normalize) { 
     return threshold_impl(h, EW_SOFT, beta, do_app, normalize, "soft_threshold");
 }
 
-int pdwt_hard_threshold(pdwt_handle h, float beta, int do_app, int normalize) {  // wt.cu:318-325
+int pdwt_hard_threshold(pdwt_handle h, real_t beta, int do_app, int normalize) {  // wt.cu:318-325
     CHECK_HANDLE(h);
     DeviceGuard guard(h->device);
     return threshold_impl(h, EW_HARD, beta, do_app, normalize, "hard_threshold");
 }
 
-int pdwt_proj_linf(pdwt_handle h, float beta, int do_app) {  // wt.cu:349-356
+int pdwt_proj_linf(pdwt_handle h, real_t beta, int do_app) {  // wt.cu:349-356
     CHECK_HANDLE(h);
     DeviceGuard guard(h->device);
     return threshold_impl(h, EW_LINF, beta, do_app, 0, "proj_linf");
 }
 
-int pdwt_group_soft_threshold(pdwt_handle h, float beta, int do_app, int normalize) {  // wt.cu:329-336
+int pdwt_group_soft_threshold(pdwt_handle h, real_t beta, int do_app, int normalize) {  // wt.cu:329-336
     CHECK_HANDLE(h);
     if (h->state == PDWT_INVERSE)
         return fail(PDWT_ERR_STATE, "cannot threshold coefficients, as they were modified by inverse()");
@@ -896,18 +896,18 @@ int pdwt_group_soft_threshold(pdwt_handle h, float beta, int do_app, int normali
     const int L = h->info.nlevels, B = h->batch;
     const int per = h->info.ndims == 2 ? 3 : 1;
     for (int l = 1; l <= L; l++) {  // common.cu:311-341
-        if (normalize > 0) beta = (float)(beta / 1.4142135623730951);
-        float* d0 = h->band(per * (l - 1) + 1);
-        float* d1 = per == 3 ? h->band(per * (l - 1) + 2) : nullptr;
-        float* d2 = per == 3 ? h->band(per * (l - 1) + 3) : nullptr;
-        float* ap = (do_app && l == L) ? h->band(0) : nullptr;
+        if (normalize > 0) beta = (real_t)(beta / 1.4142135623730951);
+        real_t* d0 = h->band(per * (l - 1) + 1);
+        real_t* d1 = per == 3 ? h->band(per * (l - 1) + 2) : nullptr;
+        real_t* d2 = per == 3 ? h->band(per * (l - 1) + 3) : nullptr;
+        real_t* ap = (do_app && l == L) ? h->band(0) : nullptr;
         Stamp st(h, "group_soft_threshold");
         HIP_TRY(launch_group_soft(d0, d1, d2, ap, h->bands[per * (l - 1) + 1].elems(B), beta, per, h->stream));
     }
     return PDWT_OK;
 }
 
-int pdwt_shrink(pdwt_handle h, float beta, int do_app) {  // wt.cu:340-347, common.cu:347-371
+int pdwt_shrink(pdwt_handle h, real_t beta, int do_app) {  // wt.cu:340-347, common.cu:347-371
     CHECK_HANDLE(h);
     if (h->state == PDWT_INVERSE)
         return fail(PDWT_ERR_STATE, "cannot threshold coefficients, as they were modified by inverse()");
@@ -944,25 +944,25 @@ static int norms_impl(pdwt_handle h, double out[2]) {
     return PDWT_OK;
 }
 
-int pdwt_norm1(pdwt_handle h, float* out) {  // wt.cu:396-416
+int pdwt_norm1(pdwt_handle h, real_t* out) {  // wt.cu:396-416
     CHECK_HANDLE(h);
     if (!out) return fail(PDWT_ERR_ARG, "pdwt_norm1: out is null");
     double r[2];
     int rc = norms_impl(h, r);
-    if (rc == PDWT_OK) *out = (float)r[0];
+    if (rc == PDWT_OK) *out = (real_t)r[0];
     return rc;
 }
 
-int pdwt_norm2sq(pdwt_handle h, float* out) {  // wt.cu:368-393
+int pdwt_norm2sq(pdwt_handle h, real_t* out) {  // wt.cu:368-393
     CHECK_HANDLE(h);
     if (!out) return fail(PDWT_ERR_ARG, "pdwt_norm2sq: out is null");
     double r[2];
     int rc = norms_impl(h, r);
-    if (rc == PDWT_OK) *out = (float)r[1];
+    if (rc == PDWT_OK) *out = (real_t)r[1];
     return rc;
 }
 
-int pdwt_add_wavelet(pdwt_handle dst, pdwt_handle src, float alpha) {  // wt.cu:622-655
+int pdwt_add_wavelet(pdwt_handle dst, pdwt_handle src, real_t alpha) {  // wt.cu:622-655
     CHECK_HANDLE(dst);
     CHECK_HANDLE(src);
     if (dst->info.nlevels != src->info.nlevels || strcasecmp(dst->wname, src->wname)) {
@@ -1003,11 +1003,11 @@ int pdwt_add_wavelet(pdwt_handle dst, pdwt_handle src, float alpha) {  // wt.cu:
     return PDWT_OK;
 }
 
-long long pdwt_get_image(pdwt_handle h, float* dst) {  // wt.cu:419-422
+long long pdwt_get_image(pdwt_handle h, real_t* dst) {  // wt.cu:419-422
     if (!h || !dst) return fail(PDWT_ERR_ARG, "pdwt_get_image: null argument");
     DeviceGuard guard(h->device);
     const long long n = (long long)h->batch * h->info.Nr * h->info.Nc;
-    HIP_TRY(hipMemcpyAsync(dst, h->image(), (size_t)n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(dst, h->image(), (size_t)n * sizeof(real_t), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     return n;
 }
@@ -1020,7 +1020,7 @@ long long pdwt_coeff_count(pdwt_handle h, int num, int* rows, int* cols) {
     return h->bands[num].elems(h->batch);
 }
 
-long long pdwt_get_coeff(pdwt_handle h, float* dst, int num) {  // wt.cu:473-506
+long long pdwt_get_coeff(pdwt_handle h, real_t* dst, int num) {  // wt.cu:473-506
     if (!h || !dst) return fail(PDWT_ERR_ARG, "pdwt_get_coeff: null argument");
     if (num < 0 || num >= (int)h->bands.size()) return fail(PDWT_ERR_ARG, "coefficient index %d out of range", num);
     if (h->state == PDWT_INVERSE) {
@@ -1033,24 +1033,24 @@ long long pdwt_get_coeff(pdwt_handle h, float* dst, int num) {  // wt.cu:473-506
         if (rc0 != PDWT_OK) return rc0;
     }
     const long long n = h->bands[num].elems(h->batch);
-    HIP_TRY(hipMemcpyAsync(dst, h->band(num), (size_t)n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(dst, h->band(num), (size_t)n * sizeof(real_t), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     return n;
 }
 
-int pdwt_set_image(pdwt_handle h, const float* src, int mem_is_on_device) {  // wt.cu:425-431
+int pdwt_set_image(pdwt_handle h, const real_t* src, int mem_is_on_device) {  // wt.cu:425-431
     CHECK_HANDLE(h);
     if (!src) return fail(PDWT_ERR_ARG, "pdwt_set_image: src is null");
     DeviceGuard guard(h->device);
     const long long n = (long long)h->batch * h->info.Nr * h->info.Nc;
-    HIP_TRY(hipMemcpyAsync(h->image(), src, (size_t)n * sizeof(float),
+    HIP_TRY(hipMemcpyAsync(h->image(), src, (size_t)n * sizeof(real_t),
                            mem_is_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, h->stream));
     if (!mem_is_on_device) HIP_TRY(hipStreamSynchronize(h->stream));  // the host buffer may be reused
     h->state = PDWT_INIT;
     return PDWT_OK;
 }
 
-int pdwt_set_coeff(pdwt_handle h, const float* src, int num, int mem_is_on_device) {  // wt.cu:435-466
+int pdwt_set_coeff(pdwt_handle h, const real_t* src, int num, int mem_is_on_device) {  // wt.cu:435-466
     CHECK_HANDLE(h);
     if (!src) return fail(PDWT_ERR_ARG, "pdwt_set_coeff: src is null");
     if (num < 0 || num >= (int)h->bands.size()) return fail(PDWT_ERR_ARG, "coefficient index %d out of range", num);
@@ -1060,7 +1060,7 @@ int pdwt_set_coeff(pdwt_handle h, const float* src, int num, int mem_is_on_devic
         if (rc0 != PDWT_OK) return rc0;
     }
     const long long n = h->bands[num].elems(h->batch);
-    HIP_TRY(hipMemcpyAsync(h->band(num), src, (size_t)n * sizeof(float),
+    HIP_TRY(hipMemcpyAsync(h->band(num), src, (size_t)n * sizeof(real_t),
                            mem_is_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, h->stream));
     if (!mem_is_on_device) HIP_TRY(hipStreamSynchronize(h->stream));
     return PDWT_OK;
@@ -1077,8 +1077,8 @@ intptr_t pdwt_coeff_ptr(pdwt_handle h, int num) {
     return (intptr_t)h->band(num);
 }
 
-int pdwt_set_filters_forward(pdwt_handle h, const char* name, unsigned int len, const float* f1, const float* f2,
-                             const float* f3, const float* f4) {  // wt.cu:558-578
+int pdwt_set_filters_forward(pdwt_handle h, const char* name, unsigned int len, const real_t* f1, const real_t* f2,
+                             const real_t* f3, const real_t* f4) {  // wt.cu:558-578
     CHECK_HANDLE(h);
     if (len > PDWT_MAX_FILTER_WIDTH || len < 1)
         return fail(PDWT_ERR_FILTER_LEN, "set_filters_forward(): filter length (%u) exceeds the maximum size (%d)", len,
@@ -1087,15 +1087,15 @@ int pdwt_set_filters_forward(pdwt_handle h, const char* name, unsigned int len, 
     DeviceGuard guard(h->device);
     if (h->do_separable) {
         memset(&h->dec, 0, sizeof(h->dec));
-        memcpy(h->dec.lo, f1, len * sizeof(float));
-        memcpy(h->dec.hi, f2, len * sizeof(float));
+        memcpy(h->dec.lo, f1, len * sizeof(real_t));
+        memcpy(h->dec.hi, f2, len * sizeof(real_t));
     } else {
         if (!f3 || !f4)
             return fail(PDWT_ERR_ARG, "set_filters_forward(): expected argument 4 and 5 for non-separable filtering");
-        if (!h->d_f2d) HIP_TRY(hipMalloc((void**)&h->d_f2d, (size_t)8 * kMaxTaps * kMaxTaps * sizeof(float)));
-        const float* f[4] = {f1, f2, f3, f4};
+        if (!h->d_f2d) HIP_TRY(hipMalloc((void**)&h->d_f2d, (size_t)8 * kMaxTaps * kMaxTaps * sizeof(real_t)));
+        const real_t* f[4] = {f1, f2, f3, f4};
         for (int k = 0; k < 4; k++)
-            HIP_TRY(hipMemcpyAsync(h->d_f2d + (size_t)k * len * len, f[k], (size_t)len * len * sizeof(float),
+            HIP_TRY(hipMemcpyAsync(h->d_f2d + (size_t)k * len * len, f[k], (size_t)len * len * sizeof(real_t),
                                    hipMemcpyHostToDevice, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
         h->f2d_custom = true;
@@ -1105,23 +1105,23 @@ int pdwt_set_filters_forward(pdwt_handle h, const char* name, unsigned int len, 
     return PDWT_OK;
 }
 
-int pdwt_set_filters_inverse(pdwt_handle h, const float* f1, const float* f2, const float* f3,
-                             const float* f4) {  // wt.cu:583-600
+int pdwt_set_filters_inverse(pdwt_handle h, const real_t* f1, const real_t* f2, const real_t* f3,
+                             const real_t* f4) {  // wt.cu:583-600
     CHECK_HANDLE(h);
     if (!f1 || !f2) return fail(PDWT_ERR_ARG, "set_filters_inverse(): filter1/filter2 are required");
     const unsigned len = (unsigned)h->info.hlen;
     DeviceGuard guard(h->device);
     if (h->do_separable) {
         memset(&h->rec, 0, sizeof(h->rec));
-        memcpy(h->rec.lo, f1, len * sizeof(float));
-        memcpy(h->rec.hi, f2, len * sizeof(float));
+        memcpy(h->rec.lo, f1, len * sizeof(real_t));
+        memcpy(h->rec.hi, f2, len * sizeof(real_t));
     } else {
         if (!f3 || !f4)
             return fail(PDWT_ERR_ARG, "set_filters_inverse(): expected argument 4 and 5 for non-separable filtering");
-        if (!h->d_f2d) HIP_TRY(hipMalloc((void**)&h->d_f2d, (size_t)8 * kMaxTaps * kMaxTaps * sizeof(float)));
-        const float* f[4] = {f1, f2, f3, f4};
+        if (!h->d_f2d) HIP_TRY(hipMalloc((void**)&h->d_f2d, (size_t)8 * kMaxTaps * kMaxTaps * sizeof(real_t)));
+        const real_t* f[4] = {f1, f2, f3, f4};
         for (int k = 0; k < 4; k++)
-            HIP_TRY(hipMemcpyAsync(h->d_f2d + (size_t)(4 + k) * len * len, f[k], (size_t)len * len * sizeof(float),
+            HIP_TRY(hipMemcpyAsync(h->d_f2d + (size_t)(4 + k) * len * len, f[k], (size_t)len * len * sizeof(real_t),
                                    hipMemcpyHostToDevice, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
         h->f2d_custom = true;
@@ -1168,16 +1168,16 @@ const char* pdwt_wavelet_name(int index) {
     return w ? w->name : nullptr;
 }
 
-int pdwt_wavelet_filters(const char* wname, float* banks, int capacity) {
+int pdwt_wavelet_filters(const char* wname, real_t* banks, int capacity) {
     const WaveletEntry* w = find_wavelet(wname);
     if (!w) return fail(PDWT_ERR_WAVELET, "unknown wavelet name %s", wname ? wname : "(null)");
     if (banks) {
         if (capacity < 4 * w->hlen) return fail(PDWT_ERR_ARG, "pdwt_wavelet_filters: capacity %d < %d", capacity, 4 * w->hlen);
         for (int i = 0; i < w->hlen; i++) {
-            banks[i] = (float)w->dec_lo[i];
-            banks[w->hlen + i] = (float)w->dec_hi[i];
-            banks[2 * w->hlen + i] = (float)w->rec_lo[i];
-            banks[3 * w->hlen + i] = (float)w->rec_hi[i];
+            banks[i] = (real_t)w->dec_lo[i];
+            banks[w->hlen + i] = (real_t)w->dec_hi[i];
+            banks[2 * w->hlen + i] = (real_t)w->rec_lo[i];
+            banks[3 * w->hlen + i] = (real_t)w->rec_hi[i];
         }
     }
     return w->hlen;
@@ -1203,7 +1203,7 @@ int pdwt_set_stream(pdwt_handle h, void* hip_stream) {
 void* pdwt_get_stream(pdwt_handle h) { return h ? (void*)h->stream : nullptr; }
 int pdwt_device(pdwt_handle h) { return h ? h->device : -1; }
 
-int pdwt_fill_image_hash(pdwt_handle h, uint32_t seed, float scale, long long index_offset) {
+int pdwt_fill_image_hash(pdwt_handle h, uint32_t seed, real_t scale, long long index_offset) {
     CHECK_HANDLE(h);
     DeviceGuard guard(h->device);
     Stamp st(h, "fill_hash");

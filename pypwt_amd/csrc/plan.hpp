@@ -52,7 +52,7 @@ struct pdwt_plan {
     char wname[128] = {0};
     int shift_r = 0, shift_c = 0;  // current cycle-spinning shift (wt.h:27-28)
 
-    float* arena = nullptr;
+    real_t* arena = nullptr;
     long long arena_elems = 0;
     std::vector<pdwt::Band> bands;      // coefficient bands, index = `num`
     long long coeff_elems = 0;          // size of the (padded) coefficient region
@@ -60,24 +60,24 @@ struct pdwt_plan {
     long long image_off = 0;
     std::vector<int> lr, lc;  // per-level image dims, lr[0] = Nr ... lr[L]
 
-    float* tmp = nullptr;  // lazily allocated scratch (circshift, SWT fallback)
+    real_t* tmp = nullptr;  // lazily allocated scratch (circshift, SWT fallback)
     long long tmp_elems = 0;
     double* d_red = nullptr;  // two fp64 accumulators for the norms
 
     pdwt::FilterBank dec{}, rec{};
-    float* d_f2d = nullptr;  // non-separable banks: fwd LL,LH,HL,HH then inv, each hlen*hlen
+    real_t* d_f2d = nullptr;  // non-separable banks: fwd LL,LH,HL,HH then inv, each hlen*hlen
     bool f2d_custom = false;
 
     // A soft_threshold that has been requested but not yet applied: the fused SWT inverse applies
     // it while it loads the detail bands (saves one read+write sweep of 3L full-size planes); any
     // other consumer of the coefficients materialises it first (plan.cpp: materialize_pending).
     bool pend_soft = false;
-    float pend_beta = 0.f;
+    real_t pend_beta = 0.f;
     int pend_normalize = 0;
 
     bool timing = false;
     std::vector<pdwt::KernelStamp> stamps;
 
-    float* image() const { return arena + image_off; }
-    float* band(int num) const { return arena + bands[num].off; }
+    real_t* image() const { return arena + image_off; }
+    real_t* band(int num) const { return arena + bands[num].off; }
 };

@@ -36,9 +36,9 @@ constexpr int swt2d_lds_floats(int hlen) {
 }
 
 #define PDWT_STAGE_TAPS()                                   \
-    float* sTaps = smem;                                    \
-    const float* lo = a.fb.lo;                              \
-    const float* hi = a.fb.hi;                              \
+    real_t* sTaps = smem;                                    \
+    const real_t* lo = a.fb.lo;                              \
+    const real_t* hi = a.fb.hi;                              \
     if (HLEN == 0) {                                        \
         PDWT_FOR_THREADS(tid, NT) {                         \
             if (tid < kMaxTaps) {                           \
@@ -53,7 +53,7 @@ constexpr int swt2d_lds_floats(int hlen) {
 
 // by enumerates (row tile, phase): ph = by % f, it = by / f
 template <int HLEN, int TX, int TY, int NT>
-PDWT_DEVICE void swt2_fwd_tile(const Swt2DArgs& a, int bx, int by, int bz, float* smem) {
+PDWT_DEVICE void swt2_fwd_tile(const Swt2DArgs& a, int bx, int by, int bz, real_t* smem) {
     static_assert(NT % TX == 0 && TY % (NT / TX) == 0, "tile/thread shape");
     constexpr int NG = NT / TX;
     constexpr int R = TY / NG;
@@ -66,23 +66,23 @@ PDWT_DEVICE void swt2_fwd_tile(const Swt2DArgs& a, int bx, int by, int bz, float
     const int RY = TY + hlen - 1;
 
     PDWT_STAGE_TAPS();
-    float* tL = smem + 2 * kMaxTaps;
-    float* tH = tL + RY * TX;
+    real_t* tL = smem + 2 * kMaxTaps;
+    real_t* tH = tL + RY * TX;
 
-    const float* PDWT_RESTRICT in = a.in + (long long)bz * a.bstride;
+    const real_t* PDWT_RESTRICT in = a.in + (long long)bz * a.bstride;
 
     // ---- phase 1: dilated row analysis straight from global -> tL, tH (RY x TX)
     PDWT_FOR_THREADS(tid, NT) {
         const int k = tid % TX;
         const int x = bx * TX + k;
         for (int r = tid / TX; r < RY; r += NG) {
-            float aL = 0.f, aH = 0.f;
+            real_t aL = 0.f, aH = 0.f;
             if (x < a.Nc) {
                 const int i = wrap_periodic(it * TY - c + r, M);
-                const float* row = in + (long long)(ph + f * i) * a.Nc;
+                const real_t* row = in + (long long)(ph + f * i) * a.Nc;
 #pragma unroll
                 for (int j = 0; j < (HLEN > 0 ? HLEN : hlen); ++j) {
-                    const float v = row[wrap_periodic(x + (j - c) * f, a.Nc)];
+                    const real_t v = row[wrap_periodic(x + (j - c) * f, a.Nc)];
                     aL = pdwt_fma(v, lo[hlen - 1 - j], aL);
                     aH = pdwt_fma(v, hi[hlen - 1 - j], aH);
                 }
@@ -100,12 +100,12 @@ PDWT_DEVICE void swt2_fwd_tile(const Swt2DArgs& a, int bx, int by, int bz, float
         const int x = bx * TX + k;
         const long long boff = (long long)bz * a.bstride;
         for (int i = 0; i < R; ++i) {
-            float rA = 0.f, rH = 0.f, rV = 0.f, rD = 0.f;
+            real_t rA = 0.f, rH = 0.f, rV = 0.f, rD = 0.f;
 #pragma unroll
             for (int j = 0; j < (HLEN > 0 ? HLEN : hlen); ++j) {
-                const float l = tL[(ty0 + i + j) * TX + k];
-                const float h = tH[(ty0 + i + j) * TX + k];
-                const float tl = lo[hlen - 1 - j], th = hi[hlen - 1 - j];
+                const real_t l = tL[(ty0 + i + j) * TX + k];
+                const real_t h = tH[(ty0 + i + j) * TX + k];
+                const real_t tl = lo[hlen - 1 - j], th = hi[hlen - 1 - j];
                 rA = pdwt_fma(l, tl, rA);
                 rH = pdwt_fma(l, th, rH);
                 rV = pdwt_fma(h, tl, rV);
@@ -124,7 +124,7 @@ PDWT_DEVICE void swt2_fwd_tile(const Swt2DArgs& a, int bx, int by, int bz, float
 }
 
 template <int HLEN, int TX, int TY, int NT>
-PDWT_DEVICE void swt2_inv_tile(const Swt2DArgs& a, int bx, int by, int bz, float* smem) {
+PDWT_DEVICE void swt2_inv_tile(const Swt2DArgs& a, int bx, int by, int bz, real_t* smem) {
     static_assert(NT % TX == 0 && TY % (NT / TX) == 0, "tile/thread shape");
     constexpr int NG = NT / TX;
     constexpr int R = TY / NG;
@@ -137,8 +137,8 @@ PDWT_DEVICE void swt2_inv_tile(const Swt2DArgs& a, int bx, int by, int bz, float
     const int RY = TY + hlen - 1;
 
     PDWT_STAGE_TAPS();
-    float* u1 = smem + 2 * kMaxTaps;
-    float* u2 = u1 + RY * TX;
+    real_t* u1 = smem + 2 * kMaxTaps;
+    real_t* u2 = u1 + RY * TX;
 
     const long long boff = (long long)bz * a.bstride;
 
@@ -147,14 +147,14 @@ PDWT_DEVICE void swt2_inv_tile(const Swt2DArgs& a, int bx, int by, int bz, float
         const int k = tid % TX;
         const int x = bx * TX + k;
         for (int r = tid / TX; r < RY; r += NG) {
-            float r1 = 0.f, r2 = 0.f;
+            real_t r1 = 0.f, r2 = 0.f;
             if (x < a.Nc) {
                 const int i = wrap_periodic(it * TY - c + r, M);
                 const long long ro = boff + (long long)(ph + f * i) * a.Nc;
 #pragma unroll
                 for (int j = 0; j < (HLEN > 0 ? HLEN : hlen); ++j) {
                     const long long o = ro + wrap_periodic(x + (j - c) * f, a.Nc);
-                    const float tl = lo[hlen - 1 - j], th = hi[hlen - 1 - j];
+                    const real_t tl = lo[hlen - 1 - j], th = hi[hlen - 1 - j];
                     // a pending soft_threshold of the plan is applied here, on the fly, to the detail
                     // bands (never to A): the thresholded coefficients are not written back
                     r1 = pdwt_fma(a.A[o], tl, r1);
@@ -175,7 +175,7 @@ PDWT_DEVICE void swt2_inv_tile(const Swt2DArgs& a, int bx, int by, int bz, float
         const int ty0 = (tid / TX) * R;
         const int x = bx * TX + k;
         for (int i = 0; i < R; ++i) {
-            float r = 0.f;
+            real_t r = 0.f;
 #pragma unroll
             for (int j = 0; j < (HLEN > 0 ? HLEN : hlen); ++j) {
                 r = pdwt_fma(u1[(ty0 + i + j) * TX + k], lo[hlen - 1 - j], r);
@@ -194,7 +194,7 @@ PDWT_DEVICE void swt2_inv_tile(const Swt2DArgs& a, int bx, int by, int bz, float
 // ---------------------------------------------------------------------------
 
 template <int NT>
-PDWT_DEVICE void swt_pass_fwd_tile(const SwtPassArgs& a, long long block, float* /*smem*/) {
+PDWT_DEVICE void swt_pass_fwd_tile(const SwtPassArgs& a, long long block, real_t* /*smem*/) {
     PDWT_FOR_THREADS(tid, NT) {
         const long long idx = block * NT + tid;
         const long long total = (long long)a.Nr * a.Nc;
@@ -202,12 +202,12 @@ PDWT_DEVICE void swt_pass_fwd_tile(const SwtPassArgs& a, long long block, float*
             const int y = (int)(idx / a.Nc);
             const int x = (int)(idx - (long long)y * a.Nc);
             const int c = analysis_centre(a.hlen);
-            float aL = 0.f, aH = 0.f;
+            real_t aL = 0.f, aH = 0.f;
             for (int j = 0; j < a.hlen; ++j) {
                 long long src;
                 if (a.along_y) src = (long long)wrap_periodic(y + (j - c) * a.f, a.Nr) * a.Nc + x;
                 else src = (long long)y * a.Nc + wrap_periodic(x + (j - c) * a.f, a.Nc);
-                const float v = a.in0[src];
+                const real_t v = a.in0[src];
                 aL = pdwt_fma(v, a.fb.lo[a.hlen - 1 - j], aL);
                 aH = pdwt_fma(v, a.fb.hi[a.hlen - 1 - j], aH);
             }
@@ -218,7 +218,7 @@ PDWT_DEVICE void swt_pass_fwd_tile(const SwtPassArgs& a, long long block, float*
 }
 
 template <int NT>
-PDWT_DEVICE void swt_pass_inv_tile(const SwtPassArgs& a, long long block, float* /*smem*/) {
+PDWT_DEVICE void swt_pass_inv_tile(const SwtPassArgs& a, long long block, real_t* /*smem*/) {
     PDWT_FOR_THREADS(tid, NT) {
         const long long idx = block * NT + tid;
         const long long total = (long long)a.Nr * a.Nc;
@@ -226,7 +226,7 @@ PDWT_DEVICE void swt_pass_inv_tile(const SwtPassArgs& a, long long block, float*
             const int y = (int)(idx / a.Nc);
             const int x = (int)(idx - (long long)y * a.Nc);
             const int c = a.hlen / 2;
-            float r = 0.f;
+            real_t r = 0.f;
             for (int j = 0; j < a.hlen; ++j) {
                 long long src;
                 if (a.along_y) src = (long long)wrap_periodic(y + (j - c) * a.f, a.Nr) * a.Nc + x;
@@ -242,12 +242,12 @@ PDWT_DEVICE void swt_pass_inv_tile(const SwtPassArgs& a, long long block, float*
 #ifndef PDWT_CPU_EMU
 template <int HLEN, int TX, int TY, int NT>
 __global__ void __launch_bounds__(NT) swt2_fwd_kernel(const Swt2DArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float pdwt_smem[];
+    extern __shared__ __attribute__((aligned(16))) real_t pdwt_smem[];
     swt2_fwd_tile<HLEN, TX, TY, NT>(a, blockIdx.x, blockIdx.y, blockIdx.z, pdwt_smem);
 }
 template <int HLEN, int TX, int TY, int NT>
 __global__ void __launch_bounds__(NT) swt2_inv_kernel(const Swt2DArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float pdwt_smem[];
+    extern __shared__ __attribute__((aligned(16))) real_t pdwt_smem[];
     swt2_inv_tile<HLEN, TX, TY, NT>(a, blockIdx.x, blockIdx.y, blockIdx.z, pdwt_smem);
 }
 template <int NT>

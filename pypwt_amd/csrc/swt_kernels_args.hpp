@@ -6,10 +6,10 @@
 namespace pdwt {
 
 struct SwtPassArgs {
-    const float* in0;  // forward: input ; inverse: approximation-like operand (rlo)
-    const float* in1;  // inverse: detail-like operand (rhi); forward: unused
-    float* out0;       // forward: low output ; inverse: output
-    float* out1;       // forward: high output
+    const real_t* in0;  // forward: input ; inverse: approximation-like operand (rlo)
+    const real_t* in1;  // inverse: detail-like operand (rhi); forward: unused
+    real_t* out0;       // forward: low output ; inverse: output
+    real_t* out1;       // forward: high output
     int Nr, Nc, f, along_y;
     int hlen;
     FilterBank fb;

@@ -16,15 +16,11 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import PdwtInfo, check, f32p, handle_t
+from ._lib import PdwtInfo, check, handle_t
 
 
 def _ptr(a):
     return a.ctypes.data_as(C.c_void_p)
-
-
-def _fptr(a):
-    return a.ctypes.data_as(f32p)
 
 
 class Wavelets(object):
@@ -48,9 +44,20 @@ class Wavelets(object):
         2 (default) or 1; a 2D array with ndim=1 is a batched 1D transform
     """
 
+    # storage / arithmetic type: float32 like the reference's Python class; the Wavelets64 subclass below
+    # binds the fp64 build of the library (the reference's DOUBLEPRECISION compile-time variant)
+    _dtype = np.float32
+    _variant = "f32"
+
+    def _check(self, rc, what=""):
+        return check(rc, what, self._lib)
+
+    def _fptr(self, a):
+        return a.ctypes.data_as(C.POINTER(self._lib.pdwt_real))
+
     def __init__(self, img, wname, levels, do_separable=1, do_cycle_spinning=0, do_swt=0, ndim=2, copy=None):
         self._h = None
-        self._lib = _lib.load()
+        self._lib = _lib.load(self._variant)
         img = self._checkarray(np.asarray(img))
 
         ndim = min(int(ndim), 2)  # src/pypwt.pyx:145
@@ -73,31 +80,31 @@ class Wavelets(object):
         self.ndim = img.ndim
 
         h = handle_t()
-        rc = self._lib.pdwt_create(_fptr(img), self.Nr, self.Nc, self._wname, self.levels, 1, self.do_separable,
+        rc = self._lib.pdwt_create(self._fptr(img), self.Nr, self.Nc, self._wname, self.levels, 1, self.do_separable,
                                    self.do_cycle_spinning, self.do_swt, ndim, C.byref(h))
-        check(rc, "Wavelets()")
+        self._check(rc, "Wavelets()")
         self._h = h
         # read back what the library clamped (src/pypwt.pyx:181-183)
         info, sep, cyc, st, b = PdwtInfo(), C.c_int(), C.c_int(), C.c_int(), C.c_int()
-        check(self._lib.pdwt_get_info(self._h, C.byref(info), C.byref(sep), C.byref(cyc), C.byref(st), C.byref(b)))
+        self._check(self._lib.pdwt_get_info(self._h, C.byref(info), C.byref(sep), C.byref(cyc), C.byref(st), C.byref(b)))
         self.levels = int(info.nlevels)
         self.hlen = int(info.hlen)
         self.do_separable = int(sep.value)
         self.sizes = self._compute_sizes()
 
         # host-side coefficient list (src/pypwt.pyx:187-205)
-        self._coeffs = [np.zeros(self.sizes[-1], dtype=np.float32)]
+        self._coeffs = [np.zeros(self.sizes[-1], dtype=self._dtype)]
         for i in range(self.levels):
             if (self.ndim < 2) or self.batched1d:
-                self._coeffs.append(np.zeros(self.sizes[i], dtype=np.float32))
+                self._coeffs.append(np.zeros(self.sizes[i], dtype=self._dtype))
             else:
-                self._coeffs.append([np.zeros(self.sizes[i], dtype=np.float32) for _ in range(3)])
+                self._coeffs.append([np.zeros(self.sizes[i], dtype=self._dtype) for _ in range(3)])
 
     # -- reference: info / __repr__ / __str__ (src/pypwt.pyx:209-221)
     def info(self):
         """Print some information on the current ``Wavelets`` instance."""
         buf = C.create_string_buffer(2048)
-        check(self._lib.pdwt_info_string(self._h, buf, len(buf)))
+        self._check(self._lib.pdwt_info_string(self._h, buf, len(buf)))
         print(buf.value.decode("utf-8", "replace"), end="")
 
     def __repr__(self):
@@ -108,11 +115,11 @@ class Wavelets(object):
         self.info()
         return ""
 
-    @staticmethod
-    def _checkarray(arr, shp=None):  # src/pypwt.pyx:224-235
+    @classmethod
+    def _checkarray(cls, arr, shp=None):  # src/pypwt.pyx:224-235
         res = arr
-        if arr.dtype != np.float32 or not arr.flags["C_CONTIGUOUS"]:
-            res = np.ascontiguousarray(arr, dtype=np.float32)
+        if arr.dtype != cls._dtype or not arr.flags["C_CONTIGUOUS"]:
+            res = np.ascontiguousarray(arr, dtype=cls._dtype)
         if shp is not None:
             if arr.ndim != len(shp):
                 raise ValueError("Invalid number of dimensions (expected %d, got %d)" % (len(shp), arr.ndim))
@@ -174,7 +181,7 @@ class Wavelets(object):
 
     @property
     def image(self):
-        res = np.zeros((self.Nr, self.Nc), dtype=np.float32)
+        res = np.zeros((self.Nr, self.Nc), dtype=self._dtype)
         numc = self._lib.pdwt_get_image(self._h, _ptr(res))
         if numc != res.size:
             raise RuntimeError("Wavelets.image(): something went wrong when retrieving image, expected %d coeffs, "
@@ -184,14 +191,14 @@ class Wavelets(object):
     def set_image(self, img):
         """Replace the image (does not update the coefficients; run forward())."""
         img = self._checkarray(np.asarray(img), (self.Nr, self.Nc))
-        check(self._lib.pdwt_set_image(self._h, _ptr(img), 0))
+        self._check(self._lib.pdwt_set_image(self._h, _ptr(img), 0))
 
     def forward(self, img=None):
         """Forward wavelet transform of ``img`` if given, else of the current image."""
         if img is not None:
             img = self._checkarray(np.asarray(img), self.shape)
-            check(self._lib.pdwt_set_image(self._h, _ptr(img), 0))
-        check(self._lib.pdwt_forward(self._h), "forward")
+            self._check(self._lib.pdwt_set_image(self._h, _ptr(img), 0))
+        self._check(self._lib.pdwt_forward(self._h), "forward")
 
     def inverse(self):
         """
@@ -204,14 +211,14 @@ class Wavelets(object):
         if rc == _lib.ERR_STATE:  # reference: puts() a warning and returns (wt.cu:272-279)
             print("Warning: " + _lib.last_error())
             return
-        check(rc, "inverse")
+        self._check(rc, "inverse")
 
     def _threshold(self, fn, beta, do_threshold_appcoeffs, normalize):
         rc = fn(self._h, float(beta), int(do_threshold_appcoeffs), int(normalize))
         if rc == _lib.ERR_STATE:  # wt.cu:309-312
             print("Warning: Wavelets(): " + _lib.last_error())
             return
-        check(rc)
+        self._check(rc)
 
     def soft_threshold(self, beta, do_threshold_appcoeffs=0, normalize=0):
         """ST(x, t) = (|x| - t)_+ . sign(x) on the detail (optionally approximation) coefficients;
@@ -232,7 +239,7 @@ class Wavelets(object):
         if rc == _lib.ERR_STATE:
             print("Warning: Wavelets(): " + _lib.last_error())
             return
-        check(rc)
+        self._check(rc)
 
     def proj_linf(self, beta, do_threshold_appcoeffs=1):
         """Projection onto the L-infinity ball of radius beta (C++-only in the reference, wt.cu:349-356)."""
@@ -240,25 +247,25 @@ class Wavelets(object):
         if rc == _lib.ERR_STATE:
             print("Warning: Wavelets(): " + _lib.last_error())
             return
-        check(rc)
+        self._check(rc)
 
     def norm1(self):
         """L1 norm of all the wavelet coefficients."""
-        out = C.c_float()
-        check(self._lib.pdwt_norm1(self._h, C.byref(out)))
+        out = self._lib.pdwt_real()
+        self._check(self._lib.pdwt_norm1(self._h, C.byref(out)))
         return out.value
 
     def norm2sq(self):
         """Squared L2 norm of all the wavelet coefficients."""
-        out = C.c_float()
-        check(self._lib.pdwt_norm2sq(self._h, C.byref(out)))
+        out = self._lib.pdwt_real()
+        self._check(self._lib.pdwt_norm2sq(self._h, C.byref(out)))
         return out.value
 
     def add_wavelet(self, W, alpha=1.0):
         """coefficients += alpha * W.coefficients"""
         rc = self._lib.pdwt_add_wavelet(self._h, W._h, float(alpha))
         if rc != 0:  # the reference prints the reason and carries on (wt.cu:625-650)
-            print(("WARNING: " if rc > 0 else "ERROR: ") + _lib.last_error())
+            print(("WARNING: " if rc > 0 else "ERROR: ") + _lib.last_error(self._lib))
         return rc
 
     def set_coeff(self, coeff, num, check=False):
@@ -271,10 +278,10 @@ class Wavelets(object):
                                  % (str(dcoeff.shape), str(coeff.shape)))
         rows, cols = C.c_int(), C.c_int()
         n = self._lib.pdwt_coeff_count(self._h, int(num), C.byref(rows), C.byref(cols))
-        _lib.check(int(n))
+        self._check(int(n))
         if coeff.size != n:  # the reference copies blindly (wt.cu:435 "There are no memory check !")
             raise ValueError("set_coeff: expected %d elements for coefficient %d, got %d" % (n, num, coeff.size))
-        _lib.check(self._lib.pdwt_set_coeff(self._h, _ptr(coeff), int(num), 0))
+        self._check(self._lib.pdwt_set_coeff(self._h, _ptr(coeff), int(num), 0))
 
     def set_wavelets_filters(self, filter_name, lowpass, highpass, i_lowpass, i_highpass, LH=None, HL=None,
                              i_LH=None, i_HL=None):
@@ -289,17 +296,17 @@ class Wavelets(object):
         f = [None if a is None else self._checkarray(np.asarray(a)) for a in arrs]
         name = filter_name.encode("ASCII")
         flen = int(len(lowpass))
-        null = C.cast(None, f32p)
+        null = C.cast(None, C.POINTER(self._lib.pdwt_real))
         if self.do_separable:
-            check(self._lib.pdwt_set_filters_forward(self._h, name, flen, _fptr(f[0]), _fptr(f[1]), null, null))
-            check(self._lib.pdwt_set_filters_inverse(self._h, _fptr(f[2]), _fptr(f[3]), null, null))
+            self._check(self._lib.pdwt_set_filters_forward(self._h, name, flen, self._fptr(f[0]), self._fptr(f[1]), null, null))
+            self._check(self._lib.pdwt_set_filters_inverse(self._h, self._fptr(f[2]), self._fptr(f[3]), null, null))
         else:
             if LH is None or HL is None or i_LH is None or i_HL is None:
                 raise ValueError("Expected LH and HL filters for non-separable transform")
             # argument order of the C side: (LL, LH, HL, HH)  (src/pypwt.pyx:557-575)
-            check(self._lib.pdwt_set_filters_forward(self._h, name, flen, _fptr(f[0]), _fptr(f[4]), _fptr(f[5]),
-                                                     _fptr(f[1])))
-            check(self._lib.pdwt_set_filters_inverse(self._h, _fptr(f[2]), _fptr(f[6]), _fptr(f[7]), _fptr(f[3])))
+            self._check(self._lib.pdwt_set_filters_forward(self._h, name, flen, self._fptr(f[0]), self._fptr(f[4]), self._fptr(f[5]),
+                                                     self._fptr(f[1])))
+            self._check(self._lib.pdwt_set_filters_inverse(self._h, self._fptr(f[2]), self._fptr(f[6]), self._fptr(f[7]), self._fptr(f[3])))
         self.hlen = flen
         self.wname = filter_name
 
@@ -313,7 +320,7 @@ class Wavelets(object):
 
     def synchronize(self):
         """Wait for every kernel enqueued by this instance (new; the reference syncs implicitly)."""
-        check(self._lib.pdwt_synchronize(self._h))
+        self._check(self._lib.pdwt_synchronize(self._h))
 
     def cleanup(self):  # should not be called manually
         if getattr(self, "_h", None):
@@ -330,6 +337,16 @@ class Wavelets(object):
     def version(cls):
         """Version of the pypwt API this class is a drop-in for."""
         return "1.0.3"
+
+
+class Wavelets64(Wavelets):
+    """`Wavelets` over the fp64 build of the library (libpypwt_amd_f64.so): float64 images and
+    coefficients, same methods.  The reference offers double precision only as a compile-time variant of
+    its C++ library (pdwt/Makefile DOUBLEPRECISION, pdwt/src/filters.h:16-30); its Python class is
+    float32-only.  Every level runs through the generic kernels (the packed-fp32 fast paths do not
+    exist in this build)."""
+    _dtype = np.float64
+    _variant = "f64"
 
 
 class BatchedWavelets(object):

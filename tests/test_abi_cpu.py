@@ -32,6 +32,26 @@ def test_library_exports_every_header_symbol(lib):
         assert hasattr(lib, n), "libpypwt_amd.so does not export %s" % n
 
 
+def test_fp64_library_exports_the_same_symbols_with_double_taps():
+    """libpypwt_amd_f64.so = the same sources with -DPDWT_DOUBLE (pdwt_real = double): every header
+    symbol is there and the built-in taps keep their float64 precision."""
+    from pypwt_amd.build import build_library
+    build_library(verbose=False, variant="f64")
+    from pypwt_amd import _lib
+    from oracle import oracle
+    lib64 = _lib.load("f64")
+    for n in header_functions():
+        assert hasattr(lib64, n), "libpypwt_amd_f64.so does not export %s" % n
+    t = oracle.filter_table()
+    buf = (C.c_double * 160)()
+    for w in ("db4", "sym8", "bior6.8", "coif5"):
+        hlen = lib64.pdwt_wavelet_filters(w.encode(), buf, 160)
+        e = t["filters"][w]
+        got = np.frombuffer(buf, dtype=np.float64, count=4 * hlen).reshape(4, hlen)
+        want = np.array([e["dec_lo"], e["dec_hi"], e["rec_lo"], e["rec_hi"]], dtype=np.float64)
+        assert np.array_equal(got, want), w
+
+
 def test_python_binding_covers_the_header(lib):
     from pypwt_amd import _lib
     assert sorted(_lib.SIGNATURES) == header_functions()

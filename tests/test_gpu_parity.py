@@ -330,3 +330,68 @@ def test_strip_paths_match_oracle(wname, monkeypatch):
     w2.inverse()
     assert np.abs(rec - x).max() <= 2e-3
     assert np.abs(rec - w2.image).max() <= 1e-3
+
+
+# ---------------------------------------------------------------------------------------------
+# fp64 build (libpypwt_amd_f64.so, Wavelets64): the reference's DOUBLEPRECISION variant
+# ---------------------------------------------------------------------------------------------
+F64_CASES = [
+    ("db4", (96, 80), 3, 2, 0), ("haar", (64, 64), 3, 2, 0), ("sym8", (61, 59), 2, 2, 0), ("bior3.1", (64, 48), 2, 2, 0),
+    ("coif5", (128, 96), 1, 2, 0), ("db20", (160, 160), 2, 2, 0), ("rbio6.8", (40, 200), 2, 2, 0),
+    ("sym8", (4, 4096), 5, 1, 0), ("db3", (1, 1000), 3, 1, 0),
+    ("haar", (64, 64), 3, 2, 1), ("db2", (48, 80), 2, 2, 1), ("sym4", (3, 256), 3, 1, 1),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("wname,shape,levels,ndim,swt", F64_CASES)
+def test_fp64_build_matches_the_fp64_oracle(wname, shape, levels, ndim, swt):
+    from pypwt_amd import Wavelets64
+    x = oracle.hash_input(shape, 777, scale=255.0).astype(np.float64)
+    x += 1e-9 * np.arange(x.size).reshape(x.shape)  # something fp32 cannot hold
+    xin = x[0] if (ndim == 1 and shape[0] == 1) else x
+    w = Wavelets64(xin, wname, levels, do_swt=swt, ndim=ndim)
+    w.forward()
+    ref = oracle.forward(x, wname, w.levels, ndim=ndim, do_swt=swt, double="full")
+    got = [w.coeffs[0]] + [b for lvl in w.coeffs[1:] for b in (lvl if isinstance(lvl, list) else [lvl])]
+    assert len(got) == len(ref)
+    for k, (g, r) in enumerate(zip(got, ref)):
+        assert g.dtype == np.float64
+        assert np.abs(g.reshape(r.shape) - r).max() <= 1e-12 * max(1.0, float(np.abs(r).max())), (wname, k)
+    w.soft_threshold(3.0)
+    w.inverse()
+    thr = [ref[0]] + [np.sign(b) * np.maximum(np.abs(b) - 3.0, 0.0) for b in ref[1:]]
+    rec = oracle.inverse(thr, x.shape, wname, w.levels, ndim=ndim, do_swt=swt, double="full")
+    assert np.abs(w.image.reshape(rec.shape) - rec).max() <= 1e-11 * 255
+
+
+@pytest.mark.gpu
+def test_fp64_roundtrip_is_exact_to_double_precision_and_ops_work():
+    from pypwt_amd import Wavelets64
+    x = oracle.hash_input((256, 256), 31, scale=255.0).astype(np.float64)
+    w = Wavelets64(x, "db4", 4)
+    w.forward()
+    n1, n2 = w.norm1(), w.norm2sq()
+    flat = np.concatenate([w.coeffs[0].ravel()] + [b.ravel() for lvl in w.coeffs[1:] for b in lvl])
+    assert abs(n1 - np.abs(flat).sum()) <= 1e-10 * n1 and abs(n2 - (flat ** 2).sum()) <= 1e-10 * n2
+    w.inverse()
+    assert np.abs(w.image - x).max() <= 1e-10  # fp32 reaches ~1e-4 here
+    w2 = Wavelets64(x, "db4", 4, do_separable=0)
+    w2.forward()
+    w.forward()
+    for a, b in zip(w.coeffs[1], w2.coeffs[1]):
+        assert np.abs(a - b).max() <= 1e-10 * 255
+
+
+@pytest.mark.gpu
+def test_fp64_every_wavelet_round_trips():
+    """All 72 filter lengths through the fp64 generic kernels (2D, 1D, SWT): the LDS tiles of doubles fit."""
+    from pypwt_amd import Wavelets64
+    names = oracle.filter_table()["order"]
+    x = oracle.hash_input((176, 208), 99, scale=255.0).astype(np.float64)
+    for wname in names:
+        for kw in ({}, {"ndim": 1}, {"do_swt": 1}):
+            w = Wavelets64(x, wname, 2, **kw)
+            w.forward()
+            w.inverse()
+            assert np.abs(w.image - x).max() <= 2e-8, (wname, kw)  # fp32 build: ~1e-4
