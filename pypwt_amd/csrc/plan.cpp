@@ -1063,6 +1063,10 @@ int pdwt_set_coeff(pdwt_handle h, const real_t* src, int num, int mem_is_on_devi
     HIP_TRY(hipMemcpyAsync(h->band(num), src, (size_t)n * sizeof(real_t),
                            mem_is_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, h->stream));
     if (!mem_is_on_device) HIP_TRY(hipStreamSynchronize(h->stream));
+    // The reference forbids coefficient access after inverse() because its inverse overwrites the
+    // approximation band d_coeffs[0] (wt.cu:272-275); once the caller has supplied that band again the
+    // coefficients are current, so a new inverse() is meaningful (the reference would still refuse it).
+    if (num == 0 && h->state == PDWT_INVERSE) h->state = PDWT_FORWARD;
     return PDWT_OK;
 }
 

@@ -147,3 +147,13 @@ def test_plain_c_program_links_against_the_abi(lib, tmp_path):
                            "-lpypwt_amd", "-Wl,-rpath," + os.path.join(ROOT, "pypwt_amd"), "-lm", "-o", exe])
     r = subprocess.run([exe], capture_output=True, text=True)
     assert r.returncode in (0, 77), r.stdout  # 77: no HIP device here; unknown-wavelet check already ran
+
+
+def test_tiled_wavelets_needs_a_gpu_and_says_so():
+    """pypwt_amd/tiled.py (one image over several GPUs) has no CPU path either."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from pypwt_amd.tiled import TiledWavelets
+    with pytest.raises(RuntimeError, match="HIP device"):
+        TiledWavelets(np.zeros((64, 64), dtype=np.float32), "db2", 2)

@@ -127,6 +127,22 @@ def test_state_machine_and_errors(W):
         w.forward(np.zeros((64, 63), dtype=np.float32))
 
 
+def test_set_coeff_zero_after_inverse_allows_a_new_inverse(W):
+    """Deliberate deviation: supplying the approximation band again after an inverse makes
+    the coefficients current, so the next inverse() runs on them."""
+    x = oracle.hash_input((64, 64), 8)
+    w = W(x, "db2", 1)
+    w.forward()
+    A = w.coeffs[0].copy()
+    w.inverse()
+    w.set_coeff(2.0 * A, 0)
+    w.inverse()
+    ref = oracle.forward(x, "db2", 1)
+    ref[0] = 2.0 * ref[0]
+    want = oracle.inverse(ref, x.shape, "db2", 1)
+    assert np.abs(w.image - want).max() <= 1e-3
+
+
 def test_level_clamp_and_attributes(W):
     x = oracle.hash_input((512, 512), 6)
     w = W(x, "db2", 99)

@@ -1,0 +1,56 @@
+"""Worker of tests/test_gpu_tiled.py: one rank of a TiledWavelets run (launched as a child process with
+RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set).  Every rank also computes the transform of the WHOLE
+image with the single-GPU `Wavelets` class and compares its own row slab of every sub-band and of the
+reconstruction; prints 'OK <rank>' on success."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    import torch
+    import torch.distributed as dist
+    from oracle import oracle
+    from pypwt_amd import Wavelets
+    from pypwt_amd.tiled import TiledWavelets
+
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    wname, levels = sys.argv[1], int(sys.argv[2])
+    Nr, Nc = int(sys.argv[3]), int(sys.argv[4])
+    backend = sys.argv[5] if len(sys.argv) > 5 else "gloo"
+    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1))
+    dist.init_process_group(backend, rank=rank, world_size=world)
+    x = oracle.hash_input((Nr, Nc), 555, scale=255.0)
+    n = Nr // world
+    tw = TiledWavelets(x[rank * n:(rank + 1) * n], wname, levels)
+    tw.forward()
+    full = Wavelets(x, wname, levels)
+    full.forward()
+    ref = full.coeffs
+    got = tw.coeffs
+
+    def slab(a):
+        k = a.shape[0] // world
+        return a[rank * k:(rank + 1) * k]
+
+    tol = 2e-6 * (levels + 1) * 255 * 4 ** levels
+    assert np.abs(got[0] - slab(ref[0])).max() <= tol, "A"
+    for lvl in range(1, levels + 1):
+        for g, r in zip(got[lvl], ref[lvl]):
+            assert g.shape == slab(r).shape and np.abs(g - slab(r)).max() <= tol, ("level", lvl)
+    tw.inverse()
+    assert np.abs(tw.image - x[rank * n:(rank + 1) * n]).max() <= 2e-3, "reconstruction"
+    tw.forward()
+    tw.inverse()  # plans are reused: a second round trip must work too
+    assert np.abs(tw.image - x[rank * n:(rank + 1) * n]).max() <= 4e-3, "second round trip"
+    dist.barrier()
+    dist.destroy_process_group()
+    print("OK %d" % rank)
+
+
+if __name__ == "__main__":
+    main()
