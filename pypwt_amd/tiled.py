@@ -36,6 +36,12 @@ class _DeviceView(object):
 
 class TiledWavelets(object):
     def __init__(self, slab, wname, levels, group=None):
+        import sys
+        if "torch" not in sys.modules and _lib._libs:
+            # PyTorch-ROCm bundles its own libamdhip64 under the same soname as /opt/rocm's: whichever is
+            # loaded first serves both, and torch does not initialise on top of the system runtime
+            raise RuntimeError("TiledWavelets: import torch before the first use of pypwt_amd in this process "
+                               "(torch and libpypwt_amd.so must share torch's HIP runtime)")
         import torch
         import torch.distributed as dist
         self._torch, self._dist = torch, dist

@@ -24,30 +24,9 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("wname,levels,shape", [("haar", 3, (64, 96)), ("db2", 2, (64, 64)), ("db4", 3, (192, 160)),
-                                                ("sym8", 2, (128, 256)), ("bior2.4", 2, (96, 64))])
-def test_single_rank_ring_equals_plain_transform(wname, levels, shape):
-    """world size 1: the ring closes on itself, so the tiled path must reproduce the ordinary transform."""
-    from pypwt_amd import Wavelets
-    from pypwt_amd.tiled import TiledWavelets
-    x = oracle.hash_input(shape, 321, scale=255.0)
-    tw = TiledWavelets(x, wname, levels)
-    tw.forward()
-    w = Wavelets(x, wname, levels)
-    w.forward()
-    tol = 2e-6 * (levels + 1) * 255 * 4 ** levels
-    got, ref = tw.coeffs, w.coeffs
-    assert np.abs(got[0] - ref[0]).max() <= tol
-    for lvl in range(1, levels + 1):
-        for g, r in zip(got[lvl], ref[lvl]):
-            assert np.abs(g - r).max() <= tol, (wname, lvl)
-    tw.inverse()
-    assert np.abs(tw.image - x).max() <= 2e-3
-
-
-@pytest.mark.parametrize("world,wname,levels,shape", [(2, "db4", 3, (256, 128)), (3, "sym4", 2, (192, 64)),
-                                                      (4, "haar", 2, (64, 64)), (2, "db8", 2, (256, 96))])
-def test_row_slabs_over_ranks_with_halo_exchange(world, wname, levels, shape):
+def _run_ranks(world, wname, levels, shape):
+    """Each rank is a child process (torch must be imported before libpypwt_amd.so in a process, and the
+    pytest process has long loaded the library): tests/tiled_worker.py compares its slabs itself."""
     port = _free_port()
     procs = []
     for r in range(world):
@@ -67,3 +46,29 @@ def test_row_slabs_over_ranks_with_halo_exchange(world, wname, levels, shape):
         outs.append(out)
     for r, (p, out) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and ("OK %d" % r) in out, "rank %d failed:\n%s" % (r, out[-3000:])
+
+
+@pytest.mark.parametrize("wname,levels,shape", [("haar", 3, (64, 96)), ("db2", 2, (64, 64)), ("db4", 3, (192, 160)),
+                                                ("sym8", 2, (128, 256)), ("bior2.4", 2, (96, 64))])
+def test_single_rank_ring_equals_plain_transform(wname, levels, shape):
+    """world size 1, no process group: the ring closes on itself, so the tiled path must reproduce the
+    ordinary transform."""
+    _run_ranks(1, wname, levels, shape)
+
+
+@pytest.mark.parametrize("world,wname,levels,shape", [(2, "db4", 3, (256, 128)), (3, "sym4", 2, (192, 64)),
+                                                      (4, "haar", 2, (64, 64)), (2, "db8", 2, (256, 96))])
+def test_row_slabs_over_ranks_with_halo_exchange(world, wname, levels, shape):
+    _run_ranks(world, wname, levels, shape)
+
+
+def test_import_order_is_checked():
+    """In a process that already loaded libpypwt_amd.so without torch, TiledWavelets refuses loudly instead
+    of running on a HIP runtime torch cannot initialise."""
+    code = ("import numpy as np, sys; sys.path.insert(0, %r)\n"
+            "from pypwt_amd import _lib; _lib.load()\n"
+            "from pypwt_amd.tiled import TiledWavelets\n"
+            "try:\n    TiledWavelets(np.zeros((64, 64), dtype=np.float32), 'db2', 2)\n"
+            "except RuntimeError as e:\n    print('REFUSED' if 'import torch before' in str(e) else e)\n" % ROOT)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert "REFUSED" in out.stdout, out.stdout + out.stderr
