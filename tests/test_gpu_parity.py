@@ -395,3 +395,26 @@ def test_fp64_every_wavelet_round_trips():
             w.forward()
             w.inverse()
             assert np.abs(w.image - x).max() <= 2e-8, (wname, kw)  # fp32 build: ~1e-4
+
+
+@pytest.mark.gpu
+def test_large_image_beyond_32bit_byte_offsets():
+    """16384 x 12288 samples (768 MiB per plane, byte offsets beyond 2^31): round trip, Parseval for the
+    orthogonal db4 and a strided comparison of level-1 details against the oracle on a row band."""
+    from pypwt_amd import Wavelets
+    shape = (16384, 12288)
+    x = oracle.hash_input(shape, 2024, scale=255.0)
+    w = Wavelets(x, "db4", 3)
+    w.forward()
+    e_in = float(np.sum(x.astype(np.float64) ** 2))
+    e_out = float(w.norm2sq())
+    assert abs(e_out - e_in) <= 2e-4 * e_in
+    # level-1 row k reads image rows 2k-3 .. 2k+4 (periodic): the last 65 rows need the last 134 image rows
+    # and the first 3.  Row kb of the band's own transform is level-1 row N/2 - 67 + kb for 2 <= kb <= 66.
+    band = np.concatenate([x[-134:], x[:6]])
+    ref = oracle.forward(band, "db4", 1)
+    for k in range(3):
+        got = w.coeffs[1][k][-65:]
+        assert np.abs(got - ref[1 + k][2:67]).max() <= 1e-4 * max(1.0, float(np.abs(ref[1 + k]).max())), k
+    w.inverse()
+    assert np.abs(w.image - x).max() <= 4e-3
