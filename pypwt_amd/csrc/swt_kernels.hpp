@@ -188,6 +188,175 @@ PDWT_DEVICE void swt2_inv_tile(const Swt2DArgs& a, int bx, int by, int bz, real_
 }
 
 // ---------------------------------------------------------------------------
+// Vectorised twins of the two fused kernels: every thread owns FOUR consecutive columns, so the
+// dilated taps are read with one 16-B load per band and tap (4-B aligned is enough for a global
+// dwordx4 load: the shift (j-c) f need not be a multiple of 4), the LDS planes are read and written
+// 16 B at a time and the results leave with 16-B stores.  rocprofv3 on cfg4 showed the scalar
+// kernels at 55 % VALU-busy with 4x the memory instructions of a streaming kernel.
+// Requirements (host): Nc % 4 == 0, 16-B aligned planes, compile-time filter length.
+// ---------------------------------------------------------------------------
+#ifdef PDWT_CPU_EMU
+struct rv4 { real_t x, y, z, w; };
+static inline rv4 load4u(const real_t* p) { return rv4{p[0], p[1], p[2], p[3]}; }
+static inline rv4 load4(const real_t* p) { return rv4{p[0], p[1], p[2], p[3]}; }
+static inline void store4(real_t* p, const rv4& v) { p[0] = v.x; p[1] = v.y; p[2] = v.z; p[3] = v.w; }
+#else
+typedef real_t rv4 __attribute__((ext_vector_type(4)));
+#ifdef PDWT_DOUBLE
+typedef real_t rv4u __attribute__((ext_vector_type(4), aligned(8)));
+#else
+typedef real_t rv4u __attribute__((ext_vector_type(4), aligned(4)));
+#endif
+static __device__ __forceinline__ rv4 load4u(const real_t* p) { return *reinterpret_cast<const rv4u*>(p); }
+static __device__ __forceinline__ rv4 load4(const real_t* p) { return *reinterpret_cast<const rv4*>(p); }
+static __device__ __forceinline__ void store4(real_t* p, const rv4& v) { *reinterpret_cast<rv4*>(p) = v; }
+#endif
+
+// four consecutive samples of a periodic row starting at (possibly negative / overflowing) column p
+PDWT_DEVICE rv4 load4_periodic(const real_t* PDWT_RESTRICT row, int p, int Nc) {
+    const int q = wrap_periodic(p, Nc);
+    if (q + 3 < Nc) return load4u(row + q);
+    rv4 v;  // the group straddles the period: only in the first / last tile of a row
+    v.x = row[q];
+    v.y = row[wrap_periodic(q + 1, Nc)];
+    v.z = row[wrap_periodic(q + 2, Nc)];
+    v.w = row[wrap_periodic(q + 3, Nc)];
+    return v;
+}
+
+PDWT_DEVICE void fma4(rv4& acc, const rv4& v, real_t t) {
+    acc.x = pdwt_fma(v.x, t, acc.x);
+    acc.y = pdwt_fma(v.y, t, acc.y);
+    acc.z = pdwt_fma(v.z, t, acc.z);
+    acc.w = pdwt_fma(v.w, t, acc.w);
+}
+
+PDWT_DEVICE rv4 soft4(const rv4& v, real_t b) {
+    rv4 r;
+    r.x = soft_shrink(v.x, b); r.y = soft_shrink(v.y, b); r.z = soft_shrink(v.z, b); r.w = soft_shrink(v.w, b);
+    return r;
+}
+
+template <int TX, int TY>
+constexpr int swt2d_vec_lds_floats(int hlen) { return 2 * (TY + hlen - 1) * TX; }
+
+template <int HLEN, int TX, int TY, int NT>
+PDWT_DEVICE void swt2_fwd_vec_tile(const Swt2DArgs& a, int bx, int by, int bz, real_t* smem) {
+    constexpr int QX = TX / 4, NG = NT / QX, R = TY / NG;
+    static_assert(HLEN > 0 && TX % 4 == 0 && NT % QX == 0 && TY % NG == 0, "tile/thread shape");
+    constexpr int c = (HLEN & 1) ? HLEN / 2 : HLEN / 2 - 1;  // analysis_centre
+    constexpr int RY = TY + HLEN - 1;
+    const int f = a.f, M = a.Nr / f, ph = by % f, it = by / f;
+    real_t* tL = smem;
+    real_t* tH = tL + RY * TX;
+    const real_t* PDWT_RESTRICT in = a.in + (long long)bz * a.bstride;
+    const real_t zero = 0;
+
+    PDWT_FOR_THREADS(tid, NT) {
+        const int k4 = tid % QX, x0 = bx * TX + 4 * k4;
+        for (int r = tid / QX; r < RY; r += NG) {
+            rv4 aL = {zero, zero, zero, zero}, aH = aL;
+            if (x0 < a.Nc) {
+                const int i = wrap_periodic(it * TY - c + r, M);
+                const real_t* row = in + (long long)(ph + f * i) * a.Nc;
+#pragma unroll
+                for (int j = 0; j < HLEN; ++j) {
+                    const rv4 v = load4_periodic(row, x0 + (j - c) * f, a.Nc);
+                    fma4(aL, v, a.fb.lo[HLEN - 1 - j]);
+                    fma4(aH, v, a.fb.hi[HLEN - 1 - j]);
+                }
+            }
+            store4(tL + r * TX + 4 * k4, aL);
+            store4(tH + r * TX + 4 * k4, aH);
+        }
+    }
+    PDWT_SYNC();
+    PDWT_FOR_THREADS(tid, NT) {
+        const int k4 = tid % QX, ty0 = (tid / QX) * R, x0 = bx * TX + 4 * k4;
+        const long long boff = (long long)bz * a.bstride;
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            rv4 rA = {zero, zero, zero, zero}, rH = rA, rV = rA, rD = rA;
+#pragma unroll
+            for (int j = 0; j < HLEN; ++j) {
+                const rv4 l = load4(tL + (ty0 + i + j) * TX + 4 * k4);
+                const rv4 h = load4(tH + (ty0 + i + j) * TX + 4 * k4);
+                const real_t tl = a.fb.lo[HLEN - 1 - j], th = a.fb.hi[HLEN - 1 - j];
+                fma4(rA, l, tl);
+                fma4(rH, l, th);
+                fma4(rV, h, tl);
+                fma4(rD, h, th);
+            }
+            const int si = it * TY + ty0 + i;
+            if (si < M && x0 < a.Nc) {
+                const long long o = boff + (long long)(ph + f * si) * a.Nc + x0;
+                store4(a.A + o, rA);
+                store4(a.H + o, rH);
+                store4(a.V + o, rV);
+                store4(a.D + o, rD);
+            }
+        }
+    }
+}
+
+template <int HLEN, int TX, int TY, int NT>
+PDWT_DEVICE void swt2_inv_vec_tile(const Swt2DArgs& a, int bx, int by, int bz, real_t* smem) {
+    constexpr int QX = TX / 4, NG = NT / QX, R = TY / NG;
+    static_assert(HLEN > 0 && TX % 4 == 0 && NT % QX == 0 && TY % NG == 0, "tile/thread shape");
+    constexpr int c = HLEN / 2;  // synthesis centre
+    constexpr int RY = TY + HLEN - 1;
+    const int f = a.f, M = a.Nr / f, ph = by % f, it = by / f;
+    real_t* u1 = smem;
+    real_t* u2 = u1 + RY * TX;
+    const long long boff = (long long)bz * a.bstride;
+    const real_t zero = 0, half = (real_t)0.5;
+
+    // dilated row synthesis from global: u1 = Lx(A) + Hx(V), u2 = Lx(H) + Hx(D) (pending soft threshold
+    // applied to the detail bands as they are loaded, never to A)
+    PDWT_FOR_THREADS(tid, NT) {
+        const int k4 = tid % QX, x0 = bx * TX + 4 * k4;
+        for (int r = tid / QX; r < RY; r += NG) {
+            rv4 r1 = {zero, zero, zero, zero}, r2 = r1;
+            if (x0 < a.Nc) {
+                const int i = wrap_periodic(it * TY - c + r, M);
+                const long long ro = boff + (long long)(ph + f * i) * a.Nc;
+#pragma unroll
+                for (int j = 0; j < HLEN; ++j) {
+                    const int p = x0 + (j - c) * f;
+                    const real_t tl = a.fb.lo[HLEN - 1 - j], th = a.fb.hi[HLEN - 1 - j];
+                    fma4(r1, load4_periodic(a.A + ro, p, a.Nc), tl);
+                    fma4(r1, soft4(load4_periodic(a.V + ro, p, a.Nc), a.soft_beta), th);
+                    fma4(r2, soft4(load4_periodic(a.H + ro, p, a.Nc), a.soft_beta), tl);
+                    fma4(r2, soft4(load4_periodic(a.D + ro, p, a.Nc), a.soft_beta), th);
+                }
+            }
+            r1.x *= half; r1.y *= half; r1.z *= half; r1.w *= half;
+            r2.x *= half; r2.y *= half; r2.z *= half; r2.w *= half;
+            store4(u1 + r * TX + 4 * k4, r1);
+            store4(u2 + r * TX + 4 * k4, r2);
+        }
+    }
+    PDWT_SYNC();
+    PDWT_FOR_THREADS(tid, NT) {
+        const int k4 = tid % QX, ty0 = (tid / QX) * R, x0 = bx * TX + 4 * k4;
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            rv4 r = {zero, zero, zero, zero};
+#pragma unroll
+            for (int j = 0; j < HLEN; ++j) {
+                fma4(r, load4(u1 + (ty0 + i + j) * TX + 4 * k4), a.fb.lo[HLEN - 1 - j]);
+                fma4(r, load4(u2 + (ty0 + i + j) * TX + 4 * k4), a.fb.hi[HLEN - 1 - j]);
+            }
+            const int si = it * TY + ty0 + i;
+            if (si < M && x0 < a.Nc) {
+                r.x *= half; r.y *= half; r.z *= half; r.w *= half;
+                store4(a.out + boff + (long long)(ph + f * si) * a.Nc + x0, r);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Direct one-pass kernels: one output sample per thread, taps read from global.
 // `along_y` selects the filtered axis.  Used for the (batched) 1D SWT and as the
 // 2D fallback when f does not divide Nr.
@@ -249,6 +418,16 @@ template <int HLEN, int TX, int TY, int NT>
 __global__ void __launch_bounds__(NT) swt2_inv_kernel(const Swt2DArgs a) {
     extern __shared__ __attribute__((aligned(16))) real_t pdwt_smem[];
     swt2_inv_tile<HLEN, TX, TY, NT>(a, blockIdx.x, blockIdx.y, blockIdx.z, pdwt_smem);
+}
+template <int HLEN, int TX, int TY, int NT>
+__global__ void __launch_bounds__(NT) swt2_fwd_vec_kernel(const Swt2DArgs a) {
+    extern __shared__ __attribute__((aligned(16))) real_t pdwt_smem[];
+    swt2_fwd_vec_tile<HLEN, TX, TY, NT>(a, blockIdx.x, blockIdx.y, blockIdx.z, pdwt_smem);
+}
+template <int HLEN, int TX, int TY, int NT>
+__global__ void __launch_bounds__(NT) swt2_inv_vec_kernel(const Swt2DArgs a) {
+    extern __shared__ __attribute__((aligned(16))) real_t pdwt_smem[];
+    swt2_inv_vec_tile<HLEN, TX, TY, NT>(a, blockIdx.x, blockIdx.y, blockIdx.z, pdwt_smem);
 }
 template <int NT>
 __global__ void __launch_bounds__(NT) swt_pass_fwd_kernel(const SwtPassArgs a) {

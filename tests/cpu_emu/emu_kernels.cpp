@@ -145,7 +145,21 @@ static void run_swt2(const Swt2DArgs& a, int batch) {
             }
 }
 
+template <int HLEN, bool INV>
+static void run_swt2_vec(const Swt2DArgs& a, int batch) {
+    constexpr int TX = 128, TY = 16, NT = 256;
+    std::vector<float> smem(swt2d_vec_lds_floats<TX, TY>(HLEN) + 64, NAN);
+    const int M = a.Nr / a.f;
+    for (int bz = 0; bz < batch; bz++)
+        for (int by = 0; by < cdiv(M, TY) * a.f; by++)
+            for (int bx = 0; bx < cdiv(a.Nc, TX); bx++) {
+                if (INV) swt2_inv_vec_tile<HLEN, TX, TY, NT>(a, bx, by, bz, smem.data());
+                else swt2_fwd_vec_tile<HLEN, TX, TY, NT>(a, bx, by, bz, smem.data());
+            }
+}
+
 // inverse != 0: A,H,V,D are inputs and io is the output plane; else io is the input plane
+// generic: 0 = compile-time filter length, 1 = run-time filter length, 2 = vectorised (4 columns per thread)
 EMU_API int emu_swt2(int inverse, float* io, int batch, int Nr, int Nc, int level, const float* lo, const float* hi,
                      int hlen, int generic, float* A, float* H, float* V, float* D) {
     Swt2DArgs a;
@@ -153,6 +167,15 @@ EMU_API int emu_swt2(int inverse, float* io, int batch, int Nr, int Nc, int leve
     a.Nr = Nr; a.Nc = Nc; a.f = 1 << (level - 1); a.bstride = (long long)Nr * Nc; a.hlen = hlen; a.soft_beta = 0.f;
     if (Nr % a.f) return -2;
     set_bank(a.fb, lo, hi, hlen);
+    if (generic == 2) {
+        if ((hlen & 1) || (Nc & 3)) return -3;
+        switch (hlen) {
+#define X(h) case h: if (inverse) run_swt2_vec<h, true>(a, batch); else run_swt2_vec<h, false>(a, batch); return 0;
+            EMU_EVEN_HLENS(X)
+#undef X
+        }
+        return -1;
+    }
     if (generic || (hlen & 1)) { if (inverse) run_swt2<0, true>(a, batch); else run_swt2<0, false>(a, batch); return 0; }
     switch (hlen) {
 #define X(h) case h: if (inverse) run_swt2<h, true>(a, batch); else run_swt2<h, false>(a, batch); return 0;

@@ -277,6 +277,60 @@ static void bench_inv_strip2(const char* tag, const float* in, float* out, int N
     printf("%-24s seg_rows=%4d wgs=%5d N=%d B=%d lds=%6zu  %8.2f us  (two levels in one launch)\n", tag, seg_rows, a.strips * a.segs, N, batch, lds, us);
 }
 
+// Six dependent copy kernels sized like the launches of one cfg2 step (64, 16, 5, 5, 16, 64 MiB of
+// traffic halves), issued as plain stream launches and as one replayed hipGraph: what a launch boundary
+// costs on this GPU and whether a graph shortens it.
+static void bench_launch_chain(const float* a, float* b) {
+    if (skip("CHAIN")) return;
+    const long long n4s[6] = {4194304, 1048576, 327680, 327680, 1048576, 4194304};  // float4 groups per kernel
+    hipStream_t st;
+    CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    auto chain = [&](hipStream_t s) {
+        for (int k = 0; k < 6; k++)
+            hipLaunchKernelGGL(copy4, dim3(2048), dim3(256), 0, s, (const float4*)a, (float4*)b, n4s[k]);
+    };
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    float ms;
+    for (int i = 0; i < 5; i++) chain(st);
+    CK(hipStreamSynchronize(st));
+    CK(hipEventRecord(e0, st));
+    for (int i = 0; i < 50; i++) chain(st);
+    CK(hipEventRecord(e1, st));
+    CK(hipEventSynchronize(e1));
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    const float plain = ms * 1e3f / 50;
+    // sum of the kernels alone
+    float sum = 0.f;
+    for (int k = 0; k < 6; k++) {
+        CK(hipEventRecord(e0, st));
+        for (int i = 0; i < 50; i++) hipLaunchKernelGGL(copy4, dim3(2048), dim3(256), 0, st, (const float4*)a, (float4*)b, n4s[k]);
+        CK(hipEventRecord(e1, st));
+        CK(hipEventSynchronize(e1));
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        sum += ms * 1e3f / 50;
+    }
+    hipGraph_t g;
+    hipGraphExec_t ge;
+    CK(hipStreamBeginCapture(st, hipStreamCaptureModeGlobal));
+    chain(st);
+    CK(hipStreamEndCapture(st, &g));
+    CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+    for (int i = 0; i < 5; i++) CK(hipGraphLaunch(ge, st));
+    CK(hipStreamSynchronize(st));
+    CK(hipEventRecord(e0, st));
+    for (int i = 0; i < 50; i++) CK(hipGraphLaunch(ge, st));
+    CK(hipEventRecord(e1, st));
+    CK(hipEventSynchronize(e1));
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    printf("CHAIN of 6 dependent copies: back-to-back same-size launches sum %.2f us ; chain as stream launches %.2f us ; "
+           "as one hipGraph %.2f us\n", sum, plain, ms * 1e3f / 50);
+    CK(hipGraphExecDestroy(ge));
+    CK(hipGraphDestroy(g));
+    CK(hipStreamDestroy(st));
+}
+
 int main(int argc, char** argv) {
     const int N = argc > 1 ? atoi(argv[1]) : 4096;
     const int B = argc > 2 ? atoi(argv[2]) : 1;
@@ -306,6 +360,7 @@ int main(int argc, char** argv) {
         us = time_it([&] { hipLaunchKernelGGL(write4, dim3(2048), dim3(256), 0, 0, (float4*)b, n4); });
         printf("write4 grid= 2048                    %8.2f us  %7.1f GB/s (w)\n", us, 4.0 * n / us / 1e3);
     }
+    bench_launch_chain(a, b);
     for (int w : {2, 4, 6, 8, 12}) bench_fwd_stream<8, 64, 8, 256>("STREAM fwd db4 TX64 TY8 NT256", a, b, N, B, w);
     for (int w : {2, 4, 6, 8}) bench_fwd_stream<8, 64, 16, 256>("STREAM fwd db4 TX64 TY16 NT256", a, b, N, B, w);
     for (int w : {2, 4, 8}) bench_fwd_stream<8, 64, 4, 128>("STREAM fwd db4 TX64 TY4 NT128", a, b, N, B, w);
