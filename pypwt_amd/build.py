@@ -34,6 +34,7 @@ SOURCES = [
     "launch_dwt1.hip",
     "launch_dwt1_fused.hip",
     "launch_swt.hip",
+    "launch_swt_vec.hip",
     "launch_ops.hip",
     "launch_nonsep.hip",
     "plan.cpp",
@@ -82,7 +83,7 @@ def build_library(force=False, verbose=True, variant="f32"):
     if force:
         for f in os.listdir(objdir):
             os.remove(os.path.join(objdir, f))
-    with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
+    with ThreadPoolExecutor(max_workers=min(os.cpu_count() or 4, len(srcs))) as ex:
         objs = list(ex.map(_compile, [(s, objdir, extra) for s in srcs]))
     cmd = [hipcc(), "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", lib] + objs
     r = subprocess.run(cmd, capture_output=True, text=True)
@@ -94,7 +95,9 @@ def build_library(force=False, verbose=True, variant="f32"):
 
 
 def build_all(force=False, verbose=True):
-    return [build_library(force, verbose, v) for v in ("f32", "f64")]
+    """Both variants; their translation units share one pool of compiler processes."""
+    with ThreadPoolExecutor(max_workers=2) as ex:
+        return list(ex.map(lambda v: build_library(force, verbose, v), ("f32", "f64")))
 
 
 if __name__ == "__main__":

@@ -1,0 +1,51 @@
+// launch_swt_vec.hip -- launchers of the vectorised a-trous level kernels (gfx950); a translation unit of
+// its own so that the 20 unrolled filter lengths compile in parallel with the scalar kernels.
+#include "launch.hpp"
+#include "launch_util.hpp"
+#include "swt_kernels.hpp"
+
+namespace pdwt {
+
+// vectorised twins: 128 columns x 16 rows of one phase, four columns per thread (16-B accesses)
+template <int HLEN, bool INV>
+static hipError_t run_vec(const Swt2DArgs& a, int batch, hipStream_t s) {
+    constexpr int TX = 128, TY = 16, NT = 256;
+    static bool big[64] = {};
+    constexpr size_t lds = (size_t)swt2d_vec_lds_floats<TX, TY>(HLEN) * sizeof(real_t);
+    const int M = a.Nr / a.f;
+    dim3 grid(cdiv(a.Nc, TX), cdiv(M, TY) * a.f, batch);
+    if (INV) {
+        hipError_t e = allow_big_lds(swt2_inv_vec_kernel<HLEN, TX, TY, NT>, lds, big);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((swt2_inv_vec_kernel<HLEN, TX, TY, NT>), grid, dim3(NT), lds, s, a);
+    } else {
+        hipError_t e = allow_big_lds(swt2_fwd_vec_kernel<HLEN, TX, TY, NT>, lds, big);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((swt2_fwd_vec_kernel<HLEN, TX, TY, NT>), grid, dim3(NT), lds, s, a);
+    }
+    return hipGetLastError();
+}
+
+static bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & (4 * sizeof(real_t) - 1)) == 0; }
+
+// preconditions of the vectorised kernels: even compile-time filter length, whole 4-column groups,
+// planes aligned for 4-element accesses
+static bool vec_ok(const Swt2DArgs& a, bool inverse) {
+    if ((a.hlen & 1) || a.hlen < 2 || a.hlen > kMaxTaps || (a.Nc & 3) || (a.bstride & 3)) return false;
+    if (!al16(a.A) || !al16(a.H) || !al16(a.V) || !al16(a.D)) return false;
+    return al16(inverse ? (const void*)a.out : (const void*)a.in);
+}
+
+hipError_t try_launch_swt2_vec(const Swt2DArgs& a, bool inverse, int batch, hipStream_t s) {
+    if (!vec_ok(a, inverse)) return hipErrorNotSupported;
+    switch (a.hlen) {
+#define X(h) \
+    case h:  \
+        return inverse ? run_vec<h, true>(a, batch, s) : run_vec<h, false>(a, batch, s);
+        PDWT_EVEN_HLENS(X)
+#undef X
+    }
+    return hipErrorNotSupported;
+}
+
+}  // namespace pdwt
