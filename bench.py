@@ -120,6 +120,9 @@ def parse_args():
     ap.add_argument("--batch", type=int, default=1, help="images per GPU per step")
     ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--preheat-ms", type=float, default=200.0,
+                    help="run the workload untimed for this long before the warmup steps: after an idle period "
+                         "the GPU needs tens of ms to ramp its clocks, and W = 10 steps last under 1 ms")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for the barrier / max-over-ranks (nccl = RCCL)")
     ap.add_argument("--dry-run", action="store_true",
@@ -257,6 +260,12 @@ def main():
             import torch
             torch.cuda.synchronize()
 
+    # pre-heat (untimed): sustained-throughput conditions for the timed steps
+    t_pre = time.perf_counter()
+    while (time.perf_counter() - t_pre) * 1e3 < args.preheat_ms:
+        for _ in range(20):
+            step()
+        device_sync()
     for _ in range(args.warmup):
         step()
     device_sync()
@@ -333,7 +342,8 @@ def main():
         "ms_per_step": step_s * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic (on-device index hash, 0..255)",
         "config": {"workload": "%s: %s" % (args.config, desc), "batch_per_gpu": B, "wavelet": wname, "levels": L,
-                   "shape": [Nr, Nc], "parallelism": "image-sharded x%d, no collectives" % world},
+                   "shape": [Nr, Nc], "parallelism": "image-sharded x%d, no collectives" % world,
+                   "preheat_ms": args.preheat_ms},
         "roofline": roofline, "end_to_end": e2e, "kernels": kernels[:12],
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
