@@ -7,13 +7,14 @@
 namespace pdwt {
 
 // vectorised twins: 128 columns x 16 rows of one phase, four columns per thread (16-B accesses)
-template <int HLEN, bool INV>
+template <int HLEN, bool INV, int TX = 128>
 static hipError_t run_vec(const Swt2DArgs& a, int batch, hipStream_t s) {
-    constexpr int TX = 128, TY = 16, NT = 256;
+    constexpr int TY = 16, NT = 256;
     static bool big[64] = {};
     constexpr size_t lds = (size_t)swt2d_vec_lds_floats<TX, TY>(HLEN) * sizeof(real_t);
     const int M = a.Nr / a.f;
-    dim3 grid(cdiv(a.Nc, TX), cdiv(M, TY) * a.f, batch);
+    const int total = cdiv(a.Nc, TX) * cdiv(M, TY) * a.f;
+    dim3 grid(8 * ((total + 7) / 8), batch);  // XCD-aware tile order, see swt_vec_tile
     if (INV) {
         hipError_t e = allow_big_lds(swt2_inv_vec_kernel<HLEN, TX, TY, NT>, lds, big);
         if (e != hipSuccess) return e;
@@ -38,6 +39,10 @@ static bool vec_ok(const Swt2DArgs& a, bool inverse) {
 
 hipError_t try_launch_swt2_vec(const Swt2DArgs& a, bool inverse, int batch, hipStream_t s) {
     if (!vec_ok(a, inverse)) return hipErrorNotSupported;
+    // short filters: 256-column tiles (1 KiB contiguous per row and band; cfg4 in-step 182 -> 176 us, although
+    // a level repeated on cache-resident data is faster with 128: 16.5 vs 18.4 us)
+    if (a.Nc >= 512 && a.hlen == 2) return inverse ? run_vec<2, true, 256>(a, batch, s) : run_vec<2, false, 256>(a, batch, s);
+    if (a.Nc >= 512 && a.hlen == 4) return inverse ? run_vec<4, true, 256>(a, batch, s) : run_vec<4, false, 256>(a, batch, s);
     switch (a.hlen) {
 #define X(h) \
     case h:  \

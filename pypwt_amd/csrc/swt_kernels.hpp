@@ -419,15 +419,38 @@ __global__ void __launch_bounds__(NT) swt2_inv_kernel(const Swt2DArgs a) {
     extern __shared__ __attribute__((aligned(16))) real_t pdwt_smem[];
     swt2_inv_tile<HLEN, TX, TY, NT>(a, blockIdx.x, blockIdx.y, blockIdx.z, pdwt_smem);
 }
+// Vector kernels: 1D grid of 8*chunk workgroups per image.  Workgroup ids b and b+8 share an XCD (and its
+// L2); XCD x gets the contiguous range [x*chunk, (x+1)*chunk) of tiles ordered (phase, row tile, column
+// tile), so the tiles that re-read each other's cache lines -- column neighbours (taps shifted by
+// (j-c) f) and row-tile neighbours of one phase (the hlen-1 halo rows) -- meet in one L2.  rocprofv3: the
+// haar inverse fetched 1.4x its algorithmic bytes with the plain 3D grid.
+template <int TX, int TY>
+__device__ __forceinline__ bool swt_vec_tile(const Swt2DArgs& a, int block, int& bx, int& by) {
+    const int tiles_x = (a.Nc + TX - 1) / TX;
+    const int nrt = (a.Nr / a.f + TY - 1) / TY;  // row tiles per phase
+    const int total = tiles_x * nrt * a.f;
+    const int chunk = (total + 7) >> 3;
+    const int tile = (block & 7) * chunk + (block >> 3);
+    if ((block >> 3) >= chunk || tile >= total) return false;
+    const int row = tile / tiles_x;  // = ph * nrt + it
+    bx = tile - row * tiles_x;
+    const int ph = row / nrt, it = row - ph * nrt;
+    by = it * a.f + ph;              // the tile functions decode by as (it, ph) = (by / f, by % f)
+    return true;
+}
 template <int HLEN, int TX, int TY, int NT>
 __global__ void __launch_bounds__(NT) swt2_fwd_vec_kernel(const Swt2DArgs a) {
     extern __shared__ __attribute__((aligned(16))) real_t pdwt_smem[];
-    swt2_fwd_vec_tile<HLEN, TX, TY, NT>(a, blockIdx.x, blockIdx.y, blockIdx.z, pdwt_smem);
+    int bx, by;
+    if (!swt_vec_tile<TX, TY>(a, blockIdx.x, bx, by)) return;
+    swt2_fwd_vec_tile<HLEN, TX, TY, NT>(a, bx, by, blockIdx.y, pdwt_smem);
 }
 template <int HLEN, int TX, int TY, int NT>
 __global__ void __launch_bounds__(NT) swt2_inv_vec_kernel(const Swt2DArgs a) {
     extern __shared__ __attribute__((aligned(16))) real_t pdwt_smem[];
-    swt2_inv_vec_tile<HLEN, TX, TY, NT>(a, blockIdx.x, blockIdx.y, blockIdx.z, pdwt_smem);
+    int bx, by;
+    if (!swt_vec_tile<TX, TY>(a, blockIdx.x, bx, by)) return;
+    swt2_inv_vec_tile<HLEN, TX, TY, NT>(a, bx, by, blockIdx.y, pdwt_smem);
 }
 template <int NT>
 __global__ void __launch_bounds__(NT) swt_pass_fwd_kernel(const SwtPassArgs a) {

@@ -145,9 +145,9 @@ static void run_swt2(const Swt2DArgs& a, int batch) {
             }
 }
 
-template <int HLEN, bool INV>
+template <int HLEN, bool INV, int TX = 128>
 static void run_swt2_vec(const Swt2DArgs& a, int batch) {
-    constexpr int TX = 128, TY = 16, NT = 256;
+    constexpr int TY = 16, NT = 256;
     std::vector<float> smem(swt2d_vec_lds_floats<TX, TY>(HLEN) + 64, NAN);
     const int M = a.Nr / a.f;
     for (int bz = 0; bz < batch; bz++)
@@ -167,6 +167,12 @@ EMU_API int emu_swt2(int inverse, float* io, int batch, int Nr, int Nc, int leve
     a.Nr = Nr; a.Nc = Nc; a.f = 1 << (level - 1); a.bstride = (long long)Nr * Nc; a.hlen = hlen; a.soft_beta = 0.f;
     if (Nr % a.f) return -2;
     set_bank(a.fb, lo, hi, hlen);
+    if (generic == 3) {  // the 256-column tiles the host uses for hlen 2 and 4
+        if ((Nc & 3) || (hlen != 2 && hlen != 4)) return -3;
+        if (hlen == 2) { if (inverse) run_swt2_vec<2, true, 256>(a, batch); else run_swt2_vec<2, false, 256>(a, batch); }
+        else { if (inverse) run_swt2_vec<4, true, 256>(a, batch); else run_swt2_vec<4, false, 256>(a, batch); }
+        return 0;
+    }
     if (generic == 2) {
         if ((hlen & 1) || (Nc & 3)) return -3;
         switch (hlen) {

@@ -54,7 +54,10 @@ def step_labels(rows, levels):
             seq[int(row["Dispatch_Id"])] = fam
     ids = sorted(seq)
     fams = [seq[i] for i in ids]
-    period = next((p for p in range(1, 65) if len(fams) >= 4 * p and all(fams[i] == fams[i + p] for i in range(3 * p))),
+    # smallest period of the launch-name sequence over its first steps (checked over at least 48 launches:
+    # a step of 5 equal launches followed by 5 others must not pass as period 1)
+    period = next((p for p in range(1, 65)
+                   if len(fams) >= max(4 * p, p + 48) and all(fams[i] == fams[i + p] for i in range(max(3 * p, 48)))),
                   None)
     if period is None:
         return {}
