@@ -325,7 +325,9 @@ def main():
     tpath = os.path.join(ROOT, "profiles", "r01_traffic_%s.json" % args.config)
     if B == 1 and os.path.exists(tpath):
         try:
-            t = json.load(open(tpath))["per_launch"].get(dom["kernel"])
+            # the profile labels launches by kernel family: "+soft" (a deferred threshold folded into the SWT
+            # inverse) is a property of the plan state, not of the kernel
+            t = json.load(open(tpath))["per_launch"].get(dom["kernel"].replace("+soft", ""))
             if t:
                 roofline["traffic"] = t["hbm_bytes"]
                 roofline["traffic_source"] = "profiles/" + os.path.basename(tpath)
