@@ -91,34 +91,106 @@ PDWT_DEVICE int fwd1d_fused_n(int TF, int hlen, int K, int k) {
     return n;
 }
 
+// Buffer layout of the forward pyramid (K >= 2).  Every buffer has 4 floats of front padding and a
+// per-level shift: local sample i of level k sits at buf[4 + sh_k + i], with
+//   sh_0 = s_0 & 3 = C & 3   (s_0 = 2^K bx TF - C (2^K - 1), 4 | 2^K)   -> the staged input is copied in
+//                            whole 16-B groups from its 4-aligned origin, no per-sample scatter;
+//   sh_k = e_k = s_k & 1     (= C & 1 for k < K, 0 for k = K)           -> a work item owns the outputs
+//                            q0 = 2t - e_k, q0 + 1, whose GLOBAL positions s_k + q0 are (even, odd): one
+//                            8-B global store per band and an 8-B aligned LDS write at buf[4 + 2t].
+// Output q of level k+1 reads the level-k samples 2q .. 2q + hlen - 1, i.e. buffer positions
+// 4 + sh_k + 2q + j = 4t + OFF + j with OFF = 4 + sh_k - 2 e_{k+1}: three compile-time cases
+// (first, middle, last level), each fully unrolled.
 constexpr int fwd1d_fused_lds_floats(int TF, int hlen, int K) {
     int n1 = TF;
     for (int i = K; i > 1; --i) n1 = 2 * n1 + hlen - 2;
     const int n0 = 2 * n1 + hlen - 2;
-    return ((n0 + 8 + 3) & ~3) + (n1 + 8);
+    return ((n0 + 16 + 3) & ~3) + ((n1 + 16 + 3) & ~3);
+}
+
+// one level of the pyramid: nk outputs of level k from `src` (layout above) -> details (and A_K) to HBM,
+// A_k to `dst`.  OFF as above, E = e_k, LAST = (k == K).
+template <int HLEN, int OFF, int E, bool LAST, int NT>
+PDWT_DEVICE void fwd1d_fused_level(int tid, const float* src, float* dst, int nk, int sk, int own_lo, int own_hi, int Nk,
+                                   float* PDWT_RESTRICT outD, float* PDWT_RESTRICT outA, const FilterBankI& fb) {
+    constexpr int B4 = OFF & ~3, O = OFF & 3;
+    constexpr int NV = (O + HLEN + 2 + 3) & ~3;  // LDS floats read per work item (two adjacent outputs)
+    for (int t = tid; 2 * t - E < nk; t += NT) {
+        float v[NV];
+        v4f w[NV / 4];
+#pragma unroll
+        for (int q = 0; q < NV / 4; ++q) w[q] = lds_load16(src + 4 * t + B4 + 4 * q);
+#pragma unroll
+        for (int q = 0; q < NV / 4; ++q) {
+            lds_pin(w[q]);
+            v[4 * q + 0] = w[q].x;
+            v[4 * q + 1] = w[q].y;
+            v[4 * q + 2] = w[q].z;
+            v[4 * q + 3] = w[q].w;
+        }
+        v2f acc0 = mk2(0.f, 0.f), acc1 = mk2(0.f, 0.f);  // (A, D) of outputs q0 = 2t - E and q0 + 1
+#pragma unroll
+        for (int j = 0; j < HLEN; ++j) {
+            const v2f tap = fb.t[HLEN - 1 - j];
+            acc0 = fma2(bc(v[O + j]), tap, acc0);
+            acc1 = fma2(bc(v[O + 2 + j]), tap, acc1);
+        }
+        f32x2 pr;
+        if (!LAST) {  // A_k for the next level (outputs outside [0, nk) land in slots nothing valid reads)
+            pr.x = acc0.x;
+            pr.y = acc1.x;
+            *reinterpret_cast<f32x2*>(dst + 4 + 2 * t) = pr;
+        }
+        const int p0 = sk + 2 * t - E;  // even; the owned range has even bounds: both outputs or neither
+        if (p0 >= own_lo && p0 < own_hi && p0 < Nk) {
+            pr.x = acc0.y;
+            pr.y = acc1.y;
+            *reinterpret_cast<f32x2*>(outD + p0) = pr;
+            if (LAST) {
+                pr.x = acc0.x;
+                pr.y = acc1.x;
+                *reinterpret_cast<f32x2*>(outA + p0) = pr;
+            }
+        }
+    }
 }
 
 template <int HLEN, int TF, int NT>
 PDWT_DEVICE void dwt1_fwd_fused_tile(const Fwd1DFusedArgs& a, int bx, int row, float* smem) {
-    constexpr int C = HLEN / 2 - 1;
-    constexpr int NV = (HLEN + 2 + 3) & ~3;  // LDS floats read per thread for two adjacent outputs
-    const int K = a.K;
+    constexpr int C = HLEN / 2 - 1, E = C & 1, SH0 = C & 3;
+    const int K = a.K;  // >= 2
 
     // region of level k: positions [s_k, s_k + n_k);  s_K = bx*TF, s_{k-1} = 2 s_k - C
     const int n1 = fwd1d_fused_n(TF, HLEN, K, 1);
     const int n0 = 2 * n1 + HLEN - 2;
-    float* buf0 = smem;             // holds level 0, 2, 4, ...
-    float* buf1 = smem + ((n0 + 8 + 3) & ~3);  // holds level 1, 3, 5, ... (16-B aligned)
+    float* buf0 = smem;                                  // holds level 0, 2, 4, ...
+    float* buf1 = smem + ((n0 + 16 + 3) & ~3);           // holds level 1, 3, 5, ... (16-B aligned)
 
     // positions fit in 32 bits (the host only uses these kernels for rows shorter than 2^30)
     int s0 = bx * TF;
     for (int k = K; k > 0; --k) s0 = 2 * s0 - C;
 
-    // ---- stage the input segment (periodic), coalesced
+    // ---- stage the input segment (periodic): whole 16-B groups from the 4-aligned origin below s0,
+    //      all of a thread's loads issued before its first LDS write
     PDWT_FOR_THREADS(tid, NT) {
         const float* PDWT_RESTRICT in = a.in + (long long)row * a.N0;
-        stage_periodic_f4<NT, 6, 1>(tid, in, a.N0, s0, n0, buf0, 0);
-        if (tid < 8) buf0[n0 + tid] = 0.f;  // slack read (never used) by the last ds_read_b128
+        const int o4 = true_mod(s0, a.N0) - SH0;  // 4-aligned (s0 = SH0 mod 4, 4 | N0), may be -SH0 < 0 .. wraps below
+        const int ngroups = (SH0 + n0 + 3) >> 2;
+        constexpr int UN = 6;
+        for (int base = tid; base < ngroups; base += NT * UN) {
+            v4f v[UN];
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                int g = base + u * NT;
+                if (g >= ngroups) g = ngroups - 1;
+                v[u] = *reinterpret_cast<const v4f*>(in + true_mod(o4 + 4 * g, a.N0));
+            }
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const int g = base + u * NT;
+                if (g < ngroups) *reinterpret_cast<v4f*>(buf0 + 4 + 4 * g) = v[u];
+            }
+        }
     }
     PDWT_SYNC();
 
@@ -135,42 +207,12 @@ PDWT_DEVICE void dwt1_fwd_fused_tile(const Fwd1DFusedArgs& a, int bx, int row, f
         PDWT_FOR_THREADS(tid, NT) {
             float* PDWT_RESTRICT outD = a.det[k - 1] + (long long)row * Nk;
             float* PDWT_RESTRICT outA = a.app + (long long)row * Nk;
-            for (int t = tid; 2 * t < nk; t += NT) {
-                float v[NV];
-                v4f w[NV / 4];
-#pragma unroll
-                for (int q = 0; q < NV / 4; ++q) w[q] = lds_load16(src + 4 * t + 4 * q);
-#pragma unroll
-                for (int q = 0; q < NV / 4; ++q) {
-                    lds_pin(w[q]);
-                    v[4 * q + 0] = w[q].x;
-                    v[4 * q + 1] = w[q].y;
-                    v[4 * q + 2] = w[q].z;
-                    v[4 * q + 3] = w[q].w;
-                }
-                v2f acc0 = mk2(0.f, 0.f), acc1 = mk2(0.f, 0.f);  // (A, D) of outputs 2t and 2t+1
-#pragma unroll
-                for (int j = 0; j < HLEN; ++j) {
-                    const v2f tap = a.fb.t[HLEN - 1 - j];
-                    acc0 = fma2(bc(v[j]), tap, acc0);
-                    acc1 = fma2(bc(v[2 + j]), tap, acc1);
-                }
-                if (k < K) {
-                    f32x2 w;
-                    w.x = acc0.x;
-                    w.y = acc1.x;
-                    *reinterpret_cast<f32x2*>(dst + 2 * t) = w;
-                }
-                const int p0 = sk + 2 * t, p1 = p0 + 1;
-                if (p0 >= own_lo && p0 < own_hi && p0 < Nk) {
-                    outD[p0] = acc0.y;
-                    if (k == K) outA[p0] = acc0.x;
-                }
-                if (p1 >= own_lo && p1 < own_hi && p1 < Nk) {
-                    outD[p1] = acc1.y;
-                    if (k == K) outA[p1] = acc1.x;
-                }
-            }
+            if (k == 1)
+                fwd1d_fused_level<HLEN, 4 + SH0 - 2 * E, E, false, NT>(tid, src, dst, nk, sk, own_lo, own_hi, Nk, outD, outA, a.fb);
+            else if (k < K)
+                fwd1d_fused_level<HLEN, 4 + E - 2 * E, E, false, NT>(tid, src, dst, nk, sk, own_lo, own_hi, Nk, outD, outA, a.fb);
+            else
+                fwd1d_fused_level<HLEN, 4 + E, 0, true, NT>(tid, src, dst, nk, sk, own_lo, own_hi, Nk, outD, outA, a.fb);
         }
         PDWT_SYNC();
         float* sw = src;
@@ -291,18 +333,32 @@ PDWT_DEVICE void dwt1_inv_fused_tile(const Inv1DFusedArgs& a, int bx, int row, f
 }
 
 #ifndef PDWT_CPU_EMU
+// Grid = 8 * chunk workgroups; ids b and b+8 share an XCD.  XCD x gets the contiguous range
+// [x*chunk, (x+1)*chunk) of (row, segment) work items, so neighbouring segments -- which re-read each
+// other's halo -- meet in one L2 (the plain order fetched 1.22x the algorithmic bytes).
+__device__ __forceinline__ bool fused1d_item(int block, long long total, int tiles_x, int& row, int& bx) {
+    const long long chunk = (total + 7) >> 3;
+    const long long item = (long long)(block & 7) * chunk + (block >> 3);
+    if ((block >> 3) >= chunk || item >= total) return false;
+    row = (int)(item / tiles_x);
+    bx = (int)(item - (long long)row * tiles_x);
+    return true;
+}
+
 template <int HLEN, int TF, int NT>
 __global__ void __launch_bounds__(NT) dwt1_fwd_fused_kernel(const Fwd1DFusedArgs a, int tiles_x) {
     extern __shared__ __attribute__((aligned(16))) float pdwt_smem[];
-    const int row = blockIdx.x / tiles_x;
-    dwt1_fwd_fused_tile<HLEN, TF, NT>(a, blockIdx.x - row * tiles_x, row, pdwt_smem);
+    int row, bx;
+    if (!fused1d_item(blockIdx.x, (long long)tiles_x * a.rows, tiles_x, row, bx)) return;
+    dwt1_fwd_fused_tile<HLEN, TF, NT>(a, bx, row, pdwt_smem);
 }
 
 template <int HLEN, int T0, int NT>
 __global__ void __launch_bounds__(NT) dwt1_inv_fused_kernel(const Inv1DFusedArgs a, int tiles_x) {
     extern __shared__ __attribute__((aligned(16))) float pdwt_smem[];
-    const int row = blockIdx.x / tiles_x;
-    dwt1_inv_fused_tile<HLEN, T0, NT>(a, blockIdx.x - row * tiles_x, row, pdwt_smem);
+    int row, bx;
+    if (!fused1d_item(blockIdx.x, (long long)tiles_x * a.rows, tiles_x, row, bx)) return;
+    dwt1_inv_fused_tile<HLEN, T0, NT>(a, bx, row, pdwt_smem);
 }
 #endif
 

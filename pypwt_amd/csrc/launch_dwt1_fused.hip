@@ -27,7 +27,8 @@ template <int HLEN, int TF>
 static hipError_t run_fwd(const Fwd1DFusedArgs& a, hipStream_t s) {
     const size_t lds = (size_t)fwd1d_fused_lds_floats(TF, HLEN, a.K) * sizeof(float);
     const int tiles = cdiv(a.N0 >> a.K, TF);
-    hipLaunchKernelGGL((dwt1_fwd_fused_kernel<HLEN, TF, 256>), dim3((unsigned)((long long)tiles * a.rows)), dim3(256),
+    const long long total = (long long)tiles * a.rows;
+    hipLaunchKernelGGL((dwt1_fwd_fused_kernel<HLEN, TF, 256>), dim3((unsigned)(8 * ((total + 7) / 8))), dim3(256),
                        lds, s, a, tiles);
     return hipGetLastError();
 }
@@ -36,16 +37,17 @@ template <int HLEN, int T0>
 static hipError_t run_inv(const Inv1DFusedArgs& a, hipStream_t s) {
     const size_t lds = (size_t)inv1d_fused_lds_floats(T0, HLEN, a.K) * sizeof(float);
     const int tiles = cdiv(a.N0, T0);
-    hipLaunchKernelGGL((dwt1_inv_fused_kernel<HLEN, T0, 256>), dim3((unsigned)((long long)tiles * a.rows)), dim3(256),
+    const long long total = (long long)tiles * a.rows;
+    hipLaunchKernelGGL((dwt1_inv_fused_kernel<HLEN, T0, 256>), dim3((unsigned)(8 * ((total + 7) / 8))), dim3(256),
                        lds, s, a, tiles);
     return hipGetLastError();
 }
 
-// levels: K >= 1 consecutive levels starting from `in` of length N0 per row; 2^(K+2) must divide N0
+// levels: K >= 2 consecutive levels starting from `in` of length N0 per row; 2^(K+2) must divide N0
 // (every level length even, every band row 16-B aligned)
 hipError_t launch_dwt1_fwd_fused(const float* in, float* const* det, float* app, int rows, int N0, int K, int hlen,
                                  const FilterBank& fb, hipStream_t s) {
-    if ((hlen & 1) || K < 1 || K > kMaxFusedLevels || (N0 % (1 << (K + 2))) || N0 >= (1 << 30)) return hipErrorNotSupported;
+    if ((hlen & 1) || K < 2 || K > kMaxFusedLevels || (N0 % (1 << (K + 2))) || N0 >= (1 << 30)) return hipErrorNotSupported;
     Fwd1DFusedArgs a;
     a.in = in; a.app = app; a.rows = rows; a.N0 = N0; a.K = K;
     for (int k = 0; k < kMaxFusedLevels; k++) a.det[k] = k < K ? det[k] : nullptr;

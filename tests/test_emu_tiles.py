@@ -304,7 +304,7 @@ def test_emu_dwt2_stream_batch():
 @pytest.mark.parametrize("wname", ["haar", "db2", "db4", "sym8", "db10", "db20"])
 def test_emu_dwt1_fused_pyramid(wname):
     hlen, dlo, dhi, rlo, rhi = oracle.filters(wname)
-    for si, (rows, N0, K) in enumerate([(1, 4096, 1), (2, 4096, 3), (1, 16384, 6), (3, 1536, 4), (1, 64, 2), (1, 24576, 5)]):
+    for si, (rows, N0, K) in enumerate([(1, 4096, 2), (2, 4096, 3), (1, 16384, 6), (3, 1536, 4), (1, 64, 2), (1, 24576, 5)]):
         if N0 % (1 << (K + 2)):
             continue
         x = oracle.hash_input((rows, N0), 7100 + si)
