@@ -364,6 +364,8 @@ int main(int argc, char** argv) {
     for (int w : {2, 4, 6, 8, 12}) bench_fwd_stream<8, 64, 8, 256>("STREAM fwd db4 TX64 TY8 NT256", a, b, N, B, w);
     for (int w : {2, 4, 6, 8}) bench_fwd_stream<8, 64, 16, 256>("STREAM fwd db4 TX64 TY16 NT256", a, b, N, B, w);
     for (int w : {2, 4, 8}) bench_fwd_stream<8, 64, 4, 128>("STREAM fwd db4 TX64 TY4 NT128", a, b, N, B, w);
+    for (int sg : {16, 32, 64, 128}) bench_fwd_strip2<8, 32, 192, 2>("STRIP2 fwd db4 TX2=32 NT192", a, b, N, B, sg);
+    for (int sg : {16, 32, 64, 128}) bench_fwd_strip2<8, 32, 320, 2>("STRIP2 fwd db4 TX2=32 NT320", a, b, N, B, sg);
     for (int sg : {16, 32, 64, 128}) bench_fwd_strip2<8, 32, 256, 1>("STRIP2 fwd db4 TX2=32 NT256", a, b, N, B, sg);
     for (int sg : {16, 32, 64, 128}) bench_fwd_strip2<8, 32, 256, 2>("STRIP2 fwd db4 TX2=32 NT256", a, b, N, B, sg);
     for (int sg : {16, 32, 64, 128}) bench_fwd_strip2<8, 32, 256, 3>("STRIP2 fwd db4 TX2=32 NT256", a, b, N, B, sg);
