@@ -32,12 +32,12 @@ struct FwdStrip2Args {
     FilterBankI fb;
 };
 
-template <int HLEN, int TX2>
+template <int HLEN, int TX2, int CHUNK2 = 4>
 struct Strip2Geom {
     using P = Pyr2Geom<HLEN, TX2, 4>;  // x geometry is the tile pyramid's
     static constexpr int H = HLEN, C = P::C, E = P::E;
     static constexpr int R1X = P::R1X, S1 = P::S1, PADL = P::PADL, RXA = P::RXA, NV1 = P::NV1, NV2 = P::NV2;
-    static constexpr int CH0 = 16, CH1 = 8, CH2 = 4;      // rows per chunk at the three levels
+    static constexpr int CH2 = CHUNK2, CH1 = 2 * CH2, CH0 = 4 * CH2;  // rows per chunk at the three levels
     static constexpr int D = (3 * C + 1) / 2;             // level-(l+1) row lag, see kernel
     static constexpr int KEEP0 = H - 2;                   // carried (L,H) rows of level l
     static constexpr int KEEP1 = 2 * D - C;               // carried (L,H) rows of level l+1
@@ -50,9 +50,9 @@ struct Strip2Geom {
     static_assert(KEEP1 <= CH1 && KEEP0 <= CH0, "carry copies do not overlap their source");
 };
 
-template <int HLEN, int TX2, int NT, int PF = 2>
+template <int HLEN, int TX2, int NT, int PF = 2, int CHUNK2 = 4>
 PDWT_DEVICE void dwt2_fwd_strip2_wg(const FwdStrip2Args& a, int strip, int seg, int bz, float* smem) {
-    using G = Strip2Geom<HLEN, TX2>;
+    using G = Strip2Geom<HLEN, TX2, CHUNK2>;
     constexpr int H = G::H, C = G::C, E = G::E, R1X = G::R1X, S1 = G::S1, PADL = G::PADL, RXA = G::RXA, NV1 = G::NV1,
                   NV2 = G::NV2, CH0 = G::CH0, CH1 = G::CH1, CH2 = G::CH2, D = G::D, KEEP0 = G::KEEP0, KEEP1 = G::KEEP1,
                   T1R = G::T1R;
@@ -253,12 +253,12 @@ PDWT_DEVICE void dwt2_fwd_strip2_wg(const FwdStrip2Args& a, int strip, int seg, 
 }
 
 #ifndef PDWT_CPU_EMU
-template <int HLEN, int TX2, int NT, int PF = 2>
+template <int HLEN, int TX2, int NT, int PF = 2, int CHUNK2 = 4>
 __global__ void __launch_bounds__(NT) dwt2_fwd_strip2_kernel(const FwdStrip2Args a) {
     extern __shared__ __attribute__((aligned(16))) float pdwt_smem[];
     // consecutive workgroup ids = consecutive column strips of one row segment (neighbours share x-halo in L2)
     const int seg = blockIdx.x / a.strips;
-    dwt2_fwd_strip2_wg<HLEN, TX2, NT, PF>(a, blockIdx.x - seg * a.strips, seg, blockIdx.y, pdwt_smem);
+    dwt2_fwd_strip2_wg<HLEN, TX2, NT, PF, CHUNK2>(a, blockIdx.x - seg * a.strips, seg, blockIdx.y, pdwt_smem);
 }
 #endif
 

@@ -241,7 +241,7 @@ static void bench_inv_pyr2(const char* tag, const float* in, float* out, int N, 
     printf("%-34s N=%d B=%d lds=%6zu  %8.2f us  (two levels in one launch)\n", tag, N, batch, lds, us);
 }
 
-template <int HLEN, int TX2, int NT, int PF>
+template <int HLEN, int TX2, int NT, int PF, int CHUNK2 = 4>
 static void bench_fwd_strip2(const char* tag, const float* in, float* out, int N, int batch, int seg2) {
     if (skip(tag)) return;
     FwdStrip2Args a;
@@ -254,8 +254,11 @@ static void bench_fwd_strip2(const char* tag, const float* in, float* out, int N
     a.strips = (N / 4 + TX2 - 1) / TX2; a.segs = (N / 4 + seg2 - 1) / seg2;
     memset(&a.fb, 0, sizeof(a.fb));
     for (int i = 0; i < 8; i++) { a.fb.t[i].x = DB4_LO[i]; a.fb.t[i].y = DB4_HI[i]; }
-    const size_t lds = (size_t)Strip2Geom<HLEN, TX2>::LDS_FLOATS * sizeof(float);
-    float us = time_it([&] { hipLaunchKernelGGL((dwt2_fwd_strip2_kernel<HLEN, TX2, NT, PF>), dim3(a.strips * a.segs, batch), dim3(NT), lds, 0, a); });
+    const size_t lds = (size_t)Strip2Geom<HLEN, TX2, CHUNK2>::LDS_FLOATS * sizeof(float);
+    if (lds > 64 * 1024)
+        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(dwt2_fwd_strip2_kernel<HLEN, TX2, NT, PF, CHUNK2>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    float us = time_it([&] { hipLaunchKernelGGL((dwt2_fwd_strip2_kernel<HLEN, TX2, NT, PF, CHUNK2>), dim3(a.strips * a.segs, batch), dim3(NT), lds, 0, a); });
     printf("%-24s PF=%d seg2=%3d wgs=%5d N=%d B=%d lds=%6zu  %8.2f us  (two levels in one launch)\n", tag, PF, seg2, a.strips * a.segs, N, batch, lds, us);
 }
 
@@ -364,6 +367,9 @@ int main(int argc, char** argv) {
     for (int w : {2, 4, 6, 8, 12}) bench_fwd_stream<8, 64, 8, 256>("STREAM fwd db4 TX64 TY8 NT256", a, b, N, B, w);
     for (int w : {2, 4, 6, 8}) bench_fwd_stream<8, 64, 16, 256>("STREAM fwd db4 TX64 TY16 NT256", a, b, N, B, w);
     for (int w : {2, 4, 8}) bench_fwd_stream<8, 64, 4, 128>("STREAM fwd db4 TX64 TY4 NT128", a, b, N, B, w);
+    for (int sg : {16, 32, 64, 128}) bench_fwd_strip2<8, 32, 256, 1, 8>("STRIP2 fwd db4 TX2=32 NT256 CH2=8", a, b, N, B, sg);
+    for (int sg : {16, 32, 64, 128}) bench_fwd_strip2<8, 32, 512, 1, 8>("STRIP2 fwd db4 TX2=32 NT512 CH2=8", a, b, N, B, sg);
+    for (int sg : {16, 32, 64, 128}) bench_fwd_strip2<8, 32, 512, 1, 16>("STRIP2 fwd db4 TX2=32 NT512 CH2=16", a, b, N, B, sg);
     for (int sg : {16, 32, 64, 128}) bench_fwd_strip2<8, 32, 192, 2>("STRIP2 fwd db4 TX2=32 NT192", a, b, N, B, sg);
     for (int sg : {16, 32, 64, 128}) bench_fwd_strip2<8, 32, 320, 2>("STRIP2 fwd db4 TX2=32 NT320", a, b, N, B, sg);
     for (int sg : {16, 32, 64, 128}) bench_fwd_strip2<8, 32, 256, 1>("STRIP2 fwd db4 TX2=32 NT256", a, b, N, B, sg);
