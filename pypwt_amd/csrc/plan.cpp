@@ -1222,23 +1222,28 @@ int pdwt_time_level(pdwt_handle h, int level, int inverse, int reps, float* ms_p
     if (!ms_per_launch || reps < 1 || level < 1 || level > h->info.nlevels)
         return fail(PDWT_ERR_ARG, "pdwt_time_level: bad arguments");
     DeviceGuard guard(h->device);
-    const bool was_timing = h->timing;
+    struct Scope {  // restores the timing flag and frees the events on every exit path
+        pdwt_plan* p;
+        bool was;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        ~Scope() {
+            p->timing = was;
+            if (e0) (void)hipEventDestroy(e0);
+            if (e1) (void)hipEventDestroy(e1);
+        }
+    } sc{h, h->timing};
     h->timing = false;
-    hipEvent_t e0, e1;
-    HIP_TRY(hipEventCreate(&e0));
-    HIP_TRY(hipEventCreate(&e1));
+    HIP_TRY(hipEventCreate(&sc.e0));
+    HIP_TRY(hipEventCreate(&sc.e1));
     int rc = PDWT_OK;
     for (int i = 0; i < 3 && rc == PDWT_OK; i++) rc = inverse ? inverse_impl(h, level) : forward_impl(h, level);
     HIP_TRY(hipStreamSynchronize(h->stream));
-    HIP_TRY(hipEventRecord(e0, h->stream));
+    HIP_TRY(hipEventRecord(sc.e0, h->stream));
     for (int i = 0; i < reps && rc == PDWT_OK; i++) rc = inverse ? inverse_impl(h, level) : forward_impl(h, level);
-    HIP_TRY(hipEventRecord(e1, h->stream));
-    HIP_TRY(hipEventSynchronize(e1));
+    HIP_TRY(hipEventRecord(sc.e1, h->stream));
+    HIP_TRY(hipEventSynchronize(sc.e1));
     float ms = 0.f;
-    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
-    h->timing = was_timing;
+    HIP_TRY(hipEventElapsedTime(&ms, sc.e0, sc.e1));
     *ms_per_launch = ms / (float)reps;
     return rc;
 }
