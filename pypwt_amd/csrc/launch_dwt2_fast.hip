@@ -54,6 +54,29 @@ static hipError_t run_fwd_fast(const Fwd2DArgs& g, int batch, hipStream_t s) {
     return hipGetLastError();
 }
 
+// One tile per workgroup (no streaming), for MID-SIZE levels: at 2048^2 (one image) 512 workgroups of 512
+// threads with 64x32 tiles are all resident at once and the level takes 7.9 us instead of 8.5-9.0 us with the
+// small streaming tiles, whose 2048 tiles need a second round of workgroups (profiles/r01c_kbench_2048.txt).
+template <int HLEN, int TX, int TY, int NT>
+static hipError_t run_fwd_fast_tile(const Fwd2DArgs& g, int batch, hipStream_t s) {
+    static bool big[64] = {};
+    constexpr size_t lds = (size_t)fwd2d_fast_lds_floats<HLEN, TX, TY>() * sizeof(float);
+    hipError_t e = allow_big_lds(dwt2_fwd_fast_kernel<HLEN, TX, TY, NT>, lds, big);
+    if (e != hipSuccess) return e;
+    Fwd2DFastArgs a;
+    a.in = g.in; a.A = g.A; a.H = g.H; a.V = g.V; a.D = g.D;
+    a.Nr = g.Nr; a.Nc = g.Nc; a.Nr2 = g.Nr2; a.Nc2 = g.Nc2;
+    a.in_bstride = g.in_bstride; a.out_bstride = g.out_bstride;
+    a.tiles_x = cdiv(g.Nc2, TX); a.tiles_y = cdiv(g.Nr2, TY);
+    interleave(a.fb, g.fb);
+    const int chunk = (a.tiles_x * a.tiles_y + 7) / 8;
+    hipLaunchKernelGGL((dwt2_fwd_fast_kernel<HLEN, TX, TY, NT>), dim3(8 * chunk, batch), dim3(NT), lds, s, a);
+    return hipGetLastError();
+}
+
+// levels whose input is between 2^20 and 2^22 samples (one 2048^2 image): the single-round tile shapes
+static bool mid_size(long long samples) { return samples > (1LL << 20) && samples <= (1LL << 22); }
+
 template <int HLEN, int TX, int TY, int NT>
 static hipError_t run_inv_fast(const Inv2DArgs& g, int batch, hipStream_t s) {
     static bool big[64] = {};
@@ -80,6 +103,14 @@ hipError_t try_launch_dwt2_fwd_fast(const Fwd2DArgs& a, int batch, hipStream_t s
     if ((a.Nc & 3) || (a.in_bstride & 3) || (a.out_bstride & 1)) return hipErrorNotSupported;
     if (!aligned16(a.in) || !aligned16(a.A) || !aligned16(a.H) || !aligned16(a.V) || !aligned16(a.D))
         return hipErrorNotSupported;
+    if (a.hlen <= 8 && mid_size((long long)batch * a.Nr * a.Nc)) {
+        switch (a.hlen) {
+            case 2: return run_fwd_fast_tile<2, 64, 32, 512>(a, batch, s);
+            case 4: return run_fwd_fast_tile<4, 64, 32, 512>(a, batch, s);
+            case 6: return run_fwd_fast_tile<6, 64, 32, 512>(a, batch, s);
+            case 8: return run_fwd_fast_tile<8, 64, 32, 512>(a, batch, s);
+        }
+    }
     switch (a.hlen) {
 #define X(h)                                                                \
     case h:                                                                 \
@@ -97,6 +128,14 @@ hipError_t try_launch_dwt2_inv_fast(const Inv2DArgs& a, int batch, hipStream_t s
     if ((a.Ncc & 3) || a.Nc != 2 * a.Ncc || (a.in_bstride & 3) || (a.out_bstride & 3)) return hipErrorNotSupported;
     if (!aligned16(a.out) || !aligned16(a.A) || !aligned16(a.H) || !aligned16(a.V) || !aligned16(a.D))
         return hipErrorNotSupported;
+    if (a.hlen <= 8 && mid_size((long long)batch * a.Nr * a.Nc)) {  // 128x16 tiles, 512 threads: 8.0 vs 8.8 us at 2048^2
+        switch (a.hlen) {
+            case 2: return run_inv_fast<2, 128, 16, 512>(a, batch, s);
+            case 4: return run_inv_fast<4, 128, 16, 512>(a, batch, s);
+            case 6: return run_inv_fast<6, 128, 16, 512>(a, batch, s);
+            case 8: return run_inv_fast<8, 128, 16, 512>(a, batch, s);
+        }
+    }
     switch (a.hlen) {
 #define X(h)                                                                \
     case h:                                                                 \
