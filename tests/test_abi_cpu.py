@@ -165,3 +165,24 @@ def test_tiled_wavelets_needs_a_gpu_and_says_so():
     from pypwt_amd.tiled import TiledWavelets
     with pytest.raises(RuntimeError, match="HIP device|import torch before"):
         TiledWavelets(np.zeros((64, 64), dtype=np.float32), "db2", 2)
+
+
+def test_python_class_has_the_reference_api_surface():
+    """Methods and properties of the reference's `cdef class Wavelets` (src/pypwt.pyx:93-615)
+    exist on the drop-in class with the same constructor parameters."""
+    import inspect
+    from pypwt_amd import Wavelets, Wavelets64
+    methods = ["info", "coeff_only", "set_image", "forward", "inverse", "soft_threshold", "hard_threshold", "shrink",
+               "norm1", "norm2sq", "add_wavelet", "set_coeff", "set_wavelets_filters", "image_int_ptr", "coeff_int_ptr",
+               "div2", "_checkarray", "_compute_sizes"]
+    for cls in (Wavelets, Wavelets64):
+        for m in methods:
+            assert callable(getattr(cls, m)), m
+        for prop in ("coeffs", "image"):
+            assert isinstance(getattr(cls, prop), property), prop
+        params = list(inspect.signature(cls.__init__).parameters)
+        assert params[:8] == ["self", "img", "wname", "levels", "do_separable", "do_cycle_spinning", "do_swt", "ndim"]
+    sig = inspect.signature(Wavelets.soft_threshold).parameters
+    assert list(sig)[1:] == ["beta", "do_threshold_appcoeffs", "normalize"]
+    assert sig["do_threshold_appcoeffs"].default == 0 and sig["normalize"].default == 0   # pypwt.pyx:386
+    assert inspect.signature(Wavelets.shrink).parameters["do_threshold_appcoeffs"].default == 1  # pypwt.pyx:425
