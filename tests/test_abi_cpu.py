@@ -184,5 +184,5 @@ def test_python_class_has_the_reference_api_surface():
         assert params[:8] == ["self", "img", "wname", "levels", "do_separable", "do_cycle_spinning", "do_swt", "ndim"]
     sig = inspect.signature(Wavelets.soft_threshold).parameters
     assert list(sig)[1:] == ["beta", "do_threshold_appcoeffs", "normalize"]
-    assert sig["do_threshold_appcoeffs"].default == 0 and sig["normalize"].default == 0   # pypwt.pyx:386
-    assert inspect.signature(Wavelets.shrink).parameters["do_threshold_appcoeffs"].default == 1  # pypwt.pyx:425
+    assert sig["do_threshold_appcoeffs"].default == 0 and sig["normalize"].default == 0   # pypwt.pyx:362
+    assert inspect.signature(Wavelets.shrink).parameters["do_threshold_appcoeffs"].default == 1  # pypwt.pyx:406
