@@ -231,33 +231,78 @@ PDWT_DEVICE void inv1d_fused_range(int lo, int hi, int H2, int& clo, int& chi) {
     chi = ((hi - 1 + S) >> 1) - C2 + H2;
 }
 
-// LDS floats: two (a,d) pair buffers sized for the two largest consecutive levels
+// ---- planar layout of the inverse pyramid -------------------------------------------------------
+// Level k keeps its approximation and detail coefficients in two FLOAT planes; coefficient c of level k
+// sits at plane[kInvFront + c - lok4], lok4 = the 4-aligned floor of the first needed coefficient, so
+// plane positions are congruent to global indices mod 4:
+//   * the detail segment is staged in whole 16-B groups (global 16-B loads, ds_write_b128, no scatter);
+//   * a work item synthesises EIGHT consecutive samples 8m .. 8m+7 of level k-1 from the coefficients
+//     4m .. 4m+3: its window starts at coefficient 4m - C2, always at offset O = (-C2) mod 4 inside an
+//     aligned group (a compile-time constant), is read with ds_read_b128 from both planes, and the eight
+//     results leave as two 16-B writes (into the next approximation plane, or to HBM at level 0).
+// The earlier (a,d)-pair layout wrote every intermediate sample with a 4-B LDS store at a 32-B lane
+// stride: rocprofv3 counted 7.2 M LDS bank-conflict cycles per launch against 2.5 M LDS-active cycles.
+constexpr int kInvFront = 8;
+
+constexpr int inv1d_fused_cap(int T0, int hlen, int parity) {  // plane capacity: odd levels (1), even levels (0)
+    const int H2 = hlen / 2;
+    return parity ? ((T0 / 2 + 2 * H2 + 32 + 3) & ~3) : ((T0 / 4 + 3 * H2 + 32 + 3) & ~3);
+}
+
 constexpr int inv1d_fused_lds_floats(int T0, int hlen, int K) {
     (void)K;
-    const int H2 = hlen / 2;
-    const int m1 = T0 / 2 + 2 * H2 + 8;   // generous bound on the level-1 coefficient count
-    const int m2 = T0 / 4 + 3 * H2 + 8;
-    // + 8 pairs in front (the 4-sample synthesis blocks read a little outside their range) + the range table
-    return 2 * (m1 + m2) + 32 + 16 + 32;
+    return 2 * (inv1d_fused_cap(T0, hlen, 1) + inv1d_fused_cap(T0, hlen, 0)) + 32;  // + the range table
 }
+
+// 16-B groups [first4, first4 + 4 ngroups) of a periodic row (4 | N, first4 a multiple of 4, possibly
+// negative) -> dst (16-B aligned); UN loads in flight per thread before the first LDS write
+template <int NT, int UN>
+PDWT_DEVICE void stage_groups(int tid, const float* PDWT_RESTRICT row, int N, int first4, int ngroups, float* dst) {
+    const int w0 = true_mod(first4, N);
+    const bool simple = w0 + 4 * ngroups <= 2 * N;  // at most one wrap
+    for (int base = tid; base < ngroups; base += NT * UN) {
+        v4f v[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            int g = base + u * NT;
+            if (g >= ngroups) g = ngroups - 1;
+            int pos = w0 + 4 * g;
+            if (simple) {
+                if (pos >= N) pos -= N;
+            } else {
+                pos = true_mod(pos, N);
+            }
+            v[u] = *reinterpret_cast<const v4f*>(row + pos);
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int g = base + u * NT;
+            if (g < ngroups) *reinterpret_cast<v4f*>(dst + 4 * g) = v[u];
+        }
+    }
+}
+
+PDWT_DEVICE int floor4(int x) { return x - true_mod(x, 4); }
 
 template <int HLEN, int T0, int NT>
 PDWT_DEVICE void dwt1_inv_fused_tile(const Inv1DFusedArgs& a, int bx, int row, float* smem) {
-    constexpr int H2 = HLEN / 2, C2 = H2 / 2;
+    constexpr int H2 = HLEN / 2, C2 = H2 / 2, S = (H2 & 1) ? 0 : 1;
+    constexpr int O = (4 - (C2 & 3)) & 3;       // offset of the window's first element in its aligned group
+    constexpr int NW = H2 + 3 + S;              // window elements of four consecutive coefficients
+    constexpr int NVI = (O + NW + 3) & ~3;      // floats read per plane and work item
+    constexpr int NJ = H2 + S;                  // taps pairs per coefficient
     const int K = a.K;
-    constexpr int M1 = T0 / 2 + 2 * H2 + 8;
-    constexpr int M2 = T0 / 4 + 3 * H2 + 8;
-    v2f* bufP = reinterpret_cast<v2f*>(smem) + 8;  // (a,d) pairs of the odd levels 1,3,5.. (8 pairs of front slack)
-    v2f* bufQ = bufP + M1 + 8;                     // even levels 2,4,6..
-    int* rng = reinterpret_cast<int*>(smem + 2 * (M1 + M2) + 32 + 16);  // [2k], [2k+1] = range of level k
+    constexpr int CAP1 = inv1d_fused_cap(T0, HLEN, 1), CAP0 = inv1d_fused_cap(T0, HLEN, 0);
+    float* aP = smem;            // odd levels 1,3,5..: approximation plane
+    float* dP = aP + CAP1;       //                     detail plane
+    float* aQ = dP + CAP1;       // even levels 2,4,..
+    float* dQ = aQ + CAP0;
+    int* rng = reinterpret_cast<int*>(dQ + CAP0);  // [2k], [2k+1] = coefficient range of level k
 
-    // coefficient range of every level, from the owned output range: computed once (a per-level
-    // recomputation is O(K^2) scalar work per wave and showed up as 2x more SALU than VALU instructions),
-    // kept in LDS because a runtime-indexed register array would live in scratch
     const int lo0 = bx * T0;
     const int hi0 = (lo0 + T0 > a.N0) ? a.N0 : lo0 + T0;
     PDWT_FOR_THREADS(tid, NT) {
-        if (tid == 0) {
+        if (tid == 0) {  // ranges once per workgroup (a per-level recomputation is O(K^2) scalar work per wave)
             int l = lo0, h = hi0;
             rng[0] = l;
             rng[1] = h;
@@ -272,60 +317,105 @@ PDWT_DEVICE void dwt1_inv_fused_tile(const Inv1DFusedArgs& a, int bx, int row, f
         }
     }
     PDWT_SYNC();
-    auto range_of = [&](int level, int& l, int& h) {
-        l = rng[2 * level];
-        h = rng[2 * level + 1];
-    };
 
-    // ---- approximation A_K -> .x of level K's buffer
-    {
-        v2f* cur = (K & 1) ? bufP : bufQ;
-        const int NK = a.N0 >> K;
-        int loK, hiK;
-        range_of(K, loK, hiK);
-        PDWT_FOR_THREADS(tid, NT) {
-            const float* PDWT_RESTRICT gA = a.app + (long long)row * NK;
-            stage_periodic_f4<NT, 2, 2>(tid, gA, NK, loK, hiK - loK, reinterpret_cast<float*>(cur), 0);
+    // packed tap pairs: (sample 2c, sample 2c+1) of coefficient c accumulate bc(a_e) * PA[j] + bc(d_e) * PD[j],
+    // e = c - C2 + j.  S = 0: both samples use base c, taps (f[H-2-2j], f[H-1-2j]).  S = 1: sample 2c has base c
+    // and tap f[H-1-2j] (j < H2), sample 2c+1 has base c+1, i.e. element j with tap f[H-2j] (j >= 1).
+    v2f PA[NJ], PD[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        if (S == 0) {
+            PA[j] = mk2(a.fb.t[HLEN - 2 - 2 * j].x, a.fb.t[HLEN - 1 - 2 * j].x);
+            PD[j] = mk2(a.fb.t[HLEN - 2 - 2 * j].y, a.fb.t[HLEN - 1 - 2 * j].y);
+        } else {
+            const float l0 = (j < H2) ? a.fb.t[(j < H2) ? HLEN - 1 - 2 * j : 0].x : 0.f;
+            const float h0 = (j < H2) ? a.fb.t[(j < H2) ? HLEN - 1 - 2 * j : 0].y : 0.f;
+            const float l1 = (j >= 1) ? a.fb.t[(j >= 1) ? HLEN - 2 * j : 0].x : 0.f;
+            const float h1 = (j >= 1) ? a.fb.t[(j >= 1) ? HLEN - 2 * j : 0].y : 0.f;
+            PA[j] = mk2(l0, l1);
+            PD[j] = mk2(h0, h1);
         }
     }
-    for (int k = K; k >= 1; --k) {
-        v2f* cur = (k & 1) ? bufP : bufQ;  // level k pairs: .x filled (A_K or previous synthesis)
-        v2f* nxt = (k & 1) ? bufQ : bufP;  // level k-1
-        const int Nk = a.N0 >> k;
-        int lok, hik, lom, him;  // level k coefficients, level k-1 samples
-        range_of(k, lok, hik);
-        range_of(k - 1, lom, him);
-        const int m = hik - lok;
-        // details D_k -> .y
+
+    // ---- A_K and D_K -> planes of level K
+    {
+        const int NK = a.N0 >> K;
+        const int loK = rng[2 * K], hiK = rng[2 * K + 1];
+        const int lo4 = floor4(loK);
+        const int ng = (hiK - lo4 + 3) >> 2;
+        float* pa = ((K & 1) ? aP : aQ) + kInvFront;
+        float* pd = ((K & 1) ? dP : dQ) + kInvFront;
         PDWT_FOR_THREADS(tid, NT) {
-            const float* PDWT_RESTRICT gD = a.det[k - 1] + (long long)row * Nk;
-            stage_periodic_f4<NT, 4, 2>(tid, gD, Nk, lok, m, reinterpret_cast<float*>(cur), 1);
+            stage_groups<NT, 2>(tid, a.app + (long long)row * NK, NK, lo4, ng, pa);
+            stage_groups<NT, 2>(tid, a.det[K - 1] + (long long)row * NK, NK, lo4, ng, pd);
         }
-        PDWT_SYNC();
-        // synthesis of level k-1 samples [lom, him): work item = the 4-aligned block of samples 4b .. 4b+3,
-        // i.e. coefficient indices 2b and 2b+1 (inv_row_synth4: 16-B LDS reads, all four results from
-        // one window of pairs, 16-B stores at the last level); samples outside [lom, him) are dropped
+    }
+    PDWT_SYNC();
+
+    for (int k = K; k >= 1; --k) {
+        const float* ca = ((k & 1) ? aP : aQ) + kInvFront;   // level k planes
+        const float* cd = ((k & 1) ? dP : dQ) + kInvFront;
+        float* na = ((k & 1) ? aQ : aP) + kInvFront;         // level k-1 planes
+        float* nd = ((k & 1) ? dQ : dP) + kInvFront;
+        const int lok4 = floor4(rng[2 * k]);
+        const int lom = rng[2 * k - 2], him = rng[2 * k - 1];
+        const int lom4 = floor4(lom);
         PDWT_FOR_THREADS(tid, NT) {
             float* PDWT_RESTRICT out = a.out + (long long)row * a.N0;
-            const int b_lo = lom >> 2, b_hi = (him - 1) >> 2;  // arithmetic shifts: floor, lom may be negative
-            const int pe = (C2 + lok) & 1;                      // parity that makes the window origin 16-B aligned
-            for (int i = tid; i <= b_hi - b_lo; i += NT) {
-                const int kk = 2 * (b_lo + i);
-                const v2f* base = cur + (kk - C2 - lok - pe);
-                float res[4];
-                if (pe) inv_row_synth4<HLEN, 1>(base, a.fb, res);
-                else inv_row_synth4<HLEN, 0>(base, a.fb, res);
-                const int g0 = 2 * kk;
-                if (k > 1) {
+            const int m_lo = lom >> 3, m_hi = (him - 1) >> 3;  // arithmetic shifts: floor
+            for (int i = tid; i <= m_hi - m_lo; i += NT) {
+                const int m = m_lo + i;
+                const int base = 4 * m - C2 - O - lok4;  // plane position of the window's aligned group
+                float va[NVI], vd[NVI];
+                v4f wa[NVI / 4], wd[NVI / 4];
 #pragma unroll
-                    for (int c = 0; c < 4; ++c)
-                        if (g0 + c >= lom && g0 + c < him) nxt[g0 + c - lom].x = res[c];
-                } else {
-                    // level 0: [lom, him) = [bx T0, min(.., N0)) is a union of whole blocks inside [0, N0)
-                    f32x4 v;
-                    v.x = res[0]; v.y = res[1]; v.z = res[2]; v.w = res[3];
-                    *reinterpret_cast<f32x4*>(out + g0) = v;
+                for (int q = 0; q < NVI / 4; ++q) {
+                    wa[q] = lds_load16(ca + base + 4 * q);
+                    wd[q] = lds_load16(cd + base + 4 * q);
                 }
+#pragma unroll
+                for (int q = 0; q < NVI / 4; ++q) {
+                    lds_pin(wa[q]);
+                    lds_pin(wd[q]);
+                    va[4 * q] = wa[q].x; va[4 * q + 1] = wa[q].y; va[4 * q + 2] = wa[q].z; va[4 * q + 3] = wa[q].w;
+                    vd[4 * q] = wd[q].x; vd[4 * q + 1] = wd[q].y; vd[4 * q + 2] = wd[q].z; vd[4 * q + 3] = wd[q].w;
+                }
+                v2f acc[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    acc[c] = mk2(0.f, 0.f);
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        // S = 1: the first element feeds only the even sample and the last only the odd one.
+                        // Those are done as scalar FMAs: the other lane's tap is a structural zero, and the
+                        // element may lie outside the staged range (0 x uninitialised LDS would be NaN).
+                        if (S == 1 && j == 0) {
+                            acc[c].x = pdwt_fma(va[O + c], PA[0].x, acc[c].x);
+                            acc[c].x = pdwt_fma(vd[O + c], PD[0].x, acc[c].x);
+                        } else if (S == 1 && j == NJ - 1) {
+                            acc[c].y = pdwt_fma(va[O + c + j], PA[j].y, acc[c].y);
+                            acc[c].y = pdwt_fma(vd[O + c + j], PD[j].y, acc[c].y);
+                        } else {
+                            acc[c] = fma2(bc(va[O + c + j]), PA[j], acc[c]);
+                            acc[c] = fma2(bc(vd[O + c + j]), PD[j], acc[c]);
+                        }
+                    }
+                }
+                f32x4 r0, r1;
+                r0.x = acc[0].x; r0.y = acc[0].y; r0.z = acc[1].x; r0.w = acc[1].y;
+                r1.x = acc[2].x; r1.y = acc[2].y; r1.z = acc[3].x; r1.w = acc[3].y;
+                if (k > 1) {  // samples outside [lom, him) land in slots nothing valid reads
+                    float* dst = na + 8 * m - lom4;
+                    *reinterpret_cast<f32x4*>(dst) = r0;
+                    *reinterpret_cast<f32x4*>(dst + 4) = r1;
+                } else {      // level 0: [lom, him) = [bx T0, min(.., N0)) is a union of whole 8-sample blocks
+                    *reinterpret_cast<f32x4*>(out + 8 * m) = r0;
+                    *reinterpret_cast<f32x4*>(out + 8 * m + 4) = r1;
+                }
+            }
+            if (k > 1) {  // the details of level k-1, into the planes this phase does not read
+                const int Nm = a.N0 >> (k - 1);
+                stage_groups<NT, 4>(tid, a.det[k - 2] + (long long)row * Nm, Nm, lom4, (him - lom4 + 3) >> 2, nd);
             }
         }
         PDWT_SYNC();
