@@ -1,4 +1,6 @@
 // launch_dwt2.hip -- instantiations + launchers of the fused 2D DWT level kernels (gfx950).
+#include <stdlib.h>
+
 #include "dwt2_kernels.hpp"
 #include "launch.hpp"
 #include "launch_util.hpp"
@@ -37,6 +39,8 @@ static hipError_t run_inv(const Inv2DArgs& a, int batch, hipStream_t s) {
 // pyramids) are not compiled; every level runs through the generic kernels of this file / launch_dwt1.hip
 hipError_t try_launch_dwt2_fwd_fast(const Fwd2DArgs&, int, hipStream_t) { return hipErrorNotSupported; }
 hipError_t try_launch_dwt2_inv_fast(const Inv2DArgs&, int, hipStream_t) { return hipErrorNotSupported; }
+hipError_t try_launch_dwt2_fwd_wave(const Fwd2DArgs&, int, hipStream_t, int) { return hipErrorNotSupported; }
+hipError_t try_launch_dwt2_inv_wave(const Inv2DArgs&, int, hipStream_t, int) { return hipErrorNotSupported; }
 bool dwt2_pyramid_supported(int, int, int) { return false; }
 hipError_t launch_dwt2_fwd_pyr2(const real_t*, real_t* const[3], real_t* const[4], int, int, int, const FilterBank&, int,
                                 hipStream_t) { return hipErrorNotSupported; }
@@ -56,7 +60,21 @@ constexpr int kTyLong = 8;   // long filters: a 32-row tile of doubles would not
 constexpr int kTyLong = 32;
 #endif
 
+// The wave-per-tile kernels take the levels that are large enough to be bandwidth-bound (>= 2^22 samples
+// enter the level: 2048^2 of one image); smaller levels are launch-bound and stay with the LDS tiles
+// (numbers in launch_dwt2_wave.hip).  PDWT_NO_WAVE=1 (read once) keeps the LDS tiles everywhere, PDWT_WAVE_MIN
+// overrides the threshold (log2 samples): A/B measurements.
+static bool wave_kernels_for(long long samples) {
+    static const bool on = getenv("PDWT_NO_WAVE") == nullptr;
+    static const int min_log2 = getenv("PDWT_WAVE_MIN") ? atoi(getenv("PDWT_WAVE_MIN")) : 22;
+    return on && samples >= (1LL << min_log2);
+}
+
 hipError_t launch_dwt2_fwd(const Fwd2DArgs& a, int batch, hipStream_t s) {
+    if (wave_kernels_for((long long)batch * a.Nr * a.Nc)) {
+        const hipError_t e = try_launch_dwt2_fwd_wave(a, batch, s);
+        if (e != hipErrorNotSupported) return e;
+    }
     {
         const hipError_t e = try_launch_dwt2_fwd_fast(a, batch, s);
         if (e != hipErrorNotSupported) return e;
@@ -75,6 +93,10 @@ hipError_t launch_dwt2_fwd(const Fwd2DArgs& a, int batch, hipStream_t s) {
 }
 
 hipError_t launch_dwt2_inv(const Inv2DArgs& a, int batch, hipStream_t s) {
+    if (wave_kernels_for((long long)batch * a.Nr * a.Nc)) {
+        const hipError_t e = try_launch_dwt2_inv_wave(a, batch, s);
+        if (e != hipErrorNotSupported) return e;
+    }
     {
         const hipError_t e = try_launch_dwt2_inv_fast(a, batch, s);
         if (e != hipErrorNotSupported) return e;

@@ -1,0 +1,118 @@
+// launch_dwt2_wave.hip -- launchers of the wave-per-tile 2D DWT level kernels (dwt2_wave_kernels.hpp).
+//
+// try_launch_* return hipErrorNotSupported when the level does not meet the kernels' preconditions
+// (even filter length <= 8, row length a multiple of 4 (forward) / coefficient row length even and
+// Nc == 2 Ncc (inverse), 16-B aligned buffers); the caller then falls back to the LDS-tiled kernels.
+//
+// Geometry: a wavefront owns a strip of 256 image columns and `seg` output rows (forward) or coefficient
+// rows (inverse).  The host picks `seg` so that a level has about ONE wavefront per SIMD (1024 on the
+// chip) and never less than one unrolled group: short segments re-read the hlen-2 rows they share with
+// their neighbour more often, long ones leave SIMDs idle.  Measured (tools/wbench.hip, db4, one image,
+// profiles/r02a_wbench_b1.txt): 4096^2 forward 24.8 / 23.1 / 22.1 / 21.7 / 27.8 us with 8192 / 4096 / 2048 /
+// 1024 / 512 wavefronts (LDS tiles: 25.2 one tile per workgroup, 23.8 streaming; float4 copy 19.6);
+// inverse 28.2 / 24.9 / 22.7 / 22.7 / 29.0 us (LDS tiles 23.6).  Register prefetch (3 rows in flight per
+// wavefront), not occupancy, covers the memory latency.  Below 2048^2 a level is launch-bound (a
+// 2 MB float4 copy takes 3.3 us, an empty kernel 2.5) and the LDS tiles' shorter per-workgroup critical
+// path wins (1024^2: 4.3 vs 4.8 us): the host keeps them there (launch_dwt2.hip).
+// The predicate-free kernels (GUARD = false) need whole strips and whole groups; anything else
+// runs the guarded twins.
+#include "dwt2_wave_kernels.hpp"
+#include "launch.hpp"
+#include "launch_util.hpp"
+
+namespace pdwt {
+
+static void interleave(FilterBankI& o, const FilterBank& fb) {
+    for (int i = 0; i < kMaxTaps; i++) {
+        o.t[i].x = fb.lo[i];
+        o.t[i].y = fb.hi[i];
+    }
+}
+
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+constexpr int kWaveTarget = 1024;  // wavefronts per launch the segment length aims for (1 per SIMD)
+
+// rows per wavefront: multiple of `unit`, about strips * ceil(rows / seg) * batch = kWaveTarget, at most 64
+static int pick_seg(int rows, int strips, int batch, int unit, int hint) {
+    long long seg = hint > 0 ? hint : ((long long)rows * strips * batch) / kWaveTarget;
+    seg = (seg / unit) * unit;
+    if (seg < unit) seg = unit;
+    if (hint <= 0 && seg > 64) seg = (64 / unit) * unit;
+    return (int)seg;
+}
+
+template <int HLEN>
+static hipError_t run_fwd(const Fwd2DArgs& g, int batch, int seg_hint, hipStream_t s) {
+    constexpr int NT = 256, G2 = FwdWaveGeom<HLEN>::GR / 2;
+    FwdWaveArgs a;
+    a.in = g.in; a.A = g.A; a.H = g.H; a.V = g.V; a.D = g.D;
+    a.Nr = g.Nr; a.Nc = g.Nc; a.Nr2 = g.Nr2; a.Nc2 = g.Nc2;
+    a.in_bstride = g.in_bstride; a.out_bstride = g.out_bstride;
+    a.strips = cdiv(g.Nc, 256);
+    a.seg_out = pick_seg(g.Nr2, a.strips, batch, G2, seg_hint);
+    a.segs = cdiv(g.Nr2, a.seg_out);
+    interleave(a.fb, g.fb);
+    const int nblk = cdiv(a.strips * a.segs, NT / 64);
+    const dim3 grid(8 * cdiv(nblk, 8), batch);
+    const bool plain = (g.Nc % 256) == 0 && (g.Nr2 % G2) == 0;
+    if (plain) hipLaunchKernelGGL((dwt2_fwd_wave_kernel<HLEN, false, NT>), grid, dim3(NT), 0, s, a);
+    else hipLaunchKernelGGL((dwt2_fwd_wave_kernel<HLEN, true, NT>), grid, dim3(NT), 0, s, a);
+    return hipGetLastError();
+}
+
+template <int HLEN>
+static hipError_t run_inv(const Inv2DArgs& g, int batch, int seg_hint, hipStream_t s) {
+    constexpr int NT = 256, GR = InvWaveGeom<HLEN>::GR;
+    InvWaveArgs a;
+    a.A = g.A; a.H = g.H; a.V = g.V; a.D = g.D; a.out = g.out;
+    a.Nrc = g.Nrc; a.Ncc = g.Ncc; a.Nr = g.Nr; a.Nc = g.Nc;
+    a.in_bstride = g.in_bstride; a.out_bstride = g.out_bstride;
+    a.strips = cdiv(g.Ncc, 128);
+    a.seg_pairs = pick_seg(g.Nrc, a.strips, batch, GR, seg_hint);
+    a.segs = cdiv(g.Nrc, a.seg_pairs);
+    interleave(a.fb, g.fb);
+    for (int d = 0; d < HLEN / 2; d++) {
+        a.pl[d].x = g.fb.lo[HLEN - 2 - 2 * d]; a.pl[d].y = g.fb.lo[HLEN - 1 - 2 * d];
+        a.ph[d].x = g.fb.hi[HLEN - 2 - 2 * d]; a.ph[d].y = g.fb.hi[HLEN - 1 - 2 * d];
+    }
+    const int nblk = cdiv(a.strips * a.segs, NT / 64);
+    const dim3 grid(8 * cdiv(nblk, 8), batch);
+    const bool plain = (g.Ncc % 128) == 0 && (g.Nrc % GR) == 0 && g.Nr == 2 * g.Nrc;
+    if (plain) hipLaunchKernelGGL((dwt2_inv_wave_kernel<HLEN, false, NT>), grid, dim3(NT), 0, s, a);
+    else hipLaunchKernelGGL((dwt2_inv_wave_kernel<HLEN, true, NT>), grid, dim3(NT), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t try_launch_dwt2_fwd_wave(const Fwd2DArgs& a, int batch, hipStream_t s, int seg_hint) {
+    if ((a.hlen & 1) || a.hlen < 2 || a.hlen > 8) return hipErrorNotSupported;
+    if ((a.Nc & 3) || (a.in_bstride & 3) || (a.out_bstride & 1) || a.Nc2 * 2 != a.Nc) return hipErrorNotSupported;
+    if ((long long)a.Nc * 4 >= (1LL << 31)) return hipErrorNotSupported;  // 32-bit byte offsets inside a row
+    if (!aligned16(a.in) || !aligned16(a.A) || !aligned16(a.H) || !aligned16(a.V) || !aligned16(a.D))
+        return hipErrorNotSupported;
+    switch (a.hlen) {
+        case 2: return run_fwd<2>(a, batch, seg_hint, s);
+        case 4: return run_fwd<4>(a, batch, seg_hint, s);
+        case 6: return run_fwd<6>(a, batch, seg_hint, s);
+        case 8: return run_fwd<8>(a, batch, seg_hint, s);
+    }
+    return hipErrorNotSupported;
+}
+
+hipError_t try_launch_dwt2_inv_wave(const Inv2DArgs& a, int batch, hipStream_t s, int seg_hint) {
+    if ((a.hlen & 1) || a.hlen < 2 || a.hlen > 8) return hipErrorNotSupported;
+    if ((a.Ncc & 1) || a.Nc != 2 * a.Ncc || (a.in_bstride & 1) || (a.out_bstride & 3)) return hipErrorNotSupported;
+    if (a.Nr > 2 * a.Nrc || a.Nr < 2 * a.Nrc - 1) return hipErrorNotSupported;
+    if ((long long)a.Nc * 4 >= (1LL << 31)) return hipErrorNotSupported;
+    if (!aligned16(a.out) || !aligned16(a.A) || !aligned16(a.H) || !aligned16(a.V) || !aligned16(a.D))
+        return hipErrorNotSupported;
+    switch (a.hlen) {
+        case 2: return run_inv<2>(a, batch, seg_hint, s);
+        case 4: return run_inv<4>(a, batch, seg_hint, s);
+        case 6: return run_inv<6>(a, batch, seg_hint, s);
+        case 8: return run_inv<8>(a, batch, seg_hint, s);
+    }
+    return hipErrorNotSupported;
+}
+
+}  // namespace pdwt

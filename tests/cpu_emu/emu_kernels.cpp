@@ -13,6 +13,7 @@
 #include "../../pypwt_amd/csrc/dwt2_kernels.hpp"
 #include "../../pypwt_amd/csrc/dwt2_pyramid_kernels.hpp"
 #include "../../pypwt_amd/csrc/dwt2_strip_kernels.hpp"
+#include "../../pypwt_amd/csrc/dwt2_wave_kernels.hpp"
 #include "../../pypwt_amd/csrc/nonsep_kernels.hpp"
 #include "../../pypwt_amd/csrc/swt_kernels.hpp"
 
@@ -495,6 +496,76 @@ EMU_API int emu_dwt2_inv_strip2(const float* l1, const float* l2, int batch, int
     set_bank_i(a.fb, lo, hi, hlen);
     switch (hlen) {
 #define X(h) case h: run_inv_strip2<h, 64, 256>(a, batch); return 0;
+        X(2) X(4) X(6) X(8)
+#undef X
+    }
+    return -1;
+}
+
+// ------------------------------------------------------------------ wave-per-tile 2D level kernels
+static void interleave_bank(FilterBankI& o, const float* lo, const float* hi, int hlen) {
+    std::memset(&o, 0, sizeof(o));
+    for (int i = 0; i < hlen; i++) { o.t[i].x = lo[i]; o.t[i].y = hi[i]; }
+}
+
+template <int HLEN>
+static void run_fwd_wave(const FwdWaveArgs& a, int batch, int guard) {
+    for (int bz = 0; bz < batch; bz++)
+        for (int seg = 0; seg < a.segs; seg++)
+            for (int strip = 0; strip < a.strips; strip++) {
+                if (guard) dwt2_fwd_wave<HLEN, true>(a, strip, seg, bz);
+                else dwt2_fwd_wave<HLEN, false>(a, strip, seg, bz);
+            }
+}
+
+// guard = 0 requires Nc % 256 == 0 and seg_out, Nr2 multiples of GR/2 (checked: returns -2 otherwise)
+EMU_API int emu_dwt2_fwd_wave(const float* in, int batch, int Nr, int Nc, const float* lo, const float* hi, int hlen,
+                              int seg_out, int guard, float* A, float* H, float* V, float* D) {
+    if ((hlen & 1) || hlen < 2 || hlen > 8 || (Nc & 3)) return -1;
+    FwdWaveArgs a;
+    a.in = in; a.A = A; a.H = H; a.V = V; a.D = D;
+    a.Nr = Nr; a.Nc = Nc; a.Nr2 = (Nr + 1) / 2; a.Nc2 = Nc / 2;
+    a.in_bstride = (long long)Nr * Nc; a.out_bstride = (long long)a.Nr2 * a.Nc2;
+    a.strips = cdiv(Nc, 256); a.seg_out = seg_out; a.segs = cdiv(a.Nr2, seg_out);
+    interleave_bank(a.fb, lo, hi, hlen);
+    switch (hlen) {
+#define X(h) case h: { constexpr int G2 = FwdWaveGeom<h>::GR / 2; \
+        if (!guard && ((Nc % 256) || (seg_out % G2) || (a.Nr2 % G2) || (a.Nr2 % seg_out))) return -2; \
+        run_fwd_wave<h>(a, batch, guard); return 0; }
+        X(2) X(4) X(6) X(8)
+#undef X
+    }
+    return -1;
+}
+
+template <int HLEN>
+static void run_inv_wave(const InvWaveArgs& a, int batch, int guard) {
+    for (int bz = 0; bz < batch; bz++)
+        for (int seg = 0; seg < a.segs; seg++)
+            for (int strip = 0; strip < a.strips; strip++) {
+                if (guard) dwt2_inv_wave<HLEN, true>(a, strip, seg, bz);
+                else dwt2_inv_wave<HLEN, false>(a, strip, seg, bz);
+            }
+}
+
+EMU_API int emu_dwt2_inv_wave(const float* A, const float* H, const float* V, const float* D, int batch, int Nrc, int Ncc,
+                              int Nr, int Nc, const float* lo, const float* hi, int hlen, int seg_pairs, int guard,
+                              float* out) {
+    if ((hlen & 1) || hlen < 2 || hlen > 8 || (Ncc & 1) || Nc != 2 * Ncc) return -1;
+    InvWaveArgs a;
+    a.A = A; a.H = H; a.V = V; a.D = D; a.out = out;
+    a.Nrc = Nrc; a.Ncc = Ncc; a.Nr = Nr; a.Nc = Nc;
+    a.in_bstride = (long long)Nrc * Ncc; a.out_bstride = (long long)Nr * Nc;
+    a.strips = cdiv(Ncc, 128); a.seg_pairs = seg_pairs; a.segs = cdiv(Nrc, seg_pairs);
+    interleave_bank(a.fb, lo, hi, hlen);
+    for (int d = 0; d < hlen / 2; d++) {
+        a.pl[d].x = lo[hlen - 2 - 2 * d]; a.pl[d].y = lo[hlen - 1 - 2 * d];
+        a.ph[d].x = hi[hlen - 2 - 2 * d]; a.ph[d].y = hi[hlen - 1 - 2 * d];
+    }
+    switch (hlen) {
+#define X(h) case h: { constexpr int GRI = InvWaveGeom<h>::GR; \
+        if (!guard && ((Ncc % 128) || (seg_pairs % GRI) || (Nrc % GRI) || (Nrc % seg_pairs) || Nr != 2 * Nrc)) return -2; \
+        run_inv_wave<h>(a, batch, guard); return 0; }
         X(2) X(4) X(6) X(8)
 #undef X
     }

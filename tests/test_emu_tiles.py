@@ -407,3 +407,70 @@ def test_emu_dwt2_inv_strip_streaming(wname):
                 want = oracle.inverse(bands, shape, wname, 2, ndim=2)
                 assert np.isfinite(out[b]).all(), (wname, shape, seg_rows)
                 assert np.abs(out[b] - want).max() <= 3 * _tol(want), (wname, shape, seg_rows)
+
+
+# ----------------------------------------------------------------------------- wave-per-tile kernels
+# (dwt2_wave_kernels.hpp: registers + DPP lane shifts, no LDS).  guard = 0 is the predicate-free variant the
+# host launches for whole strips / whole groups; guard = 1 takes any Nc % 4 == 0.
+WAVE_WNAMES = ["haar", "db2", "db3", "db4", "sym4", "bior1.3", "bior2.2", "rbio1.3", "coif1"]
+WAVE_SHAPES = [(64, 256, 8, 0), (96, 512, 12, 0), (48, 256, 24, 0), (24, 768, 12, 0),
+               (64, 256, 6, 1), (61, 72, 5, 1), (32, 260, 16, 1), (129, 8, 7, 1), (6, 12, 2, 1), (2, 4, 1, 1),
+               (200, 516, 32, 1), (50, 1028, 3, 1)]
+
+
+@pytest.mark.parametrize("wname", WAVE_WNAMES)
+def test_emu_dwt2_wave_fwd(wname):
+    hlen, dlo, dhi, rlo, rhi = oracle.filters(wname)
+    assert hlen <= 8
+    for si, (nr, nc, seg_out, guard) in enumerate(WAVE_SHAPES):
+        x = oracle.hash_input((nr, nc), 5100 + si)
+        ref = oracle.forward(x, wname, 1, ndim=2)
+        r2, c2 = (nr + 1) // 2, nc // 2
+        outs = [np.full((r2, c2), np.nan, dtype=np.float32) for _ in range(4)]
+        rc = lib().emu_dwt2_fwd_wave(P(x), 1, nr, nc, P(dlo), P(dhi), hlen, seg_out, guard, *[P(o) for o in outs])
+        if rc == -2:  # geometry not eligible for the predicate-free variant with this filter length
+            assert guard == 0
+            rc = lib().emu_dwt2_fwd_wave(P(x), 1, nr, nc, P(dlo), P(dhi), hlen, seg_out, 1, *[P(o) for o in outs])
+        assert rc == 0
+        for got, want in zip(outs, ref):
+            assert np.isfinite(got).all(), (wname, nr, nc)
+            assert np.abs(got - want).max() <= _tol(want), (wname, nr, nc, seg_out, guard)
+
+
+@pytest.mark.parametrize("wname", WAVE_WNAMES)
+def test_emu_dwt2_wave_inv(wname):
+    hlen, dlo, dhi, rlo, rhi = oracle.filters(wname)
+    for si, (nr, nc, seg, guard) in enumerate(WAVE_SHAPES):
+        if (nc // 2) % 2:
+            continue
+        r2, c2 = (nr + 1) // 2, nc // 2
+        bands = [oracle.hash_input((r2, c2), 5900 + 7 * si + b, 2.0) - 1.0 for b in range(4)]
+        ref = oracle.inverse(bands, (nr, nc), wname, 1, ndim=2)
+        out = np.full((nr, nc), np.nan, dtype=np.float32)
+        args = [P(b) for b in bands] + [1, r2, c2, nr, nc, P(rlo), P(rhi), hlen, seg]
+        rc = lib().emu_dwt2_inv_wave(*args, guard, P(out))
+        if rc == -2:
+            assert guard == 0
+            rc = lib().emu_dwt2_inv_wave(*args, 1, P(out))
+        assert rc == 0
+        assert np.isfinite(out).all(), (wname, nr, nc)
+        assert np.abs(out - ref).max() <= _tol(ref), (wname, nr, nc, seg, guard)
+
+
+def test_emu_dwt2_wave_batch_and_custom_filter():
+    rng = np.random.default_rng(7)
+    lo, hi = f32(rng.standard_normal(8)), f32(rng.standard_normal(8))
+    B, nr, nc = 2, 32, 512
+    x = oracle.hash_input((B, nr, nc), 91)
+    outs = [np.zeros((B, nr // 2, nc // 2), dtype=np.float32) for _ in range(4)]
+    assert lib().emu_dwt2_fwd_wave(P(x), B, nr, nc, P(lo), P(hi), 8, 8, 0, *[P(o) for o in outs]) == 0
+    for b in range(B):
+        ref = oracle.forward(x[b], "db4", 1, ndim=2, filt=(8, lo, hi, lo, hi))
+        for got, want in zip(outs, ref):
+            assert np.abs(got[b] - want).max() <= _tol(want)
+    rec = np.zeros((B, nr, nc), dtype=np.float32)
+    assert lib().emu_dwt2_inv_wave(*[P(o) for o in outs], B, nr // 2, nc // 2, nr, nc, P(lo), P(hi), 8, 4, 0,
+                                   P(rec)) == 0
+    for b in range(B):
+        ref = oracle.inverse([o[b] for o in outs], (nr, nc), "db4", 1, ndim=2, filt=(8, lo, hi, lo, hi))
+        assert np.abs(rec[b] - ref).max() <= _tol(ref)
