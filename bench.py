@@ -10,16 +10,23 @@ forward+inverse.  A "step" is one forward + one inverse of `--batch` images per 
 already resident in HBM (generated on the device).  With N > 1 every rank owns an independent plan on
 its own GPU and transforms its own images: the path shards by image, there is NO collective on the
 data path; torch.distributed (RCCL) is used only for the barrier and the max-over-ranks of the time.
-K steps x batch B per rank is exactly BASELINE config 5's "batch of images sharded over the GPUs"
-(1024 images over 8 GPUs = --steps 128 --batch 1, or --steps 1 --batch 128).
+`python bench.py --gpus N` without a launcher starts the N ranks itself (one child process per GPU,
+before anything touches a GPU).  `--config cfg5` is BASELINE config 5's per-GPU shard: 128 images of
+4096^2 per GPU and step (1024 images over 8 GPUs).  `--scaling strong` fixes the TOTAL batch (--batch
+images split over the ranks) instead of the per-GPU batch.
 
 Rank 0 prints ONE JSON line: the contract's keys plus
   roofline      dominant kernel: algorithmic bytes per launch / HIP-event duration vs 8 TB/s
   cpu_baseline  the C oracle (a port of the reference's algorithm) timed on this host's cores
+  end_to_end    algorithmic bytes of the whole step / step time, cold (no pre-heat) step time
+  extra         (1 GPU) one-thread CPU baseline, quoted / measured pywt, PCIe transfers and the reference's
+                own benchmark method (set_image + forward + coeffs), a working set beyond the Infinity Cache
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -35,19 +42,41 @@ CONFIGS = {
     "cfg3": (1, 1 << 24, "sym8", 6, 0, 1, None, "1D 2^24-sample fp32 sym8 6-level DWT fwd+inv"),
     "cfg4": (2048, 2048, "haar", 5, 1, 2, 25.5, "SWT 2048x2048 fp32 haar 5-level fwd + soft_threshold + inv"),
     "cfg1": (512, 512, "db2", 3, 0, 2, None, "512x512 fp32 db2 3-level 2D DWT fwd+inv"),
+    "cfg5": (4096, 4096, "db4", 4, 0, 2, None, "batch of 4096x4096 fp32 db4 4-level 2D DWT fwd+inv, 128 images per GPU"),
 }
+DEFAULT_BATCH = {"cfg5": 128}
+
+# pywt 1.1.1 timed in the BUILD container (one core of an 8-vCPU Xeon 2.1 GHz; pywt is single-threaded),
+# quoted when pywt is not importable on the GPU box
+PYWT_QUOTED = {"cfg1": 32.6, "cfg2": 12.6, "cfg3": 24.3, "cfg4": 1.16, "cfg5": 12.6}
 
 
-def algorithmic_bytes_per_sample(cfg):
-    """Compulsory HBM traffic per input sample of one step (SURVEY.md 8d / BASELINE.md 4)."""
+def algorithmic_bytes_per_sample(cfg, threshold_separate=True):
+    """Compulsory HBM traffic per input sample of one step (SURVEY.md 8d / BASELINE.md 4): input read once,
+    final coefficients written once, coefficients read once, output written once.  An SWT soft_threshold
+    costs a read + write of every detail plane ONLY when it runs as its own sweep (`threshold_separate`);
+    folded into the inverse's loads (the deferred threshold of 2D SWT plans) it moves nothing."""
     Nr, Nc, wname, L, swt, ndim, beta, _ = cfg
     if not swt:
         return 16.0  # fwd: read x, write all coefficients; inv: read them, write x
     nb = 3 * L + 1 if ndim == 2 else L + 1
     b = 4.0 * (1 + nb) + 4.0 * (nb + 1)
-    if beta is not None:
+    if beta is not None and threshold_separate:
         b += 2 * 4.0 * (nb - 1)
     return b
+
+
+def per_level_streaming_bytes_per_sample(cfg, threshold_separate=True):
+    """Diagnostic: every level reads its input and writes its outputs once."""
+    Nr, Nc, wname, L, swt, ndim, beta, _ = cfg
+    if swt:
+        planes = 5 if ndim == 2 else 3
+        b = 2 * 4.0 * planes * L
+        if beta is not None and threshold_separate:
+            b += 2 * 4.0 * (planes - 2) * L
+        return b
+    q = 4.0 if ndim == 2 else 2.0
+    return 2 * 8.0 * sum(q ** -l for l in range(L))
 
 
 def kernel_algorithmic_bytes(label, cfg, batch):
@@ -112,14 +141,19 @@ def level_of_kernel(kernel, L):
     return int(lvl[1:]), ("_inv_" in name)
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--batch", type=int, default=1, help="images per GPU per step")
+    ap.add_argument("--batch", type=int, default=None,
+                    help="images per GPU per step (weak scaling, default 1; cfg5: 128) or in total (--scaling strong)")
     ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: --batch images per GPU; strong: --batch images in total, split over the ranks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the `extra` measurements (one-thread CPU, pywt, PCIe, beyond-Infinity-Cache batch)")
     ap.add_argument("--preheat-ms", type=float, default=200.0,
                     help="run the workload untimed for this long before the warmup steps: after an idle period "
                          "the GPU needs tens of ms to ramp its clocks, and W = 10 steps last under 1 ms")
@@ -127,7 +161,32 @@ def parse_args():
                     help="torch.distributed backend for the barrier / max-over-ranks (nccl = RCCL)")
     ap.add_argument("--dry-run", action="store_true",
                     help="CPU/gloo plumbing test: no GPU work, exercises rendezvous + aggregation only")
-    return ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with no launcher: start the N ranks here, one child process per GPU, with the
+    same environment torch.distributed.run would give them.  This process never touches a GPU (no HIP call,
+    no torch import) -- it only waits and forwards rank 0's JSON line."""
+    n = args.gpus
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        print("bench.py: ranks failed (rank, exit code): %s" % bad, file=sys.stderr)
+        return max(abs(rc) for _, rc in bad) or 1
+    return 0
 
 
 def init_dist(args):
@@ -181,18 +240,28 @@ def shard_images(total, world, rank):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def cpu_baseline(cfg):
-    """The C oracle (a port of the reference's algorithm, fp32, OpenMP over rows) on this host:
-    a bounded sample of the same workload -- one image, forward + inverse, best of 3."""
+def rank_batch(args, world, rank):
+    """(images of this rank per step, first image index, total images per step)."""
+    b = args.batch if args.batch is not None else DEFAULT_BATCH.get(args.config, 1)
+    if args.scaling == "strong":
+        lo, hi = shard_images(b, world, rank)
+        return hi - lo, lo, b
+    return b, rank * b, world * b
+
+
+def cpu_baseline(cfg, threads=None):
+    """The C oracle (a port of the reference's algorithm, fp32, OpenMP over rows) on this host's cores (or on
+    `threads` of them): a bounded sample of the same workload -- one image, forward (+ threshold) + inverse,
+    best of 3 (one run for the slow configurations).  The ONLY place bench.py touches oracle/."""
     import numpy as np
 
     from oracle import oracle
     oracle.build()
     Nr, Nc, wname, L, swt, ndim, beta, desc = cfg
-    cores = oracle.set_threads(oracle.usable_cpus())
+    cores = oracle.set_threads(threads if threads else oracle.usable_cpus())
     x = oracle.hash_input((Nr, Nc), 20242)
     best = None
-    reps = 3 if not swt else 1
+    reps = (3 if not swt else 1) if cores > 1 else 1
     for _ in range(reps):
         t0 = time.perf_counter()
         bands = oracle.forward(x, wname, L, ndim=ndim, do_swt=swt)
@@ -203,35 +272,136 @@ def cpu_baseline(cfg):
         best = dt if best is None else min(best, dt)
     assert np.isfinite(rec).all()
     return {"value": Nr * Nc / best / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
-            "sample": "1 image of the bench workload (%s), best of %d, oracle/pdwt_oracle.c fp32 + OpenMP" % (desc, reps),
+            "sample": "1 image of the bench workload (%s), best of %d, oracle/pdwt_oracle.c fp32%s"
+                      % (desc, reps, " + OpenMP" if cores > 1 else ", one thread"),
             "seconds": best}
+
+
+def synthetic_host_image(Nr, Nc):
+    import numpy as np
+    return (np.random.RandomState(0).rand(Nr, Nc) * 255.0).astype(np.float32)
+
+
+def pywt_baseline(name, cfg):
+    """pywt on this host when importable (the reference's own CPU oracle, test/test_wavelets.py:230,301,372,438;
+    single-threaded by nature), else the figure measured in the build container, labelled."""
+    Nr, Nc, wname, L, swt, ndim, beta, desc = cfg
+    quoted = {"value": PYWT_QUOTED[name], "unit": "Msamples/s", "cores": 1,
+              "kind": "quoted, build container (pywt 1.1.1, one core of an 8-vCPU Xeon 2.1 GHz; BASELINE.md 2)"}
+    try:
+        import numpy as np
+        import pywt
+    except Exception:
+        return quoted
+    try:
+        x = synthetic_host_image(Nr, Nc)
+        t0 = time.perf_counter()
+        if swt:
+            co = pywt.swt2(x, wname, L)
+            if beta is not None:
+                co = [(a, tuple(pywt.threshold(d, beta, "soft") for d in det)) for a, det in co]
+            pywt.iswt2(co, wname)
+        elif ndim == 2:
+            pywt.waverec2(pywt.wavedec2(x, wname, mode="periodization", level=L), wname, mode="periodization")
+        else:
+            pywt.waverec(pywt.wavedec(x[0], wname, mode="periodization", level=L), wname, mode="periodization")
+        dt = time.perf_counter() - t0
+        return {"value": Nr * Nc / dt / 1e6, "unit": "Msamples/s", "cores": 1,
+                "kind": "measured here, pywt %s" % pywt.__version__, "seconds": dt}
+    except Exception as e:  # never let the optional baseline break the bench line
+        quoted["note"] = "pywt import ok but the run failed: %r" % (e,)
+        return quoted
+
+
+def transfers(name, cfg, device):
+    """PCIe side of the API, reported separately from `value`: H2D of one image (set_image), D2H of all its
+    coefficients (coeffs), and the reference's own benchmark method set_image + forward + coeffs
+    (test/benchmark.py:141-162, test/bench.py:128-155), best of 3 on a one-image plan."""
+    from pypwt_amd import Wavelets
+    Nr, Nc, wname, L, swt, ndim, beta, desc = cfg
+    x = synthetic_host_image(Nr, Nc)  # a 1D plan keeps its signal as one row: (1, N)
+    w = Wavelets(x, wname, L, do_swt=swt, ndim=ndim)
+    w.forward()
+    _ = w.coeffs
+    h2d = d2h = ref = None
+    for _ in range(3):
+        t0 = time.perf_counter(); w.set_image(x); t1 = time.perf_counter()
+        w.forward(); w.synchronize(); t2 = time.perf_counter()
+        _ = w.coeffs; t3 = time.perf_counter()
+        h2d = min(h2d, t1 - t0) if h2d else t1 - t0
+        d2h = min(d2h, t3 - t2) if d2h else t3 - t2
+        ref = min(ref, t3 - t0) if ref else t3 - t0
+    nbytes = x.nbytes
+    coeff_planes = (3 * L + 1 if ndim == 2 else L + 1) if swt else 1  # DWT: as many coefficients as samples
+    return {"h2d_ms": h2d * 1e3, "d2h_ms": d2h * 1e3, "h2d_GBps": nbytes / h2d / 1e9,
+            "d2h_GBps": nbytes * coeff_planes / d2h / 1e9,
+            "reference_method_ms": ref * 1e3,
+            "reference_method_Msamples_s": Nr * Nc / ref / 1e6,
+            "note": "pageable host memory; the reference times set_image + forward + coeffs (H2D + kernels + D2H)"}
+
+
+def timed_steps(step, device_sync, steps):
+    device_sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    device_sync()
+    return (time.perf_counter() - t0) / steps
+
+
+def beyond_mall(cfg, device, steps):
+    """The same step with 16 images per launch (2.4 GiB of plan, far beyond the 256 MiB Infinity Cache): what the
+    chip sustains from HBM rather than from its last-level cache."""
+    from pypwt_amd import BatchedWavelets
+    Nr, Nc, wname, L, swt, ndim, beta, desc = cfg
+    B = 16
+    plan = BatchedWavelets(B, Nr, Nc, wname, L, do_swt=swt, ndim=ndim, device=device)
+    plan.fill_hash(20240 + 2, 255.0)
+
+    def step():
+        plan.forward()
+        if beta is not None:
+            plan.soft_threshold(beta)
+        plan.inverse()
+
+    for _ in range(3):
+        step()
+    dt = timed_steps(step, plan.synchronize, max(5, min(steps, 20)))
+    bytes_step = algorithmic_bytes_per_sample(cfg, threshold_separate=False) * B * Nr * Nc
+    plan.cleanup()
+    return {"batch": B, "ms_per_step": dt * 1e3, "Msamples_s": B * Nr * Nc / dt / 1e6,
+            "frac_of_hbm_peak": bytes_step / dt / 1e9 / HBM_PEAK_GBPS}
 
 
 def dry_run(args, rank, world, dist, backend):
     """No GPU: sleep-based steps so the launch / barrier / max-over-ranks / JSON path is testable
     with gloo on CPU."""
     cfg = CONFIGS[args.config]
+    B, first, total = rank_batch(args, world, rank)
     barrier(dist, backend)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         time.sleep(0.001 * (1 + rank))
     dt = max_over_ranks(time.perf_counter() - t0, dist, backend)
     barrier(dist, backend)
-    lo, hi = shard_images(world * args.batch * args.steps, world, rank)
     if rank == 0:
-        samples = world * args.batch * cfg[0] * cfg[1]
+        samples = total * cfg[0] * cfg[1]
         print(json.dumps({"metric": "dry_run", "value": samples / (dt / args.steps) / 1e6, "unit": "Msamples/s",
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                          "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+                          "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
                           "vs_baseline": None, "dtype": "f32", "data": "none (dry run)",
-                          "config": {"workload": "dry-run", "shard_rank0": [lo, hi]}}))
+                          "config": {"workload": "dry-run", "shard_rank0": [first, first + B],
+                                     "images_per_step": total}}))
 
 
 def main():
     args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args))  # before any GPU / torch activity in this process
     rank, world, local_rank, dist, backend = init_dist(args)
-    if args.gpus != world and rank == 0 and world > 1:
-        print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
+    if args.gpus != world and rank == 0:
+        print("warning: --gpus %d but WORLD_SIZE %d; running %d rank(s) and reporting n_gpus = %d"
+              % (args.gpus, world, world, world), file=sys.stderr)
     if args.dry_run:
         dry_run(args, rank, world, dist, backend)
         if dist is not None:
@@ -241,12 +411,14 @@ def main():
     from pypwt_amd import BatchedWavelets
     cfg = CONFIGS[args.config]
     Nr, Nc, wname, L, swt, ndim, beta, desc = cfg
-    B = args.batch
+    B, first_image, total_images = rank_batch(args, world, rank)
+    if B < 1:
+        raise SystemExit("bench.py: rank %d has no image (--scaling strong with --batch %s over %d ranks)"
+                         % (rank, args.batch, world))
 
     plan = BatchedWavelets(B, Nr, Nc, wname, L, do_swt=swt, ndim=ndim, device=local_rank)
     # deterministic synthetic input generated ON the device; every rank gets different images
-    lo, _ = shard_images(world * B, world, rank)
-    plan.fill_hash(20240 + 2, 255.0, index_offset=lo * Nr * Nc)
+    plan.fill_hash(20240 + 2, 255.0, index_offset=first_image * Nr * Nc)
 
     def step():
         plan.forward()
@@ -259,6 +431,11 @@ def main():
         if dist is not None and backend == "nccl":
             import torch
             torch.cuda.synchronize()
+
+    # cold figure: W warm-up steps after an idle period, then K steps (no pre-heat): what a one-shot caller sees
+    for _ in range(args.warmup):
+        step()
+    cold_s = timed_steps(step, device_sync, args.steps)
 
     # pre-heat (untimed): sustained-throughput conditions for the timed steps
     t_pre = time.perf_counter()
@@ -278,9 +455,10 @@ def main():
     barrier(dist, backend)
     device_sync()
     dt = max_over_ranks(time.perf_counter() - t0, dist, backend)
+    cold_s = max_over_ranks(cold_s, dist, backend)
 
     step_s = dt / args.steps
-    samples_per_step = world * B * Nr * Nc
+    samples_per_step = total_images * Nr * Nc
     value = samples_per_step / step_s / 1e6
 
     # ---- per-kernel durations from HIP events on the plan's stream (second pass, same steps)
@@ -292,7 +470,8 @@ def main():
     plan.enable_kernel_timing(False)
     plan.reset_kernel_times()
     per_step = len(times) // args.steps
-    labels = label_step_kernels([n for n, _ in times[:per_step]], L)
+    step_names = [n for n, _ in times[:per_step]]
+    labels = label_step_kernels(step_names, L)
     agg = {}
     for i, (name, ms) in enumerate(times):
         agg.setdefault(labels[i % per_step], []).append(ms)
@@ -322,34 +501,64 @@ def main():
     # HBM bytes per launch of that kernel from the rocprofv3 PMC passes of this same command
     # (FETCH_SIZE x2 + WRITE_SIZE, collected separately; tools/prof.sh + tools/summarize_pmc.py).
     # Counters cannot be read from inside the process, so the committed measurement is quoted.
-    tpath = os.path.join(ROOT, "profiles", "r01_traffic_%s.json" % args.config)
-    if B == 1 and os.path.exists(tpath):
-        try:
-            # the profile labels launches by kernel family: "+soft" (a deferred threshold folded into the SWT
-            # inverse) is a property of the plan state, not of the kernel
-            t = json.load(open(tpath))["per_launch"].get(dom["kernel"].replace("+soft", ""))
-            if t:
-                roofline["traffic"] = t["hbm_bytes"]
-                roofline["traffic_source"] = "profiles/" + os.path.basename(tpath)
-        except Exception:
-            pass
-    e2e_bytes = algorithmic_bytes_per_sample(cfg) * B * Nr * Nc  # per GPU per step
-    e2e = {"algorithmic_bytes_per_step_per_gpu": e2e_bytes, "GBps_per_gpu": e2e_bytes / step_s / 1e9,
+    for tag in ("r02", "r01"):
+        tpath = os.path.join(ROOT, "profiles", "%s_traffic_%s.json" % (tag, args.config))
+        if B == 1 and os.path.exists(tpath):
+            try:
+                # the profile labels launches by kernel family: "+soft" (a deferred threshold folded into the SWT
+                # inverse) is a property of the plan state, not of the kernel
+                t = json.load(open(tpath))["per_launch"].get(dom["kernel"].replace("+soft", ""))
+                if t:
+                    roofline["traffic"] = t["hbm_bytes"]
+                    roofline["traffic_source"] = "profiles/" + os.path.basename(tpath)
+                    break
+            except Exception:
+                pass
+    # the soft threshold costs bytes only when it ran as its own sweep (a `soft_threshold` launch in the step)
+    thr_separate = any(n.startswith("soft_threshold") for n in step_names)
+    bps = algorithmic_bytes_per_sample(cfg, threshold_separate=thr_separate)
+    e2e_bytes = bps * B * Nr * Nc  # per GPU per step
+    e2e = {"algorithmic_bytes_per_sample": bps, "algorithmic_bytes_per_step_per_gpu": e2e_bytes,
+           "GBps_per_gpu": e2e_bytes / step_s / 1e9,
            "frac_of_hbm_peak": e2e_bytes / step_s / 1e9 / HBM_PEAK_GBPS,
+           "cold_ms_per_step": cold_s * 1e3, "cold_Msamples_s": samples_per_step / cold_s / 1e6,
+           "per_level_streaming_bytes_per_sample": per_level_streaming_bytes_per_sample(cfg, thr_separate),
            "sum_kernel_us": sum(k["avg_us"] for k in kernels)}
+    if swt and beta is not None:
+        e2e["threshold"] = ("separate sweep" if thr_separate else
+                            "folded into the inverse's loads (no launch, no bytes); as a separate sweep the step "
+                            "would be charged %.0f B/sample" % algorithmic_bytes_per_sample(cfg, True))
 
+    workload = args.config if args.config != "cfg5" else "cfg5 (per-GPU shard of cfg2 images)"
     out = {
-        "metric": "Msamples/s, 4096x4096 fp32 db4 L4 2D DWT fwd+inv" if args.config == "cfg2" else "Msamples/s, " + desc,
+        "metric": "Msamples/s, 4096x4096 fp32 db4 L4 2D DWT fwd+inv" if args.config in ("cfg2", "cfg5") else "Msamples/s, " + desc,
         "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": step_s * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": step_s * 1e3, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
         "dtype": "f32", "data": "synthetic (on-device index hash, 0..255)",
-        "config": {"workload": "%s: %s" % (args.config, desc), "batch_per_gpu": B, "wavelet": wname, "levels": L,
-                   "shape": [Nr, Nc], "parallelism": "image-sharded x%d, no collectives" % world,
-                   "preheat_ms": args.preheat_ms},
+        "config": {"workload": "%s: %s" % (workload, desc), "batch_per_gpu": B, "images_per_step": total_images,
+                   "wavelet": wname, "levels": L, "shape": [Nr, Nc],
+                   "parallelism": "image-sharded x%d, no collectives" % world, "preheat_ms": args.preheat_ms},
         "roofline": roofline, "end_to_end": e2e, "kernels": kernels[:12],
     }
+    if world > 1:
+        out["config"]["multi_gpu_note"] = "measured on this node's GPUs; one process per GPU, barrier + max over ranks via RCCL"
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg)
+    if rank == 0 and world == 1 and not args.no_extras:
+        extra = {}
+        if not args.no_cpu_baseline:
+            extra["cpu_baseline_1thread"] = cpu_baseline(cfg, threads=1)
+            extra["pywt"] = pywt_baseline(args.config, cfg)
+        try:
+            extra["transfers"] = transfers(args.config, cfg, local_rank)
+        except Exception as e:
+            extra["transfers"] = {"error": repr(e)}
+        if args.config == "cfg2" and B == 1:
+            try:
+                extra["beyond_infinity_cache"] = beyond_mall(cfg, local_rank, args.steps)
+            except Exception as e:
+                extra["beyond_infinity_cache"] = {"error": repr(e)}
+        out["extra"] = extra
     if rank == 0:
         print(json.dumps(out))
     plan.cleanup()

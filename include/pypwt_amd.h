@@ -129,6 +129,10 @@ long long pdwt_get_coeff(pdwt_handle h, pdwt_real* dst, int num); /* 0 if refuse
 int pdwt_set_image(pdwt_handle h, const pdwt_real* src, int mem_is_on_device);
 int pdwt_set_coeff(pdwt_handle h, const pdwt_real* src, int num, int mem_is_on_device);
 long long pdwt_coeff_count(pdwt_handle h, int num, int* rows, int* cols); /* elements incl. batch */
+/* NEW (batched plans): one image / one image's sub-band of a batch, so that a 128-image shard can be
+ * inspected without a host buffer for the whole batch; same refusal rule as pdwt_get_coeff (wt.cu:473-477) */
+long long pdwt_get_image_at(pdwt_handle h, pdwt_real* dst, int image_index);
+long long pdwt_get_coeff_at(pdwt_handle h, pdwt_real* dst, int num, int image_index);
 intptr_t pdwt_image_ptr(pdwt_handle h);                                   /* wt.cu:658-660 */
 intptr_t pdwt_coeff_ptr(pdwt_handle h, int num);                          /* wt.cu:663-665 */
 

@@ -86,6 +86,8 @@ def load(double=False):
     lib.oracle_fill_hash.argtypes = [f32p, sz, C.c_uint32, f]
     lib.oracle_nonsep_fwd_level.argtypes = [f32p, i, i, f32p, f32p, f32p, f32p, i, i, i,
                                             f32p, f32p, f32p, f32p]
+    lib.oracle_nonsep_inv_level.argtypes = [f32p, f32p, f32p, f32p, i, i, i, i, f32p, f32p, f32p, f32p, i, i, i, f32p]
+    lib.oracle_fill_hash_off.argtypes = [f32p, sz, C.c_uint32, f, C.c_longlong]
     lib.oracle_max_level.argtypes = [i, i]
     lib.oracle_div2.argtypes = [i]
     lib.oracle_set_threads.argtypes = [i]
@@ -121,10 +123,13 @@ def filters(wname, dtype=np.float32):
                                 for k in ("dec_lo", "dec_hi", "rec_lo", "rec_hi"))
 
 
-def hash_input(shape, seed, scale=255.0):
+def hash_input(shape, seed, scale=255.0, index_offset=0):
     n = int(np.prod(shape))
     x = np.empty(n, dtype=np.float32)
-    load().oracle_fill_hash(_ptr(x), n, seed & 0xFFFFFFFF, scale)
+    if index_offset:
+        load().oracle_fill_hash_off(_ptr(x), n, seed & 0xFFFFFFFF, scale, int(index_offset))
+    else:
+        load().oracle_fill_hash(_ptr(x), n, seed & 0xFFFFFFFF, scale)
     return x.reshape(shape)
 
 
@@ -245,6 +250,17 @@ def nonsep_forward_level(x, FA, FH, FV, FD, hlen, do_swt=0, level=1, double=Fals
     lib.oracle_nonsep_fwd_level(_ptr(x), Nr, Nc, _ptr(_f32(FA)), _ptr(_f32(FH)), _ptr(_f32(FV)),
                                 _ptr(_f32(FD)), hlen, int(do_swt), level, *[_ptr(o) for o in outs])
     return outs
+
+
+def nonsep_inverse_level(bands, shape, FA, FH, FV, FD, hlen, do_swt=0, level=1, double=False):
+    """One non-separable synthesis level: bands = [A, H, V, D] (coefficient planes) -> image of `shape`."""
+    A, H, V, D = [_f32(b) for b in bands]
+    Nr, Nc = shape
+    out = np.zeros((Nr, Nc), dtype=np.float32)
+    load(double).oracle_nonsep_inv_level(_ptr(A), _ptr(H), _ptr(V), _ptr(D), A.shape[0], A.shape[1], Nr, Nc,
+                                         _ptr(_f32(FA)), _ptr(_f32(FH)), _ptr(_f32(FV)), _ptr(_f32(FD)), hlen,
+                                         int(do_swt), level, _ptr(out))
+    return out
 
 
 def set_threads(n):

@@ -607,6 +607,56 @@ API void oracle_nonsep_fwd_level(const DATA *in, int Nr, int Nc, const DATA *FA,
         }
 }
 
+/* Non-separable synthesis, one level.
+ * DWT (nonseparable.cu:176-225): one thread per output pixel (gy,gx); h2 = hlen/2; for an odd h2 the
+ * centre is c = h2/2, for an even h2 it is c = h2/2 and the pixel index is shifted by one ("virtual id",
+ * :193-194, result written back at (g-1), :223); coefficient (g/2 - c + j) (periodic, :197-208) meets
+ * tap hlen-1-(2j + off), off = 1 - (g & 1) (:202-203, :213-216); the four bands are summed (:222-223).
+ * SWT (nonseparable.cu:360-401): c = hlen/2 times the dilation 2^(level-1), coefficient
+ * (g - c + j f) (periodic), tap hlen-1-j, every product divided by 4 (:393-396).
+ * Coefficient planes are (Nrc, Ncc); the output is (Nr, Nc) with Nr <= 2 Nrc (DWT) or == (SWT). */
+API void oracle_nonsep_inv_level(const DATA *A, const DATA *H, const DATA *V, const DATA *D, int Nrc, int Ncc,
+                                 int Nr, int Nc, const DATA *FA, const DATA *FH, const DATA *FV, const DATA *FD,
+                                 int hlen, int do_swt, int level, DATA *out) {
+#pragma omp parallel for schedule(static)
+    for (int gy = 0; gy < Nr; gy++)
+        for (int gx = 0; gx < Nc; gx++) {
+            REAL r = 0;
+            if (!do_swt) {
+                const int h2 = hlen / 2, c = h2 / 2, shift = (h2 & 1) ? 0 : 1;
+                const int vy = gy + shift, vx = gx + shift;
+                const int offy = 1 - (vy & 1), offx = 1 - (vx & 1);
+                for (int jy = 0; jy < h2; jy++) {
+                    const int ty = hlen - 1 - (2 * jy + offy);
+                    const int iy = mod_n(vy / 2 - c + jy, Nrc);
+                    if (ty < 0) continue;
+                    for (int jx = 0; jx < h2; jx++) {
+                        const int tx = hlen - 1 - (2 * jx + offx);
+                        const int ix = mod_n(vx / 2 - c + jx, Ncc);
+                        if (tx < 0) continue;
+                        const size_t o = (size_t)iy * Ncc + ix;
+                        const int t = ty * hlen + tx;
+                        r += (REAL)A[o] * (REAL)FA[t] + (REAL)H[o] * (REAL)FH[t] + (REAL)V[o] * (REAL)FV[t] +
+                             (REAL)D[o] * (REAL)FD[t];
+                    }
+                }
+            } else {
+                const int f = 1 << (level - 1), c = (hlen / 2) * f;
+                for (int jy = 0; jy < hlen; jy++) {
+                    const int iy = mod_n(gy - c + jy * f, Nr);
+                    for (int jx = 0; jx < hlen; jx++) {
+                        const int ix = mod_n(gx - c + jx * f, Nc);
+                        const size_t o = (size_t)iy * Nc + ix;
+                        const int t = (hlen - 1 - jy) * hlen + (hlen - 1 - jx);
+                        r += ((REAL)A[o] * (REAL)FA[t] + (REAL)H[o] * (REAL)FH[t] + (REAL)V[o] * (REAL)FV[t] +
+                              (REAL)D[o] * (REAL)FD[t]) / 4;
+                    }
+                }
+            }
+            out[(size_t)gy * Nc + gx] = (DATA)r;
+        }
+}
+
 /* ------------------------------------------------------------ test inputs */
 
 /* Counter-based generator shared with tests/golden/make_golden.py:hash_input
@@ -615,6 +665,19 @@ API void oracle_fill_hash(DATA *x, size_t n, uint32_t seed, DATA scale) {
 #pragma omp parallel for schedule(static)
     for (size_t i = 0; i < n; i++) {
         uint32_t h = (uint32_t)i ^ seed;
+        h ^= h >> 16; h *= 0x7FEB352Du;
+        h ^= h >> 15; h *= 0x846CA68Bu;
+        h ^= h >> 16;
+        x[i] = (DATA)((double)(h >> 8) * (1.0 / 16777216.0) * (double)scale);
+    }
+}
+
+/* same generator with an index offset (image b of a batch: offset = b * Nr * Nc); the product's
+ * pdwt_fill_image_hash takes the same parameter */
+API void oracle_fill_hash_off(DATA *x, size_t n, uint32_t seed, DATA scale, long long index_offset) {
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < n; i++) {
+        uint32_t h = (uint32_t)((long long)i + index_offset) ^ seed;
         h ^= h >> 16; h *= 0x7FEB352Du;
         h ^= h >> 15; h *= 0x846CA68Bu;
         h ^= h >> 16;

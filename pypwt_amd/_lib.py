@@ -49,6 +49,8 @@ def signatures(real=C.c_float):
         "pdwt_add_wavelet": (C.c_int, [handle_t, handle_t, real]),
         "pdwt_get_image": (C.c_longlong, [handle_t, C.c_void_p]),
         "pdwt_get_coeff": (C.c_longlong, [handle_t, C.c_void_p, C.c_int]),
+        "pdwt_get_image_at": (C.c_longlong, [handle_t, C.c_void_p, C.c_int]),
+        "pdwt_get_coeff_at": (C.c_longlong, [handle_t, C.c_void_p, C.c_int, C.c_int]),
         "pdwt_set_image": (C.c_int, [handle_t, C.c_void_p, C.c_int]),
         "pdwt_set_coeff": (C.c_int, [handle_t, C.c_void_p, C.c_int, C.c_int]),
         "pdwt_coeff_count": (C.c_longlong, [handle_t, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),

@@ -38,6 +38,7 @@ hipError_t launch_dwt1_fwd(const Fwd1DArgs& a, hipStream_t s);
 hipError_t launch_dwt1_inv(const Inv1DArgs& a, hipStream_t s);
 // K consecutive 1D levels in one launch (2^K must divide N0, even hlen); hipErrorNotSupported otherwise
 int dwt1_fused_max_levels(int hlen);
+bool dwt1_fused_supported(int hlen, int N0, int K);
 hipError_t launch_dwt1_fwd_fused(const real_t* in, real_t* const* det, real_t* app, int rows, int N0, int K, int hlen,
                                  const FilterBank& fb, hipStream_t s);
 hipError_t launch_dwt1_inv_fused(const real_t* app, const real_t* const* det, real_t* out, int rows, int N0, int K,

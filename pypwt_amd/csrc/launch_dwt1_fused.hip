@@ -43,11 +43,18 @@ static hipError_t run_inv(const Inv1DFusedArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
-// levels: K >= 2 consecutive levels starting from `in` of length N0 per row; 2^(K+2) must divide N0
-// (every level length even, every band row 16-B aligned)
+// ONE predicate for planner (plan.cpp) and launchers: K consecutive levels starting from a row of N0
+// samples can run fused iff hlen is even, 2^(K+2) divides N0 (every level length even, every band row
+// 16-B aligned) and N0 < 2^30 (32-bit tile arithmetic)
+bool dwt1_fused_supported(int hlen, int N0, int K) {
+    return !(hlen & 1) && hlen >= 2 && hlen <= kMaxTaps && K >= 1 && K <= kMaxFusedLevels && (N0 % (1 << (K + 2))) == 0 &&
+           N0 < (1 << 30);
+}
+
+// levels: K >= 2 consecutive levels starting from `in` of length N0 per row
 hipError_t launch_dwt1_fwd_fused(const float* in, float* const* det, float* app, int rows, int N0, int K, int hlen,
                                  const FilterBank& fb, hipStream_t s) {
-    if ((hlen & 1) || K < 2 || K > kMaxFusedLevels || (N0 % (1 << (K + 2))) || N0 >= (1 << 30)) return hipErrorNotSupported;
+    if (K < 2 || !dwt1_fused_supported(hlen, N0, K)) return hipErrorNotSupported;
     Fwd1DFusedArgs a;
     a.in = in; a.app = app; a.rows = rows; a.N0 = N0; a.K = K;
     for (int k = 0; k < kMaxFusedLevels; k++) a.det[k] = k < K ? det[k] : nullptr;
@@ -64,7 +71,7 @@ hipError_t launch_dwt1_fwd_fused(const float* in, float* const* det, float* app,
 
 hipError_t launch_dwt1_inv_fused(const float* app, const float* const* det, float* out, int rows, int N0, int K,
                                  int hlen, const FilterBank& fb, hipStream_t s) {
-    if ((hlen & 1) || K < 1 || K > kMaxFusedLevels || (N0 % (1 << (K + 2))) || N0 >= (1 << 30)) return hipErrorNotSupported;
+    if (!dwt1_fused_supported(hlen, N0, K)) return hipErrorNotSupported;
     Inv1DFusedArgs a;
     a.app = app; a.out = out; a.rows = rows; a.N0 = N0; a.K = K;
     for (int k = 0; k < kMaxFusedLevels; k++) a.det[k] = k < K ? det[k] : nullptr;

@@ -12,7 +12,7 @@ namespace pdwt {
 // 4 workgroups per CU); long filters amortise their (hlen-2)-row halo over TY = 32.
 template <int HLEN, int TX, int TY, int NT>
 static hipError_t run_fwd(const Fwd2DArgs& a, int batch, hipStream_t s) {
-    static bool big[64] = {};
+    static std::atomic<bool> big[64] = {};
     const size_t lds = (size_t)fwd2d_lds_floats<TX, TY>(HLEN ? HLEN : kMaxTaps) * sizeof(real_t);
     hipError_t e = allow_big_lds(dwt2_fwd_kernel<HLEN, TX, TY, NT>, lds, big);
     if (e != hipSuccess) return e;
@@ -24,7 +24,7 @@ static hipError_t run_fwd(const Fwd2DArgs& a, int batch, hipStream_t s) {
 
 template <int HLEN, int TX, int TY, int NT>
 static hipError_t run_inv(const Inv2DArgs& a, int batch, hipStream_t s) {
-    static bool big[64] = {};
+    static std::atomic<bool> big[64] = {};
     const size_t lds = (size_t)inv2d_lds_floats<TX, TY>(HLEN ? HLEN : kMaxTaps) * sizeof(real_t);
     hipError_t e = allow_big_lds(dwt2_inv_kernel<HLEN, TX, TY, NT>, lds, big);
     if (e != hipSuccess) return e;
@@ -51,6 +51,7 @@ hipError_t launch_dwt2_inv_strip2(const real_t* const[4], const real_t* const[3]
 hipError_t launch_dwt2_inv_pyr2(const real_t* const[4], const real_t* const[3], real_t*, int, int, int,
                                 const FilterBank&, int, hipStream_t) { return hipErrorNotSupported; }
 int dwt1_fused_max_levels(int) { return 1; }
+bool dwt1_fused_supported(int, int, int) { return false; }
 hipError_t launch_dwt1_fwd_fused(const real_t*, real_t* const*, real_t*, int, int, int, int, const FilterBank&,
                                  hipStream_t) { return hipErrorNotSupported; }
 hipError_t launch_dwt1_inv_fused(const real_t*, const real_t* const*, real_t*, int, int, int, int, const FilterBank&,

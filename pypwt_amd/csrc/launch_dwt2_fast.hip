@@ -39,7 +39,7 @@ static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 template <int HLEN, int TX, int TY, int NT>
 static hipError_t run_fwd_fast(const Fwd2DArgs& g, int batch, hipStream_t s) {
-    static bool big[64] = {};
+    static std::atomic<bool> big[64] = {};
     constexpr size_t lds = (size_t)fwd2d_fast_lds_floats<HLEN, TX, TY>() * sizeof(float);
     hipError_t e = allow_big_lds(dwt2_fwd_fast_stream_kernel<HLEN, TX, TY, NT>, lds, big);
     if (e != hipSuccess) return e;
@@ -59,7 +59,7 @@ static hipError_t run_fwd_fast(const Fwd2DArgs& g, int batch, hipStream_t s) {
 // small streaming tiles, whose 2048 tiles need a second round of workgroups (profiles/r01c_kbench_2048.txt).
 template <int HLEN, int TX, int TY, int NT>
 static hipError_t run_fwd_fast_tile(const Fwd2DArgs& g, int batch, hipStream_t s) {
-    static bool big[64] = {};
+    static std::atomic<bool> big[64] = {};
     constexpr size_t lds = (size_t)fwd2d_fast_lds_floats<HLEN, TX, TY>() * sizeof(float);
     hipError_t e = allow_big_lds(dwt2_fwd_fast_kernel<HLEN, TX, TY, NT>, lds, big);
     if (e != hipSuccess) return e;
@@ -79,7 +79,7 @@ static bool mid_size(long long samples) { return samples > (1LL << 20) && sample
 
 template <int HLEN, int TX, int TY, int NT>
 static hipError_t run_inv_fast(const Inv2DArgs& g, int batch, hipStream_t s) {
-    static bool big[64] = {};
+    static std::atomic<bool> big[64] = {};
     constexpr size_t lds = (size_t)inv2d_fast_lds_floats<HLEN, TX, TY>() * sizeof(float);
     hipError_t e = allow_big_lds(dwt2_inv_fast_kernel<HLEN, TX, TY, NT>, lds, big);
     if (e != hipSuccess) return e;

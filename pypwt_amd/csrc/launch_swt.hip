@@ -9,7 +9,7 @@ namespace pdwt {
 // (row tile, phase).
 template <int HLEN, int TX, int TY, int NT>
 static hipError_t run_fwd(const Swt2DArgs& a, int batch, hipStream_t s) {
-    static bool big[64] = {};
+    static std::atomic<bool> big[64] = {};
     const size_t lds = (size_t)swt2d_lds_floats<TX, TY>(HLEN ? HLEN : kMaxTaps) * sizeof(real_t);
     hipError_t e = allow_big_lds(swt2_fwd_kernel<HLEN, TX, TY, NT>, lds, big);
     if (e != hipSuccess) return e;
@@ -22,7 +22,7 @@ static hipError_t run_fwd(const Swt2DArgs& a, int batch, hipStream_t s) {
 
 template <int HLEN, int TX, int TY, int NT>
 static hipError_t run_inv(const Swt2DArgs& a, int batch, hipStream_t s) {
-    static bool big[64] = {};
+    static std::atomic<bool> big[64] = {};
     const size_t lds = (size_t)swt2d_lds_floats<TX, TY>(HLEN ? HLEN : kMaxTaps) * sizeof(real_t);
     hipError_t e = allow_big_lds(swt2_inv_kernel<HLEN, TX, TY, NT>, lds, big);
     if (e != hipSuccess) return e;

@@ -10,7 +10,7 @@ namespace pdwt {
 template <int HLEN, bool INV, int TX = 128>
 static hipError_t run_vec(const Swt2DArgs& a, int batch, hipStream_t s) {
     constexpr int TY = 16, NT = 256;
-    static bool big[64] = {};
+    static std::atomic<bool> big[64] = {};
     constexpr size_t lds = (size_t)swt2d_vec_lds_floats<TX, TY>(HLEN) * sizeof(real_t);
     const int M = a.Nr / a.f;
     const int total = cdiv(a.Nc, TX) * cdiv(M, TY) * a.f;

@@ -3,24 +3,27 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+
 namespace pdwt {
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline long long cdivll(long long a, long long b) { return (a + b - 1) / b; }
 
 // Kernels that stage more than 64 KiB of dynamic LDS (long filters) must opt in once per
-// device; gfx950 has 160 KiB per CU.
+// device; gfx950 has 160 KiB per CU.  The per-device flags are atomics: two host threads driving two
+// devices may race to set one (setting the attribute twice is harmless).
 template <typename K>
-static inline hipError_t allow_big_lds(K kernel, size_t bytes, bool* done_per_device) {
+static inline hipError_t allow_big_lds(K kernel, size_t bytes, std::atomic<bool>* done_per_device) {
     if (bytes <= 64 * 1024) return hipSuccess;
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (dev < 0 || dev >= 64) dev = 0;
-    if (done_per_device[dev]) return hipSuccess;
+    if (done_per_device[dev].load(std::memory_order_relaxed)) return hipSuccess;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024);
-    if (e == hipSuccess) done_per_device[dev] = true;
+    if (e == hipSuccess) done_per_device[dev].store(true, std::memory_order_relaxed);
     return e;
 }
 

@@ -192,6 +192,8 @@ int upload_builtin_f2d(pdwt_plan* p) {
     return PDWT_OK;
 }
 
+void build_schedule(pdwt_plan* p);
+
 int create_impl(const real_t* img, int batch, int Nr, int Nc, const char* wname, int levels, int mem_is_on_host,
                 int do_separable, int do_cycle_spinning, int do_swt, int ndim, int device_id, void* stream,
                 pdwt_handle* out) {
@@ -270,6 +272,7 @@ int create_impl(const real_t* img, int batch, int Nr, int Nc, const char* wname,
         p->own_stream = true;
     }
     if ((rc = build_layout(p)) != PDWT_OK) return bail(rc);
+    build_schedule(p);
     if (img) {
         hipError_t e = hipMemcpyAsync(p->image(), img, (size_t)batch * Nr * Nc * sizeof(real_t),
                                       mem_is_on_host ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, p->stream);
@@ -285,360 +288,333 @@ int create_impl(const real_t* img, int batch, int Nr, int Nc, const char* wname,
 }
 
 // ---------------------------------------------------------------- level loops
-
-// First levels l of the 2D level pairs (l, l+1) that run as ONE pyramid launch: separable DWT, short even
-// filters, even / aligned sizes, and SMALL levels only -- at most 2^20 samples enter the pair, where the
-// fixed cost of a launch (not bandwidth) is what the level costs (launch_dwt2_pyramid.hip has the numbers).
-std::vector<int> pyramid_pairs(const pdwt_plan* p) {
-    std::vector<int> v;
-    if (p->info.ndims != 2 || p->info.do_swt || !p->do_separable || getenv("PDWT_NO_PYRAMID")) return v;
-    const int L = p->info.nlevels;
-    for (int l = 1; l + 1 <= L; l++) {
-        const long long samples = (long long)p->batch * p->lr[l - 1] * p->lc[l - 1];
-        if (samples <= (1LL << 20) && dwt2_pyramid_supported(p->info.hlen, p->lr[l - 1], p->lc[l - 1])) {
-            v.push_back(l);
-            l++;  // level l+1 is consumed by the pair
-        }
-    }
-    return v;
-}
-
-// First levels l of the level pairs (l, l+1) that run as one streaming-strip launch (dwt2_strip_kernels.hpp):
-// the opposite regime of the tile pyramid -- at least 2^26 samples enter the pair (a batch of large
-// images), where the level is bandwidth-bound and not writing + re-reading A_l is what pays.
-// Measured (MI355X, db4, 8 x 4096^2, profiles/r01f_kbench_strip.txt): forward 284 -> 232 us; the INVERSE
-// strip kernel is no faster than two launches (292 vs 290 us: it reads seven bands at once), so it
-// only runs when PDWT_FORCE_STRIP=1 (tests); that variable also drops the size threshold.
-// PDWT_NO_STRIP=1 disables the path.
-std::vector<int> strip_pairs(const pdwt_plan* p, bool inverse) {
-    std::vector<int> v;
-    if (p->info.ndims != 2 || p->info.do_swt || !p->do_separable || getenv("PDWT_NO_STRIP")) return v;
-    const bool force = getenv("PDWT_FORCE_STRIP") != nullptr;
-    if (inverse && !force) return v;
-    const long long min_samples = force ? 0 : (1LL << 26);
-    const int L = p->info.nlevels;
-    for (int l = 1; l + 1 <= L; l++) {
-        const long long samples = (long long)p->batch * p->lr[l - 1] * p->lc[l - 1];
-        if (samples >= min_samples && dwt2_pyramid_supported(p->info.hlen, p->lr[l - 1], p->lc[l - 1])) {
-            v.push_back(l);
-            l++;
-        }
-    }
-    return v;
-}
-
-bool in_list(const std::vector<int>& v, int x) {
-    for (int e : v)
-        if (e == x) return true;
-    return false;
-}
+//
+// The launch list of a plan is decided ONCE (create, clone, set_filters_forward: build_schedule) and
+// replayed by forward_impl / inverse_impl: no environment lookups, no allocations per call.  A step is
+// one launch: a single level, a two-level tile pyramid (small 2D levels), a two-level streaming strip
+// (batches of large images) or a fused run of K 1D levels.  The planner's eligibility tests are the
+// launchers' own predicates (dwt2_pyramid_supported, dwt1_fused_supported); should a launcher still
+// answer hipErrorNotSupported, the step's levels run through the per-level kernels instead.
 
 constexpr int kMaxFusedLevelsHost = 10;  // == kMaxFusedLevels of dwt1_fused_kernels.hpp
 
-// Partition of the 1D levels into runs handled by ONE fused launch: (first level - 1, K) with K >= 2,
-// 2^K dividing the run's input length (every level length even, see dwt1_fused_kernels.hpp) and K
-// within the LDS budget of the filter length.  Levels not covered run through the per-level kernels.
-std::vector<std::pair<int, int>> fused_groups_1d(const pdwt_plan* p) {
-    std::vector<std::pair<int, int>> g;
-    const int L = p->info.nlevels, hlen = p->info.hlen;
-    if ((hlen & 1) || hlen > kMaxTaps || getenv("PDWT_NO_FUSED_1D")) return g;
-    const int cap = dwt1_fused_max_levels(hlen);
-    int l = 0;
-    while (l < L) {
-        int K = L - l < cap ? L - l : cap;
-        // 2^K | N makes every level length even (exactness); 4 | N >> K keeps every band row 16-B aligned
-        while (K >= 2 && (p->lc[l] % (1 << (K + 2))) != 0) --K;
-        if (K >= 2) {
-            g.push_back({l, K});
-            l += K;
-        } else {
-            ++l;
-        }
-    }
-    return g;
+// Where the approximation of level l lives: l = 0 the image, l = L band 0, otherwise its slot in the
+// arena (SWT: two ping-pong planes).  Forward level l reads slot l-1 and writes slot l; inverse level l
+// reads slot l and writes slot l-1 (band 0 is never overwritten).
+real_t* approx_slot(const pdwt_plan* p, int l) {
+    const int L = p->info.nlevels;
+    if (l <= 0) return p->image();
+    if (l >= L) return p->band(0);
+    return p->arena + (p->info.do_swt ? p->approx_off[l & 1] : p->approx_off[l]);
 }
 
-// only == 0: every level; only == l: just the launch(es) of level l (pdwt_time_level)
-int forward_impl(pdwt_plan* p, int only = 0) {
-    const int L = p->info.nlevels, B = p->batch, hlen = p->info.hlen;
+void build_schedule(pdwt_plan* p) {
+    using pdwt::Step;
+    p->sched_fwd.clear();
+    p->sched_inv.clear();
+    const int L = p->info.nlevels, hlen = p->info.hlen;
     const bool swt = p->info.do_swt != 0;
-    const real_t* src = p->image();
     if (p->info.ndims == 2) {
-        const std::vector<int> strips = strip_pairs(p, false);
-        std::vector<int> pyr = pyramid_pairs(p);
-        for (int l = 1; l <= L; l++) {
-            const bool run = (only == 0 || only == l);
-            if (in_list(strips, l)) {
-                real_t* det1[3] = {p->band(3 * (l - 1) + 1), p->band(3 * (l - 1) + 2), p->band(3 * (l - 1) + 3)};
-                real_t* A2 = (l + 1 == L) ? p->band(0) : p->arena + p->approx_off[l + 1];
-                real_t* band2[4] = {A2, p->band(3 * l + 1), p->band(3 * l + 2), p->band(3 * l + 3)};
-                Stamp st(p, "dwt2_fwd_strip2");
-                if (run) HIP_TRY(launch_dwt2_fwd_strip2(src, det1, band2, p->lr[l - 1], p->lc[l - 1], hlen, p->dec, B,
-                                                        p->stream));
-                src = A2;
-                l++;
-                continue;
+        const bool fusable = !swt && p->do_separable;
+        // Tile pyramid: SMALL level pairs (at most 2^20 samples enter the pair), where the fixed cost of a
+        // launch is what a level costs (launch_dwt2_pyramid.hip has the numbers).  Streaming strips: the
+        // opposite regime, >= 2^26 samples enter the pair (a batch of large images): the level is
+        // bandwidth-bound and not writing + re-reading A_l pays (forward 284 -> 232 us for 8 x 4096^2,
+        // profiles/r01f_kbench_strip.txt); the INVERSE strip kernel is no faster than two launches and only
+        // runs under PDWT_FORCE_STRIP=1 (tests), which also drops the size threshold.
+        const bool no_pyr = getenv("PDWT_NO_PYRAMID") != nullptr, no_strip = getenv("PDWT_NO_STRIP") != nullptr;
+        const bool force_strip = getenv("PDWT_FORCE_STRIP") != nullptr;
+        auto samples = [&](int l) { return (long long)p->batch * p->lr[l - 1] * p->lc[l - 1]; };
+        auto pair_ok = [&](int l) { return l + 1 <= L && dwt2_pyramid_supported(hlen, p->lr[l - 1], p->lc[l - 1]); };
+        auto strip_at = [&](int l, bool inverse) {
+            if (!fusable || no_strip || !pair_ok(l) || (inverse && !force_strip)) return false;
+            return force_strip || samples(l) >= (1LL << 26);
+        };
+        auto pyr_at = [&](int l) { return fusable && !no_pyr && pair_ok(l) && samples(l) <= (1LL << 20); };
+        for (int dir = 0; dir < 2; dir++) {
+            std::vector<Step>& out = dir ? p->sched_inv : p->sched_fwd;
+            for (int l = 1; l <= L; l++) {
+                if (strip_at(l, dir != 0)) { out.push_back({Step::STRIP2, l, 2}); l++; }
+                else if (pyr_at(l) && !strip_at(l + 1, dir != 0)) { out.push_back({Step::PYR2, l, 2}); l++; }
+                else out.push_back({Step::LEVEL, l, 1});
             }
-            if (in_list(pyr, l) && !in_list(strips, l + 1)) {
-                // levels l and l+1 in one launch; A_l never leaves LDS
-                real_t* det1[3] = {p->band(3 * (l - 1) + 1), p->band(3 * (l - 1) + 2), p->band(3 * (l - 1) + 3)};
-                real_t* A2 = (l + 1 == L) ? p->band(0) : p->arena + p->approx_off[l + 1];
-                real_t* band2[4] = {A2, p->band(3 * l + 1), p->band(3 * l + 2), p->band(3 * l + 3)};
-                Stamp st(p, "dwt2_fwd_pyr2");
-                if (run) HIP_TRY(launch_dwt2_fwd_pyr2(src, det1, band2, p->lr[l - 1], p->lc[l - 1], hlen, p->dec, B,
-                                                      p->stream));
-                src = A2;
-                l++;
-                continue;
-            }
-            real_t* dstA = (l == L) ? p->band(0)
-                                   : p->arena + (swt ? p->approx_off[l & 1] : p->approx_off[l]);
-            real_t* H = p->band(3 * (l - 1) + 1);
-            real_t* V = p->band(3 * (l - 1) + 2);
-            real_t* D = p->band(3 * (l - 1) + 3);
-            if (!p->do_separable) {
-                NonsepArgs a;
-                a.in = src; a.A = dstA; a.H = H; a.V = V; a.D = D; a.out = nullptr;
-                a.filt = p->d_f2d;  // forward banks
-                a.Nr = p->lr[l - 1]; a.Nc = p->lc[l - 1]; a.Nrc = p->lr[l]; a.Ncc = p->lc[l];
-                a.f = 1 << (l - 1); a.do_swt = swt ? 1 : 0;
-                a.img_bstride = (long long)a.Nr * a.Nc; a.coef_bstride = (long long)a.Nrc * a.Ncc;
-                a.hlen = hlen;
-                Stamp st(p, "nonsep_fwd_level");
-                if (run) HIP_TRY(launch_nonsep_fwd(a, B, p->stream));
-            } else if (!swt) {
-                Fwd2DArgs a;
-                a.in = src; a.A = dstA; a.H = H; a.V = V; a.D = D;
-                a.Nr = p->lr[l - 1]; a.Nc = p->lc[l - 1]; a.Nr2 = p->lr[l]; a.Nc2 = p->lc[l];
-                a.in_bstride = (long long)a.Nr * a.Nc;
-                a.out_bstride = (long long)a.Nr2 * a.Nc2;
-                a.hlen = hlen;
-                a.fb = p->dec;
-                Stamp st(p, "dwt2_fwd_level");
-                if (run) HIP_TRY(launch_dwt2_fwd(a, B, p->stream));
-            } else {
-                const int f = 1 << (l - 1);
-                const int Nr = p->info.Nr, Nc = p->info.Nc;
-                if (Nr % f == 0) {
-                    Swt2DArgs a;
-                    a.in = src; a.A = dstA; a.H = H; a.V = V; a.D = D; a.out = nullptr;
-                    a.Nr = Nr; a.Nc = Nc; a.f = f;
-                    a.bstride = (long long)Nr * Nc;
-                    a.hlen = hlen;
-                    a.soft_beta = 0.f;
-                    a.fb = p->dec;
-                    Stamp st(p, "swt2_fwd_level");
-                    if (run) HIP_TRY(launch_swt2_fwd(a, B, p->stream));
-                } else {
-                    // dilation does not divide the row count: two direct passes through scratch
-                    const long long plane = (long long)Nr * Nc;
-                    int rc = ensure_tmp(p, 2 * plane);
-                    if (rc != PDWT_OK) return rc;
-                    for (int b = 0; b < B; b++) {
-                        SwtPassArgs r;
-                        r.in0 = src + b * plane; r.in1 = nullptr; r.out0 = p->tmp; r.out1 = p->tmp + plane;
-                        r.Nr = Nr; r.Nc = Nc; r.f = f; r.along_y = 0; r.hlen = hlen; r.fb = p->dec;
-                        Stamp st(p, "swt_pass_fwd");
-                        if (run) HIP_TRY(launch_swt_pass_fwd(r, p->stream));
-                        SwtPassArgs c1 = r;
-                        c1.in0 = p->tmp; c1.out0 = dstA + b * plane; c1.out1 = H + b * plane; c1.along_y = 1;
-                        if (run) HIP_TRY(launch_swt_pass_fwd(c1, p->stream));
-                        SwtPassArgs c2 = c1;
-                        c2.in0 = p->tmp + plane; c2.out0 = V + b * plane; c2.out1 = D + b * plane;
-                        if (run) HIP_TRY(launch_swt_pass_fwd(c2, p->stream));
-                    }
-                }
-            }
-            src = dstA;
         }
+        // the inverse undoes the deepest level first
+        std::vector<Step> rev(p->sched_inv.rbegin(), p->sched_inv.rend());
+        p->sched_inv.swap(rev);
     } else {
-        const int rows = B * p->info.Nr;
-        std::vector<std::pair<int, int>> groups = swt ? std::vector<std::pair<int, int>>() : fused_groups_1d(p);
-        size_t gi = 0;
-        for (int l = 1; l <= L; l++) {
-            const bool run = (only == 0 || only == l);
-            if (gi < groups.size() && groups[gi].first == l - 1) {
-                // levels l .. l+K-1 in ONE launch (dwt1_fused_kernels.hpp)
-                const int K = groups[gi].second;
-                real_t* det[kMaxFusedLevelsHost] = {};
-                for (int k = 0; k < K; k++) det[k] = p->band(l + k);
-                real_t* app = (l + K - 1 == L) ? p->band(0) : p->arena + p->approx_off[l + K - 1];
-                Stamp st(p, "dwt1_fwd_fused");
-                if (run) HIP_TRY(launch_dwt1_fwd_fused(src, det, app, rows, p->lc[l - 1], K, hlen, p->dec, p->stream));
-                src = app;
-                l += K - 1;
-                gi++;
-                continue;
-            }
-            real_t* dstA = (l == L) ? p->band(0)
-                                   : p->arena + (swt ? p->approx_off[l & 1] : p->approx_off[l]);
-            real_t* Dl = p->band(l);
-            if (!swt) {
-                Fwd1DArgs a;
-                a.in = src; a.L = dstA; a.H = Dl;
-                a.rows = rows; a.Nc = p->lc[l - 1]; a.Nc2 = p->lc[l];
-                a.hlen = hlen;
-                a.fb = p->dec;
-                Stamp st(p, "dwt1_fwd_level");
-                if (run) HIP_TRY(launch_dwt1_fwd(a, p->stream));
+        // 1D: runs of K >= 2 levels in ONE fused launch (dwt1_fused_kernels.hpp); the rest level by level
+        const bool fuse = !swt && getenv("PDWT_NO_FUSED_1D") == nullptr;
+        const int cap = dwt1_fused_max_levels(hlen);
+        int l = 0;
+        while (l < L) {
+            int K = fuse ? (L - l < cap ? L - l : cap) : 1;
+            while (K >= 2 && !dwt1_fused_supported(hlen, p->lc[l], K)) --K;
+            if (K >= 2) {
+                p->sched_fwd.push_back({Step::FUSED1D, l + 1, K});
+                l += K;
             } else {
-                SwtPassArgs r;
-                r.in0 = src; r.in1 = nullptr; r.out0 = dstA; r.out1 = Dl;
-                r.Nr = rows; r.Nc = p->info.Nc; r.f = 1 << (l - 1); r.along_y = 0; r.hlen = hlen; r.fb = p->dec;
-                Stamp st(p, "swt1_fwd_level");
-                if (run) HIP_TRY(launch_swt_pass_fwd(r, p->stream));
+                p->sched_fwd.push_back({Step::LEVEL, l + 1, 1});
+                ++l;
             }
-            src = dstA;
+        }
+        p->sched_inv.assign(p->sched_fwd.rbegin(), p->sched_fwd.rend());
+    }
+}
+
+// ---- one 2D level (any kind of plan)
+int fwd_level_2d(pdwt_plan* p, int l, bool run) {
+    const int B = p->batch, hlen = p->info.hlen;
+    const bool swt = p->info.do_swt != 0;
+    const real_t* src = approx_slot(p, l - 1);
+    real_t* dstA = approx_slot(p, l);
+    real_t* H = p->band(3 * (l - 1) + 1);
+    real_t* V = p->band(3 * (l - 1) + 2);
+    real_t* D = p->band(3 * (l - 1) + 3);
+    if (!p->do_separable) {
+        NonsepArgs a;
+        a.in = src; a.A = dstA; a.H = H; a.V = V; a.D = D; a.out = nullptr;
+        a.filt = p->d_f2d;  // forward banks
+        a.Nr = p->lr[l - 1]; a.Nc = p->lc[l - 1]; a.Nrc = p->lr[l]; a.Ncc = p->lc[l];
+        a.f = 1 << (l - 1); a.do_swt = swt ? 1 : 0;
+        a.img_bstride = (long long)a.Nr * a.Nc; a.coef_bstride = (long long)a.Nrc * a.Ncc;
+        a.hlen = hlen;
+        Stamp st(p, "nonsep_fwd_level");
+        if (run) HIP_TRY(launch_nonsep_fwd(a, B, p->stream));
+    } else if (!swt) {
+        Fwd2DArgs a;
+        a.in = src; a.A = dstA; a.H = H; a.V = V; a.D = D;
+        a.Nr = p->lr[l - 1]; a.Nc = p->lc[l - 1]; a.Nr2 = p->lr[l]; a.Nc2 = p->lc[l];
+        a.in_bstride = (long long)a.Nr * a.Nc;
+        a.out_bstride = (long long)a.Nr2 * a.Nc2;
+        a.hlen = hlen;
+        a.fb = p->dec;
+        Stamp st(p, "dwt2_fwd_level");
+        if (run) HIP_TRY(launch_dwt2_fwd(a, B, p->stream));
+    } else {
+        const int f = 1 << (l - 1);
+        const int Nr = p->info.Nr, Nc = p->info.Nc;
+        if (Nr % f == 0) {
+            Swt2DArgs a;
+            a.in = src; a.A = dstA; a.H = H; a.V = V; a.D = D; a.out = nullptr;
+            a.Nr = Nr; a.Nc = Nc; a.f = f;
+            a.bstride = (long long)Nr * Nc;
+            a.hlen = hlen;
+            a.soft_beta = 0.f;
+            a.fb = p->dec;
+            Stamp st(p, "swt2_fwd_level");
+            if (run) HIP_TRY(launch_swt2_fwd(a, B, p->stream));
+        } else {
+            // dilation does not divide the row count: two direct passes through scratch
+            const long long plane = (long long)Nr * Nc;
+            int rc = ensure_tmp(p, 2 * plane);
+            if (rc != PDWT_OK) return rc;
+            for (int b = 0; b < B; b++) {
+                SwtPassArgs r;
+                r.in0 = src + b * plane; r.in1 = nullptr; r.out0 = p->tmp; r.out1 = p->tmp + plane;
+                r.Nr = Nr; r.Nc = Nc; r.f = f; r.along_y = 0; r.hlen = hlen; r.fb = p->dec;
+                Stamp st(p, "swt_pass_fwd");
+                if (run) HIP_TRY(launch_swt_pass_fwd(r, p->stream));
+                SwtPassArgs c1 = r;
+                c1.in0 = p->tmp; c1.out0 = dstA + b * plane; c1.out1 = H + b * plane; c1.along_y = 1;
+                if (run) HIP_TRY(launch_swt_pass_fwd(c1, p->stream));
+                SwtPassArgs c2 = c1;
+                c2.in0 = p->tmp + plane; c2.out0 = V + b * plane; c2.out1 = D + b * plane;
+                if (run) HIP_TRY(launch_swt_pass_fwd(c2, p->stream));
+            }
+        }
+    }
+    return PDWT_OK;
+}
+
+int inv_level_2d(pdwt_plan* p, int l, bool run) {
+    const int B = p->batch, hlen = p->info.hlen;
+    const bool swt = p->info.do_swt != 0;
+    const real_t* cur = approx_slot(p, l);
+    real_t* dst = approx_slot(p, l - 1);
+    const real_t* H = p->band(3 * (l - 1) + 1);
+    const real_t* V = p->band(3 * (l - 1) + 2);
+    const real_t* D = p->band(3 * (l - 1) + 3);
+    if (!p->do_separable) {
+        NonsepArgs a;
+        a.in = nullptr;
+        a.A = const_cast<real_t*>(cur); a.H = const_cast<real_t*>(H);
+        a.V = const_cast<real_t*>(V); a.D = const_cast<real_t*>(D);
+        a.out = dst;
+        a.filt = p->d_f2d + (size_t)4 * hlen * hlen;  // inverse banks
+        a.Nr = p->lr[l - 1]; a.Nc = p->lc[l - 1]; a.Nrc = p->lr[l]; a.Ncc = p->lc[l];
+        a.f = 1 << (l - 1); a.do_swt = swt ? 1 : 0;
+        a.img_bstride = (long long)a.Nr * a.Nc; a.coef_bstride = (long long)a.Nrc * a.Ncc;
+        a.hlen = hlen;
+        Stamp st(p, "nonsep_inv_level");
+        if (run) HIP_TRY(launch_nonsep_inv(a, B, p->stream));
+    } else if (!swt) {
+        Inv2DArgs a;
+        a.A = cur; a.H = H; a.V = V; a.D = D; a.out = dst;
+        a.Nrc = p->lr[l]; a.Ncc = p->lc[l]; a.Nr = p->lr[l - 1]; a.Nc = p->lc[l - 1];
+        a.in_bstride = (long long)a.Nrc * a.Ncc;
+        a.out_bstride = (long long)a.Nr * a.Nc;
+        a.hlen = hlen;
+        a.fb = p->rec;
+        Stamp st(p, "dwt2_inv_level");
+        if (run) HIP_TRY(launch_dwt2_inv(a, B, p->stream));
+    } else {
+        const int f = 1 << (l - 1);
+        const int Nr = p->info.Nr, Nc = p->info.Nc;
+        if (Nr % f == 0) {
+            Swt2DArgs a;
+            a.in = nullptr;
+            a.A = const_cast<real_t*>(cur); a.H = const_cast<real_t*>(H);
+            a.V = const_cast<real_t*>(V); a.D = const_cast<real_t*>(D);
+            a.out = dst;
+            a.Nr = Nr; a.Nc = Nc; a.f = f;
+            a.bstride = (long long)Nr * Nc;
+            a.hlen = hlen;
+            a.soft_beta = 0.f;
+            if (p->pend_soft) {  // deferred soft_threshold: beta (/ sqrt(2)^l when normalised)
+                real_t b = p->pend_beta;
+                if (p->pend_normalize > 0)
+                    for (int i = 0; i < l; i++) b = (real_t)(b / 1.4142135623730951);
+                a.soft_beta = b;
+            }
+            a.fb = p->rec;
+            Stamp st(p, p->pend_soft ? "swt2_inv_level+soft" : "swt2_inv_level");
+            if (run) HIP_TRY(launch_swt2_inv(a, B, p->stream));
+        } else {
+            const long long plane = (long long)Nr * Nc;
+            int rc = ensure_tmp(p, 2 * plane);
+            if (rc != PDWT_OK) return rc;
+            for (int b = 0; b < B; b++) {
+                SwtPassArgs c1;
+                c1.in0 = cur + b * plane; c1.in1 = H + b * plane; c1.out0 = p->tmp; c1.out1 = nullptr;
+                c1.Nr = Nr; c1.Nc = Nc; c1.f = f; c1.along_y = 1; c1.hlen = hlen; c1.fb = p->rec;
+                Stamp st(p, "swt_pass_inv");
+                if (run) HIP_TRY(launch_swt_pass_inv(c1, p->stream));
+                SwtPassArgs c2 = c1;
+                c2.in0 = V + b * plane; c2.in1 = D + b * plane; c2.out0 = p->tmp + plane;
+                if (run) HIP_TRY(launch_swt_pass_inv(c2, p->stream));
+                SwtPassArgs r = c1;
+                r.in0 = p->tmp; r.in1 = p->tmp + plane; r.out0 = dst + b * plane; r.along_y = 0;
+                if (run) HIP_TRY(launch_swt_pass_inv(r, p->stream));
+            }
+        }
+    }
+    return PDWT_OK;
+}
+
+// ---- one 1D level
+int fwd_level_1d(pdwt_plan* p, int l, bool run) {
+    const int rows = p->batch * p->info.Nr, hlen = p->info.hlen;
+    const real_t* src = approx_slot(p, l - 1);
+    real_t* dstA = approx_slot(p, l);
+    real_t* Dl = p->band(l);
+    if (!p->info.do_swt) {
+        Fwd1DArgs a;
+        a.in = src; a.L = dstA; a.H = Dl;
+        a.rows = rows; a.Nc = p->lc[l - 1]; a.Nc2 = p->lc[l];
+        a.hlen = hlen;
+        a.fb = p->dec;
+        Stamp st(p, "dwt1_fwd_level");
+        if (run) HIP_TRY(launch_dwt1_fwd(a, p->stream));
+    } else {
+        SwtPassArgs r;
+        r.in0 = src; r.in1 = nullptr; r.out0 = dstA; r.out1 = Dl;
+        r.Nr = rows; r.Nc = p->info.Nc; r.f = 1 << (l - 1); r.along_y = 0; r.hlen = hlen; r.fb = p->dec;
+        Stamp st(p, "swt1_fwd_level");
+        if (run) HIP_TRY(launch_swt_pass_fwd(r, p->stream));
+    }
+    return PDWT_OK;
+}
+
+int inv_level_1d(pdwt_plan* p, int l, bool run) {
+    const int rows = p->batch * p->info.Nr, hlen = p->info.hlen;
+    const real_t* cur = approx_slot(p, l);
+    real_t* dst = approx_slot(p, l - 1);
+    const real_t* Dl = p->band(l);
+    if (!p->info.do_swt) {
+        Inv1DArgs a;
+        a.L = cur; a.H = Dl; a.out = dst;
+        a.rows = rows; a.Ncc = p->lc[l]; a.Nc = p->lc[l - 1];
+        a.hlen = hlen;
+        a.fb = p->rec;
+        Stamp st(p, "dwt1_inv_level");
+        if (run) HIP_TRY(launch_dwt1_inv(a, p->stream));
+    } else {
+        SwtPassArgs r;
+        r.in0 = cur; r.in1 = Dl; r.out0 = dst; r.out1 = nullptr;
+        r.Nr = rows; r.Nc = p->info.Nc; r.f = 1 << (l - 1); r.along_y = 0; r.hlen = hlen; r.fb = p->rec;
+        Stamp st(p, "swt1_inv_level");
+        if (run) HIP_TRY(launch_swt_pass_inv(r, p->stream));
+    }
+    return PDWT_OK;
+}
+
+// only == 0: every step; only == l: just the launch whose first (finest) level is l (pdwt_time_level)
+int forward_impl(pdwt_plan* p, int only = 0) {
+    using pdwt::Step;
+    const int L = p->info.nlevels, B = p->batch, hlen = p->info.hlen;
+    const bool two_d = p->info.ndims == 2;
+    for (const Step& s : p->sched_fwd) {
+        const int l = s.level;
+        const bool run = (only == 0 || only == l);
+        hipError_t e = hipErrorNotSupported;
+        if (s.kind == Step::STRIP2 || s.kind == Step::PYR2) {
+            // levels l and l+1 in one launch; A_l never reaches HBM
+            real_t* det1[3] = {p->band(3 * (l - 1) + 1), p->band(3 * (l - 1) + 2), p->band(3 * (l - 1) + 3)};
+            real_t* band2[4] = {approx_slot(p, l + 1), p->band(3 * l + 1), p->band(3 * l + 2), p->band(3 * l + 3)};
+            Stamp st(p, s.kind == Step::STRIP2 ? "dwt2_fwd_strip2" : "dwt2_fwd_pyr2");
+            if (!run) continue;
+            e = s.kind == Step::STRIP2
+                    ? launch_dwt2_fwd_strip2(approx_slot(p, l - 1), det1, band2, p->lr[l - 1], p->lc[l - 1], hlen, p->dec, B, p->stream)
+                    : launch_dwt2_fwd_pyr2(approx_slot(p, l - 1), det1, band2, p->lr[l - 1], p->lc[l - 1], hlen, p->dec, B, p->stream);
+        } else if (s.kind == Step::FUSED1D) {
+            real_t* det[kMaxFusedLevelsHost] = {};
+            for (int k = 0; k < s.K; k++) det[k] = p->band(l + k);
+            Stamp st(p, "dwt1_fwd_fused");
+            if (!run) continue;
+            e = launch_dwt1_fwd_fused(approx_slot(p, l - 1), det, approx_slot(p, l + s.K - 1), B * p->info.Nr, p->lc[l - 1], s.K,
+                                      hlen, p->dec, p->stream);
+        }
+        if (e == hipSuccess) continue;
+        if (e != hipErrorNotSupported) HIP_TRY(e);
+        // a single level, or a fused step its launcher declined: level by level
+        for (int k = 0; k < s.K && l + k <= L; k++) {
+            const int rc = two_d ? fwd_level_2d(p, l + k, run) : fwd_level_1d(p, l + k, run);
+            if (rc != PDWT_OK) return rc;
         }
     }
     return PDWT_OK;
 }
 
 int inverse_impl(pdwt_plan* p, int only = 0) {
-    const int L = p->info.nlevels, B = p->batch, hlen = p->info.hlen;
-    const bool swt = p->info.do_swt != 0;
-    const real_t* cur = p->band(0);
-    if (p->info.ndims == 2) {
-        const std::vector<int> pyr = pyramid_pairs(p);
-        const std::vector<int> strips = strip_pairs(p, true);
-        for (int l = L; l >= 1; l--) {
-            if (l >= 2 && in_list(strips, l - 1)) {
-                const int l1 = l - 1;
-                const real_t* band2[4] = {cur, p->band(3 * (l - 1) + 1), p->band(3 * (l - 1) + 2), p->band(3 * (l - 1) + 3)};
-                const real_t* det1[3] = {p->band(3 * (l1 - 1) + 1), p->band(3 * (l1 - 1) + 2), p->band(3 * (l1 - 1) + 3)};
-                real_t* dst = (l1 == 1) ? p->image() : p->arena + p->approx_off[l1 - 1];
-                Stamp st(p, "dwt2_inv_strip2");
-                if (only == 0 || only == l1)
-                    HIP_TRY(launch_dwt2_inv_strip2(band2, det1, dst, p->lr[l1 - 1], p->lc[l1 - 1], hlen, p->rec, B,
-                                                   p->stream));
-                cur = dst;
-                l--;
-                continue;
-            }
-            if (l >= 2 && in_list(pyr, l - 1) && !in_list(strips, l)) {
-                // levels l and l-1 undone in one launch: A_{l-1} is synthesised in LDS
-                const int l1 = l - 1;
-                const real_t* band2[4] = {cur, p->band(3 * (l - 1) + 1), p->band(3 * (l - 1) + 2), p->band(3 * (l - 1) + 3)};
-                const real_t* det1[3] = {p->band(3 * (l1 - 1) + 1), p->band(3 * (l1 - 1) + 2), p->band(3 * (l1 - 1) + 3)};
-                real_t* dst = (l1 == 1) ? p->image() : p->arena + p->approx_off[l1 - 1];
-                Stamp st(p, "dwt2_inv_pyr2");
-                if (only == 0 || only == l1)
-                    HIP_TRY(launch_dwt2_inv_pyr2(band2, det1, dst, p->lr[l1 - 1], p->lc[l1 - 1], hlen, p->rec, B,
-                                                 p->stream));
-                cur = dst;
-                l--;
-                continue;
-            }
-            const bool run = (only == 0 || only == l);
-            real_t* dst = (l == 1) ? p->image()
-                                  : p->arena + (swt ? p->approx_off[(l - 1) & 1] : p->approx_off[l - 1]);
-            const real_t* H = p->band(3 * (l - 1) + 1);
-            const real_t* V = p->band(3 * (l - 1) + 2);
-            const real_t* D = p->band(3 * (l - 1) + 3);
-            if (!p->do_separable) {
-                NonsepArgs a;
-                a.in = nullptr;
-                a.A = const_cast<real_t*>(cur); a.H = const_cast<real_t*>(H);
-                a.V = const_cast<real_t*>(V); a.D = const_cast<real_t*>(D);
-                a.out = dst;
-                a.filt = p->d_f2d + (size_t)4 * hlen * hlen;  // inverse banks
-                a.Nr = p->lr[l - 1]; a.Nc = p->lc[l - 1]; a.Nrc = p->lr[l]; a.Ncc = p->lc[l];
-                a.f = 1 << (l - 1); a.do_swt = swt ? 1 : 0;
-                a.img_bstride = (long long)a.Nr * a.Nc; a.coef_bstride = (long long)a.Nrc * a.Ncc;
-                a.hlen = hlen;
-                Stamp st(p, "nonsep_inv_level");
-                if (run) HIP_TRY(launch_nonsep_inv(a, B, p->stream));
-            } else if (!swt) {
-                Inv2DArgs a;
-                a.A = cur; a.H = H; a.V = V; a.D = D; a.out = dst;
-                a.Nrc = p->lr[l]; a.Ncc = p->lc[l]; a.Nr = p->lr[l - 1]; a.Nc = p->lc[l - 1];
-                a.in_bstride = (long long)a.Nrc * a.Ncc;
-                a.out_bstride = (long long)a.Nr * a.Nc;
-                a.hlen = hlen;
-                a.fb = p->rec;
-                Stamp st(p, "dwt2_inv_level");
-                if (run) HIP_TRY(launch_dwt2_inv(a, B, p->stream));
-            } else {
-                const int f = 1 << (l - 1);
-                const int Nr = p->info.Nr, Nc = p->info.Nc;
-                if (Nr % f == 0) {
-                    Swt2DArgs a;
-                    a.in = nullptr;
-                    a.A = const_cast<real_t*>(cur); a.H = const_cast<real_t*>(H);
-                    a.V = const_cast<real_t*>(V); a.D = const_cast<real_t*>(D);
-                    a.out = dst;
-                    a.Nr = Nr; a.Nc = Nc; a.f = f;
-                    a.bstride = (long long)Nr * Nc;
-                    a.hlen = hlen;
-                    a.soft_beta = 0.f;
-                    if (p->pend_soft) {  // deferred soft_threshold: beta (/ sqrt(2)^l when normalised)
-                        real_t b = p->pend_beta;
-                        if (p->pend_normalize > 0)
-                            for (int i = 0; i < l; i++) b = (real_t)(b / 1.4142135623730951);
-                        a.soft_beta = b;
-                    }
-                    a.fb = p->rec;
-                    Stamp st(p, p->pend_soft ? "swt2_inv_level+soft" : "swt2_inv_level");
-                    if (run) HIP_TRY(launch_swt2_inv(a, B, p->stream));
-                } else {
-                    const long long plane = (long long)Nr * Nc;
-                    int rc = ensure_tmp(p, 2 * plane);
-                    if (rc != PDWT_OK) return rc;
-                    for (int b = 0; b < B; b++) {
-                        SwtPassArgs c1;
-                        c1.in0 = cur + b * plane; c1.in1 = H + b * plane; c1.out0 = p->tmp; c1.out1 = nullptr;
-                        c1.Nr = Nr; c1.Nc = Nc; c1.f = f; c1.along_y = 1; c1.hlen = hlen; c1.fb = p->rec;
-                        Stamp st(p, "swt_pass_inv");
-                        if (run) HIP_TRY(launch_swt_pass_inv(c1, p->stream));
-                        SwtPassArgs c2 = c1;
-                        c2.in0 = V + b * plane; c2.in1 = D + b * plane; c2.out0 = p->tmp + plane;
-                        if (run) HIP_TRY(launch_swt_pass_inv(c2, p->stream));
-                        SwtPassArgs r = c1;
-                        r.in0 = p->tmp; r.in1 = p->tmp + plane; r.out0 = dst + b * plane; r.along_y = 0;
-                        if (run) HIP_TRY(launch_swt_pass_inv(r, p->stream));
-                    }
-                }
-            }
-            cur = dst;
+    using pdwt::Step;
+    const int B = p->batch, hlen = p->info.hlen;
+    const bool two_d = p->info.ndims == 2;
+    for (const Step& s : p->sched_inv) {
+        const int l = s.level;  // the step undoes levels l+K-1 .. l and writes approximation slot l-1
+        const bool run = (only == 0 || only == l);
+        hipError_t e = hipErrorNotSupported;
+        if (s.kind == Step::STRIP2 || s.kind == Step::PYR2) {
+            const real_t* band2[4] = {approx_slot(p, l + 1), p->band(3 * l + 1), p->band(3 * l + 2), p->band(3 * l + 3)};
+            const real_t* det1[3] = {p->band(3 * (l - 1) + 1), p->band(3 * (l - 1) + 2), p->band(3 * (l - 1) + 3)};
+            Stamp st(p, s.kind == Step::STRIP2 ? "dwt2_inv_strip2" : "dwt2_inv_pyr2");
+            if (!run) continue;
+            e = s.kind == Step::STRIP2
+                    ? launch_dwt2_inv_strip2(band2, det1, approx_slot(p, l - 1), p->lr[l - 1], p->lc[l - 1], hlen, p->rec, B, p->stream)
+                    : launch_dwt2_inv_pyr2(band2, det1, approx_slot(p, l - 1), p->lr[l - 1], p->lc[l - 1], hlen, p->rec, B, p->stream);
+        } else if (s.kind == Step::FUSED1D) {
+            const real_t* det[kMaxFusedLevelsHost] = {};
+            for (int k = 0; k < s.K; k++) det[k] = p->band(l + k);
+            Stamp st(p, "dwt1_inv_fused");
+            if (!run) continue;
+            e = launch_dwt1_inv_fused(approx_slot(p, l + s.K - 1), det, approx_slot(p, l - 1), B * p->info.Nr, p->lc[l - 1], s.K, hlen,
+                                      p->rec, p->stream);
         }
-    } else {
-        const int rows = B * p->info.Nr;
-        std::vector<std::pair<int, int>> groups = swt ? std::vector<std::pair<int, int>>() : fused_groups_1d(p);
-        int gi = (int)groups.size() - 1;
-        for (int l = L; l >= 1; l--) {
-            const bool run = (only == 0 || only == l);
-            if (gi >= 0 && groups[gi].first + groups[gi].second == l) {
-                // levels l-K+1 .. l undone in ONE launch
-                const int K = groups[gi].second, l0 = groups[gi].first;  // l0 = level of the output (0 = image)
-                const real_t* det[kMaxFusedLevelsHost] = {};
-                for (int k = 0; k < K; k++) det[k] = p->band(l0 + 1 + k);
-                real_t* dst = (l0 == 0) ? p->image() : p->arena + p->approx_off[l0];
-                Stamp st(p, "dwt1_inv_fused");
-                if (only == 0 || only == l0 + 1) HIP_TRY(launch_dwt1_inv_fused(cur, det, dst, rows, p->lc[l0], K, hlen, p->rec, p->stream));
-                cur = dst;
-                l = l0 + 1;
-                gi--;
-                continue;
-            }
-            real_t* dst = (l == 1) ? p->image()
-                                  : p->arena + (swt ? p->approx_off[(l - 1) & 1] : p->approx_off[l - 1]);
-            const real_t* Dl = p->band(l);
-            if (!swt) {
-                Inv1DArgs a;
-                a.L = cur; a.H = Dl; a.out = dst;
-                a.rows = rows; a.Ncc = p->lc[l]; a.Nc = p->lc[l - 1];
-                a.hlen = hlen;
-                a.fb = p->rec;
-                Stamp st(p, "dwt1_inv_level");
-                if (run) HIP_TRY(launch_dwt1_inv(a, p->stream));
-            } else {
-                SwtPassArgs r;
-                r.in0 = cur; r.in1 = Dl; r.out0 = dst; r.out1 = nullptr;
-                r.Nr = rows; r.Nc = p->info.Nc; r.f = 1 << (l - 1); r.along_y = 0; r.hlen = hlen; r.fb = p->rec;
-                Stamp st(p, "swt1_inv_level");
-                if (run) HIP_TRY(launch_swt_pass_inv(r, p->stream));
-            }
-            cur = dst;
+        if (e == hipSuccess) continue;
+        if (e != hipErrorNotSupported) HIP_TRY(e);
+        for (int k = s.K - 1; k >= 0; k--) {
+            const int rc = two_d ? inv_level_2d(p, l + k, run) : inv_level_1d(p, l + k, run);
+            if (rc != PDWT_OK) return rc;
         }
     }
     return PDWT_OK;
@@ -675,6 +651,7 @@ real_t app_beta(real_t beta, int levels, int normalize) {
 }
 
 int threshold_impl(pdwt_plan* p, int op, real_t beta, int do_app, int normalize, const char* what);
+int threshold_sweep(pdwt_plan* p, int op, real_t beta, int do_app, int normalize, const char* what);
 
 // apply a deferred soft_threshold now (every consumer of the coefficients other than the fused SWT
 // inverse calls this first)
@@ -682,6 +659,15 @@ int materialize_pending(pdwt_plan* p) {
     if (!p->pend_soft) return PDWT_OK;
     p->pend_soft = false;
     return threshold_impl(p, EW_SOFT, p->pend_beta, 0, p->pend_normalize, "soft_threshold");
+}
+
+// A deferred threshold that the fused SWT inverse applied on the fly never reached the stored detail
+// bands.  Before they become observable again (set_coeff re-arming the inverse, a device pointer handed
+// out) it is applied to them, so that the result does not depend on whether the fused path was taken.
+int materialize_consumed(pdwt_plan* p) {
+    if (!p->soft_consumed) return PDWT_OK;
+    p->soft_consumed = false;
+    return threshold_sweep(p, EW_SOFT, p->consumed_beta, 0, p->consumed_normalize, "soft_threshold");
 }
 
 // can the inverse of this plan apply a soft threshold on the fly?  (fused 2D SWT kernels on every level)
@@ -698,6 +684,10 @@ int threshold_impl(pdwt_plan* p, int op, real_t beta, int do_app, int normalize,
         const int rc = materialize_pending(p);
         if (rc != PDWT_OK) return rc;
     }
+    return threshold_sweep(p, op, beta, do_app, normalize, what);
+}
+
+int threshold_sweep(pdwt_plan* p, int op, real_t beta, int do_app, int normalize, const char* what) {
     const int L = p->info.nlevels, B = p->batch;
     if (do_app) {
         Stamp st(p, what);
@@ -796,6 +786,8 @@ int pdwt_clone(pdwt_handle src, pdwt_handle* out) {
     p->own_stream = true;
     int rc = build_layout(p);
     if (rc != PDWT_OK) { pdwt_destroy(p); return rc; }
+    p->sched_fwd = src->sched_fwd;
+    p->sched_inv = src->sched_inv;
     e = hipStreamSynchronize(src->stream);
     if (e == hipSuccess)
         e = hipMemcpyAsync(p->arena, src->arena, (size_t)p->arena_elems * sizeof(real_t), hipMemcpyDeviceToDevice,
@@ -833,6 +825,7 @@ int pdwt_forward(pdwt_handle h) {  // Wavelets::forward, wt.cu:236-269
         return fail(PDWT_ERR_STATE, "forward transform not computed, as there was an error when creating the wavelets");
     DeviceGuard guard(h->device);
     h->pend_soft = false;  // the coefficients a deferred threshold referred to are about to be overwritten
+    h->soft_consumed = false;
     if (h->do_cycle_spinning) {  // wt.cu:242-246
         h->shift_r = rand() % h->info.Nr;
         h->shift_c = rand() % h->info.Nc;
@@ -852,7 +845,12 @@ int pdwt_inverse(pdwt_handle h) {  // Wavelets::inverse, wt.cu:271-305
         return fail(PDWT_ERR_STATE, "inverse transform not computed, as there was an error in a previous stage");
     DeviceGuard guard(h->device);
     int rc = inverse_impl(h);
-    h->pend_soft = false;  // consumed by the fused kernels
+    if (h->pend_soft && rc == PDWT_OK) {  // consumed by the fused kernels, not written back (materialize_consumed)
+        h->soft_consumed = true;
+        h->consumed_beta = h->pend_beta;
+        h->consumed_normalize = h->pend_normalize;
+    }
+    h->pend_soft = false;
     if (rc == PDWT_OK && h->do_cycle_spinning) rc = circshift_impl(h, -h->shift_r, -h->shift_c, 1);  // wt.cu:303
     h->state = (rc == PDWT_OK) ? PDWT_INVERSE : PDWT_INVERSE_ERROR;
     return rc;
@@ -1038,6 +1036,39 @@ long long pdwt_get_coeff(pdwt_handle h, real_t* dst, int num) {  // wt.cu:473-50
     return n;
 }
 
+long long pdwt_get_image_at(pdwt_handle h, real_t* dst, int image_index) {  // wt.cu:419-422, one image of a batch
+    if (!h || !dst) return fail(PDWT_ERR_ARG, "pdwt_get_image_at: null argument");
+    if (image_index < 0 || image_index >= h->batch)
+        return fail(PDWT_ERR_ARG, "pdwt_get_image_at: image %d out of range (batch %d)", image_index, h->batch);
+    DeviceGuard guard(h->device);
+    const long long n = (long long)h->info.Nr * h->info.Nc;
+    HIP_TRY(hipMemcpyAsync(dst, h->image() + (long long)image_index * n, (size_t)n * sizeof(real_t),
+                           hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return n;
+}
+
+long long pdwt_get_coeff_at(pdwt_handle h, real_t* dst, int num, int image_index) {  // wt.cu:473-506, one image
+    if (!h || !dst) return fail(PDWT_ERR_ARG, "pdwt_get_coeff_at: null argument");
+    if (num < 0 || num >= (int)h->bands.size()) return fail(PDWT_ERR_ARG, "coefficient index %d out of range", num);
+    if (image_index < 0 || image_index >= h->batch)
+        return fail(PDWT_ERR_ARG, "pdwt_get_coeff_at: image %d out of range (batch %d)", image_index, h->batch);
+    if (h->state == PDWT_INVERSE) {
+        fail(PDWT_ERR_STATE, "get_coeff(): inverse() has been performed, the coefficients has been modified and do not make sense anymore.");
+        return 0;
+    }
+    DeviceGuard guard(h->device);
+    {
+        const int rc0 = materialize_pending(h);
+        if (rc0 != PDWT_OK) return rc0;
+    }
+    const long long n = h->bands[num].elems(1);
+    HIP_TRY(hipMemcpyAsync(dst, h->band(num) + (long long)image_index * n, (size_t)n * sizeof(real_t),
+                           hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return n;
+}
+
 int pdwt_set_image(pdwt_handle h, const real_t* src, int mem_is_on_device) {  // wt.cu:425-431
     CHECK_HANDLE(h);
     if (!src) return fail(PDWT_ERR_ARG, "pdwt_set_image: src is null");
@@ -1056,7 +1087,8 @@ int pdwt_set_coeff(pdwt_handle h, const real_t* src, int num, int mem_is_on_devi
     if (num < 0 || num >= (int)h->bands.size()) return fail(PDWT_ERR_ARG, "coefficient index %d out of range", num);
     DeviceGuard guard(h->device);
     {
-        const int rc0 = materialize_pending(h);  // a deferred threshold applies to the OLD contents only
+        int rc0 = materialize_pending(h);  // a deferred threshold applies to the OLD contents only
+        if (rc0 == PDWT_OK) rc0 = materialize_consumed(h);
         if (rc0 != PDWT_OK) return rc0;
     }
     const long long n = h->bands[num].elems(h->batch);
@@ -1076,7 +1108,8 @@ intptr_t pdwt_coeff_ptr(pdwt_handle h, int num) {
     if (!h || num < 0 || num >= (int)h->bands.size()) return 0;
     {
         DeviceGuard guard(h->device);
-        if (materialize_pending(h) != PDWT_OK) return 0;  // the caller will read device memory directly
+        // the caller will read device memory directly
+        if (materialize_pending(h) != PDWT_OK || materialize_consumed(h) != PDWT_OK) return 0;
     }
     return (intptr_t)h->band(num);
 }
@@ -1106,6 +1139,7 @@ int pdwt_set_filters_forward(pdwt_handle h, const char* name, unsigned int len, 
     }
     h->info.hlen = (int)len;
     if (name) snprintf(h->wname, sizeof(h->wname), "%s", name);
+    build_schedule(h);  // the fused kernels' eligibility depends on the filter length
     return PDWT_OK;
 }
 

@@ -32,6 +32,14 @@ struct Band {
     long long elems(int batch) const { return (long long)batch * rows * cols; }
 };
 
+// one launch of a plan's forward / inverse launch list (plan.cpp: build_schedule)
+struct Step {
+    enum Kind { LEVEL = 0, PYR2 = 1, STRIP2 = 2, FUSED1D = 3 };
+    int kind;
+    int level;  // first (finest) level the launch works on
+    int K;      // number of levels it covers
+};
+
 struct KernelStamp {
     hipEvent_t start, stop;
     char name[48];
@@ -74,6 +82,13 @@ struct pdwt_plan {
     bool pend_soft = false;
     real_t pend_beta = 0.f;
     int pend_normalize = 0;
+    // ... and one that the fused inverse has applied on the fly without writing the thresholded details
+    // back (plan.cpp: materialize_consumed)
+    bool soft_consumed = false;
+    real_t consumed_beta = 0.f;
+    int consumed_normalize = 0;
+
+    std::vector<pdwt::Step> sched_fwd, sched_inv;  // launch lists, in execution order
 
     bool timing = false;
     std::vector<pdwt::KernelStamp> stamps;

@@ -164,7 +164,7 @@ class Wavelets(object):
         numc = self._lib.pdwt_get_coeff(self._h, _ptr(coeff_ref), num)
         if numc != coeff_ref.size:  # src/pypwt.pyx:284-285 (0 when refused after inverse())
             raise RuntimeError("Wavelets.coeff_only(): something went wrong when retrieving coefficients numbef %d, "
-                               "expected %d coeffs, got %d (%s)" % (num, coeff_ref.size, numc, _lib.last_error()))
+                               "expected %d coeffs, got %d (%s)" % (num, coeff_ref.size, numc, _lib.last_error(self._lib)))
         return coeff_ref
 
     @property
@@ -185,7 +185,7 @@ class Wavelets(object):
         numc = self._lib.pdwt_get_image(self._h, _ptr(res))
         if numc != res.size:
             raise RuntimeError("Wavelets.image(): something went wrong when retrieving image, expected %d coeffs, "
-                               "got %d (%s)" % (res.size, numc, _lib.last_error()))
+                               "got %d (%s)" % (res.size, numc, _lib.last_error(self._lib)))
         return res
 
     def set_image(self, img):
@@ -209,14 +209,14 @@ class Wavelets(object):
         """
         rc = self._lib.pdwt_inverse(self._h)
         if rc == _lib.ERR_STATE:  # reference: puts() a warning and returns (wt.cu:272-279)
-            print("Warning: " + _lib.last_error())
+            print("Warning: " + _lib.last_error(self._lib))
             return
         self._check(rc, "inverse")
 
     def _threshold(self, fn, beta, do_threshold_appcoeffs, normalize):
         rc = fn(self._h, float(beta), int(do_threshold_appcoeffs), int(normalize))
         if rc == _lib.ERR_STATE:  # wt.cu:309-312
-            print("Warning: Wavelets(): " + _lib.last_error())
+            print("Warning: Wavelets(): " + _lib.last_error(self._lib))
             return
         self._check(rc)
 
@@ -237,7 +237,7 @@ class Wavelets(object):
         """shrink(x, t) = x / (1 + t)"""
         rc = self._lib.pdwt_shrink(self._h, float(beta), int(do_threshold_appcoeffs))
         if rc == _lib.ERR_STATE:
-            print("Warning: Wavelets(): " + _lib.last_error())
+            print("Warning: Wavelets(): " + _lib.last_error(self._lib))
             return
         self._check(rc)
 
@@ -245,7 +245,7 @@ class Wavelets(object):
         """Projection onto the L-infinity ball of radius beta (C++-only in the reference, wt.cu:349-356)."""
         rc = self._lib.pdwt_proj_linf(self._h, float(beta), int(do_threshold_appcoeffs))
         if rc == _lib.ERR_STATE:
-            print("Warning: Wavelets(): " + _lib.last_error())
+            print("Warning: Wavelets(): " + _lib.last_error(self._lib))
             return
         self._check(rc)
 
@@ -317,6 +317,14 @@ class Wavelets(object):
     def coeff_int_ptr(self, num):
         """Address of device coefficient band ``num``."""
         return int(self._lib.pdwt_coeff_ptr(self._h, int(num)))
+
+    @property
+    def current_shift(self):
+        """(rows, cols) circular shift the last forward() applied (do_cycle_spinning; the reference keeps it in
+        Wavelets::current_shift_r/c, pdwt/src/wt.h:27-28, without exposing it to Python)."""
+        sr, sc = C.c_int(), C.c_int()
+        self._check(self._lib.pdwt_current_shift(self._h, C.byref(sr), C.byref(sc)))
+        return int(sr.value), int(sc.value)
 
     def synchronize(self):
         """Wait for every kernel enqueued by this instance (new; the reference syncs implicitly)."""
@@ -399,15 +407,39 @@ class BatchedWavelets(object):
         out = np.zeros((self.batch, rows.value, cols.value), dtype=np.float32)
         got = self._lib.pdwt_get_coeff(self._h, _ptr(out), int(num))
         if got != n:
-            raise RuntimeError("BatchedWavelets.coeff(%d): expected %d, got %d (%s)" % (num, n, got, _lib.last_error()))
+            raise RuntimeError("BatchedWavelets.coeff(%d): expected %d, got %d (%s)" % (num, n, got, _lib.last_error(self._lib)))
         return out
+
+    def coeff_at(self, num, image_index):
+        """Sub-band `num` of ONE image of the batch (a 128-image shard does not fit a host array per band)."""
+        rows, cols = C.c_int(), C.c_int()
+        check(int(self._lib.pdwt_coeff_count(self._h, int(num), C.byref(rows), C.byref(cols))))
+        out = np.zeros((rows.value, cols.value), dtype=np.float32)
+        got = self._lib.pdwt_get_coeff_at(self._h, _ptr(out), int(num), int(image_index))
+        if got != out.size:
+            raise RuntimeError("BatchedWavelets.coeff_at(%d, %d): expected %d, got %d (%s)"
+                               % (num, image_index, out.size, got, _lib.last_error(self._lib)))
+        return out
+
+    def image_at(self, image_index):
+        out = np.zeros((self.Nr, self.Nc), dtype=np.float32)
+        got = self._lib.pdwt_get_image_at(self._h, _ptr(out), int(image_index))
+        if got != out.size:
+            raise RuntimeError("BatchedWavelets.image_at(%d): expected %d, got %d (%s)"
+                               % (image_index, out.size, got, _lib.last_error(self._lib)))
+        return out
+
+    def norm2sq(self):
+        out = C.c_float()
+        check(self._lib.pdwt_norm2sq(self._h, C.byref(out)))
+        return float(out.value)
 
     @property
     def image(self):
         out = np.zeros((self.batch, self.Nr, self.Nc), dtype=np.float32)
         got = self._lib.pdwt_get_image(self._h, _ptr(out))
         if got != out.size:
-            raise RuntimeError("BatchedWavelets.image: expected %d, got %d (%s)" % (out.size, got, _lib.last_error()))
+            raise RuntimeError("BatchedWavelets.image: expected %d, got %d (%s)" % (out.size, got, _lib.last_error(self._lib)))
         return out
 
     def synchronize(self):

@@ -26,7 +26,13 @@ def test_algorithmic_bytes_match_baseline_md():
     import bench
     assert bench.algorithmic_bytes_per_sample(bench.CONFIGS["cfg2"]) == 16.0
     assert bench.algorithmic_bytes_per_sample(bench.CONFIGS["cfg3"]) == 16.0
-    assert bench.algorithmic_bytes_per_sample(bench.CONFIGS["cfg4"]) == 256.0  # 68 + 120 + 68
+    assert bench.algorithmic_bytes_per_sample(bench.CONFIGS["cfg4"]) == 256.0  # 68 + 120 + 68: threshold as its own sweep
+    # the deferred threshold of 2D SWT plans is folded into the inverse's loads: no launch, no bytes
+    assert bench.algorithmic_bytes_per_sample(bench.CONFIGS["cfg4"], threshold_separate=False) == 136.0
+    assert bench.per_level_streaming_bytes_per_sample(bench.CONFIGS["cfg4"], True) == 320.0
+    assert bench.per_level_streaming_bytes_per_sample(bench.CONFIGS["cfg4"], False) == 200.0
+    assert bench.per_level_streaming_bytes_per_sample(bench.CONFIGS["cfg2"]) == 21.25
+    assert bench.per_level_streaming_bytes_per_sample(bench.CONFIGS["cfg3"]) == 31.5
     # level-1 kernels move 8 B per input sample; each deeper 2D level a quarter of that
     c = bench.CONFIGS["cfg2"]
     assert bench.kernel_algorithmic_bytes("dwt2_fwd_level[L1]", c, 1) == 8.0 * 4096 * 4096
@@ -61,3 +67,37 @@ def test_dry_run_world2_gloo():
 def test_dry_run_single():
     out = _run([sys.executable, "bench.py", "--steps", "3", "--dry-run"])
     assert out["n_gpus"] == 1 and out["vs_baseline"] is None
+
+
+def test_gpus_flag_starts_the_ranks_itself():
+    """`python bench.py --gpus 2` with no launcher and no WORLD_SIZE: bench.py spawns the two ranks (one child
+    process each, gloo rendezvous on 127.0.0.1) and prints ONE line with n_gpus = 2."""
+    env_clean = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "4", "--warmup", "1", "--dry-run"],
+                       capture_output=True, text=True, cwd=ROOT, env=env_clean, timeout=240)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["ms_per_step"] >= 1.9
+    assert out["config"]["images_per_step"] == 2 and out["config"]["shard_rank0"] == [0, 1]
+
+
+def test_strong_scaling_splits_a_fixed_batch_and_cfg5_is_128_per_gpu():
+    import bench
+    a = bench.parse_args(["--config", "cfg5"])
+    assert bench.rank_batch(a, 8, 3) == (128, 384, 1024)  # BASELINE config 5: 1024 images over 8 GPUs
+    a = bench.parse_args(["--config", "cfg2", "--batch", "1024", "--scaling", "strong"])
+    spans = [bench.rank_batch(a, 8, r) for r in range(8)]
+    assert [s[0] for s in spans] == [128] * 8 and [s[1] for s in spans] == list(range(0, 1024, 128))
+    assert all(s[2] == 1024 for s in spans)
+    a = bench.parse_args([])
+    assert bench.rank_batch(a, 1, 0) == (1, 0, 1)
+
+
+def test_world_size_mismatch_is_reported_even_for_one_rank():
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "8", "--steps", "2", "--dry-run"], capture_output=True,
+                       text=True, cwd=ROOT, env=env, timeout=120)
+    assert r.returncode == 0 and "--gpus 8 but WORLD_SIZE 1" in r.stderr
+    assert json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])["n_gpus"] == 1

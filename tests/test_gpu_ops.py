@@ -294,6 +294,52 @@ def test_custom_nonseparable_filter_bank(W):
         w.set_wavelets_filters("missing", g4[0], g4[3], i[0], i[3])
 
 
+def test_nonseparable_inverse_of_a_genuinely_nonseparable_bank_vs_oracle(W):
+    """nonsep_inv_kernel against the oracle's restatement of w_kern_inverse / w_kern_inverse_swt
+    (pdwt/src/nonseparable.cu:176-225, 360-401) on banks that are NOT outer products: DWT (even and odd
+    shapes, two levels) and SWT (two levels, dilation 2)."""
+    rng = np.random.RandomState(12)
+
+    def rand_banks(hlen):
+        return [(0.3 * rng.randn(hlen, hlen)).astype(np.float32) for _ in range(4)]  # A, H, V, D
+
+    for shape, hlen in (((48, 56), 4), ((33, 47), 6), ((40, 24), 2)):
+        x = oracle.hash_input(shape, 31, 10.0) - 5.0
+        f, i = rand_banks(hlen), rand_banks(hlen)
+        w = W(x, "db2", 2, do_separable=0)
+        w.set_wavelets_filters("rnd", f[0], f[3], i[0], i[3], LH=f[1], HL=f[2], i_LH=i[1], i_HL=i[2])
+        assert w.levels == 2 and w.hlen == hlen
+        w.forward()
+        co = [c.copy() for c in flat_coeffs(w)]  # A2, H1 V1 D1, H2 V2 D2
+        # forward, level by level, vs the oracle
+        l1 = oracle.nonsep_forward_level(x, *[b.ravel() for b in f], hlen)
+        l2 = oracle.nonsep_forward_level(l1[0], *[b.ravel() for b in f], hlen)
+        for g, r in zip(co, [l2[0]] + l1[1:] + l2[1:]):
+            assert np.abs(g - r).max() <= 2e-5 * max(np.abs(r).max(), 1.0)
+        w.inverse()
+        ib = [b.ravel() for b in i]
+        a1 = oracle.nonsep_inverse_level([co[0]] + co[4:7], l1[0].shape, *ib, hlen)
+        ref = oracle.nonsep_inverse_level([a1] + co[1:4], shape, *ib, hlen)
+        assert np.abs(w.image - ref).max() <= 3e-5 * max(np.abs(ref).max(), 1.0), (shape, hlen)
+    # SWT
+    shape, hlen = (32, 40), 4
+    x = oracle.hash_input(shape, 32, 10.0) - 5.0
+    f, i = rand_banks(hlen), rand_banks(hlen)
+    w = W(x, "db2", 2, do_separable=0, do_swt=1)
+    w.set_wavelets_filters("rnd", f[0], f[3], i[0], i[3], LH=f[1], HL=f[2], i_LH=i[1], i_HL=i[2])
+    w.forward()
+    co = [c.copy() for c in flat_coeffs(w)]
+    l1 = oracle.nonsep_forward_level(x, *[b.ravel() for b in f], hlen, do_swt=1, level=1)
+    l2 = oracle.nonsep_forward_level(l1[0], *[b.ravel() for b in f], hlen, do_swt=1, level=2)
+    for g, r in zip(co, [l2[0]] + l1[1:] + l2[1:]):
+        assert np.abs(g - r).max() <= 2e-5 * max(np.abs(r).max(), 1.0)
+    w.inverse()
+    ib = [b.ravel() for b in i]
+    a1 = oracle.nonsep_inverse_level([co[0]] + co[4:7], shape, *ib, hlen, do_swt=1, level=2)
+    ref = oracle.nonsep_inverse_level([a1] + co[1:4], shape, *ib, hlen, do_swt=1, level=1)
+    assert np.abs(w.image - ref).max() <= 3e-5 * max(np.abs(ref).max(), 1.0)
+
+
 def test_deferred_soft_threshold_fused_into_swt_inverse(W):
     """On a 2D SWT plan soft_threshold() is deferred and applied by the fused inverse kernels while they
     load the detail bands.  Every observable result must equal the eager semantics: reconstruction vs the
@@ -389,3 +435,146 @@ def test_long_rows_1d_fused_and_unfused(W, wname, n, lv):
             assert np.abs(g - r).max() <= 1.5e-6 * (1 + lv) * max(np.abs(r).max(), 1.0), (wname, n)
         w.inverse()
         assert np.abs(w.image - np.atleast_2d(data)).max() < 2e-3
+
+
+# ----------------------------------------------------------------------------- cycle spinning, coefficients
+def test_cycle_spinning_coefficients_equal_the_transform_of_the_shifted_image(W):
+    """do_cycle_spinning: forward() shifts the image circularly by a random (sr, sc) first
+    (pdwt/src/wt.cu:242-246, common.cu:202-211), inverse() shifts back (wt.cu:303).  The coefficients must
+    be those of the oracle on oracle.circshift(x, sr, sc), for several draws."""
+    x = oracle.hash_input((96, 80), 51)
+    w = W(x, "db3", 2, do_cycle_spinning=1)
+    seen = set()
+    for _ in range(4):
+        w.set_image(x)
+        w.forward()
+        sr, sc = w.current_shift
+        assert 0 <= sr < 96 and 0 <= sc < 80
+        seen.add((sr, sc))
+        ref = oracle.forward(oracle.circshift(x, sr, sc), "db3", 2)
+        for g, r in zip(flat_coeffs(w), ref):
+            assert np.abs(g - r).max() <= 3e-6 * 3 * max(np.abs(r).max(), 1.0)
+        w.inverse()
+        assert np.abs(w.image - x).max() < 7e-4
+    assert len(seen) >= 2  # rand() really moves
+
+
+# ----------------------------------------------------------------------------- device-memory interop (C ABI)
+def _hip():
+    """The HIP runtime the product library is linked against (already mapped by it): hipMalloc & friends for
+    the tests that hand DEVICE buffers to the C ABI."""
+    import ctypes as C
+    lib = C.CDLL("libamdhip64.so")
+    lib.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    lib.hipFree.argtypes = [C.c_void_p]
+    lib.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    lib.hipStreamCreate.argtypes = [C.POINTER(C.c_void_p)]
+    lib.hipStreamDestroy.argtypes = [C.c_void_p]
+    lib.hipStreamSynchronize.argtypes = [C.c_void_p]
+    return lib
+
+
+def test_c_abi_device_memory_create_set_image_set_coeff_clone_and_stream(W):
+    """SURVEY 8(f) rank 2 through the C ABI, each against the oracle: pdwt_create(mem_is_on_host = 0)
+    (pdwt/src/wt.cu:117-126), pdwt_set_image / pdwt_set_coeff(mem_is_on_device = 1) (wt.cu:425-466), the deep copy
+    pdwt_clone (wt.cu:191-222) and a caller-owned stream (pdwt_set_stream)."""
+    import ctypes as C
+    from pypwt_amd import _lib
+    lib, hip = _lib.load(), _hip()
+    H2D, D2H = 1, 2
+    shape, wname, lv = (64, 96), "db4", 2
+    x = oracle.hash_input(shape, 61)
+    y = oracle.hash_input(shape, 62)
+    n = x.size
+    dx, dy = C.c_void_p(), C.c_void_p()
+    assert hip.hipMalloc(C.byref(dx), 4 * n) == 0 and hip.hipMalloc(C.byref(dy), 4 * n) == 0
+    assert hip.hipMemcpy(dx, x.ctypes.data, 4 * n, H2D) == 0 and hip.hipMemcpy(dy, y.ctypes.data, 4 * n, H2D) == 0
+
+    def coeffs_of(h):
+        out = []
+        nb = 3 * lv + 1
+        for num in range(nb):
+            r, c = C.c_int(), C.c_int()
+            cnt = lib.pdwt_coeff_count(h, num, C.byref(r), C.byref(c))
+            a = np.zeros((r.value, c.value), dtype=np.float32)
+            assert lib.pdwt_get_coeff(h, a.ctypes.data, num) == cnt
+            out.append(a)
+        return out
+
+    def close(got, ref, k=3e-6 * 3):
+        for g, r in zip(got, ref):
+            assert np.abs(g - r).max() <= k * max(np.abs(r).max(), 1.0)
+
+    h = _lib.handle_t()
+    # 1. image handed over as a DEVICE pointer at creation
+    fp = C.cast(dx, C.POINTER(C.c_float))
+    assert lib.pdwt_create(fp, shape[0], shape[1], wname.encode(), lv, 0, 1, 0, 0, 2, C.byref(h)) == 0
+    assert lib.pdwt_forward(h) == 0
+    close(coeffs_of(h), oracle.forward(x, wname, lv))
+    # 2. a new image from device memory
+    assert lib.pdwt_set_image(h, dy, 1) == 0
+    assert lib.pdwt_forward(h) == 0
+    ry = oracle.forward(y, wname, lv)
+    close(coeffs_of(h), ry)
+    # 3. deep copy: same coefficients, independent afterwards
+    h2 = _lib.handle_t()
+    assert lib.pdwt_clone(h, C.byref(h2)) == 0
+    close(coeffs_of(h2), ry)
+    assert lib.pdwt_soft_threshold(h2, C.c_float(4.0), 0, 0) == 0
+    thr = oracle.threshold(ry, shape, lv, "soft", 4.0)
+    close(coeffs_of(h2), thr)
+    close(coeffs_of(h), ry)  # the original is untouched
+    assert lib.pdwt_inverse(h2) == 0
+    rec = np.zeros(shape, dtype=np.float32)
+    assert lib.pdwt_get_image(h2, rec.ctypes.data) == n
+    want = oracle.inverse(thr, shape, wname, lv)
+    assert np.abs(rec - want).max() <= 3e-6 * 255 * 3
+    # 4. a caller-owned stream
+    st = C.c_void_p()
+    assert hip.hipStreamCreate(C.byref(st)) == 0
+    assert lib.pdwt_set_stream(h, st) == 0
+    assert lib.pdwt_get_stream(h) == st.value
+    assert lib.pdwt_set_image(h, dx, 1) == 0
+    assert lib.pdwt_forward(h) == 0
+    assert lib.pdwt_synchronize(h) == 0
+    rx = oracle.forward(x, wname, lv)
+    close(coeffs_of(h), rx)
+    # 5. a sub-band supplied from device memory: band 0 of the y-transform (still in h2's... own copy) -> h
+    dA = C.c_void_p()
+    A_y = np.ascontiguousarray(ry[0])
+    assert hip.hipMalloc(C.byref(dA), A_y.nbytes) == 0 and hip.hipMemcpy(dA, A_y.ctypes.data, A_y.nbytes, H2D) == 0
+    assert lib.pdwt_set_coeff(h, dA, 0, 1) == 0
+    assert lib.pdwt_inverse(h) == 0
+    assert lib.pdwt_get_image(h, rec.ctypes.data) == n
+    want = oracle.inverse([ry[0]] + rx[1:], shape, wname, lv)
+    assert np.abs(rec - want).max() <= 3e-6 * 255 * 3
+    # zero-copy read: the plan's image through its device pointer
+    back = np.zeros(shape, dtype=np.float32)
+    assert lib.pdwt_synchronize(h) == 0
+    assert hip.hipMemcpy(back.ctypes.data, C.c_void_p(lib.pdwt_image_ptr(h)), 4 * n, D2H) == 0
+    assert np.array_equal(back, rec)
+    assert lib.pdwt_destroy(h) == 0 and lib.pdwt_destroy(h2) == 0
+    hip.hipStreamDestroy(st)
+    for p in (dx, dy, dA):
+        hip.hipFree(p)
+
+
+def test_deferred_threshold_consumed_by_the_fused_inverse_is_written_back_before_a_second_inverse(W):
+    """forward -> soft_threshold (deferred on a 2D SWT plan) -> inverse (applies it on the fly) ->
+    set_coeff(0) (re-arms the inverse) -> inverse: the second inverse must see THRESHOLDED details, exactly
+    as the eager path (PDWT_NO_LAZY_THRESHOLD) or a non-SWT plan would."""
+    x = oracle.hash_input((64, 96), 71, 100.0) - 50.0
+    wname, lv = "db2", 2
+    ora = oracle.forward(x, wname, lv, do_swt=1)
+    thr = oracle.threshold(ora, x.shape, lv, "soft", 6.0, 0, 0, do_swt=1)
+    w = W(x, wname, lv, do_swt=1)
+    w.forward()
+    w.soft_threshold(6.0, 0, 0)
+    w.inverse()
+    first = w.image.copy()
+    assert np.abs(first - oracle.inverse(thr, x.shape, wname, lv, do_swt=1)).max() <= 2e-5 * 100
+    newA = (0.5 * thr[0]).astype(np.float32)
+    w.set_coeff(newA, 0)
+    w.inverse()
+    want = oracle.inverse([newA] + thr[1:], x.shape, wname, lv, do_swt=1)
+    assert np.abs(w.image - want).max() <= 2e-5 * 100

@@ -418,3 +418,40 @@ def test_large_image_beyond_32bit_byte_offsets():
         assert np.abs(got - ref[1 + k][2:67]).max() <= 1e-4 * max(1.0, float(np.abs(ref[1 + k]).max())), k
     w.inverse()
     assert np.abs(w.image - x).max() <= 4e-3
+
+
+# ----------------------------------------------------------------------------- config 5: the per-GPU shard
+@pytest.mark.parametrize("B", [16, 128])
+def test_cfg5_shard(B):
+    """BASELINE.json configs[4]: 1024 images of 4096^2 db4 L4 over 8 GPUs = 128 images per GPU (19 GiB of plan);
+    B = 16 is the smallest batch on the same dispatch path (two-level streaming strips for >= 2^26 samples).
+    Image 0 and image B-1 against the cfg2 pywt digests (the device generator's index offset puts the cfg2
+    input there), Parseval over the whole batch, round trip of three images."""
+    from pypwt_amd import BatchedWavelets
+    c = load_digests()["configs"]["cfg2"]
+    Nr, Nc = c["shape"]
+    n = Nr * Nc
+    bw = BatchedWavelets(B, Nr, Nc, "db4", 4)
+    assert bw.levels == 4
+
+    def check_image_against_digests(b):
+        for num, ref in enumerate(c["bands"]):
+            _check_digest(bw.coeff_at(num, b), ref, ("cfg5 B=%d image %d" % (B, b), num))
+
+    bw.fill_hash(c["seed"], 255.0, index_offset=0)  # image 0 == the cfg2 input
+    energy = 0.0
+    for b in range(B):  # fp64 energy of every input image (the CPU generator with the image's index offset)
+        xb = oracle.hash_input((Nr, Nc), c["seed"], 255.0, index_offset=b * n).astype(np.float64)
+        energy += float((xb * xb).sum())
+    bw.forward()
+    check_image_against_digests(0)
+    e2 = bw.norm2sq()
+    assert abs(e2 - energy) <= 2e-5 * energy, (e2, energy)  # orthogonal wavelet + periodization: Parseval
+    bw.inverse()
+    for b in (0, B // 2, B - 1):
+        xb = oracle.hash_input((Nr, Nc), c["seed"], 255.0, index_offset=b * n)
+        assert np.abs(bw.image_at(b) - xb).max() < 7e-4, b
+    bw.fill_hash(c["seed"], 255.0, index_offset=-(B - 1) * n)  # image B-1 == the cfg2 input
+    bw.forward()
+    check_image_against_digests(B - 1)
+    bw.cleanup()

@@ -151,3 +151,35 @@ def test_level_clamp_rule():
     assert oracle.max_level(1 << 24, 16) == 20
     assert oracle.max_level(2048, 2) == 11
     assert oracle.max_level(512, 4) == 7
+
+
+def test_nonseparable_inverse_restatement_is_pinned_to_the_separable_one():
+    """oracle_nonsep_inv_level (pdwt/src/nonseparable.cu:176-225, 360-401) on outer-product banks must equal
+    the separable inverse, which the pywt vectors above pin (the reference has no test of its own for the
+    non-separable mode).  DWT: even and odd shapes; SWT: levels 1 and 2 chained."""
+    for wname in ("haar", "db2", "db3", "db4", "sym5", "bior2.2", "rbio3.1"):
+        hlen, dlo, dhi, rlo, rhi = oracle.filters(wname)
+        F = [np.outer(rlo, rlo).ravel(), np.outer(rhi, rlo).ravel(), np.outer(rlo, rhi).ravel(),
+             np.outer(rhi, rhi).ravel()]  # A, H, V, D banks (H = high along y)
+        for shape in ((48, 56), (31, 45), (8, 6)):
+            r2, c2 = (shape[0] + 1) // 2, (shape[1] + 1) // 2
+            bands = [oracle.hash_input((r2, c2), 77 + b, 2.0) - 1.0 for b in range(4)]
+            ref = oracle.inverse(bands, shape, wname, 1)
+            got = oracle.nonsep_inverse_level(bands, shape, *F, hlen)
+            assert np.abs(got - ref).max() <= 2e-6 * max(np.abs(ref).max(), 1.0), (wname, shape)
+        shape = (32, 40)
+        if 2 * (hlen - 1) > min(shape):
+            continue
+        bands = [oracle.hash_input(shape, 5 + b, 2.0) - 1.0 for b in range(7)]  # A2, H1 V1 D1, H2 V2 D2
+        ref = oracle.inverse(bands, shape, wname, 2, do_swt=1)
+        a1 = oracle.nonsep_inverse_level([bands[0]] + bands[4:7], shape, *F, hlen, do_swt=1, level=2)
+        got = oracle.nonsep_inverse_level([a1] + bands[1:4], shape, *F, hlen, do_swt=1, level=1)
+        assert np.abs(got - ref).max() <= 4e-6 * max(np.abs(ref).max(), 1.0), wname
+
+
+def test_hash_input_with_an_index_offset():
+    a = oracle.hash_input((3, 5, 7), 11)
+    b = oracle.hash_input((5, 7), 11, index_offset=2 * 35)
+    assert np.array_equal(a[2], b)
+    c = oracle.hash_input((5, 7), 11, index_offset=-35)  # wraps modulo 2^32 like the device kernel
+    assert np.isfinite(c).all() and c.min() >= 0 and c.max() < 255
