@@ -179,6 +179,12 @@ int pdwt_reset_kernel_times(pdwt_handle h);
  * milliseconds per repetition.  The data the level reads is whatever the buffers hold (run a
  * forward first); nothing else of the plan's state changes. */
 int pdwt_time_level(pdwt_handle h, int level, int inverse, int reps, float* ms_per_launch);
+/* NEW: process-wide dispatch knobs (tests and A/B measurements; no counterpart in the reference, whose
+ * kernel choice is fixed at compile time, pdwt/src/wt.cu:236-305).  Returns the previous value, or
+ * PDWT_ERR_ARG for an unknown key.  Keys:
+ *   "wave_min_log2"  a 2D DWT level runs on the wave-per-tile kernels when at least 2^value samples
+ *                    enter it (default 22; 0 = always when eligible; 63 = never) */
+int pdwt_set_tuning(const char* key, int value);
 
 #ifdef __cplusplus
 }

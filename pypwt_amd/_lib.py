@@ -77,6 +77,7 @@ def signatures(real=C.c_float):
         "pdwt_kernel_times": (C.c_int, [handle_t, f32p, C.c_void_p, C.c_int]),
         "pdwt_reset_kernel_times": (C.c_int, [handle_t]),
         "pdwt_time_level": (C.c_int, [handle_t, C.c_int, C.c_int, C.c_int, f32p]),
+        "pdwt_set_tuning": (C.c_int, [C.c_char_p, C.c_int]),
     }
 
 

@@ -23,6 +23,7 @@ hipError_t try_launch_dwt2_inv_fast(const Inv2DArgs& a, int batch, hipStream_t s
 // wave-per-tile kernels (registers + DPP, no LDS): hlen <= 8; seg_hint > 0 forces the rows per wavefront
 hipError_t try_launch_dwt2_fwd_wave(const Fwd2DArgs& a, int batch, hipStream_t s, int seg_hint = 0);
 hipError_t try_launch_dwt2_inv_wave(const Inv2DArgs& a, int batch, hipStream_t s, int seg_hint = 0);
+int set_wave_min_log2(int value);  // returns the previous threshold
 // two consecutive 2D levels in one launch (small levels only, see launch_dwt2_pyramid.hip)
 bool dwt2_pyramid_supported(int hlen, int N0r, int N0c);
 hipError_t launch_dwt2_fwd_pyr2(const real_t* in, real_t* const det1[3], real_t* const band2[4], int N0r, int N0c,

@@ -1,6 +1,8 @@
 // launch_dwt2.hip -- instantiations + launchers of the fused 2D DWT level kernels (gfx950).
 #include <stdlib.h>
 
+#include <atomic>
+
 #include "dwt2_kernels.hpp"
 #include "launch.hpp"
 #include "launch_util.hpp"
@@ -63,12 +65,20 @@ constexpr int kTyLong = 32;
 
 // The wave-per-tile kernels take the levels that are large enough to be bandwidth-bound (>= 2^22 samples
 // enter the level: 2048^2 of one image); smaller levels are launch-bound and stay with the LDS tiles
-// (numbers in launch_dwt2_wave.hip).  PDWT_NO_WAVE=1 (read once) keeps the LDS tiles everywhere, PDWT_WAVE_MIN
-// overrides the threshold (log2 samples): A/B measurements.
+// (numbers in launch_dwt2_wave.hip).  PDWT_NO_WAVE=1 (read once) keeps the LDS tiles everywhere, PDWT_WAVE_MIN /
+// pdwt_set_tuning("wave_min_log2") override the threshold (log2 samples): tests and A/B measurements.
+static std::atomic<int>& wave_min_log2() {
+    static std::atomic<int> v{getenv("PDWT_NO_WAVE") ? 63 : (getenv("PDWT_WAVE_MIN") ? atoi(getenv("PDWT_WAVE_MIN")) : 22)};
+    return v;
+}
+int set_wave_min_log2(int value) {  // pdwt_set_tuning("wave_min_log2")
+    if (value < 0) value = 0;
+    if (value > 63) value = 63;
+    return wave_min_log2().exchange(value);
+}
 static bool wave_kernels_for(long long samples) {
-    static const bool on = getenv("PDWT_NO_WAVE") == nullptr;
-    static const int min_log2 = getenv("PDWT_WAVE_MIN") ? atoi(getenv("PDWT_WAVE_MIN")) : 22;
-    return on && samples >= (1LL << min_log2);
+    const int m = wave_min_log2().load(std::memory_order_relaxed);
+    return m < 63 && samples >= (1LL << m);
 }
 
 hipError_t launch_dwt2_fwd(const Fwd2DArgs& a, int batch, hipStream_t s) {

@@ -1282,6 +1282,11 @@ int pdwt_time_level(pdwt_handle h, int level, int inverse, int reps, float* ms_p
     return rc;
 }
 
+int pdwt_set_tuning(const char* key, int value) {
+    if (key && !strcmp(key, "wave_min_log2")) return set_wave_min_log2(value);
+    return fail(PDWT_ERR_ARG, "pdwt_set_tuning: unknown key %s", key ? key : "(null)");
+}
+
 int pdwt_enable_kernel_timing(pdwt_handle h, int enable) {
     CHECK_HANDLE(h);
     h->timing = enable != 0;

@@ -1,0 +1,116 @@
+"""The wave-per-tile 2D level kernels (dwt2_wave_kernels.hpp: registers + DPP lane shifts) on the GPU at
+SMALL and ragged shapes.  By default the host only routes levels of >= 2^22 samples to them (full-size
+tests cover that: cfg2, the cfg5 shard); here pdwt_set_tuning("wave_min_log2", 0) sends every eligible
+level there, so partial wavefronts, guarded stores, odd heights, the periodic wrap of tiny images and all
+four filter lengths meet the oracle and the pywt vectors."""
+import numpy as np
+import pytest
+
+from golden_util import load_cases, ndim_of, rel_err, swt_of
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+
+SHORT = None
+
+
+def _short_wavelets():
+    global SHORT
+    if SHORT is None:
+        t = oracle.filter_table()
+        SHORT = [w for w in t["order"] if oracle.filters(w)[0] <= 8]
+    return SHORT
+
+
+@pytest.fixture(scope="module", autouse=True)
+def forced_wave():
+    from pypwt_amd import _lib
+    lib = _lib.load()
+    import os
+    prev = lib.pdwt_set_tuning(b"wave_min_log2", 0)
+    assert prev >= 0
+    os.environ["PDWT_NO_PYRAMID"] = "1"  # read when a plan is created: every level as its own launch
+    yield
+    os.environ.pop("PDWT_NO_PYRAMID", None)
+    lib.pdwt_set_tuning(b"wave_min_log2", prev)
+
+
+def _flat(c):
+    return [c[0]] + [b for lvl in c[1:] for b in (lvl if isinstance(lvl, list) else [lvl])]
+
+
+def _check(x, wname, levels, tag):
+    from pypwt_amd import Wavelets
+    w = Wavelets(x, wname, levels)
+    w.forward()
+    ref = oracle.forward(x, wname, w.levels)
+    for k, (g, r) in enumerate(zip(_flat(w.coeffs), ref)):
+        tol = 2e-6 * (1 + w.levels) * max(float(np.abs(r).max()), float(np.abs(x).max()), 1.0)
+        assert g.shape == r.shape and np.abs(g - r).max() <= tol, (tag, wname, x.shape, w.levels, k)
+    w.inverse()
+    want = oracle.inverse(ref, x.shape, wname, w.levels)
+    assert np.abs(w.image - want).max() <= 2e-6 * (1 + w.levels) * 255.0, (tag, wname, x.shape, w.levels)
+    return w
+
+
+# (rows, cols): whole strips / ragged strips (cols % 256), odd heights, fewer rows than one unrolled group,
+# widths below one lane group, cols % 4 != 0 (not eligible: must still be right through the fallback)
+SHAPES = [(64, 256), (96, 512), (61, 72), (130, 36), (96, 516), (33, 1028), (200, 260), (8, 8), (2, 4), (5, 12),
+          (48, 250), (127, 768)]
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_wave_kernels_every_short_wavelet_vs_oracle(shape):
+    for wi, wname in enumerate(_short_wavelets()):
+        x = oracle.hash_input(shape, 8100 + wi)
+        hlen = oracle.filters(wname)[0]
+        lv = max(1, min(3, oracle.max_level(min(shape), hlen)))
+        _check(x, wname, lv, "short")
+
+
+def test_wave_kernels_golden_small_cases():
+    """the committed pywt vectors (2D DWT cases with filters of at most 8 taps) through the wave kernels"""
+    from pypwt_amd import Wavelets
+    z, meta = load_cases("small_cases.npz")
+    done = 0
+    for m in meta:
+        if ndim_of(m["kind"]) != 2 or swt_of(m["kind"]) or oracle.filters(m["wname"])[0] > 8:
+            continue
+        x = z[m["key"] + "_x"]
+        w = Wavelets(x, m["wname"], m["levels"])
+        w.forward()
+        for b, g in enumerate(_flat(w.coeffs)):
+            ref = z["%s_b%d" % (m["key"], b)]
+            assert g.shape == ref.shape and rel_err(g, ref) < 1e-4, (m, b)
+        w.inverse()
+        if m["wname"] != "rbio3.1":  # ill-conditioned: the reference skips its inversion (test_wavelets.py:174-176)
+            assert np.abs(w.image - x).max() < (5e-3 if m["wname"] == "bior3.1" else 7e-4), m
+        done += 1
+    assert done >= 8
+
+
+def test_wave_kernels_batched_and_custom_filters():
+    from pypwt_amd import BatchedWavelets, Wavelets
+    B, shape = 3, (72, 520)
+    x = oracle.hash_input((B,) + shape, 8300)
+    bw = BatchedWavelets(B, shape[0], shape[1], "db3", 2, img=x)
+    bw.forward()
+    for b in range(B):
+        ref = oracle.forward(x[b], "db3", 2)
+        for num, r in enumerate(ref):
+            assert np.abs(bw.coeff_at(num, b) - r).max() <= 6e-6 * max(np.abs(r).max(), 255.0)
+    bw.inverse()
+    assert np.abs(bw.image - x).max() < 7e-4
+    # user-supplied separable bank of 8 taps (set_wavelets_filters, src/pypwt.pyx:487-575)
+    rng = np.random.default_rng(5)
+    lo, hi, ilo, ihi = [rng.standard_normal(8).astype(np.float32) for _ in range(4)]
+    y = oracle.hash_input((64, 256), 8301, 10.0) - 5.0
+    w = Wavelets(y, "db2", 2)
+    w.set_wavelets_filters("rand8", lo, hi, ilo, ihi)
+    w.forward()
+    filt = (8, lo, hi, ilo, ihi)
+    ref = oracle.forward(y, "db4", 2, filt=filt)
+    for g, r in zip(_flat(w.coeffs), ref):
+        assert np.abs(g - r).max() <= 2e-5 * max(np.abs(r).max(), 1.0)
+    w.inverse()
+    assert np.abs(w.image - oracle.inverse(ref, y.shape, "db4", 2, filt=filt)).max() <= 2e-4 * max(np.abs(y).max(), 1.0) * 8
