@@ -89,7 +89,7 @@ def kernel_algorithmic_bytes(label, cfg, batch):
     lvl = None if lvl == "-" else int(lvl[1:])
     if name in ("dwt1_fwd_fused", "dwt1_inv_fused"):
         return 8.0 * samples / (2 ** (lvl - 1))  # all remaining levels: input once, every band once
-    if name in ("dwt2_fwd_pyr2", "dwt2_inv_pyr2", "dwt2_fwd_strip2", "dwt2_inv_strip2"):
+    if name in ("dwt2_fwd_pyr2", "dwt2_inv_pyr2", "dwt2_fwd_strip2", "dwt2_inv_strip2", "dwt2_fwd_wave2", "dwt2_inv_wave2"):
         # two levels in one launch: the pair's input read once, details of the first and all four bands
         # of the second level written once = 8 B per sample entering the pair
         return 8.0 * samples / (4 ** (lvl - 1))
@@ -117,13 +117,13 @@ def label_step_kernels(names, L):
         base = n.replace("+soft", "")
         if base in ("dwt2_fwd_level", "dwt1_fwd_level", "swt2_fwd_level", "swt1_fwd_level", "nonsep_fwd_level"):
             out.append("%s[L%d]" % (n, f)); f += 1
-        elif base in ("dwt2_fwd_pyr2", "dwt2_fwd_strip2"):
+        elif base in ("dwt2_fwd_pyr2", "dwt2_fwd_strip2", "dwt2_fwd_wave2"):
             out.append("%s[L%d]" % (n, f)); f += 2
         elif base == "dwt1_fwd_fused":
             out.append("%s[L%d]" % (n, f)); f = L + 1
         elif base in ("dwt2_inv_level", "dwt1_inv_level", "swt2_inv_level", "swt1_inv_level", "nonsep_inv_level"):
             out.append("%s[L%d]" % (n, i)); i -= 1
-        elif base in ("dwt2_inv_pyr2", "dwt2_inv_strip2"):
+        elif base in ("dwt2_inv_pyr2", "dwt2_inv_strip2", "dwt2_inv_wave2"):
             out.append("%s[L%d]" % (n, i - 1)); i -= 2
         elif base == "dwt1_inv_fused":
             out.append("%s[L%d]" % (n, 1)); i = 0

@@ -183,7 +183,9 @@ int pdwt_time_level(pdwt_handle h, int level, int inverse, int reps, float* ms_p
  * kernel choice is fixed at compile time, pdwt/src/wt.cu:236-305).  Returns the previous value, or
  * PDWT_ERR_ARG for an unknown key.  Keys:
  *   "wave_min_log2"  a 2D DWT level runs on the wave-per-tile kernels when at least 2^value samples
- *                    enter it (default 22; 0 = always when eligible; 63 = never) */
+ *                    enter it (default 22; 0 = always when eligible; 63 = never)
+ *   "wave2"          1: eligible forward level pairs run as ONE two-level wave launch (default 0: measured
+ *                    slower than two launches on MI355X, kept for tests and re-measurement) */
 int pdwt_set_tuning(const char* key, int value);
 
 #ifdef __cplusplus

@@ -41,6 +41,8 @@ struct WaveReg {
     // element idx of lane-1 / lane+1; lane 0 / lane 63 get `fill`
     T from_prev(int idx, int lane, T fill) const { return lane > 0 ? v[lane - 1][idx] : fill; }
     T from_next(int idx, int lane, T fill) const { return lane < 63 ? v[lane + 1][idx] : fill; }
+    T from_prev2(int idx, int lane, T fill) const { return lane > 1 ? v[lane - 2][idx] : fill; }
+    T from_next2(int idx, int lane, T fill) const { return lane < 62 ? v[lane + 2][idx] : fill; }
 };
 #else
 #define PDWT_WAVE_LANES(lane) for (int lane = threadIdx.x & 63, pdwt_once_ = 1; pdwt_once_; pdwt_once_ = 0)
@@ -59,6 +61,13 @@ struct WaveReg {
     __device__ __forceinline__ T* mine(int) { return v; }
     __device__ __forceinline__ T from_prev(int idx, int, T fill) const { return dpp_from_prev(v[idx], fill); }
     __device__ __forceinline__ T from_next(int idx, int, T fill) const { return dpp_from_next(v[idx], fill); }
+    // two lanes away: the shift applied twice
+    __device__ __forceinline__ T from_prev2(int idx, int, T fill) const {
+        return dpp_from_prev(dpp_from_prev(v[idx], fill), fill);
+    }
+    __device__ __forceinline__ T from_next2(int idx, int, T fill) const {
+        return dpp_from_next(dpp_from_next(v[idx], fill), fill);
+    }
 };
 #endif
 
@@ -535,6 +544,298 @@ PDWT_DEVICE void dwt2_inv_wave(const InvWaveArgs& a, int strip, int seg, int bz)
     for (int it = 0; it < ngroups; ++it) inv_wave_group<HLEN, GUARD>(st, a, bin, bout, walk, rows, pairs_left, kx0);
 }
 
+// ------------------------------------------------------------------------------------------------
+// TWO forward levels in one wavefront: in (N0r, N0c) -> H1, V1, D1 (N0r/2, N0c/2) and A2, H2, V2, D2
+// (N0r/4, N0c/4).  The approximation of the first level never leaves the registers: a finished A1 row
+// (two columns per lane) is filtered along x with the samples of the lanes l-2 .. l+2 (DPP shifts, one
+// level-2 column per lane) and added to level-2 running column sums.  No lane can borrow A1 columns
+// from ANOTHER wavefront, so strips overlap: a wavefront still loads 256 image columns (lanes 0 .. 63),
+// but only the lanes 2 .. 61 own outputs -- 240 image columns, 120 level-1 and 60 level-2 columns per
+// strip -- and the A1 rows above and below the segment are recomputed (3 hlen - 6 extra image rows per
+// segment).  What it buys: A1 (a quarter of the level-1 output) is neither written nor read back, and
+// one launch disappears.  Every store goes through a buffer descriptor whose range check drops the
+// lanes that own nothing (offset 0xFFFFFFFF) and the columns right of the image (num_records = one
+// row): no store sits under a branch, so the s_waitcnt counts of the load ring stay exact.
+// Needs N0r % 4 == 0 and N0c % 16 == 0 (even sizes at both levels: exact periodization).
+// ------------------------------------------------------------------------------------------------
+struct FwdWave2Args {
+    const float* in;
+    float *H1, *V1, *D1;
+    float *A2, *H2, *V2, *D2;
+    int N0r, N0c;
+    long long in_bstride, l1_bstride, l2_bstride;
+    int strips;     // ceil(N0c / 240)
+    int segs;       // ceil(N0r / 4 / seg2_out)
+    int seg2_out;   // level-2 output rows per wavefront
+    FilterBankI fb;
+};
+
+// One band row as a range-checked store target: (uniform row pointer) + (per-lane byte offset); offsets
+// >= the row's byte length (in particular kDropped) are dropped.  The descriptor is rebuilt per row from
+// the row pointer -- a few scalar instructions -- because on gfx950 the range check of a raw buffer covers
+// voffset + soffset, so the row cannot ride in soffset (measured: everything below row 0 was dropped).
+#ifdef PDWT_CPU_EMU
+struct RowBuf {
+    char* base;
+    unsigned bytes;
+};
+PDWT_DEVICE RowBuf row_buf(float* row, unsigned row_bytes) { return RowBuf{(char*)row, row_bytes}; }
+PDWT_DEVICE void row_st8(const RowBuf& r, unsigned off, float x, float y) {
+    if (off < r.bytes) { float* p = reinterpret_cast<float*>(r.base + off); p[0] = x; p[1] = y; }
+}
+PDWT_DEVICE void row_st4(const RowBuf& r, unsigned off, float x) {
+    if (off < r.bytes) *reinterpret_cast<float*>(r.base + off) = x;
+}
+#else
+struct RowBuf {
+    __amdgpu_buffer_rsrc_t rsrc;
+};
+static __device__ __forceinline__ RowBuf row_buf(float* row, unsigned row_bytes) {
+    RowBuf r;
+    r.rsrc = __builtin_amdgcn_make_buffer_rsrc(row, (short)0, (int)row_bytes, 0x00020000);
+    return r;
+}
+typedef unsigned pdwt_u2 __attribute__((ext_vector_type(2)));
+static __device__ __forceinline__ void row_st8(const RowBuf& r, unsigned off, float x, float y) {
+    pdwt_u2 d;
+    d.x = __builtin_bit_cast(unsigned, x);
+    d.y = __builtin_bit_cast(unsigned, y);
+    __builtin_amdgcn_raw_buffer_store_b64(d, r.rsrc, (int)off, 0, 0);
+}
+static __device__ __forceinline__ void row_st4(const RowBuf& r, unsigned off, float x) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, x), r.rsrc, (int)off, 0, 0);
+}
+#endif
+
+constexpr unsigned kDropped = 0xFFFFFFFFu;  // a byte offset no descriptor accepts
+
+template <int HLEN>
+struct FwdWave2State {
+    using G = FwdWaveGeom<HLEN>;
+    WaveReg<float, 4 * G::NR> ring;
+    WaveReg<float, 4 * G::NR> hring;
+    WaveReg<v2f, 4 * G::NS> acc;    // level 1: per slot (A,V) col 0, (A,V) col 1, (H,D) col 0, (H,D) col 1
+    WaveReg<float, 2> a1;           // the finished A1 row: this lane's two columns
+    WaveReg<v2f, 2 * G::NS> acc2;   // level 2: per slot (A,V), (H,D) of this lane's column
+    WaveReg<unsigned, 4> off;       // byte offsets: own float4, halo float4, level-1 pair, level-2 sample (or kDropped)
+};
+
+struct Fwd2Bufs {  // per-image base pointers and row lengths
+    const float* in;
+    float *H1, *V1, *D1, *A2, *H2, *V2, *D2;
+    unsigned row1_bytes, row2_bytes;
+};
+
+template <int HLEN>
+PDWT_DEVICE void fwd2_wave_load(FwdWave2State<HLEN>& st, int slot, const float* in, int Nc, RowWalk& walk) {
+    const float* row = in + (long long)walk.next() * Nc;
+    PDWT_WAVE_LANES(lane) {
+        const v4f x = wave_ld16(row, st.off.mine(lane)[0]);
+        float* r = st.ring.mine(lane) + 4 * slot;
+        r[0] = x.x; r[1] = x.y; r[2] = x.z; r[3] = x.w;
+        if (FwdWaveGeom<HLEN>::C > 0) {
+            const v4f h = wave_ld16(row, st.off.mine(lane)[1]);
+            float* q = st.hring.mine(lane) + 4 * slot;
+            q[0] = h.x; q[1] = h.y; q[2] = h.z; q[3] = h.w;
+        }
+    }
+}
+
+// level-1 part of image row r (same arithmetic as fwd_wave_row)
+template <int HLEN, int SLOT, int R1, int IH, bool WARM, int DMAX>
+PDWT_DEVICE void fwd2_wave_row(FwdWave2State<HLEN>& st, const FilterBankI& fb) {
+    using G = FwdWaveGeom<HLEN>;
+    constexpr int C = G::C, NS = G::NS;
+    PDWT_WAVE_LANES(lane) {
+        float v[HLEN + 2];
+        if (C > 0) {
+            const float* hv = st.hring.mine(lane) + 4 * SLOT;
+#pragma unroll
+            for (int t = 0; t < C; ++t) {
+                v[t] = st.ring.from_prev(4 * SLOT + 4 - C + t, lane, hv[4 - C + t]);
+                v[C + 4 + t] = st.ring.from_next(4 * SLOT + t, lane, hv[t]);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[C + q] = st.ring.mine(lane)[4 * SLOT + q];
+        v2f lh0 = mk2(0.f, 0.f), lh1 = mk2(0.f, 0.f);
+#pragma unroll
+        for (int j = 0; j < HLEN; ++j) {
+            const v2f tap = fb.t[HLEN - 1 - j];
+            lh0 = fma2(bc(v[j]), tap, lh0);
+            lh1 = fma2(bc(v[2 + j]), tap, lh1);
+        }
+        v2f* a = st.acc.mine(lane);
+#pragma unroll
+        for (int d = 0; d < NS; ++d) {
+            if (WARM && d > DMAX) continue;
+            constexpr int kNS = NS;
+            const int slot = ((IH - d) % kNS + kNS) % kNS;
+            const int j = R1 + 2 * d;
+            const v2f tap = fb.t[HLEN - 1 - j];
+            v2f* s = a + 4 * slot;
+            const v2f z = mk2(0.f, 0.f);
+            s[0] = fma2(lh0, bc(tap.x), j == 0 ? z : s[0]);
+            s[1] = fma2(lh1, bc(tap.x), j == 0 ? z : s[1]);
+            s[2] = fma2(lh0, bc(tap.y), j == 0 ? z : s[2]);
+            s[3] = fma2(lh1, bc(tap.y), j == 0 ? z : s[3]);
+        }
+    }
+}
+
+// A finished level-1 row sits in accumulator slot SLOT1: store its details (if this wavefront owns the row),
+// then run it through level 2: it is A1 row j1 of the wavefront's walk, J1 = j1 & 1, IH2 = (j1 >> 1) mod NS.
+template <int HLEN, int SLOT1, int J1, int IH2>
+PDWT_DEVICE void fwd2_wave_a1row(FwdWave2State<HLEN>& st, const FwdWave2Args& a, const Fwd2Bufs& b, bool own1,
+                                 long long row1, bool own2, long long row2) {
+    using G = FwdWaveGeom<HLEN>;
+    constexpr int C = G::C, NS = G::NS;
+    // a row this wavefront does not own gets an empty descriptor: every lane is dropped
+    const unsigned bytes1 = own1 ? b.row1_bytes : 0u, bytes2 = own2 ? b.row2_bytes : 0u;
+    const RowBuf bH1 = row_buf(b.H1 + row1, bytes1), bV1 = row_buf(b.V1 + row1, bytes1), bD1 = row_buf(b.D1 + row1, bytes1);
+    PDWT_WAVE_LANES(lane) {
+        const v2f* s = st.acc.mine(lane) + 4 * SLOT1;
+        const unsigned o = st.off.mine(lane)[2];
+        row_st8(bV1, o, s[0].y, s[1].y);
+        row_st8(bH1, o, s[2].x, s[3].x);
+        row_st8(bD1, o, s[2].y, s[3].y);
+        st.a1.mine(lane)[0] = s[0].x;
+        st.a1.mine(lane)[1] = s[1].x;
+    }
+    PDWT_WAVE_LANES(lane) {
+        // level-2 row filter: output column of lane l needs A1 columns 2l - C .. 2l - C + HLEN - 1 (lane-relative)
+        float v[HLEN];
+#pragma unroll
+        for (int j = 0; j < HLEN; ++j) {
+            const int rel = j - C;             // A1 column relative to this lane's first
+            const int dl = rel >= 0 ? rel / 2 : -((1 - rel) / 2);  // lane distance (floor division by 2)
+            const int e = rel - 2 * dl;        // element 0 / 1 of that lane
+            float x;
+            if (dl == 0) x = st.a1.mine(lane)[e];
+            else if (dl == -1) x = st.a1.from_prev(e, lane, 0.f);
+            else if (dl == 1) x = st.a1.from_next(e, lane, 0.f);
+            else if (dl == -2) x = st.a1.from_prev2(e, lane, 0.f);
+            else x = st.a1.from_next2(e, lane, 0.f);
+            v[j] = x;
+        }
+        v2f lh = mk2(0.f, 0.f);
+#pragma unroll
+        for (int j = 0; j < HLEN; ++j) lh = fma2(bc(v[j]), a.fb.t[HLEN - 1 - j], lh);
+        v2f* c = st.acc2.mine(lane);
+#pragma unroll
+        for (int d = 0; d < NS; ++d) {
+            constexpr int kNS = NS;
+            const int slot = ((IH2 - d) % kNS + kNS) % kNS;
+            const int j = J1 + 2 * d;
+            const v2f tap = a.fb.t[HLEN - 1 - j];
+            const v2f z = mk2(0.f, 0.f);
+            c[2 * slot] = fma2(lh, bc(tap.x), j == 0 ? z : c[2 * slot]);
+            c[2 * slot + 1] = fma2(lh, bc(tap.y), j == 0 ? z : c[2 * slot + 1]);
+        }
+        if (J1) {  // level-2 output row (j1 >> 1) - NS + 1 is complete
+            constexpr int kNS = NS;
+            const int so = ((IH2 - (NS - 1)) % kNS + kNS) % kNS;
+            const unsigned o = st.off.mine(lane)[3];
+            row_st4(row_buf(b.A2 + row2, bytes2), o, c[2 * so].x);
+            row_st4(row_buf(b.V2 + row2, bytes2), o, c[2 * so].y);
+            row_st4(row_buf(b.H2 + row2, bytes2), o, c[2 * so + 1].x);
+            row_st4(row_buf(b.D2 + row2, bytes2), o, c[2 * so + 1].y);
+        }
+    }
+}
+
+// rows r = HLEN - 2 + 2 GR it + G0 of the steady state, G0 = 0 .. 2 GR - 1 (the level-2 pattern's period)
+template <int HLEN, int G0 = 0>
+PDWT_DEVICE void fwd2_wave_group(FwdWave2State<HLEN>& st, const FwdWave2Args& a, const Fwd2Bufs& b, RowWalk& walk, int& j1,
+                                 int own1_lo, int own1_hi, int n2, int r1_first, int oy2_0) {
+    using G = FwdWaveGeom<HLEN>;
+    constexpr int NS = G::NS, GR = G::GR, NR = G::NR;
+    if constexpr (G0 < 2 * GR) {
+        constexpr int r = HLEN - 2 + G0;
+        fwd2_wave_load<HLEN>(st, (r + NR - 1) % NR, b.in, a.N0c, walk);
+        fwd2_wave_row<HLEN, r % NR, (r & 1), ((r >> 1) % NS), false, 0>(st, a.fb);
+        if constexpr (G0 & 1) {
+            constexpr int so = ((((r >> 1) - (NS - 1)) % NS) + NS) % NS;
+            constexpr int J = (G0 - 1) / 2;  // j1 = GR it + J
+            const int i2 = ((j1 - (HLEN - 1)) >> 1);  // level-2 row finished by an odd j1
+            const bool own1 = j1 >= own1_lo && j1 < own1_hi;
+            const bool own2 = (J & 1) && i2 >= 0 && i2 < n2;
+            const long long row1 = own1 ? (long long)(r1_first + j1) * (a.N0c >> 1) : 0;  // element offsets of the rows
+            const long long row2 = own2 ? (long long)(oy2_0 + i2) * (a.N0c >> 2) : 0;
+            fwd2_wave_a1row<HLEN, so, (J & 1), ((J >> 1) % NS)>(st, a, b, own1, row1, own2, row2);
+            ++j1;
+        }
+        PDWT_ROW_FENCE();
+        fwd2_wave_group<HLEN, G0 + 1>(st, a, b, walk, j1, own1_lo, own1_hi, n2, r1_first, oy2_0);
+    }
+}
+
+template <int HLEN, int R = 0>
+PDWT_DEVICE void fwd2_wave_warmup(FwdWave2State<HLEN>& st, const FwdWave2Args& a, const Fwd2Bufs& b, RowWalk& walk) {
+    using G = FwdWaveGeom<HLEN>;
+    constexpr int NS = G::NS, NR = G::NR;
+    if constexpr (R < HLEN - 2) {
+        fwd2_wave_load<HLEN>(st, (R + NR - 1) % NR, b.in, a.N0c, walk);
+        fwd2_wave_row<HLEN, R % NR, (R & 1), ((R >> 1) % NS), true, (R >> 1)>(st, a.fb);
+        PDWT_ROW_FENCE();
+        fwd2_wave_warmup<HLEN, R + 1>(st, a, b, walk);
+    }
+}
+
+// One wavefront: strip `strip` (level-2 columns [60 strip, 60 strip + 60)), level-2 rows
+// [seg * seg2_out, (seg + 1) * seg2_out) of image bz.
+template <int HLEN>
+PDWT_DEVICE void dwt2_fwd2_wave(const FwdWave2Args& a, int strip, int seg, int bz) {
+    using G = FwdWaveGeom<HLEN>;
+    constexpr int C = G::C, GR = G::GR, NR = G::NR;
+    const int N1r = a.N0r >> 1, N1c = a.N0c >> 1, N2r = a.N0r >> 2, N2c = a.N0c >> 2;
+    const int oy2_0 = seg * a.seg2_out;
+    int oy2_end = oy2_0 + a.seg2_out;
+    if (oy2_end > N2r) oy2_end = N2r;
+    const int n2 = oy2_end - oy2_0;
+    if (n2 <= 0) return;
+    const int nA1 = 2 * n2 + HLEN - 2;          // A1 rows this wavefront computes
+    const int r1_first = 2 * oy2_0 - C;         // ... starting here (may be negative: periodic)
+    const int nrows = 2 * nA1 + HLEN - 2;       // image rows it filters
+    const int a0 = 120 * strip - 4;             // first A1 column of lane 0
+    const int x0 = 2 * a0;                      // first image column of lane 0
+
+    FwdWave2State<HLEN> st;
+    PDWT_WAVE_LANES(lane) {
+        unsigned* o = st.off.mine(lane);
+        o[0] = 4u * (unsigned)wrap_periodic(x0 + 4 * lane, a.N0c);
+        o[1] = 4u * (unsigned)wrap_periodic(lane < 32 ? x0 - 4 : x0 + 256, a.N0c);
+        const bool owner = lane >= 2 && lane < 62;
+        o[2] = owner ? 4u * (unsigned)(a0 + 2 * lane) : kDropped;          // columns >= N1c: dropped by the range check
+        o[3] = owner ? 4u * (unsigned)(60 * strip + lane - 2) : kDropped;
+    }
+    Fwd2Bufs b;
+    b.in = a.in + (long long)bz * a.in_bstride;
+    b.H1 = a.H1 + (long long)bz * a.l1_bstride;
+    b.V1 = a.V1 + (long long)bz * a.l1_bstride;
+    b.D1 = a.D1 + (long long)bz * a.l1_bstride;
+    b.A2 = a.A2 + (long long)bz * a.l2_bstride;
+    b.H2 = a.H2 + (long long)bz * a.l2_bstride;
+    b.V2 = a.V2 + (long long)bz * a.l2_bstride;
+    b.D2 = a.D2 + (long long)bz * a.l2_bstride;
+    b.row1_bytes = (unsigned)N1c * 4u;
+    b.row2_bytes = (unsigned)N2c * 4u;
+
+    RowWalk walk;
+    walk.start_periodic(2 * r1_first - C, a.N0r, nrows);
+#pragma unroll
+    for (int p = 0; p < NR - 1; ++p) fwd2_wave_load<HLEN>(st, p, b.in, a.N0c, walk);
+    fwd2_wave_warmup<HLEN>(st, a, b, walk);
+    // A1 row j1 (0-based in the walk) is image-level row r1_first + j1 (periodic); the wavefront owns, i.e.
+    // stores the details of, the rows [2 oy2_0, 2 oy2_end)
+    const int own1_lo = C, own1_hi = C + 2 * n2;
+    int j1 = 0;
+    const int ngroups = (nA1 + GR - 1) / GR;
+#pragma unroll 1
+    for (int it = 0; it < ngroups; ++it) fwd2_wave_group<HLEN>(st, a, b, walk, j1, own1_lo, own1_hi, n2, r1_first, oy2_0);
+    (void)N1r;
+}
+
 // wave-tile id -> (strip, seg): XCD x (workgroup ids b with b % 8 == x share an L2) gets a contiguous band
 // of segment rows, so vertically adjacent segments re-read their shared rows from that XCD's own L2.
 // Placement only affects speed.
@@ -558,6 +859,14 @@ __global__ void __launch_bounds__(NT, 4) dwt2_fwd_wave_kernel(const FwdWaveArgs 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (!wave_tile(blockIdx.x, wave, NT / 64, a.strips, a.segs, strip, seg)) return;
     dwt2_fwd_wave<HLEN, GUARD>(a, strip, seg, blockIdx.y);
+}
+
+template <int HLEN, int NT>
+__global__ void __launch_bounds__(NT, 4) dwt2_fwd2_wave_kernel(const FwdWave2Args a) {
+    int strip, seg;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (!wave_tile(blockIdx.x, wave, NT / 64, a.strips, a.segs, strip, seg)) return;
+    dwt2_fwd2_wave<HLEN>(a, strip, seg, blockIdx.y);
 }
 
 template <int HLEN, bool GUARD, int NT>

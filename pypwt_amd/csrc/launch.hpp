@@ -24,6 +24,13 @@ hipError_t try_launch_dwt2_inv_fast(const Inv2DArgs& a, int batch, hipStream_t s
 hipError_t try_launch_dwt2_fwd_wave(const Fwd2DArgs& a, int batch, hipStream_t s, int seg_hint = 0);
 hipError_t try_launch_dwt2_inv_wave(const Inv2DArgs& a, int batch, hipStream_t s, int seg_hint = 0);
 int set_wave_min_log2(int value);  // returns the previous threshold
+int get_wave_min_log2();
+int set_wave2_enabled(int value);  // two-levels-per-wavefront forward (opt-in); returns the previous setting
+int get_wave2_enabled();
+// two forward levels per wavefront (A_l stays in registers); contract of launch_dwt2_fwd_pyr2
+bool dwt2_wave2_supported(int hlen, int N0r, int N0c);
+hipError_t launch_dwt2_fwd_wave2(const real_t* in, real_t* const det1[3], real_t* const band2[4], int N0r, int N0c,
+                                 int hlen, const FilterBank& fb, int batch, hipStream_t s, int seg_hint = 0);
 // two consecutive 2D levels in one launch (small levels only, see launch_dwt2_pyramid.hip)
 bool dwt2_pyramid_supported(int hlen, int N0r, int N0c);
 hipError_t launch_dwt2_fwd_pyr2(const real_t* in, real_t* const det1[3], real_t* const band2[4], int N0r, int N0c,

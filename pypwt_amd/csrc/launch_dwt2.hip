@@ -43,6 +43,9 @@ hipError_t try_launch_dwt2_fwd_fast(const Fwd2DArgs&, int, hipStream_t) { return
 hipError_t try_launch_dwt2_inv_fast(const Inv2DArgs&, int, hipStream_t) { return hipErrorNotSupported; }
 hipError_t try_launch_dwt2_fwd_wave(const Fwd2DArgs&, int, hipStream_t, int) { return hipErrorNotSupported; }
 hipError_t try_launch_dwt2_inv_wave(const Inv2DArgs&, int, hipStream_t, int) { return hipErrorNotSupported; }
+bool dwt2_wave2_supported(int, int, int) { return false; }
+hipError_t launch_dwt2_fwd_wave2(const real_t*, real_t* const[3], real_t* const[4], int, int, int, const FilterBank&, int,
+                                 hipStream_t, int) { return hipErrorNotSupported; }
 bool dwt2_pyramid_supported(int, int, int) { return false; }
 hipError_t launch_dwt2_fwd_pyr2(const real_t*, real_t* const[3], real_t* const[4], int, int, int, const FilterBank&, int,
                                 hipStream_t) { return hipErrorNotSupported; }
@@ -76,6 +79,13 @@ int set_wave_min_log2(int value) {  // pdwt_set_tuning("wave_min_log2")
     if (value > 63) value = 63;
     return wave_min_log2().exchange(value);
 }
+int get_wave_min_log2() { return wave_min_log2().load(std::memory_order_relaxed); }
+static std::atomic<int>& wave2_flag() {
+    static std::atomic<int> v{getenv("PDWT_WAVE2") ? 1 : 0};
+    return v;
+}
+int set_wave2_enabled(int value) { return wave2_flag().exchange(value ? 1 : 0); }
+int get_wave2_enabled() { return wave2_flag().load(std::memory_order_relaxed); }
 static bool wave_kernels_for(long long samples) {
     const int m = wave_min_log2().load(std::memory_order_relaxed);
     return m < 63 && samples >= (1LL << m);

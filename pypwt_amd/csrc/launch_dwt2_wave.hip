@@ -84,6 +84,51 @@ static hipError_t run_inv(const Inv2DArgs& g, int batch, int seg_hint, hipStream
     return hipGetLastError();
 }
 
+// ---- two forward levels per wavefront (dwt2_fwd2_wave): same contract as launch_dwt2_fwd_pyr2
+bool dwt2_wave2_supported(int hlen, int N0r, int N0c) {
+    return !(hlen & 1) && hlen >= 2 && hlen <= 8 && (N0r % 4) == 0 && (N0c % 16) == 0 && N0r >= 4 && N0c >= 16 &&
+           (long long)N0r * N0c < (1LL << 30);  // 32-bit byte offsets inside one image
+}
+
+template <int HLEN>
+static hipError_t run_fwd2(FwdWave2Args& a, int batch, int seg_hint, hipStream_t s) {
+    constexpr int NT = 256;
+    a.strips = cdiv(a.N0c, 240);
+    const int N2r = a.N0r / 4;
+    // level-2 rows per wavefront: about one wavefront per SIMD; every segment recomputes 3 hlen - 6 image rows
+    long long seg = seg_hint > 0 ? seg_hint : cdivll((long long)N2r * a.strips * batch, kWaveTarget);
+    if (seg < 2) seg = 2;
+    if (seg_hint <= 0 && seg > 32) seg = 32;
+    a.seg2_out = (int)seg;
+    a.segs = cdiv(N2r, a.seg2_out);
+    const int nblk = cdiv(a.strips * a.segs, NT / 64);
+    hipLaunchKernelGGL((dwt2_fwd2_wave_kernel<HLEN, NT>), dim3(8 * cdiv(nblk, 8), batch), dim3(NT), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_dwt2_fwd_wave2(const float* in, float* const det1[3], float* const band2[4], int N0r, int N0c,
+                                 int hlen, const FilterBank& fb, int batch, hipStream_t s, int seg_hint) {
+    if (!dwt2_wave2_supported(hlen, N0r, N0c)) return hipErrorNotSupported;
+    if (!aligned16(in) || !aligned16(det1[0]) || !aligned16(det1[1]) || !aligned16(det1[2]) || !aligned16(band2[0]) ||
+        !aligned16(band2[1]) || !aligned16(band2[2]) || !aligned16(band2[3]))
+        return hipErrorNotSupported;
+    FwdWave2Args a;
+    a.in = in; a.H1 = det1[0]; a.V1 = det1[1]; a.D1 = det1[2];
+    a.A2 = band2[0]; a.H2 = band2[1]; a.V2 = band2[2]; a.D2 = band2[3];
+    a.N0r = N0r; a.N0c = N0c;
+    a.in_bstride = (long long)N0r * N0c;
+    a.l1_bstride = (long long)(N0r / 2) * (N0c / 2);
+    a.l2_bstride = (long long)(N0r / 4) * (N0c / 4);
+    interleave(a.fb, fb);
+    switch (hlen) {
+        case 2: return run_fwd2<2>(a, batch, seg_hint, s);
+        case 4: return run_fwd2<4>(a, batch, seg_hint, s);
+        case 6: return run_fwd2<6>(a, batch, seg_hint, s);
+        case 8: return run_fwd2<8>(a, batch, seg_hint, s);
+    }
+    return hipErrorNotSupported;
+}
+
 hipError_t try_launch_dwt2_fwd_wave(const Fwd2DArgs& a, int batch, hipStream_t s, int seg_hint) {
     if ((a.hlen & 1) || a.hlen < 2 || a.hlen > 8) return hipErrorNotSupported;
     if ((a.Nc & 3) || (a.in_bstride & 3) || (a.out_bstride & 1) || a.Nc2 * 2 != a.Nc) return hipErrorNotSupported;

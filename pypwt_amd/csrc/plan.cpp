@@ -331,10 +331,22 @@ void build_schedule(pdwt_plan* p) {
             return force_strip || samples(l) >= (1LL << 26);
         };
         auto pyr_at = [&](int l) { return fusable && !no_pyr && pair_ok(l) && samples(l) <= (1LL << 20); };
+        // Two levels per WAVEFRONT (dwt2_fwd2_wave: A_l stays in registers, overlapping strips).  Correct and
+        // tested, but NOT faster than two launches on MI355X (profiles/r02g_wbench_*.txt: 4096^2 31.3 us against
+        // 21.9 + 7.9 us; 8 x 4096^2 267 us against 209 + ~50 us, streaming strips 229 us): one wavefront per SIMD is
+        // issue-bound, and the second level's shifts, descriptors and 4-B stores add 50 % instructions for 20 %
+        // fewer bytes.  Opt-in only: PDWT_WAVE2=1 or pdwt_set_tuning("wave2", 1) (tests keep it covered).
+        const bool wave2_on = get_wave2_enabled() != 0;
+        const int wmin = get_wave_min_log2();
+        auto wave2_at = [&](int l, bool inverse) {
+            return fusable && !inverse && wave2_on && wmin < 63 && l + 1 <= L && samples(l) >= (1LL << wmin) &&
+                   dwt2_wave2_supported(hlen, p->lr[l - 1], p->lc[l - 1]);
+        };
         for (int dir = 0; dir < 2; dir++) {
             std::vector<Step>& out = dir ? p->sched_inv : p->sched_fwd;
             for (int l = 1; l <= L; l++) {
                 if (strip_at(l, dir != 0)) { out.push_back({Step::STRIP2, l, 2}); l++; }
+                else if (wave2_at(l, dir != 0)) { out.push_back({Step::WAVE2, l, 2}); l++; }
                 else if (pyr_at(l) && !strip_at(l + 1, dir != 0)) { out.push_back({Step::PYR2, l, 2}); l++; }
                 else out.push_back({Step::LEVEL, l, 1});
             }
@@ -558,15 +570,17 @@ int forward_impl(pdwt_plan* p, int only = 0) {
         const int l = s.level;
         const bool run = (only == 0 || only == l);
         hipError_t e = hipErrorNotSupported;
-        if (s.kind == Step::STRIP2 || s.kind == Step::PYR2) {
+        if (s.kind == Step::STRIP2 || s.kind == Step::PYR2 || s.kind == Step::WAVE2) {
             // levels l and l+1 in one launch; A_l never reaches HBM
             real_t* det1[3] = {p->band(3 * (l - 1) + 1), p->band(3 * (l - 1) + 2), p->band(3 * (l - 1) + 3)};
             real_t* band2[4] = {approx_slot(p, l + 1), p->band(3 * l + 1), p->band(3 * l + 2), p->band(3 * l + 3)};
-            Stamp st(p, s.kind == Step::STRIP2 ? "dwt2_fwd_strip2" : "dwt2_fwd_pyr2");
+            Stamp st(p, s.kind == Step::STRIP2 ? "dwt2_fwd_strip2" : (s.kind == Step::WAVE2 ? "dwt2_fwd_wave2" : "dwt2_fwd_pyr2"));
             if (!run) continue;
-            e = s.kind == Step::STRIP2
-                    ? launch_dwt2_fwd_strip2(approx_slot(p, l - 1), det1, band2, p->lr[l - 1], p->lc[l - 1], hlen, p->dec, B, p->stream)
-                    : launch_dwt2_fwd_pyr2(approx_slot(p, l - 1), det1, band2, p->lr[l - 1], p->lc[l - 1], hlen, p->dec, B, p->stream);
+            const real_t* src = approx_slot(p, l - 1);
+            const int r0 = p->lr[l - 1], c0 = p->lc[l - 1];
+            e = s.kind == Step::STRIP2  ? launch_dwt2_fwd_strip2(src, det1, band2, r0, c0, hlen, p->dec, B, p->stream)
+                : s.kind == Step::WAVE2 ? launch_dwt2_fwd_wave2(src, det1, band2, r0, c0, hlen, p->dec, B, p->stream)
+                                        : launch_dwt2_fwd_pyr2(src, det1, band2, r0, c0, hlen, p->dec, B, p->stream);
         } else if (s.kind == Step::FUSED1D) {
             real_t* det[kMaxFusedLevelsHost] = {};
             for (int k = 0; k < s.K; k++) det[k] = p->band(l + k);
@@ -1284,6 +1298,7 @@ int pdwt_time_level(pdwt_handle h, int level, int inverse, int reps, float* ms_p
 
 int pdwt_set_tuning(const char* key, int value) {
     if (key && !strcmp(key, "wave_min_log2")) return set_wave_min_log2(value);
+    if (key && !strcmp(key, "wave2")) return set_wave2_enabled(value);
     return fail(PDWT_ERR_ARG, "pdwt_set_tuning: unknown key %s", key ? key : "(null)");
 }
 

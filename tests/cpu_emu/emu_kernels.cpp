@@ -571,3 +571,27 @@ EMU_API int emu_dwt2_inv_wave(const float* A, const float* H, const float* V, co
     }
     return -1;
 }
+
+// two forward levels per wavefront: in (N0r, N0c) -> det1 = H1|V1|D1 planes, band2 = A2|H2|V2|D2 planes
+EMU_API int emu_dwt2_fwd2_wave(const float* in, int batch, int N0r, int N0c, const float* lo, const float* hi, int hlen,
+                               int seg2_out, float* det1, float* band2) {
+    if ((hlen & 1) || hlen < 2 || hlen > 8 || (N0r & 3) || (N0c & 15)) return -1;
+    FwdWave2Args a;
+    const long long q1 = (long long)batch * (N0r / 2) * (N0c / 2), q2 = (long long)batch * (N0r / 4) * (N0c / 4);
+    a.in = in; a.H1 = det1; a.V1 = det1 + q1; a.D1 = det1 + 2 * q1;
+    a.A2 = band2; a.H2 = band2 + q2; a.V2 = band2 + 2 * q2; a.D2 = band2 + 3 * q2;
+    a.N0r = N0r; a.N0c = N0c;
+    a.in_bstride = (long long)N0r * N0c; a.l1_bstride = (long long)(N0r / 2) * (N0c / 2);
+    a.l2_bstride = (long long)(N0r / 4) * (N0c / 4);
+    a.strips = cdiv(N0c, 240); a.seg2_out = seg2_out; a.segs = cdiv(N0r / 4, seg2_out);
+    interleave_bank(a.fb, lo, hi, hlen);
+    for (int bz = 0; bz < batch; bz++)
+        for (int seg = 0; seg < a.segs; seg++)
+            for (int strip = 0; strip < a.strips; strip++) switch (hlen) {
+                case 2: dwt2_fwd2_wave<2>(a, strip, seg, bz); break;
+                case 4: dwt2_fwd2_wave<4>(a, strip, seg, bz); break;
+                case 6: dwt2_fwd2_wave<6>(a, strip, seg, bz); break;
+                case 8: dwt2_fwd2_wave<8>(a, strip, seg, bz); break;
+            }
+    return 0;
+}

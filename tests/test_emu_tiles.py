@@ -474,3 +474,26 @@ def test_emu_dwt2_wave_batch_and_custom_filter():
     for b in range(B):
         ref = oracle.inverse([o[b] for o in outs], (nr, nc), "db4", 1, ndim=2, filt=(8, lo, hi, lo, hi))
         assert np.abs(rec[b] - ref).max() <= _tol(ref)
+
+
+WAVE2_SHAPES = [(64, 256, 4), (32, 480, 8), (96, 240, 5), (16, 16, 1), (8, 32, 2), (128, 512, 32), (40, 1008, 3),
+                (4, 16, 1)]
+
+
+@pytest.mark.parametrize("wname", WAVE_WNAMES)
+def test_emu_dwt2_wave_two_levels_forward(wname):
+    """dwt2_fwd2_wave: levels l and l+1 in one wavefront (A_l stays in registers), against two oracle levels."""
+    hlen, dlo, dhi, rlo, rhi = oracle.filters(wname)
+    for si, (nr, nc, seg2) in enumerate(WAVE2_SHAPES):
+        x = oracle.hash_input((2, nr, nc), 6100 + si)
+        det1 = np.full((3, 2, nr // 2, nc // 2), np.nan, dtype=np.float32)
+        band2 = np.full((4, 2, nr // 4, nc // 4), np.nan, dtype=np.float32)
+        assert lib().emu_dwt2_fwd2_wave(P(x), 2, nr, nc, P(dlo), P(dhi), hlen, seg2, P(det1), P(band2)) == 0
+        assert np.isfinite(det1).all() and np.isfinite(band2).all(), (wname, nr, nc)
+        for b in range(2):
+            l1 = oracle.forward(x[b], wname, 1, filt=(hlen, dlo, dhi, rlo, rhi))
+            l2 = oracle.forward(l1[0], wname, 1, filt=(hlen, dlo, dhi, rlo, rhi))
+            for k in range(3):
+                assert np.abs(det1[k, b] - l1[1 + k]).max() <= _tol(l1[1 + k]), (wname, nr, nc, "det1", k)
+            for k in range(4):
+                assert np.abs(band2[k, b] - l2[k]).max() <= 2 * _tol(l2[k]), (wname, nr, nc, "band2", k)

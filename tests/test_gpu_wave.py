@@ -29,10 +29,12 @@ def forced_wave():
     import os
     prev = lib.pdwt_set_tuning(b"wave_min_log2", 0)
     assert prev >= 0
+    prev2 = lib.pdwt_set_tuning(b"wave2", 1)  # level pairs with N0r % 4 == 0, N0c % 16 == 0: two levels per wavefront
     os.environ["PDWT_NO_PYRAMID"] = "1"  # read when a plan is created: every level as its own launch
     yield
     os.environ.pop("PDWT_NO_PYRAMID", None)
     lib.pdwt_set_tuning(b"wave_min_log2", prev)
+    lib.pdwt_set_tuning(b"wave2", prev2)
 
 
 def _flat(c):
@@ -114,3 +116,16 @@ def test_wave_kernels_batched_and_custom_filters():
         assert np.abs(g - r).max() <= 2e-5 * max(np.abs(r).max(), 1.0)
     w.inverse()
     assert np.abs(w.image - oracle.inverse(ref, y.shape, "db4", 2, filt=filt)).max() <= 2e-4 * max(np.abs(y).max(), 1.0) * 8
+
+
+def test_wave_single_level_kernels_without_the_two_level_fusion():
+    """the same shapes with pdwt_set_tuning("wave2", 0): every level through dwt2_fwd_wave / dwt2_inv_wave"""
+    from pypwt_amd import _lib
+    lib = _lib.load()
+    was = lib.pdwt_set_tuning(b"wave2", 0)
+    try:
+        for shape in ((64, 256), (96, 512), (48, 1008), (16, 16)):
+            for wname in ("haar", "db2", "db3", "db4"):
+                _check(oracle.hash_input(shape, 8400), wname, 2, "single")
+    finally:
+        lib.pdwt_set_tuning(b"wave2", was)

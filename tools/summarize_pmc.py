@@ -31,7 +31,7 @@ def short(name):
 def family(kernel):
     """Demangled kernel name -> the launch name plan.cpp stamps (what bench.py labels)."""
     k = short(kernel)
-    for sub, fam in (("fwd_pyr2", "dwt2_fwd_pyr2"), ("inv_pyr2", "dwt2_inv_pyr2"), ("fwd_strip2", "dwt2_fwd_strip2"),
+    for sub, fam in (("fwd2_wave", "dwt2_fwd_wave2"), ("inv2_wave", "dwt2_inv_wave2"), ("fwd_pyr2", "dwt2_fwd_pyr2"), ("inv_pyr2", "dwt2_inv_pyr2"), ("fwd_strip2", "dwt2_fwd_strip2"),
                      ("inv_strip2", "dwt2_inv_strip2"), ("dwt1_fwd_fused", "dwt1_fwd_fused"),
                      ("dwt1_inv_fused", "dwt1_inv_fused"), ("dwt2_fwd", "dwt2_fwd_level"), ("dwt2_inv", "dwt2_inv_level"),
                      ("dwt1_fwd", "dwt1_fwd_level"), ("dwt1_inv", "dwt1_inv_level"), ("swt2_fwd", "swt2_fwd_level"),
@@ -88,6 +88,27 @@ def main(root, traffic_out=None, config=None):
             v = sorted(dur[key])
             print("  %-66s grid=%9d n=%4d mean=%8.2f med=%8.2f min=%8.2f" % (key[0], key[1], len(v), sum(v) / len(v),
                   v[len(v) // 2], v[0]))
+    if dur and config:
+        # the same (kernel, grid) can serve several levels (the wave kernels run every large level with ~1024
+        # wavefronts): label the dispatches by their position in the step as well
+        from bench import CONFIGS
+        rows = []
+        for f in sorted(glob.glob(os.path.join(root, "stats", "**", "*kernel_trace.csv"), recursive=True)):
+            rows += list(csv.DictReader(open(f)))
+        lab = step_labels(rows, CONFIGS[config][3])
+        by = defaultdict(list)
+        for row in rows:
+            i = int(row["Dispatch_Id"])
+            if i in lab:
+                by[lab[i]].append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e3)
+        if by:
+            print("== kernel trace: duration per launch of the step (label = bench.py's) in us: n, mean, median, min")
+            tot = 0.0
+            for k, v in by.items():
+                v = sorted(v)
+                tot += sum(v) / len(v)
+                print("  %-28s n=%4d mean=%8.2f med=%8.2f min=%8.2f" % (k, len(v), sum(v) / len(v), v[len(v) // 2], v[0]))
+            print("  sum of the means: %.2f us per step" % tot)
     traffic = defaultdict(dict)
     for d in sorted(glob.glob(os.path.join(root, "pmc_*"))):
         if not os.path.isdir(d):

@@ -75,6 +75,10 @@ static void launch_fwd_wave(const FwdWaveArgs& a, int batch) {
     const int nblk = (a.strips * a.segs + NT / 64 - 1) / (NT / 64);
     hipLaunchKernelGGL((dwt2_fwd_wave_kernel<8, false, NT>), dim3(8 * ((nblk + 7) / 8), batch), dim3(NT), 0, 0, a);
 }
+static void launch_fwd2_wave(const FwdWave2Args& a, int batch) {
+    const int nblk = (a.strips * a.segs + 3) / 4;
+    hipLaunchKernelGGL((dwt2_fwd2_wave_kernel<8, 256>), dim3(8 * ((nblk + 7) / 8), batch), dim3(256), 0, 0, a);
+}
 template <int NT>
 static void launch_inv_wave(const InvWaveArgs& a, int batch) {
     const int nblk = (a.strips * a.segs + NT / 64 - 1) / (NT / 64);
@@ -159,6 +163,39 @@ int main(int argc, char** argv) {
             float us2 = time_it([&] { launch_fwd_wave<128>(w, B); });
             printf("WAVE fwd seg_out=%2d waves=%6d   NT256 %8.2f us %7.1f GB/s | NT128 %8.2f | NT64 %8.2f   max|diff| %.3g\n",
                    seg, w.strips * w.segs * B, us, bytes / us / 1e3, us2, us1, err);
+        }
+        // ---------------- two forward levels per wavefront vs. the two single-level launches
+        if (N >= 64) {
+            // reference for level 2: the LDS-tiled kernel on the A band of level 1 (co) -> img2 (4 planes of (N/4)^2)
+            const long long q2 = n / 16;
+            Fwd2DFastArgs f2 = f;
+            f2.in = co; f2.A = img2; f2.H = img2 + q2; f2.V = img2 + 2 * q2; f2.D = img2 + 3 * q2;
+            f2.Nr = N / 2; f2.Nc = N / 2; f2.Nr2 = N / 4; f2.Nc2 = N / 4;
+            f2.in_bstride = f.out_bstride; f2.out_bstride = (long long)(N / 4) * (N / 4);
+            f2.tiles_x = (N / 4 + 63) / 64; f2.tiles_y = (N / 4 + 7) / 8;
+            constexpr size_t lds = (size_t)fwd2d_fast_lds_floats<8, 64, 8>() * sizeof(float);
+            hipLaunchKernelGGL((dwt2_fwd_fast_kernel<8, 64, 8, 256>), dim3(8 * ((f2.tiles_x * f2.tiles_y + 7) / 8), B), dim3(256), lds, 0, f2);
+            FwdWave2Args w2;
+            float* l2out = co2 + 3 * q;  // A2 H2 V2 D2 packed into the (unused) fourth plane of co2
+            w2.in = img; w2.H1 = co2; w2.V1 = co2 + q; w2.D1 = co2 + 2 * q;
+            w2.A2 = l2out; w2.H2 = l2out + q2; w2.V2 = l2out + 2 * q2; w2.D2 = l2out + 3 * q2;
+            w2.N0r = N; w2.N0c = N;
+            w2.in_bstride = f.in_bstride; w2.l1_bstride = f.out_bstride; w2.l2_bstride = f2.out_bstride;
+            w2.strips = (N + 239) / 240;
+            bank(w2.fb, false);
+            for (int seg2 : {4, 8, 12, 16, 18, 24, 32}) {
+                if (seg2 > N / 4) continue;
+                w2.seg2_out = seg2; w2.segs = (N / 4 + seg2 - 1) / seg2;
+                CK(hipMemset(co2, 0xff, n * sizeof(float)));
+                launch_fwd2_wave(w2, B);
+                // co: A H V D ; co2: H1 V1 D1 [A2 H2 V2 D2]
+                const double e1 = fmax(fmax(max_abs_diff(co + q, co2, q), max_abs_diff(co + 2 * q, co2 + q, q)),
+                                       max_abs_diff(co + 3 * q, co2 + 2 * q, q));
+                const double e2 = max_abs_diff(img2, l2out, 4 * q2);
+                float us = time_it([&] { launch_fwd2_wave(w2, B); });
+                printf("WAVE2 fwd (L+1 fused) seg2_out=%2d waves=%6d  %8.2f us  %7.1f GB/s (8 B/sample)   max|diff| L1 %.3g L2 %.3g\n",
+                       seg2, w2.strips * w2.segs * B, us, bytes / us / 1e3, e1, e2);
+            }
         }
         // ---------------- inverse: reference = LDS-tiled kernel on the coefficients of the forward
         Inv2DFastArgs v;
