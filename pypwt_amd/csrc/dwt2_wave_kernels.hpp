@@ -113,7 +113,10 @@ struct FwdWaveGeom {
     static constexpr int NS = HLEN / 2;                // output rows a filtered row contributes to
     // rows per unrolled group (the slot pattern's period) and ring slots (NR - 1 rows of loads in flight)
     static constexpr int GR = HLEN < 4 ? 4 : (HLEN == 6 ? 12 : HLEN);
-    static constexpr int NR = HLEN == 10 ? 5 : 4;
+#ifndef PDWT_FWD_RING_H8
+#define PDWT_FWD_RING_H8 4  // ring slots of the hlen-8 forward kernel (wbench sweeps it)
+#endif
+    static constexpr int NR = HLEN == 10 ? 5 : (HLEN == 8 ? PDWT_FWD_RING_H8 : 4);
     static_assert(HLEN >= 2 && (HLEN & 1) == 0 && HLEN <= kWaveMaxHlen, "short even filters only");
     static_assert((GR / 2) % NS == 0 && GR % NR == 0, "slot / ring indices are static inside a group");
 };
@@ -341,8 +344,11 @@ struct InvWaveGeom {
     static constexpr int S = (H2 & 1) ? 0 : 1;
     static constexpr int NLEFT = C;                           // coefficient columns needed from the previous lane
     static constexpr int NRIGHT = S ? H2 - C : H2 - C - 1;    // ... and from the next lane
-    static constexpr int NR = (H2 == 3 || H2 == 5) ? H2 : 4;  // ring slots
-    static constexpr int GR = (H2 == 3 || H2 == 5) ? H2 : 4;  // rows per unrolled group; H2 | GR, NR | GR
+#ifndef PDWT_INV_RING_H8
+#define PDWT_INV_RING_H8 4  // ring slots of the hlen-8 inverse kernel (wbench sweeps it)
+#endif
+    static constexpr int NR = (H2 == 3 || H2 == 5) ? H2 : (H2 == 4 ? PDWT_INV_RING_H8 : 4);  // ring slots
+    static constexpr int GR = (H2 == 3 || H2 == 5) ? H2 : NR;  // rows per unrolled group; H2 | GR, NR | GR
     static_assert(HLEN >= 2 && (HLEN & 1) == 0 && HLEN <= kWaveMaxHlen, "short even filters only");
     static_assert(NLEFT <= 2 && NRIGHT <= 2 && GR % H2 == 0 && GR % NR == 0, "one neighbour lane per side");
 };
@@ -853,8 +859,9 @@ PDWT_DEVICE bool wave_tile(int block, int wave, int waves_per_block, int strips,
 }
 
 #ifndef PDWT_CPU_EMU
+// register budget: 4 wavefronts per SIMD with the default ring, fewer when a deeper ring is compiled in
 template <int HLEN, bool GUARD, int NT>
-__global__ void __launch_bounds__(NT, 4) dwt2_fwd_wave_kernel(const FwdWaveArgs a) {
+__global__ void __launch_bounds__(NT, PDWT_FWD_RING_H8 > 4 ? 2 : 4) dwt2_fwd_wave_kernel(const FwdWaveArgs a) {
     int strip, seg;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (!wave_tile(blockIdx.x, wave, NT / 64, a.strips, a.segs, strip, seg)) return;
@@ -870,7 +877,7 @@ __global__ void __launch_bounds__(NT, 4) dwt2_fwd2_wave_kernel(const FwdWave2Arg
 }
 
 template <int HLEN, bool GUARD, int NT>
-__global__ void __launch_bounds__(NT, 3) dwt2_inv_wave_kernel(const InvWaveArgs a) {
+__global__ void __launch_bounds__(NT, PDWT_INV_RING_H8 > 4 ? 2 : 3) dwt2_inv_wave_kernel(const InvWaveArgs a) {
     int strip, seg;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (!wave_tile(blockIdx.x, wave, NT / 64, a.strips, a.segs, strip, seg)) return;

@@ -11,9 +11,14 @@ kernels on the slab extended by the halo rows, keeping the interior of the resul
 the kernels only touches rows that are discarded.  The ring is periodic, like the transform
 (reference semantics pdwt/src/separable.cu:114-121).
 
-Restrictions: separable decimated 2D DWT, float32, rows-per-rank and columns divisible by 2^levels, and
-a slab at the coarsest level at least as tall as the halo (beyond that the remaining approximation is
-small enough to gather on one GPU, which this class does not do).
+After some levels a slab is thinner than the halo (or no longer divisible by two): the remaining
+approximation band -- by then 4^-t of the image -- is GATHERED on rank 0 (one all-gather: the only
+collective of the path), rank 0 finishes the transform with an ordinary single-GPU plan, and the inverse
+hands the slabs back with one broadcast ("after ~log2(G) levels ... gather the remaining A
+band onto one GPU").  `tiled_levels` says how many levels ran as slabs.
+
+Restrictions: separable decimated 2D DWT, float32, columns divisible by 2^levels, rows per rank divisible
+by 2^tiled_levels with tiled_levels >= 1.
 
 torch is plumbing here (device tensors, streams, torch.distributed); all arithmetic is done by the HIP
 library through the C ABI, with zero-copy views of the plans' device buffers.
@@ -64,18 +69,23 @@ class TiledWavelets(object):
         check(hlen, "TiledWavelets()", self._lib)
         self.hlen = int(hlen)
         self.levels = int(levels)
-        if self.levels < 1 or self.n % (1 << self.levels) or self.Nc % (1 << self.levels):
-            raise ValueError("TiledWavelets: rows per rank (%d) and columns (%d) must be divisible by 2^levels"
-                             % (self.n, self.Nc))
+        if self.levels < 1 or self.Nc % (1 << self.levels):
+            raise ValueError("TiledWavelets: columns (%d) must be divisible by 2^levels" % self.Nc)
         c = self.hlen // 2 - 1
         self._hp = c + (c & 1)                        # analysis halo rows (even)
         H2 = self.hlen // 2
         C2, S = H2 // 2, (0 if (H2 & 1) else 1)
         self._hq = max(C2, H2 - 1 - C2 + S)           # synthesis halo rows (coefficient rows)
-        coarse = self.n >> (self.levels - 1)
-        if coarse < self._hp or (coarse >> 1) < self._hq:
-            raise ValueError("TiledWavelets: the slab at the last level (%d rows) is thinner than the halo (%d)"
-                             % (coarse, max(self._hp, 2 * self._hq)))
+        # levels that run as slabs: the slab entering the level is even, at least as tall as the analysis halo,
+        # and its half at least as tall as the synthesis halo; the rest runs on rank 0 after the gather
+        t, m = 0, self.n
+        while t < self.levels and m % 2 == 0 and m >= self._hp and (m >> 1) >= self._hq and m >= 2:
+            t, m = t + 1, m >> 1
+        if t < 1:
+            raise ValueError("TiledWavelets: a slab of %d rows is too thin (or odd) for one level of %s (halo %d)"
+                             % (self.n, self.wname, max(self._hp, 2 * self._hq)))
+        self.tiled_levels, self.deep_levels = t, self.levels - t
+        self._deep = None    # rank 0: the single-GPU plan of the gathered approximation
         self._plans = {}
         self._bands = None   # after forward(): [A_L, (H1,V1,D1), ...] torch slabs
         # every plan runs on ONE side stream that torch also uses for its copies (a NULL stream handle would
@@ -160,7 +170,7 @@ class TiledWavelets(object):
             self.slab.copy_(torch.as_tensor(slab, dtype=torch.float32, device=self.device))
         cur, hp = self.slab, self._hp
         bands = [None]
-        for _ in range(self.levels):
+        for _ in range(self.tiled_levels):
             m, w = int(cur.shape[0]), int(cur.shape[1])
             h = self._plan(m + 2 * hp, w)
             img = self._view(self._lib.pdwt_image_ptr(h), (m + 2 * hp, w))
@@ -176,15 +186,88 @@ class TiledWavelets(object):
             bands.append((out[1], out[2], out[3]))
             cur = out[0]
         bands[0] = cur
+        if self.deep_levels:
+            bands[0] = None
+            self._a_slab_shape = tuple(cur.shape)
+            full = self._gather_rows(cur)            # every rank receives it (all-gather); rank 0 uses it
+            if self.rank == 0:
+                h = self._deep_plan(int(full.shape[0]), int(full.shape[1]))
+                check(self._lib.pdwt_set_image(h, C.c_void_p(full.contiguous().data_ptr()), 1), lib=self._lib)
+                check(self._lib.pdwt_forward(h), "TiledWavelets.forward (gathered levels)", self._lib)
+                rows, cols = C.c_int(), C.c_int()
+                deep = []
+                for num in range(3 * self.deep_levels + 1):
+                    self._lib.pdwt_coeff_count(h, num, C.byref(rows), C.byref(cols))
+                    deep.append(self._view(self._lib.pdwt_coeff_ptr(h, num), (rows.value, cols.value)).clone())
+                bands[0] = deep[0]
+                for l in range(self.deep_levels):
+                    bands.append(tuple(deep[1 + 3 * l:4 + 3 * l]))
+            else:
+                bands += [None] * self.deep_levels
         self._bands = bands
         return self
+
+    def _deep_plan(self, rows, cols):
+        if self._deep is None:
+            h = handle_t()
+            rc = self._lib.pdwt_create_batched(None, 1, rows, cols, self.wname.encode("ASCII"), self.deep_levels, 1, 1, 0,
+                                               0, 2, self.device.index, C.c_void_p(self._stream.cuda_stream), C.byref(h))
+            check(rc, "TiledWavelets gathered plan", self._lib)
+            info = PdwtInfo()
+            check(self._lib.pdwt_get_info(h, C.byref(info), None, None, None, None), lib=self._lib)
+            if info.nlevels != self.deep_levels:
+                self._lib.pdwt_destroy(h)
+                raise ValueError("TiledWavelets: %d levels requested, the image allows only %d"
+                                 % (self.levels, self.tiled_levels + info.nlevels))
+            self._deep = h
+        return self._deep
+
+    # ---- the ONE collective of the path: all ranks' slabs stacked in rank order
+    def _gather_rows(self, slab):
+        torch, dist = self._torch, self._dist
+        if self.world == 1:
+            return slab
+        if self._via_host:
+            parts = [torch.empty(slab.shape, dtype=slab.dtype) for _ in range(self.world)]
+            dist.all_gather(parts, slab.cpu().contiguous(), group=self.group)
+            return torch.cat(parts).to(self.device)
+        parts = [torch.empty_like(slab) for _ in range(self.world)]
+        dist.all_gather(parts, slab.contiguous(), group=self.group)
+        return torch.cat(parts)
+
+    def _scatter_rows(self, full, slab_shape):
+        """rank 0 holds `full`; every rank gets its slab (one broadcast, each rank slices)."""
+        torch, dist = self._torch, self._dist
+        if self.world == 1:
+            return full
+        rows = slab_shape[0] * self.world
+        if self._via_host:
+            buf = full.cpu().contiguous() if self.rank == 0 else torch.empty((rows, slab_shape[1]), dtype=torch.float32)
+            dist.broadcast(buf, 0, group=self.group)
+            return buf[self.rank * slab_shape[0]:(self.rank + 1) * slab_shape[0]].to(self.device)
+        buf = full.contiguous() if self.rank == 0 else torch.empty((rows, slab_shape[1]), dtype=torch.float32,
+                                                                    device=self.device)
+        dist.broadcast(buf, 0, group=self.group)
+        return buf[self.rank * slab_shape[0]:(self.rank + 1) * slab_shape[0]].clone()
 
     def _inverse(self):
         if self._bands is None:
             raise RuntimeError("TiledWavelets.inverse: call forward() first")
         torch, hq = self._torch, self._hq
         cur = self._bands[0]
-        for lvl in range(self.levels, 0, -1):
+        if self.deep_levels:
+            full = None
+            if self.rank == 0:  # undo the gathered levels, then hand the slabs of A_t back
+                h = self._deep
+                check(self._lib.pdwt_set_coeff(h, C.c_void_p(self._bands[0].contiguous().data_ptr()), 0, 1), lib=self._lib)
+                for l in range(self.deep_levels):
+                    for k in range(3):
+                        b = self._bands[self.tiled_levels + 1 + l][k]
+                        self._view(self._lib.pdwt_coeff_ptr(h, 1 + 3 * l + k), tuple(b.shape)).copy_(b)
+                check(self._lib.pdwt_inverse(h), "TiledWavelets.inverse (gathered levels)", self._lib)
+                full = self._view(self._lib.pdwt_image_ptr(h), (self._a_slab_shape[0] * self.world, self._a_slab_shape[1]))
+            cur = self._scatter_rows(full, self._a_slab_shape)
+        for lvl in range(self.tiled_levels, 0, -1):
             H, V, D = self._bands[lvl]
             m2, w2 = int(cur.shape[0]), int(cur.shape[1])
             h = self._plan(2 * (m2 + 2 * hq), 2 * w2)
@@ -212,16 +295,21 @@ class TiledWavelets(object):
 
     @property
     def coeffs(self):
-        """[A, [H1, V1, D1], [H2, V2, D2], ...] like Wavelets.coeffs, each the row slab of this rank."""
+        """[A, [H1, V1, D1], [H2, V2, D2], ...] like Wavelets.coeffs.  Levels 1 .. tiled_levels: the row slab of this
+        rank.  Gathered levels (and A): the WHOLE band on rank 0, None on the other ranks."""
         if self._bands is None:
             raise RuntimeError("TiledWavelets.coeffs: call forward() first")
         self._torch.cuda.synchronize(self.device)
-        return [self._bands[0].cpu().numpy()] + [[b.cpu().numpy() for b in lvl] for lvl in self._bands[1:]]
+        A = None if self._bands[0] is None else self._bands[0].cpu().numpy()
+        return [A] + [None if lvl is None else [b.cpu().numpy() for b in lvl] for lvl in self._bands[1:]]
 
     def cleanup(self):
         for h in self._plans.values():
             self._lib.pdwt_destroy(h)
         self._plans = {}
+        if getattr(self, "_deep", None):
+            self._lib.pdwt_destroy(self._deep)
+            self._deep = None
 
     def __del__(self):
         try:

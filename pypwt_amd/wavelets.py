@@ -23,6 +23,54 @@ def _ptr(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
+def _device_array(obj, dtype):
+    """(device pointer, shape) of an object that lives in GPU memory -- anything exposing
+    ``__cuda_array_interface__`` (PyTorch-ROCm tensors, CuPy-ROCm arrays, the DeviceArray views below) --
+    or None for host data.  Only C-contiguous arrays of the instance's dtype are accepted: the library copies
+    device-to-device, it does not convert."""
+    iface = getattr(obj, "__cuda_array_interface__", None)
+    if iface is None:
+        return None
+    want = np.dtype(dtype)
+    if np.dtype(iface["typestr"]) != want:
+        raise ValueError("device array has dtype %s, expected %s" % (iface["typestr"], want.str))
+    shape = tuple(int(x) for x in iface["shape"])
+    strides = iface.get("strides")
+    if strides is not None:
+        expect, acc = [], want.itemsize
+        for n in reversed(shape):
+            expect.append(acc)
+            acc *= n
+        if tuple(strides) != tuple(reversed(expect)):
+            raise ValueError("device array must be C-contiguous")
+    return int(iface["data"][0]), shape
+
+
+class _Shape(object):
+    def __init__(self, shape):
+        self.shape = tuple(shape)
+        self.ndim = len(self.shape)
+
+
+class DeviceArray(object):
+    """A borrowed, zero-copy view of a plan-owned device buffer (the image or one sub-band): exposes
+    ``__cuda_array_interface__`` (version 3, with the plan's stream), so ``torch.as_tensor(view, device="cuda")``
+    or ``cupy.asarray(view)`` wrap it without a copy.  Valid while the owning ``Wavelets`` lives
+    (reference: image_int_ptr / coeff_int_ptr hand out raw addresses, src/pypwt.pyx:578-592)."""
+
+    def __init__(self, owner, ptr, shape, dtype, stream):
+        self._owner = owner  # keeps the plan alive
+        self.ptr = int(ptr)
+        self.shape = tuple(int(x) for x in shape)
+        self.dtype = np.dtype(dtype)
+        self.__cuda_array_interface__ = {"shape": self.shape, "typestr": self.dtype.str, "data": (self.ptr, False),
+                                         "version": 3, "strides": None, "stream": int(stream) if stream else None}
+
+    @property
+    def nbytes(self):
+        return int(np.prod(self.shape)) * self.dtype.itemsize
+
+
 class Wavelets(object):
     """
     Initializes the Wavelet transform from an image and given parameters.
@@ -58,7 +106,13 @@ class Wavelets(object):
     def __init__(self, img, wname, levels, do_separable=1, do_cycle_spinning=0, do_swt=0, ndim=2, copy=None):
         self._h = None
         self._lib = _lib.load(self._variant)
-        img = self._checkarray(np.asarray(img))
+        # NEW: an image that already lives on the GPU is taken over device-to-device
+        # (pdwt_create with mem_is_on_host = 0, pdwt/src/wt.cu:117-126); `dev` = (pointer, shape) or None
+        dev = _device_array(img, self._dtype)
+        if dev is None:
+            img = self._checkarray(np.asarray(img))
+        else:
+            img = _Shape(dev[1])  # shape carrier only: nothing is copied to the host
 
         ndim = min(int(ndim), 2)  # src/pypwt.pyx:145
         self.batched1d = 0
@@ -80,8 +134,9 @@ class Wavelets(object):
         self.ndim = img.ndim
 
         h = handle_t()
-        rc = self._lib.pdwt_create(self._fptr(img), self.Nr, self.Nc, self._wname, self.levels, 1, self.do_separable,
-                                   self.do_cycle_spinning, self.do_swt, ndim, C.byref(h))
+        src = self._fptr(img) if dev is None else C.cast(C.c_void_p(dev[0]), C.POINTER(self._lib.pdwt_real))
+        rc = self._lib.pdwt_create(src, self.Nr, self.Nc, self._wname, self.levels, 1 if dev is None else 0,
+                                   self.do_separable, self.do_cycle_spinning, self.do_swt, ndim, C.byref(h))
         self._check(rc, "Wavelets()")
         self._h = h
         # read back what the library clamped (src/pypwt.pyx:181-183)
@@ -188,16 +243,25 @@ class Wavelets(object):
                                "got %d (%s)" % (res.size, numc, _lib.last_error(self._lib)))
         return res
 
-    def set_image(self, img):
-        """Replace the image (does not update the coefficients; run forward())."""
-        img = self._checkarray(np.asarray(img), (self.Nr, self.Nc))
+    def _set_image_any(self, img, shp):
+        dev = _device_array(img, self._dtype)
+        if dev is not None:  # device-to-device (pdwt_set_image with mem_is_on_device = 1, wt.cu:425-431)
+            if int(np.prod(dev[1])) != self.Nr * self.Nc:
+                raise ValueError("The image does not have the correct shape (expected %s, got %s)" % (str(shp), str(dev[1])))
+            self._check(self._lib.pdwt_set_image(self._h, C.c_void_p(dev[0]), 1))
+            return
+        img = self._checkarray(np.asarray(img), shp)
         self._check(self._lib.pdwt_set_image(self._h, _ptr(img), 0))
+
+    def set_image(self, img):
+        """Replace the image (does not update the coefficients; run forward()).  Host arrays are uploaded;
+        device arrays (``__cuda_array_interface__``) are copied device-to-device on the plan's stream."""
+        self._set_image_any(img, (self.Nr, self.Nc))
 
     def forward(self, img=None):
         """Forward wavelet transform of ``img`` if given, else of the current image."""
         if img is not None:
-            img = self._checkarray(np.asarray(img), self.shape)
-            self._check(self._lib.pdwt_set_image(self._h, _ptr(img), 0))
+            self._set_image_any(img, self.shape)
         self._check(self._lib.pdwt_forward(self._h), "forward")
 
     def inverse(self):
@@ -269,7 +333,14 @@ class Wavelets(object):
         return rc
 
     def set_coeff(self, coeff, num, check=False):
-        """Set coefficient band ``num`` (see coeff_only for the numbering)."""
+        """Set coefficient band ``num`` (see coeff_only for the numbering); host or device array."""
+        dev = _device_array(coeff, self._dtype)
+        if dev is not None:  # wt.cu:435-466 with mem_is_on_device = 1
+            n = self._check(int(self._lib.pdwt_coeff_count(self._h, int(num), None, None)))
+            if int(np.prod(dev[1])) != n:
+                raise ValueError("set_coeff: expected %d elements for coefficient %d, got %d" % (n, num, int(np.prod(dev[1]))))
+            self._check(self._lib.pdwt_set_coeff(self._h, C.c_void_p(dev[0]), int(num), 1))
+            return
         coeff = self._checkarray(np.asarray(coeff))
         if check:
             dcoeff = self.coeff_only(num)
@@ -317,6 +388,33 @@ class Wavelets(object):
     def coeff_int_ptr(self, num):
         """Address of device coefficient band ``num``."""
         return int(self._lib.pdwt_coeff_ptr(self._h, int(num)))
+
+    def _stream(self):
+        return int(self._lib.pdwt_get_stream(self._h) or 0)
+
+    @property
+    def image_device(self):
+        """NEW: zero-copy device view of the image (``__cuda_array_interface__``); see DeviceArray."""
+        return DeviceArray(self, self.image_int_ptr(), (self.Nr, self.Nc) if self.ndim == 2 or self.batched1d else (self.Nc,),
+                           self._dtype, self._stream())
+
+    def coeff_device(self, num):
+        """NEW: zero-copy device view of coefficient band ``num`` (numbering of coeff_only)."""
+        rows, cols = C.c_int(), C.c_int()
+        self._check(int(self._lib.pdwt_coeff_count(self._h, int(num), C.byref(rows), C.byref(cols))))
+        ptr = self.coeff_int_ptr(num)
+        if not ptr:
+            raise _lib.PdwtError("coeff_device(%d): %s" % (num, _lib.last_error(self._lib)))
+        return DeviceArray(self, ptr, (rows.value, cols.value), self._dtype, self._stream())
+
+    @property
+    def coeffs_device(self):
+        """NEW: the ``coeffs`` list as zero-copy device views: [A, [H1, V1, D1], ...] (2D) / [A, D1, ...] (1D)."""
+        out = [self.coeff_device(0)]
+        two_d = (self.ndim == 2) and not self.batched1d
+        for lvl in range(self.levels):
+            out.append([self.coeff_device(1 + 3 * lvl + k) for k in range(3)] if two_d else self.coeff_device(1 + lvl))
+        return out
 
     @property
     def current_shift(self):

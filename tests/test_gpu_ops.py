@@ -578,3 +578,112 @@ def test_deferred_threshold_consumed_by_the_fused_inverse_is_written_back_before
     w.inverse()
     want = oracle.inverse([newA] + thr[1:], x.shape, wname, lv, do_swt=1)
     assert np.abs(w.image - want).max() <= 2e-5 * 100
+
+
+# ----------------------------------------------------------------------------- Python-side device arrays
+class _DevBuf(object):
+    """A device buffer with ``__cuda_array_interface__`` (what a PyTorch-ROCm tensor or a CuPy array exposes),
+    made with hipMalloc so the test needs neither."""
+
+    def __init__(self, host):
+        import ctypes as C
+        self._hip = _hip()
+        self._p = C.c_void_p()
+        host = np.ascontiguousarray(host, dtype=np.float32)
+        assert self._hip.hipMalloc(C.byref(self._p), host.nbytes) == 0
+        assert self._hip.hipMemcpy(self._p, host.ctypes.data, host.nbytes, 1) == 0
+        self.__cuda_array_interface__ = {"shape": host.shape, "typestr": "<f4", "data": (self._p.value, False),
+                                         "version": 3, "strides": None}
+
+    def __del__(self):
+        self._hip.hipFree(self._p)
+
+
+def _download(view):
+    import ctypes as C
+    out = np.zeros(view.shape, dtype=np.float32)
+    assert _hip().hipMemcpy(out.ctypes.data, C.c_void_p(view.ptr), out.nbytes, 2) == 0
+    return out
+
+
+def test_python_class_takes_and_returns_device_arrays(W):
+    """SURVEY 8(f) rank 2 on the Python side (reference: image_int_ptr / coeff_int_ptr, src/pypwt.pyx:578-592):
+    Wavelets(img=<device array>), set_image / forward(img) / set_coeff with device arrays, and the zero-copy
+    views image_device / coeff_device / coeffs_device -- every result against the oracle."""
+    shape, wname, lv = (96, 80), "db3", 2
+    x, y = oracle.hash_input(shape, 81), oracle.hash_input(shape, 82)
+    dx, dy = _DevBuf(x), _DevBuf(y)
+    w = W(dx, wname, lv)
+    assert (w.Nr, w.Nc, w.ndim) == (96, 80, 2)
+    w.forward()
+    rx = oracle.forward(x, wname, lv)
+    for g, r in zip(flat_coeffs(w), rx):
+        assert np.abs(g - r).max() <= 1e-5 * max(np.abs(r).max(), 1.0)
+    w.synchronize()
+    views = w.coeffs_device
+    assert len(views) == lv + 1 and len(views[1]) == 3 and views[0].shape == rx[0].shape
+    flat_views = [views[0]] + [v for lvl in views[1:] for v in lvl]
+    for v, r in zip(flat_views, rx):
+        assert v.__cuda_array_interface__["data"][0] == v.ptr and v.shape == r.shape
+        assert np.abs(_download(v) - r).max() <= 1e-5 * max(np.abs(r).max(), 1.0)
+    w.forward(dy)  # device image handed to forward()
+    ry = oracle.forward(y, wname, lv)
+    for g, r in zip(flat_coeffs(w), ry):
+        assert np.abs(g - r).max() <= 1e-5 * max(np.abs(r).max(), 1.0)
+    # a sub-band from another plan's device memory, zero-copy
+    w2 = W(x, wname, lv)
+    w2.forward()
+    w.set_coeff(w2.coeff_device(0), 0)
+    w.inverse()
+    want = oracle.inverse([rx[0]] + ry[1:], shape, wname, lv)
+    assert np.abs(w.image - want).max() <= 2e-5 * 255
+    w.synchronize()
+    assert np.array_equal(_download(w.image_device), w.image)
+    with pytest.raises(ValueError):
+        w.set_image(_DevBuf(np.zeros((8, 8), dtype=np.float32)))
+    # 1D plan from a device vector
+    v = oracle.hash_input((1, 300), 83)
+    w1 = W(_DevBuf(v[0]), "sym4", 2, ndim=1)
+    w1.forward()
+    for g, r in zip(flat_coeffs(w1), oracle.forward(v, "sym4", 2, ndim=1)):
+        assert np.abs(g - r).max() <= 1e-5 * max(np.abs(r).max(), 1.0)
+
+
+def test_torch_tensors_in_and_out_zero_copy():
+    """The same through PyTorch-ROCm when it is importable (a child process: torch must be imported first so that
+    the library shares torch's HIP runtime)."""
+    import subprocess
+    import sys
+    code = r"""
+import sys
+try:
+    import torch
+    assert torch.cuda.is_available()
+except Exception as e:
+    print("SKIP", e); sys.exit(0)
+import numpy as np
+from oracle import oracle
+from pypwt_amd import Wavelets
+x = oracle.hash_input((64, 128), 91)
+t = torch.from_numpy(x).cuda()
+w = Wavelets(t, "db2", 2)
+w.forward(); w.synchronize()
+ref = oracle.forward(x, "db2", 2)
+a = torch.as_tensor(w.coeff_device(0), device="cuda")
+assert a.data_ptr() == w.coeff_int_ptr(0)          # zero copy
+assert np.abs(a.cpu().numpy() - ref[0]).max() <= 1e-5 * np.abs(ref[0]).max()
+h1 = torch.as_tensor(w.coeffs_device[1][0], device="cuda")
+assert np.abs(h1.cpu().numpy() - ref[1]).max() <= 1e-5 * max(np.abs(ref[1]).max(), 1.0)
+w.set_coeff(2 * a, 0)                                # a torch expression as the new approximation band
+w.inverse(); w.synchronize()
+ref[0] = 2 * ref[0]
+want = oracle.inverse(ref, x.shape, "db2", 2)
+img = torch.as_tensor(w.image_device, device="cuda")
+assert np.abs(img.cpu().numpy() - want).max() <= 2e-5 * 255 * 2
+print("TORCH_OK")
+"""
+    import os
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "TORCH_OK" in r.stdout or "SKIP" in r.stdout, r.stdout

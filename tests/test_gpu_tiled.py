@@ -1,5 +1,6 @@
 """A single image split in row slabs over several ranks (pypwt_amd/tiled.py): the slabs of every
-sub-band and of the reconstruction must equal those of the single-GPU transform of the whole image.
+sub-band and of the reconstruction must equal those of the CPU oracle's transform of the whole image;
+levels whose slabs would be thinner than the halo are gathered on rank 0 and compared whole.
 The GPU box has ONE GPU: the ranks share it and exchange their halos through gloo (staged on the host);
 with the nccl backend (RCCL) the same code path uses grouped device-to-device send/recv."""
 import os
@@ -59,6 +60,15 @@ def test_single_rank_ring_equals_plain_transform(wname, levels, shape):
 @pytest.mark.parametrize("world,wname,levels,shape", [(2, "db4", 3, (256, 128)), (3, "sym4", 2, (192, 64)),
                                                       (4, "haar", 2, (64, 64)), (2, "db8", 2, (256, 96))])
 def test_row_slabs_over_ranks_with_halo_exchange(world, wname, levels, shape):
+    _run_ranks(world, wname, levels, shape)
+
+
+@pytest.mark.parametrize("world,wname,levels,shape", [(2, "db2", 4, (80, 64)), (4, "haar", 4, (96, 64)),
+                                                      (3, "db3", 4, (120, 96)), (1, "db2", 4, (40, 64)),
+                                                      (2, "db2", 5, (160, 128))])
+def test_deep_levels_are_gathered_on_rank0(world, wname, levels, shape):
+    """more levels than the slabs support: the remaining approximation is gathered (one all-gather), finished on
+    rank 0, and handed back by the inverse (one broadcast)"""
     _run_ranks(world, wname, levels, shape)
 
 

@@ -1,7 +1,7 @@
 """Worker of tests/test_gpu_tiled.py: one rank of a TiledWavelets run (launched as a child process with
-RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set).  Every rank also computes the transform of the WHOLE
-image with the single-GPU `Wavelets` class and compares its own row slab of every sub-band and of the
-reconstruction; prints 'OK <rank>' on success."""
+RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set).  Every rank computes the transform of the WHOLE image
+with the CPU ORACLE and compares its own row slab of every sub-band (the whole band for the levels that
+were gathered on rank 0) and of the reconstruction; prints 'OK <rank> tiled=<t> deep=<d>' on success."""
 import os
 import sys
 
@@ -15,7 +15,6 @@ def main():
     import torch
     import torch.distributed as dist
     from oracle import oracle
-    from pypwt_amd import Wavelets
     from pypwt_amd.tiled import TiledWavelets
 
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
@@ -29,20 +28,31 @@ def main():
     n = Nr // world
     tw = TiledWavelets(x[rank * n:(rank + 1) * n], wname, levels)
     tw.forward()
-    full = Wavelets(x, wname, levels)
-    full.forward()
-    ref = full.coeffs
+    flat = oracle.forward(x, wname, levels)  # [A, H1, V1, D1, H2, ...] from the CPU oracle
+    ref = [flat[0]] + [flat[1 + 3 * l:4 + 3 * l] for l in range(levels)]
     got = tw.coeffs
+    assert tw.tiled_levels + tw.deep_levels == levels and tw.tiled_levels >= 1
 
     def slab(a):
         k = a.shape[0] // world
         return a[rank * k:(rank + 1) * k]
 
     tol = 2e-6 * (levels + 1) * 255 * 4 ** levels
-    assert np.abs(got[0] - slab(ref[0])).max() <= tol, "A"
     for lvl in range(1, levels + 1):
-        for g, r in zip(got[lvl], ref[lvl]):
-            assert g.shape == slab(r).shape and np.abs(g - slab(r)).max() <= tol, ("level", lvl)
+        if lvl <= tw.tiled_levels:
+            for g, r in zip(got[lvl], ref[lvl]):
+                assert g.shape == slab(r).shape and np.abs(g - slab(r)).max() <= tol, ("level", lvl)
+        elif rank == 0:  # gathered levels: the whole band lives on rank 0
+            for g, r in zip(got[lvl], ref[lvl]):
+                assert g.shape == r.shape and np.abs(g - r).max() <= tol, ("gathered level", lvl)
+        else:
+            assert got[lvl] is None
+    if tw.deep_levels == 0:
+        assert np.abs(got[0] - slab(ref[0])).max() <= tol, "A"
+    elif rank == 0:
+        assert got[0].shape == ref[0].shape and np.abs(got[0] - ref[0]).max() <= tol, "A (gathered)"
+    else:
+        assert got[0] is None
     tw.inverse()
     assert np.abs(tw.image - x[rank * n:(rank + 1) * n]).max() <= 2e-3, "reconstruction"
     tw.forward()
@@ -51,7 +61,7 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    print("OK %d" % rank)
+    print("OK %d tiled=%d deep=%d" % (rank, tw.tiled_levels, tw.deep_levels))
 
 
 if __name__ == "__main__":
