@@ -1,5 +1,6 @@
 // launch_dwt1_fused.hip -- launchers of the multi-level fused 1D DWT kernels (gfx950).
 #include "dwt1_fused_kernels.hpp"
+#include "dwt1_wave_kernels.hpp"
 #include "launch.hpp"
 #include "launch_util.hpp"
 
@@ -63,6 +64,49 @@ hipError_t launch_dwt1_fwd_fused(const float* in, float* const* det, float* app,
     // 55 KB of LDS leaves 2 workgroups per CU)
     switch (hlen) {
 #define X(h) case h: return run_fwd<h, 64>(a, s);
+        PDWT_EVEN_HLENS(X)
+#undef X
+    }
+    return hipErrorNotSupported;
+}
+
+// ---- one wavefront per segment (dwt1_wave_kernels.hpp): K >= 1 levels, 128 * 2^K | N0
+bool dwt1_wave_supported(int hlen, int N0, int K) {
+    return !(hlen & 1) && hlen >= 2 && hlen <= kMaxTaps && K >= 1 && K <= kWave1MaxLevels && N0 >= (128 << K) &&
+           (N0 % (128 << K)) == 0 && N0 < (1 << 30);
+}
+
+template <int HLEN>
+static hipError_t run_fwd_wave(Fwd1DWaveArgs& a, hipStream_t s) {
+    constexpr int NT = 64;  // one wavefront per workgroup: 14 KB of LDS rings each (K = 6) -> 11 wavefronts per CU
+    // level-K passes per wavefront: about 2048 wavefronts per launch; each wavefront recomputes ~2 passes per level
+    // and side, so longer segments waste less
+    const long long passesK = (long long)(a.N0 >> a.K) / 128;
+    int unitK = 1;
+    while (unitK < 4 && passesK % (2 * unitK) == 0 && passesK / (2 * unitK) * a.rows >= 2048) unitK *= 2;
+    a.unitK = unitK;
+    a.units = (int)(passesK / unitK);
+    a.nsched = dwt1_wave_build_schedule(a.K, HLEN, unitK, a.sched, kWave1MaxSched);
+    if (a.nsched < 0) return hipErrorNotSupported;
+    const size_t lds = (size_t)(NT / 64) * dwt1_wave_lds_floats(a.K) * sizeof(float);
+    static std::atomic<bool> big[64] = {};
+    hipError_t e = allow_big_lds(dwt1_fwd_wave_kernel<HLEN, NT>, lds, big);
+    if (e != hipSuccess) return e;
+    const long long total = (long long)a.rows * a.units;
+    hipLaunchKernelGGL((dwt1_fwd_wave_kernel<HLEN, NT>), dim3((unsigned)cdivll(total, NT / 64)), dim3(NT), lds, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_dwt1_fwd_wave(const float* in, float* const* det, float* app, int rows, int N0, int K, int hlen,
+                                const FilterBank& fb, hipStream_t s) {
+    if (!dwt1_wave_supported(hlen, N0, K)) return hipErrorNotSupported;
+    if ((reinterpret_cast<uintptr_t>(in) & 15) || (reinterpret_cast<uintptr_t>(app) & 7)) return hipErrorNotSupported;
+    Fwd1DWaveArgs a;
+    a.in = in; a.app = app; a.rows = rows; a.N0 = N0; a.K = K;
+    for (int k = 0; k < kMaxFusedLevels; k++) a.det[k] = k < K ? det[k] : nullptr;
+    interleave(a.fb, fb);
+    switch (hlen) {
+#define X(h) case h: return run_fwd_wave<h>(a, s);
         PDWT_EVEN_HLENS(X)
 #undef X
     }

@@ -57,6 +57,10 @@ hipError_t launch_dwt2_inv_pyr2(const real_t* const[4], const real_t* const[3], 
                                 const FilterBank&, int, hipStream_t) { return hipErrorNotSupported; }
 int dwt1_fused_max_levels(int) { return 1; }
 bool dwt1_fused_supported(int, int, int) { return false; }
+bool dwt1_wave_supported(int, int, int) { return false; }
+hipError_t launch_dwt1_fwd_wave(const real_t*, real_t* const*, real_t*, int, int, int, int, const FilterBank&, hipStream_t) {
+    return hipErrorNotSupported;
+}
 hipError_t launch_dwt1_fwd_fused(const real_t*, real_t* const*, real_t*, int, int, int, int, const FilterBank&,
                                  hipStream_t) { return hipErrorNotSupported; }
 hipError_t launch_dwt1_inv_fused(const real_t*, const real_t* const*, real_t*, int, int, int, int, const FilterBank&,
@@ -84,6 +88,12 @@ static std::atomic<int>& wave2_flag() {
     static std::atomic<int> v{getenv("PDWT_WAVE2") ? 1 : 0};
     return v;
 }
+static std::atomic<int>& wave1d_flag() {
+    static std::atomic<int> v{getenv("PDWT_WAVE1D") ? 1 : 0};
+    return v;
+}
+int set_wave1d_enabled(int value) { return wave1d_flag().exchange(value ? 1 : 0); }
+int get_wave1d_enabled() { return wave1d_flag().load(std::memory_order_relaxed); }
 int set_wave2_enabled(int value) { return wave2_flag().exchange(value ? 1 : 0); }
 int get_wave2_enabled() { return wave2_flag().load(std::memory_order_relaxed); }
 static bool wave_kernels_for(long long samples) {
@@ -114,7 +124,11 @@ hipError_t launch_dwt2_fwd(const Fwd2DArgs& a, int batch, hipStream_t s) {
 }
 
 hipError_t launch_dwt2_inv(const Inv2DArgs& a, int batch, hipStream_t s) {
-    if (wave_kernels_for((long long)batch * a.Nr * a.Nc)) {
+    // inverse: the wave kernel wins while the working set sits in the 256 MiB Infinity Cache (4096^2: 22.5 vs
+    // 23.6 us) and loses slightly to the LDS tiles on a batch streamed from HBM (8 x 4096^2: 224-232 vs 219 us,
+    // profiles/r02b_wbench_b8.txt): 2^26 samples and beyond go to the tiles
+    const long long samples = (long long)batch * a.Nr * a.Nc;
+    if (wave_kernels_for(samples) && samples < (1LL << 26)) {
         const hipError_t e = try_launch_dwt2_inv_wave(a, batch, s);
         if (e != hipErrorNotSupported) return e;
     }

@@ -586,8 +586,14 @@ int forward_impl(pdwt_plan* p, int only = 0) {
             for (int k = 0; k < s.K; k++) det[k] = p->band(l + k);
             Stamp st(p, "dwt1_fwd_fused");
             if (!run) continue;
-            e = launch_dwt1_fwd_fused(approx_slot(p, l - 1), det, approx_slot(p, l + s.K - 1), B * p->info.Nr, p->lc[l - 1], s.K,
-                                      hlen, p->dec, p->stream);
+            // opt-in: one wavefront per segment (dwt1_wave_kernels.hpp) where whole passes fit; default and
+            // fallback: the workgroup-wide kernel
+            e = get_wave1d_enabled() ? launch_dwt1_fwd_wave(approx_slot(p, l - 1), det, approx_slot(p, l + s.K - 1),
+                                                            B * p->info.Nr, p->lc[l - 1], s.K, hlen, p->dec, p->stream)
+                                     : hipErrorNotSupported;
+            if (e == hipErrorNotSupported)
+                e = launch_dwt1_fwd_fused(approx_slot(p, l - 1), det, approx_slot(p, l + s.K - 1), B * p->info.Nr,
+                                          p->lc[l - 1], s.K, hlen, p->dec, p->stream);
         }
         if (e == hipSuccess) continue;
         if (e != hipErrorNotSupported) HIP_TRY(e);
@@ -1299,6 +1305,7 @@ int pdwt_time_level(pdwt_handle h, int level, int inverse, int reps, float* ms_p
 int pdwt_set_tuning(const char* key, int value) {
     if (key && !strcmp(key, "wave_min_log2")) return set_wave_min_log2(value);
     if (key && !strcmp(key, "wave2")) return set_wave2_enabled(value);
+    if (key && !strcmp(key, "wave1d")) return set_wave1d_enabled(value);
     return fail(PDWT_ERR_ARG, "pdwt_set_tuning: unknown key %s", key ? key : "(null)");
 }
 

@@ -252,6 +252,9 @@ PDWT_DEVICE void swt2_fwd_vec_tile(const Swt2DArgs& a, int bx, int by, int bz, r
     const real_t* PDWT_RESTRICT in = a.in + (long long)bz * a.bstride;
     const real_t zero = 0;
 
+    // tiles whose dilated taps stay inside the row (all but the first / last of a row) skip the periodic-wrap
+    // arithmetic of every load: a tile-uniform branch (it was a third of the kernel's vector instructions)
+    const bool interior = bx * TX - c * f >= 0 && bx * TX + TX + (HLEN - 1 - c) * f <= a.Nc;
     PDWT_FOR_THREADS(tid, NT) {
         const int k4 = tid % QX, x0 = bx * TX + 4 * k4;
         for (int r = tid / QX; r < RY; r += NG) {
@@ -261,7 +264,7 @@ PDWT_DEVICE void swt2_fwd_vec_tile(const Swt2DArgs& a, int bx, int by, int bz, r
                 const real_t* row = in + (long long)(ph + f * i) * a.Nc;
 #pragma unroll
                 for (int j = 0; j < HLEN; ++j) {
-                    const rv4 v = load4_periodic(row, x0 + (j - c) * f, a.Nc);
+                    const rv4 v = interior ? load4u(row + x0 + (j - c) * f) : load4_periodic(row, x0 + (j - c) * f, a.Nc);
                     fma4(aL, v, a.fb.lo[HLEN - 1 - j]);
                     fma4(aH, v, a.fb.hi[HLEN - 1 - j]);
                 }
@@ -313,6 +316,7 @@ PDWT_DEVICE void swt2_inv_vec_tile(const Swt2DArgs& a, int bx, int by, int bz, r
 
     // dilated row synthesis from global: u1 = Lx(A) + Hx(V), u2 = Lx(H) + Hx(D) (pending soft threshold
     // applied to the detail bands as they are loaded, never to A)
+    const bool interior = bx * TX - c * f >= 0 && bx * TX + TX + (HLEN - 1 - c) * f <= a.Nc;  // see the forward tile
     PDWT_FOR_THREADS(tid, NT) {
         const int k4 = tid % QX, x0 = bx * TX + 4 * k4;
         for (int r = tid / QX; r < RY; r += NG) {
@@ -320,14 +324,26 @@ PDWT_DEVICE void swt2_inv_vec_tile(const Swt2DArgs& a, int bx, int by, int bz, r
             if (x0 < a.Nc) {
                 const int i = wrap_periodic(it * TY - c + r, M);
                 const long long ro = boff + (long long)(ph + f * i) * a.Nc;
+                if (interior) {
 #pragma unroll
-                for (int j = 0; j < HLEN; ++j) {
-                    const int p = x0 + (j - c) * f;
-                    const real_t tl = a.fb.lo[HLEN - 1 - j], th = a.fb.hi[HLEN - 1 - j];
-                    fma4(r1, load4_periodic(a.A + ro, p, a.Nc), tl);
-                    fma4(r1, soft4(load4_periodic(a.V + ro, p, a.Nc), a.soft_beta), th);
-                    fma4(r2, soft4(load4_periodic(a.H + ro, p, a.Nc), a.soft_beta), tl);
-                    fma4(r2, soft4(load4_periodic(a.D + ro, p, a.Nc), a.soft_beta), th);
+                    for (int j = 0; j < HLEN; ++j) {
+                        const long long o = ro + x0 + (j - c) * f;
+                        const real_t tl = a.fb.lo[HLEN - 1 - j], th = a.fb.hi[HLEN - 1 - j];
+                        fma4(r1, load4u(a.A + o), tl);
+                        fma4(r1, soft4(load4u(a.V + o), a.soft_beta), th);
+                        fma4(r2, soft4(load4u(a.H + o), a.soft_beta), tl);
+                        fma4(r2, soft4(load4u(a.D + o), a.soft_beta), th);
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < HLEN; ++j) {
+                        const int p = x0 + (j - c) * f;
+                        const real_t tl = a.fb.lo[HLEN - 1 - j], th = a.fb.hi[HLEN - 1 - j];
+                        fma4(r1, load4_periodic(a.A + ro, p, a.Nc), tl);
+                        fma4(r1, soft4(load4_periodic(a.V + ro, p, a.Nc), a.soft_beta), th);
+                        fma4(r2, soft4(load4_periodic(a.H + ro, p, a.Nc), a.soft_beta), tl);
+                        fma4(r2, soft4(load4_periodic(a.D + ro, p, a.Nc), a.soft_beta), th);
+                    }
                 }
             }
             r1.x *= half; r1.y *= half; r1.z *= half; r1.w *= half;

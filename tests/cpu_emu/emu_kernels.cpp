@@ -9,6 +9,7 @@
 
 #include "../../pypwt_amd/csrc/dwt1_fused_kernels.hpp"
 #include "../../pypwt_amd/csrc/dwt1_kernels.hpp"
+#include "../../pypwt_amd/csrc/dwt1_wave_kernels.hpp"
 #include "../../pypwt_amd/csrc/dwt2_fast_kernels.hpp"
 #include "../../pypwt_amd/csrc/dwt2_kernels.hpp"
 #include "../../pypwt_amd/csrc/dwt2_pyramid_kernels.hpp"
@@ -593,5 +594,32 @@ EMU_API int emu_dwt2_fwd2_wave(const float* in, int batch, int N0r, int N0c, con
                 case 6: dwt2_fwd2_wave<6>(a, strip, seg, bz); break;
                 case 8: dwt2_fwd2_wave<8>(a, strip, seg, bz); break;
             }
+    return 0;
+}
+
+// ------------------------------------------------------------------ 1D, all levels per wavefront
+EMU_API int emu_dwt1_fwd_wave(const float* in, int rows, int N0, int K, const float* lo, const float* hi, int hlen,
+                              int unitK, float* det, float* app) {
+    if ((hlen & 1) || K < 1 || K > kWave1MaxLevels || (N0 % (128 << K)) || ((N0 >> K) / 128) % unitK) return -2;
+    Fwd1DWaveArgs a;
+    a.nsched = dwt1_wave_build_schedule(K, hlen, unitK, a.sched, kWave1MaxSched);
+    if (a.nsched < 0) return -3;
+    a.in = in; a.app = app; a.rows = rows; a.N0 = N0; a.K = K; a.unitK = unitK;
+    a.units = (N0 >> K) / 128 / unitK;
+    size_t off = 0;
+    for (int k = 0; k < kMaxFusedLevels; k++) a.det[k] = nullptr;
+    for (int k = 1; k <= K; k++) { a.det[k - 1] = det + off; off += (size_t)rows * (N0 >> k); }
+    set_bank_i(a.fb, lo, hi, hlen);
+    std::vector<float> lds(dwt1_wave_lds_floats(K), NAN);
+    for (int row = 0; row < rows; row++)
+        for (int unit = 0; unit < a.units; unit++) {
+            std::fill(lds.begin(), lds.end(), NAN);
+            switch (hlen) {
+#define X(h) case h: dwt1_fwd_wave<h>(a, row, unit, lds.data()); break;
+                EMU_EVEN_HLENS(X)
+#undef X
+                default: return -1;
+            }
+        }
     return 0;
 }

@@ -497,3 +497,26 @@ def test_emu_dwt2_wave_two_levels_forward(wname):
                 assert np.abs(det1[k, b] - l1[1 + k]).max() <= _tol(l1[1 + k]), (wname, nr, nc, "det1", k)
             for k in range(4):
                 assert np.abs(band2[k, b] - l2[k]).max() <= 2 * _tol(l2[k]), (wname, nr, nc, "band2", k)
+
+
+@pytest.mark.parametrize("wname", ["haar", "db2", "db4", "sym8", "coif2", "db10", "db20", "bior3.1"])
+def test_emu_dwt1_wave_cascade_forward(wname):
+    """dwt1_fwd_wave: all K levels by one wavefront per segment (LDS rings, a pass = 128 outputs), vs the oracle"""
+    hlen, dlo, dhi, rlo, rhi = oracle.filters(wname)
+    for si, (rows, N0, K, unitK) in enumerate([(1, 1024, 2, 1), (2, 2048, 3, 1), (1, 8192, 6, 1), (1, 16384, 6, 2),
+                                                (3, 4096, 4, 2), (1, 256, 1, 1), (1, 4096, 5, 1)]):
+        x = oracle.hash_input((rows, N0), 7300 + si)
+        ref = oracle.forward(x, wname, K, ndim=1, filt=(hlen, dlo, dhi, rlo, rhi))  # [A_K, D_1, ..., D_K]
+        ndet = sum(rows * (N0 >> k) for k in range(1, K + 1))
+        det = np.full(ndet, np.nan, dtype=np.float32)
+        app = np.full((rows, N0 >> K), np.nan, dtype=np.float32)
+        assert lib().emu_dwt1_fwd_wave(P(x), rows, N0, K, P(dlo), P(dhi), hlen, unitK, P(det), P(app)) == 0
+        assert np.isfinite(app).all(), (wname, N0, K)
+        assert np.abs(app - ref[0]).max() <= _tol(ref[0]) * (1 + K), (wname, rows, N0, K)
+        off = 0
+        for k in range(1, K + 1):
+            n = rows * (N0 >> k)
+            got = det[off:off + n].reshape(rows, N0 >> k)
+            off += n
+            assert np.isfinite(got).all(), (wname, N0, K, k)
+            assert np.abs(got - ref[k]).max() <= _tol(ref[k]) * (1 + K), (wname, rows, N0, K, k)
