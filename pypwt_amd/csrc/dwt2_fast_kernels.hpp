@@ -520,95 +520,6 @@ PDWT_DEVICE void dwt2_inv_fast_tile(const Inv2DFastArgs& a, int bx, int by, int 
     PDWT_FOR_THREADS(tid, NT) { inv_fast_row_pass<HLEN, TX, TY, NT>(tid, tt, a, bx, by, bz); }
 }
 
-// Streaming variant (see dwt2_fwd_fast_stream): the four coefficient float4 of the NEXT tile are in
-// flight while the current tile is synthesised.
-template <int HLEN, int TX, int TY, int NT>
-PDWT_DEVICE void dwt2_inv_fast_stream(const Inv2DFastArgs& a, int wg, int nwg, int batch, float* smem) {
-    using G = InvFastGeom<HLEN, TX>;
-    constexpr int H2 = G::H2, C = G::C, PADL = G::PADL, CXA = G::CXA;
-    constexpr int CR = TY + H2 + 1;
-    constexpr int V4 = CXA / 4;
-    constexpr int NLD = (CR * V4 + NT - 1) / NT;
-
-    v2f* sAV = reinterpret_cast<v2f*>(smem);
-    v2f* sHD = sAV + CR * CXA;
-    v2f* tt = sHD + CR * CXA;
-
-    const int total = a.tiles_x * a.tiles_y;
-    const int chunk = (total + 7) >> 3;
-    const int xcd = wg & 7;
-    const int stride = nwg >> 3;
-    const int limit = batch * chunk;
-
-    PDWT_PER_THREAD(v4f, stA, NLD, NT);
-    PDWT_PER_THREAD(v4f, stV, NLD, NT);
-    PDWT_PER_THREAD(v4f, stH, NLD, NT);
-    PDWT_PER_THREAD(v4f, stD, NLD, NT);
-
-    int q = wg >> 3;
-    int bx = 0, by = 0, bz = 0;
-    while (q < limit && !stream_pos(q, xcd, chunk, total, batch, a.tiles_x, bx, by, bz)) q += stride;
-    bool have = q < limit;
-    if (have) {
-        PDWT_FOR_THREADS(tid, NT) {
-            const long long boff = (long long)bz * a.in_bstride;
-            const int cy0 = by * TY - C, cxa = bx * TX - C - PADL;
-#pragma unroll
-            for (int i = 0; i < NLD; ++i) {
-                const int idx = (tid + i * NT < CR * V4) ? tid + i * NT : CR * V4 - 1;
-                const int r = idx / V4, g = idx - r * V4;
-                const long long o = boff + (long long)wrap_periodic(cy0 + r, a.Nrc) * a.Ncc +
-                                    wrap_periodic(cxa + 4 * g, a.Ncc);
-                PDWT_MINE(stA, tid)[i] = *reinterpret_cast<const v4f*>(a.A + o);
-                PDWT_MINE(stV, tid)[i] = *reinterpret_cast<const v4f*>(a.V + o);
-                PDWT_MINE(stH, tid)[i] = *reinterpret_cast<const v4f*>(a.H + o);
-                PDWT_MINE(stD, tid)[i] = *reinterpret_cast<const v4f*>(a.D + o);
-            }
-        }
-    }
-    while (have) {
-        PDWT_FOR_THREADS(tid, NT) {
-#pragma unroll
-            for (int i = 0; i < NLD; ++i) {
-                const int idx = tid + i * NT;
-                if (idx < CR * V4)
-                    inv_fast_interleave(sAV, sHD, 4 * idx, PDWT_MINE(stA, tid)[i], PDWT_MINE(stV, tid)[i],
-                                        PDWT_MINE(stH, tid)[i], PDWT_MINE(stD, tid)[i]);
-            }
-        }
-        PDWT_SYNC();
-        int qn = q + stride;
-        int nbx = 0, nby = 0, nbz = 0;
-        while (qn < limit && !stream_pos(qn, xcd, chunk, total, batch, a.tiles_x, nbx, nby, nbz)) qn += stride;
-        const bool have_next = qn < limit;
-        if (have_next) {
-            PDWT_FOR_THREADS(tid, NT) {
-                const long long boff = (long long)nbz * a.in_bstride;
-                const int cy0 = nby * TY - C, cxa = nbx * TX - C - PADL;
-#pragma unroll
-                for (int i = 0; i < NLD; ++i) {
-                    const int idx = (tid + i * NT < CR * V4) ? tid + i * NT : CR * V4 - 1;
-                    const int r = idx / V4, g = idx - r * V4;
-                    const long long o = boff + (long long)wrap_periodic(cy0 + r, a.Nrc) * a.Ncc +
-                                        wrap_periodic(cxa + 4 * g, a.Ncc);
-                    PDWT_MINE(stA, tid)[i] = *reinterpret_cast<const v4f*>(a.A + o);
-                    PDWT_MINE(stV, tid)[i] = *reinterpret_cast<const v4f*>(a.V + o);
-                    PDWT_MINE(stH, tid)[i] = *reinterpret_cast<const v4f*>(a.H + o);
-                    PDWT_MINE(stD, tid)[i] = *reinterpret_cast<const v4f*>(a.D + o);
-                }
-            }
-        }
-        PDWT_FOR_THREADS(tid, NT) { inv_fast_col_pass<HLEN, TX, TY, NT>(tid, sAV, sHD, tt, a.fb); }
-        PDWT_SYNC();
-        PDWT_FOR_THREADS(tid, NT) { inv_fast_row_pass<HLEN, TX, TY, NT>(tid, tt, a, bx, by, bz); }
-        bx = nbx;
-        by = nby;
-        bz = nbz;
-        q = qn;
-        have = have_next;
-    }
-}
-
 #ifndef PDWT_CPU_EMU
 template <int HLEN, int TX, int TY, int NT>
 __global__ void __launch_bounds__(NT) dwt2_fwd_fast_kernel(const Fwd2DFastArgs a) {
@@ -622,12 +533,6 @@ template <int HLEN, int TX, int TY, int NT>
 __global__ void __launch_bounds__(NT) dwt2_fwd_fast_stream_kernel(const Fwd2DFastArgs a, int batch) {
     extern __shared__ __attribute__((aligned(16))) float pdwt_smem[];
     dwt2_fwd_fast_stream<HLEN, TX, TY, NT>(a, blockIdx.x, gridDim.x, batch, pdwt_smem);
-}
-
-template <int HLEN, int TX, int TY, int NT>
-__global__ void __launch_bounds__(NT) dwt2_inv_fast_stream_kernel(const Inv2DFastArgs a, int batch) {
-    extern __shared__ __attribute__((aligned(16))) float pdwt_smem[];
-    dwt2_inv_fast_stream<HLEN, TX, TY, NT>(a, blockIdx.x, gridDim.x, batch, pdwt_smem);
 }
 
 template <int HLEN, int TX, int TY, int NT>

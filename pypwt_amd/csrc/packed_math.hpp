@@ -32,17 +32,11 @@ static PDWT_DEVICE v2f bc(float a) { return mk2(a, a); }
 // run at half the LDS rate (MI355X_MICROARCH.md, LDS table).
 #ifdef PDWT_CPU_EMU
 typedef f32x4 v4f;
-static inline v4f lds_read16(const void* p) { return *reinterpret_cast<const v4f*>(p); }
 static inline v4f lds_load16(const void* p) { return *reinterpret_cast<const v4f*>(p); }
 static inline void lds_pin(v4f&) {}
 #else
 typedef float v4f __attribute__((ext_vector_type(4)));
-static __device__ __forceinline__ v4f lds_read16(const void* p) {
-    v4f w = *reinterpret_cast<const v4f*>(p);
-    asm volatile("" : "+v"(w));
-    return w;
-}
-// The barrier in lds_read16 also makes the wave WAIT for that load before issuing the next one.
+// An empty asm barrier right after the load would also make the wave WAIT for it before issuing the next one.
 // Where several loads feed one computation, issue them all with lds_load16 and pin them afterwards
 // (LDS returns in order, so the compiler waits with a counting s_waitcnt and the loads pipeline).
 static __device__ __forceinline__ v4f lds_load16(const void* p) { return *reinterpret_cast<const v4f*>(p); }

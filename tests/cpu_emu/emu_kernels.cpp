@@ -282,29 +282,6 @@ EMU_API int emu_dwt2_fwd_fast(const float* in, int batch, int Nr, int Nc, const 
     return -1;
 }
 
-template <int HLEN, int TX, int TY, int NT>
-static void run_inv2d_stream(Inv2DFastArgs a, int batch, int nwg) {
-    std::vector<float> smem(inv2d_fast_lds_floats<HLEN, TX, TY>() + 64, -12345.f);
-    a.tiles_x = cdiv(a.Nc, 2 * TX); a.tiles_y = cdiv(a.Nr, 2 * TY);
-    for (int wg = 0; wg < nwg; wg++) dwt2_inv_fast_stream<HLEN, TX, TY, NT>(a, wg, nwg, batch, smem.data());
-}
-
-EMU_API int emu_dwt2_inv_stream(const float* A, const float* H, const float* V, const float* D, int batch, int Nrc,
-                                int Ncc, int Nr, int Nc, const float* lo, const float* hi, int hlen, int nwg, float* out) {
-    if ((hlen & 1) || (Ncc & 3) || Nc != 2 * Ncc || (nwg & 7)) return -2;
-    Inv2DFastArgs a;
-    a.A = A; a.H = H; a.V = V; a.D = D; a.out = out;
-    a.Nrc = Nrc; a.Ncc = Ncc; a.Nr = Nr; a.Nc = Nc;
-    a.in_bstride = (long long)Nrc * Ncc; a.out_bstride = (long long)Nr * Nc;
-    set_bank_i(a.fb, lo, hi, hlen);
-    switch (hlen) {
-#define X(h) case h: run_inv2d_stream<h, 64, 8, 256>(a, batch, nwg); return 0;
-        EMU_EVEN_HLENS(X)
-#undef X
-    }
-    return -1;
-}
-
 EMU_API int emu_dwt2_inv_fast(const float* A, const float* H, const float* V, const float* D, int batch, int Nrc,
                               int Ncc, int Nr, int Nc, const float* lo, const float* hi, int hlen, int tile, float* out) {
     if ((hlen & 1) || (Ncc & 3) || Nc != 2 * Ncc) return -2;

@@ -267,23 +267,8 @@ def test_emu_dwt2_fwd_stream(wname):
                 assert np.abs(got - want).max() <= _tol(want), (wname, shape, nwg)
 
 
-@pytest.mark.parametrize("wname", ["haar", "db2", "db4", "sym8", "db20"])
-def test_emu_dwt2_inv_stream(wname):
-    hlen, dlo, dhi, rlo, rhi = oracle.filters(wname)
-    for si, shape in enumerate([(64, 64), (61, 72), (200, 264), (6, 8), (300, 136)]):
-        r2, c2 = (shape[0] + 1) // 2, shape[1] // 2
-        bands = [oracle.hash_input((r2, c2), 6900 + 7 * si + b, 2.0) - 1.0 for b in range(4)]
-        ref = oracle.inverse(bands, shape, wname, 1, ndim=2)
-        for nwg in (8, 16, 64, 1024):
-            out = np.full(shape, np.nan, dtype=np.float32)
-            assert lib().emu_dwt2_inv_stream(*[P(b) for b in bands], 1, r2, c2, shape[0], shape[1], P(rlo), P(rhi),
-                                             hlen, nwg, P(out)) == 0
-            assert np.isfinite(out).all(), (wname, shape, nwg)
-            assert np.abs(out - ref).max() <= _tol(ref), (wname, shape, nwg)
-
-
 def test_emu_dwt2_stream_batch():
-    """The streaming kernels walk over (image, tile) pairs: every image of a batch must come out right
+    """The streaming forward kernel walks over (image, tile) pairs: every image of a batch must come out right
     for any workgroup count."""
     hlen, dlo, dhi, rlo, rhi = oracle.filters("db4")
     B, shape = 3, (48, 136)
@@ -294,10 +279,6 @@ def test_emu_dwt2_stream_batch():
         for b in range(B):
             for got, want in zip(outs, oracle.forward(x[b], "db4", 1, ndim=2)):
                 assert np.abs(got[b] - want).max() <= _tol(want), (nwg, b)
-        rec = np.full((B,) + shape, np.nan, dtype=np.float32)
-        assert lib().emu_dwt2_inv_stream(*[P(o) for o in outs], B, 24, 68, shape[0], shape[1], P(rlo), P(rhi), hlen,
-                                         nwg, P(rec)) == 0
-        assert np.abs(rec - x).max() < 1e-3, nwg
 
 
 # ----------------------------------------------------------------------------- fused multi-level 1D

@@ -155,27 +155,6 @@ static void bench_fwd_stream(const char* tag, const float* in, float* out4, int 
 }
 
 template <int HLEN, int TX, int TY, int NT>
-static void bench_inv_stream(const char* tag, const float* in4, float* out, int N, int batch, int wg_per_cu) {
-    if (skip(tag)) return;
-    Inv2DFastArgs a;
-    const long long q = (long long)batch * (N / 2) * (N / 2);
-    a.A = in4; a.H = in4 + q; a.V = in4 + 2 * q; a.D = in4 + 3 * q; a.out = out;
-    a.Nrc = N / 2; a.Ncc = N / 2; a.Nr = N; a.Nc = N;
-    a.in_bstride = (long long)(N / 2) * (N / 2); a.out_bstride = (long long)N * N;
-    a.tiles_x = (N + 2 * TX - 1) / (2 * TX); a.tiles_y = (N + 2 * TY - 1) / (2 * TY);
-    memset(&a.fb, 0, sizeof(a.fb));
-    for (int i = 0; i < 8; i++) { a.fb.t[i].x = DB4_LO[7 - i]; a.fb.t[i].y = DB4_HI[7 - i]; }
-    const size_t lds = (size_t)inv2d_fast_lds_floats<HLEN, TX, TY>() * sizeof(float);
-    const int chunk = (a.tiles_x * a.tiles_y + 7) / 8;
-    int nwg = 256 * wg_per_cu;
-    if (nwg > 8 * chunk * batch) nwg = 8 * chunk * batch;
-    nwg = (nwg + 7) & ~7;
-    float us = time_it([&] { hipLaunchKernelGGL((dwt2_inv_fast_stream_kernel<HLEN, TX, TY, NT>), dim3(nwg), dim3(NT), lds, 0, a, batch); });
-    const double bytes = 8.0 * batch * N * N;
-    printf("%-30s wg/cu=%d N=%d B=%d lds=%6zu  %8.2f us  %7.1f GB/s (algorithmic)\n", tag, wg_per_cu, N, batch, lds, us, bytes / us / 1e3);
-}
-
-template <int HLEN, int TX, int TY, int NT>
 static void bench_inv_fast(const char* tag, const float* in4, float* out, int N, int batch) {
     if (skip(tag)) return;
     Inv2DFastArgs a;
@@ -400,8 +379,6 @@ int main(int argc, char** argv) {
     bench_inv_fast<8, 64, 4, 256>("FAST inv db4 TX64 TY4 NT256", b, a, N, B);
     bench_inv_fast<8, 32, 8, 128>("FAST inv db4 TX32 TY8 NT128", b, a, N, B);
     bench_inv_fast<8, 128, 8, 256>("FAST inv db4 TX128 TY8 NT256", b, a, N, B);
-    for (int w : {4, 6, 8}) bench_inv_stream<8, 64, 8, 256>("STREAM inv db4 TX64 TY8 NT256", b, a, N, B, w);
-    for (int w : {2, 4}) bench_inv_stream<8, 64, 16, 256>("STREAM inv db4 TX64 TY16 NT256", b, a, N, B, w);
     bench_fwd_fast<8, 64, 16, 256>("FAST fwd db4 TX64 TY16 NT256", a, b, N, B);
     bench_fwd_fast<8, 64, 32, 256>("FAST fwd db4 TX64 TY32 NT256", a, b, N, B);
     bench_fwd_fast<8, 64, 32, 512>("FAST fwd db4 TX64 TY32 NT512", a, b, N, B);
