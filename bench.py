@@ -121,12 +121,17 @@ def label_step_kernels(names, L):
             out.append("%s[L%d]" % (n, f)); f += 2
         elif base == "dwt1_fwd_fused":
             out.append("%s[L%d]" % (n, f)); f = L + 1
+        elif base == "dwt1_fwd_reg":  # up to three levels per launch
+            out.append("%s[L%d]" % (n, f)); f = min(f + 3, L + 1)
         elif base in ("dwt2_inv_level", "dwt1_inv_level", "swt2_inv_level", "swt1_inv_level", "nonsep_inv_level"):
             out.append("%s[L%d]" % (n, i)); i -= 1
         elif base in ("dwt2_inv_pyr2", "dwt2_inv_strip2", "dwt2_inv_wave2"):
             out.append("%s[L%d]" % (n, i - 1)); i -= 2
         elif base == "dwt1_inv_fused":
             out.append("%s[L%d]" % (n, 1)); i = 0
+        elif base == "dwt1_inv_reg":  # the chunks are cut from level 1 upwards: [1-3], [4-6], ...; undone last first
+            first = 3 * ((i - 1) // 3) + 1
+            out.append("%s[L%d]" % (n, first)); i = first - 1
         else:
             out.append("%s[-]" % n)
     return out

@@ -184,9 +184,10 @@ int pdwt_time_level(pdwt_handle h, int level, int inverse, int reps, float* ms_p
  * PDWT_ERR_ARG for an unknown key.  Keys:
  *   "wave_min_log2"  a 2D DWT level runs on the wave-per-tile kernels when at least 2^value samples
  *                    enter it (default 22; 0 = always when eligible; 63 = never)
- *   "wave1d"         1: the fused 1D forward levels run as one wavefront per segment where 128 * 2^K divides the
- *                    row length (default 0: on MI355X it only matches the workgroup-wide kernel, 37 vs 33-37 us
- *                    on 2^24 samples; kept for tests and re-measurement)
+ *   "reg1d"          bit 0 / bit 1: the forward / inverse 1D DWT levels run three at a time in registers
+ *                    (dwt1_reg_kernels.hpp) where the rows qualify (even hlen <= 20, rows of >= 2048 samples that
+ *                    are multiples of 32); default 3; 0 = the workgroup-wide LDS pyramids (57.6 vs 69.5 us per
+ *                    forward+inverse on 2^24 samples).  Read when a plan is created.
  *   "wave2"          1: eligible forward level pairs run as ONE two-level wave launch (default 0: measured
  *                    slower than two launches on MI355X, kept for tests and re-measurement) */
 int pdwt_set_tuning(const char* key, int value);

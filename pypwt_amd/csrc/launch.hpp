@@ -27,8 +27,8 @@ int set_wave_min_log2(int value);  // returns the previous threshold
 int get_wave_min_log2();
 int set_wave2_enabled(int value);  // two-levels-per-wavefront forward (opt-in); returns the previous setting
 int get_wave2_enabled();
-int set_wave1d_enabled(int value);  // fused 1D forward by one wavefront per segment (opt-in: PDWT_WAVE1D=1 / "wave1d")
-int get_wave1d_enabled();
+int set_reg1d_enabled(int value);   // 1D levels three at a time in registers (dwt1_reg_kernels.hpp); bit 0 forward, bit 1 inverse; read when a plan is built
+int get_reg1d_enabled();
 // two forward levels per wavefront (A_l stays in registers); contract of launch_dwt2_fwd_pyr2
 bool dwt2_wave2_supported(int hlen, int N0r, int N0c);
 hipError_t launch_dwt2_fwd_wave2(const real_t* in, real_t* const det1[3], real_t* const band2[4], int N0r, int N0c,
@@ -49,10 +49,12 @@ hipError_t launch_dwt1_inv(const Inv1DArgs& a, hipStream_t s);
 // K consecutive 1D levels in one launch (2^K must divide N0, even hlen); hipErrorNotSupported otherwise
 int dwt1_fused_max_levels(int hlen);
 bool dwt1_fused_supported(int hlen, int N0, int K);
-// one wavefront per segment runs all K levels (LDS rings, no workgroup barrier); 128 * 2^K must divide N0
-bool dwt1_wave_supported(int hlen, int N0, int K);
-hipError_t launch_dwt1_fwd_wave(const real_t* in, real_t* const* det, real_t* app, int rows, int N0, int K, int hlen,
-                                const FilterBank& fb, hipStream_t s);
+// up to three levels per launch in registers (dwt1_reg_kernels.hpp): even hlen <= 20, rows of >= 2048 samples
+bool dwt1_reg_supported(int hlen, int N0, int K);
+hipError_t launch_dwt1_fwd_reg(const real_t* in, real_t* const* det, real_t* app, int rows, int N0, int K, int hlen,
+                               const FilterBank& fb, hipStream_t s);
+hipError_t launch_dwt1_inv_reg(const real_t* app, const real_t* const* det, real_t* out, int rows, int N0, int K, int hlen,
+                               const FilterBank& fb, hipStream_t s);
 hipError_t launch_dwt1_fwd_fused(const real_t* in, real_t* const* det, real_t* app, int rows, int N0, int K, int hlen,
                                  const FilterBank& fb, hipStream_t s);
 hipError_t launch_dwt1_inv_fused(const real_t* app, const real_t* const* det, real_t* out, int rows, int N0, int K,

@@ -57,8 +57,11 @@ hipError_t launch_dwt2_inv_pyr2(const real_t* const[4], const real_t* const[3], 
                                 const FilterBank&, int, hipStream_t) { return hipErrorNotSupported; }
 int dwt1_fused_max_levels(int) { return 1; }
 bool dwt1_fused_supported(int, int, int) { return false; }
-bool dwt1_wave_supported(int, int, int) { return false; }
-hipError_t launch_dwt1_fwd_wave(const real_t*, real_t* const*, real_t*, int, int, int, int, const FilterBank&, hipStream_t) {
+bool dwt1_reg_supported(int, int, int) { return false; }
+hipError_t launch_dwt1_inv_reg(const real_t*, const real_t* const*, real_t*, int, int, int, int, const FilterBank&, hipStream_t) {
+    return hipErrorNotSupported;
+}
+hipError_t launch_dwt1_fwd_reg(const real_t*, real_t* const*, real_t*, int, int, int, int, const FilterBank&, hipStream_t) {
     return hipErrorNotSupported;
 }
 hipError_t launch_dwt1_fwd_fused(const real_t*, real_t* const*, real_t*, int, int, int, int, const FilterBank&,
@@ -88,12 +91,12 @@ static std::atomic<int>& wave2_flag() {
     static std::atomic<int> v{getenv("PDWT_WAVE2") ? 1 : 0};
     return v;
 }
-static std::atomic<int>& wave1d_flag() {
-    static std::atomic<int> v{getenv("PDWT_WAVE1D") ? 1 : 0};
+static std::atomic<int>& reg1d_flag() {
+    static std::atomic<int> v{getenv("PDWT_REG1D") ? atoi(getenv("PDWT_REG1D")) : 3};
     return v;
 }
-int set_wave1d_enabled(int value) { return wave1d_flag().exchange(value ? 1 : 0); }
-int get_wave1d_enabled() { return wave1d_flag().load(std::memory_order_relaxed); }
+int set_reg1d_enabled(int value) { return reg1d_flag().exchange(value); }
+int get_reg1d_enabled() { return reg1d_flag().load(std::memory_order_relaxed); }
 int set_wave2_enabled(int value) { return wave2_flag().exchange(value ? 1 : 0); }
 int get_wave2_enabled() { return wave2_flag().load(std::memory_order_relaxed); }
 static bool wave_kernels_for(long long samples) {

@@ -358,19 +358,33 @@ void build_schedule(pdwt_plan* p) {
         // 1D: runs of K >= 2 levels in ONE fused launch (dwt1_fused_kernels.hpp); the rest level by level
         const bool fuse = !swt && getenv("PDWT_NO_FUSED_1D") == nullptr;
         const int cap = dwt1_fused_max_levels(hlen);
-        int l = 0;
-        while (l < L) {
-            int K = fuse ? (L - l < cap ? L - l : cap) : 1;
-            while (K >= 2 && !dwt1_fused_supported(hlen, p->lc[l], K)) --K;
-            if (K >= 2) {
-                p->sched_fwd.push_back({Step::FUSED1D, l + 1, K});
-                l += K;
-            } else {
-                p->sched_fwd.push_back({Step::LEVEL, l + 1, 1});
-                ++l;
+        const int reg = swt ? 0 : get_reg1d_enabled();  // bit 0: forward, bit 1: inverse
+        for (int dir = 0; dir < 2; dir++) {
+            std::vector<Step>& out = dir ? p->sched_inv : p->sched_fwd;
+            int l = 0;
+            while (l < L) {
+                // three levels at a time in registers (dwt1_reg_kernels.hpp) where the rows qualify ...
+                int K = (reg >> dir) & 1 ? (L - l < 3 ? L - l : 3) : 0;
+                while (K >= 1 && !dwt1_reg_supported(hlen, p->lc[l], K)) --K;
+                if (K >= 1) {
+                    out.push_back({Step::REG1D, l + 1, K});
+                    l += K;
+                    continue;
+                }
+                // ... else runs of K >= 2 levels out of LDS (dwt1_fused_kernels.hpp), else level by level
+                K = fuse ? (L - l < cap ? L - l : cap) : 1;
+                while (K >= 2 && !dwt1_fused_supported(hlen, p->lc[l], K)) --K;
+                if (K >= 2) {
+                    out.push_back({Step::FUSED1D, l + 1, K});
+                    l += K;
+                } else {
+                    out.push_back({Step::LEVEL, l + 1, 1});
+                    ++l;
+                }
             }
         }
-        p->sched_inv.assign(p->sched_fwd.rbegin(), p->sched_fwd.rend());
+        std::vector<Step> rev(p->sched_inv.rbegin(), p->sched_inv.rend());
+        p->sched_inv.swap(rev);
     }
 }
 
@@ -581,19 +595,20 @@ int forward_impl(pdwt_plan* p, int only = 0) {
             e = s.kind == Step::STRIP2  ? launch_dwt2_fwd_strip2(src, det1, band2, r0, c0, hlen, p->dec, B, p->stream)
                 : s.kind == Step::WAVE2 ? launch_dwt2_fwd_wave2(src, det1, band2, r0, c0, hlen, p->dec, B, p->stream)
                                         : launch_dwt2_fwd_pyr2(src, det1, band2, r0, c0, hlen, p->dec, B, p->stream);
+        } else if (s.kind == Step::REG1D) {
+            real_t* det[kMaxFusedLevelsHost] = {};
+            for (int k = 0; k < s.K; k++) det[k] = p->band(l + k);
+            Stamp st(p, "dwt1_fwd_reg");
+            if (!run) continue;
+            e = launch_dwt1_fwd_reg(approx_slot(p, l - 1), det, approx_slot(p, l + s.K - 1), B * p->info.Nr, p->lc[l - 1],
+                                    s.K, hlen, p->dec, p->stream);
         } else if (s.kind == Step::FUSED1D) {
             real_t* det[kMaxFusedLevelsHost] = {};
             for (int k = 0; k < s.K; k++) det[k] = p->band(l + k);
             Stamp st(p, "dwt1_fwd_fused");
             if (!run) continue;
-            // opt-in: one wavefront per segment (dwt1_wave_kernels.hpp) where whole passes fit; default and
-            // fallback: the workgroup-wide kernel
-            e = get_wave1d_enabled() ? launch_dwt1_fwd_wave(approx_slot(p, l - 1), det, approx_slot(p, l + s.K - 1),
-                                                            B * p->info.Nr, p->lc[l - 1], s.K, hlen, p->dec, p->stream)
-                                     : hipErrorNotSupported;
-            if (e == hipErrorNotSupported)
-                e = launch_dwt1_fwd_fused(approx_slot(p, l - 1), det, approx_slot(p, l + s.K - 1), B * p->info.Nr,
-                                          p->lc[l - 1], s.K, hlen, p->dec, p->stream);
+            e = launch_dwt1_fwd_fused(approx_slot(p, l - 1), det, approx_slot(p, l + s.K - 1), B * p->info.Nr, p->lc[l - 1],
+                                      s.K, hlen, p->dec, p->stream);
         }
         if (e == hipSuccess) continue;
         if (e != hipErrorNotSupported) HIP_TRY(e);
@@ -622,6 +637,13 @@ int inverse_impl(pdwt_plan* p, int only = 0) {
             e = s.kind == Step::STRIP2
                     ? launch_dwt2_inv_strip2(band2, det1, approx_slot(p, l - 1), p->lr[l - 1], p->lc[l - 1], hlen, p->rec, B, p->stream)
                     : launch_dwt2_inv_pyr2(band2, det1, approx_slot(p, l - 1), p->lr[l - 1], p->lc[l - 1], hlen, p->rec, B, p->stream);
+        } else if (s.kind == Step::REG1D) {
+            const real_t* det[kMaxFusedLevelsHost] = {};
+            for (int k = 0; k < s.K; k++) det[k] = p->band(l + k);
+            Stamp st(p, "dwt1_inv_reg");
+            if (!run) continue;
+            e = launch_dwt1_inv_reg(approx_slot(p, l + s.K - 1), det, approx_slot(p, l - 1), B * p->info.Nr, p->lc[l - 1], s.K, hlen,
+                                    p->rec, p->stream);
         } else if (s.kind == Step::FUSED1D) {
             const real_t* det[kMaxFusedLevelsHost] = {};
             for (int k = 0; k < s.K; k++) det[k] = p->band(l + k);
@@ -1305,7 +1327,7 @@ int pdwt_time_level(pdwt_handle h, int level, int inverse, int reps, float* ms_p
 int pdwt_set_tuning(const char* key, int value) {
     if (key && !strcmp(key, "wave_min_log2")) return set_wave_min_log2(value);
     if (key && !strcmp(key, "wave2")) return set_wave2_enabled(value);
-    if (key && !strcmp(key, "wave1d")) return set_wave1d_enabled(value);
+    if (key && !strcmp(key, "reg1d")) return set_reg1d_enabled(value);
     return fail(PDWT_ERR_ARG, "pdwt_set_tuning: unknown key %s", key ? key : "(null)");
 }
 

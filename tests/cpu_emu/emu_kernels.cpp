@@ -9,7 +9,7 @@
 
 #include "../../pypwt_amd/csrc/dwt1_fused_kernels.hpp"
 #include "../../pypwt_amd/csrc/dwt1_kernels.hpp"
-#include "../../pypwt_amd/csrc/dwt1_wave_kernels.hpp"
+#include "../../pypwt_amd/csrc/dwt1_reg_kernels.hpp"
 #include "../../pypwt_amd/csrc/dwt2_fast_kernels.hpp"
 #include "../../pypwt_amd/csrc/dwt2_kernels.hpp"
 #include "../../pypwt_amd/csrc/dwt2_pyramid_kernels.hpp"
@@ -574,29 +574,56 @@ EMU_API int emu_dwt2_fwd2_wave(const float* in, int batch, int N0r, int N0c, con
     return 0;
 }
 
-// ------------------------------------------------------------------ 1D, all levels per wavefront
-EMU_API int emu_dwt1_fwd_wave(const float* in, int rows, int N0, int K, const float* lo, const float* hi, int hlen,
-                              int unitK, float* det, float* app) {
-    if ((hlen & 1) || K < 1 || K > kWave1MaxLevels || (N0 % (128 << K)) || ((N0 >> K) / 128) % unitK) return -2;
-    Fwd1DWaveArgs a;
-    a.nsched = dwt1_wave_build_schedule(K, hlen, unitK, a.sched, kWave1MaxSched);
-    if (a.nsched < 0) return -3;
-    a.in = in; a.app = app; a.rows = rows; a.N0 = N0; a.K = K; a.unitK = unitK;
-    a.units = (N0 >> K) / 128 / unitK;
+// ------------------------------------------------------------------ 1D, up to three levels in registers
+template <int HLEN, int K>
+static void run_fwd1d_reg(const Fwd1DRegArgs& a) {
+    const long long waves = (long long)a.rows * a.wpr;
+    for (long long w = 0; w < waves; w++) dwt1_fwd_reg<HLEN, K>(a, w);
+}
+
+EMU_API int emu_dwt1_fwd_reg(const float* in, int rows, int N0, int K, const float* lo, const float* hi, int hlen,
+                             int bpw, float* det, float* app) {
+    if ((hlen & 1) || hlen > kReg1MaxHlen || K < 1 || K > kReg1MaxLevels || (N0 % 16) || N0 < 2048) return -2;
+    Fwd1DRegArgs a;
+    a.in = in; a.app = app; a.rows = rows; a.N0 = N0;
     size_t off = 0;
-    for (int k = 0; k < kMaxFusedLevels; k++) a.det[k] = nullptr;
+    for (int k = 0; k < kReg1MaxLevels; k++) a.det[k] = nullptr;
     for (int k = 1; k <= K; k++) { a.det[k - 1] = det + off; off += (size_t)rows * (N0 >> k); }
+    reg1_fwd_blocks(hlen, K, N0, &a.nblk, &a.nplain);
+    a.bpw = bpw;
+    a.wpr = (a.nblk + bpw - 1) / bpw;
     set_bank_i(a.fb, lo, hi, hlen);
-    std::vector<float> lds(dwt1_wave_lds_floats(K), NAN);
-    for (int row = 0; row < rows; row++)
-        for (int unit = 0; unit < a.units; unit++) {
-            std::fill(lds.begin(), lds.end(), NAN);
-            switch (hlen) {
-#define X(h) case h: dwt1_fwd_wave<h>(a, row, unit, lds.data()); break;
-                EMU_EVEN_HLENS(X)
+#define Y(h, k) if (hlen == h && K == k) { run_fwd1d_reg<h, k>(a); return 0; }
+#define X(h) Y(h, 1) Y(h, 2) Y(h, 3)
+    X(2) X(4) X(6) X(8) X(10) X(12) X(14) X(16) X(18) X(20)
 #undef X
-                default: return -1;
-            }
-        }
-    return 0;
+#undef Y
+    return -1;
+}
+
+template <int HLEN, int K>
+static void run_inv1d_reg(const Inv1DRegArgs& a) {
+    const long long waves = (long long)a.rows * a.wpr;
+    std::vector<float> lds(kReg1LdsFloats, NAN);
+    for (long long w = 0; w < waves; w++) dwt1_inv_reg<HLEN, K>(a, w, lds.data());
+}
+
+EMU_API int emu_dwt1_inv_reg(const float* app, const float* det, int rows, int N0, int K, const float* lo, const float* hi,
+                             int hlen, int bpw, float* out) {
+    if ((hlen & 1) || hlen > kReg1MaxHlen || K < 1 || K > kReg1MaxLevels || (N0 % 16) || N0 < 2048) return -2;
+    Inv1DRegArgs a;
+    a.app = app; a.out = out; a.rows = rows; a.N0 = N0;
+    size_t off = 0;
+    for (int k = 0; k < kReg1MaxLevels; k++) a.det[k] = nullptr;
+    for (int k = 1; k <= K; k++) { a.det[k - 1] = det + off; off += (size_t)rows * (N0 >> k); }
+    reg1_inv_blocks(hlen, K, N0, &a.nblk, &a.nplain);
+    a.bpw = bpw;
+    a.wpr = (a.nblk + bpw - 1) / bpw;
+    set_bank_i(a.fb, lo, hi, hlen);
+#define Y(h, k) if (hlen == h && K == k) { run_inv1d_reg<h, k>(a); return 0; }
+#define X(h) Y(h, 1) Y(h, 2) Y(h, 3)
+    X(2) X(4) X(6) X(8) X(10) X(12) X(14) X(16) X(18) X(20)
+#undef X
+#undef Y
+    return -1;
 }

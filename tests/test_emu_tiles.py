@@ -480,18 +480,27 @@ def test_emu_dwt2_wave_two_levels_forward(wname):
                 assert np.abs(band2[k, b] - l2[k]).max() <= 2 * _tol(l2[k]), (wname, nr, nc, "band2", k)
 
 
-@pytest.mark.parametrize("wname", ["haar", "db2", "db4", "sym8", "coif2", "db10", "db20", "bior3.1"])
-def test_emu_dwt1_wave_cascade_forward(wname):
-    """dwt1_fwd_wave: all K levels by one wavefront per segment (LDS rings, a pass = 128 outputs), vs the oracle"""
+# ----------------------------------------------------------------------------- 1D, three levels in registers
+def _reg_cases():
+    # (rows, N0, K, blocks per wavefront): rows that are not a whole number of blocks, rows barely two blocks long
+    return [(1, 2048, 3, 1), (2, 4096, 3, 2), (1, 8192, 2, 3), (3, 2064, 1, 1), (1, 16384, 3, 4), (1, 2048 + 16 * 57, 3, 1),
+            (2, 3200, 2, 2), (1, 65536, 3, 8)]
+
+
+@pytest.mark.parametrize("wname", ["haar", "db2", "db3", "db4", "sym8", "coif2", "db7", "db10", "bior3.1"])
+def test_emu_dwt1_reg_forward(wname):
+    """dwt1_fwd_reg: up to three levels per launch in registers (a lane owns 16 consecutive samples, neighbours by
+    lane shifts, overlapping blocks), vs the oracle"""
     hlen, dlo, dhi, rlo, rhi = oracle.filters(wname)
-    for si, (rows, N0, K, unitK) in enumerate([(1, 1024, 2, 1), (2, 2048, 3, 1), (1, 8192, 6, 1), (1, 16384, 6, 2),
-                                                (3, 4096, 4, 2), (1, 256, 1, 1), (1, 4096, 5, 1)]):
-        x = oracle.hash_input((rows, N0), 7300 + si)
+    for si, (rows, N0, K, bpw) in enumerate(_reg_cases()):
+        if N0 % (16 << K):
+            continue
+        x = oracle.hash_input((rows, N0), 7700 + si)
         ref = oracle.forward(x, wname, K, ndim=1, filt=(hlen, dlo, dhi, rlo, rhi))  # [A_K, D_1, ..., D_K]
         ndet = sum(rows * (N0 >> k) for k in range(1, K + 1))
         det = np.full(ndet, np.nan, dtype=np.float32)
         app = np.full((rows, N0 >> K), np.nan, dtype=np.float32)
-        assert lib().emu_dwt1_fwd_wave(P(x), rows, N0, K, P(dlo), P(dhi), hlen, unitK, P(det), P(app)) == 0
+        assert lib().emu_dwt1_fwd_reg(P(x), rows, N0, K, P(dlo), P(dhi), hlen, bpw, P(det), P(app)) == 0
         assert np.isfinite(app).all(), (wname, N0, K)
         assert np.abs(app - ref[0]).max() <= _tol(ref[0]) * (1 + K), (wname, rows, N0, K)
         off = 0
@@ -501,3 +510,21 @@ def test_emu_dwt1_wave_cascade_forward(wname):
             off += n
             assert np.isfinite(got).all(), (wname, N0, K, k)
             assert np.abs(got - ref[k]).max() <= _tol(ref[k]) * (1 + K), (wname, rows, N0, K, k)
+
+
+@pytest.mark.parametrize("wname", ["haar", "db2", "db3", "db4", "sym8", "coif2", "db7", "db10", "bior3.1"])
+def test_emu_dwt1_reg_inverse(wname):
+    """dwt1_inv_reg: up to three synthesis levels per launch in registers, vs the oracle's inverse of the same
+    (arbitrary) coefficients"""
+    hlen, dlo, dhi, rlo, rhi = oracle.filters(wname)
+    for si, (rows, N0, K, bpw) in enumerate(_reg_cases()):
+        if N0 % (16 << K):
+            continue
+        bands = [oracle.hash_input((rows, N0 >> K), 7800 + si, 2.0) - 1.0]
+        bands += [oracle.hash_input((rows, N0 >> k), 7810 + 10 * si + k, 2.0) - 1.0 for k in range(1, K + 1)]
+        ref = oracle.inverse(bands, (rows, N0), wname, K, ndim=1, filt=(hlen, dlo, dhi, rlo, rhi))
+        det = np.concatenate([b.ravel() for b in bands[1:]]).astype(np.float32)
+        out = np.full((rows, N0), np.nan, dtype=np.float32)
+        assert lib().emu_dwt1_inv_reg(P(bands[0]), P(det), rows, N0, K, P(rlo), P(rhi), hlen, bpw, P(out)) == 0
+        assert np.isfinite(out).all(), (wname, rows, N0, K)
+        assert np.abs(out - ref).max() <= _tol(ref) * (1 + K), (wname, rows, N0, K)
