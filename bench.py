@@ -99,6 +99,9 @@ def kernel_algorithmic_bytes(label, cfg, batch):
         return 8.0 * samples / (2 ** (lvl - 1))
     if name in ("swt2_fwd_level", "swt2_inv_level"):
         return 4.0 * 5 * samples
+    if name in ("swt2_fwd_fused", "swt2_inv_fused"):  # K levels: one plane in, 3 K + 1 planes out (or the reverse)
+        K = min(3, L - lvl + 1)
+        return 4.0 * (3 * K + 2) * samples
     if name in ("swt1_fwd_level", "swt1_inv_level"):
         return 4.0 * 3 * samples
     if name == "soft_threshold":
@@ -121,6 +124,8 @@ def label_step_kernels(names, L):
             out.append("%s[L%d]" % (n, f)); f += 2
         elif base == "dwt1_fwd_fused":
             out.append("%s[L%d]" % (n, f)); f = L + 1
+        elif base == "swt2_fwd_fused":  # levels 1-3 / 4-6 of a 2-tap SWT in one launch (two levels when only two are left)
+            out.append("%s[L%d]" % (n, f)); f += min(3, L - f + 1)
         elif base == "dwt1_fwd_reg":  # up to three levels per launch
             out.append("%s[L%d]" % (n, f)); f = min(f + 3, L + 1)
         elif base in ("dwt2_inv_level", "dwt1_inv_level", "swt2_inv_level", "swt1_inv_level", "nonsep_inv_level"):
@@ -129,6 +134,9 @@ def label_step_kernels(names, L):
             out.append("%s[L%d]" % (n, i - 1)); i -= 2
         elif base == "dwt1_inv_fused":
             out.append("%s[L%d]" % (n, 1)); i = 0
+        elif base == "swt2_inv_fused":  # groups start at levels 1 and 4
+            first = 4 if i >= 4 else 1
+            out.append("%s[L%d]" % (n, first)); i = first - 1
         elif base == "dwt1_inv_reg":  # the chunks are cut from level 1 upwards: [1-3], [4-6], ...; undone last first
             first = 3 * ((i - 1) // 3) + 1
             out.append("%s[L%d]" % (n, first)); i = first - 1

@@ -24,7 +24,8 @@ LIB_F64 = os.path.join(HERE, "libpypwt_amd_f64.so")
 VARIANTS = {
     "f32": (OBJ, LIB, [], ()),
     "f64": (os.path.join(ROOT, "build", "obj_f64"), LIB_F64, ["-DPDWT_DOUBLE"],
-            ("launch_dwt2_fast.hip", "launch_dwt2_pyramid.hip", "launch_dwt2_wave.hip", "launch_dwt1_fused.hip")),
+            ("launch_dwt2_fast.hip", "launch_dwt2_pyramid.hip", "launch_dwt2_wave.hip", "launch_dwt1_fused.hip",
+             "launch_swt_fused.hip")),
 }
 
 SOURCES = [
@@ -36,6 +37,7 @@ SOURCES = [
     "launch_dwt1_fused.hip",
     "launch_swt.hip",
     "launch_swt_vec.hip",
+    "launch_swt_fused.hip",
     "launch_ops.hip",
     "launch_nonsep.hip",
     "plan.cpp",

@@ -107,10 +107,15 @@ PDWT_DEVICE int wrap_analysis(int i, int n) {
 PDWT_DEVICE int analysis_centre(int hlen) { return (hlen & 1) ? hlen / 2 : hlen / 2 - 1; }
 
 // soft threshold sign(x) max(|x|-b, 0) written as x - clamp(x, -b, b): the same value for every
-// finite x (b >= 0), the identity for b == 0, two instructions (v_med3_f32 + v_sub_f32)
+// finite x (b >= 0), the identity for b == 0.  fp32 on the GPU: v_med3_f32 + v_sub_f32 (the two-comparison
+// form compiled to two v_cmp + two v_cndmask + v_sub: 30 % of the fused SWT inverse's vector instructions).
 PDWT_DEVICE real_t soft_shrink(real_t x, real_t b) {
+#if !defined(PDWT_CPU_EMU) && !defined(PDWT_DOUBLE)
+    return x - __builtin_amdgcn_fmed3f(x, -b, b);
+#else
     const real_t c = x < -b ? -b : (x > b ? b : x);
     return x - c;
+#endif
 }
 
 // ---- argument blocks -----------------------------------------------------

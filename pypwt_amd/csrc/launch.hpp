@@ -27,6 +27,8 @@ int set_wave_min_log2(int value);  // returns the previous threshold
 int get_wave_min_log2();
 int set_wave2_enabled(int value);  // two-levels-per-wavefront forward (opt-in); returns the previous setting
 int get_wave2_enabled();
+int set_swt_fused_enabled(int value);  // 2-tap 2D SWT levels 1-3 / 4-6 in one launch each (swt2_fused_kernels.hpp); read when a plan is built
+int get_swt_fused_enabled();
 int set_reg1d_enabled(int value);   // 1D levels three at a time in registers (dwt1_reg_kernels.hpp); bit 0 forward, bit 1 inverse; read when a plan is built
 int get_reg1d_enabled();
 // two forward levels per wavefront (A_l stays in registers); contract of launch_dwt2_fwd_pyr2
@@ -62,6 +64,10 @@ hipError_t launch_dwt1_inv_fused(const real_t* app, const real_t* const* det, re
 // fused a-trous level; the host guarantees a.f divides a.Nr
 hipError_t launch_swt2_fwd(const Swt2DArgs& a, int batch, hipStream_t s);
 hipError_t launch_swt2_inv(const Swt2DArgs& a, int batch, hipStream_t s);
+// levels l0 .. l0+K-1 (K = 2, 3; l0 = 1 or 4) of a 2-tap 2D SWT in one launch (swt2_fused_kernels.hpp)
+bool swt2_fused_supported(int hlen, int Nr, int Nc, int l0, int K);
+hipError_t launch_swt2_fused(const real_t* in, real_t* out, real_t* const* det, int Nr, int Nc, int l0, int K, bool inverse,
+                             const FilterBank& fb, const real_t* beta, int batch, hipStream_t s);
 hipError_t launch_swt_pass_fwd(const SwtPassArgs& a, hipStream_t s);
 hipError_t launch_swt_pass_inv(const SwtPassArgs& a, hipStream_t s);
 

@@ -55,6 +55,9 @@ hipError_t launch_dwt2_inv_strip2(const real_t* const[4], const real_t* const[3]
                                   const FilterBank&, int, hipStream_t) { return hipErrorNotSupported; }
 hipError_t launch_dwt2_inv_pyr2(const real_t* const[4], const real_t* const[3], real_t*, int, int, int,
                                 const FilterBank&, int, hipStream_t) { return hipErrorNotSupported; }
+bool swt2_fused_supported(int, int, int, int, int) { return false; }
+hipError_t launch_swt2_fused(const real_t*, real_t*, real_t* const*, int, int, int, int, bool, const FilterBank&, const real_t*, int,
+                             hipStream_t) { return hipErrorNotSupported; }
 int dwt1_fused_max_levels(int) { return 1; }
 bool dwt1_fused_supported(int, int, int) { return false; }
 bool dwt1_reg_supported(int, int, int) { return false; }
@@ -91,6 +94,12 @@ static std::atomic<int>& wave2_flag() {
     static std::atomic<int> v{getenv("PDWT_WAVE2") ? 1 : 0};
     return v;
 }
+static std::atomic<int>& swt_fused_flag() {
+    static std::atomic<int> v{getenv("PDWT_SWT_FUSED") ? atoi(getenv("PDWT_SWT_FUSED")) : 1};
+    return v;
+}
+int set_swt_fused_enabled(int value) { return swt_fused_flag().exchange(value ? 1 : 0); }
+int get_swt_fused_enabled() { return swt_fused_flag().load(std::memory_order_relaxed); }
 static std::atomic<int>& reg1d_flag() {
     static std::atomic<int> v{getenv("PDWT_REG1D") ? atoi(getenv("PDWT_REG1D")) : 3};
     return v;

@@ -1,0 +1,83 @@
+// launch_swt_fused.hip -- launchers of the multi-level 2D SWT kernels for 2-tap filter banks (swt2_fused_kernels.hpp).
+#include "launch.hpp"
+#include "launch_util.hpp"
+#include "swt2_fused_kernels.hpp"
+
+#include <cstdlib>
+
+namespace pdwt {
+
+// Levels l0 .. l0+K-1 of an (Nr, Nc) plane in one launch: 2-tap filters, 16-B aligned rows of at least one strip,
+// first dilation 1 or 8 (levels 1.. or 4..: the lane shifts of a group must stay inside a wavefront), the dilation
+// dividing the row count (whole phases), at least one unrolled group of rows per phase, planes of at most 1 GiB (the
+// dropped-store offsets of swt2_fused_kernels.hpp start at 2^30).
+bool swt2_fused_supported(int hlen, int Nr, int Nc, int l0, int K) {
+    if (hlen != 2 || K < 2 || K > kSwtFusedMaxLevels || (l0 != 1 && l0 != 4)) return false;
+    const int f0 = 1 << (l0 - 1);
+    return (Nc % 4) == 0 && Nc >= 256 && (long long)Nr * Nc <= (1LL << 28) && (Nr % f0) == 0 && Nr / f0 >= (1 << K);
+}
+
+// Phase rows per wavefront.  A segment reads 2^K - 1 rows it does not own (the inverse: of all 3 K + 1 planes), so
+// long segments move fewer bytes; but a wavefront is alone on its SIMD (up to 286 VGPRs) and a row costs it about a
+// microsecond of latency, so the launch needs at least ~768 wavefronts.  Measured on one 2048^2 image, levels 1-3
+// (9 strips): 8 / 16 / 24 / 32 / 64 rows = 66 / 52 / 48 / 51 / 68 us inverse, 40 / 42 / 37 / 39 / 55 us forward
+// (profiles/r02w_*).  Hence: the longest segment that still gives 768 wavefronts.  PDWT_SWT_SEG overrides (tuning).
+static int fused_seg_rows(int K, int f0, int rows_phase, int strips, int batch) {
+    const int P = 1 << K;  // SwtFusedGeom::P
+    static const int forced = [] { const char* e = getenv("PDWT_SWT_SEG"); return e ? atoi(e) : 0; }();
+    int seg;
+    if (forced > 0) {
+        seg = (forced + P - 1) / P * P;
+    } else {
+        auto waves = [&](int s) { return (long long)batch * f0 * strips * ((rows_phase + s - 1) / s); };
+        seg = 256;
+        while (seg > P && waves(seg) < 768) seg -= P;
+    }
+    if (seg > rows_phase) seg = (rows_phase + P - 1) / P * P;
+    return seg;
+}
+
+template <int K, int F0>
+static hipError_t run(SwtFusedArgs& a, bool inverse, int batch, hipStream_t s) {
+    using G = SwtFusedGeom<K, F0>;
+    constexpr int NT = 64;  // one wavefront per workgroup: up to 512 VGPRs each, placed on any free SIMD
+    a.strips = cdiv(a.Nc, 4 * G::V);
+    const int rows_phase = a.Nr / F0;
+    a.seg_rows = fused_seg_rows(K, F0, rows_phase, a.strips, batch);
+    a.segs = cdiv(rows_phase, a.seg_rows);
+    const long long waves = (long long)batch * F0 * a.segs * a.strips;
+    const unsigned grid = (unsigned)cdivll(waves, NT / 64);
+    // inverse: load slots (rows in flight + 1); PDWT_SWT_SLOTS=8 selects the deep variant of the 3-level kernels (A/B tuning)
+    static const int slots = [] { const char* e = getenv("PDWT_SWT_SLOTS"); return e ? atoi(e) : 4; }();
+    if (inverse && K == 3 && slots == 8) hipLaunchKernelGGL((swt2_inv_fused_kernel<K, F0, (K == 3 ? 8 : 4), NT>), dim3(grid), dim3(NT), 0, s, a, waves);
+    else if (inverse && slots == 2) hipLaunchKernelGGL((swt2_inv_fused_kernel<K, F0, 2, NT>), dim3(grid), dim3(NT), 0, s, a, waves);
+    else if (inverse) hipLaunchKernelGGL((swt2_inv_fused_kernel<K, F0, 4, NT>), dim3(grid), dim3(NT), 0, s, a, waves);
+    else hipLaunchKernelGGL((swt2_fwd_fused_kernel<K, F0, NT>), dim3(grid), dim3(NT), 0, s, a, waves);
+    return hipGetLastError();
+}
+
+// in / out: the approximation planes on either side of the group; det[3 k + {0,1,2}] = H, V, D of level l0 + k;
+// beta[k]: soft threshold the inverse applies to level l0 + k's details as it loads them (nullptr: none)
+hipError_t launch_swt2_fused(const float* in, float* out, float* const* det, int Nr, int Nc, int l0, int K, bool inverse,
+                             const FilterBank& fb, const float* beta, int batch, hipStream_t s) {
+    if (!swt2_fused_supported(2, Nr, Nc, l0, K)) return hipErrorNotSupported;
+    SwtFusedArgs a;
+    a.in = in; a.out = out; a.Nr = Nr; a.Nc = Nc; a.bstride = (long long)Nr * Nc;
+    for (int k = 0; k < kSwtFusedMaxLevels; k++) {
+        a.H[k] = k < K ? det[3 * k] : nullptr;
+        a.V[k] = k < K ? det[3 * k + 1] : nullptr;
+        a.D[k] = k < K ? det[3 * k + 2] : nullptr;
+        a.beta[k] = (beta && k < K) ? beta[k] : 0.f;
+    }
+    for (int k = 0; k < 3 * K; k++)
+        if (reinterpret_cast<uintptr_t>(det[k]) & 15) return hipErrorNotSupported;
+    if ((reinterpret_cast<uintptr_t>(in) & 15) || (reinterpret_cast<uintptr_t>(out) & 15)) return hipErrorNotSupported;
+    a.lo[0] = fb.lo[0]; a.lo[1] = fb.lo[1]; a.hi[0] = fb.hi[0]; a.hi[1] = fb.hi[1];
+    if (l0 == 1 && K == 2) return run<2, 1>(a, inverse, batch, s);
+    if (l0 == 1 && K == 3) return run<3, 1>(a, inverse, batch, s);
+    if (l0 == 4 && K == 2) return run<2, 8>(a, inverse, batch, s);
+    if (l0 == 4 && K == 3) return run<3, 8>(a, inverse, batch, s);
+    return hipErrorNotSupported;
+}
+
+}  // namespace pdwt

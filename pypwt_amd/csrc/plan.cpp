@@ -342,9 +342,21 @@ void build_schedule(pdwt_plan* p) {
             return fusable && !inverse && wave2_on && wmin < 63 && l + 1 <= L && samples(l) >= (1LL << wmin) &&
                    dwt2_wave2_supported(hlen, p->lr[l - 1], p->lc[l - 1]);
         };
+        // 2-tap SWT: levels 1-3 and 4-6 in one launch each (swt2_fused_kernels.hpp).  The approximations between
+        // groups live in the two ping-pong planes (slot l & 1): a two-level group in the MIDDLE would read and
+        // write the same plane, so it is only taken next to the image or to band 0.
+        auto swt_group = [&](int l) {
+            if (!swt || !p->do_separable || !get_swt_fused_enabled() || (l != 1 && l != 4)) return 0;
+            for (int K = (L - l + 1 < 3 ? L - l + 1 : 3); K >= 2; --K) {
+                const bool same_plane = K == 2 && l - 1 >= 1 && l + K - 1 <= L - 1;
+                if (!same_plane && swt2_fused_supported(hlen, p->info.Nr, p->info.Nc, l, K)) return K;
+            }
+            return 0;
+        };
         for (int dir = 0; dir < 2; dir++) {
             std::vector<Step>& out = dir ? p->sched_inv : p->sched_fwd;
             for (int l = 1; l <= L; l++) {
+                if (const int K = swt_group(l)) { out.push_back({Step::SWTF, l, K}); l += K - 1; continue; }
                 if (strip_at(l, dir != 0)) { out.push_back({Step::STRIP2, l, 2}); l++; }
                 else if (wave2_at(l, dir != 0)) { out.push_back({Step::WAVE2, l, 2}); l++; }
                 else if (pyr_at(l) && !strip_at(l + 1, dir != 0)) { out.push_back({Step::PYR2, l, 2}); l++; }
@@ -453,6 +465,14 @@ int fwd_level_2d(pdwt_plan* p, int l, bool run) {
     return PDWT_OK;
 }
 
+// deferred soft_threshold: beta of level l's details (/ sqrt(2)^l when normalised)
+real_t pending_beta_of_level(const pdwt_plan* p, int l) {
+    real_t b = p->pend_beta;
+    if (p->pend_normalize > 0)
+        for (int i = 0; i < l; i++) b = (real_t)(b / 1.4142135623730951);
+    return b;
+}
+
 int inv_level_2d(pdwt_plan* p, int l, bool run) {
     const int B = p->batch, hlen = p->info.hlen;
     const bool swt = p->info.do_swt != 0;
@@ -497,12 +517,7 @@ int inv_level_2d(pdwt_plan* p, int l, bool run) {
             a.bstride = (long long)Nr * Nc;
             a.hlen = hlen;
             a.soft_beta = 0.f;
-            if (p->pend_soft) {  // deferred soft_threshold: beta (/ sqrt(2)^l when normalised)
-                real_t b = p->pend_beta;
-                if (p->pend_normalize > 0)
-                    for (int i = 0; i < l; i++) b = (real_t)(b / 1.4142135623730951);
-                a.soft_beta = b;
-            }
+            if (p->pend_soft) a.soft_beta = pending_beta_of_level(p, l);
             a.fb = p->rec;
             Stamp st(p, p->pend_soft ? "swt2_inv_level+soft" : "swt2_inv_level");
             if (run) HIP_TRY(launch_swt2_inv(a, B, p->stream));
@@ -595,6 +610,13 @@ int forward_impl(pdwt_plan* p, int only = 0) {
             e = s.kind == Step::STRIP2  ? launch_dwt2_fwd_strip2(src, det1, band2, r0, c0, hlen, p->dec, B, p->stream)
                 : s.kind == Step::WAVE2 ? launch_dwt2_fwd_wave2(src, det1, band2, r0, c0, hlen, p->dec, B, p->stream)
                                         : launch_dwt2_fwd_pyr2(src, det1, band2, r0, c0, hlen, p->dec, B, p->stream);
+        } else if (s.kind == Step::SWTF) {
+            real_t* det[9] = {};
+            for (int k = 0; k < 3 * s.K; k++) det[k] = p->band(3 * (l - 1) + 1 + k);
+            Stamp st(p, "swt2_fwd_fused");
+            if (!run) continue;
+            e = launch_swt2_fused(approx_slot(p, l - 1), approx_slot(p, l + s.K - 1), det, p->info.Nr, p->info.Nc, l, s.K, false,
+                                  p->dec, nullptr, B, p->stream);
         } else if (s.kind == Step::REG1D) {
             real_t* det[kMaxFusedLevelsHost] = {};
             for (int k = 0; k < s.K; k++) det[k] = p->band(l + k);
@@ -637,6 +659,16 @@ int inverse_impl(pdwt_plan* p, int only = 0) {
             e = s.kind == Step::STRIP2
                     ? launch_dwt2_inv_strip2(band2, det1, approx_slot(p, l - 1), p->lr[l - 1], p->lc[l - 1], hlen, p->rec, B, p->stream)
                     : launch_dwt2_inv_pyr2(band2, det1, approx_slot(p, l - 1), p->lr[l - 1], p->lc[l - 1], hlen, p->rec, B, p->stream);
+        } else if (s.kind == Step::SWTF) {
+            real_t* det[9] = {};
+            for (int k = 0; k < 3 * s.K; k++) det[k] = p->band(3 * (l - 1) + 1 + k);
+            real_t beta[3] = {0, 0, 0};
+            if (p->pend_soft)  // deferred soft_threshold, applied as the details are loaded (see inv_level_2d)
+                for (int k = 0; k < s.K; k++) beta[k] = pending_beta_of_level(p, l + k);
+            Stamp st(p, p->pend_soft ? "swt2_inv_fused+soft" : "swt2_inv_fused");
+            if (!run) continue;
+            e = launch_swt2_fused(approx_slot(p, l + s.K - 1), approx_slot(p, l - 1), det, p->info.Nr, p->info.Nc, l, s.K, true,
+                                  p->rec, beta, B, p->stream);
         } else if (s.kind == Step::REG1D) {
             const real_t* det[kMaxFusedLevelsHost] = {};
             for (int k = 0; k < s.K; k++) det[k] = p->band(l + k);
@@ -1328,6 +1360,7 @@ int pdwt_set_tuning(const char* key, int value) {
     if (key && !strcmp(key, "wave_min_log2")) return set_wave_min_log2(value);
     if (key && !strcmp(key, "wave2")) return set_wave2_enabled(value);
     if (key && !strcmp(key, "reg1d")) return set_reg1d_enabled(value);
+    if (key && !strcmp(key, "swt_fused")) return set_swt_fused_enabled(value);
     return fail(PDWT_ERR_ARG, "pdwt_set_tuning: unknown key %s", key ? key : "(null)");
 }
 

@@ -1,0 +1,483 @@
+// swt2_fused_kernels.hpp -- up to THREE levels of a 2D stationary (a-trous) transform with a 2-tap filter bank
+// (haar) in ONE launch, one wavefront per strip, everything in registers (gfx950).
+//
+// Why: the SWT writes four full-size planes per level, so a level-per-launch transform of L levels moves
+// 5 L planes per direction (reference: pdwt/src/separable.cu:409-537, :553-672; here swt_kernels.hpp) although
+// only 3 L + 2 are compulsory: every intermediate approximation is written and read back.  Unlike the decimated
+// transform, the halo of fused SWT levels does NOT grow relative to the data -- K levels starting at dilation
+// f0 reach (hlen-1) f0 (2^K - 1) samples, 7 for haar levels 1-3 -- so fusing costs a few lanes, not a factor.
+// Levels l0 .. l0+K-1 (f0 = 2^(l0-1)) in one launch move 3K + 2 planes instead of 5K: 11 instead of 15 for
+// levels 1-3, 8 instead of 10 for levels 4-5.
+//
+// Scheme (forward).  A wavefront owns a strip of 256 columns (a lane owns 4: one 16-B load per row) and walks
+// DOWN the rows of ONE dilation phase of f0 (rows py, py + f0, py + 2 f0, ...: inside a phase the group's
+// dilations are 1, 2, 4 rows).  Per input row:
+//   * the row filter of level k needs the sample d_k = f0 2^k columns to the right: in the same lane or
+//     (d_k + c) / 4 lanes ahead -- DPP wave_shl:1 moves;
+//   * the filtered row (L, H: 8 values per lane) goes into a register ring of 2 / 4 / 8 rows (level 1 / 2 / 3 of
+//     the group); the column filter combines it with the row 1 / 2 / 4 phase rows earlier and emits the level's
+//     A, H, V, D row: H, V, D are stored (16 B per lane and plane), A is the next level's input row, in registers;
+//   * an output row of level k lags the input by 2^k - 1 rows: a wavefront reads 2^K - 1 rows past its segment
+//     and stores only the rows it owns (a row it does not own gets an empty buffer descriptor: no branch around a
+//     store, exact s_waitcnt counts, NR rows of loads in flight).
+// Strips overlap by ceil(sum_k d_k / 4) lanes (2 of 64 for levels 1-3): those lanes lack their right neighbours
+// and store nothing.  The inverse walks the same way with the dependencies reversed (left neighbours, earlier
+// rows: warm-up rows BEFORE the segment), all K levels on the same row per step; the row synthesis' terms that
+// come from the left are combined in the source lane and shifted afterwards (half the lane moves, bit-identical
+// sums); a pending soft threshold is applied to the details as they are loaded, like swt2_inv_vec_tile does.
+//
+// Arithmetic (restated in oracle/pdwt_oracle.c): analysis out[g] = x[g] f[1] + x[g + d] f[0]; synthesis
+// out[g] = 0.5 (a[g - d] rlo[1] + b[g - d] rhi[1] + a[g] rlo[0] + b[g] rhi[0]), periodic in both directions.
+#pragma once
+
+#include "dwt2_wave_kernels.hpp"  // WaveReg, DPP shifts, RowBuf, wave_ld16
+#include "dwt1_reg_kernels.hpp"   // row_st16, kReg1Dropped
+#include "kernels_common.hpp"
+#include "packed_math.hpp"
+
+namespace pdwt {
+
+constexpr int kSwtFusedMaxLevels = 3;
+
+
+struct SwtFusedArgs {
+    const float* in;                    // forward: A_{l0-1}; inverse: A_{l0+K-1}
+    float* out;                         // forward: A_{l0+K-1}; inverse: A_{l0-1}
+    float* H[kSwtFusedMaxLevels];       // detail planes of the group's levels (forward: written; inverse: read)
+    float* V[kSwtFusedMaxLevels];
+    float* D[kSwtFusedMaxLevels];
+    int Nr, Nc;
+    long long bstride;                  // floats between the images of a batch
+    int strips;                         // ceil(Nc / (4 V))
+    int segs;                           // segments per phase: ceil(Nr / f0 / seg_rows)
+    int seg_rows;                       // phase rows a wavefront owns (multiple of 2^K)
+    float beta[kSwtFusedMaxLevels];     // inverse: soft threshold of each level's details (0 = none)
+    float lo[2], hi[2];                 // analysis (forward) / synthesis (inverse) taps
+};
+
+template <int K, int F0>
+struct SwtFusedGeom {
+    static_assert(K >= 2 && K <= kSwtFusedMaxLevels && (F0 == 1 || F0 % 4 == 0), "two or three levels; levels 1.. or whole-lane dilations");
+    static constexpr int dist(int k) { return F0 << k; }                  // columns between the two taps of level k
+    static constexpr int halo_cols = F0 * ((1 << K) - 1);
+    static constexpr int halo_lanes = (halo_cols + 3) / 4;
+    static constexpr int V = 64 - halo_lanes;                            // lanes that own output columns
+    static constexpr int W = (1 << K) - 1;                               // extra phase rows a segment reads
+    static constexpr int P = 1 << K;                                     // rows per unrolled group: ring and load-slot periods divide it
+    static constexpr int NR = P;                                         // forward: input rows in flight (+ the current one)
+    static_assert(halo_lanes < 32, "strip wide enough");
+};
+
+// sh[c] = the value D columns to the RIGHT of the lane's column c (forward) -- (c + D) / 4 lanes ahead
+template <int D>
+PDWT_DEVICE void swt_shift_right(WaveReg<float, 4>& src, WaveReg<float, 4>& sh) {
+    constexpr int M = (3 + D) / 4;  // most lanes any column looks ahead
+    WaveReg<float, 4 * (M + 1)> hop;  // hop[m] = the row as lane + m holds it
+    PDWT_WAVE_LANES(lane) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) hop.mine(lane)[i] = src.mine(lane)[i];
+    }
+#pragma unroll
+    for (int m = 1; m <= M; ++m) {
+        PDWT_WAVE_LANES(lane) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) hop.mine(lane)[4 * m + i] = hop.from_next(4 * (m - 1) + i, lane, 0.f);
+        }
+    }
+    PDWT_WAVE_LANES(lane) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) sh.mine(lane)[c] = hop.mine(lane)[4 * ((c + D) / 4) + (c + D) % 4];
+    }
+}
+// sh[c] = the value D columns to the LEFT of the lane's column c (inverse)
+template <int D>
+PDWT_DEVICE void swt_shift_left(WaveReg<float, 4>& src, WaveReg<float, 4>& sh) {
+    constexpr int M = (D + 3) / 4;
+    WaveReg<float, 4 * (M + 1)> hop;  // hop[m] = the row as lane - m holds it
+    PDWT_WAVE_LANES(lane) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) hop.mine(lane)[i] = src.mine(lane)[i];
+    }
+#pragma unroll
+    for (int m = 1; m <= M; ++m) {
+        PDWT_WAVE_LANES(lane) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) hop.mine(lane)[4 * m + i] = hop.from_prev(4 * (m - 1) + i, lane, 0.f);
+        }
+    }
+    PDWT_WAVE_LANES(lane) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            constexpr int kBig = 1 << 20;                      // keeps the C++ division / modulo non-negative
+            const int q = c - D + 4 * kBig;                    // column c - D, as lanes back (kBig - q / 4) and index q % 4
+            sh.mine(lane)[c] = hop.mine(lane)[4 * (kBig - q / 4) + q % 4];
+        }
+    }
+}
+
+// Store targets are ONE range-checked buffer descriptor per plane and image, built once per wavefront (a descriptor
+// per row and plane cost 4 SGPRs x 10 planes x 8 unrolled rows: hipcc spilled 250-450 SGPRs to VGPR lanes and the
+// loop was 60 % v_readlane / v_writelane).  The byte offset of a store = (uniform) row offset + (per-lane) column
+// offset; a row the wavefront does not own contributes kSwtRowDropped, a lane without output kSwtLaneDropped: either
+// way the sum is >= 2^30 > the plane's bytes (the host checks Nr Nc <= 2^28) and the hardware drops the store.
+constexpr unsigned kSwtRowDropped = 0x80000000u, kSwtLaneDropped = 0x40000000u;
+PDWT_DEVICE RowBuf swt_plane(float* plane, long long image_off, int Nr, int Nc) {
+    return row_buf(plane + image_off, 4u * (unsigned)Nr * (unsigned)Nc);
+}
+
+// ---------------------------------------------------------------------------------------------- forward
+template <int K, int F0>
+struct SwtFwdState {
+    using G = SwtFusedGeom<K, F0>;
+    WaveReg<float, 4 * G::NR> ld;        // input rows in flight: slot (row mod NR)
+    WaveReg<float, 8 * 2> ring1;         // (L, H) rows of level 1 of the group: [slot][L0..3 H0..3]
+    WaveReg<float, 8 * 4> ring2;
+    WaveReg<float, 8 * 8> ring3;
+    WaveReg<unsigned, 2> off;            // byte offsets in a row: load (wrapped), store (or kSwtLaneDropped)
+    RowBuf bH[3], bV[3], bD[3], bA;      // the output planes of this wavefront's image
+};
+
+// one level of one step: `a` = the level's input row (row index q of the walk), ring depth RD, lag LAG = RD / 2:
+// emits the level's output row q - LAG: details through the descriptors, approximation into `anext`
+template <int D, int RD, int SLOT, int NRING>
+PDWT_DEVICE void swt_fwd_level(const SwtFusedArgs& a, WaveReg<float, 4>& ain, WaveReg<float, NRING>& ring, WaveReg<float, 4>& anext,
+                               WaveReg<unsigned, 2>& off, const RowBuf& bH, const RowBuf& bV, const RowBuf& bD, unsigned rowoff) {
+    constexpr int LAG = RD / 2, OLD = (SLOT - LAG + RD) % RD;
+    WaveReg<float, 4> sh;
+    swt_shift_right<D>(ain, sh);
+    PDWT_WAVE_LANES(lane) {
+        const float* x = ain.mine(lane);
+        const float* s = sh.mine(lane);
+        float* cur = ring.mine(lane) + 8 * SLOT;
+        const float* old = ring.mine(lane) + 8 * OLD;
+        // row filter: out = x f[1] + x(+d) f[0]
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            cur[c] = pdwt_fma(s[c], a.lo[0], x[c] * a.lo[1]);
+            cur[4 + c] = pdwt_fma(s[c], a.hi[0], x[c] * a.hi[1]);
+        }
+        // column filter with the row LAG phase rows earlier (the earlier row is the output's own row)
+        float* an = anext.mine(lane);
+        float h[4], v[4], d[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            an[c] = pdwt_fma(cur[c], a.lo[0], old[c] * a.lo[1]);
+            h[c] = pdwt_fma(cur[c], a.hi[0], old[c] * a.hi[1]);
+            v[c] = pdwt_fma(cur[4 + c], a.lo[0], old[4 + c] * a.lo[1]);
+            d[c] = pdwt_fma(cur[4 + c], a.hi[0], old[4 + c] * a.hi[1]);
+        }
+        const unsigned o = off.mine(lane)[1] + rowoff;
+        row_st16(bH, o, h[0], h[1], h[2], h[3]);
+        row_st16(bV, o, v[0], v[1], v[2], v[3]);
+        row_st16(bD, o, d[0], d[1], d[2], d[3]);
+    }
+}
+
+// step R of a group of P rows (R static): input row r = g0 + R of the walk
+template <int K, int F0, int R>
+PDWT_DEVICE void swt_fwd_step(const SwtFusedArgs& a, SwtFwdState<K, F0>& st, const float* in, int g0, int i0, int rows_phase,
+                              int py, long long boff) {
+    using G = SwtFusedGeom<K, F0>;
+    const int r = g0 + R;
+    // request row r + NR - 1 (wrapped): its slot was consumed at the previous step
+    {
+        int rr = i0 + r + G::NR - 1;
+        rr %= rows_phase;
+        const float* row = in + (long long)(py + F0 * rr) * a.Nc;
+        PDWT_WAVE_LANES(lane) {
+            const v4f w = wave_ld16(row, st.off.mine(lane)[0]);
+            float* v = st.ld.mine(lane) + 4 * ((R + G::NR - 1) % G::NR);
+            v[0] = w.x; v[1] = w.y; v[2] = w.z; v[3] = w.w;
+        }
+    }
+    PDWT_ROW_FENCE();
+    WaveReg<float, 4> a0, a1, a2, a3;
+    PDWT_WAVE_LANES(lane) {
+        const float* v = st.ld.mine(lane) + 4 * (R % G::NR);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) a0.mine(lane)[c] = v[c];
+    }
+    // output rows of this step (relative to the segment): level k emits row r - (2^(k+1) - 1); byte offset of that
+    // row in a plane, or kSwtRowDropped for a row another wavefront owns
+    auto rowoff = [&](int rel) -> unsigned {
+        const bool ow = rel >= 0 && rel < a.seg_rows && i0 + rel < rows_phase;
+        return ow ? 4u * (unsigned)(py + F0 * (i0 + rel)) * (unsigned)a.Nc : kSwtRowDropped;
+    };
+    {
+        const unsigned ro = rowoff(r - 1);
+        swt_fwd_level<G::dist(0), 2, R % 2, 16>(a, a0, st.ring1, a1, st.off, st.bH[0], st.bV[0], st.bD[0], ro);
+    }
+    {
+        const unsigned ro = rowoff(r - 3);
+        // a1 is row q = r - 1 of level 2's input: slot q mod 4 = (R + 3) mod 4
+        swt_fwd_level<G::dist(1), 4, (R + 3) % 4, 32>(a, a1, st.ring2, a2, st.off, st.bH[1], st.bV[1], st.bD[1], ro);
+        if constexpr (K == 2) {
+            PDWT_WAVE_LANES(lane) { const float* v = a2.mine(lane); row_st16(st.bA, st.off.mine(lane)[1] + ro, v[0], v[1], v[2], v[3]); }
+        }
+    }
+    if constexpr (K >= 3) {
+        const unsigned ro = rowoff(r - 7);
+        // a2 is row p = r - 3 of level 3's input: slot p mod 8 = (R + 5) mod 8
+        swt_fwd_level<G::dist(2), 8, (R + 5) % 8, 64>(a, a2, st.ring3, a3, st.off, st.bH[2], st.bV[2], st.bD[2], ro);
+        PDWT_WAVE_LANES(lane) { const float* v = a3.mine(lane); row_st16(st.bA, st.off.mine(lane)[1] + ro, v[0], v[1], v[2], v[3]); }
+    }
+}
+
+template <int K, int F0, int R>
+PDWT_DEVICE void swt_fwd_group(const SwtFusedArgs& a, SwtFwdState<K, F0>& st, const float* in, int g0, int i0, int rows_phase,
+                               int py, long long boff) {
+    if constexpr (R < SwtFusedGeom<K, F0>::P) {
+        swt_fwd_step<K, F0, R>(a, st, in, g0, i0, rows_phase, py, boff);
+        swt_fwd_group<K, F0, R + 1>(a, st, in, g0, i0, rows_phase, py, boff);
+    }
+}
+
+// wavefront `w` of the launch: (image, phase, segment, strip)
+template <int K, int F0>
+PDWT_DEVICE void swt2_fwd_fused(const SwtFusedArgs& a, long long w) {
+    using G = SwtFusedGeom<K, F0>;
+    const int strip = (int)(w % a.strips);
+    long long t = w / a.strips;
+    const int seg = (int)(t % a.segs);
+    t /= a.segs;
+    const int py = (int)(t % F0);
+    const long long img = t / F0;
+    const int rows_phase = a.Nr / F0;
+    const int i0 = seg * a.seg_rows;
+    const long long boff = img * a.bstride;
+    const float* in = a.in + boff;
+    SwtFwdState<K, F0> st;
+    PDWT_WAVE_LANES(lane) {
+        const int x = strip * 4 * G::V + 4 * lane;
+        const int xl = x >= a.Nc ? x - a.Nc : x;                      // Nc % 4 == 0, strips * 4 V < 2 Nc
+        st.off.mine(lane)[0] = 4u * (unsigned)xl;
+        st.off.mine(lane)[1] = (lane < G::V && x < a.Nc) ? 4u * (unsigned)x : kSwtLaneDropped;
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        st.bH[k] = swt_plane(a.H[k], boff, a.Nr, a.Nc);
+        st.bV[k] = swt_plane(a.V[k], boff, a.Nr, a.Nc);
+        st.bD[k] = swt_plane(a.D[k], boff, a.Nr, a.Nc);
+    }
+    st.bA = swt_plane(a.out, boff, a.Nr, a.Nc);
+    // rows 0 .. NR-2 of the walk in flight before the first step
+#pragma unroll
+    for (int p = 0; p < G::NR - 1; ++p) {
+        const float* row = in + (long long)(py + F0 * ((i0 + p) % rows_phase)) * a.Nc;
+        PDWT_WAVE_LANES(lane) {
+            const v4f v4 = wave_ld16(row, st.off.mine(lane)[0]);
+            float* v = st.ld.mine(lane) + 4 * p;
+            v[0] = v4.x; v[1] = v4.y; v[2] = v4.z; v[3] = v4.w;
+        }
+    }
+    PDWT_WAIT_VMEM();  // the loop header must not inherit pending loads (see dwt1_inv_reg)
+    // seg_rows + W input rows, in groups of P (seg_rows is a multiple of P: one extra group covers the W <= P - 1 rows)
+    const int ngroups = a.seg_rows / G::P + 1;
+    for (int g = 0; g < ngroups; ++g) swt_fwd_group<K, F0, 0>(a, st, in, g * G::P, i0, rows_phase, py, boff);
+}
+
+// ---------------------------------------------------------------------------------------------- inverse
+template <int K, int F0, int NRI_>
+struct SwtInvState {
+    using G = SwtFusedGeom<K, F0>;
+    // load slots: the current row + NRI - 1 in flight, 1 + 3 K planes each.  One wavefront per SIMD (the rings
+    // and the slots take 280-490 VGPRs), so the rows in flight are ALL the latency hiding there is: 3 rows ahead
+    // measured 1.3 us per row and wavefront (3.6 TB/s for levels 1-3 of 2048^2), one round trip per 3 rows.  A
+    // wavefront can have 63 vector-memory operations outstanding: 6 rows of 10 loads.
+    static constexpr int NRI = NRI_;
+    static_assert(G::P % NRI_ == 0, "static slot numbers");
+    WaveReg<float, 4 * NRI*(1 + 3 * K)> ld;             // [slot][plane][4]: plane 0 = A, then H, V, D of the group's levels, deepest first
+    WaveReg<float, 8 * 2> ring1;                        // (u1, u2) rows of level 1 of the group
+    WaveReg<float, 8 * 4> ring2;
+    WaveReg<float, 8 * 8> ring3;
+    WaveReg<unsigned, 2> off;
+    RowBuf bo;                                          // the output plane of this wavefront's image
+};
+
+// all planes of input row `ro` (byte offset of the row in a plane of this image) into load slot SLOT
+template <int K, int F0, int NRI, int SLOT>
+PDWT_DEVICE void swt_inv_load(const SwtFusedArgs& a, SwtInvState<K, F0, NRI>& st, long long boff, unsigned ro) {
+    constexpr int NP = 1 + 3 * K;
+    PDWT_WAVE_LANES(lane) {
+        const unsigned o = st.off.mine(lane)[0] + ro;
+        float* base = st.ld.mine(lane) + 4 * NP * SLOT;
+        auto put = [&](int p, const float* plane) {
+            const v4f w = wave_ld16(plane + boff, o);
+            float* v = base + 4 * p;
+            v[0] = w.x; v[1] = w.y; v[2] = w.z; v[3] = w.w;
+        };
+        put(0, a.in);
+#pragma unroll
+        for (int k = K - 1; k >= 0; --k) {  // deepest level first
+            const int p = 1 + 3 * (K - 1 - k);
+            put(p, a.H[k]);
+            put(p + 1, a.V[k]);
+            put(p + 2, a.D[k]);
+        }
+    }
+}
+
+// one synthesis level on the current row: ain (approximation row) + the level's details (thresholded) -> aout;
+// the (u1, u2) row goes into ring slot SLOT, the row LAG = RD / 2 phase rows earlier is its column partner
+template <int D, int RD, int SLOT, int NRING>
+PDWT_DEVICE void swt_inv_level(const SwtFusedArgs& a, WaveReg<float, 4>& ain, const float* /*unused*/, WaveReg<float, 12>& det, float beta,
+                               WaveReg<float, NRING>& ring, WaveReg<float, 4>& aout) {
+    constexpr int LAG = RD / 2, OLD = (SLOT - LAG + RD) % RD;
+    // the two terms of the row synthesis that come from D columns to the left, combined where they live
+    WaveReg<float, 4> t1, t2, s1, s2;
+    PDWT_WAVE_LANES(lane) {
+        const float* x = ain.mine(lane);
+        float* dd = det.mine(lane);
+#pragma unroll
+        for (int i = 0; i < 12; ++i) dd[i] = soft_shrink(dd[i], beta);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            t1.mine(lane)[c] = pdwt_fma(dd[4 + c], a.hi[1], x[c] * a.lo[1]);        // A rlo[1] + V rhi[1]
+            t2.mine(lane)[c] = pdwt_fma(dd[8 + c], a.hi[1], dd[c] * a.lo[1]);       // H rlo[1] + D rhi[1]
+        }
+    }
+    swt_shift_left<D>(t1, s1);
+    swt_shift_left<D>(t2, s2);
+    PDWT_WAVE_LANES(lane) {
+        const float* x = ain.mine(lane);
+        const float* dd = det.mine(lane);
+        float* cur = ring.mine(lane) + 8 * SLOT;
+        const float* old = ring.mine(lane) + 8 * OLD;
+        float* o = aout.mine(lane);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float u1 = pdwt_fma(x[c], a.lo[0], s1.mine(lane)[c]);
+            u1 = pdwt_fma(dd[4 + c], a.hi[0], u1);
+            float u2 = pdwt_fma(dd[c], a.lo[0], s2.mine(lane)[c]);
+            u2 = pdwt_fma(dd[8 + c], a.hi[0], u2);
+            cur[c] = 0.5f * u1;
+            cur[4 + c] = 0.5f * u2;
+            float r = old[c] * a.lo[1];
+            r = pdwt_fma(old[4 + c], a.hi[1], r);
+            r = pdwt_fma(cur[c], a.lo[0], r);
+            r = pdwt_fma(cur[4 + c], a.hi[0], r);
+            o[c] = 0.5f * r;
+        }
+    }
+}
+
+template <int K, int F0, int NRI, int R>
+PDWT_DEVICE void swt_inv_step(const SwtFusedArgs& a, SwtInvState<K, F0, NRI>& st, int g0, int i0, int rows_phase, int py, long long boff) {
+    using G = SwtFusedGeom<K, F0>;
+    using S = SwtInvState<K, F0, NRI>;
+    constexpr int NP = 1 + 3 * K;
+    const int r = g0 + R;  // row r of the walk = phase row i0 - W + r
+    {
+        int rr = i0 - G::W + r + S::NRI - 1;
+        rr = ((rr % rows_phase) + rows_phase) % rows_phase;
+        swt_inv_load<K, F0, NRI, (R + S::NRI - 1) % S::NRI>(a, st, boff, 4u * (unsigned)(py + F0 * rr) * (unsigned)a.Nc);
+    }
+    PDWT_ROW_FENCE();
+    WaveReg<float, 4> cur, nxt;
+    WaveReg<float, 12> det;
+    const float* none = nullptr;
+    auto take = [&](int plane0) {
+        PDWT_WAVE_LANES(lane) {
+            const float* v = st.ld.mine(lane) + 4 * NP * (R % S::NRI) + 4 * plane0;
+#pragma unroll
+            for (int i = 0; i < 12; ++i) det.mine(lane)[i] = v[i];
+        }
+    };
+    PDWT_WAVE_LANES(lane) {
+        const float* v = st.ld.mine(lane) + 4 * NP * (R % S::NRI);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) cur.mine(lane)[c] = v[c];
+    }
+    // deepest level of the group first; ring slots: all levels work on row r
+    if constexpr (K >= 3) {
+        take(1);
+        swt_inv_level<G::dist(2), 8, R % 8, 64>(a, cur, none, det, a.beta[2], st.ring3, nxt);
+        PDWT_WAVE_LANES(lane) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) cur.mine(lane)[c] = nxt.mine(lane)[c];
+        }
+    }
+    if constexpr (K >= 2) {
+        take(1 + 3 * (K - 2));
+        swt_inv_level<G::dist(1), 4, R % 4, 32>(a, cur, none, det, a.beta[1], st.ring2, nxt);
+        PDWT_WAVE_LANES(lane) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) cur.mine(lane)[c] = nxt.mine(lane)[c];
+        }
+    }
+    take(1 + 3 * (K - 1));
+    swt_inv_level<G::dist(0), 2, R % 2, 16>(a, cur, none, det, a.beta[0], st.ring1, nxt);
+    const int rel = r - G::W;  // output row relative to the segment
+    const bool ow = rel >= 0 && rel < a.seg_rows && i0 + rel < rows_phase;
+    const unsigned ro = ow ? 4u * (unsigned)(py + F0 * (i0 + rel)) * (unsigned)a.Nc : kSwtRowDropped;
+    PDWT_WAVE_LANES(lane) {
+        const float* v = nxt.mine(lane);
+        row_st16(st.bo, st.off.mine(lane)[1] + ro, v[0], v[1], v[2], v[3]);
+    }
+}
+
+template <int K, int F0, int NRI, int R>
+PDWT_DEVICE void swt_inv_group(const SwtFusedArgs& a, SwtInvState<K, F0, NRI>& st, int g0, int i0, int rows_phase, int py, long long boff) {
+    if constexpr (R < SwtFusedGeom<K, F0>::P) {
+        swt_inv_step<K, F0, NRI, R>(a, st, g0, i0, rows_phase, py, boff);
+        swt_inv_group<K, F0, NRI, R + 1>(a, st, g0, i0, rows_phase, py, boff);
+    }
+}
+
+// rows 0 .. NRI-2 of the walk into slots 0 .. NRI-2
+template <int K, int F0, int NRI, int I, class RowBytes>
+PDWT_DEVICE void swt_inv_preload(const SwtFusedArgs& a, SwtInvState<K, F0, NRI>& st, long long boff, const RowBytes& rowbytes) {
+    if constexpr (I < NRI - 1) {
+        swt_inv_load<K, F0, NRI, I>(a, st, boff, rowbytes(I));
+        swt_inv_preload<K, F0, NRI, I + 1>(a, st, boff, rowbytes);
+    }
+}
+
+template <int K, int F0, int NRI>
+PDWT_DEVICE void swt2_inv_fused(const SwtFusedArgs& a, long long w) {
+    using G = SwtFusedGeom<K, F0>;
+    const int strip = (int)(w % a.strips);
+    long long t = w / a.strips;
+    const int seg = (int)(t % a.segs);
+    t /= a.segs;
+    const int py = (int)(t % F0);
+    const long long img = t / F0;
+    const int rows_phase = a.Nr / F0;
+    const int i0 = seg * a.seg_rows;
+    const long long boff = img * a.bstride;
+    SwtInvState<K, F0, NRI> st;
+    PDWT_WAVE_LANES(lane) {
+        // the first halo_lanes lanes lack their left neighbours: lane halo_lanes owns column strip * 4 V
+        const int x = strip * 4 * G::V + 4 * (lane - G::halo_lanes);
+        const int xl = x < 0 ? x + a.Nc : (x >= a.Nc ? x - a.Nc : x);
+        st.off.mine(lane)[0] = 4u * (unsigned)xl;
+        st.off.mine(lane)[1] = (lane >= G::halo_lanes && x < a.Nc) ? 4u * (unsigned)x : kSwtLaneDropped;
+    }
+    st.bo = swt_plane(a.out, boff, a.Nr, a.Nc);
+    // rows 0 .. NRI-2 of the walk (phase rows i0 - W ...) in flight before the first step
+    {
+        auto rowbytes = [&](int i) { return 4u * (unsigned)(py + F0 * (((i0 - G::W + i) % rows_phase + rows_phase) % rows_phase)) * (unsigned)a.Nc; };
+        swt_inv_preload<K, F0, NRI, 0>(a, st, boff, rowbytes);
+    }
+    PDWT_WAIT_VMEM();
+    // W warm-up rows + seg_rows rows, in groups of P
+    const int ngroups = a.seg_rows / G::P + 1;
+    for (int g = 0; g < ngroups; ++g) swt_inv_group<K, F0, NRI, 0>(a, st, g * G::P, i0, rows_phase, py, boff);
+}
+
+#ifndef PDWT_CPU_EMU
+template <int K, int F0, int NT>
+__global__ void __launch_bounds__(NT, 1) swt2_fwd_fused_kernel(const SwtFusedArgs a, long long waves) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long long w = (long long)blockIdx.x * (NT / 64) + wave;
+    if (w < waves) swt2_fwd_fused<K, F0>(a, w);
+}
+template <int K, int F0, int NRI, int NT>
+__global__ void __launch_bounds__(NT, 1) swt2_inv_fused_kernel(const SwtFusedArgs a, long long waves) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long long w = (long long)blockIdx.x * (NT / 64) + wave;
+    if (w < waves) swt2_inv_fused<K, F0, NRI>(a, w);
+}
+#endif
+
+}  // namespace pdwt

@@ -10,6 +10,7 @@
 #include "../../pypwt_amd/csrc/dwt1_fused_kernels.hpp"
 #include "../../pypwt_amd/csrc/dwt1_kernels.hpp"
 #include "../../pypwt_amd/csrc/dwt1_reg_kernels.hpp"
+#include "../../pypwt_amd/csrc/swt2_fused_kernels.hpp"
 #include "../../pypwt_amd/csrc/dwt2_fast_kernels.hpp"
 #include "../../pypwt_amd/csrc/dwt2_kernels.hpp"
 #include "../../pypwt_amd/csrc/dwt2_pyramid_kernels.hpp"
@@ -624,6 +625,41 @@ EMU_API int emu_dwt1_inv_reg(const float* app, const float* det, int rows, int N
 #define X(h) Y(h, 1) Y(h, 2) Y(h, 3)
     X(2) X(4) X(6) X(8) X(10) X(12) X(14) X(16) X(18) X(20)
 #undef X
+#undef Y
+    return -1;
+}
+
+// ------------------------------------------------------------------ 2D SWT, 2-tap filters, two or three levels per launch
+template <int K, int F0>
+static void run_swt_fused(const SwtFusedArgs& a, int batch, bool inverse) {
+    const long long waves = (long long)batch * F0 * a.segs * a.strips;
+    for (long long w = 0; w < waves; w++) {
+        if (inverse) swt2_inv_fused<K, F0, 4>(a, w);
+        else swt2_fwd_fused<K, F0>(a, w);
+    }
+}
+
+// planes: forward  in -> det (K x [H, V, D] planes, level l0 first) and out;  inverse  in (A) + det -> out
+EMU_API int emu_swt2_fused(const float* in, float* det, float* out, int batch, int Nr, int Nc, int K, int f0, int seg_rows,
+                           const float* lo, const float* hi, const float* beta, int inverse) {
+    if (K < 2 || K > 3 || (f0 != 1 && f0 != 8) || (Nc % 4) || Nc < 256 || (Nr % f0) || seg_rows % (1 << K)) return -2;
+    SwtFusedArgs a;
+    const long long plane = (long long)Nr * Nc;
+    a.in = in; a.out = out; a.Nr = Nr; a.Nc = Nc; a.bstride = plane;
+    for (int k = 0; k < kSwtFusedMaxLevels; k++) {
+        a.H[k] = a.V[k] = a.D[k] = nullptr;
+        a.beta[k] = (beta && k < K) ? beta[k] : 0.f;
+    }
+    for (int k = 0; k < K; k++) {
+        a.H[k] = det + (3 * k + 0) * batch * plane;
+        a.V[k] = det + (3 * k + 1) * batch * plane;
+        a.D[k] = det + (3 * k + 2) * batch * plane;
+    }
+    a.lo[0] = lo[0]; a.lo[1] = lo[1]; a.hi[0] = hi[0]; a.hi[1] = hi[1];
+    a.seg_rows = seg_rows;
+    a.segs = (Nr / f0 + seg_rows - 1) / seg_rows;
+#define Y(k, f) if (K == k && f0 == f) { a.strips = (Nc + 4 * SwtFusedGeom<k, f>::V - 1) / (4 * SwtFusedGeom<k, f>::V); run_swt_fused<k, f>(a, batch, inverse != 0); return 0; }
+    Y(2, 1) Y(3, 1) Y(2, 8) Y(3, 8)
 #undef Y
     return -1;
 }

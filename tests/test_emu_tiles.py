@@ -528,3 +528,54 @@ def test_emu_dwt1_reg_inverse(wname):
         assert lib().emu_dwt1_inv_reg(P(bands[0]), P(det), rows, N0, K, P(rlo), P(rhi), hlen, bpw, P(out)) == 0
         assert np.isfinite(out).all(), (wname, rows, N0, K)
         assert np.abs(out - ref).max() <= _tol(ref) * (1 + K), (wname, rows, N0, K)
+
+
+# ----------------------------------------------------------------------------- 2D SWT, several levels per launch (2 taps)
+def _swt_fused_cases():
+    # (batch, Nr, Nc, l0, K, seg_rows): whole and ragged strips, partial last segments, phase rows (l0 = 4 -> f0 = 8)
+    return [(1, 32, 256, 1, 3, 8), (2, 24, 512, 1, 2, 8), (1, 40, 260, 1, 3, 16), (1, 64, 256, 4, 2, 8), (1, 128, 744, 4, 2, 8),
+            (1, 192, 256, 4, 3, 8), (1, 16, 1024, 1, 3, 8)]
+
+
+def test_emu_swt2_fused_forward_and_inverse():
+    """swt2_fwd_fused / swt2_inv_fused (haar levels l0 .. l0+K-1 in one launch, registers and lane shifts only) vs the
+    oracle's level-by-level SWT; the inverse also with a pending soft threshold on the details"""
+    hlen, dlo, dhi, rlo, rhi = oracle.filters("haar")
+    for si, (B, Nr, Nc, l0, K, seg) in enumerate(_swt_fused_cases()):
+        L = l0 + K - 1
+        f0 = 1 << (l0 - 1)
+        x = oracle.hash_input((B, Nr, Nc), 9100 + si)
+        refs = [oracle.forward(x[b], "haar", L, do_swt=1) for b in range(B)]          # [A_L, H1, V1, D1, ...]
+        prev = [oracle.forward(x[b], "haar", l0 - 1, do_swt=1)[0] if l0 > 1 else x[b] for b in range(B)]
+        ain = np.stack(prev).astype(np.float32)
+        det = np.full((3 * K, B, Nr, Nc), np.nan, dtype=np.float32)
+        out = np.full((B, Nr, Nc), np.nan, dtype=np.float32)
+        assert lib().emu_swt2_fused(P(ain), P(det), P(out), B, Nr, Nc, K, f0, seg, P(dlo), P(dhi), None, 0) == 0
+        for b in range(B):
+            assert np.isfinite(out[b]).all(), (si, "A")
+            assert np.abs(out[b] - refs[b][0]).max() <= _tol(refs[b][0]) * (1 + K), (si, "A")
+            for k in range(K):
+                for j in range(3):
+                    want = refs[b][1 + 3 * (l0 - 1 + k) + j]
+                    got = det[3 * k + j, b]
+                    assert np.isfinite(got).all(), (si, k, j)
+                    assert np.abs(got - want).max() <= _tol(want) * (1 + K), (si, k, j)
+        # inverse of arbitrary coefficients, with and without a pending soft threshold
+        for beta in (None, np.array([0.3, 0.2, 0.1], dtype=np.float32)):
+            aK = (oracle.hash_input((B, Nr, Nc), 9200 + si, 2.0) - 1.0).astype(np.float32)
+            dets = (oracle.hash_input((3 * K, B, Nr, Nc), 9300 + si, 2.0) - 1.0).astype(np.float32)
+            rec = np.full((B, Nr, Nc), np.nan, dtype=np.float32)
+            assert lib().emu_swt2_fused(P(aK), P(dets), P(rec), B, Nr, Nc, K, f0, seg, P(rlo), P(rhi),
+                                        P(beta) if beta is not None else None, 1) == 0
+            for b in range(B):
+                d = dets[:, b]
+                if beta is not None:  # x - clamp(x, -beta, beta), as the kernels and the oracle compute it
+                    d = np.stack([d[3 * k + j] - np.clip(d[3 * k + j], -beta[k], beta[k]) for k in range(K) for j in range(3)])
+                want = np.zeros((Nr, Nc), dtype=np.float32)
+                for py in range(f0):      # dilation f0 = the same transform on each of the f0 x f0 phase sub-images
+                    for px in range(f0):
+                        sub = [np.ascontiguousarray(aK[b][py::f0, px::f0])]
+                        sub += [np.ascontiguousarray(d[i][py::f0, px::f0]) for i in range(3 * K)]
+                        want[py::f0, px::f0] = oracle.inverse(sub, sub[0].shape, "haar", K, do_swt=1)
+                assert np.isfinite(rec[b]).all(), (si, "inverse")
+                assert np.abs(rec[b] - want).max() <= 4e-6 * (1 + K), (si, "inverse", beta is not None)

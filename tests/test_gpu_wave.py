@@ -153,3 +153,43 @@ def test_reg_1d_three_levels_in_registers_on_the_gpu():
             assert np.abs(w.image.reshape(x.shape) - x).max() < 7e-4 * (4 if wname == "db10" else 1), (wname, N)
     finally:
         lib.pdwt_set_tuning(b"reg1d", was)
+
+
+def test_swt_haar_levels_fused_per_launch_on_the_gpu():
+    """swt2_fwd_fused / swt2_inv_fused (2-tap 2D SWT, levels 1-3 and 4-6 in one launch each, registers + lane shifts)
+    against the oracle: coefficients of every level, reconstruction, and the deferred soft threshold folded into the
+    fused inverse; shapes with ragged strips, partial segments and a batch."""
+    from pypwt_amd import Wavelets, BatchedWavelets, _lib
+    lib = _lib.load()
+    was = lib.pdwt_set_tuning(b"swt_fused", 1)
+    try:
+        for shape, lv in (((64, 256), 3), ((128, 520), 5), ((96, 1024), 2), ((256, 256), 6), ((2048, 2048), 5), ((64, 260), 4)):
+            x = oracle.hash_input(shape, 8700 + lv)
+            w = Wavelets(x, "haar", lv, do_swt=1)
+            assert w.levels == lv
+            w.forward()
+            ref = oracle.forward(x, "haar", lv, do_swt=1)
+            for k, (g, r) in enumerate(zip(_flat(w.coeffs), ref)):
+                assert np.isfinite(g).all(), (shape, lv, k)
+                assert np.abs(g - r).max() <= 2e-6 * (1 + lv) * max(float(np.abs(r).max()), 255.0), (shape, lv, k)
+            w.inverse()
+            assert np.abs(w.image - x).max() < 2e-3, (shape, lv)
+            # forward, soft threshold (deferred, folded into the fused inverse), inverse vs the oracle's sequence
+            w.forward()
+            w.soft_threshold(12.5, 0, 1)
+            w.inverse()
+            thr = oracle.threshold(ref, shape, lv, "soft", 12.5, do_app=0, normalize=1, do_swt=1)
+            want = oracle.inverse(thr, shape, "haar", lv, do_swt=1)
+            assert np.abs(w.image - want).max() < 2e-3, (shape, lv, "soft")
+        xb = oracle.hash_input((3, 64, 512), 8790)
+        bw = BatchedWavelets(3, 64, 512, "haar", 5, do_swt=1, img=xb)
+        bw.forward()
+        for b in range(3):
+            ref = oracle.forward(xb[b], "haar", 5, do_swt=1)
+            for num in (0, 1, 9, 15):
+                assert np.abs(bw.coeff_at(num, b) - ref[num]).max() <= 2e-5 * max(float(np.abs(ref[num]).max()), 255.0), (b, num)
+        bw.inverse()
+        for b in range(3):
+            assert np.abs(bw.image_at(b) - xb[b]).max() < 2e-3
+    finally:
+        lib.pdwt_set_tuning(b"swt_fused", was)
