@@ -91,3 +91,44 @@ def test_fuzz_batched_plans(seed):
                 assert np.abs(g - r).max() <= 1e-5 * max(1.0, float(np.abs(r).max())), (wname, B, Nr, Nc, levels, swt, k)
         bw.inverse()
         assert np.abs(bw.image - x).max() <= (0.2 if wname.startswith("bior") else 4e-3)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_fuzz_register_kernels(seed):
+    """Shapes and wavelets that reach the register kernels of round 2: 1D rows of >= 2048 samples with short and
+    medium filters (dwt1_reg_kernels.hpp, 1-3 levels per launch, rows that are and are not whole blocks) and 2D SWT
+    with the 2-tap banks (swt2_fused_kernels.hpp, levels 1-3 / 4-6 per launch, ragged strips, phases); forward vs
+    the oracle, then soft threshold + inverse vs the oracle's sequence."""
+    from pypwt_amd import Wavelets
+    rng = np.random.default_rng(4200 + seed)
+    two_tap = ["haar", "db1", "bior1.1", "rbio1.1"]
+    short = ["haar", "db2", "db3", "db4", "sym4", "sym5", "coif1", "coif2", "db7", "sym8", "db9", "db10", "bior2.2", "bior4.4"]
+    for it in range(16):
+        if it % 2 == 0:
+            wname = str(rng.choice(short))
+            rows = int(rng.choice([1, 1, 2, 3]))
+            N = int(rng.choice([2048, 2080, 2112, 3072, 4096, 4128, 8192, 12288, 20000 // 32 * 32, 65536]))
+            levels = int(rng.integers(1, 8))
+            x = oracle.hash_input((rows, N), int(rng.integers(1, 1 << 30)), scale=255.0)
+            w = Wavelets(x if rows > 1 else x[0], wname, levels, ndim=1)
+            kw = dict(ndim=1)
+        else:
+            wname = str(rng.choice(two_tap))
+            shape = (int(rng.choice([64, 96, 128, 192, 256, 320])), int(rng.choice([256, 260, 320, 512, 744, 1000, 1024])))
+            levels = int(rng.integers(2, 7))
+            x = oracle.hash_input(shape, int(rng.integers(1, 1 << 30)), scale=255.0)
+            w = Wavelets(x, wname, levels, do_swt=1)
+            kw = dict(do_swt=1)
+        w.forward()
+        ref = oracle.forward(x, wname, w.levels, **kw)
+        xmax = float(np.abs(x).max())
+        for k, (g, r) in enumerate(zip(_flat(w.coeffs), ref)):
+            tol = 2e-6 * (1 + w.levels) * max(1.0, xmax, float(np.abs(r).max()))
+            assert np.isfinite(g).all() and np.abs(g.reshape(r.shape) - r).max() <= tol, (wname, x.shape, w.levels, k)
+        beta = float(rng.choice([0.0, 3.0, 20.0]))
+        norm = int(rng.integers(0, 2))
+        w.soft_threshold(beta, 0, norm)
+        w.inverse()
+        thr = oracle.threshold(ref, x.shape, w.levels, "soft", beta, do_app=0, normalize=norm, **kw)
+        want = oracle.inverse(thr, x.shape, wname, w.levels, **kw)
+        assert np.abs(w.image.reshape(want.shape) - want).max() <= 4e-3, (wname, x.shape, w.levels, beta, norm)

@@ -183,7 +183,7 @@ int main(int argc, char** argv) {
             w2.in_bstride = f.in_bstride; w2.l1_bstride = f.out_bstride; w2.l2_bstride = f2.out_bstride;
             w2.strips = (N + 239) / 240;
             bank(w2.fb, false);
-            for (int seg2 : {4, 8, 12, 16, 18, 24, 32}) {
+            for (int seg2 : {8, 12, 24, 32, 64, 128, 256, 512}) {
                 if (seg2 > N / 4) continue;
                 w2.seg2_out = seg2; w2.segs = (N / 4 + seg2 - 1) / seg2;
                 CK(hipMemset(co2, 0xff, n * sizeof(float)));
