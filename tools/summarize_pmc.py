@@ -34,6 +34,7 @@ def family(kernel):
     for sub, fam in (("fwd2_wave", "dwt2_fwd_wave2"), ("inv2_wave", "dwt2_inv_wave2"), ("fwd_pyr2", "dwt2_fwd_pyr2"), ("inv_pyr2", "dwt2_inv_pyr2"), ("fwd_strip2", "dwt2_fwd_strip2"),
                      ("inv_strip2", "dwt2_inv_strip2"), ("dwt1_fwd_fused", "dwt1_fwd_fused"),
                      ("dwt1_inv_fused", "dwt1_inv_fused"), ("dwt1_fwd_reg", "dwt1_fwd_reg"), ("dwt1_inv_reg", "dwt1_inv_reg"),
+                     ("swt2_fwd_fused", "swt2_fwd_fused"), ("swt2_inv_fused", "swt2_inv_fused"),
                      ("dwt2_fwd", "dwt2_fwd_level"), ("dwt2_inv", "dwt2_inv_level"),
                      ("dwt1_fwd", "dwt1_fwd_level"), ("dwt1_inv", "dwt1_inv_level"), ("swt2_fwd", "swt2_fwd_level"),
                      ("swt2_inv", "swt2_inv_level"), ("swt_pass_fwd", "swt1_fwd_level"), ("swt_pass_inv", "swt1_inv_level"),
