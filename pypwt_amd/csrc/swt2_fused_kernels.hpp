@@ -181,8 +181,11 @@ PDWT_DEVICE void swt_fwd_step(const SwtFusedArgs& a, SwtFwdState<K, F0>& st, con
     const int r = g0 + R;
     // request row r + NR - 1 (wrapped): its slot was consumed at the previous step
     {
-        int rr = i0 + r + G::NR - 1;
-        rr %= rows_phase;
+        // never past the last row this wavefront filters (seg_rows + W - 1): the tail of the walk re-requests that
+        // row (a cache hit) instead of rows nobody will use
+        int rr = r + G::NR - 1;
+        rr = rr < a.seg_rows + G::W ? rr : a.seg_rows + G::W - 1;
+        rr = (i0 + rr) % rows_phase;
         const float* row = in + (long long)(py + F0 * rr) * a.Nc;
         PDWT_WAVE_LANES(lane) {
             const v4f w = wave_ld16(row, st.off.mine(lane)[0]);
@@ -249,7 +252,10 @@ PDWT_DEVICE void swt2_fwd_fused(const SwtFusedArgs& a, long long w) {
     SwtFwdState<K, F0> st;
     PDWT_WAVE_LANES(lane) {
         const int x = strip * 4 * G::V + 4 * lane;
-        const int xl = x >= a.Nc ? x - a.Nc : x;                      // Nc % 4 == 0, strips * 4 V < 2 Nc
+        // columns past the row end wrap (Nc % 4 == 0, strips * 4 V < 2 Nc) as far as a valid lane's window reaches;
+        // further right nothing is used: those lanes re-read the row's last group (a cache hit, no extra traffic)
+        int xl = x >= a.Nc ? x - a.Nc : x;
+        if (x >= a.Nc + G::halo_cols + 3) xl = a.Nc - 4;
         st.off.mine(lane)[0] = 4u * (unsigned)xl;
         st.off.mine(lane)[1] = (lane < G::V && x < a.Nc) ? 4u * (unsigned)x : kSwtLaneDropped;
     }
@@ -368,7 +374,9 @@ PDWT_DEVICE void swt_inv_step(const SwtFusedArgs& a, SwtInvState<K, F0, NRI>& st
     constexpr int NP = 1 + 3 * K;
     const int r = g0 + R;  // row r of the walk = phase row i0 - W + r
     {
-        int rr = i0 - G::W + r + S::NRI - 1;
+        int rr = r + S::NRI - 1;
+        rr = rr < a.seg_rows + G::W ? rr : a.seg_rows + G::W - 1;  // see swt_fwd_step
+        rr = i0 - G::W + rr;
         rr = ((rr % rows_phase) + rows_phase) % rows_phase;
         swt_inv_load<K, F0, NRI, (R + S::NRI - 1) % S::NRI>(a, st, boff, 4u * (unsigned)(py + F0 * rr) * (unsigned)a.Nc);
     }
@@ -449,7 +457,8 @@ PDWT_DEVICE void swt2_inv_fused(const SwtFusedArgs& a, long long w) {
     PDWT_WAVE_LANES(lane) {
         // the first halo_lanes lanes lack their left neighbours: lane halo_lanes owns column strip * 4 V
         const int x = strip * 4 * G::V + 4 * (lane - G::halo_lanes);
-        const int xl = x < 0 ? x + a.Nc : (x >= a.Nc ? x - a.Nc : x);
+        // left of the row start: wrapped (the halo of the first columns); at or past the row end: nothing is used
+        const int xl = x < 0 ? x + a.Nc : (x >= a.Nc ? a.Nc - 4 : x);
         st.off.mine(lane)[0] = 4u * (unsigned)xl;
         st.off.mine(lane)[1] = (lane >= G::halo_lanes && x < a.Nc) ? 4u * (unsigned)x : kSwtLaneDropped;
     }
