@@ -35,7 +35,15 @@ constexpr int kWaveTarget = 1024;  // wavefronts per launch the segment length a
 
 // rows per wavefront: multiple of `unit`, about strips * ceil(rows / seg) * batch = kWaveTarget, at most 64
 static int pick_seg(int rows, int strips, int batch, int unit, int hint) {
-    long long seg = hint > 0 ? hint : ((long long)rows * strips * batch) / kWaveTarget;
+    // A level that lives in the Infinity Cache: about one wavefront per SIMD, at most 64 rows each.  A level of a batch
+    // beyond it (a wavefront moves 4 KiB per output row / coefficient row pair: 2^17 of them = 512 MiB; half that
+    // when the batch is large, i.e. every level is cold): every row then costs a wavefront an HBM round trip and
+    // 16-row walks of many wavefronts win -- 4 x 4096^2: 99 us at 16 rows against 105-108 at 32-64; the 512^2
+    // inverse level of 128 images: 67 us against 161 us in 67-row walks (profiles/r02y_wbench_b{2,4}.txt,
+    // r02z_bench_cfg5_shard.json vs r02y_bench_cfg5.json).
+    const long long work = (long long)rows * strips * batch;
+    const bool cold = work >= (1LL << 17) || (work >= (1LL << 16) && batch > 2);
+    long long seg = hint > 0 ? hint : (cold ? 16 : work / kWaveTarget);
     seg = (seg / unit) * unit;
     if (seg < unit) seg = unit;
     if (hint <= 0 && seg > 64) seg = (64 / unit) * unit;
