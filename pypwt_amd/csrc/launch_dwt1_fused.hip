@@ -73,7 +73,8 @@ hipError_t launch_dwt1_fwd_fused(const float* in, float* const* det, float* app,
 // ---- up to three levels per launch in registers (dwt1_reg_kernels.hpp)
 bool dwt1_reg_supported(int hlen, int N0, int K) {
     const int q = (4 << K) > 16 ? (4 << K) : 16;  // 16-B loads of whole lanes; every store unit inside its row
-    return !(hlen & 1) && hlen >= 2 && hlen <= kReg1MaxHlen && K >= 1 && K <= kReg1MaxLevels && N0 >= 2048 &&
+    static const int nmin = [] { const char* e = getenv("PDWT_REG1_MIN"); return e ? atoi(e) : 2048; }();  // tuning
+    return !(hlen & 1) && hlen >= 2 && hlen <= kReg1MaxHlen && K >= 1 && K <= kReg1MaxLevels && N0 >= nmin &&
            (N0 % q) == 0 && N0 < (1 << 29);
 }
 
