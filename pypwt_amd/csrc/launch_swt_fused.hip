@@ -37,22 +37,38 @@ static int fused_seg_rows(int K, int f0, int rows_phase, int strips, int batch) 
     return seg;
 }
 
+template <int K, int F0, int C>
+static hipError_t run_inv(SwtFusedArgs& a, int batch, hipStream_t s) {
+    constexpr int NT = 64;
+    a.strips = cdiv(a.Nc, C * SwtInvGeom<K, F0, C>::V);
+    const int rows_phase = a.Nr / F0;
+    a.seg_rows = fused_seg_rows(K, F0, rows_phase, a.strips, batch);
+    a.segs = cdiv(rows_phase, a.seg_rows);
+    const long long waves = (long long)batch * F0 * a.segs * a.strips;
+    hipLaunchKernelGGL((swt2_inv_fused_kernel<K, F0, 4, C, NT>), dim3((unsigned)waves), dim3(NT), 0, s, a, waves);
+    return hipGetLastError();
+}
+
 template <int K, int F0>
 static hipError_t run(SwtFusedArgs& a, bool inverse, int batch, hipStream_t s) {
     using G = SwtFusedGeom<K, F0>;
     constexpr int NT = 64;  // one wavefront per workgroup: up to 512 VGPRs each, placed on any free SIMD
+    if (inverse) {
+        // 16-B lanes.  8-B lanes (128-column strips: twice the wavefronts per segment length, half the registers) were
+        // built to afford longer segments for ONE image and measured no better: 2048^2 levels 1-3 49.1-51.8 us at
+        // 24-64 rows against 47.8 us (16-B lanes, 24 rows), levels 4-5 39.9-42.1 against 35.1-37.0 us
+        // (profiles/r02y_bench_cfg4_lanes_sweep.txt).  PDWT_SWT_CPL=2 selects them for re-measurement.
+        static const int forced = [] { const char* e = getenv("PDWT_SWT_CPL"); return e ? atoi(e) : 0; }();
+        const bool narrow = forced == 2;
+        return narrow ? run_inv<K, F0, 2>(a, batch, s) : run_inv<K, F0, 4>(a, batch, s);
+    }
     a.strips = cdiv(a.Nc, 4 * G::V);
     const int rows_phase = a.Nr / F0;
     a.seg_rows = fused_seg_rows(K, F0, rows_phase, a.strips, batch);
     a.segs = cdiv(rows_phase, a.seg_rows);
     const long long waves = (long long)batch * F0 * a.segs * a.strips;
     const unsigned grid = (unsigned)cdivll(waves, NT / 64);
-    // inverse: load slots (rows in flight + 1); PDWT_SWT_SLOTS=8 selects the deep variant of the 3-level kernels (A/B tuning)
-    static const int slots = [] { const char* e = getenv("PDWT_SWT_SLOTS"); return e ? atoi(e) : 4; }();
-    if (inverse && K == 3 && slots == 8) hipLaunchKernelGGL((swt2_inv_fused_kernel<K, F0, (K == 3 ? 8 : 4), NT>), dim3(grid), dim3(NT), 0, s, a, waves);
-    else if (inverse && slots == 2) hipLaunchKernelGGL((swt2_inv_fused_kernel<K, F0, 2, NT>), dim3(grid), dim3(NT), 0, s, a, waves);
-    else if (inverse) hipLaunchKernelGGL((swt2_inv_fused_kernel<K, F0, 4, NT>), dim3(grid), dim3(NT), 0, s, a, waves);
-    else hipLaunchKernelGGL((swt2_fwd_fused_kernel<K, F0, NT>), dim3(grid), dim3(NT), 0, s, a, waves);
+    hipLaunchKernelGGL((swt2_fwd_fused_kernel<K, F0, NT>), dim3(grid), dim3(NT), 0, s, a, waves);
     return hipGetLastError();
 }
 

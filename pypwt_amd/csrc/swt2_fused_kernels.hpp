@@ -94,32 +94,6 @@ PDWT_DEVICE void swt_shift_right(WaveReg<float, 4>& src, WaveReg<float, 4>& sh) 
         for (int c = 0; c < 4; ++c) sh.mine(lane)[c] = hop.mine(lane)[4 * ((c + D) / 4) + (c + D) % 4];
     }
 }
-// sh[c] = the value D columns to the LEFT of the lane's column c (inverse)
-template <int D>
-PDWT_DEVICE void swt_shift_left(WaveReg<float, 4>& src, WaveReg<float, 4>& sh) {
-    constexpr int M = (D + 3) / 4;
-    WaveReg<float, 4 * (M + 1)> hop;  // hop[m] = the row as lane - m holds it
-    PDWT_WAVE_LANES(lane) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) hop.mine(lane)[i] = src.mine(lane)[i];
-    }
-#pragma unroll
-    for (int m = 1; m <= M; ++m) {
-        PDWT_WAVE_LANES(lane) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) hop.mine(lane)[4 * m + i] = hop.from_prev(4 * (m - 1) + i, lane, 0.f);
-        }
-    }
-    PDWT_WAVE_LANES(lane) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            constexpr int kBig = 1 << 20;                      // keeps the C++ division / modulo non-negative
-            const int q = c - D + 4 * kBig;                    // column c - D, as lanes back (kBig - q / 4) and index q % 4
-            sh.mine(lane)[c] = hop.mine(lane)[4 * (kBig - q / 4) + q % 4];
-        }
-    }
-}
-
 // Store targets are ONE range-checked buffer descriptor per plane and image, built once per wavefront (a descriptor
 // per row and plane cost 4 SGPRs x 10 planes x 8 unrolled rows: hipcc spilled 250-450 SGPRs to VGPR lanes and the
 // loop was 60 % v_readlane / v_writelane).  The byte offset of a store = (uniform) row offset + (per-lane) column
@@ -288,34 +262,75 @@ PDWT_DEVICE void swt2_fwd_fused(const SwtFusedArgs& a, long long w) {
 }
 
 // ---------------------------------------------------------------------------------------------- inverse
-template <int K, int F0, int NRI_>
+// C = columns per lane: 4 (16-B accesses, strips of 256 columns; what the host launches) or 2 (8-B accesses, strips
+// of 128 columns: twice the wavefronts for the same segment length and half the registers -- built to afford longer
+// segments for one image, measured 3-8 % slower at every segment length, kept selectable for re-measurement).
+template <int K, int F0, int C>
+struct SwtInvGeom {
+    static_assert(C == 2 || C == 4, "8-B or 16-B lanes");
+    using G = SwtFusedGeom<K, F0>;
+    static constexpr int halo_lanes = (G::halo_cols + C - 1) / C;
+    static constexpr int V = 64 - halo_lanes;
+    static_assert(halo_lanes < 32, "strip wide enough");
+};
+
+// sh[c] = the value D columns to the LEFT of the lane's column c
+template <int D, int C>
+PDWT_DEVICE void swt_shift_left(WaveReg<float, C>& src, WaveReg<float, C>& sh) {
+    constexpr int M = (D + C - 1) / C;
+    WaveReg<float, C * (M + 1)> hop;  // hop[m] = the row as lane - m holds it
+    PDWT_WAVE_LANES(lane) {
+#pragma unroll
+        for (int i = 0; i < C; ++i) hop.mine(lane)[i] = src.mine(lane)[i];
+    }
+#pragma unroll
+    for (int m = 1; m <= M; ++m) {
+        PDWT_WAVE_LANES(lane) {
+#pragma unroll
+            for (int i = 0; i < C; ++i) hop.mine(lane)[C * m + i] = hop.from_prev(C * (m - 1) + i, lane, 0.f);
+        }
+    }
+    PDWT_WAVE_LANES(lane) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            constexpr int kBig = 1 << 20;                      // keeps the C++ division / modulo non-negative
+            const int q = c - D + C * kBig;                    // column c - D, as lanes back (kBig - q / C) and index q % C
+            sh.mine(lane)[c] = hop.mine(lane)[C * (kBig - q / C) + q % C];
+        }
+    }
+}
+
+template <int K, int F0, int NRI_, int C>
 struct SwtInvState {
     using G = SwtFusedGeom<K, F0>;
-    // load slots: the current row + NRI - 1 in flight, 1 + 3 K planes each.  One wavefront per SIMD (the rings
-    // and the slots take 280-490 VGPRs), so the rows in flight are ALL the latency hiding there is: 3 rows ahead
-    // measured 1.3 us per row and wavefront (3.6 TB/s for levels 1-3 of 2048^2), one round trip per 3 rows.  A
-    // wavefront can have 63 vector-memory operations outstanding: 6 rows of 10 loads.
+    // load slots: the current row + NRI - 1 in flight, 1 + 3 K planes each.  8 slots (C = 4: 476 VGPRs, 256 SGPRs
+    // spilled) measured 15 % slower than 4, 2 slots the same as 4 (profiles/r02w_bench_cfg4_fused_sweep.txt).
     static constexpr int NRI = NRI_;
     static_assert(G::P % NRI_ == 0, "static slot numbers");
-    WaveReg<float, 4 * NRI*(1 + 3 * K)> ld;             // [slot][plane][4]: plane 0 = A, then H, V, D of the group's levels, deepest first
-    WaveReg<float, 8 * 2> ring1;                        // (u1, u2) rows of level 1 of the group
-    WaveReg<float, 8 * 4> ring2;
-    WaveReg<float, 8 * 8> ring3;
+    WaveReg<float, C * NRI*(1 + 3 * K)> ld;             // [slot][plane][C]: plane 0 = A, then H, V, D of the group's levels, deepest first
+    WaveReg<float, 2 * C * 2> ring1;                    // (u1, u2) rows of level 1 of the group
+    WaveReg<float, 2 * C * 4> ring2;
+    WaveReg<float, 2 * C * 8> ring3;
     WaveReg<unsigned, 2> off;
     RowBuf bo;                                          // the output plane of this wavefront's image
 };
 
 // all planes of input row `ro` (byte offset of the row in a plane of this image) into load slot SLOT
-template <int K, int F0, int NRI, int SLOT>
-PDWT_DEVICE void swt_inv_load(const SwtFusedArgs& a, SwtInvState<K, F0, NRI>& st, long long boff, unsigned ro) {
+template <int K, int F0, int NRI, int C, int SLOT>
+PDWT_DEVICE void swt_inv_load(const SwtFusedArgs& a, SwtInvState<K, F0, NRI, C>& st, long long boff, unsigned ro) {
     constexpr int NP = 1 + 3 * K;
     PDWT_WAVE_LANES(lane) {
         const unsigned o = st.off.mine(lane)[0] + ro;
-        float* base = st.ld.mine(lane) + 4 * NP * SLOT;
+        float* base = st.ld.mine(lane) + C * NP * SLOT;
         auto put = [&](int p, const float* plane) {
-            const v4f w = wave_ld16(plane + boff, o);
-            float* v = base + 4 * p;
-            v[0] = w.x; v[1] = w.y; v[2] = w.z; v[3] = w.w;
+            float* v = base + C * p;
+            if constexpr (C == 4) {
+                const v4f w = wave_ld16(plane + boff, o);
+                v[0] = w.x; v[1] = w.y; v[2] = w.z; v[3] = w.w;
+            } else {
+                const v2f w = wave_ld8(plane + boff, o);
+                v[0] = w.x; v[1] = w.y;
+            }
         };
         put(0, a.in);
 #pragma unroll
@@ -330,52 +345,52 @@ PDWT_DEVICE void swt_inv_load(const SwtFusedArgs& a, SwtInvState<K, F0, NRI>& st
 
 // one synthesis level on the current row: ain (approximation row) + the level's details (thresholded) -> aout;
 // the (u1, u2) row goes into ring slot SLOT, the row LAG = RD / 2 phase rows earlier is its column partner
-template <int D, int RD, int SLOT, int NRING>
-PDWT_DEVICE void swt_inv_level(const SwtFusedArgs& a, WaveReg<float, 4>& ain, const float* /*unused*/, WaveReg<float, 12>& det, float beta,
-                               WaveReg<float, NRING>& ring, WaveReg<float, 4>& aout) {
+template <int D, int RD, int SLOT, int C, int NRING>
+PDWT_DEVICE void swt_inv_level(const SwtFusedArgs& a, WaveReg<float, C>& ain, WaveReg<float, 3 * C>& det, float beta,
+                               WaveReg<float, NRING>& ring, WaveReg<float, C>& aout) {
     constexpr int LAG = RD / 2, OLD = (SLOT - LAG + RD) % RD;
     // the two terms of the row synthesis that come from D columns to the left, combined where they live
-    WaveReg<float, 4> t1, t2, s1, s2;
+    WaveReg<float, C> t1, t2, s1, s2;
     PDWT_WAVE_LANES(lane) {
         const float* x = ain.mine(lane);
-        float* dd = det.mine(lane);
+        float* dd = det.mine(lane);   // [H | V | D]
 #pragma unroll
-        for (int i = 0; i < 12; ++i) dd[i] = soft_shrink(dd[i], beta);
+        for (int i = 0; i < 3 * C; ++i) dd[i] = soft_shrink(dd[i], beta);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            t1.mine(lane)[c] = pdwt_fma(dd[4 + c], a.hi[1], x[c] * a.lo[1]);        // A rlo[1] + V rhi[1]
-            t2.mine(lane)[c] = pdwt_fma(dd[8 + c], a.hi[1], dd[c] * a.lo[1]);       // H rlo[1] + D rhi[1]
+        for (int c = 0; c < C; ++c) {
+            t1.mine(lane)[c] = pdwt_fma(dd[C + c], a.hi[1], x[c] * a.lo[1]);          // A rlo[1] + V rhi[1]
+            t2.mine(lane)[c] = pdwt_fma(dd[2 * C + c], a.hi[1], dd[c] * a.lo[1]);     // H rlo[1] + D rhi[1]
         }
     }
-    swt_shift_left<D>(t1, s1);
-    swt_shift_left<D>(t2, s2);
+    swt_shift_left<D, C>(t1, s1);
+    swt_shift_left<D, C>(t2, s2);
     PDWT_WAVE_LANES(lane) {
         const float* x = ain.mine(lane);
         const float* dd = det.mine(lane);
-        float* cur = ring.mine(lane) + 8 * SLOT;
-        const float* old = ring.mine(lane) + 8 * OLD;
+        float* cur = ring.mine(lane) + 2 * C * SLOT;
+        const float* old = ring.mine(lane) + 2 * C * OLD;
         float* o = aout.mine(lane);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
+        for (int c = 0; c < C; ++c) {
             float u1 = pdwt_fma(x[c], a.lo[0], s1.mine(lane)[c]);
-            u1 = pdwt_fma(dd[4 + c], a.hi[0], u1);
+            u1 = pdwt_fma(dd[C + c], a.hi[0], u1);
             float u2 = pdwt_fma(dd[c], a.lo[0], s2.mine(lane)[c]);
-            u2 = pdwt_fma(dd[8 + c], a.hi[0], u2);
+            u2 = pdwt_fma(dd[2 * C + c], a.hi[0], u2);
             cur[c] = 0.5f * u1;
-            cur[4 + c] = 0.5f * u2;
+            cur[C + c] = 0.5f * u2;
             float r = old[c] * a.lo[1];
-            r = pdwt_fma(old[4 + c], a.hi[1], r);
+            r = pdwt_fma(old[C + c], a.hi[1], r);
             r = pdwt_fma(cur[c], a.lo[0], r);
-            r = pdwt_fma(cur[4 + c], a.hi[0], r);
+            r = pdwt_fma(cur[C + c], a.hi[0], r);
             o[c] = 0.5f * r;
         }
     }
 }
 
-template <int K, int F0, int NRI, int R>
-PDWT_DEVICE void swt_inv_step(const SwtFusedArgs& a, SwtInvState<K, F0, NRI>& st, int g0, int i0, int rows_phase, int py, long long boff) {
+template <int K, int F0, int NRI, int C, int R>
+PDWT_DEVICE void swt_inv_step(const SwtFusedArgs& a, SwtInvState<K, F0, NRI, C>& st, int g0, int i0, int rows_phase, int py, long long boff) {
     using G = SwtFusedGeom<K, F0>;
-    using S = SwtInvState<K, F0, NRI>;
+    using S = SwtInvState<K, F0, NRI, C>;
     constexpr int NP = 1 + 3 * K;
     const int r = g0 + R;  // row r of the walk = phase row i0 - W + r
     {
@@ -383,72 +398,74 @@ PDWT_DEVICE void swt_inv_step(const SwtFusedArgs& a, SwtInvState<K, F0, NRI>& st
         rr = rr < a.seg_rows + G::W ? rr : a.seg_rows + G::W - 1;  // see swt_fwd_step
         rr = i0 - G::W + rr;
         rr = ((rr % rows_phase) + rows_phase) % rows_phase;
-        swt_inv_load<K, F0, NRI, (R + S::NRI - 1) % S::NRI>(a, st, boff, 4u * (unsigned)(py + F0 * rr) * (unsigned)a.Nc);
+        swt_inv_load<K, F0, NRI, C, (R + S::NRI - 1) % S::NRI>(a, st, boff, 4u * (unsigned)(py + F0 * rr) * (unsigned)a.Nc);
     }
     PDWT_ROW_FENCE();
-    WaveReg<float, 4> cur, nxt;
-    WaveReg<float, 12> det;
-    const float* none = nullptr;
+    WaveReg<float, C> cur, nxt;
+    WaveReg<float, 3 * C> det;
     auto take = [&](int plane0) {
         PDWT_WAVE_LANES(lane) {
-            const float* v = st.ld.mine(lane) + 4 * NP * (R % S::NRI) + 4 * plane0;
+            const float* v = st.ld.mine(lane) + C * NP * (R % S::NRI) + C * plane0;
 #pragma unroll
-            for (int i = 0; i < 12; ++i) det.mine(lane)[i] = v[i];
+            for (int i = 0; i < 3 * C; ++i) det.mine(lane)[i] = v[i];
         }
     };
     PDWT_WAVE_LANES(lane) {
-        const float* v = st.ld.mine(lane) + 4 * NP * (R % S::NRI);
+        const float* v = st.ld.mine(lane) + C * NP * (R % S::NRI);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) cur.mine(lane)[c] = v[c];
+        for (int c = 0; c < C; ++c) cur.mine(lane)[c] = v[c];
     }
     // deepest level of the group first; ring slots: all levels work on row r
     if constexpr (K >= 3) {
         take(1);
-        swt_inv_level<G::dist(2), 8, R % 8, 64>(a, cur, none, det, a.beta[2], st.ring3, nxt);
+        swt_inv_level<G::dist(2), 8, R % 8, C>(a, cur, det, a.beta[2], st.ring3, nxt);
         PDWT_WAVE_LANES(lane) {
 #pragma unroll
-            for (int c = 0; c < 4; ++c) cur.mine(lane)[c] = nxt.mine(lane)[c];
+            for (int c = 0; c < C; ++c) cur.mine(lane)[c] = nxt.mine(lane)[c];
         }
     }
     if constexpr (K >= 2) {
         take(1 + 3 * (K - 2));
-        swt_inv_level<G::dist(1), 4, R % 4, 32>(a, cur, none, det, a.beta[1], st.ring2, nxt);
+        swt_inv_level<G::dist(1), 4, R % 4, C>(a, cur, det, a.beta[1], st.ring2, nxt);
         PDWT_WAVE_LANES(lane) {
 #pragma unroll
-            for (int c = 0; c < 4; ++c) cur.mine(lane)[c] = nxt.mine(lane)[c];
+            for (int c = 0; c < C; ++c) cur.mine(lane)[c] = nxt.mine(lane)[c];
         }
     }
     take(1 + 3 * (K - 1));
-    swt_inv_level<G::dist(0), 2, R % 2, 16>(a, cur, none, det, a.beta[0], st.ring1, nxt);
+    swt_inv_level<G::dist(0), 2, R % 2, C>(a, cur, det, a.beta[0], st.ring1, nxt);
     const int rel = r - G::W;  // output row relative to the segment
     const bool ow = rel >= 0 && rel < a.seg_rows && i0 + rel < rows_phase;
     const unsigned ro = ow ? 4u * (unsigned)(py + F0 * (i0 + rel)) * (unsigned)a.Nc : kSwtRowDropped;
     PDWT_WAVE_LANES(lane) {
         const float* v = nxt.mine(lane);
-        row_st16(st.bo, st.off.mine(lane)[1] + ro, v[0], v[1], v[2], v[3]);
+        if constexpr (C == 4) row_st16(st.bo, st.off.mine(lane)[1] + ro, v[0], v[1], v[2], v[3]);
+        else row_st8(st.bo, st.off.mine(lane)[1] + ro, v[0], v[1]);
     }
 }
 
-template <int K, int F0, int NRI, int R>
-PDWT_DEVICE void swt_inv_group(const SwtFusedArgs& a, SwtInvState<K, F0, NRI>& st, int g0, int i0, int rows_phase, int py, long long boff) {
+template <int K, int F0, int NRI, int C, int R>
+PDWT_DEVICE void swt_inv_group(const SwtFusedArgs& a, SwtInvState<K, F0, NRI, C>& st, int g0, int i0, int rows_phase, int py, long long boff) {
     if constexpr (R < SwtFusedGeom<K, F0>::P) {
-        swt_inv_step<K, F0, NRI, R>(a, st, g0, i0, rows_phase, py, boff);
-        swt_inv_group<K, F0, NRI, R + 1>(a, st, g0, i0, rows_phase, py, boff);
+        swt_inv_step<K, F0, NRI, C, R>(a, st, g0, i0, rows_phase, py, boff);
+        swt_inv_group<K, F0, NRI, C, R + 1>(a, st, g0, i0, rows_phase, py, boff);
     }
 }
 
 // rows 0 .. NRI-2 of the walk into slots 0 .. NRI-2
-template <int K, int F0, int NRI, int I, class RowBytes>
-PDWT_DEVICE void swt_inv_preload(const SwtFusedArgs& a, SwtInvState<K, F0, NRI>& st, long long boff, const RowBytes& rowbytes) {
+template <int K, int F0, int NRI, int C, int I, class RowBytes>
+PDWT_DEVICE void swt_inv_preload(const SwtFusedArgs& a, SwtInvState<K, F0, NRI, C>& st, long long boff, const RowBytes& rowbytes) {
     if constexpr (I < NRI - 1) {
-        swt_inv_load<K, F0, NRI, I>(a, st, boff, rowbytes(I));
-        swt_inv_preload<K, F0, NRI, I + 1>(a, st, boff, rowbytes);
+        swt_inv_load<K, F0, NRI, C, I>(a, st, boff, rowbytes(I));
+        swt_inv_preload<K, F0, NRI, C, I + 1>(a, st, boff, rowbytes);
     }
 }
 
-template <int K, int F0, int NRI>
+// a.strips = ceil(Nc / (C V)) with V of SwtInvGeom<K, F0, C>
+template <int K, int F0, int NRI, int C>
 PDWT_DEVICE void swt2_inv_fused(const SwtFusedArgs& a, long long w) {
     using G = SwtFusedGeom<K, F0>;
+    using GI = SwtInvGeom<K, F0, C>;
     const int strip = (int)(w % a.strips);
     long long t = w / a.strips;
     const int seg = (int)(t % a.segs);
@@ -458,25 +475,25 @@ PDWT_DEVICE void swt2_inv_fused(const SwtFusedArgs& a, long long w) {
     const int rows_phase = a.Nr / F0;
     const int i0 = seg * a.seg_rows;
     const long long boff = img * a.bstride;
-    SwtInvState<K, F0, NRI> st;
+    SwtInvState<K, F0, NRI, C> st;
     PDWT_WAVE_LANES(lane) {
-        // the first halo_lanes lanes lack their left neighbours: lane halo_lanes owns column strip * 4 V
-        const int x = strip * 4 * G::V + 4 * (lane - G::halo_lanes);
+        // the first halo_lanes lanes lack their left neighbours: lane halo_lanes owns column strip * C V
+        const int x = strip * C * GI::V + C * (lane - GI::halo_lanes);
         // left of the row start: wrapped (the halo of the first columns); at or past the row end: nothing is used
-        const int xl = x < 0 ? x + a.Nc : (x >= a.Nc ? a.Nc - 4 : x);
+        const int xl = x < 0 ? x + a.Nc : (x >= a.Nc ? a.Nc - C : x);
         st.off.mine(lane)[0] = 4u * (unsigned)xl;
-        st.off.mine(lane)[1] = (lane >= G::halo_lanes && x < a.Nc) ? 4u * (unsigned)x : kSwtLaneDropped;
+        st.off.mine(lane)[1] = (lane >= GI::halo_lanes && x < a.Nc) ? 4u * (unsigned)x : kSwtLaneDropped;
     }
     st.bo = swt_plane(a.out, boff, a.Nr, a.Nc);
     // rows 0 .. NRI-2 of the walk (phase rows i0 - W ...) in flight before the first step
     {
         auto rowbytes = [&](int i) { return 4u * (unsigned)(py + F0 * (((i0 - G::W + i) % rows_phase + rows_phase) % rows_phase)) * (unsigned)a.Nc; };
-        swt_inv_preload<K, F0, NRI, 0>(a, st, boff, rowbytes);
+        swt_inv_preload<K, F0, NRI, C, 0>(a, st, boff, rowbytes);
     }
     PDWT_WAIT_VMEM();
     // W warm-up rows + seg_rows rows, in groups of P
     const int ngroups = a.seg_rows / G::P + 1;
-    for (int g = 0; g < ngroups; ++g) swt_inv_group<K, F0, NRI, 0>(a, st, g * G::P, i0, rows_phase, py, boff);
+    for (int g = 0; g < ngroups; ++g) swt_inv_group<K, F0, NRI, C, 0>(a, st, g * G::P, i0, rows_phase, py, boff);
 }
 
 #ifndef PDWT_CPU_EMU
@@ -486,11 +503,11 @@ __global__ void __launch_bounds__(NT, 1) swt2_fwd_fused_kernel(const SwtFusedArg
     const long long w = (long long)blockIdx.x * (NT / 64) + wave;
     if (w < waves) swt2_fwd_fused<K, F0>(a, w);
 }
-template <int K, int F0, int NRI, int NT>
+template <int K, int F0, int NRI, int C, int NT>
 __global__ void __launch_bounds__(NT, 1) swt2_inv_fused_kernel(const SwtFusedArgs a, long long waves) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long long w = (long long)blockIdx.x * (NT / 64) + wave;
-    if (w < waves) swt2_inv_fused<K, F0, NRI>(a, w);
+    if (w < waves) swt2_inv_fused<K, F0, NRI, C>(a, w);
 }
 #endif
 

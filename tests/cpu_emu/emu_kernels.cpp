@@ -631,17 +631,21 @@ EMU_API int emu_dwt1_inv_reg(const float* app, const float* det, int rows, int N
 
 // ------------------------------------------------------------------ 2D SWT, 2-tap filters, two or three levels per launch
 template <int K, int F0>
-static void run_swt_fused(const SwtFusedArgs& a, int batch, bool inverse) {
+static void run_swt_fused(SwtFusedArgs& a, int batch, bool inverse, int cpl) {
+    if (inverse) a.strips = cpl == 2 ? (a.Nc + 2 * SwtInvGeom<K, F0, 2>::V - 1) / (2 * SwtInvGeom<K, F0, 2>::V)
+                                     : (a.Nc + 4 * SwtInvGeom<K, F0, 4>::V - 1) / (4 * SwtInvGeom<K, F0, 4>::V);
+    else a.strips = (a.Nc + 4 * SwtFusedGeom<K, F0>::V - 1) / (4 * SwtFusedGeom<K, F0>::V);
     const long long waves = (long long)batch * F0 * a.segs * a.strips;
     for (long long w = 0; w < waves; w++) {
-        if (inverse) swt2_inv_fused<K, F0, 4>(a, w);
-        else swt2_fwd_fused<K, F0>(a, w);
+        if (!inverse) swt2_fwd_fused<K, F0>(a, w);
+        else if (cpl == 2) swt2_inv_fused<K, F0, 4, 2>(a, w);
+        else swt2_inv_fused<K, F0, 4, 4>(a, w);
     }
 }
 
 // planes: forward  in -> det (K x [H, V, D] planes, level l0 first) and out;  inverse  in (A) + det -> out
 EMU_API int emu_swt2_fused(const float* in, float* det, float* out, int batch, int Nr, int Nc, int K, int f0, int seg_rows,
-                           const float* lo, const float* hi, const float* beta, int inverse) {
+                           const float* lo, const float* hi, const float* beta, int inverse, int cpl) {
     if (K < 2 || K > 3 || (f0 != 1 && f0 != 8) || (Nc % 4) || Nc < 256 || (Nr % f0) || seg_rows % (1 << K)) return -2;
     SwtFusedArgs a;
     const long long plane = (long long)Nr * Nc;
@@ -658,7 +662,7 @@ EMU_API int emu_swt2_fused(const float* in, float* det, float* out, int batch, i
     a.lo[0] = lo[0]; a.lo[1] = lo[1]; a.hi[0] = hi[0]; a.hi[1] = hi[1];
     a.seg_rows = seg_rows;
     a.segs = (Nr / f0 + seg_rows - 1) / seg_rows;
-#define Y(k, f) if (K == k && f0 == f) { a.strips = (Nc + 4 * SwtFusedGeom<k, f>::V - 1) / (4 * SwtFusedGeom<k, f>::V); run_swt_fused<k, f>(a, batch, inverse != 0); return 0; }
+#define Y(k, f) if (K == k && f0 == f) { run_swt_fused<k, f>(a, batch, inverse != 0, cpl); return 0; }
     Y(2, 1) Y(3, 1) Y(2, 8) Y(3, 8)
 #undef Y
     return -1;

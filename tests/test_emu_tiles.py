@@ -550,7 +550,7 @@ def test_emu_swt2_fused_forward_and_inverse():
         ain = np.stack(prev).astype(np.float32)
         det = np.full((3 * K, B, Nr, Nc), np.nan, dtype=np.float32)
         out = np.full((B, Nr, Nc), np.nan, dtype=np.float32)
-        assert lib().emu_swt2_fused(P(ain), P(det), P(out), B, Nr, Nc, K, f0, seg, P(dlo), P(dhi), None, 0) == 0
+        assert lib().emu_swt2_fused(P(ain), P(det), P(out), B, Nr, Nc, K, f0, seg, P(dlo), P(dhi), None, 0, 4) == 0
         for b in range(B):
             assert np.isfinite(out[b]).all(), (si, "A")
             assert np.abs(out[b] - refs[b][0]).max() <= _tol(refs[b][0]) * (1 + K), (si, "A")
@@ -561,12 +561,13 @@ def test_emu_swt2_fused_forward_and_inverse():
                     assert np.isfinite(got).all(), (si, k, j)
                     assert np.abs(got - want).max() <= _tol(want) * (1 + K), (si, k, j)
         # inverse of arbitrary coefficients, with and without a pending soft threshold
-        for beta in (None, np.array([0.3, 0.2, 0.1], dtype=np.float32)):
+        for beta, cpl in ((None, 4), (np.array([0.3, 0.2, 0.1], dtype=np.float32), 4), (None, 2),
+                          (np.array([0.3, 0.2, 0.1], dtype=np.float32), 2)):  # cpl: 16-B or 8-B lanes
             aK = (oracle.hash_input((B, Nr, Nc), 9200 + si, 2.0) - 1.0).astype(np.float32)
             dets = (oracle.hash_input((3 * K, B, Nr, Nc), 9300 + si, 2.0) - 1.0).astype(np.float32)
             rec = np.full((B, Nr, Nc), np.nan, dtype=np.float32)
             assert lib().emu_swt2_fused(P(aK), P(dets), P(rec), B, Nr, Nc, K, f0, seg, P(rlo), P(rhi),
-                                        P(beta) if beta is not None else None, 1) == 0
+                                        P(beta) if beta is not None else None, 1, cpl) == 0
             for b in range(B):
                 d = dets[:, b]
                 if beta is not None:  # x - clamp(x, -beta, beta), as the kernels and the oracle compute it
@@ -578,4 +579,4 @@ def test_emu_swt2_fused_forward_and_inverse():
                         sub += [np.ascontiguousarray(d[i][py::f0, px::f0]) for i in range(3 * K)]
                         want[py::f0, px::f0] = oracle.inverse(sub, sub[0].shape, "haar", K, do_swt=1)
                 assert np.isfinite(rec[b]).all(), (si, "inverse")
-                assert np.abs(rec[b] - want).max() <= 4e-6 * (1 + K), (si, "inverse", beta is not None)
+                assert np.abs(rec[b] - want).max() <= 4e-6 * (1 + K), (si, "inverse", beta is not None, cpl)
