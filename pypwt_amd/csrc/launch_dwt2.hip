@@ -98,7 +98,7 @@ static std::atomic<int>& swt_fused_flag() {
     static std::atomic<int> v{getenv("PDWT_SWT_FUSED") ? atoi(getenv("PDWT_SWT_FUSED")) : 1};
     return v;
 }
-int set_swt_fused_enabled(int value) { return swt_fused_flag().exchange(value ? 1 : 0); }
+int set_swt_fused_enabled(int value) { return swt_fused_flag().exchange(value < 0 ? 0 : (value > 2 ? 2 : value)); }
 int get_swt_fused_enabled() { return swt_fused_flag().load(std::memory_order_relaxed); }
 static std::atomic<int>& reg1d_flag() {
     static std::atomic<int> v{getenv("PDWT_REG1D") ? atoi(getenv("PDWT_REG1D")) : 3};

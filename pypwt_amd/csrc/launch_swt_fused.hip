@@ -32,6 +32,10 @@ static int fused_seg_rows(int K, int f0, int rows_phase, int strips, int batch) 
         auto waves = [&](int s) { return (long long)batch * f0 * strips * ((rows_phase + s - 1) / s); };
         seg = 256;
         while (seg > P && waves(seg) < 768) seg -= P;
+        // a batch beyond the Infinity Cache (more than 2^26 samples per launch): every row is an HBM round trip for its
+        // wavefront, long walks of few wavefronts starve the memory system (4 x 2048^2, levels 4-5: 189 us at 88-row
+        // walks) -- at most 32 rows
+        if ((long long)batch * rows_phase * f0 * strips * 256 > (1LL << 26) && seg > 32) seg = 32 / P * P;
     }
     if (seg > rows_phase) seg = (rows_phase + P - 1) / P * P;
     return seg;

@@ -345,8 +345,14 @@ void build_schedule(pdwt_plan* p) {
         // 2-tap SWT: levels 1-3 and 4-6 in one launch each (swt2_fused_kernels.hpp).  The approximations between
         // groups live in the two ping-pong planes (slot l & 1): a two-level group in the MIDDLE would read and
         // write the same plane, so it is only taken next to the image or to band 0.
+        // Only while the transform's planes (3 L + 2 of them) about fit the 256 MiB Infinity Cache: the fused kernels
+        // keep 7-10 output (input) streams per wavefront going, 1 KiB per row each, which HBM serves badly once the
+        // planes are cold -- two 2048^2 images: 343 us fused against 329 us level by level, four: 746 against 715 us,
+        // one: 137 against 183 us (profiles/r02y_bench_cfg4_batch.txt).
+        const long long swt_bytes = 4LL * (3 * L + 2) * p->batch * p->info.Nr * p->info.Nc;
         auto swt_group = [&](int l) {
             if (!swt || !p->do_separable || !get_swt_fused_enabled() || (l != 1 && l != 4)) return 0;
+            if (swt_bytes > (320LL << 20) && get_swt_fused_enabled() < 2) return 0;  // "swt_fused" = 2 forces (tests)
             for (int K = (L - l + 1 < 3 ? L - l + 1 : 3); K >= 2; --K) {
                 const bool same_plane = K == 2 && l - 1 >= 1 && l + K - 1 <= L - 1;
                 if (!same_plane && swt2_fused_supported(hlen, p->info.Nr, p->info.Nc, l, K)) return K;

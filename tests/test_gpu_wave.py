@@ -161,7 +161,7 @@ def test_swt_haar_levels_fused_per_launch_on_the_gpu():
     fused inverse; shapes with ragged strips, partial segments and a batch."""
     from pypwt_amd import Wavelets, BatchedWavelets, _lib
     lib = _lib.load()
-    was = lib.pdwt_set_tuning(b"swt_fused", 1)
+    was = lib.pdwt_set_tuning(b"swt_fused", 2)  # 2: also beyond the cache-size limit of the default dispatch
     try:
         for shape, lv in (((64, 256), 3), ((128, 520), 5), ((96, 1024), 2), ((256, 256), 6), ((2048, 2048), 5), ((64, 260), 4)):
             x = oracle.hash_input(shape, 8700 + lv)
