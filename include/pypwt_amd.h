@@ -187,7 +187,8 @@ int pdwt_time_level(pdwt_handle h, int level, int inverse, int reps, float* ms_p
  *   "reg1d"          bit 0 / bit 1: the forward / inverse 1D DWT levels run three at a time in registers
  *                    (dwt1_reg_kernels.hpp) where the rows qualify (even hlen <= 20, rows of >= 2048 samples that
  *                    are multiples of 32); default 3; 0 = the workgroup-wide LDS pyramids (57.6 vs 69.5 us per
- *                    forward+inverse on 2^24 samples).  Read when a plan is created.
+ *                    forward+inverse on 2^24 samples); the forward uses them up to 2^25 samples per plan (a batch of
+ *                    long rows is faster through the LDS pyramid), bit 2 lifts that limit.  Read when a plan is created.
  *   "swt_fused"      1 (default): 2D SWT plans with a 2-tap filter bank (haar) whose 3L+2 planes about fit the
  *                    Infinity Cache (<= 320 MiB) run levels 1-3 and 4-6 in one launch each (swt2_fused_kernels.hpp:
  *                    11 / 8 instead of 15 / 10 planes of traffic); 2: at any size; 0: a launch per level.  Read when
