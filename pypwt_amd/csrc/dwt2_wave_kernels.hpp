@@ -55,6 +55,19 @@ static __device__ __forceinline__ float dpp_from_next(float v, float fill) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, fill),
                                                                  __builtin_bit_cast(int, v), 0x130, 0xF, 0xF, false));
 }
+// fp64 values move as two 32-bit halves
+static __device__ __forceinline__ double dpp_from_prev(double v, double fill) {
+    const unsigned long long a = __builtin_bit_cast(unsigned long long, v), f = __builtin_bit_cast(unsigned long long, fill);
+    const unsigned lo = __builtin_amdgcn_update_dpp((int)(unsigned)f, (int)(unsigned)a, 0x138, 0xF, 0xF, false);
+    const unsigned hi = __builtin_amdgcn_update_dpp((int)(unsigned)(f >> 32), (int)(unsigned)(a >> 32), 0x138, 0xF, 0xF, false);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+static __device__ __forceinline__ double dpp_from_next(double v, double fill) {
+    const unsigned long long a = __builtin_bit_cast(unsigned long long, v), f = __builtin_bit_cast(unsigned long long, fill);
+    const unsigned lo = __builtin_amdgcn_update_dpp((int)(unsigned)f, (int)(unsigned)a, 0x130, 0xF, 0xF, false);
+    const unsigned hi = __builtin_amdgcn_update_dpp((int)(unsigned)(f >> 32), (int)(unsigned)(a >> 32), 0x130, 0xF, 0xF, false);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
 template <class T, int N>
 struct WaveReg {
     T v[N];
@@ -81,24 +94,26 @@ struct WaveReg {
 
 constexpr int kWaveMaxHlen = 10;  // one neighbouring lane on each side covers the row filter's support
 
-// 16-B / 8-B accesses at (uniform base) + (per-lane unsigned byte offset): the form hipcc turns into
+constexpr unsigned kRealBytes = (unsigned)sizeof(real_t);
+
+// 16-B / 8-B accesses (fp64: 32-B / 16-B) at (uniform base) + (per-lane unsigned byte offset): the form hipcc turns into
 // global_load/store ... v_offset, s[base:base+1] (no 64-bit vector address arithmetic)
-PDWT_DEVICE v4f wave_ld16(const float* base, unsigned byte_off) {
+PDWT_DEVICE v4f wave_ld16(const real_t* base, unsigned byte_off) {
     return *reinterpret_cast<const v4f*>(reinterpret_cast<const char*>(base) + byte_off);
 }
-PDWT_DEVICE void wave_st8(float* base, unsigned byte_off, float x, float y) {
-    f32x2 w;
+PDWT_DEVICE void wave_st8(real_t* base, unsigned byte_off, real_t x, real_t y) {
+    v2f w;
     w.x = x;
     w.y = y;
-    *reinterpret_cast<f32x2*>(reinterpret_cast<char*>(base) + byte_off) = w;
+    *reinterpret_cast<v2f*>(reinterpret_cast<char*>(base) + byte_off) = w;
 }
 
 // ------------------------------------------------------------------------------------------------
 // forward level: in (Nr, Nc) -> A, H, V, D (Nr2, Nc2);  Nc % 4 == 0, 16-B aligned rows
 // ------------------------------------------------------------------------------------------------
 struct FwdWaveArgs {
-    const float* in;
-    float *A, *H, *V, *D;
+    const real_t* in;
+    real_t *A, *H, *V, *D;
     int Nr, Nc, Nr2, Nc2;
     long long in_bstride, out_bstride;
     int strips;    // ceil(Nc / 256)
@@ -154,23 +169,23 @@ struct RowWalk {
 template <int HLEN>
 struct FwdWaveState {
     using G = FwdWaveGeom<HLEN>;
-    WaveReg<float, 4 * G::NR> ring;   // [slot][4]: own columns of the rows in flight
-    WaveReg<float, 4 * G::NR> hring;  // halo columns (lanes 0..31: left of the strip, 32..63: right)
+    WaveReg<real_t, 4 * G::NR> ring;   // [slot][4]: own columns of the rows in flight
+    WaveReg<real_t, 4 * G::NR> hring;  // halo columns (lanes 0..31: left of the strip, 32..63: right)
     WaveReg<v2f, 4 * G::NS> acc;     // per slot: (A,V) col 0, (A,V) col 1, (H,D) col 0, (H,D) col 1
     WaveReg<unsigned, 3> off;        // byte offsets: own float4, halo float4, own output pair
 };
 
 // load the next row of the walk into ring slot `slot`
 template <int HLEN>
-PDWT_DEVICE void fwd_wave_load(FwdWaveState<HLEN>& st, int slot, const float* in, int Nc, RowWalk& walk) {
-    const float* row = in + (long long)walk.next() * Nc;
+PDWT_DEVICE void fwd_wave_load(FwdWaveState<HLEN>& st, int slot, const real_t* in, int Nc, RowWalk& walk) {
+    const real_t* row = in + (long long)walk.next() * Nc;
     PDWT_WAVE_LANES(lane) {
         const v4f x = wave_ld16(row, st.off.mine(lane)[0]);
-        float* r = st.ring.mine(lane) + 4 * slot;
+        real_t* r = st.ring.mine(lane) + 4 * slot;
         r[0] = x.x; r[1] = x.y; r[2] = x.z; r[3] = x.w;
         if (FwdWaveGeom<HLEN>::C > 0) {
             const v4f h = wave_ld16(row, st.off.mine(lane)[1]);
-            float* q = st.hring.mine(lane) + 4 * slot;
+            real_t* q = st.hring.mine(lane) + 4 * slot;
             q[0] = h.x; q[1] = h.y; q[2] = h.z; q[3] = h.w;
         }
     }
@@ -184,9 +199,9 @@ PDWT_DEVICE void fwd_wave_row(FwdWaveState<HLEN>& st, const FilterBankI& fb) {
     using G = FwdWaveGeom<HLEN>;
     constexpr int C = G::C, NS = G::NS;
     PDWT_WAVE_LANES(lane) {
-        float v[HLEN + 2];
+        real_t v[HLEN + 2];
         if (C > 0) {
-            const float* hv = st.hring.mine(lane) + 4 * SLOT;
+            const real_t* hv = st.hring.mine(lane) + 4 * SLOT;
 #pragma unroll
             for (int t = 0; t < C; ++t) {
                 v[t] = st.ring.from_prev(4 * SLOT + 4 - C + t, lane, hv[4 - C + t]);
@@ -239,7 +254,7 @@ PDWT_DEVICE void fwd_wave_store(FwdWaveState<HLEN>& st, const FwdWaveArgs& a, lo
 
 // One group of GR rows of the steady state (after the HLEN - 2 warm-up rows): rows r = HLEN - 2 + GR it + g.
 template <int HLEN, bool GUARD, int G0 = 0>
-PDWT_DEVICE void fwd_wave_group(FwdWaveState<HLEN>& st, const FwdWaveArgs& a, const float* in, RowWalk& walk,
+PDWT_DEVICE void fwd_wave_group(FwdWaveState<HLEN>& st, const FwdWaveArgs& a, const real_t* in, RowWalk& walk,
                                 long long& rowoff, int& out_left, int x0) {
     using G = FwdWaveGeom<HLEN>;
     constexpr int NS = G::NS, GR = G::GR, NR = G::NR;
@@ -261,7 +276,7 @@ PDWT_DEVICE void fwd_wave_group(FwdWaveState<HLEN>& st, const FwdWaveArgs& a, co
 }
 
 template <int HLEN, int R = 0>
-PDWT_DEVICE void fwd_wave_warmup(FwdWaveState<HLEN>& st, const FwdWaveArgs& a, const float* in, RowWalk& walk) {
+PDWT_DEVICE void fwd_wave_warmup(FwdWaveState<HLEN>& st, const FwdWaveArgs& a, const real_t* in, RowWalk& walk) {
     using G = FwdWaveGeom<HLEN>;
     constexpr int NS = G::NS, NR = G::NR;
     if constexpr (R < HLEN - 2) {
@@ -288,15 +303,15 @@ PDWT_DEVICE void dwt2_fwd_wave(const FwdWaveArgs& a, int strip, int seg, int bz)
     if (out_left <= 0) return;
     const int nrows = 2 * out_left + HLEN - 2;  // image rows this wavefront filters
     const int x0 = strip * 256;
-    const float* PDWT_RESTRICT in = a.in + (long long)bz * a.in_bstride;
+    const real_t* PDWT_RESTRICT in = a.in + (long long)bz * a.in_bstride;
     long long rowoff = (long long)bz * a.out_bstride + (long long)oy0 * a.Nc2;
 
     FwdWaveState<HLEN> st;
     PDWT_WAVE_LANES(lane) {
         // lanes past the right image edge load the periodic continuation: their neighbours need it
-        st.off.mine(lane)[0] = 4u * (unsigned)wrap_periodic(x0 + 4 * lane, a.Nc);
-        st.off.mine(lane)[1] = 4u * (unsigned)wrap_periodic(lane < 32 ? x0 - 4 : x0 + 256, a.Nc);
-        st.off.mine(lane)[2] = 4u * (unsigned)((x0 >> 1) + 2 * lane);
+        st.off.mine(lane)[0] = kRealBytes * (unsigned)wrap_periodic(x0 + 4 * lane, a.Nc);
+        st.off.mine(lane)[1] = kRealBytes * (unsigned)wrap_periodic(lane < 32 ? x0 - 4 : x0 + 256, a.Nc);
+        st.off.mine(lane)[2] = kRealBytes * (unsigned)((x0 >> 1) + 2 * lane);
     }
     RowWalk walk;
     walk.start(2 * oy0 - C, a.Nr, nrows);
@@ -326,8 +341,8 @@ PDWT_DEVICE void dwt2_fwd_wave(const FwdWaveArgs& a, int strip, int seg, int bz)
 // pair of image rows leaves as two 16-B stores per lane (1 KiB contiguous per wavefront and row).
 // ------------------------------------------------------------------------------------------------
 struct InvWaveArgs {
-    const float *A, *H, *V, *D;
-    float* out;
+    const real_t *A, *H, *V, *D;
+    real_t* out;
     int Nrc, Ncc, Nr, Nc;
     long long in_bstride, out_bstride;
     int strips;      // ceil(Ncc / 128)
@@ -353,20 +368,20 @@ struct InvWaveGeom {
     static_assert(NLEFT <= 2 && NRIGHT <= 2 && GR % H2 == 0 && GR % NR == 0, "one neighbour lane per side");
 };
 
-PDWT_DEVICE v2f wave_ld8(const float* base, unsigned byte_off) {
+PDWT_DEVICE v2f wave_ld8(const real_t* base, unsigned byte_off) {
     return *reinterpret_cast<const v2f*>(reinterpret_cast<const char*>(base) + byte_off);
 }
-PDWT_DEVICE void wave_st16(float* base, unsigned byte_off, float x, float y, float z, float w) {
-    f32x4 o;
+PDWT_DEVICE void wave_st16(real_t* base, unsigned byte_off, real_t x, real_t y, real_t z, real_t w) {
+    v4f o;
     o.x = x; o.y = y; o.z = z; o.w = w;
-    *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(base) + byte_off) = o;
+    *reinterpret_cast<v4f*>(reinterpret_cast<char*>(base) + byte_off) = o;
 }
 
 template <int HLEN>
 struct InvWaveState {
     using G = InvWaveGeom<HLEN>;
-    WaveReg<float, 8 * G::NR> ring;   // [slot][A0 A1 H0 H1 V0 V1 D0 D1]: the lane's two coefficient columns
-    WaveReg<float, 8 * G::NR> hring;  // halo columns (lanes 0..31: left of the strip, 32..63: right)
+    WaveReg<real_t, 8 * G::NR> ring;   // [slot][A0 A1 H0 H1 V0 V1 D0 D1]: the lane's two coefficient columns
+    WaveReg<real_t, 8 * G::NR> hring;  // halo columns (lanes 0..31: left of the strip, 32..63: right)
     WaveReg<v2f, 4 * G::H2> acc;     // [slot][image column 0..3] = (even row, odd row)
     WaveReg<unsigned, 3> off;        // byte offsets: own float2, halo float2, own output float4
 };
@@ -376,13 +391,13 @@ PDWT_DEVICE void inv_wave_load(InvWaveState<HLEN>& st, int slot, const InvWaveAr
     const long long ro = boff + (long long)walk.next() * a.Ncc;
     PDWT_WAVE_LANES(lane) {
         const unsigned o = st.off.mine(lane)[0], oh = st.off.mine(lane)[1];
-        float* r = st.ring.mine(lane) + 8 * slot;
+        real_t* r = st.ring.mine(lane) + 8 * slot;
         const v2f xa = wave_ld8(a.A + ro, o), xh = wave_ld8(a.H + ro, o);
         const v2f xv = wave_ld8(a.V + ro, o), xd = wave_ld8(a.D + ro, o);
         r[0] = xa.x; r[1] = xa.y; r[2] = xh.x; r[3] = xh.y;
         r[4] = xv.x; r[5] = xv.y; r[6] = xd.x; r[7] = xd.y;
         if (InvWaveGeom<HLEN>::NLEFT + InvWaveGeom<HLEN>::NRIGHT > 0) {
-            float* h = st.hring.mine(lane) + 8 * slot;
+            real_t* h = st.hring.mine(lane) + 8 * slot;
             const v2f ya = wave_ld8(a.A + ro, oh), yh = wave_ld8(a.H + ro, oh);
             const v2f yv = wave_ld8(a.V + ro, oh), yd = wave_ld8(a.D + ro, oh);
             h[0] = ya.x; h[1] = ya.y; h[2] = yh.x; h[3] = yh.y;
@@ -402,11 +417,11 @@ PDWT_DEVICE void inv_wave_row(InvWaveState<HLEN>& st, const InvWaveArgs& a) {
         v2f pAH[6], pVD[6];
 #pragma unroll
         for (int m = 0; m < 6; ++m) pAH[m] = pVD[m] = mk2(0.f, 0.f);
-        const float* c = st.ring.mine(lane) + 8 * SLOT;
+        const real_t* c = st.ring.mine(lane) + 8 * SLOT;
         pAH[2] = mk2(c[0], c[2]); pAH[3] = mk2(c[1], c[3]);
         pVD[2] = mk2(c[4], c[6]); pVD[3] = mk2(c[5], c[7]);
         if (NL + NRT > 0) {
-            const float* hv = st.hring.mine(lane) + 8 * SLOT;
+            const real_t* hv = st.hring.mine(lane) + 8 * SLOT;
             constexpr int B = 8 * SLOT;
 #pragma unroll
             for (int t = 0; t < NL; ++t) {  // previous lane's column 2 - NL + t (its element e = 2 - NL + t)
@@ -457,8 +472,8 @@ PDWT_DEVICE void inv_wave_row(InvWaveState<HLEN>& st, const InvWaveArgs& a) {
 template <int HLEN, int SLOT_OUT, bool GUARD>
 PDWT_DEVICE void inv_wave_store(InvWaveState<HLEN>& st, const InvWaveArgs& a, long long boff, int oy_e, int oy_o,
                                 bool pair_ok, int kx0) {
-    float* re = a.out + boff + (long long)oy_e * a.Nc;
-    float* ro = a.out + boff + (long long)oy_o * a.Nc;
+    real_t* re = a.out + boff + (long long)oy_e * a.Nc;
+    real_t* ro = a.out + boff + (long long)oy_o * a.Nc;
     PDWT_WAVE_LANES(lane) {
         const v2f* s = st.acc.mine(lane) + 4 * SLOT_OUT;
         const unsigned o = st.off.mine(lane)[2];
@@ -533,9 +548,9 @@ PDWT_DEVICE void dwt2_inv_wave(const InvWaveArgs& a, int strip, int seg, int bz)
 
     InvWaveState<HLEN> st;
     PDWT_WAVE_LANES(lane) {
-        st.off.mine(lane)[0] = 4u * (unsigned)wrap_periodic(kx0 + 2 * lane, a.Ncc);
-        st.off.mine(lane)[1] = 4u * (unsigned)wrap_periodic(lane < 32 ? kx0 - 2 : kx0 + 128, a.Ncc);
-        st.off.mine(lane)[2] = 4u * (unsigned)(2 * kx0 + 4 * lane);
+        st.off.mine(lane)[0] = kRealBytes * (unsigned)wrap_periodic(kx0 + 2 * lane, a.Ncc);
+        st.off.mine(lane)[1] = kRealBytes * (unsigned)wrap_periodic(lane < 32 ? kx0 - 2 : kx0 + 128, a.Ncc);
+        st.off.mine(lane)[2] = kRealBytes * (unsigned)(2 * kx0 + 4 * lane);
     }
     RowWalk walk;
     walk.start_periodic(K0, a.Nrc, nrows);
@@ -550,6 +565,7 @@ PDWT_DEVICE void dwt2_inv_wave(const InvWaveArgs& a, int strip, int seg, int bz)
     for (int it = 0; it < ngroups; ++it) inv_wave_group<HLEN, GUARD>(st, a, bin, bout, walk, rows, pairs_left, kx0);
 }
 
+#ifndef PDWT_DOUBLE  // the two-level kernel exists in fp32 only
 // ------------------------------------------------------------------------------------------------
 // TWO forward levels in one wavefront: in (N0r, N0c) -> H1, V1, D1 (N0r/2, N0c/2) and A2, H2, V2, D2
 // (N0r/4, N0c/4).  The approximation of the first level never leaves the registers: a finished A1 row
@@ -842,6 +858,8 @@ PDWT_DEVICE void dwt2_fwd2_wave(const FwdWave2Args& a, int strip, int seg, int b
     (void)N1r;
 }
 
+#endif  // !PDWT_DOUBLE
+
 // wave-tile id -> (strip, seg): XCD x (workgroup ids b with b % 8 == x share an L2) gets a contiguous band
 // of segment rows, so vertically adjacent segments re-read their shared rows from that XCD's own L2.
 // Placement only affects speed.
@@ -859,15 +877,22 @@ PDWT_DEVICE bool wave_tile(int block, int wave, int waves_per_block, int strips,
 }
 
 #ifndef PDWT_CPU_EMU
-// register budget: 4 wavefronts per SIMD with the default ring, fewer when a deeper ring is compiled in
+// register budget: 4 wavefronts per SIMD with the default ring, fewer when a deeper ring is compiled in; the fp64
+// build's rings and running sums take twice the registers (2 wavefronts per SIMD)
+#ifdef PDWT_DOUBLE
+constexpr int kFwdWaveBlocks = 2, kInvWaveBlocks = 1;
+#else
+constexpr int kFwdWaveBlocks = PDWT_FWD_RING_H8 > 4 ? 2 : 4, kInvWaveBlocks = PDWT_INV_RING_H8 > 4 ? 2 : 3;
+#endif
 template <int HLEN, bool GUARD, int NT>
-__global__ void __launch_bounds__(NT, PDWT_FWD_RING_H8 > 4 ? 2 : 4) dwt2_fwd_wave_kernel(const FwdWaveArgs a) {
+__global__ void __launch_bounds__(NT, kFwdWaveBlocks) dwt2_fwd_wave_kernel(const FwdWaveArgs a) {
     int strip, seg;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (!wave_tile(blockIdx.x, wave, NT / 64, a.strips, a.segs, strip, seg)) return;
     dwt2_fwd_wave<HLEN, GUARD>(a, strip, seg, blockIdx.y);
 }
 
+#ifndef PDWT_DOUBLE
 template <int HLEN, int NT>
 __global__ void __launch_bounds__(NT, 4) dwt2_fwd2_wave_kernel(const FwdWave2Args a) {
     int strip, seg;
@@ -875,9 +900,10 @@ __global__ void __launch_bounds__(NT, 4) dwt2_fwd2_wave_kernel(const FwdWave2Arg
     if (!wave_tile(blockIdx.x, wave, NT / 64, a.strips, a.segs, strip, seg)) return;
     dwt2_fwd2_wave<HLEN>(a, strip, seg, blockIdx.y);
 }
+#endif
 
 template <int HLEN, bool GUARD, int NT>
-__global__ void __launch_bounds__(NT, PDWT_INV_RING_H8 > 4 ? 2 : 3) dwt2_inv_wave_kernel(const InvWaveArgs a) {
+__global__ void __launch_bounds__(NT, kInvWaveBlocks) dwt2_inv_wave_kernel(const InvWaveArgs a) {
     int strip, seg;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (!wave_tile(blockIdx.x, wave, NT / 64, a.strips, a.segs, strip, seg)) return;

@@ -37,12 +37,11 @@ static hipError_t run_inv(const Inv2DArgs& a, int batch, hipStream_t s) {
 }
 
 #ifdef PDWT_DOUBLE
-// fp64 build: the packed-fp32 kernels (tuned single-level, tile pyramid, streaming strips, fused 1D
-// pyramids) are not compiled; every level runs through the generic kernels of this file / launch_dwt1.hip
+// fp64 build: of the tuned kernels only the register (wave) kernels of dwt2_wave_kernels.hpp are compiled (they are
+// written over real_t); the LDS-tiled packed-fp32 kernels (tuned single-level, tile pyramid, streaming strips, fused
+// 1D pyramids, fused SWT groups) are not: those levels run through the generic kernels of this file / launch_dwt1.hip
 hipError_t try_launch_dwt2_fwd_fast(const Fwd2DArgs&, int, hipStream_t) { return hipErrorNotSupported; }
 hipError_t try_launch_dwt2_inv_fast(const Inv2DArgs&, int, hipStream_t) { return hipErrorNotSupported; }
-hipError_t try_launch_dwt2_fwd_wave(const Fwd2DArgs&, int, hipStream_t, int) { return hipErrorNotSupported; }
-hipError_t try_launch_dwt2_inv_wave(const Inv2DArgs&, int, hipStream_t, int) { return hipErrorNotSupported; }
 bool dwt2_wave2_supported(int, int, int) { return false; }
 hipError_t launch_dwt2_fwd_wave2(const real_t*, real_t* const[3], real_t* const[4], int, int, int, const FilterBank&, int,
                                  hipStream_t, int) { return hipErrorNotSupported; }
@@ -80,8 +79,14 @@ constexpr int kTyLong = 32;
 // enter the level: 2048^2 of one image); smaller levels are launch-bound and stay with the LDS tiles
 // (numbers in launch_dwt2_wave.hip).  PDWT_NO_WAVE=1 (read once) keeps the LDS tiles everywhere, PDWT_WAVE_MIN /
 // pdwt_set_tuning("wave_min_log2") override the threshold (log2 samples): tests and A/B measurements.
+// fp64 build: the alternative is the generic kernel, not a tuned LDS tile, so the wave kernels start at 2^16 samples
+#ifdef PDWT_DOUBLE
+constexpr int kWaveMinDefault = 16;
+#else
+constexpr int kWaveMinDefault = 22;
+#endif
 static std::atomic<int>& wave_min_log2() {
-    static std::atomic<int> v{getenv("PDWT_NO_WAVE") ? 63 : (getenv("PDWT_WAVE_MIN") ? atoi(getenv("PDWT_WAVE_MIN")) : 22)};
+    static std::atomic<int> v{getenv("PDWT_NO_WAVE") ? 63 : (getenv("PDWT_WAVE_MIN") ? atoi(getenv("PDWT_WAVE_MIN")) : kWaveMinDefault)};
     return v;
 }
 int set_wave_min_log2(int value) {  // pdwt_set_tuning("wave_min_log2")
@@ -140,7 +145,12 @@ hipError_t launch_dwt2_inv(const Inv2DArgs& a, int batch, hipStream_t s) {
     // 23.6 us) and loses slightly to the LDS tiles on a batch streamed from HBM (8 x 4096^2: 224-232 vs 219 us,
     // profiles/r02b_wbench_b8.txt): 2^26 samples and beyond go to the tiles
     const long long samples = (long long)batch * a.Nr * a.Nc;
-    if (wave_kernels_for(samples) && samples < (1LL << 26)) {
+#ifdef PDWT_DOUBLE
+    constexpr long long kInvWaveMax = 1LL << 62;  // no tuned LDS tile to hand a large batch to
+#else
+    constexpr long long kInvWaveMax = 1LL << 26;
+#endif
+    if (wave_kernels_for(samples) && samples < kInvWaveMax) {
         const hipError_t e = try_launch_dwt2_inv_wave(a, batch, s);
         if (e != hipErrorNotSupported) return e;
     }

@@ -92,6 +92,7 @@ static hipError_t run_inv(const Inv2DArgs& g, int batch, int seg_hint, hipStream
     return hipGetLastError();
 }
 
+#ifndef PDWT_DOUBLE
 // ---- two forward levels per wavefront (dwt2_fwd2_wave): same contract as launch_dwt2_fwd_pyr2
 bool dwt2_wave2_supported(int hlen, int N0r, int N0c) {
     return !(hlen & 1) && hlen >= 2 && hlen <= 8 && (N0r % 4) == 0 && (N0c % 16) == 0 && N0r >= 4 && N0c >= 16 &&
@@ -136,11 +137,12 @@ hipError_t launch_dwt2_fwd_wave2(const float* in, float* const det1[3], float* c
     }
     return hipErrorNotSupported;
 }
+#endif  // !PDWT_DOUBLE
 
 hipError_t try_launch_dwt2_fwd_wave(const Fwd2DArgs& a, int batch, hipStream_t s, int seg_hint) {
     if ((a.hlen & 1) || a.hlen < 2 || a.hlen > 8) return hipErrorNotSupported;
     if ((a.Nc & 3) || (a.in_bstride & 3) || (a.out_bstride & 1) || a.Nc2 * 2 != a.Nc) return hipErrorNotSupported;
-    if ((long long)a.Nc * 4 >= (1LL << 31)) return hipErrorNotSupported;  // 32-bit byte offsets inside a row
+    if ((long long)a.Nc * (long long)sizeof(real_t) >= (1LL << 31)) return hipErrorNotSupported;  // 32-bit byte offsets inside a row
     if (!aligned16(a.in) || !aligned16(a.A) || !aligned16(a.H) || !aligned16(a.V) || !aligned16(a.D))
         return hipErrorNotSupported;
     switch (a.hlen) {
@@ -156,7 +158,7 @@ hipError_t try_launch_dwt2_inv_wave(const Inv2DArgs& a, int batch, hipStream_t s
     if ((a.hlen & 1) || a.hlen < 2 || a.hlen > 8) return hipErrorNotSupported;
     if ((a.Ncc & 1) || a.Nc != 2 * a.Ncc || (a.in_bstride & 1) || (a.out_bstride & 3)) return hipErrorNotSupported;
     if (a.Nr > 2 * a.Nrc || a.Nr < 2 * a.Nrc - 1) return hipErrorNotSupported;
-    if ((long long)a.Nc * 4 >= (1LL << 31)) return hipErrorNotSupported;
+    if ((long long)a.Nc * (long long)sizeof(real_t) >= (1LL << 31)) return hipErrorNotSupported;
     if (!aligned16(a.out) || !aligned16(a.A) || !aligned16(a.H) || !aligned16(a.V) || !aligned16(a.D))
         return hipErrorNotSupported;
     switch (a.hlen) {

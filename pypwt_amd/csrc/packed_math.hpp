@@ -1,8 +1,10 @@
-// packed_math.hpp -- 2-wide fp32 helpers shared by the tuned kernels.
+// packed_math.hpp -- 2-wide helpers shared by the tuned kernels.
 //
 // gfx950 executes v_pk_fma_f32 on (x,y) register pairs; keeping the low/high filter outputs (or the
 // (A,V)/(H,D) band pairs) interleaved makes every multiply-add of the transform one packed
-// instruction with the (lo,hi) tap pair coming from SGPRs.
+// instruction with the (lo,hi) tap pair coming from SGPRs.  The element type is real_t: the fp64 build
+// (-DPDWT_DOUBLE) compiles the register kernels of dwt2_wave_kernels.hpp with the same code, where a "pair"
+// is two v_fma_f64 (there is no packed fp64 FMA) and a 4-vector two 16-B memory instructions.
 #pragma once
 
 #include "kernels_common.hpp"
@@ -11,13 +13,13 @@ namespace pdwt {
 
 #ifdef PDWT_CPU_EMU
 struct v2f {
-    float x, y;
+    real_t x, y;
 };
-static inline v2f mk2(float a, float b) { return v2f{a, b}; }
+static inline v2f mk2(real_t a, real_t b) { return v2f{a, b}; }
 static inline v2f fma2(v2f a, v2f b, v2f c) { return v2f{a.x * b.x + c.x, a.y * b.y + c.y}; }
 #else
-typedef float v2f __attribute__((ext_vector_type(2)));
-static __device__ __forceinline__ v2f mk2(float a, float b) {
+typedef real_t v2f __attribute__((ext_vector_type(2)));
+static __device__ __forceinline__ v2f mk2(real_t a, real_t b) {
     v2f r;
     r.x = a;
     r.y = b;
@@ -25,7 +27,7 @@ static __device__ __forceinline__ v2f mk2(float a, float b) {
 }
 static __device__ __forceinline__ v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
 #endif
-static PDWT_DEVICE v2f bc(float a) { return mk2(a, a); }
+static PDWT_DEVICE v2f bc(real_t a) { return mk2(a, a); }
 
 // Reads 16 B from LDS as ONE ds_read_b128 (256 B/clk) even when only some components are used
 // afterwards; without the barrier hipcc narrows it to ds_read2_b32 / ds_read2_b64 pairs, which
@@ -35,7 +37,7 @@ typedef f32x4 v4f;
 static inline v4f lds_load16(const void* p) { return *reinterpret_cast<const v4f*>(p); }
 static inline void lds_pin(v4f&) {}
 #else
-typedef float v4f __attribute__((ext_vector_type(4)));
+typedef real_t v4f __attribute__((ext_vector_type(4)));
 // An empty asm barrier right after the load would also make the wave WAIT for it before issuing the next one.
 // Where several loads feed one computation, issue them all with lds_load16 and pin them afterwards
 // (LDS returns in order, so the compiler waits with a counting s_waitcnt and the loads pipeline).

@@ -131,6 +131,34 @@ def test_wave_single_level_kernels_without_the_two_level_fusion():
         lib.pdwt_set_tuning(b"wave2", was)
 
 
+def test_fp64_wave_kernels_vs_the_fp64_oracle():
+    """The fp64 library compiles the same register kernels over doubles (two v_fma_f64 per pair, DPP shifts of both
+    halves, 32-B lane loads): every short filter at whole, ragged and odd shapes against the fp64-storage oracle at
+    1e-12, with every eligible level forced onto them (the default starts at 2^16 samples per level)."""
+    from pypwt_amd import Wavelets64, _lib
+    lib = _lib.load("f64")
+    was = lib.pdwt_set_tuning(b"wave_min_log2", 0)
+    assert was == 16
+    try:
+        for si, shape in enumerate(((64, 256), (96, 512), (61, 72), (33, 1028), (200, 260), (8, 8), (127, 768), (512, 512))):
+            for wi, wname in enumerate(("haar", "db2", "db3", "sym4", "bior1.3", "rbio2.2", "bior3.3")):
+                hlen = oracle.filters(wname)[0]
+                x = oracle.hash_input(shape, 8500 + 16 * si + wi, scale=255.0).astype(np.float64)
+                x += 1e-9 * np.arange(x.size).reshape(x.shape)  # something fp32 cannot hold
+                lv = max(1, min(3, oracle.max_level(min(shape), hlen)))
+                w = Wavelets64(x, wname, lv)
+                w.forward()
+                ref = oracle.forward(x, wname, w.levels, double="full")
+                for k, (g, r) in enumerate(zip(_flat(w.coeffs), ref)):
+                    assert g.dtype == np.float64 and g.shape == r.shape
+                    assert np.abs(g - r).max() <= 1e-12 * max(1.0, float(np.abs(r).max())), (wname, shape, k)
+                w.inverse()
+                want = oracle.inverse(ref, x.shape, wname, w.levels, double="full")
+                assert np.abs(w.image - want).max() <= 1e-11 * 255, (wname, shape)
+    finally:
+        lib.pdwt_set_tuning(b"wave_min_log2", was)
+
+
 def test_reg_1d_three_levels_in_registers_on_the_gpu():
     """dwt1_fwd_reg / dwt1_inv_reg (three 1D levels per launch in registers, lane shifts instead of LDS) against the
     oracle: rows that are and are not whole numbers of blocks, several filter lengths, batched rows, 1-6 levels."""
