@@ -20,7 +20,7 @@ OBJ = os.path.join(ROOT, "build", "obj")
 LIB = os.path.join(HERE, "libpypwt_amd.so")
 LIB_F64 = os.path.join(HERE, "libpypwt_amd_f64.so")
 # (object directory, library, extra flags, sources left out) per variant; of the tuned kernels the fp64 build
-# has the register (wave) 2D DWT levels only
+# has the register kernels only (2D DWT levels, 1D DWT level triples)
 VARIANTS = {
     "f32": (OBJ, LIB, [], ()),
     "f64": (os.path.join(ROOT, "build", "obj_f64"), LIB_F64, ["-DPDWT_DOUBLE"],
@@ -34,6 +34,7 @@ SOURCES = [
     "launch_dwt2_wave.hip",
     "launch_dwt1.hip",
     "launch_dwt1_fused.hip",
+    "launch_dwt1_reg.hip",
     "launch_swt.hip",
     "launch_swt_vec.hip",
     "launch_swt_fused.hip",

@@ -112,9 +112,9 @@ constexpr int reg1_inv_o0(int hlen, int K) {
 }
 
 struct Fwd1DRegArgs {
-    const float* in;                 // (rows, N0)
-    float* det[kReg1MaxLevels];      // det[k-1] = D_k: (rows, N0 >> k)
-    float* app;                      // A_K: (rows, N0 >> K)
+    const real_t* in;                 // (rows, N0)
+    real_t* det[kReg1MaxLevels];      // det[k-1] = D_k: (rows, N0 >> k)
+    real_t* app;                      // A_K: (rows, N0 >> K)
     int rows, N0;
     int nblk;                        // blocks per row: ceil(N0 / (16 V))
     int nplain;                      // blocks [0, nplain) of a row touch no index beyond the row (no wrap arithmetic)
@@ -124,9 +124,9 @@ struct Fwd1DRegArgs {
 };
 
 struct Inv1DRegArgs {
-    const float* app;                // A_K
-    const float* det[kReg1MaxLevels];
-    float* out;                      // (rows, N0)
+    const real_t* app;                // A_K
+    const real_t* det[kReg1MaxLevels];
+    real_t* out;                      // (rows, N0)
     int rows, N0;
     int nblk, nplain, bpw, wpr;
     FilterBankI fb;                  // (rec_lo, rec_hi)
@@ -150,13 +150,12 @@ inline void reg1_fwd_blocks(int hlen, int K, int N0, int* nblk, int* nplain) {
     *nplain = np;
 }
 
-// 16-B range-checked store (see RowBuf in dwt2_wave_kernels.hpp)
+// range-checked store of four values (16 B; fp64: two 16-B halves) -- see RowBuf in dwt2_wave_kernels.hpp
 #ifdef PDWT_CPU_EMU
-PDWT_DEVICE void row_st16(const RowBuf& r, unsigned off, float x, float y, float z, float w) {
-    if (off < r.bytes) { float* p = reinterpret_cast<float*>(r.base + off); p[0] = x; p[1] = y; p[2] = z; p[3] = w; }
+PDWT_DEVICE void row_st16(const RowBuf& r, unsigned off, real_t x, real_t y, real_t z, real_t w) {
+    if (off < r.bytes) { real_t* p = reinterpret_cast<real_t*>(r.base + off); p[0] = x; p[1] = y; p[2] = z; p[3] = w; }
 }
 #else
-typedef unsigned pdwt_u4 __attribute__((ext_vector_type(4)));
 static __device__ __forceinline__ void row_st16(const RowBuf& r, unsigned off, float x, float y, float z, float w) {
     pdwt_u4 d;
     d.x = __builtin_bit_cast(unsigned, x);
@@ -165,16 +164,20 @@ static __device__ __forceinline__ void row_st16(const RowBuf& r, unsigned off, f
     d.w = __builtin_bit_cast(unsigned, w);
     __builtin_amdgcn_raw_buffer_store_b128(d, r.rsrc, (int)off, 0, 0);
 }
+static __device__ __forceinline__ void row_st16(const RowBuf& r, unsigned off, double x, double y, double z, double w) {
+    row_st8(r, off, x, y);  // an out-of-range offset (kReg1Dropped) stays out of range 16 B further on
+    row_st8(r, off + 16u, z, w);
+}
 #endif
 
 // ext[N .. N+E) = the first E values of the following lanes (lane + m holds ext[m N + i] = its own value i)
 template <int N, int E, int NE>
-PDWT_DEVICE void reg1_extend(WaveReg<float, NE>& ext) {
+PDWT_DEVICE void reg1_extend(WaveReg<real_t, NE>& ext) {
     static_assert(N + E <= NE, "extension fits");
 #pragma unroll
     for (int m = 1; (m - 1) * N < E; ++m) {
         PDWT_WAVE_LANES(lane) {
-            float* v = ext.mine(lane);
+            real_t* v = ext.mine(lane);
 #pragma unroll
             for (int i = 0; i < N; ++i)
                 if ((m - 1) * N + i < E) v[m * N + i] = ext.from_next((m - 1) * N + i, lane, 0.f);
@@ -185,12 +188,12 @@ PDWT_DEVICE void reg1_extend(WaveReg<float, NE>& ext) {
 // n consecutive values of one band row, first global index `idx` (per lane), in units of U floats; GUARD wraps each
 // unit at the row length Nk (units never straddle it); `ok` false -> nothing is stored (out-of-range offset)
 template <int NV, int U, bool GUARD>
-PDWT_DEVICE void reg1_store(const RowBuf& rb, const float* v, int idx, int Nk, bool ok) {
+PDWT_DEVICE void reg1_store(const RowBuf& rb, const real_t* v, int idx, int Nk, bool ok) {
 #pragma unroll
     for (int j = 0; j < NV / U; ++j) {
         int p = idx + U * j;
         if (GUARD && p >= Nk) p -= Nk;
-        const unsigned off = ok ? 4u * (unsigned)p : kReg1Dropped;
+        const unsigned off = ok ? kRealBytes * (unsigned)p : kReg1Dropped;
         if (U == 4) row_st16(rb, off, v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
         else if (U == 2) row_st8(rb, off, v[2 * j], v[2 * j + 1]);
         else row_st4(rb, off, v[j]);
@@ -201,20 +204,20 @@ constexpr int reg1_unit(int n, int d) { return (n % 4 == 0 && d % 4 == 0) ? 4 : 
 // ---------------------------------------------------------------------------------------------- forward
 template <int HLEN, int K>
 struct Fwd1DRegState {
-    WaveReg<float, 16> x;     // the block being transformed
-    WaveReg<float, 16> xn;    // the next block's samples, in flight
+    WaveReg<real_t, 16> x;     // the block being transformed
+    WaveReg<real_t, 16> xn;    // the next block's samples, in flight
 };
 
 template <bool GUARD>
-PDWT_DEVICE void fwd1d_reg_load(WaveReg<float, 16>& x, const float* row, long long base, int N0) {
+PDWT_DEVICE void fwd1d_reg_load(WaveReg<real_t, 16>& x, const real_t* row, long long base, int N0) {
     PDWT_WAVE_LANES(lane) {
         long long s = base + 16 * lane;
         if (GUARD) s %= N0;  // N0 % 16 == 0: the lane's 64 B never straddle the end of the row
-        const unsigned off = 4u * (unsigned)s;
-        float* v = x.mine(lane);
+        const unsigned off = kRealBytes * (unsigned)s;
+        real_t* v = x.mine(lane);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const v4f w = wave_ld16(row, off + 16u * i);
+            const v4f w = wave_ld16(row, off + 4u * kRealBytes * i);
             v[4 * i] = w.x; v[4 * i + 1] = w.y; v[4 * i + 2] = w.z; v[4 * i + 3] = w.w;
         }
     }
@@ -223,25 +226,25 @@ PDWT_DEVICE void fwd1d_reg_load(WaveReg<float, 16>& x, const float* row, long lo
 // one level: `src` (NIN values per lane) -> A (NIN/2 per lane, the next level's input), details to `outD`
 // (and A to `outA` at the last level)
 template <int HLEN, int K, int LV, bool GUARD, int NIN>
-PDWT_DEVICE void fwd1d_reg_level(const Fwd1DRegArgs& a, WaveReg<float, NIN>& src, WaveReg<float, NIN / 2>& A,
+PDWT_DEVICE void fwd1d_reg_level(const Fwd1DRegArgs& a, WaveReg<real_t, NIN>& src, WaveReg<real_t, NIN / 2>& A,
                                  long long base, long long row) {
     constexpr Reg1Geom g = reg1_fwd_geom(HLEN, K);
     constexpr int E = g.E[LV], e = g.e[LV], d = g.d[LV], NO = NIN / 2, NE = NIN + E;
-    WaveReg<float, NE> ext;
+    WaveReg<real_t, NE> ext;
     PDWT_WAVE_LANES(lane) {
-        float* v = ext.mine(lane);
-        const float* s = src.mine(lane);
+        real_t* v = ext.mine(lane);
+        const real_t* s = src.mine(lane);
 #pragma unroll
         for (int i = 0; i < NIN; ++i) v[i] = s[i];
     }
     reg1_extend<NIN, E, NE>(ext);
     const int Nk = a.N0 >> LV;
-    const RowBuf bD = row_buf(a.det[LV - 1] + row * Nk, 4u * (unsigned)Nk);
-    const RowBuf bA = row_buf((LV == K ? a.app : a.det[LV - 1]) + row * Nk, 4u * (unsigned)Nk);  // used at the last level only
+    const RowBuf bD = row_buf(a.det[LV - 1] + row * Nk, kRealBytes * (unsigned)Nk);
+    const RowBuf bA = row_buf((LV == K ? a.app : a.det[LV - 1]) + row * Nk, kRealBytes * (unsigned)Nk);  // used at the last level only
     PDWT_WAVE_LANES(lane) {
-        const float* v = ext.mine(lane);
-        float* av = A.mine(lane);
-        float dv[NO];
+        const real_t* v = ext.mine(lane);
+        real_t* av = A.mine(lane);
+        real_t dv[NO];
 #pragma unroll
         for (int q = 0; q < NO; ++q) {
             v2f acc = mk2(0.f, 0.f);
@@ -260,14 +263,14 @@ PDWT_DEVICE void fwd1d_reg_level(const Fwd1DRegArgs& a, WaveReg<float, NIN>& src
 }
 
 template <int HLEN, int K, bool GUARD>
-PDWT_DEVICE void fwd1d_reg_block(const Fwd1DRegArgs& a, WaveReg<float, 16>& x, long long base, long long row) {
-    WaveReg<float, 8> a1;
+PDWT_DEVICE void fwd1d_reg_block(const Fwd1DRegArgs& a, WaveReg<real_t, 16>& x, long long base, long long row) {
+    WaveReg<real_t, 8> a1;
     fwd1d_reg_level<HLEN, K, 1, GUARD, 16>(a, x, a1, base, row);
     if constexpr (K >= 2) {
-        WaveReg<float, 4> a2;
+        WaveReg<real_t, 4> a2;
         fwd1d_reg_level<HLEN, K, 2, GUARD, 8>(a, a1, a2, base, row);
         if constexpr (K >= 3) {
-            WaveReg<float, 2> a3;
+            WaveReg<real_t, 2> a3;
             fwd1d_reg_level<HLEN, K, 3, GUARD, 4>(a, a2, a3, base, row);
         }
     }
@@ -283,15 +286,15 @@ PDWT_DEVICE void dwt1_fwd_reg(const Fwd1DRegArgs& a, long long w) {
     const int first = (int)(w - row * a.wpr) * a.bpw;
     const int last = first + a.bpw < a.nblk ? first + a.bpw : a.nblk;  // exclusive
     const int plain_end = last < a.nplain ? last : a.nplain;
-    const float* rin = a.in + row * a.N0;
+    const real_t* rin = a.in + row * a.N0;
     Fwd1DRegState<HLEN, K> st;
     if (first < plain_end) {
         fwd1d_reg_load<false>(st.xn, rin, (long long)first * STEP, a.N0);
         PDWT_WAIT_VMEM();  // see dwt1_inv_reg
         for (int b = first; b < plain_end; ++b) {
             PDWT_WAVE_LANES(lane) {
-                float* v = st.x.mine(lane);
-                const float* n = st.xn.mine(lane);
+                real_t* v = st.x.mine(lane);
+                const real_t* n = st.xn.mine(lane);
 #pragma unroll
                 for (int i = 0; i < 16; ++i) v[i] = n[i];
             }
@@ -328,18 +331,18 @@ inline void reg1_inv_blocks(int hlen, int K, int N0, int* nblk, int* nplain) {
     *nplain = np;
 }
 
-PDWT_DEVICE float wave_ld4(const float* base, unsigned byte_off) {
-    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
+PDWT_DEVICE real_t wave_ld4(const real_t* base, unsigned byte_off) {
+    return *reinterpret_cast<const real_t*>(reinterpret_cast<const char*>(base) + byte_off);
 }
 
 // n consecutive values of one band row from global index idx (per lane), in units of U floats
 template <int NV, int U, bool GUARD>
-PDWT_DEVICE void reg1_load(const float* row, float* v, int idx, int Nk) {
+PDWT_DEVICE void reg1_load(const real_t* row, real_t* v, int idx, int Nk) {
 #pragma unroll
     for (int j = 0; j < NV / U; ++j) {
         int p = idx + U * j;
         if (GUARD && p >= Nk) p -= Nk;
-        const unsigned off = 4u * (unsigned)p;
+        const unsigned off = kRealBytes * (unsigned)p;
         if (U == 4) {
             const v4f w = wave_ld16(row, off);
             v[4 * j] = w.x; v[4 * j + 1] = w.y; v[4 * j + 2] = w.z; v[4 * j + 3] = w.w;
@@ -353,10 +356,10 @@ PDWT_DEVICE void reg1_load(const float* row, float* v, int idx, int Nk) {
 }
 
 template <int HLEN, int K, bool GUARD>
-PDWT_DEVICE void inv1d_reg_load(const Inv1DRegArgs& a, WaveReg<float, 16>& in, long long base, long long row) {
+PDWT_DEVICE void inv1d_reg_load(const Inv1DRegArgs& a, WaveReg<real_t, 16>& in, long long base, long long row) {
     constexpr Reg1Geom g = reg1_inv_geom(HLEN, K, reg1_inv_o0(HLEN, K));
     PDWT_WAVE_LANES(lane) {
-        float* v = in.mine(lane);
+        real_t* v = in.mine(lane);
 #pragma unroll
         for (int k = 1; k <= K; ++k) {
             const int n = 16 >> k, Nk = a.N0 >> k;
@@ -378,14 +381,14 @@ PDWT_DEVICE void inv1d_reg_load(const Inv1DRegArgs& a, WaveReg<float, 16>& in, l
 // level LV: the lane's N = 16 >> LV approximations `A` and details in.mine()[reg1_inv_slot(LV) ..] -> its 2 N values of
 // A_{LV-1} in `out`
 template <int HLEN, int K, int LV, int N>
-PDWT_DEVICE void inv1d_reg_level(const FilterBankI& fb, WaveReg<float, N>& A, WaveReg<float, 16>& in, WaveReg<float, 2 * N>& out) {
+PDWT_DEVICE void inv1d_reg_level(const FilterBankI& fb, WaveReg<real_t, N>& A, WaveReg<real_t, 16>& in, WaveReg<real_t, 2 * N>& out) {
     constexpr Reg1Geom g = reg1_inv_geom(HLEN, K, reg1_inv_o0(HLEN, K));
     constexpr int H2 = HLEN / 2, S = (H2 & 1) ? 0 : 1, E = g.E[LV], OP = g.d[LV - 1], NE = 2 * (N + E);
-    WaveReg<float, NE> ext;  // (A, D) pairs: own N, then E of the following lanes
+    WaveReg<real_t, NE> ext;  // (A, D) pairs: own N, then E of the following lanes
     PDWT_WAVE_LANES(lane) {
-        float* v = ext.mine(lane);
-        const float* av = A.mine(lane);
-        const float* dv = in.mine(lane) + reg1_inv_slot(LV);
+        real_t* v = ext.mine(lane);
+        const real_t* av = A.mine(lane);
+        const real_t* dv = in.mine(lane) + reg1_inv_slot(LV);
 #pragma unroll
         for (int i = 0; i < N; ++i) {
             v[2 * i] = av[i];
@@ -394,8 +397,8 @@ PDWT_DEVICE void inv1d_reg_level(const FilterBankI& fb, WaveReg<float, N>& A, Wa
     }
     reg1_extend<2 * N, 2 * E, NE>(ext);
     PDWT_WAVE_LANES(lane) {
-        const float* v = ext.mine(lane);
-        float* o = out.mine(lane);
+        const real_t* v = ext.mine(lane);
+        real_t* o = out.mine(lane);
 #pragma unroll
         for (int i = 0; i < 2 * N; ++i) {
             constexpr int kBase = reg1_floor_half(OP + S);
@@ -410,29 +413,29 @@ PDWT_DEVICE void inv1d_reg_level(const FilterBankI& fb, WaveReg<float, N>& A, Wa
 }
 
 template <int HLEN, int K, bool GUARD>
-PDWT_DEVICE void inv1d_reg_block(const Inv1DRegArgs& a, WaveReg<float, 16>& in, long long base, long long row, float* lds) {
+PDWT_DEVICE void inv1d_reg_block(const Inv1DRegArgs& a, WaveReg<real_t, 16>& in, long long base, long long row, real_t* lds) {
     constexpr int O0 = reg1_inv_o0(HLEN, K);
     constexpr Reg1Geom g = reg1_inv_geom(HLEN, K, O0);
-    WaveReg<float, 16> x;
+    WaveReg<real_t, 16> x;
     if constexpr (K == 3) {
-        WaveReg<float, 2> a3;
+        WaveReg<real_t, 2> a3;
         PDWT_WAVE_LANES(lane) { a3.mine(lane)[0] = in.mine(lane)[reg1_inv_slot(4)]; a3.mine(lane)[1] = in.mine(lane)[reg1_inv_slot(4) + 1]; }
-        WaveReg<float, 4> a2;
+        WaveReg<real_t, 4> a2;
         inv1d_reg_level<HLEN, K, 3, 2>(a.fb, a3, in, a2);
-        WaveReg<float, 8> a1;
+        WaveReg<real_t, 8> a1;
         inv1d_reg_level<HLEN, K, 2, 4>(a.fb, a2, in, a1);
         inv1d_reg_level<HLEN, K, 1, 8>(a.fb, a1, in, x);
     } else if constexpr (K == 2) {
-        WaveReg<float, 4> a2;
+        WaveReg<real_t, 4> a2;
         PDWT_WAVE_LANES(lane) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) a2.mine(lane)[i] = in.mine(lane)[reg1_inv_slot(3) + i];
         }
-        WaveReg<float, 8> a1;
+        WaveReg<real_t, 8> a1;
         inv1d_reg_level<HLEN, K, 2, 4>(a.fb, a2, in, a1);
         inv1d_reg_level<HLEN, K, 1, 8>(a.fb, a1, in, x);
     } else {
-        WaveReg<float, 8> a1;
+        WaveReg<real_t, 8> a1;
         PDWT_WAVE_LANES(lane) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) a1.mine(lane)[i] = in.mine(lane)[reg1_inv_slot(2) + i];
@@ -445,30 +448,30 @@ PDWT_DEVICE void inv1d_reg_block(const Inv1DRegArgs& a, WaveReg<float, 16>& in, 
     // accesses of both passes are conflict-free) and leave as four 1-KiB-contiguous stores.  No barrier: the tile
     // belongs to this wavefront and LDS executes a wavefront's accesses in order.
     PDWT_WAVE_LANES(lane) {
-        const float* v = x.mine(lane);
+        const real_t* v = x.mine(lane);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            f32x4 w;
+            v4f w;
             w.x = v[4 * i]; w.y = v[4 * i + 1]; w.z = v[4 * i + 2]; w.w = v[4 * i + 3];
-            *reinterpret_cast<f32x4*>(lds + kReg1LdsStride * lane + 4 * i) = w;
+            *reinterpret_cast<v4f*>(lds + kReg1LdsStride * lane + 4 * i) = w;
         }
     }
-    const RowBuf bo = row_buf(a.out + row * a.N0, 4u * (unsigned)a.N0);
+    const RowBuf bo = row_buf(a.out + row * a.N0, kRealBytes * (unsigned)a.N0);
     PDWT_WAVE_LANES(lane) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int q = 64 * i + lane;  // quad q of the block = samples 4q .. 4q+3, computed by lane q / 4
-            const f32x4 w = *reinterpret_cast<const f32x4*>(lds + kReg1LdsStride * (q >> 2) + 4 * (q & 3));
+            const v4f w = *reinterpret_cast<const v4f*>(lds + kReg1LdsStride * (q >> 2) + 4 * (q & 3));
             long long sidx = base + O0 + 4 * q;
             if (GUARD) sidx %= a.N0;  // N0 % 16 == 0: a quad never straddles the end of the row
             const bool ok = (q >> 2) < g.V;
-            row_st16(bo, ok ? 4u * (unsigned)sidx : kReg1Dropped, w.x, w.y, w.z, w.w);
+            row_st16(bo, ok ? kRealBytes * (unsigned)sidx : kReg1Dropped, w.x, w.y, w.z, w.w);
         }
     }
 }
 
 template <int HLEN, int K>
-PDWT_DEVICE void dwt1_inv_reg(const Inv1DRegArgs& a, long long w, float* lds) {
+PDWT_DEVICE void dwt1_inv_reg(const Inv1DRegArgs& a, long long w, real_t* lds) {
     constexpr Reg1Geom g = reg1_inv_geom(HLEN, K, reg1_inv_o0(HLEN, K));
     constexpr int STEP = 16 * g.V;
     const long long row = w / a.wpr;
@@ -476,7 +479,7 @@ PDWT_DEVICE void dwt1_inv_reg(const Inv1DRegArgs& a, long long w, float* lds) {
     const int first = (int)(w - row * a.wpr) * a.bpw;
     const int last = first + a.bpw < a.nblk ? first + a.bpw : a.nblk;  // exclusive
     const int plain_end = last < a.nplain ? last : a.nplain;
-    WaveReg<float, 16> in, nx;
+    WaveReg<real_t, 16> in, nx;
     if (first < plain_end) {
         inv1d_reg_load<HLEN, K, false>(a, nx, (long long)first * STEP, row);
         // Without this the loop header inherits "first block's loads pending" from here and "four stores pending" from
@@ -485,8 +488,8 @@ PDWT_DEVICE void dwt1_inv_reg(const Inv1DRegArgs& a, long long w, float* lds) {
         PDWT_WAIT_VMEM();
         for (int b = first; b < plain_end; ++b) {
             PDWT_WAVE_LANES(lane) {
-                float* v = in.mine(lane);
-                const float* n = nx.mine(lane);
+                real_t* v = in.mine(lane);
+                const real_t* n = nx.mine(lane);
 #pragma unroll
                 for (int i = 0; i < 16; ++i) v[i] = n[i];
             }
@@ -510,7 +513,7 @@ __global__ void __launch_bounds__(NT) dwt1_fwd_reg_kernel(const Fwd1DRegArgs a) 
 }
 template <int HLEN, int K, int NT>
 __global__ void __launch_bounds__(NT) dwt1_inv_reg_kernel(const Inv1DRegArgs a) {
-    __shared__ __attribute__((aligned(16))) float tile[(NT / 64) * kReg1LdsFloats];
+    __shared__ __attribute__((aligned(32))) real_t tile[(NT / 64) * kReg1LdsFloats];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     dwt1_inv_reg<HLEN, K>(a, (long long)blockIdx.x * (NT / 64) + wave, tile + wave * kReg1LdsFloats);
 }

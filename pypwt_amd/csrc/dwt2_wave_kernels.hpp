@@ -565,6 +565,52 @@ PDWT_DEVICE void dwt2_inv_wave(const InvWaveArgs& a, int strip, int seg, int bz)
     for (int it = 0; it < ngroups; ++it) inv_wave_group<HLEN, GUARD>(st, a, bin, bout, walk, rows, pairs_left, kx0);
 }
 
+// Range-checked row stores through a buffer descriptor (explained with the two-level kernel below; also used by
+// dwt1_reg_kernels.hpp and swt2_fused_kernels.hpp).
+#ifdef PDWT_CPU_EMU
+struct RowBuf {
+    char* base;
+    unsigned bytes;
+};
+PDWT_DEVICE RowBuf row_buf(real_t* row, unsigned row_bytes) { return RowBuf{(char*)row, row_bytes}; }
+PDWT_DEVICE void row_st8(const RowBuf& r, unsigned off, real_t x, real_t y) {
+    if (off < r.bytes) { real_t* p = reinterpret_cast<real_t*>(r.base + off); p[0] = x; p[1] = y; }
+}
+PDWT_DEVICE void row_st4(const RowBuf& r, unsigned off, real_t x) {
+    if (off < r.bytes) *reinterpret_cast<real_t*>(r.base + off) = x;
+}
+#else
+struct RowBuf {
+    __amdgpu_buffer_rsrc_t rsrc;
+};
+static __device__ __forceinline__ RowBuf row_buf(real_t* row, unsigned row_bytes) {
+    RowBuf r;
+    r.rsrc = __builtin_amdgcn_make_buffer_rsrc(row, (short)0, (int)row_bytes, 0x00020000);
+    return r;
+}
+typedef unsigned pdwt_u2 __attribute__((ext_vector_type(2)));
+typedef unsigned pdwt_u4 __attribute__((ext_vector_type(4)));
+// two values / one value of a row (fp32: 8 B / 4 B; fp64: 16 B / 8 B)
+static __device__ __forceinline__ void row_st8(const RowBuf& r, unsigned off, float x, float y) {
+    pdwt_u2 d;
+    d.x = __builtin_bit_cast(unsigned, x);
+    d.y = __builtin_bit_cast(unsigned, y);
+    __builtin_amdgcn_raw_buffer_store_b64(d, r.rsrc, (int)off, 0, 0);
+}
+static __device__ __forceinline__ void row_st4(const RowBuf& r, unsigned off, float x) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, x), r.rsrc, (int)off, 0, 0);
+}
+static __device__ __forceinline__ void row_st8(const RowBuf& r, unsigned off, double x, double y) {
+    const pdwt_u2 a = __builtin_bit_cast(pdwt_u2, x), b = __builtin_bit_cast(pdwt_u2, y);
+    pdwt_u4 d;
+    d.x = a.x; d.y = a.y; d.z = b.x; d.w = b.y;
+    __builtin_amdgcn_raw_buffer_store_b128(d, r.rsrc, (int)off, 0, 0);
+}
+static __device__ __forceinline__ void row_st4(const RowBuf& r, unsigned off, double x) {
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(pdwt_u2, x), r.rsrc, (int)off, 0, 0);
+}
+#endif
+
 #ifndef PDWT_DOUBLE  // the two-level kernel exists in fp32 only
 // ------------------------------------------------------------------------------------------------
 // TWO forward levels in one wavefront: in (N0r, N0c) -> H1, V1, D1 (N0r/2, N0c/2) and A2, H2, V2, D2
@@ -596,39 +642,6 @@ struct FwdWave2Args {
 // >= the row's byte length (in particular kDropped) are dropped.  The descriptor is rebuilt per row from
 // the row pointer -- a few scalar instructions -- because on gfx950 the range check of a raw buffer covers
 // voffset + soffset, so the row cannot ride in soffset (measured: everything below row 0 was dropped).
-#ifdef PDWT_CPU_EMU
-struct RowBuf {
-    char* base;
-    unsigned bytes;
-};
-PDWT_DEVICE RowBuf row_buf(float* row, unsigned row_bytes) { return RowBuf{(char*)row, row_bytes}; }
-PDWT_DEVICE void row_st8(const RowBuf& r, unsigned off, float x, float y) {
-    if (off < r.bytes) { float* p = reinterpret_cast<float*>(r.base + off); p[0] = x; p[1] = y; }
-}
-PDWT_DEVICE void row_st4(const RowBuf& r, unsigned off, float x) {
-    if (off < r.bytes) *reinterpret_cast<float*>(r.base + off) = x;
-}
-#else
-struct RowBuf {
-    __amdgpu_buffer_rsrc_t rsrc;
-};
-static __device__ __forceinline__ RowBuf row_buf(float* row, unsigned row_bytes) {
-    RowBuf r;
-    r.rsrc = __builtin_amdgcn_make_buffer_rsrc(row, (short)0, (int)row_bytes, 0x00020000);
-    return r;
-}
-typedef unsigned pdwt_u2 __attribute__((ext_vector_type(2)));
-static __device__ __forceinline__ void row_st8(const RowBuf& r, unsigned off, float x, float y) {
-    pdwt_u2 d;
-    d.x = __builtin_bit_cast(unsigned, x);
-    d.y = __builtin_bit_cast(unsigned, y);
-    __builtin_amdgcn_raw_buffer_store_b64(d, r.rsrc, (int)off, 0, 0);
-}
-static __device__ __forceinline__ void row_st4(const RowBuf& r, unsigned off, float x) {
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, x), r.rsrc, (int)off, 0, 0);
-}
-#endif
-
 constexpr unsigned kDropped = 0xFFFFFFFFu;  // a byte offset no descriptor accepts
 
 template <int HLEN>

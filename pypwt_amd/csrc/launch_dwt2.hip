@@ -37,8 +37,8 @@ static hipError_t run_inv(const Inv2DArgs& a, int batch, hipStream_t s) {
 }
 
 #ifdef PDWT_DOUBLE
-// fp64 build: of the tuned kernels only the register (wave) kernels of dwt2_wave_kernels.hpp are compiled (they are
-// written over real_t); the LDS-tiled packed-fp32 kernels (tuned single-level, tile pyramid, streaming strips, fused
+// fp64 build: of the tuned kernels only the register kernels of dwt2_wave_kernels.hpp and dwt1_reg_kernels.hpp are
+// compiled (they are written over real_t); the LDS-tiled packed-fp32 kernels (tuned single-level, tile pyramid, streaming strips, fused
 // 1D pyramids, fused SWT groups) are not: those levels run through the generic kernels of this file / launch_dwt1.hip
 hipError_t try_launch_dwt2_fwd_fast(const Fwd2DArgs&, int, hipStream_t) { return hipErrorNotSupported; }
 hipError_t try_launch_dwt2_inv_fast(const Inv2DArgs&, int, hipStream_t) { return hipErrorNotSupported; }
@@ -59,13 +59,6 @@ hipError_t launch_swt2_fused(const real_t*, real_t*, real_t* const*, int, int, i
                              hipStream_t) { return hipErrorNotSupported; }
 int dwt1_fused_max_levels(int) { return 1; }
 bool dwt1_fused_supported(int, int, int) { return false; }
-bool dwt1_reg_supported(int, int, int) { return false; }
-hipError_t launch_dwt1_inv_reg(const real_t*, const real_t* const*, real_t*, int, int, int, int, const FilterBank&, hipStream_t) {
-    return hipErrorNotSupported;
-}
-hipError_t launch_dwt1_fwd_reg(const real_t*, real_t* const*, real_t*, int, int, int, int, const FilterBank&, hipStream_t) {
-    return hipErrorNotSupported;
-}
 hipError_t launch_dwt1_fwd_fused(const real_t*, real_t* const*, real_t*, int, int, int, int, const FilterBank&,
                                  hipStream_t) { return hipErrorNotSupported; }
 hipError_t launch_dwt1_inv_fused(const real_t*, const real_t* const*, real_t*, int, int, int, int, const FilterBank&,

@@ -386,7 +386,8 @@ void build_schedule(pdwt_plan* p) {
                 // pyramid, which reads and writes every sample once in ONE launch, is ahead -- 16 x 2^24: 462 us against
                 // 513 + 71 us -- while the inverse register kernels stay ahead, 440 + 53 against 607 us;
                 // profiles/r02y_bench_cfg3_batch.txt.  Bit 2 of the knob forces the forward too.)
-                const bool reg_here = ((reg >> dir) & 1) && (dir == 1 || ((reg >> 2) & 1) ||
+                // (The fp64 build has no LDS pyramid to prefer.)
+                const bool reg_here = ((reg >> dir) & 1) && (dir == 1 || ((reg >> 2) & 1) || sizeof(real_t) == 8 ||
                                                              (long long)p->batch * p->info.Nr * p->info.Nc <= (1LL << 25));
                 int K = reg_here ? (L - l < 3 ? L - l : 3) : 0;
                 while (K >= 1 && !dwt1_reg_supported(hlen, p->lc[l], K)) --K;

@@ -183,6 +183,27 @@ def test_reg_1d_three_levels_in_registers_on_the_gpu():
         lib.pdwt_set_tuning(b"reg1d", was)
 
 
+def test_fp64_reg_1d_kernels_vs_the_fp64_oracle():
+    """The same 1D register kernels compiled over doubles (fp64 library: every eligible level triple, forward and
+    inverse) against the fp64-storage oracle at 1e-12."""
+    from pypwt_amd import Wavelets64
+    for wname, N, lv, rows in (("sym8", 1 << 16, 6, 1), ("db4", 1 << 14, 5, 3), ("haar", 1 << 13, 4, 2),
+                               ("db10", 1 << 15, 3, 1), ("coif2", 3 * (1 << 13), 4, 1), ("sym8", 1 << 20, 6, 1),
+                               ("db2", 2048 + 64 * 57, 1, 2), ("db7", 5 * (1 << 12), 2, 1)):
+        x = oracle.hash_input((rows, N), 8650, scale=255.0).astype(np.float64)
+        x += 1e-9 * np.arange(x.size).reshape(x.shape)
+        w = Wavelets64(x if rows > 1 else x[0], wname, lv, ndim=1)
+        assert w.levels == lv
+        w.forward()
+        ref = oracle.forward(x, wname, lv, ndim=1, double="full")
+        for k, (g, r) in enumerate(zip(_flat(w.coeffs), ref)):
+            assert g.dtype == np.float64
+            assert np.abs(g.reshape(r.shape) - r).max() <= 1e-12 * max(1.0, float(np.abs(r).max())), (wname, N, k)
+        w.inverse()
+        want = oracle.inverse(ref, x.shape, wname, lv, ndim=1, double="full")
+        assert np.abs(w.image.reshape(x.shape) - want).max() <= 1e-11 * 255, (wname, N)
+
+
 def test_swt_haar_levels_fused_per_launch_on_the_gpu():
     """swt2_fwd_fused / swt2_inv_fused (2-tap 2D SWT, levels 1-3 and 4-6 in one launch each, registers + lane shifts)
     against the oracle: coefficients of every level, reconstruction, and the deferred soft threshold folded into the
