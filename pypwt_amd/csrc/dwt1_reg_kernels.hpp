@@ -451,9 +451,9 @@ PDWT_DEVICE void inv1d_reg_block(const Inv1DRegArgs& a, WaveReg<real_t, 16>& in,
         const real_t* v = x.mine(lane);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            v4f w;
+            real4_t w;
             w.x = v[4 * i]; w.y = v[4 * i + 1]; w.z = v[4 * i + 2]; w.w = v[4 * i + 3];
-            *reinterpret_cast<v4f*>(lds + kReg1LdsStride * lane + 4 * i) = w;
+            *reinterpret_cast<real4_t*>(lds + kReg1LdsStride * lane + 4 * i) = w;
         }
     }
     const RowBuf bo = row_buf(a.out + row * a.N0, kRealBytes * (unsigned)a.N0);
@@ -461,7 +461,7 @@ PDWT_DEVICE void inv1d_reg_block(const Inv1DRegArgs& a, WaveReg<real_t, 16>& in,
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int q = 64 * i + lane;  // quad q of the block = samples 4q .. 4q+3, computed by lane q / 4
-            const v4f w = *reinterpret_cast<const v4f*>(lds + kReg1LdsStride * (q >> 2) + 4 * (q & 3));
+            const real4_t w = *reinterpret_cast<const real4_t*>(lds + kReg1LdsStride * (q >> 2) + 4 * (q & 3));
             long long sidx = base + O0 + 4 * q;
             if (GUARD) sidx %= a.N0;  // N0 % 16 == 0: a quad never straddles the end of the row
             const bool ok = (q >> 2) < g.V;

@@ -102,10 +102,10 @@ PDWT_DEVICE v4f wave_ld16(const real_t* base, unsigned byte_off) {
     return *reinterpret_cast<const v4f*>(reinterpret_cast<const char*>(base) + byte_off);
 }
 PDWT_DEVICE void wave_st8(real_t* base, unsigned byte_off, real_t x, real_t y) {
-    v2f w;
+    real2_t w;  // the HIP struct type, not the ext vector: its stores do not alias the row loads for the scheduler
     w.x = x;
     w.y = y;
-    *reinterpret_cast<v2f*>(reinterpret_cast<char*>(base) + byte_off) = w;
+    *reinterpret_cast<real2_t*>(reinterpret_cast<char*>(base) + byte_off) = w;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -372,9 +372,9 @@ PDWT_DEVICE v2f wave_ld8(const real_t* base, unsigned byte_off) {
     return *reinterpret_cast<const v2f*>(reinterpret_cast<const char*>(base) + byte_off);
 }
 PDWT_DEVICE void wave_st16(real_t* base, unsigned byte_off, real_t x, real_t y, real_t z, real_t w) {
-    v4f o;
+    real4_t o;
     o.x = x; o.y = y; o.z = z; o.w = w;
-    *reinterpret_cast<v4f*>(reinterpret_cast<char*>(base) + byte_off) = o;
+    *reinterpret_cast<real4_t*>(reinterpret_cast<char*>(base) + byte_off) = o;
 }
 
 template <int HLEN>
