@@ -17,8 +17,14 @@ collective of the path), rank 0 finishes the transform with an ordinary single-G
 hands the slabs back with one broadcast ("after ~log2(G) levels ... gather the remaining A
 band onto one GPU").  `tiled_levels` says how many levels ran as slabs.
 
-Restrictions: separable decimated 2D DWT, float32, columns divisible by 2^levels, rows per rank divisible
-by 2^tiled_levels with tiled_levels >= 1.
+The undecimated transform (do_swt=1) needs no per-level exchange: an output row of level l depends on the image
+rows within hlen (2^l - 1) of it, so ONE exchange of hs = hlen (2^levels - 1) image rows per side lets every rank run
+the whole multi-level SWT plan on its extended slab and keep the interior rows of every band (the inverse: one
+exchange of the same halo of all 3 levels + 1 bands, stacked into one message per neighbour).  SURVEY.md 8e's
+"halo x 2^(l-1)" summed over the levels.
+
+Restrictions: separable 2D transforms, float32.  DWT: columns divisible by 2^levels, rows per rank divisible by
+2^tiled_levels with tiled_levels >= 1.  SWT: rows per rank >= hlen (2^levels - 1).
 
 torch is plumbing here (device tensors, streams, torch.distributed); all arithmetic is done by the HIP
 library through the C ABI, with zero-copy views of the plans' device buffers.
@@ -40,7 +46,7 @@ class _DeviceView(object):
 
 
 class TiledWavelets(object):
-    def __init__(self, slab, wname, levels, group=None):
+    def __init__(self, slab, wname, levels, group=None, do_swt=0):
         import sys
         if "torch" not in sys.modules and _lib._libs:
             # PyTorch-ROCm bundles its own libamdhip64 under the same soname as /opt/rocm's: whichever is
@@ -69,6 +75,22 @@ class TiledWavelets(object):
         check(hlen, "TiledWavelets()", self._lib)
         self.hlen = int(hlen)
         self.levels = int(levels)
+        self.do_swt = int(bool(do_swt))
+        self._deep = None    # rank 0: the single-GPU plan of the gathered approximation
+        self._plans = {}
+        self._bands = None   # after forward(): [A_L, (H1,V1,D1), ...] torch slabs
+        # every plan runs on ONE side stream that torch also uses for its copies (a NULL stream handle would
+        # mean "private stream" to pdwt_create_batched, unordered with torch's default stream)
+        self._stream = torch.cuda.Stream(device=self.device)
+        if self.do_swt:
+            if self.levels < 1:
+                raise ValueError("TiledWavelets: levels must be >= 1")
+            self._hs = self.hlen * ((1 << self.levels) - 1)   # rows of each neighbour every band of this slab depends on
+            if self._hs > self.n:
+                raise ValueError("TiledWavelets: a slab of %d rows is thinner than the halo of a %d-level SWT with %s (%d rows)"
+                                 % (self.n, self.levels, self.wname, self._hs))
+            self.tiled_levels, self.deep_levels = self.levels, 0
+            return
         if self.levels < 1 or self.Nc % (1 << self.levels):
             raise ValueError("TiledWavelets: columns (%d) must be divisible by 2^levels" % self.Nc)
         c = self.hlen // 2 - 1
@@ -85,12 +107,6 @@ class TiledWavelets(object):
             raise ValueError("TiledWavelets: a slab of %d rows is too thin (or odd) for one level of %s (halo %d)"
                              % (self.n, self.wname, max(self._hp, 2 * self._hq)))
         self.tiled_levels, self.deep_levels = t, self.levels - t
-        self._deep = None    # rank 0: the single-GPU plan of the gathered approximation
-        self._plans = {}
-        self._bands = None   # after forward(): [A_L, (H1,V1,D1), ...] torch slabs
-        # every plan runs on ONE side stream that torch also uses for its copies (a NULL stream handle would
-        # mean "private stream" to pdwt_create_batched, unordered with torch's default stream)
-        self._stream = torch.cuda.Stream(device=self.device)
 
     # ---- single-level plans on the extended slab, cached per shape
     def _plan(self, rows, cols):
@@ -164,10 +180,61 @@ class TiledWavelets(object):
         with self._on_stream():
             return self._inverse()
 
+    # ---- undecimated transform: the whole multi-level plan on the slab extended by hs rows per side
+    def _swt_plan(self):
+        key = ("swt", self.n + 2 * self._hs, self.Nc)
+        if key not in self._plans:
+            h = handle_t()
+            rc = self._lib.pdwt_create_batched(None, 1, key[1], key[2], self.wname.encode("ASCII"), self.levels, 1, 1, 0,
+                                               1, 2, self.device.index, C.c_void_p(self._stream.cuda_stream), C.byref(h))
+            check(rc, "TiledWavelets SWT plan", self._lib)
+            info = PdwtInfo()
+            check(self._lib.pdwt_get_info(h, C.byref(info), None, None, None, None), lib=self._lib)
+            if info.nlevels != self.levels:
+                self._lib.pdwt_destroy(h)
+                raise ValueError("TiledWavelets: %d SWT levels requested, the slab allows only %d" % (self.levels, info.nlevels))
+            self._plans[key] = h
+        return self._plans[key]
+
+    def _forward_swt(self):
+        m, w, hs = self.n, self.Nc, self._hs
+        h = self._swt_plan()
+        img = self._view(self._lib.pdwt_image_ptr(h), (m + 2 * hs, w))
+        from_prev, from_next = self._exchange(self.slab[:hs], self.slab[m - hs:])
+        img[:hs].copy_(from_prev)
+        img[hs + m:].copy_(from_next)
+        img[hs:hs + m].copy_(self.slab)
+        check(self._lib.pdwt_forward(h), "TiledWavelets.forward (SWT)", self._lib)
+        flat = [self._view(self._lib.pdwt_coeff_ptr(h, k), (m + 2 * hs, w))[hs:hs + m].clone()
+                for k in range(3 * self.levels + 1)]
+        self._bands = [flat[0]] + [tuple(flat[1 + 3 * l:4 + 3 * l]) for l in range(self.levels)]
+        return self
+
+    def _inverse_swt(self):
+        torch = self._torch
+        m, w, hs = self.n, self.Nc, self._hs
+        h = self._swt_plan()
+        flat = [self._bands[0]] + [b for lvl in self._bands[1:] for b in lvl]
+        stack = torch.stack(flat)                                            # (3 levels + 1, m, w)
+        from_prev, from_next = self._exchange(stack[:, :hs].contiguous(), stack[:, m - hs:].contiguous())
+        ext0 = torch.cat([from_prev[0], flat[0], from_next[0]]).contiguous()
+        # band 0 through set_coeff (it makes the plan's coefficients current), the details into the plan's buffers
+        check(self._lib.pdwt_set_coeff(h, C.c_void_p(ext0.data_ptr()), 0, 1), lib=self._lib)
+        for k in range(1, len(flat)):
+            dst = self._view(self._lib.pdwt_coeff_ptr(h, k), (m + 2 * hs, w))
+            dst[:hs].copy_(from_prev[k])
+            dst[hs:hs + m].copy_(flat[k])
+            dst[hs + m:].copy_(from_next[k])
+        check(self._lib.pdwt_inverse(h), "TiledWavelets.inverse (SWT)", self._lib)
+        self.slab = self._view(self._lib.pdwt_image_ptr(h), (m + 2 * hs, w))[hs:hs + m].clone()
+        return self
+
     def _forward(self, slab=None):
         torch = self._torch
         if slab is not None:
             self.slab.copy_(torch.as_tensor(slab, dtype=torch.float32, device=self.device))
+        if self.do_swt:
+            return self._forward_swt()
         cur, hp = self.slab, self._hp
         bands = [None]
         for _ in range(self.tiled_levels):
@@ -253,6 +320,8 @@ class TiledWavelets(object):
     def _inverse(self):
         if self._bands is None:
             raise RuntimeError("TiledWavelets.inverse: call forward() first")
+        if self.do_swt:
+            return self._inverse_swt()
         torch, hq = self._torch, self._hq
         cur = self._bands[0]
         if self.deep_levels:

@@ -25,7 +25,7 @@ def _free_port():
     return p
 
 
-def _run_ranks(world, wname, levels, shape):
+def _run_ranks(world, wname, levels, shape, swt=0):
     """Each rank is a child process (torch must be imported before libpypwt_amd.so in a process, and the
     pytest process has long loaded the library): tests/tiled_worker.py compares its slabs itself."""
     port = _free_port()
@@ -34,7 +34,7 @@ def _run_ranks(world, wname, levels, shape):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port))
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "tiled_worker.py"), wname,
-                                       str(levels), str(shape[0]), str(shape[1]), "gloo"],
+                                       str(levels), str(shape[0]), str(shape[1]), "gloo", str(swt)],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = []
     for p in procs:
@@ -70,6 +70,15 @@ def test_deep_levels_are_gathered_on_rank0(world, wname, levels, shape):
     """more levels than the slabs support: the remaining approximation is gathered (one all-gather), finished on
     rank 0, and handed back by the inverse (one broadcast)"""
     _run_ranks(world, wname, levels, shape)
+
+
+@pytest.mark.parametrize("world,wname,levels,shape", [(1, "haar", 3, (64, 96)), (2, "haar", 4, (128, 256)),
+                                                      (2, "db2", 3, (128, 100)), (3, "sym4", 2, (96, 64)),
+                                                      (4, "haar", 5, (512, 256)), (2, "bior2.2", 2, (90, 64))])
+def test_swt_slabs_with_one_halo_exchange(world, wname, levels, shape):
+    """undecimated transform: ONE exchange of hlen (2^levels - 1) rows per side, the whole multi-level SWT plan on the
+    extended slab, interiors kept; every band's slab and the reconstruction against the oracle"""
+    _run_ranks(world, wname, levels, shape, swt=1)
 
 
 def test_import_order_is_checked():

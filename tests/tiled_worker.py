@@ -1,7 +1,8 @@
 """Worker of tests/test_gpu_tiled.py: one rank of a TiledWavelets run (launched as a child process with
 RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set).  Every rank computes the transform of the WHOLE image
 with the CPU ORACLE and compares its own row slab of every sub-band (the whole band for the levels that
-were gathered on rank 0) and of the reconstruction; prints 'OK <rank> tiled=<t> deep=<d>' on success."""
+were gathered on rank 0) and of the reconstruction; prints 'OK <rank> tiled=<t> deep=<d>' on success.
+argv: wname levels Nr Nc [backend [do_swt]]."""
 import os
 import sys
 
@@ -21,14 +22,15 @@ def main():
     wname, levels = sys.argv[1], int(sys.argv[2])
     Nr, Nc = int(sys.argv[3]), int(sys.argv[4])
     backend = sys.argv[5] if len(sys.argv) > 5 else "gloo"
+    swt = int(sys.argv[6]) if len(sys.argv) > 6 else 0
     torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1))
     if world > 1:  # world 1 runs WITHOUT a process group: the ring closes on the rank itself
         dist.init_process_group(backend, rank=rank, world_size=world)
     x = oracle.hash_input((Nr, Nc), 555, scale=255.0)
     n = Nr // world
-    tw = TiledWavelets(x[rank * n:(rank + 1) * n], wname, levels)
+    tw = TiledWavelets(x[rank * n:(rank + 1) * n], wname, levels, do_swt=swt)
     tw.forward()
-    flat = oracle.forward(x, wname, levels)  # [A, H1, V1, D1, H2, ...] from the CPU oracle
+    flat = oracle.forward(x, wname, levels, do_swt=swt)  # [A, H1, V1, D1, H2, ...] from the CPU oracle
     ref = [flat[0]] + [flat[1 + 3 * l:4 + 3 * l] for l in range(levels)]
     got = tw.coeffs
     assert tw.tiled_levels + tw.deep_levels == levels and tw.tiled_levels >= 1
@@ -37,7 +39,7 @@ def main():
         k = a.shape[0] // world
         return a[rank * k:(rank + 1) * k]
 
-    tol = 2e-6 * (levels + 1) * 255 * 4 ** levels
+    tol = 2e-6 * (levels + 1) * 255 * 4 ** levels  # SWT bands grow by 2 per level like the decimated ones
     for lvl in range(1, levels + 1):
         if lvl <= tw.tiled_levels:
             for g, r in zip(got[lvl], ref[lvl]):
@@ -54,6 +56,9 @@ def main():
     else:
         assert got[0] is None
     tw.inverse()
+    if swt:  # the reconstruction against the oracle's inverse of the oracle's coefficients too
+        rec = oracle.inverse(flat, x.shape, wname, levels, do_swt=1)
+        assert np.abs(tw.image - rec[rank * n:(rank + 1) * n]).max() <= 2e-3, "reconstruction vs oracle"
     assert np.abs(tw.image - x[rank * n:(rank + 1) * n]).max() <= 2e-3, "reconstruction"
     tw.forward()
     tw.inverse()  # plans are reused: a second round trip must work too
