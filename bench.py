@@ -93,6 +93,8 @@ def kernel_algorithmic_bytes(label, cfg, batch):
         # two levels in one launch: the pair's input read once, details of the first and all four bands
         # of the second level written once = 8 B per sample entering the pair
         return 8.0 * samples / (4 ** (lvl - 1))
+    if name in ("dwt2_fwd_pyr3", "dwt2_inv_pyr3"):  # three levels in one launch: 8 B per sample entering the group
+        return 8.0 * samples / (4 ** (lvl - 1))
     if name.startswith("dwt2"):
         return 8.0 * samples / (4 ** (lvl - 1))
     if name.startswith("dwt1"):
@@ -122,6 +124,8 @@ def label_step_kernels(names, L):
             out.append("%s[L%d]" % (n, f)); f += 1
         elif base in ("dwt2_fwd_pyr2", "dwt2_fwd_strip2", "dwt2_fwd_wave2"):
             out.append("%s[L%d]" % (n, f)); f += 2
+        elif base == "dwt2_fwd_pyr3":
+            out.append("%s[L%d]" % (n, f)); f += 3
         elif base == "dwt1_fwd_fused":
             out.append("%s[L%d]" % (n, f)); f = L + 1
         elif base == "swt2_fwd_fused":  # levels 1-3 / 4-6 of a 2-tap SWT in one launch (two levels when only two are left)
@@ -132,6 +136,8 @@ def label_step_kernels(names, L):
             out.append("%s[L%d]" % (n, i)); i -= 1
         elif base in ("dwt2_inv_pyr2", "dwt2_inv_strip2", "dwt2_inv_wave2"):
             out.append("%s[L%d]" % (n, i - 1)); i -= 2
+        elif base == "dwt2_inv_pyr3":
+            out.append("%s[L%d]" % (n, i - 2)); i -= 3
         elif base == "dwt1_inv_fused":
             out.append("%s[L%d]" % (n, 1)); i = 0
         elif base == "swt2_inv_fused":  # groups start at levels 1 and 4

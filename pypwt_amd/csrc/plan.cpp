@@ -331,6 +331,16 @@ void build_schedule(pdwt_plan* p) {
             return force_strip || samples(l) >= (1LL << 26);
         };
         auto pyr_at = [&](int l) { return fusable && !no_pyr && pair_ok(l) && samples(l) <= (1LL << 20); };
+        // Three levels per launch where a small image (at most 2^19 samples, 2^20 over the batch) has three (or five, six, ...) levels
+        // left: one launch fewer per direction -- 512^2 db2 L3: 15.6 -> 9.9 us per forward+inverse, 256^2 db4 L5: 26.8 ->
+        // 18.4 us, 64 x 128^2 db4 L3: 27.0 -> 20.3 us; at 1024^2 the pairs are ahead (db4 L3: 18.6 against 20.4 us).  Four levels left stay two tile
+        // pyramids.  PDWT_NO_PYR3=1 keeps the pairs (A/B measurements).
+        const bool no_pyr3 = no_pyr || getenv("PDWT_NO_PYR3") != nullptr;
+        auto pyr3_at = [&](int l) {
+            const int left = L - l + 1;
+            return fusable && !no_pyr3 && left >= 3 && left != 4 && samples(l) <= (1LL << 20) &&
+                   (long long)p->lr[l - 1] * p->lc[l - 1] <= (1LL << 19) && dwt2_pyr3_supported(hlen, p->lr[l - 1], p->lc[l - 1]);
+        };
         // Two levels per WAVEFRONT (dwt2_fwd2_wave: A_l stays in registers, overlapping strips).  Correct and
         // tested, but NOT faster than two launches on MI355X (profiles/r02g_wbench_*.txt: 4096^2 31.3 us against
         // 21.9 + 7.9 us; 8 x 4096^2 267 us against 209 + ~50 us, streaming strips 229 us): one wavefront per SIMD is
@@ -365,6 +375,7 @@ void build_schedule(pdwt_plan* p) {
                 if (const int K = swt_group(l)) { out.push_back({Step::SWTF, l, K}); l += K - 1; continue; }
                 if (strip_at(l, dir != 0)) { out.push_back({Step::STRIP2, l, 2}); l++; }
                 else if (wave2_at(l, dir != 0)) { out.push_back({Step::WAVE2, l, 2}); l++; }
+                else if (pyr3_at(l)) { out.push_back({Step::PYR3, l, 3}); l += 2; }
                 else if (pyr_at(l) && !strip_at(l + 1, dir != 0)) { out.push_back({Step::PYR2, l, 2}); l++; }
                 else out.push_back({Step::LEVEL, l, 1});
             }
@@ -623,6 +634,13 @@ int forward_impl(pdwt_plan* p, int only = 0) {
             e = s.kind == Step::STRIP2  ? launch_dwt2_fwd_strip2(src, det1, band2, r0, c0, hlen, p->dec, B, p->stream)
                 : s.kind == Step::WAVE2 ? launch_dwt2_fwd_wave2(src, det1, band2, r0, c0, hlen, p->dec, B, p->stream)
                                         : launch_dwt2_fwd_pyr2(src, det1, band2, r0, c0, hlen, p->dec, B, p->stream);
+        } else if (s.kind == Step::PYR3) {
+            real_t* det[9];
+            for (int k = 0; k < 9; k++) det[k] = p->band(3 * (l - 1) + 1 + k);
+            Stamp st(p, "dwt2_fwd_pyr3");
+            if (!run) continue;
+            e = launch_dwt2_fwd_pyr3(approx_slot(p, l - 1), det, approx_slot(p, l + 2), p->lr[l - 1], p->lc[l - 1], hlen, p->dec, B,
+                                     p->stream);
         } else if (s.kind == Step::SWTF) {
             real_t* det[9] = {};
             for (int k = 0; k < 3 * s.K; k++) det[k] = p->band(3 * (l - 1) + 1 + k);
@@ -672,6 +690,13 @@ int inverse_impl(pdwt_plan* p, int only = 0) {
             e = s.kind == Step::STRIP2
                     ? launch_dwt2_inv_strip2(band2, det1, approx_slot(p, l - 1), p->lr[l - 1], p->lc[l - 1], hlen, p->rec, B, p->stream)
                     : launch_dwt2_inv_pyr2(band2, det1, approx_slot(p, l - 1), p->lr[l - 1], p->lc[l - 1], hlen, p->rec, B, p->stream);
+        } else if (s.kind == Step::PYR3) {
+            real_t* det[9];
+            for (int k = 0; k < 9; k++) det[k] = p->band(3 * (l - 1) + 1 + k);
+            Stamp st(p, "dwt2_inv_pyr3");
+            if (!run) continue;
+            e = launch_dwt2_inv_pyr3(approx_slot(p, l + 2), det, approx_slot(p, l - 1), p->lr[l - 1], p->lc[l - 1], hlen, p->rec, B,
+                                     p->stream);
         } else if (s.kind == Step::SWTF) {
             real_t* det[9] = {};
             for (int k = 0; k < 3 * s.K; k++) det[k] = p->band(3 * (l - 1) + 1 + k);

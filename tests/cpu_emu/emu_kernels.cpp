@@ -14,6 +14,7 @@
 #include "../../pypwt_amd/csrc/dwt2_fast_kernels.hpp"
 #include "../../pypwt_amd/csrc/dwt2_kernels.hpp"
 #include "../../pypwt_amd/csrc/dwt2_pyramid_kernels.hpp"
+#include "../../pypwt_amd/csrc/dwt2_pyr3_kernels.hpp"
 #include "../../pypwt_amd/csrc/dwt2_strip_kernels.hpp"
 #include "../../pypwt_amd/csrc/dwt2_wave_kernels.hpp"
 #include "../../pypwt_amd/csrc/nonsep_kernels.hpp"
@@ -418,6 +419,47 @@ EMU_API int emu_dwt2_inv_pyr2(const float* l1, const float* l2, int batch, int N
     set_bank_i(a.fb, lo, hi, hlen);
     switch (hlen) {
 #define X(h) case h: if (tile == 0) run_inv_pyr2<h, 64, 8, 256>(a, batch); else run_inv_pyr2<h, 64, 16, 256>(a, batch); return 0;
+        X(2) X(4) X(6) X(8)
+#undef X
+    }
+    return -1;
+}
+
+// ------------------------------------------------------------------ three-level pyramid (small images)
+// det: H,V,D of level 1 (3 x batch x N0r/2 x N0c/2), then of level 2, then of level 3; app: A3 (batch x N0r/8 x N0c/8)
+template <int HLEN, int T>
+static void run_pyr3(Pyr3Args a, int batch, bool inverse) {
+    constexpr int T0 = 8 * T, NT = 256;
+    if (!inverse) {
+        std::vector<float> smem(Pyr3FwdGeom<HLEN, T>::LDS + 64, NAN);
+        a.tiles_x = cdiv(a.N0c / 8, T); a.tiles_y = cdiv(a.N0r / 8, T);
+        for (int bz = 0; bz < batch; bz++)
+            for (int by = 0; by < a.tiles_y; by++)
+                for (int bx = 0; bx < a.tiles_x; bx++) dwt2_fwd_pyr3_tile<HLEN, T, NT>(a, bx, by, bz, smem.data());
+    } else {
+        std::vector<float> smem(Pyr3InvGeom<HLEN, T0>::LDS + 64, NAN);
+        a.tiles_x = cdiv(a.N0c, T0); a.tiles_y = cdiv(a.N0r, T0);
+        for (int bz = 0; bz < batch; bz++)
+            for (int by = 0; by < a.tiles_y; by++)
+                for (int bx = 0; bx < a.tiles_x; bx++) dwt2_inv_pyr3_tile<HLEN, T0, NT>(a, bx, by, bz, smem.data());
+    }
+}
+
+EMU_API int emu_dwt2_pyr3(int inverse, float* image, int batch, int N0r, int N0c, const float* lo, const float* hi, int hlen,
+                          int tile, float* det, float* app) {
+    if ((hlen & 1) || hlen > 8 || (N0c & 7) || (N0r & 7)) return -2;
+    Pyr3Args a;
+    long long off = 0;
+    for (int k = 0; k < 3; k++) {
+        const long long n = (long long)batch * (N0r >> (k + 1)) * (N0c >> (k + 1));
+        for (int b = 0; b < 3; b++) { a.det[k][b] = det + off; off += n; }
+    }
+    a.in = inverse ? app : image;
+    a.out = inverse ? image : app;
+    a.N0r = N0r; a.N0c = N0c;
+    set_bank(a.fb, lo, hi, hlen);
+    switch (hlen) {
+#define X(h) case h: if (tile == 2) run_pyr3<h, 2>(a, batch, inverse != 0); else if (tile == 4) run_pyr3<h, 4>(a, batch, inverse != 0); else run_pyr3<h, 8>(a, batch, inverse != 0); return 0;
         X(2) X(4) X(6) X(8)
 #undef X
     }

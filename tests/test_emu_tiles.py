@@ -351,6 +351,51 @@ def test_emu_dwt2_inv_pyramid(wname):
                 assert np.abs(out[b] - want).max() <= 3 * _tol(want), (wname, shape, tile)
 
 
+# ----------------------------------------------------------------------------- three-level pyramid (small images)
+@pytest.mark.parametrize("wname", ["haar", "db2", "db3", "db4", "sym4", "bior3.1", "rbio2.2"])
+def test_emu_dwt2_pyramid_of_three_levels(wname):
+    """dwt2_fwd_pyr3_tile / dwt2_inv_pyr3_tile: three levels per launch out of LDS -- whole and partial tiles, images
+    smaller than one tile's halo (the wrap goes around more than once), a batch."""
+    hlen, dlo, dhi, rlo, rhi = oracle.filters(wname)
+    for si, (B, shape) in enumerate([(1, (64, 64)), (1, (128, 192)), (2, (40, 72)), (1, (8, 8)), (1, (16, 264)), (1, (200, 136)),
+                                    (1, (96, 64)), (1, (72, 104)), (2, (8, 16))]):
+        x = oracle.hash_input((B,) + shape, 8800 + si)
+        dims = [(shape[0] >> k, shape[1] >> k) for k in (1, 2, 3)]
+        ndet = sum(3 * B * r * c for r, c in dims)
+        tile = (8, 4, 2)[si % 3]  # the launcher's three tile sizes
+        det = np.full(ndet, np.nan, dtype=np.float32)
+        app = np.full((B,) + dims[2], np.nan, dtype=np.float32)
+        assert lib().emu_dwt2_pyr3(0, P(x), B, shape[0], shape[1], P(dlo), P(dhi), hlen, tile, P(det), P(app)) == 0
+        assert np.isfinite(det).all() and np.isfinite(app).all(), (wname, shape)
+
+        def bands_of(flat, b):
+            out, off = [], 0
+            for r, c in dims:
+                lvl = []
+                for _ in range(3):
+                    lvl.append(flat[off:off + B * r * c].reshape(B, r, c)[b])
+                    off += B * r * c
+                out.append(lvl)
+            return out
+
+        for b in range(B):
+            ref = oracle.forward(x[b], wname, 3, ndim=2)  # [A3, H1,V1,D1, H2,V2,D2, H3,V3,D3]
+            got = [app[b]] + [band for lvl in bands_of(det, b) for band in lvl]
+            scale = 8.0 * float(np.abs(x[b]).max())  # a level-3 detail is a difference of sums of 64 samples
+            for k, (g, r) in enumerate(zip(got, ref)):
+                assert np.abs(g - r).max() <= 3e-6 * max(float(np.abs(r).max()), scale), (wname, shape, k)
+        # inverse of arbitrary coefficients
+        det_in = (oracle.hash_input((ndet,), 8900 + si, 2.0) - 1.0).astype(np.float32)
+        app_in = (oracle.hash_input((B,) + dims[2], 8950 + si, 2.0) - 1.0).astype(np.float32)
+        out = np.full((B,) + shape, np.nan, dtype=np.float32)
+        assert lib().emu_dwt2_pyr3(1, P(out), B, shape[0], shape[1], P(rlo), P(rhi), hlen, (2, 8, 4)[si % 3], P(det_in), P(app_in)) == 0
+        for b in range(B):
+            bands = [app_in[b]] + [band for lvl in bands_of(det_in, b) for band in lvl]
+            want = oracle.inverse(bands, shape, wname, 3, ndim=2)
+            assert np.isfinite(out[b]).all(), (wname, shape)
+            assert np.abs(out[b] - want).max() <= 4 * _tol(want), (wname, shape)
+
+
 @pytest.mark.parametrize("wname", ["haar", "db2", "db3", "db4", "sym4", "bior3.1"])
 def test_emu_dwt2_fwd_strip_streaming(wname):
     """Two levels per launch, streaming down column strips with carried (L,H) rows."""

@@ -332,6 +332,40 @@ def test_strip_paths_match_oracle(wname, monkeypatch):
     assert np.abs(rec - w2.image).max() <= 1e-3
 
 
+@pytest.mark.gpu
+def test_three_level_pyramid_on_small_images():
+    """Small images with three (five, six) levels left run three levels per launch (dwt2_fwd_pyr3 / dwt2_inv_pyr3):
+    the launch names say so, and every band and the reconstruction equal the oracle's."""
+    from pypwt_amd import BatchedWavelets
+    cases = (("db2", (512, 512), 3, 1), ("haar", (64, 64), 3, 2), ("db3", (256, 384), 5, 1), ("db4", (256, 256), 3, 1),
+             ("sym4", (512, 1024), 6, 1), ("db2", (40, 72), 3, 3), ("bior3.1", (256, 128), 3, 1), ("haar", (8, 8), 3, 1),
+             ("db4", (128, 128), 3, 64), ("db3", (264, 200), 3, 2))
+    for ci, (wname, shape, L, B) in enumerate(cases):
+        x = oracle.hash_input((B,) + shape, 4300 + ci, scale=255.0)
+        bw = BatchedWavelets(B, shape[0], shape[1], wname, L, img=x)
+        assert bw.levels == L, (wname, shape)
+        bw.enable_kernel_timing(True)
+        bw.reset_kernel_times()
+        bw.forward()
+        names = [n for n, _ in bw.kernel_times()]
+        assert names[0] == "dwt2_fwd_pyr3", (wname, shape, names)
+        refs = [oracle.forward(x[b], wname, L) for b in range(B)]
+        for b in range(B):
+            for num, r in enumerate(refs[b]):
+                g = bw.coeff_at(num, b)
+                tol = 2e-6 * (1 + L) * max(float(np.abs(r).max()), 255.0 * 2 ** L)
+                assert g.shape == r.shape and np.abs(g - r).max() <= tol, (wname, shape, b, num)
+        bw.reset_kernel_times()
+        bw.inverse()
+        names = [n for n, _ in bw.kernel_times()]
+        assert names[-1] == "dwt2_inv_pyr3", (wname, shape, names)
+        bw.enable_kernel_timing(False)
+        img = bw.image
+        for b in range(B):
+            want = oracle.inverse(refs[b], shape, wname, L)
+            assert np.abs(img[b] - want).max() <= 2e-6 * (1 + L) * 255.0 * 8, (wname, shape, b)
+
+
 # ---------------------------------------------------------------------------------------------
 # fp64 build (libpypwt_amd_f64.so, Wavelets64): the reference's DOUBLEPRECISION variant
 # ---------------------------------------------------------------------------------------------
