@@ -75,15 +75,33 @@ PDWT_DEVICE void dwt2_fwd_pyr2_tile(const FwdPyr2Args& a, int bx, int by, int bz
     const int xa = 2 * r1x0 - C - PADL;  // multiple of 4
     const int y0 = 2 * r1y0 - C;
 
-    // ---- phase 1: stage the input region with 16-B loads (periodic wrap; interior tiles skip it)
+    // ---- phase 1: stage the input region with 16-B loads (periodic wrap; interior tiles skip it).  Branch-free: a
+    // constant number of trips, indices past the end clamped (those threads re-write the last quad with the same
+    // value), so a thread's loads are all in flight together -- as a loop with an exit test per trip every load was
+    // waited for before the next one was issued (s_waitcnt vmcnt(0) inside the loop: four round trips instead of one).
     PDWT_FOR_THREADS(tid, NT) {
         const float* PDWT_RESTRICT in = a.in + (long long)bz * a.in_bstride;
         const bool interior = xa >= 0 && xa + RXA <= a.N0c && y0 >= 0 && y0 + R0Y <= a.N0r;
+        constexpr int TOTAL = R0Y * V4, TRIPS = (TOTAL + NT - 1) / NT;
         if (interior) {
             const float* base = in + (long long)y0 * a.N0c + xa;
-            for (int idx = tid; idx < R0Y * V4; idx += NT) {
+#pragma unroll
+            for (int t = 0; t < TRIPS; ++t) {
+                int idx = tid + t * NT;
+                idx = idx < TOTAL ? idx : TOTAL - 1;
                 const int r = idx / V4, g = idx - r * V4;
                 *reinterpret_cast<v4f*>(sIn + r * RXA + 4 * g) = *reinterpret_cast<const v4f*>(base + (long long)r * a.N0c + 4 * g);
+            }
+        } else if (a.N0r >= R0Y && a.N0c >= RXA) {  // one conditional add/sub wraps every index
+#pragma unroll
+            for (int t = 0; t < TRIPS; ++t) {
+                int idx = tid + t * NT;
+                idx = idx < TOTAL ? idx : TOTAL - 1;
+                const int r = idx / V4, g = idx - r * V4;
+                int sy = y0 + r, sx = xa + 4 * g;
+                sy = sy < 0 ? sy + a.N0r : (sy >= a.N0r ? sy - a.N0r : sy);
+                sx = sx < 0 ? sx + a.N0c : (sx >= a.N0c ? sx - a.N0c : sx);
+                *reinterpret_cast<v4f*>(sIn + r * RXA + 4 * g) = *reinterpret_cast<const v4f*>(in + (long long)sy * a.N0c + sx);
             }
         } else {
             for (int idx = tid; idx < R0Y * V4; idx += NT) {
@@ -314,18 +332,43 @@ PDWT_DEVICE void dwt2_inv_pyr2_tile(const InvPyr2Args& a, int bx, int by, int bz
     const int c2xa = c2x0 & ~3;                                            // 4-aligned (two's complement floor)
     const int nc2 = (kx_hi - C2 + H2 - c2xa + 3) & ~3;                     // cols [c2xa, c2xa+nc2), <= W2
 
-    // ---- phase 1: stage level-(l+1) quadruples and the level-l details
+    // ---- phase 1: stage level-(l+1) quadruples and the level-l details.  The first trip of both loops is taken with
+    // clamped indices and predicated LDS writes, so its seven 16-B loads are in flight together (as two loops with an
+    // exit test each, the second loop's loads waited for the first loop's); later trips (larger tiles) follow.
     PDWT_FOR_THREADS(tid, NT) {
         const long long b2 = (long long)bz * a.l2_bstride, b1 = (long long)bz * a.l1_bstride;
         const int g4 = nc2 >> 2;
-        for (int idx = tid; idx < nr2 * g4; idx += NT) {
+        const int n2 = nr2 * g4;
+        constexpr int n1 = CR * V4;
+        {
+            const int i2 = tid < n2 ? tid : n2 - 1, i1 = tid < n1 ? tid : n1 - 1;
+            const int r2 = i2 / g4, gg2 = i2 - r2 * g4;
+            const int r1 = i1 / V4, gg1 = i1 - r1 * V4;
+            const long long o2 = b2 + (long long)wrap_periodic(c2y0 + r2, N2r) * N2c + wrap_periodic(c2xa + 4 * gg2, N2c);
+            const long long o1 = b1 + (long long)wrap_periodic(cy0 + r1, N1r) * N1c + wrap_periodic(cxa + 4 * gg1, N1c);
+            const v4f qA = *reinterpret_cast<const v4f*>(a.A2 + o2), qV = *reinterpret_cast<const v4f*>(a.V2 + o2);
+            const v4f qH = *reinterpret_cast<const v4f*>(a.H2 + o2), qD = *reinterpret_cast<const v4f*>(a.D2 + o2);
+            const v4f vV = *reinterpret_cast<const v4f*>(a.V1 + o1);
+            const v4f vH = *reinterpret_cast<const v4f*>(a.H1 + o1);
+            const v4f vD = *reinterpret_cast<const v4f*>(a.D1 + o1);
+            if (tid < n2) inv_fast_interleave(sAV2, sHD2, r2 * W2 + 4 * gg2, qA, qV, qH, qD);
+            if (tid < n1) {
+                v2f* dAV = sAV + r1 * CXA + 4 * gg1;
+                dAV[0].y = vV.x; dAV[1].y = vV.y; dAV[2].y = vV.z; dAV[3].y = vV.w;
+                f32x4 w;
+                f32x4* dHD = reinterpret_cast<f32x4*>(sHD + r1 * CXA + 4 * gg1);
+                w.x = vH.x; w.y = vD.x; w.z = vH.y; w.w = vD.y; dHD[0] = w;
+                w.x = vH.z; w.y = vD.z; w.z = vH.w; w.w = vD.w; dHD[1] = w;
+            }
+        }
+        for (int idx = tid + NT; idx < n2; idx += NT) {
             const int r = idx / g4, g = idx - r * g4;
             const long long o = b2 + (long long)wrap_periodic(c2y0 + r, N2r) * N2c + wrap_periodic(c2xa + 4 * g, N2c);
             inv_fast_interleave(sAV2, sHD2, r * W2 + 4 * g, *reinterpret_cast<const v4f*>(a.A2 + o),
                                 *reinterpret_cast<const v4f*>(a.V2 + o), *reinterpret_cast<const v4f*>(a.H2 + o),
                                 *reinterpret_cast<const v4f*>(a.D2 + o));
         }
-        for (int idx = tid; idx < CR * V4; idx += NT) {
+        for (int idx = tid + NT; idx < n1; idx += NT) {
             const int r = idx / V4, g = idx - r * V4;
             const long long o = b1 + (long long)wrap_periodic(cy0 + r, N1r) * N1c + wrap_periodic(cxa + 4 * g, N1c);
             const v4f vV = *reinterpret_cast<const v4f*>(a.V1 + o);
