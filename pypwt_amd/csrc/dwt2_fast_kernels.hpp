@@ -179,15 +179,34 @@ PDWT_DEVICE void dwt2_fwd_fast_tile(const Fwd2DFastArgs& a, int bx, int by, int 
     const int xa = 2 * bx * TX - C - PADL;  // multiple of 4
     const int y0 = 2 * by * TY - C;
 
-    // ---- phase 1: stage rows [y0, y0+RY) x cols [xa, xa+RXA) with 16-B loads
+    // ---- phase 1: stage rows [y0, y0+RY) x cols [xa, xa+RXA) with 16-B loads.  Branch-free where the image is even
+    // and at least as large as the region: a constant number of trips, indices past the end clamped (those threads
+    // re-write the last quad with the same value), the periodic wrap as one conditional add/sub -- so a thread's
+    // loads are all in flight together (a loop with an exit test per trip waits for every load before the next).
     PDWT_FOR_THREADS(tid, NT) {
-        for (int idx = tid; idx < RY * V4; idx += NT) {
-            const int r = idx / V4;
-            const int g = idx - r * V4;
-            const int sy = wrap_analysis(y0 + r, a.Nr);
-            const int sx = wrap_periodic(xa + 4 * g, a.Nc);  // Nc % 4 == 0: the group never straddles
-            const f32x4 v = *reinterpret_cast<const f32x4*>(in + (long long)sy * a.Nc + sx);
-            *reinterpret_cast<f32x4*>(sIn + r * RXA + 4 * g) = v;
+        constexpr int TOTAL = RY * V4, TRIPS = (TOTAL + NT - 1) / NT;
+        if (!(a.Nr & 1) && a.Nr >= RY && a.Nc >= RXA) {
+#pragma unroll
+            for (int t = 0; t < TRIPS; ++t) {
+                int idx = tid + t * NT;
+                idx = idx < TOTAL ? idx : TOTAL - 1;
+                const int r = idx / V4;
+                const int g = idx - r * V4;
+                int sy = y0 + r, sx = xa + 4 * g;  // Nc % 4 == 0: the group never straddles
+                sy = sy < 0 ? sy + a.Nr : (sy >= a.Nr ? sy - a.Nr : sy);
+                sx = sx < 0 ? sx + a.Nc : (sx >= a.Nc ? sx - a.Nc : sx);
+                const f32x4 v = *reinterpret_cast<const f32x4*>(in + (long long)sy * a.Nc + sx);
+                *reinterpret_cast<f32x4*>(sIn + r * RXA + 4 * g) = v;
+            }
+        } else {
+            for (int idx = tid; idx < RY * V4; idx += NT) {
+                const int r = idx / V4;
+                const int g = idx - r * V4;
+                const int sy = wrap_analysis(y0 + r, a.Nr);
+                const int sx = wrap_periodic(xa + 4 * g, a.Nc);
+                const f32x4 v = *reinterpret_cast<const f32x4*>(in + (long long)sy * a.Nc + sx);
+                *reinterpret_cast<f32x4*>(sIn + r * RXA + 4 * g) = v;
+            }
         }
     }
     PDWT_SYNC();
@@ -492,12 +511,31 @@ PDWT_DEVICE void dwt2_inv_fast_tile(const Inv2DFastArgs& a, int bx, int by, int 
     // interior tiles (all but the border ring) skip the periodic-wrap arithmetic (a uniform branch)
     const bool interior = cxa >= 0 && cxa + CXA <= a.Ncc && cy0 >= 0 && cy0 + CR <= a.Nrc;
     PDWT_FOR_THREADS(tid, NT) {
-        if (interior) {
+        constexpr int TOTAL = CR * V4, TRIPS = (TOTAL + NT - 1) / NT;
+        if (interior) {  // branch-free (see dwt2_fwd_fast_tile): all of a thread's loads in flight together
             const long long o0 = boff + (long long)cy0 * a.Ncc + cxa;
-            for (int idx = tid; idx < CR * V4; idx += NT) {
+#pragma unroll
+            for (int t = 0; t < TRIPS; ++t) {
+                int idx = tid + t * NT;
+                idx = idx < TOTAL ? idx : TOTAL - 1;
                 const int r = idx / V4;
                 const int g = idx - r * V4;
                 const long long o = o0 + (long long)r * a.Ncc + 4 * g;
+                inv_fast_interleave(sAV, sHD, r * CXA + 4 * g, *reinterpret_cast<const v4f*>(a.A + o),
+                                    *reinterpret_cast<const v4f*>(a.V + o), *reinterpret_cast<const v4f*>(a.H + o),
+                                    *reinterpret_cast<const v4f*>(a.D + o));
+            }
+        } else if (a.Nrc >= CR && a.Ncc >= CXA) {
+#pragma unroll
+            for (int t = 0; t < TRIPS; ++t) {
+                int idx = tid + t * NT;
+                idx = idx < TOTAL ? idx : TOTAL - 1;
+                const int r = idx / V4;
+                const int g = idx - r * V4;
+                int sy = cy0 + r, sx = cxa + 4 * g;
+                sy = sy < 0 ? sy + a.Nrc : (sy >= a.Nrc ? sy - a.Nrc : sy);
+                sx = sx < 0 ? sx + a.Ncc : (sx >= a.Ncc ? sx - a.Ncc : sx);
+                const long long o = boff + (long long)sy * a.Ncc + sx;
                 inv_fast_interleave(sAV, sHD, r * CXA + 4 * g, *reinterpret_cast<const v4f*>(a.A + o),
                                     *reinterpret_cast<const v4f*>(a.V + o), *reinterpret_cast<const v4f*>(a.H + o),
                                     *reinterpret_cast<const v4f*>(a.D + o));
