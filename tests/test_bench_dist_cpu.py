@@ -44,6 +44,11 @@ def test_algorithmic_bytes_match_baseline_md():
                                                    "dwt2_inv_pyr2[L3]", "dwt2_inv_level[L2]", "dwt2_inv_level[L1]"]
     assert bench.level_of_kernel("dwt2_inv_level[L1]", 4) == (1, True)
     assert bench.kernel_algorithmic_bytes("dwt2_fwd_pyr2[L3]", c, 1) == 8.0 * 1024 * 1024
+    # small images: three levels per launch (cfg1), then a pair when five levels are asked for
+    assert bench.label_step_kernels(["dwt2_fwd_pyr3", "dwt2_inv_pyr3"], 3) == ["dwt2_fwd_pyr3[L1]", "dwt2_inv_pyr3[L1]"]
+    assert bench.label_step_kernels(["dwt2_fwd_pyr3", "dwt2_fwd_pyr2", "dwt2_inv_pyr2", "dwt2_inv_pyr3"], 5) == [
+        "dwt2_fwd_pyr3[L1]", "dwt2_fwd_pyr2[L4]", "dwt2_inv_pyr2[L4]", "dwt2_inv_pyr3[L1]"]
+    assert bench.kernel_algorithmic_bytes("dwt2_inv_pyr3[L1]", bench.CONFIGS["cfg1"], 1) == 8.0 * 512 * 512
 
 
 def _run(cmd):
