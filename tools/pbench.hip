@@ -131,6 +131,55 @@ __global__ void __launch_bounds__(256) pat_inv(const float* __restrict__ co, flo
     }
 }
 
+// wide strips: a lane owns 8 adjacent columns (two 16-B loads per row), a wavefront 512 columns: every band row leaves as
+// one 16-B store per lane = 1 KiB contiguous per wavefront (the 256-column strips write 512 B per band and row)
+__global__ void __launch_bounds__(256) pat_fwd_wide(const float* __restrict__ in, float* __restrict__ out, int N, int seg_out, int strips) {
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int segs = (N / 2) / seg_out;
+    if (wave >= strips * segs) return;
+    const int strip = wave % strips, seg = wave / strips;
+    const long long img = (long long)blockIdx.y * N * N;
+    const long long q = (long long)(N / 2) * (N / 2);
+    const float* src = in + img + (long long)(2 * seg * seg_out) * N + strip * 512 + 8 * lane;
+    float* o = out + img + (long long)(seg * seg_out) * (N / 2) + strip * 256 + 4 * lane;
+#pragma unroll 2
+    for (int r = 0; r < seg_out; ++r) {
+        f4 x0 = ld16<false>(src), x1 = ld16<false>(src + 4), y0 = ld16<false>(src + N), y1 = ld16<false>(src + N + 4);
+        src += 2 * N;
+        f4 A = {x0.x + y0.x, x0.z + y0.z, x1.x + y1.x, x1.z + y1.z}, H = {x0.y + y0.y, x0.w + y0.w, x1.y + y1.y, x1.w + y1.w};
+        f4 V = {x0.x - y0.x, x0.z - y0.z, x1.x - y1.x, x1.z - y1.z}, D = {x0.y - y0.y, x0.w - y0.w, x1.y - y1.y, x1.w - y1.w};
+        st16<false>(o, A);
+        st16<false>(o + q, H);
+        st16<false>(o + 2 * q, V);
+        st16<false>(o + 3 * q, D);
+        o += N / 2;
+    }
+}
+__global__ void __launch_bounds__(256) pat_inv_wide(const float* __restrict__ co, float* __restrict__ img_out, int N, int seg_out, int strips) {
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int segs = (N / 2) / seg_out;
+    if (wave >= strips * segs) return;
+    const int strip = wave % strips, seg = wave / strips;
+    const long long img = (long long)blockIdx.y * N * N;
+    const long long q = (long long)(N / 2) * (N / 2);
+    float* dst = img_out + img + (long long)(2 * seg * seg_out) * N + strip * 512 + 8 * lane;
+    const float* c = co + img + (long long)(seg * seg_out) * (N / 2) + strip * 256 + 4 * lane;
+#pragma unroll 2
+    for (int r = 0; r < seg_out; ++r) {
+        f4 A = ld16<false>(c), H = ld16<false>(c + q), V = ld16<false>(c + 2 * q), D = ld16<false>(c + 3 * q);
+        f4 a0 = {A.x + V.x, H.x + D.x, A.y + V.y, H.y + D.y}, a1 = {A.z + V.z, H.z + D.z, A.w + V.w, H.w + D.w};
+        f4 b0 = {A.x - V.x, H.x - D.x, A.y - V.y, H.y - D.y}, b1 = {A.z - V.z, H.z - D.z, A.w - V.w, H.w - D.w};
+        st16<false>(dst, a0);
+        st16<false>(dst + 4, a1);
+        st16<false>(dst + N, b0);
+        st16<false>(dst + N + 4, b1);
+        dst += 2 * N;
+        c += N / 2;
+    }
+}
+
 static float time_it(const std::function<void()>& fn, int reps = 40, int warm = 5) {
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -187,6 +236,14 @@ int main(int argc, char** argv) {
         RUN("inv pattern, 8-B loads, nt ld+st", (pat_inv<false, true, true>));
         RUN("inv pattern, 16-B loads, nt ld+st", (pat_inv<true, true, true>));
         RUN("inv pattern, 8-B loads, nt ld", (pat_inv<false, true, false>));
+        if (N % 512 == 0) {  // 512-column strips: the same segment length gives half the wavefronts
+            const int wstrips = N / 512, wwaves = wstrips * ((N / 2) / seg_out);
+            dim3 gw((wwaves + 3) / 4, B);
+#define RUNW(name, K) { float us = time_it([&] { hipLaunchKernelGGL(K, gw, b, 0, 0, (const float*)img, co, N, seg_out, wstrips); }); \
+                        printf("%-40s %8.2f us  %7.1f GB/s  (%d waves)\n", name, us, bytes / us / 1e3, wwaves); }
+            RUNW("fwd pattern, 512-column strips", pat_fwd_wide);
+            RUNW("inv pattern, 512-column strips", pat_inv_wide);
+        }
     }
     return 0;
 }
