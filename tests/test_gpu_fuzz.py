@@ -132,3 +132,48 @@ def test_fuzz_register_kernels(seed):
         thr = oracle.threshold(ref, x.shape, w.levels, "soft", beta, do_app=0, normalize=norm, **kw)
         want = oracle.inverse(thr, x.shape, wname, w.levels, **kw)
         assert np.abs(w.image.reshape(want.shape) - want).max() <= 4e-3, (wname, x.shape, w.levels, beta, norm)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_fuzz_three_level_pyramid(seed):
+    """Small 2D images whose sizes are multiples of 8, filters of at most 8 taps, three / five / six levels, batches:
+    the shapes that run three levels per launch (dwt2_pyr3_kernels.hpp, all three tile sizes, tiles that wrap more than
+    once, partial tiles); forward vs the oracle, then soft threshold + inverse vs the oracle's sequence, in both
+    precisions."""
+    from pypwt_amd import BatchedWavelets, Wavelets64
+    rng = np.random.default_rng(4300 + seed)
+    short = ["haar", "db2", "db3", "db4", "sym4", "coif1", "bior1.3", "bior2.2", "rbio3.3", "bior3.1"]
+    for it in range(14):
+        wname = str(rng.choice(short))
+        hlen = oracle.filters(wname)[0]
+        shape = (8 * int(rng.integers(1, 60)), 8 * int(rng.integers(1, 60)))
+        B = int(rng.choice([1, 1, 2, 5]))
+        lmax = oracle.max_level(min(shape), hlen)
+        levels = max(1, min(int(rng.choice([3, 3, 5, 6])), lmax))
+        x = oracle.hash_input((B,) + shape, int(rng.integers(1, 1 << 30)), scale=255.0)
+        bw = BatchedWavelets(B, shape[0], shape[1], wname, levels, img=x)
+        assert bw.levels == levels
+        bw.forward()
+        refs = [oracle.forward(x[b], wname, levels) for b in range(B)]
+        scale = 40.0 if wname in ("bior3.1", "rbio3.1") else 1.0
+        for b in range(B):
+            for num, r in enumerate(refs[b]):
+                tol = scale * 2e-6 * (1 + levels) * max(255.0 * 2 ** levels, float(np.abs(r).max()))
+                assert np.abs(bw.coeff_at(num, b) - r).max() <= tol, (wname, shape, levels, b, num)
+        beta = float(rng.choice([0.0, 5.0]))
+        bw.soft_threshold(beta)
+        bw.inverse()
+        img = bw.image
+        for b in range(B):
+            thr = oracle.threshold(refs[b], shape, levels, "soft", beta, do_app=0, normalize=0)
+            want = oracle.inverse(thr, shape, wname, levels)
+            assert np.abs(img[b] - want).max() <= scale * 4e-3, (wname, shape, levels, b)
+        if it % 4 == 0:  # the fp64 library compiles the same kernels over doubles
+            xd = x[0].astype(np.float64)
+            wd = Wavelets64(xd, wname, levels)
+            wd.forward()
+            refd = oracle.forward(xd, wname, levels, double="full")
+            for k, (g, r) in enumerate(zip(_flat(wd.coeffs), refd)):
+                assert np.abs(g - r).max() <= 1e-12 * max(1.0, float(np.abs(r).max())), (wname, shape, levels, k)
+            wd.inverse()
+            assert np.abs(wd.image - oracle.inverse(refd, shape, wname, levels, double="full")).max() <= scale * 1e-10 * 255
