@@ -20,11 +20,11 @@ OBJ = os.path.join(ROOT, "build", "obj")
 LIB = os.path.join(HERE, "libpypwt_amd.so")
 LIB_F64 = os.path.join(HERE, "libpypwt_amd_f64.so")
 # (object directory, library, extra flags, sources left out) per variant; of the tuned kernels the fp64 build
-# has the register kernels only (2D DWT levels, 1D DWT level triples)
+# has the register kernels only (2D DWT levels, 1D DWT level triples, fused 2-tap SWT groups) and the small-image pyramid
 VARIANTS = {
     "f32": (OBJ, LIB, [], ()),
     "f64": (os.path.join(ROOT, "build", "obj_f64"), LIB_F64, ["-DPDWT_DOUBLE"],
-            ("launch_dwt2_fast.hip", "launch_dwt2_pyramid.hip", "launch_dwt1_fused.hip", "launch_swt_fused.hip")),
+            ("launch_dwt2_fast.hip", "launch_dwt2_pyramid.hip", "launch_dwt1_fused.hip")),
 }
 
 SOURCES = [

@@ -54,9 +54,6 @@ hipError_t launch_dwt2_inv_strip2(const real_t* const[4], const real_t* const[3]
                                   const FilterBank&, int, hipStream_t) { return hipErrorNotSupported; }
 hipError_t launch_dwt2_inv_pyr2(const real_t* const[4], const real_t* const[3], real_t*, int, int, int,
                                 const FilterBank&, int, hipStream_t) { return hipErrorNotSupported; }
-bool swt2_fused_supported(int, int, int, int, int) { return false; }
-hipError_t launch_swt2_fused(const real_t*, real_t*, real_t* const*, int, int, int, int, bool, const FilterBank&, const real_t*, int,
-                             hipStream_t) { return hipErrorNotSupported; }
 int dwt1_fused_max_levels(int) { return 1; }
 bool dwt1_fused_supported(int, int, int) { return false; }
 hipError_t launch_dwt1_fwd_fused(const real_t*, real_t* const*, real_t*, int, int, int, int, const FilterBank&,

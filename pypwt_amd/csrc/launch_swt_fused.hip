@@ -14,7 +14,7 @@ namespace pdwt {
 bool swt2_fused_supported(int hlen, int Nr, int Nc, int l0, int K) {
     if (hlen != 2 || K < 2 || K > kSwtFusedMaxLevels || (l0 != 1 && l0 != 4)) return false;
     const int f0 = 1 << (l0 - 1);
-    return (Nc % 4) == 0 && Nc >= 256 && (long long)Nr * Nc <= (1LL << 28) && (Nr % f0) == 0 && Nr / f0 >= (1 << K);
+    return (Nc % 4) == 0 && Nc >= 256 && (long long)Nr * Nc * (long long)sizeof(real_t) <= (1LL << 30) && (Nr % f0) == 0 && Nr / f0 >= (1 << K);
 }
 
 // Phase rows per wavefront.  A segment reads 2^K - 1 rows it does not own (the inverse: of all 3 K + 1 planes), so
@@ -63,7 +63,7 @@ static hipError_t run(SwtFusedArgs& a, bool inverse, int batch, hipStream_t s) {
         // 24-64 rows against 47.8 us (16-B lanes, 24 rows), levels 4-5 39.9-42.1 against 35.1-37.0 us
         // (profiles/r02y_bench_cfg4_lanes_sweep.txt).  PDWT_SWT_CPL=2 selects them for re-measurement.
         static const int forced = [] { const char* e = getenv("PDWT_SWT_CPL"); return e ? atoi(e) : 0; }();
-        const bool narrow = forced == 2;
+        const bool narrow = forced == 2 || sizeof(real_t) == 8;  // fp64: two doubles per lane (the four-column lanes need > 512 registers)
         return narrow ? run_inv<K, F0, 2>(a, batch, s) : run_inv<K, F0, 4>(a, batch, s);
     }
     a.strips = cdiv(a.Nc, 4 * G::V);
@@ -78,8 +78,8 @@ static hipError_t run(SwtFusedArgs& a, bool inverse, int batch, hipStream_t s) {
 
 // in / out: the approximation planes on either side of the group; det[3 k + {0,1,2}] = H, V, D of level l0 + k;
 // beta[k]: soft threshold the inverse applies to level l0 + k's details as it loads them (nullptr: none)
-hipError_t launch_swt2_fused(const float* in, float* out, float* const* det, int Nr, int Nc, int l0, int K, bool inverse,
-                             const FilterBank& fb, const float* beta, int batch, hipStream_t s) {
+hipError_t launch_swt2_fused(const real_t* in, real_t* out, real_t* const* det, int Nr, int Nc, int l0, int K, bool inverse,
+                             const FilterBank& fb, const real_t* beta, int batch, hipStream_t s) {
     if (!swt2_fused_supported(2, Nr, Nc, l0, K)) return hipErrorNotSupported;
     SwtFusedArgs a;
     a.in = in; a.out = out; a.Nr = Nr; a.Nc = Nc; a.bstride = (long long)Nr * Nc;
@@ -87,7 +87,7 @@ hipError_t launch_swt2_fused(const float* in, float* out, float* const* det, int
         a.H[k] = k < K ? det[3 * k] : nullptr;
         a.V[k] = k < K ? det[3 * k + 1] : nullptr;
         a.D[k] = k < K ? det[3 * k + 2] : nullptr;
-        a.beta[k] = (beta && k < K) ? beta[k] : 0.f;
+        a.beta[k] = (beta && k < K) ? beta[k] : real_t(0);
     }
     for (int k = 0; k < 3 * K; k++)
         if (reinterpret_cast<uintptr_t>(det[k]) & 15) return hipErrorNotSupported;

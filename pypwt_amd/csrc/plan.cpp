@@ -359,7 +359,7 @@ void build_schedule(pdwt_plan* p) {
         // keep 7-10 output (input) streams per wavefront going, 1 KiB per row each, which HBM serves badly once the
         // planes are cold -- two 2048^2 images: 343 us fused against 329 us level by level, four: 746 against 715 us,
         // one: 137 against 183 us (profiles/r02y_bench_cfg4_batch.txt).
-        const long long swt_bytes = 4LL * (3 * L + 2) * p->batch * p->info.Nr * p->info.Nc;
+        const long long swt_bytes = (long long)sizeof(real_t) * (3 * L + 2) * p->batch * p->info.Nr * p->info.Nc;
         auto swt_group = [&](int l) {
             if (!swt || !p->do_separable || !get_swt_fused_enabled() || (l != 1 && l != 4)) return 0;
             if (swt_bytes > (320LL << 20) && get_swt_fused_enabled() < 2) return 0;  // "swt_fused" = 2 forces (tests)

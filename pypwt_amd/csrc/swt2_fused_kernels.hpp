@@ -46,18 +46,18 @@ constexpr int kSwtFusedMaxLevels = 3;
 
 
 struct SwtFusedArgs {
-    const float* in;                    // forward: A_{l0-1}; inverse: A_{l0+K-1}
-    float* out;                         // forward: A_{l0+K-1}; inverse: A_{l0-1}
-    float* H[kSwtFusedMaxLevels];       // detail planes of the group's levels (forward: written; inverse: read)
-    float* V[kSwtFusedMaxLevels];
-    float* D[kSwtFusedMaxLevels];
+    const real_t* in;                    // forward: A_{l0-1}; inverse: A_{l0+K-1}
+    real_t* out;                         // forward: A_{l0+K-1}; inverse: A_{l0-1}
+    real_t* H[kSwtFusedMaxLevels];       // detail planes of the group's levels (forward: written; inverse: read)
+    real_t* V[kSwtFusedMaxLevels];
+    real_t* D[kSwtFusedMaxLevels];
     int Nr, Nc;
     long long bstride;                  // floats between the images of a batch
     int strips;                         // ceil(Nc / (4 V))
     int segs;                           // segments per phase: ceil(Nr / f0 / seg_rows)
     int seg_rows;                       // phase rows a wavefront owns (multiple of 2^K)
-    float beta[kSwtFusedMaxLevels];     // inverse: soft threshold of each level's details (0 = none)
-    float lo[2], hi[2];                 // analysis (forward) / synthesis (inverse) taps
+    real_t beta[kSwtFusedMaxLevels];     // inverse: soft threshold of each level's details (0 = none)
+    real_t lo[2], hi[2];                 // analysis (forward) / synthesis (inverse) taps
 };
 
 template <int K, int F0>
@@ -75,9 +75,9 @@ struct SwtFusedGeom {
 
 // sh[c] = the value D columns to the RIGHT of the lane's column c (forward) -- (c + D) / 4 lanes ahead
 template <int D>
-PDWT_DEVICE void swt_shift_right(WaveReg<float, 4>& src, WaveReg<float, 4>& sh) {
+PDWT_DEVICE void swt_shift_right(WaveReg<real_t, 4>& src, WaveReg<real_t, 4>& sh) {
     constexpr int M = (3 + D) / 4;  // most lanes any column looks ahead
-    WaveReg<float, 4 * (M + 1)> hop;  // hop[m] = the row as lane + m holds it
+    WaveReg<real_t, 4 * (M + 1)> hop;  // hop[m] = the row as lane + m holds it
     PDWT_WAVE_LANES(lane) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) hop.mine(lane)[i] = src.mine(lane)[i];
@@ -100,18 +100,18 @@ PDWT_DEVICE void swt_shift_right(WaveReg<float, 4>& src, WaveReg<float, 4>& sh) 
 // offset; a row the wavefront does not own contributes kSwtRowDropped, a lane without output kSwtLaneDropped: either
 // way the sum is >= 2^30 > the plane's bytes (the host checks Nr Nc <= 2^28) and the hardware drops the store.
 constexpr unsigned kSwtRowDropped = 0x80000000u, kSwtLaneDropped = 0x40000000u;
-PDWT_DEVICE RowBuf swt_plane(float* plane, long long image_off, int Nr, int Nc) {
-    return row_buf(plane + image_off, 4u * (unsigned)Nr * (unsigned)Nc);
+PDWT_DEVICE RowBuf swt_plane(real_t* plane, long long image_off, int Nr, int Nc) {
+    return row_buf(plane + image_off, kRealBytes * (unsigned)Nr * (unsigned)Nc);
 }
 
 // ---------------------------------------------------------------------------------------------- forward
 template <int K, int F0>
 struct SwtFwdState {
     using G = SwtFusedGeom<K, F0>;
-    WaveReg<float, 4 * G::NR> ld;        // input rows in flight: slot (row mod NR)
-    WaveReg<float, 8 * 2> ring1;         // (L, H) rows of level 1 of the group: [slot][L0..3 H0..3]
-    WaveReg<float, 8 * 4> ring2;
-    WaveReg<float, 8 * 8> ring3;
+    WaveReg<real_t, 4 * G::NR> ld;        // input rows in flight: slot (row mod NR)
+    WaveReg<real_t, 8 * 2> ring1;         // (L, H) rows of level 1 of the group: [slot][L0..3 H0..3]
+    WaveReg<real_t, 8 * 4> ring2;
+    WaveReg<real_t, 8 * 8> ring3;
     WaveReg<unsigned, 2> off;            // byte offsets in a row: load (wrapped), store (or kSwtLaneDropped)
     RowBuf bH[3], bV[3], bD[3], bA;      // the output planes of this wavefront's image
 };
@@ -119,16 +119,16 @@ struct SwtFwdState {
 // one level of one step: `a` = the level's input row (row index q of the walk), ring depth RD, lag LAG = RD / 2:
 // emits the level's output row q - LAG: details through the descriptors, approximation into `anext`
 template <int D, int RD, int SLOT, int NRING>
-PDWT_DEVICE void swt_fwd_level(const SwtFusedArgs& a, WaveReg<float, 4>& ain, WaveReg<float, NRING>& ring, WaveReg<float, 4>& anext,
+PDWT_DEVICE void swt_fwd_level(const SwtFusedArgs& a, WaveReg<real_t, 4>& ain, WaveReg<real_t, NRING>& ring, WaveReg<real_t, 4>& anext,
                                WaveReg<unsigned, 2>& off, const RowBuf& bH, const RowBuf& bV, const RowBuf& bD, unsigned rowoff) {
     constexpr int LAG = RD / 2, OLD = (SLOT - LAG + RD) % RD;
-    WaveReg<float, 4> sh;
+    WaveReg<real_t, 4> sh;
     swt_shift_right<D>(ain, sh);
     PDWT_WAVE_LANES(lane) {
-        const float* x = ain.mine(lane);
-        const float* s = sh.mine(lane);
-        float* cur = ring.mine(lane) + 8 * SLOT;
-        const float* old = ring.mine(lane) + 8 * OLD;
+        const real_t* x = ain.mine(lane);
+        const real_t* s = sh.mine(lane);
+        real_t* cur = ring.mine(lane) + 8 * SLOT;
+        const real_t* old = ring.mine(lane) + 8 * OLD;
         // row filter: out = x f[1] + x(+d) f[0]
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -136,8 +136,8 @@ PDWT_DEVICE void swt_fwd_level(const SwtFusedArgs& a, WaveReg<float, 4>& ain, Wa
             cur[4 + c] = pdwt_fma(s[c], a.hi[0], x[c] * a.hi[1]);
         }
         // column filter with the row LAG phase rows earlier (the earlier row is the output's own row)
-        float* an = anext.mine(lane);
-        float h[4], v[4], d[4];
+        real_t* an = anext.mine(lane);
+        real_t h[4], v[4], d[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             an[c] = pdwt_fma(cur[c], a.lo[0], old[c] * a.lo[1]);
@@ -154,7 +154,7 @@ PDWT_DEVICE void swt_fwd_level(const SwtFusedArgs& a, WaveReg<float, 4>& ain, Wa
 
 // step R of a group of P rows (R static): input row r = g0 + R of the walk
 template <int K, int F0, int R>
-PDWT_DEVICE void swt_fwd_step(const SwtFusedArgs& a, SwtFwdState<K, F0>& st, const float* in, int g0, int i0, int rows_phase,
+PDWT_DEVICE void swt_fwd_step(const SwtFusedArgs& a, SwtFwdState<K, F0>& st, const real_t* in, int g0, int i0, int rows_phase,
                               int py, long long boff) {
     using G = SwtFusedGeom<K, F0>;
     const int r = g0 + R;
@@ -165,17 +165,17 @@ PDWT_DEVICE void swt_fwd_step(const SwtFusedArgs& a, SwtFwdState<K, F0>& st, con
         int rr = r + G::NR - 1;
         rr = rr < a.seg_rows + G::W ? rr : a.seg_rows + G::W - 1;
         rr = (i0 + rr) % rows_phase;
-        const float* row = in + (long long)(py + F0 * rr) * a.Nc;
+        const real_t* row = in + (long long)(py + F0 * rr) * a.Nc;
         PDWT_WAVE_LANES(lane) {
             const v4f w = wave_ld16(row, st.off.mine(lane)[0]);
-            float* v = st.ld.mine(lane) + 4 * ((R + G::NR - 1) % G::NR);
+            real_t* v = st.ld.mine(lane) + 4 * ((R + G::NR - 1) % G::NR);
             v[0] = w.x; v[1] = w.y; v[2] = w.z; v[3] = w.w;
         }
     }
     PDWT_ROW_FENCE();
-    WaveReg<float, 4> a0, a1, a2, a3;
+    WaveReg<real_t, 4> a0, a1, a2, a3;
     PDWT_WAVE_LANES(lane) {
-        const float* v = st.ld.mine(lane) + 4 * (R % G::NR);
+        const real_t* v = st.ld.mine(lane) + 4 * (R % G::NR);
 #pragma unroll
         for (int c = 0; c < 4; ++c) a0.mine(lane)[c] = v[c];
     }
@@ -183,7 +183,7 @@ PDWT_DEVICE void swt_fwd_step(const SwtFusedArgs& a, SwtFwdState<K, F0>& st, con
     // row in a plane, or kSwtRowDropped for a row another wavefront owns
     auto rowoff = [&](int rel) -> unsigned {
         const bool ow = rel >= 0 && rel < a.seg_rows && i0 + rel < rows_phase;
-        return ow ? 4u * (unsigned)(py + F0 * (i0 + rel)) * (unsigned)a.Nc : kSwtRowDropped;
+        return ow ? kRealBytes * (unsigned)(py + F0 * (i0 + rel)) * (unsigned)a.Nc : kSwtRowDropped;
     };
     {
         const unsigned ro = rowoff(r - 1);
@@ -194,19 +194,19 @@ PDWT_DEVICE void swt_fwd_step(const SwtFusedArgs& a, SwtFwdState<K, F0>& st, con
         // a1 is row q = r - 1 of level 2's input: slot q mod 4 = (R + 3) mod 4
         swt_fwd_level<G::dist(1), 4, (R + 3) % 4, 32>(a, a1, st.ring2, a2, st.off, st.bH[1], st.bV[1], st.bD[1], ro);
         if constexpr (K == 2) {
-            PDWT_WAVE_LANES(lane) { const float* v = a2.mine(lane); row_st16(st.bA, st.off.mine(lane)[1] + ro, v[0], v[1], v[2], v[3]); }
+            PDWT_WAVE_LANES(lane) { const real_t* v = a2.mine(lane); row_st16(st.bA, st.off.mine(lane)[1] + ro, v[0], v[1], v[2], v[3]); }
         }
     }
     if constexpr (K >= 3) {
         const unsigned ro = rowoff(r - 7);
         // a2 is row p = r - 3 of level 3's input: slot p mod 8 = (R + 5) mod 8
         swt_fwd_level<G::dist(2), 8, (R + 5) % 8, 64>(a, a2, st.ring3, a3, st.off, st.bH[2], st.bV[2], st.bD[2], ro);
-        PDWT_WAVE_LANES(lane) { const float* v = a3.mine(lane); row_st16(st.bA, st.off.mine(lane)[1] + ro, v[0], v[1], v[2], v[3]); }
+        PDWT_WAVE_LANES(lane) { const real_t* v = a3.mine(lane); row_st16(st.bA, st.off.mine(lane)[1] + ro, v[0], v[1], v[2], v[3]); }
     }
 }
 
 template <int K, int F0, int R>
-PDWT_DEVICE void swt_fwd_group(const SwtFusedArgs& a, SwtFwdState<K, F0>& st, const float* in, int g0, int i0, int rows_phase,
+PDWT_DEVICE void swt_fwd_group(const SwtFusedArgs& a, SwtFwdState<K, F0>& st, const real_t* in, int g0, int i0, int rows_phase,
                                int py, long long boff) {
     if constexpr (R < SwtFusedGeom<K, F0>::P) {
         swt_fwd_step<K, F0, R>(a, st, in, g0, i0, rows_phase, py, boff);
@@ -227,7 +227,7 @@ PDWT_DEVICE void swt2_fwd_fused(const SwtFusedArgs& a, long long w) {
     const int rows_phase = a.Nr / F0;
     const int i0 = seg * a.seg_rows;
     const long long boff = img * a.bstride;
-    const float* in = a.in + boff;
+    const real_t* in = a.in + boff;
     SwtFwdState<K, F0> st;
     PDWT_WAVE_LANES(lane) {
         const int x = strip * 4 * G::V + 4 * lane;
@@ -235,8 +235,8 @@ PDWT_DEVICE void swt2_fwd_fused(const SwtFusedArgs& a, long long w) {
         // further right nothing is used: those lanes re-read the row's last group (a cache hit, no extra traffic)
         int xl = x >= a.Nc ? x - a.Nc : x;
         if (x >= a.Nc + G::halo_cols + 3) xl = a.Nc - 4;
-        st.off.mine(lane)[0] = 4u * (unsigned)xl;
-        st.off.mine(lane)[1] = (lane < G::V && x < a.Nc) ? 4u * (unsigned)x : kSwtLaneDropped;
+        st.off.mine(lane)[0] = kRealBytes * (unsigned)xl;
+        st.off.mine(lane)[1] = (lane < G::V && x < a.Nc) ? kRealBytes * (unsigned)x : kSwtLaneDropped;
     }
 #pragma unroll
     for (int k = 0; k < K; ++k) {
@@ -248,10 +248,10 @@ PDWT_DEVICE void swt2_fwd_fused(const SwtFusedArgs& a, long long w) {
     // rows 0 .. NR-2 of the walk in flight before the first step
 #pragma unroll
     for (int p = 0; p < G::NR - 1; ++p) {
-        const float* row = in + (long long)(py + F0 * ((i0 + p) % rows_phase)) * a.Nc;
+        const real_t* row = in + (long long)(py + F0 * ((i0 + p) % rows_phase)) * a.Nc;
         PDWT_WAVE_LANES(lane) {
             const v4f v4 = wave_ld16(row, st.off.mine(lane)[0]);
-            float* v = st.ld.mine(lane) + 4 * p;
+            real_t* v = st.ld.mine(lane) + 4 * p;
             v[0] = v4.x; v[1] = v4.y; v[2] = v4.z; v[3] = v4.w;
         }
     }
@@ -276,9 +276,9 @@ struct SwtInvGeom {
 
 // sh[c] = the value D columns to the LEFT of the lane's column c
 template <int D, int C>
-PDWT_DEVICE void swt_shift_left(WaveReg<float, C>& src, WaveReg<float, C>& sh) {
+PDWT_DEVICE void swt_shift_left(WaveReg<real_t, C>& src, WaveReg<real_t, C>& sh) {
     constexpr int M = (D + C - 1) / C;
-    WaveReg<float, C * (M + 1)> hop;  // hop[m] = the row as lane - m holds it
+    WaveReg<real_t, C * (M + 1)> hop;  // hop[m] = the row as lane - m holds it
     PDWT_WAVE_LANES(lane) {
 #pragma unroll
         for (int i = 0; i < C; ++i) hop.mine(lane)[i] = src.mine(lane)[i];
@@ -307,10 +307,10 @@ struct SwtInvState {
     // spilled) measured 15 % slower than 4, 2 slots the same as 4 (profiles/r02w_bench_cfg4_fused_sweep.txt).
     static constexpr int NRI = NRI_;
     static_assert(G::P % NRI_ == 0, "static slot numbers");
-    WaveReg<float, C * NRI*(1 + 3 * K)> ld;             // [slot][plane][C]: plane 0 = A, then H, V, D of the group's levels, deepest first
-    WaveReg<float, 2 * C * 2> ring1;                    // (u1, u2) rows of level 1 of the group
-    WaveReg<float, 2 * C * 4> ring2;
-    WaveReg<float, 2 * C * 8> ring3;
+    WaveReg<real_t, C * NRI*(1 + 3 * K)> ld;             // [slot][plane][C]: plane 0 = A, then H, V, D of the group's levels, deepest first
+    WaveReg<real_t, 2 * C * 2> ring1;                    // (u1, u2) rows of level 1 of the group
+    WaveReg<real_t, 2 * C * 4> ring2;
+    WaveReg<real_t, 2 * C * 8> ring3;
     WaveReg<unsigned, 2> off;
     RowBuf bo;                                          // the output plane of this wavefront's image
 };
@@ -321,9 +321,9 @@ PDWT_DEVICE void swt_inv_load(const SwtFusedArgs& a, SwtInvState<K, F0, NRI, C>&
     constexpr int NP = 1 + 3 * K;
     PDWT_WAVE_LANES(lane) {
         const unsigned o = st.off.mine(lane)[0] + ro;
-        float* base = st.ld.mine(lane) + C * NP * SLOT;
-        auto put = [&](int p, const float* plane) {
-            float* v = base + C * p;
+        real_t* base = st.ld.mine(lane) + C * NP * SLOT;
+        auto put = [&](int p, const real_t* plane) {
+            real_t* v = base + C * p;
             if constexpr (C == 4) {
                 const v4f w = wave_ld16(plane + boff, o);
                 v[0] = w.x; v[1] = w.y; v[2] = w.z; v[3] = w.w;
@@ -346,14 +346,14 @@ PDWT_DEVICE void swt_inv_load(const SwtFusedArgs& a, SwtInvState<K, F0, NRI, C>&
 // one synthesis level on the current row: ain (approximation row) + the level's details (thresholded) -> aout;
 // the (u1, u2) row goes into ring slot SLOT, the row LAG = RD / 2 phase rows earlier is its column partner
 template <int D, int RD, int SLOT, int C, int NRING>
-PDWT_DEVICE void swt_inv_level(const SwtFusedArgs& a, WaveReg<float, C>& ain, WaveReg<float, 3 * C>& det, float beta,
-                               WaveReg<float, NRING>& ring, WaveReg<float, C>& aout) {
+PDWT_DEVICE void swt_inv_level(const SwtFusedArgs& a, WaveReg<real_t, C>& ain, WaveReg<real_t, 3 * C>& det, real_t beta,
+                               WaveReg<real_t, NRING>& ring, WaveReg<real_t, C>& aout) {
     constexpr int LAG = RD / 2, OLD = (SLOT - LAG + RD) % RD;
     // the two terms of the row synthesis that come from D columns to the left, combined where they live
-    WaveReg<float, C> t1, t2, s1, s2;
+    WaveReg<real_t, C> t1, t2, s1, s2;
     PDWT_WAVE_LANES(lane) {
-        const float* x = ain.mine(lane);
-        float* dd = det.mine(lane);   // [H | V | D]
+        const real_t* x = ain.mine(lane);
+        real_t* dd = det.mine(lane);   // [H | V | D]
 #pragma unroll
         for (int i = 0; i < 3 * C; ++i) dd[i] = soft_shrink(dd[i], beta);
 #pragma unroll
@@ -365,20 +365,20 @@ PDWT_DEVICE void swt_inv_level(const SwtFusedArgs& a, WaveReg<float, C>& ain, Wa
     swt_shift_left<D, C>(t1, s1);
     swt_shift_left<D, C>(t2, s2);
     PDWT_WAVE_LANES(lane) {
-        const float* x = ain.mine(lane);
-        const float* dd = det.mine(lane);
-        float* cur = ring.mine(lane) + 2 * C * SLOT;
-        const float* old = ring.mine(lane) + 2 * C * OLD;
-        float* o = aout.mine(lane);
+        const real_t* x = ain.mine(lane);
+        const real_t* dd = det.mine(lane);
+        real_t* cur = ring.mine(lane) + 2 * C * SLOT;
+        const real_t* old = ring.mine(lane) + 2 * C * OLD;
+        real_t* o = aout.mine(lane);
 #pragma unroll
         for (int c = 0; c < C; ++c) {
-            float u1 = pdwt_fma(x[c], a.lo[0], s1.mine(lane)[c]);
+            real_t u1 = pdwt_fma(x[c], a.lo[0], s1.mine(lane)[c]);
             u1 = pdwt_fma(dd[C + c], a.hi[0], u1);
-            float u2 = pdwt_fma(dd[c], a.lo[0], s2.mine(lane)[c]);
+            real_t u2 = pdwt_fma(dd[c], a.lo[0], s2.mine(lane)[c]);
             u2 = pdwt_fma(dd[2 * C + c], a.hi[0], u2);
             cur[c] = 0.5f * u1;
             cur[C + c] = 0.5f * u2;
-            float r = old[c] * a.lo[1];
+            real_t r = old[c] * a.lo[1];
             r = pdwt_fma(old[C + c], a.hi[1], r);
             r = pdwt_fma(cur[c], a.lo[0], r);
             r = pdwt_fma(cur[C + c], a.hi[0], r);
@@ -398,20 +398,20 @@ PDWT_DEVICE void swt_inv_step(const SwtFusedArgs& a, SwtInvState<K, F0, NRI, C>&
         rr = rr < a.seg_rows + G::W ? rr : a.seg_rows + G::W - 1;  // see swt_fwd_step
         rr = i0 - G::W + rr;
         rr = ((rr % rows_phase) + rows_phase) % rows_phase;
-        swt_inv_load<K, F0, NRI, C, (R + S::NRI - 1) % S::NRI>(a, st, boff, 4u * (unsigned)(py + F0 * rr) * (unsigned)a.Nc);
+        swt_inv_load<K, F0, NRI, C, (R + S::NRI - 1) % S::NRI>(a, st, boff, kRealBytes * (unsigned)(py + F0 * rr) * (unsigned)a.Nc);
     }
     PDWT_ROW_FENCE();
-    WaveReg<float, C> cur, nxt;
-    WaveReg<float, 3 * C> det;
+    WaveReg<real_t, C> cur, nxt;
+    WaveReg<real_t, 3 * C> det;
     auto take = [&](int plane0) {
         PDWT_WAVE_LANES(lane) {
-            const float* v = st.ld.mine(lane) + C * NP * (R % S::NRI) + C * plane0;
+            const real_t* v = st.ld.mine(lane) + C * NP * (R % S::NRI) + C * plane0;
 #pragma unroll
             for (int i = 0; i < 3 * C; ++i) det.mine(lane)[i] = v[i];
         }
     };
     PDWT_WAVE_LANES(lane) {
-        const float* v = st.ld.mine(lane) + C * NP * (R % S::NRI);
+        const real_t* v = st.ld.mine(lane) + C * NP * (R % S::NRI);
 #pragma unroll
         for (int c = 0; c < C; ++c) cur.mine(lane)[c] = v[c];
     }
@@ -436,9 +436,9 @@ PDWT_DEVICE void swt_inv_step(const SwtFusedArgs& a, SwtInvState<K, F0, NRI, C>&
     swt_inv_level<G::dist(0), 2, R % 2, C>(a, cur, det, a.beta[0], st.ring1, nxt);
     const int rel = r - G::W;  // output row relative to the segment
     const bool ow = rel >= 0 && rel < a.seg_rows && i0 + rel < rows_phase;
-    const unsigned ro = ow ? 4u * (unsigned)(py + F0 * (i0 + rel)) * (unsigned)a.Nc : kSwtRowDropped;
+    const unsigned ro = ow ? kRealBytes * (unsigned)(py + F0 * (i0 + rel)) * (unsigned)a.Nc : kSwtRowDropped;
     PDWT_WAVE_LANES(lane) {
-        const float* v = nxt.mine(lane);
+        const real_t* v = nxt.mine(lane);
         if constexpr (C == 4) row_st16(st.bo, st.off.mine(lane)[1] + ro, v[0], v[1], v[2], v[3]);
         else row_st8(st.bo, st.off.mine(lane)[1] + ro, v[0], v[1]);
     }
@@ -481,13 +481,13 @@ PDWT_DEVICE void swt2_inv_fused(const SwtFusedArgs& a, long long w) {
         const int x = strip * C * GI::V + C * (lane - GI::halo_lanes);
         // left of the row start: wrapped (the halo of the first columns); at or past the row end: nothing is used
         const int xl = x < 0 ? x + a.Nc : (x >= a.Nc ? a.Nc - C : x);
-        st.off.mine(lane)[0] = 4u * (unsigned)xl;
-        st.off.mine(lane)[1] = (lane >= GI::halo_lanes && x < a.Nc) ? 4u * (unsigned)x : kSwtLaneDropped;
+        st.off.mine(lane)[0] = kRealBytes * (unsigned)xl;
+        st.off.mine(lane)[1] = (lane >= GI::halo_lanes && x < a.Nc) ? kRealBytes * (unsigned)x : kSwtLaneDropped;
     }
     st.bo = swt_plane(a.out, boff, a.Nr, a.Nc);
     // rows 0 .. NRI-2 of the walk (phase rows i0 - W ...) in flight before the first step
     {
-        auto rowbytes = [&](int i) { return 4u * (unsigned)(py + F0 * (((i0 - G::W + i) % rows_phase + rows_phase) % rows_phase)) * (unsigned)a.Nc; };
+        auto rowbytes = [&](int i) { return kRealBytes * (unsigned)(py + F0 * (((i0 - G::W + i) % rows_phase + rows_phase) % rows_phase)) * (unsigned)a.Nc; };
         swt_inv_preload<K, F0, NRI, C, 0>(a, st, boff, rowbytes);
     }
     PDWT_WAIT_VMEM();

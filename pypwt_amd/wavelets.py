@@ -450,7 +450,8 @@ class Wavelets64(Wavelets):
     coefficients, same methods.  The reference offers double precision only as a compile-time variant of
     its C++ library (pdwt/Makefile DOUBLEPRECISION, pdwt/src/filters.h:16-30); its Python class is
     float32-only.  Of the tuned kernels this build has the register kernels (2D DWT levels with filters of at
-    most 8 taps, 1D DWT level triples); everything else runs through the generic kernels."""
+    most 8 taps, 1D DWT level triples, fused 2-tap SWT groups) and the small-image pyramid; everything else runs
+    through the generic kernels."""
     _dtype = np.float64
     _variant = "f64"
 

@@ -242,3 +242,32 @@ def test_swt_haar_levels_fused_per_launch_on_the_gpu():
             assert np.abs(bw.image_at(b) - xb[b]).max() < 2e-3
     finally:
         lib.pdwt_set_tuning(b"swt_fused", was)
+
+
+def test_fp64_swt_fused_groups_vs_the_fp64_oracle():
+    """The fused 2-tap SWT groups compiled over doubles (fp64 library: two doubles per lane in the inverse): every level's
+    coefficients, the reconstruction, and the deferred soft threshold folded into the fused inverse, at 1e-12."""
+    from pypwt_amd import Wavelets64, _lib
+    lib = _lib.load("f64")
+    was = lib.pdwt_set_tuning(b"swt_fused", 2)
+    try:
+        for shape, lv, wname in (((64, 256), 3, "haar"), ((128, 520), 5, "db1"), ((96, 1024), 2, "haar"), ((256, 256), 6, "bior1.1"),
+                                 ((64, 260), 4, "haar")):
+            x = oracle.hash_input(shape, 8750 + lv, scale=255.0).astype(np.float64)
+            x += 1e-9 * np.arange(x.size).reshape(x.shape)
+            w = Wavelets64(x, wname, lv, do_swt=1)
+            assert w.levels == lv
+            w.forward()
+            ref = oracle.forward(x, wname, lv, do_swt=1, double="full")
+            for k, (g, r) in enumerate(zip(_flat(w.coeffs), ref)):
+                assert g.dtype == np.float64 and np.abs(g - r).max() <= 1e-12 * max(1.0, float(np.abs(r).max())), (shape, lv, k)
+            w.inverse()
+            assert np.abs(w.image - oracle.inverse(ref, shape, wname, lv, do_swt=1, double="full")).max() <= 1e-11 * 255, (shape, lv)
+            w.forward()
+            w.soft_threshold(7.0)
+            w.inverse()
+            thr = [ref[0]] + [np.sign(b) * np.maximum(np.abs(b) - 7.0, 0.0) for b in ref[1:]]
+            want = oracle.inverse(thr, shape, wname, lv, do_swt=1, double="full")
+            assert np.abs(w.image - want).max() <= 1e-11 * 255, (shape, lv, "soft")
+    finally:
+        lib.pdwt_set_tuning(b"swt_fused", was)
