@@ -184,6 +184,8 @@ int pdwt_time_level(pdwt_handle h, int level, int inverse, int reps, float* ms_p
  * PDWT_ERR_ARG for an unknown key.  Keys:
  *   "wave_min_log2"  a 2D DWT level runs on the wave-per-tile kernels when at least 2^value samples
  *                    enter it (default 22, fp64 library 16; 0 = always when eligible; 63 = never)
+ *   "lds_max_log2"   a 2D DWT level of at most 2^value samples (one cache-resident image) prefers the LDS tiles to
+ *                    the wave-per-tile kernels (default 24; fp64 library 0 = never)
  *   "reg1d"          bit 0 / bit 1: the forward / inverse 1D DWT levels run three at a time in registers
  *                    (dwt1_reg_kernels.hpp) where the rows qualify (even hlen <= 20, rows of >= 2048 samples that
  *                    are multiples of 32); default 3; 0 = the workgroup-wide LDS pyramids (57.6 vs 69.5 us per

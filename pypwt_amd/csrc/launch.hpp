@@ -25,6 +25,8 @@ hipError_t try_launch_dwt2_fwd_wave(const Fwd2DArgs& a, int batch, hipStream_t s
 hipError_t try_launch_dwt2_inv_wave(const Inv2DArgs& a, int batch, hipStream_t s, int seg_hint = 0);
 int set_wave_min_log2(int value);  // returns the previous threshold
 int get_wave_min_log2();
+int set_lds_max_log2(int value);   // 2D DWT levels of at most 2^value samples prefer the LDS tiles to the wave kernels (0 = never)
+int get_lds_max_log2();
 int set_wave2_enabled(int value);  // two-levels-per-wavefront forward (opt-in); returns the previous setting
 int get_wave2_enabled();
 int set_swt_fused_enabled(int value);  // 2-tap 2D SWT levels 1-3 / 4-6 in one launch each (swt2_fused_kernels.hpp); read when a plan is built

@@ -108,7 +108,34 @@ static bool wave_kernels_for(long long samples) {
     return m < 63 && samples >= (1LL << m);
 }
 
+// fp32: the large levels of ONE cache-resident image (2^22 < samples <= 2^24) run on the LDS tiles: with branch-free staging
+// they are ahead of the wave kernels there -- 4096^2 db4: 21.0 / 21.8 us forward / inverse against 21.7 / 22.6,
+// 2048^2: 7.0 / 8.1 against 7.8 / 8.8 (profiles/r02y_kbench_tiles.txt) -- while a batch streamed from HBM keeps the
+// wave kernels' forward (4 x 4096^2: 99 against 107 us).  "lds_max_log2" (PDWT_LDS_MAX) moves the limit (0 = wave kernels
+// wherever they apply, as before).
+#ifdef PDWT_DOUBLE
+constexpr int kLdsMaxDefault = 0;   // no tuned LDS tiles in the fp64 build
+#else
+constexpr int kLdsMaxDefault = 24;
+#endif
+static std::atomic<int>& lds_max_log2() {
+    static std::atomic<int> v{getenv("PDWT_LDS_MAX") ? atoi(getenv("PDWT_LDS_MAX")) : kLdsMaxDefault};
+    return v;
+}
+int set_lds_max_log2(int value) { return lds_max_log2().exchange(value < 0 ? 0 : (value > 62 ? 62 : value)); }
+int get_lds_max_log2() { return lds_max_log2().load(std::memory_order_relaxed); }
+static bool lds_tiles_for(long long samples, int hlen) {
+    // ... and only above 2^22 samples: in the step the 2048^2 level of cfg2 is 0.3-0.4 us faster on the wave kernels
+    // (10.6 / 11.6 against 11.0 / 11.9 us event-timed), the 4096^2 level 1.0 / 0.3 us faster on the tiles
+    const int m = lds_max_log2().load(std::memory_order_relaxed);
+    return m > 0 && !(hlen & 1) && samples > (1LL << 22) && samples <= (1LL << m);
+}
+
 hipError_t launch_dwt2_fwd(const Fwd2DArgs& a, int batch, hipStream_t s) {
+    if (lds_tiles_for((long long)batch * a.Nr * a.Nc, a.hlen)) {
+        const hipError_t e = try_launch_dwt2_fwd_fast(a, batch, s);
+        if (e != hipErrorNotSupported) return e;
+    }
     if (wave_kernels_for((long long)batch * a.Nr * a.Nc)) {
         const hipError_t e = try_launch_dwt2_fwd_wave(a, batch, s);
         if (e != hipErrorNotSupported) return e;
@@ -135,6 +162,10 @@ hipError_t launch_dwt2_inv(const Inv2DArgs& a, int batch, hipStream_t s) {
     // 23.6 us) and loses slightly to the LDS tiles on a batch streamed from HBM (8 x 4096^2: 224-232 vs 219 us,
     // profiles/r02b_wbench_b8.txt): 2^26 samples and beyond go to the tiles
     const long long samples = (long long)batch * a.Nr * a.Nc;
+    if (lds_tiles_for(samples, a.hlen)) {
+        const hipError_t e = try_launch_dwt2_inv_fast(a, batch, s);
+        if (e != hipErrorNotSupported) return e;
+    }
 #ifdef PDWT_DOUBLE
     constexpr long long kInvWaveMax = 1LL << 62;  // no tuned LDS tile to hand a large batch to
 #else

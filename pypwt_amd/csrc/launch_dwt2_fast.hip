@@ -103,19 +103,24 @@ hipError_t try_launch_dwt2_fwd_fast(const Fwd2DArgs& a, int batch, hipStream_t s
     if ((a.Nc & 3) || (a.in_bstride & 3) || (a.out_bstride & 1)) return hipErrorNotSupported;
     if (!aligned16(a.in) || !aligned16(a.A) || !aligned16(a.H) || !aligned16(a.V) || !aligned16(a.D))
         return hipErrorNotSupported;
+    // One tile per workgroup everywhere.  Since the staging loops are branch-free (all of a thread's loads in flight
+    // together) the plain tile kernel is ahead of the streaming form (persistent workgroups that prefetch the next tile
+    // into registers) at every size measured -- db4, one 4096^2 image: 21.0 us (64x8 tiles, 256 threads) against 23.4;
+    // 2048^2: 7.0 us (64x16, 512 threads) against 8.6; 1024^2: 4.1 against 4.6; 4 x 4096^2: 107 against 116 us; 16 taps,
+    // 4096^2: 29.2 us (64x16, 512 threads) against 38.5 (profiles/r02y_kbench_tiles.txt).
     if (a.hlen <= 8 && mid_size((long long)batch * a.Nr * a.Nc)) {
         switch (a.hlen) {
-            case 2: return run_fwd_fast_tile<2, 64, 32, 512>(a, batch, s);
-            case 4: return run_fwd_fast_tile<4, 64, 32, 512>(a, batch, s);
-            case 6: return run_fwd_fast_tile<6, 64, 32, 512>(a, batch, s);
-            case 8: return run_fwd_fast_tile<8, 64, 32, 512>(a, batch, s);
+            case 2: return run_fwd_fast_tile<2, 64, 16, 512>(a, batch, s);
+            case 4: return run_fwd_fast_tile<4, 64, 16, 512>(a, batch, s);
+            case 6: return run_fwd_fast_tile<6, 64, 16, 512>(a, batch, s);
+            case 8: return run_fwd_fast_tile<8, 64, 16, 512>(a, batch, s);
         }
     }
     switch (a.hlen) {
 #define X(h)                                                                \
     case h:                                                                 \
-        if constexpr (h <= 8) return run_fwd_fast<h, 64, 8, 256>(a, batch, s);   \
-        else if constexpr (h <= 20) return run_fwd_fast<h, 64, 16, 256>(a, batch, s); \
+        if constexpr (h <= 8) return run_fwd_fast_tile<h, 64, 8, 256>(a, batch, s);   \
+        else if constexpr (h <= 20) return run_fwd_fast_tile<h, 64, 16, 512>(a, batch, s); \
         else return run_fwd_fast<h, 64, 32, 256>(a, batch, s);
         PDWT_EVEN_HLENS(X)
 #undef X
@@ -140,7 +145,7 @@ hipError_t try_launch_dwt2_inv_fast(const Inv2DArgs& a, int batch, hipStream_t s
 #define X(h)                                                                \
     case h:                                                                 \
         if constexpr (h <= 8) return run_inv_fast<h, 64, 8, 256>(a, batch, s);   \
-        else if constexpr (h <= 20) return run_inv_fast<h, 64, 16, 256>(a, batch, s); \
+        else if constexpr (h <= 20) return run_inv_fast<h, 64, 16, 512>(a, batch, s); \
         else return run_inv_fast<h, 64, 32, 256>(a, batch, s);
         PDWT_EVEN_HLENS(X)
 #undef X

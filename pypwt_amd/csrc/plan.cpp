@@ -1396,6 +1396,7 @@ int pdwt_time_level(pdwt_handle h, int level, int inverse, int reps, float* ms_p
 
 int pdwt_set_tuning(const char* key, int value) {
     if (key && !strcmp(key, "wave_min_log2")) return set_wave_min_log2(value);
+    if (key && !strcmp(key, "lds_max_log2")) return set_lds_max_log2(value);
     if (key && !strcmp(key, "wave2")) return set_wave2_enabled(value);
     if (key && !strcmp(key, "reg1d")) return set_reg1d_enabled(value);
     if (key && !strcmp(key, "swt_fused")) return set_swt_fused_enabled(value);

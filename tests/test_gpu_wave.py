@@ -29,11 +29,13 @@ def forced_wave():
     import os
     prev = lib.pdwt_set_tuning(b"wave_min_log2", 0)
     assert prev >= 0
+    prev_lds = lib.pdwt_set_tuning(b"lds_max_log2", 0)  # the default prefers the LDS tiles for one cache-resident image
     prev2 = lib.pdwt_set_tuning(b"wave2", 1)  # level pairs with N0r % 4 == 0, N0c % 16 == 0: two levels per wavefront
     os.environ["PDWT_NO_PYRAMID"] = "1"  # read when a plan is created: every level as its own launch
     yield
     os.environ.pop("PDWT_NO_PYRAMID", None)
     lib.pdwt_set_tuning(b"wave_min_log2", prev)
+    lib.pdwt_set_tuning(b"lds_max_log2", prev_lds)
     lib.pdwt_set_tuning(b"wave2", prev2)
 
 
@@ -157,6 +159,26 @@ def test_fp64_wave_kernels_vs_the_fp64_oracle():
                 assert np.abs(w.image - want).max() <= 1e-11 * 255, (wname, shape)
     finally:
         lib.pdwt_set_tuning(b"wave_min_log2", was)
+
+
+def test_wave_kernels_on_a_full_size_image():
+    """4096 x 4096 db4, two levels, every level on dwt2_fwd_wave / dwt2_inv_wave (the default dispatch now takes the LDS
+    tiles for one cache-resident image of this size; batches of 2^25 samples and the fp64 library still take these):
+    all seven bands against the oracle, then the reconstruction."""
+    from pypwt_amd import Wavelets, _lib
+    lib = _lib.load()
+    was = lib.pdwt_set_tuning(b"wave2", 0)
+    try:
+        x = oracle.hash_input((4096, 4096), 8450, scale=255.0)
+        w = Wavelets(x, "db4", 2)
+        w.forward()
+        ref = oracle.forward(x, "db4", 2)
+        for k, (g, r) in enumerate(zip(_flat(w.coeffs), ref)):
+            assert np.abs(g - r).max() <= 6e-6 * max(float(np.abs(r).max()), 255.0), k
+        w.inverse()
+        assert np.abs(w.image - x).max() < 7e-4
+    finally:
+        lib.pdwt_set_tuning(b"wave2", was)
 
 
 def test_reg_1d_three_levels_in_registers_on_the_gpu():

@@ -394,6 +394,23 @@ int main(int argc, char** argv) {
     bench_inv_fast<8, 128, 16, 512>("FAST inv db4 TX128 TY16 NT512", b, a, N, B);
     bench_inv_fast<8, 32, 16, 128>("FAST inv db4 TX32 TY16 NT128", b, a, N, B);
     bench_inv_fast<2, 64, 16, 256>("FAST inv hlen2 TX64 TY16 NT256", b, a, N, B);
+    // long filters (16 taps): tile shapes of the LDS kernels (run with the name filter "h16")
+    for (int w : {2, 3, 4, 6}) bench_fwd_stream<16, 64, 16, 256>("STREAM fwd h16 TX64 TY16 NT256", a, b, N, B, w);
+    for (int w : {2, 4, 6}) bench_fwd_stream<16, 64, 8, 256>("STREAM fwd h16 TX64 TY8 NT256", a, b, N, B, w);
+    for (int w : {1, 2}) bench_fwd_stream<16, 64, 32, 256>("STREAM fwd h16 TX64 TY32 NT256", a, b, N, B, w);
+    bench_fwd_fast<16, 64, 8, 256>("FAST fwd h16 TX64 TY8 NT256", a, b, N, B);
+    bench_fwd_fast<16, 64, 16, 256>("FAST fwd h16 TX64 TY16 NT256", a, b, N, B);
+    bench_fwd_fast<16, 64, 16, 512>("FAST fwd h16 TX64 TY16 NT512", a, b, N, B);
+    bench_fwd_fast<16, 64, 32, 512>("FAST fwd h16 TX64 TY32 NT512", a, b, N, B);
+    bench_fwd_fast<16, 128, 16, 512>("FAST fwd h16 TX128 TY16 NT512", a, b, N, B);
+    bench_fwd_fast<16, 128, 8, 512>("FAST fwd h16 TX128 TY8 NT512", a, b, N, B);
+    bench_inv_fast<16, 64, 8, 256>("FAST inv h16 TX64 TY8 NT256", b, a, N, B);
+    bench_inv_fast<16, 64, 16, 256>("FAST inv h16 TX64 TY16 NT256", b, a, N, B);
+    bench_inv_fast<16, 64, 16, 512>("FAST inv h16 TX64 TY16 NT512", b, a, N, B);
+    bench_inv_fast<16, 64, 32, 512>("FAST inv h16 TX64 TY32 NT512", b, a, N, B);
+    bench_inv_fast<16, 128, 16, 512>("FAST inv h16 TX128 TY16 NT512", b, a, N, B);
+    bench_inv_fast<16, 128, 8, 512>("FAST inv h16 TX128 TY8 NT512", b, a, N, B);
+    bench_inv_fast<16, 128, 8, 256>("FAST inv h16 TX128 TY8 NT256", b, a, N, B);
     bench_fwd<8, 64, 16, 256>("fwd db4 TX64 TY16 NT256", a, b, N, B);
     bench_fwd<8, 64, 32, 256>("fwd db4 TX64 TY32 NT256", a, b, N, B);
     bench_fwd<8, 64, 8, 256>("fwd db4 TX64 TY8  NT256", a, b, N, B);
