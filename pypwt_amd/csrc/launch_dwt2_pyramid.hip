@@ -41,9 +41,8 @@ static hipError_t run_fwd(FwdPyr2Args& a, int batch, hipStream_t s) {
     return hipGetLastError();
 }
 
-template <int HLEN>
-static hipError_t run_inv(InvPyr2Args& a, int batch, hipStream_t s) {
-    constexpr int TX = 64, TY = 8, NT = 256;
+template <int HLEN, int TX, int TY, int NT>
+static hipError_t run_inv_t(InvPyr2Args& a, int batch, hipStream_t s) {
     constexpr size_t lds = (size_t)InvPyr2Geom<HLEN, TX, TY>::LDS_FLOATS * sizeof(float);
     static_assert(lds <= 64 * 1024, "fits the default dynamic-LDS limit");
     a.tiles_x = cdiv(a.N0c, 2 * TX);
@@ -51,6 +50,14 @@ static hipError_t run_inv(InvPyr2Args& a, int batch, hipStream_t s) {
     const int chunk = (a.tiles_x * a.tiles_y + 7) / 8;
     hipLaunchKernelGGL((dwt2_inv_pyr2_kernel<HLEN, TX, TY, NT>), dim3(8 * chunk, batch), dim3(NT), lds, s, a);
     return hipGetLastError();
+}
+
+// 128x32-sample tiles of 512 threads from 2^20 samples on (1024^2 db4: 5.5 us against 6.1 us with 128x16 tiles of 256
+// threads; 512^2: 4.95 against 4.85 us -- profiles/r02y_kbench_tiles.txt)
+template <int HLEN>
+static hipError_t run_inv(InvPyr2Args& a, int batch, hipStream_t s) {
+    if ((long long)batch * a.N0r * a.N0c >= (1LL << 20)) return run_inv_t<HLEN, 64, 16, 512>(a, batch, s);
+    return run_inv_t<HLEN, 64, 8, 256>(a, batch, s);
 }
 
 // in (N0r,N0c) -> details of level l (det1 = H,V,D) and all four bands of level l+1 (band2 = A,H,V,D)
