@@ -45,8 +45,22 @@ PDWT_DEVICE void dwt1_fwd_tile(const Fwd1DArgs& a, int bx, int row, real_t* smem
     const real_t* PDWT_RESTRICT in = a.in + (long long)row * a.Nc;
     const int x0 = 2 * bx * TXO - c;
 
-    PDWT_FOR_THREADS(tid, NT) {
-        for (int q = tid; q < RX; q += NT) sIn[q] = in[wrap_analysis(x0 + q, a.Nc)];
+    PDWT_FOR_THREADS(tid, NT) {  // four loads per thread in flight (see the staging note in dwt2_kernels.hpp)
+        for (int base = 0; base < RX; base += 4 * NT) {
+            real_t v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                int q = base + u * NT + tid;
+                q = q < RX ? q : RX - 1;
+                v[u] = in[wrap_analysis(x0 + q, a.Nc)];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                int q = base + u * NT + tid;
+                q = q < RX ? q : RX - 1;
+                sIn[q] = v[u];
+            }
+        }
     }
     PDWT_SYNC();
 
@@ -119,11 +133,24 @@ PDWT_DEVICE void dwt1_inv_tile(const Inv1DArgs& a, int bx, int row, real_t* smem
     const real_t* PDWT_RESTRICT gH = a.H + (long long)row * a.Ncc;
     const int cx0 = bx * TXO - c;
 
-    PDWT_FOR_THREADS(tid, NT) {
-        for (int q = tid; q < CX; q += NT) {
-            const int sx = wrap_periodic(cx0 + q, a.Ncc);
-            sL[q] = gL[sx];
-            sH[q] = gH[sx];
+    PDWT_FOR_THREADS(tid, NT) {  // two positions of both bands (four loads) in flight per thread
+        for (int base = 0; base < CX; base += 2 * NT) {
+            real_t vl[2], vh[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                int q = base + u * NT + tid;
+                q = q < CX ? q : CX - 1;
+                const int sx = wrap_periodic(cx0 + q, a.Ncc);
+                vl[u] = gL[sx];
+                vh[u] = gH[sx];
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                int q = base + u * NT + tid;
+                q = q < CX ? q : CX - 1;
+                sL[q] = vl[u];
+                sH[q] = vh[u];
+            }
         }
     }
     PDWT_SYNC();

@@ -65,14 +65,28 @@ PDWT_DEVICE void dwt2_fwd_tile(const Fwd2DArgs& a, int bx, int by, int bz, real_
     const int y0 = 2 * by * TY - c;
 
     // ---- phase 1: stage the input tile + halo, periodized, coalesced along x
+    // eight loads per thread are issued before the first of them is stored (a loop with an exit test per element waits
+    // for every load before it issues the next: DESIGN.md, "staging loop")
     PDWT_FOR_THREADS(tid, NT) {
         const int total = RY * RXp;
-        for (int idx = tid; idx < total; idx += NT) {
-            const int r = idx / RXp;
-            const int q = idx - r * RXp;
-            const int sy = wrap_analysis(y0 + r, a.Nr);
-            const int sx = wrap_analysis(x0 + q, a.Nc);
-            sIn[idx] = in[(long long)sy * a.Nc + sx];
+        for (int base = 0; base < total; base += 8 * NT) {
+            real_t v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                int idx = base + u * NT + tid;
+                idx = idx < total ? idx : total - 1;
+                const int r = idx / RXp;
+                const int q = idx - r * RXp;
+                const int sy = wrap_analysis(y0 + r, a.Nr);
+                const int sx = wrap_analysis(x0 + q, a.Nc);
+                v[u] = in[(long long)sy * a.Nc + sx];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                int idx = base + u * NT + tid;
+                idx = idx < total ? idx : total - 1;
+                sIn[idx] = v[u];
+            }
         }
     }
     PDWT_SYNC();
@@ -230,18 +244,27 @@ PDWT_DEVICE void dwt2_inv_tile(const Inv2DArgs& a, int bx, int by, int bz, real_
     const int cx0 = bx * TX - c;
 
     // ---- phase 1: stage the four coefficient tiles (+ halo), periodic
-    PDWT_FOR_THREADS(tid, NT) {
+    PDWT_FOR_THREADS(tid, NT) {  // two elements of all four bands (eight loads) in flight per thread
         const int total = CR * CXp;
-        for (int idx = tid; idx < total; idx += NT) {
-            const int r = idx / CXp;
-            const int q = idx - r * CXp;
-            const int sy = wrap_periodic(cy0 + r, a.Nrc);
-            const int sx = wrap_periodic(cx0 + q, a.Ncc);
-            const long long g = (long long)sy * a.Ncc + sx;
-            sA[idx] = gA[g];
-            sH[idx] = gH[g];
-            sV[idx] = gV[g];
-            sD[idx] = gD[g];
+        for (int base = 0; base < total; base += 2 * NT) {
+            real_t v[2][4];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                int idx = base + u * NT + tid;
+                idx = idx < total ? idx : total - 1;
+                const int r = idx / CXp;
+                const int q = idx - r * CXp;
+                const int sy = wrap_periodic(cy0 + r, a.Nrc);
+                const int sx = wrap_periodic(cx0 + q, a.Ncc);
+                const long long g = (long long)sy * a.Ncc + sx;
+                v[u][0] = gA[g]; v[u][1] = gH[g]; v[u][2] = gV[g]; v[u][3] = gD[g];
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                int idx = base + u * NT + tid;
+                idx = idx < total ? idx : total - 1;
+                sA[idx] = v[u][0]; sH[idx] = v[u][1]; sV[idx] = v[u][2]; sD[idx] = v[u][3];
+            }
         }
     }
     PDWT_SYNC();
