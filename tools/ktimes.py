@@ -1,11 +1,12 @@
 """Per-launch HIP-event times of one forward+inverse step of an arbitrary plan (developer tool):
-python tools/ktimes.py wname rows cols levels [batch]"""
+python tools/ktimes.py wname rows cols levels [batch [do_swt]]"""
 import sys
 sys.path.insert(0, '.')
 from pypwt_amd import BatchedWavelets
 wname, r, c, L = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
 B = int(sys.argv[5]) if len(sys.argv) > 5 else 1
-bw = BatchedWavelets(B, r, c, wname, L)
+swt = int(sys.argv[6]) if len(sys.argv) > 6 else 0
+bw = BatchedWavelets(B, r, c, wname, L, do_swt=swt)
 bw.fill_hash(1)
 for _ in range(50): bw.forward(); bw.inverse()
 bw.synchronize()
