@@ -49,7 +49,7 @@ hipError_t launch_dwt2_inv_strip2(const real_t* const band2[4], const real_t* co
 hipError_t launch_dwt2_inv_pyr2(const real_t* const band2[4], const real_t* const det1[3], real_t* out, int N0r, int N0c,
                                 int hlen, const FilterBank& fb, int batch, hipStream_t s);
 // three consecutive 2D levels in one launch, small images (launch_dwt2_pyr3.hip): det[3 k + b] = band b (H, V, D) of the
-// k-th level of the group (finest first); rows and columns multiples of 8, even filters of at most 8 taps
+// k-th level of the group (finest first); rows and columns multiples of 8, even filters of at most 16 taps (fp64: 8)
 bool dwt2_pyr3_supported(int hlen, int N0r, int N0c);
 hipError_t launch_dwt2_fwd_pyr3(const real_t* in, real_t* const det[9], real_t* out, int N0r, int N0c, int hlen,
                                 const FilterBank& fb, int batch, hipStream_t s);

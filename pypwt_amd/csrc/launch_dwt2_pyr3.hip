@@ -15,10 +15,22 @@ static constexpr size_t pyr3_fwd_lds() { return (size_t)Pyr3FwdGeom<HLEN, T>::LD
 template <int HLEN, int T>
 static constexpr size_t pyr3_inv_lds() { return (size_t)Pyr3InvGeom<HLEN, 8 * T>::LDS * sizeof(real_t); }
 
-// even filters of at most 8 taps, even sizes at all three levels (the smallest tile always fits the LDS)
+// even filters of at most 16 taps whose smallest tile fits the LDS (fp64: at most 8 taps), even sizes at all three levels
+template <int HLEN>
+static constexpr bool pyr3_fits() { return pyr3_fwd_lds<HLEN, 2>() <= kPyr3LdsMax && pyr3_inv_lds<HLEN, 2>() <= kPyr3LdsMax; }
 bool dwt2_pyr3_supported(int hlen, int N0r, int N0c) {
-    static_assert(pyr3_fwd_lds<8, 2>() <= kPyr3LdsMax && pyr3_inv_lds<8, 2>() <= kPyr3LdsMax, "smallest tile, longest filter");
-    return !(hlen & 1) && hlen >= 2 && hlen <= 8 && (N0r % 8) == 0 && (N0c % 8) == 0 && N0r >= 8 && N0c >= 8;
+    if ((N0r % 8) || (N0c % 8) || N0r < 8 || N0c < 8) return false;
+    switch (hlen) {
+        case 2: return pyr3_fits<2>();
+        case 4: return pyr3_fits<4>();
+        case 6: return pyr3_fits<6>();
+        case 8: return pyr3_fits<8>();
+        case 10: return pyr3_fits<10>();
+        case 12: return pyr3_fits<12>();
+        case 14: return pyr3_fits<14>();
+        case 16: return pyr3_fits<16>();
+    }
+    return false;
 }
 
 // Tile edge T at the third level (a workgroup covers an 8T x 8T block of the input): the launch is a latency chain of
@@ -44,7 +56,8 @@ template <int HLEN, int T, int NT>
 static hipError_t run_fwd_t(Pyr3Args& a, int batch, hipStream_t s) {
     constexpr size_t lds = pyr3_fwd_lds<HLEN, T>();
     if constexpr (lds > kPyr3LdsMax) {
-        return run_fwd_t<HLEN, T / 2, NT>(a, batch, s);  // fp64, long filters: the next smaller tile
+        if constexpr (T > 2) return run_fwd_t<HLEN, T / 2, NT>(a, batch, s);  // long filters, fp64: the next smaller tile
+        else return hipErrorNotSupported;
     } else {
         static std::atomic<bool> big[64] = {};
         const hipError_t e = allow_big_lds(dwt2_fwd_pyr3_kernel<HLEN, T, NT>, lds, big);
@@ -59,7 +72,8 @@ template <int HLEN, int T, int NT>
 static hipError_t run_inv_t(Pyr3Args& a, int batch, hipStream_t s) {
     constexpr size_t lds = pyr3_inv_lds<HLEN, T>();
     if constexpr (lds > kPyr3LdsMax) {
-        return run_inv_t<HLEN, T / 2, NT>(a, batch, s);
+        if constexpr (T > 2) return run_inv_t<HLEN, T / 2, NT>(a, batch, s);
+        else return hipErrorNotSupported;
     } else {
         constexpr int T0 = 8 * T;
         static std::atomic<bool> big[64] = {};
@@ -96,6 +110,10 @@ hipError_t launch_dwt2_fwd_pyr3(const real_t* in, real_t* const det[9], real_t* 
         case 4: return run_fwd<4>(a, batch, s);
         case 6: return run_fwd<6>(a, batch, s);
         case 8: return run_fwd<8>(a, batch, s);
+        case 10: return run_fwd<10>(a, batch, s);
+        case 12: return run_fwd<12>(a, batch, s);
+        case 14: return run_fwd<14>(a, batch, s);
+        case 16: return run_fwd<16>(a, batch, s);
     }
     return hipErrorNotSupported;
 }
@@ -112,6 +130,10 @@ hipError_t launch_dwt2_inv_pyr3(const real_t* app, real_t* const det[9], real_t*
         case 4: return run_inv<4>(a, batch, s);
         case 6: return run_inv<6>(a, batch, s);
         case 8: return run_inv<8>(a, batch, s);
+        case 10: return run_inv<10>(a, batch, s);
+        case 12: return run_inv<12>(a, batch, s);
+        case 14: return run_inv<14>(a, batch, s);
+        case 16: return run_inv<16>(a, batch, s);
     }
     return hipErrorNotSupported;
 }

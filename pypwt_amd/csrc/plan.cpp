@@ -338,8 +338,11 @@ void build_schedule(pdwt_plan* p) {
         const bool no_pyr3 = no_pyr || getenv("PDWT_NO_PYR3") != nullptr;
         auto pyr3_at = [&](int l) {
             const int left = L - l + 1;
+            // filters of 10-16 taps recompute a 16x larger halo: ahead up to 512^2 only (sym8 512^2 L3: 21.6 against 25.0 us,
+            // 1024 x 512: 37.3 against 25.4 us; profiles/r02y_pyr3_sweep.txt)
+            const long long per_image = hlen <= 8 ? (1LL << 19) : (1LL << 18);
             return fusable && !no_pyr3 && left >= 3 && left != 4 && samples(l) <= (1LL << 20) &&
-                   (long long)p->lr[l - 1] * p->lc[l - 1] <= (1LL << 19) && dwt2_pyr3_supported(hlen, p->lr[l - 1], p->lc[l - 1]);
+                   (long long)p->lr[l - 1] * p->lc[l - 1] <= per_image && dwt2_pyr3_supported(hlen, p->lr[l - 1], p->lc[l - 1]);
         };
         // Two levels per WAVEFRONT (dwt2_fwd2_wave: A_l stays in registers, overlapping strips).  Correct and
         // tested, but NOT faster than two launches on MI355X (profiles/r02g_wbench_*.txt: 4096^2 31.3 us against

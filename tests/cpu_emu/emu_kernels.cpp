@@ -447,7 +447,7 @@ static void run_pyr3(Pyr3Args a, int batch, bool inverse) {
 
 EMU_API int emu_dwt2_pyr3(int inverse, float* image, int batch, int N0r, int N0c, const float* lo, const float* hi, int hlen,
                           int tile, float* det, float* app) {
-    if ((hlen & 1) || hlen > 8 || (N0c & 7) || (N0r & 7)) return -2;
+    if ((hlen & 1) || hlen > 16 || (N0c & 7) || (N0r & 7)) return -2;
     Pyr3Args a;
     long long off = 0;
     for (int k = 0; k < 3; k++) {
@@ -460,7 +460,7 @@ EMU_API int emu_dwt2_pyr3(int inverse, float* image, int batch, int N0r, int N0c
     set_bank(a.fb, lo, hi, hlen);
     switch (hlen) {
 #define X(h) case h: if (tile == 2) run_pyr3<h, 2>(a, batch, inverse != 0); else if (tile == 4) run_pyr3<h, 4>(a, batch, inverse != 0); else run_pyr3<h, 8>(a, batch, inverse != 0); return 0;
-        X(2) X(4) X(6) X(8)
+        X(2) X(4) X(6) X(8) X(10) X(12) X(14) X(16)
 #undef X
     }
     return -1;

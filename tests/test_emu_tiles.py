@@ -352,7 +352,7 @@ def test_emu_dwt2_inv_pyramid(wname):
 
 
 # ----------------------------------------------------------------------------- three-level pyramid (small images)
-@pytest.mark.parametrize("wname", ["haar", "db2", "db3", "db4", "sym4", "bior3.1", "rbio2.2"])
+@pytest.mark.parametrize("wname", ["haar", "db2", "db3", "db4", "sym4", "bior3.1", "rbio2.2", "db5", "coif2", "db7", "sym8"])
 def test_emu_dwt2_pyramid_of_three_levels(wname):
     """dwt2_fwd_pyr3_tile / dwt2_inv_pyr3_tile: three levels per launch out of LDS -- whole and partial tiles, images
     smaller than one tile's halo (the wrap goes around more than once), a batch."""

@@ -136,13 +136,13 @@ def test_fuzz_register_kernels(seed):
 
 @pytest.mark.parametrize("seed", range(4))
 def test_fuzz_three_level_pyramid(seed):
-    """Small 2D images whose sizes are multiples of 8, filters of at most 8 taps, three / five / six levels, batches:
-    the shapes that run three levels per launch (dwt2_pyr3_kernels.hpp, all three tile sizes, tiles that wrap more than
+    """Small 2D images whose sizes are multiples of 8, filters of at most 16 taps, three / five / six levels, batches:
+    the shapes that run three levels per launch (dwt2_pyr3_kernels.hpp, filters of up to 16 taps, all three tile sizes, tiles that wrap more than
     once, partial tiles); forward vs the oracle, then soft threshold + inverse vs the oracle's sequence, in both
     precisions."""
     from pypwt_amd import BatchedWavelets, Wavelets64
     rng = np.random.default_rng(4300 + seed)
-    short = ["haar", "db2", "db3", "db4", "sym4", "coif1", "bior1.3", "bior2.2", "rbio3.3", "bior3.1"]
+    short = ["haar", "db2", "db3", "db4", "sym4", "coif1", "bior1.3", "bior2.2", "rbio3.3", "bior3.1", "db5", "sym6", "db7", "sym8"]
     for it in range(14):
         wname = str(rng.choice(short))
         hlen = oracle.filters(wname)[0]

@@ -339,7 +339,8 @@ def test_three_level_pyramid_on_small_images():
     from pypwt_amd import BatchedWavelets
     cases = (("db2", (512, 512), 3, 1), ("haar", (64, 64), 3, 2), ("db3", (256, 384), 5, 1), ("db4", (256, 256), 3, 1),
              ("sym4", (512, 1024), 6, 1), ("db2", (40, 72), 3, 3), ("bior3.1", (256, 128), 3, 1), ("haar", (8, 8), 3, 1),
-             ("db4", (128, 128), 3, 64), ("db3", (264, 200), 3, 2))
+             ("db4", (128, 128), 3, 64), ("db3", (264, 200), 3, 2), ("sym8", (512, 512), 3, 1), ("db5", (256, 320), 3, 2),
+             ("coif2", (512, 256), 3, 1), ("db7", (512, 512), 3, 1))
     for ci, (wname, shape, L, B) in enumerate(cases):
         x = oracle.hash_input((B,) + shape, 4300 + ci, scale=255.0)
         bw = BatchedWavelets(B, shape[0], shape[1], wname, L, img=x)
