@@ -46,6 +46,7 @@ bool dwt2_wave2_supported(int, int, int) { return false; }
 hipError_t launch_dwt2_fwd_wave2(const real_t*, real_t* const[3], real_t* const[4], int, int, int, const FilterBank&, int,
                                  hipStream_t, int) { return hipErrorNotSupported; }
 bool dwt2_pyramid_supported(int, int, int) { return false; }
+bool dwt2_strip_supported(int, int, int) { return false; }
 hipError_t launch_dwt2_fwd_pyr2(const real_t*, real_t* const[3], real_t* const[4], int, int, int, const FilterBank&, int,
                                 hipStream_t) { return hipErrorNotSupported; }
 hipError_t launch_dwt2_fwd_strip2(const real_t*, real_t* const[3], real_t* const[4], int, int, int, const FilterBank&,

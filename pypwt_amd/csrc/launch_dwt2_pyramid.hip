@@ -24,16 +24,20 @@ static void interleave(FilterBankI& o, const FilterBank& fb) {
 static bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 bool dwt2_pyramid_supported(int hlen, int N0r, int N0c) {
-    // even sizes at both levels (exact periodization), 16-B aligned rows at level l+1
-    return (hlen == 2 || hlen == 4 || hlen == 6 || hlen == 8) && (N0r % 4) == 0 && (N0c % 16) == 0 && N0r >= 4 &&
-           N0c >= 16;
+    // even filters of at most 16 taps (LDS), even sizes at both levels (exact periodization), 16-B aligned rows at level l+1
+    return !(hlen & 1) && hlen >= 2 && hlen <= 16 && (N0r % 4) == 0 && (N0c % 16) == 0 && N0r >= 4 && N0c >= 16;
 }
+// the streaming strips carry (hlen - 2) rows per level in LDS: filters of at most 8 taps
+bool dwt2_strip_supported(int hlen, int N0r, int N0c) { return hlen <= 8 && dwt2_pyramid_supported(hlen, N0r, N0c); }
 
 template <int HLEN>
 static hipError_t run_fwd(FwdPyr2Args& a, int batch, hipStream_t s) {
     constexpr int TX2 = 32, TY2 = 8, NT = 512;
     constexpr size_t lds = (size_t)Pyr2Geom<HLEN, TX2, TY2>::LDS_FLOATS * sizeof(float);
-    static_assert(lds <= 64 * 1024, "fits the default dynamic-LDS limit");
+    static_assert(lds <= 150 * 1024, "fits the LDS (filters of more than 8 taps opt in to more than 64 KiB)");
+    static std::atomic<bool> big[64] = {};
+    const hipError_t e = allow_big_lds(dwt2_fwd_pyr2_kernel<HLEN, TX2, TY2, NT>, lds, big);
+    if (e != hipSuccess) return e;
     a.tiles_x = cdiv(a.N0c / 4, TX2);
     a.tiles_y = cdiv(a.N0r / 4, TY2);
     const int chunk = (a.tiles_x * a.tiles_y + 7) / 8;
@@ -44,7 +48,10 @@ static hipError_t run_fwd(FwdPyr2Args& a, int batch, hipStream_t s) {
 template <int HLEN, int TX, int TY, int NT>
 static hipError_t run_inv_t(InvPyr2Args& a, int batch, hipStream_t s) {
     constexpr size_t lds = (size_t)InvPyr2Geom<HLEN, TX, TY>::LDS_FLOATS * sizeof(float);
-    static_assert(lds <= 64 * 1024, "fits the default dynamic-LDS limit");
+    static_assert(lds <= 150 * 1024, "fits the LDS");
+    static std::atomic<bool> big[64] = {};
+    const hipError_t e = allow_big_lds(dwt2_inv_pyr2_kernel<HLEN, TX, TY, NT>, lds, big);
+    if (e != hipSuccess) return e;
     a.tiles_x = cdiv(a.N0c, 2 * TX);
     a.tiles_y = cdiv(a.N0r, 2 * TY);
     const int chunk = (a.tiles_x * a.tiles_y + 7) / 8;
@@ -80,6 +87,10 @@ hipError_t launch_dwt2_fwd_pyr2(const float* in, float* const det1[3], float* co
         case 4: return run_fwd<4>(a, batch, s);
         case 6: return run_fwd<6>(a, batch, s);
         case 8: return run_fwd<8>(a, batch, s);
+        case 10: return run_fwd<10>(a, batch, s);
+        case 12: return run_fwd<12>(a, batch, s);
+        case 14: return run_fwd<14>(a, batch, s);
+        case 16: return run_fwd<16>(a, batch, s);
     }
     return hipErrorNotSupported;
 }
@@ -105,7 +116,7 @@ static hipError_t run_fwd_strip(FwdStrip2Args& a, int batch, hipStream_t s) {
 
 hipError_t launch_dwt2_fwd_strip2(const float* in, float* const det1[3], float* const band2[4], int N0r, int N0c,
                                   int hlen, const FilterBank& fb, int batch, hipStream_t s) {
-    if (!dwt2_pyramid_supported(hlen, N0r, N0c)) return hipErrorNotSupported;
+    if (!dwt2_strip_supported(hlen, N0r, N0c)) return hipErrorNotSupported;
     if (!al16(in) || !al16(det1[0]) || !al16(det1[1]) || !al16(det1[2]) || !al16(band2[0]) || !al16(band2[1]) ||
         !al16(band2[2]) || !al16(band2[3]))
         return hipErrorNotSupported;
@@ -143,7 +154,7 @@ static hipError_t run_inv_strip(InvStrip2Args& a, int batch, hipStream_t s) {
 // same contract as launch_dwt2_inv_pyr2, streaming-strip kernel for large inputs
 hipError_t launch_dwt2_inv_strip2(const float* const band2[4], const float* const det1[3], float* out, int N0r,
                                   int N0c, int hlen, const FilterBank& fb, int batch, hipStream_t s) {
-    if (!dwt2_pyramid_supported(hlen, N0r, N0c)) return hipErrorNotSupported;
+    if (!dwt2_strip_supported(hlen, N0r, N0c)) return hipErrorNotSupported;
     if (!al16(out) || !al16(det1[0]) || !al16(det1[1]) || !al16(det1[2]) || !al16(band2[0]) || !al16(band2[1]) ||
         !al16(band2[2]) || !al16(band2[3]))
         return hipErrorNotSupported;
@@ -183,6 +194,10 @@ hipError_t launch_dwt2_inv_pyr2(const float* const band2[4], const float* const 
         case 4: return run_inv<4>(a, batch, s);
         case 6: return run_inv<6>(a, batch, s);
         case 8: return run_inv<8>(a, batch, s);
+        case 10: return run_inv<10>(a, batch, s);
+        case 12: return run_inv<12>(a, batch, s);
+        case 14: return run_inv<14>(a, batch, s);
+        case 16: return run_inv<16>(a, batch, s);
     }
     return hipErrorNotSupported;
 }

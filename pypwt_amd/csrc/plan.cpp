@@ -327,7 +327,9 @@ void build_schedule(pdwt_plan* p) {
         auto samples = [&](int l) { return (long long)p->batch * p->lr[l - 1] * p->lc[l - 1]; };
         auto pair_ok = [&](int l) { return l + 1 <= L && dwt2_pyramid_supported(hlen, p->lr[l - 1], p->lc[l - 1]); };
         auto strip_at = [&](int l, bool inverse) {
-            if (!fusable || no_strip || !pair_ok(l) || (inverse && !force_strip)) return false;
+            if (!fusable || no_strip || !pair_ok(l) || !dwt2_strip_supported(hlen, p->lr[l - 1], p->lc[l - 1]) ||
+                (inverse && !force_strip))
+                return false;
             return force_strip || samples(l) >= (1LL << 26);
         };
         auto pyr_at = [&](int l) { return fusable && !no_pyr && pair_ok(l) && samples(l) <= (1LL << 20); };

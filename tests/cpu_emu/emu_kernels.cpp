@@ -379,7 +379,7 @@ static void run_fwd_pyr2(FwdPyr2Args a, int batch) {
 // l1: H,V,D planes of the first level (3 x batch x N0r/2 x N0c/2), l2: A,H,V,D of the second (4 x ...)
 EMU_API int emu_dwt2_fwd_pyr2(const float* in, int batch, int N0r, int N0c, const float* lo, const float* hi, int hlen,
                               int tile, float* l1, float* l2) {
-    if ((hlen & 1) || hlen > 8 || (N0c & 7) || (N0r & 3)) return -2;
+    if ((hlen & 1) || hlen > 16 || (N0c & 7) || (N0r & 3)) return -2;
     FwdPyr2Args a;
     const long long n1 = (long long)batch * (N0r / 2) * (N0c / 2), n2 = (long long)batch * (N0r / 4) * (N0c / 4);
     a.in = in; a.H1 = l1; a.V1 = l1 + n1; a.D1 = l1 + 2 * n1;
@@ -390,7 +390,7 @@ EMU_API int emu_dwt2_fwd_pyr2(const float* in, int batch, int N0r, int N0c, cons
     set_bank_i(a.fb, lo, hi, hlen);
     switch (hlen) {
 #define X(h) case h: if (tile == 0) run_fwd_pyr2<h, 32, 4, 256>(a, batch); else run_fwd_pyr2<h, 32, 8, 256>(a, batch); return 0;
-        X(2) X(4) X(6) X(8)
+        X(2) X(4) X(6) X(8) X(10) X(12) X(14) X(16)
 #undef X
     }
     return -1;
@@ -408,7 +408,7 @@ static void run_inv_pyr2(InvPyr2Args a, int batch) {
 
 EMU_API int emu_dwt2_inv_pyr2(const float* l1, const float* l2, int batch, int N0r, int N0c, const float* lo,
                               const float* hi, int hlen, int tile, float* out) {
-    if ((hlen & 1) || hlen > 8 || (N0c & 15) || (N0r & 3)) return -2;
+    if ((hlen & 1) || hlen > 16 || (N0c & 15) || (N0r & 3)) return -2;
     InvPyr2Args a;
     const long long n1 = (long long)batch * (N0r / 2) * (N0c / 2), n2 = (long long)batch * (N0r / 4) * (N0c / 4);
     a.H1 = l1; a.V1 = l1 + n1; a.D1 = l1 + 2 * n1;
@@ -419,7 +419,7 @@ EMU_API int emu_dwt2_inv_pyr2(const float* l1, const float* l2, int batch, int N
     set_bank_i(a.fb, lo, hi, hlen);
     switch (hlen) {
 #define X(h) case h: if (tile == 0) run_inv_pyr2<h, 64, 8, 256>(a, batch); else run_inv_pyr2<h, 64, 16, 256>(a, batch); return 0;
-        X(2) X(4) X(6) X(8)
+        X(2) X(4) X(6) X(8) X(10) X(12) X(14) X(16)
 #undef X
     }
     return -1;

@@ -314,7 +314,7 @@ def test_emu_dwt1_fused_pyramid(wname):
 
 
 # ----------------------------------------------------------------------------- two-level pyramid
-@pytest.mark.parametrize("wname", ["haar", "db2", "db3", "db4", "sym4", "bior3.1"])
+@pytest.mark.parametrize("wname", ["haar", "db2", "db3", "db4", "sym4", "bior3.1", "db5", "coif2", "db7", "sym8"])
 def test_emu_dwt2_fwd_pyramid(wname):
     hlen, dlo, dhi, rlo, rhi = oracle.filters(wname)
     for si, (B, shape) in enumerate([(1, (64, 64)), (1, (32, 136)), (2, (40, 72)), (1, (128, 512)), (1, (4, 8)), (1, (260, 264))]):
@@ -333,7 +333,7 @@ def test_emu_dwt2_fwd_pyramid(wname):
                     assert np.abs(g - r).max() <= 2 * _tol(r), (wname, shape, tile, k)
 
 
-@pytest.mark.parametrize("wname", ["haar", "db2", "db3", "db4", "sym4", "bior3.1"])
+@pytest.mark.parametrize("wname", ["haar", "db2", "db3", "db4", "sym4", "bior3.1", "db5", "coif2", "db7", "sym8"])
 def test_emu_dwt2_inv_pyramid(wname):
     hlen, dlo, dhi, rlo, rhi = oracle.filters(wname)
     for si, (B, shape) in enumerate([(1, (64, 64)), (1, (32, 144)), (2, (40, 80)), (1, (128, 512)), (1, (4, 16)), (1, (260, 272))]):
