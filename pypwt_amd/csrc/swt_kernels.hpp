@@ -257,7 +257,15 @@ PDWT_DEVICE void swt2_fwd_vec_tile(const Swt2DArgs& a, int bx, int by, int bz, r
     const bool interior = bx * TX - c * f >= 0 && bx * TX + TX + (HLEN - 1 - c) * f <= a.Nc;
     PDWT_FOR_THREADS(tid, NT) {
         const int k4 = tid % QX, x0 = bx * TX + 4 * k4;
-        for (int r = tid / QX; r < RY; r += NG) {
+        // Long filters: constant trip count, row clamped (surplus trips redo the last row with the same result) -- no exit
+        // test between the trips, so the next row's HLEN loads are issued while this row is summed: 16 taps at 2048^2
+        // 49 -> 41 us per level; 2-8 taps unchanged, and unrolling them only grows the binary (tools/ktimes.py).
+        constexpr int TRIPS = (RY + NG - 1) / NG;
+#pragma unroll(HLEN >= 10 ? TRIPS : 1)
+        for (int t = 0; t < TRIPS; ++t) {
+            int r = tid / QX + t * NG;
+            if (HLEN < 10 && r >= RY) break;
+            r = r < RY ? r : RY - 1;
             rv4 aL = {zero, zero, zero, zero}, aH = aL;
             if (x0 < a.Nc) {
                 const int i = wrap_periodic(it * TY - c + r, M);
