@@ -11,7 +11,9 @@ template <int HLEN, bool INV, int TX = 128>
 static hipError_t run_vec(const Swt2DArgs& a, int batch, hipStream_t s) {
     constexpr int TY = 16, NT = 256;
     static std::atomic<bool> big[64] = {};
-    constexpr size_t lds = (size_t)swt2d_vec_lds_floats<TX, TY>(HLEN) * sizeof(real_t);
+    // the inverse stages its rows in LDS where the dilation allows it (swt_inv_staged): a larger request for those launches
+    const bool staged = INV && swt_inv_staged(HLEN, a.f);
+    const size_t lds = (size_t)swt2d_inv_vec_lds_floats<TX, TY, NT>(HLEN, staged) * sizeof(real_t);
     const int M = a.Nr / a.f;
     const int total = cdiv(a.Nc, TX) * cdiv(M, TY) * a.f;
     dim3 grid(8 * ((total + 7) / 8), batch);  // XCD-aware tile order, see swt_vec_tile

@@ -240,6 +240,17 @@ PDWT_DEVICE rv4 soft4(const rv4& v, real_t b) {
 template <int TX, int TY>
 constexpr int swt2d_vec_lds_floats(int hlen) { return 2 * (TY + hlen - 1) * TX; }
 
+// The inverse row pass reads hlen taps of FOUR bands per output quad.  Where the dilation is a multiple of 4 (levels
+// >= 3) the taps of a lane are other lanes' own quads: each row group then stages its row of the four bands (tile +
+// (hlen - 1) f halo columns, at most kSwtStageHalo) in LDS once -- 4 (1 + halo / TX) global loads per quad instead of
+// 4 hlen -- and takes the taps from there (16 taps at 2048^2, level 3+: 210 -> ~45 us per level).
+constexpr int kSwtStageHalo = 256;
+constexpr bool swt_inv_staged(int hlen, int f) { return hlen >= 4 && (f & 3) == 0 && (hlen - 1) * f <= kSwtStageHalo; }  // host and device
+template <int TX, int TY, int NT>
+constexpr int swt2d_inv_vec_lds_floats(int hlen, bool staged) {
+    return swt2d_vec_lds_floats<TX, TY>(hlen) + (staged ? (NT / (TX / 4)) * 4 * (TX + kSwtStageHalo) : 0);
+}
+
 template <int HLEN, int TX, int TY, int NT>
 PDWT_DEVICE void swt2_fwd_vec_tile(const Swt2DArgs& a, int bx, int by, int bz, real_t* smem) {
     constexpr int QX = TX / 4, NG = NT / QX, R = TY / NG;
@@ -322,9 +333,57 @@ PDWT_DEVICE void swt2_inv_vec_tile(const Swt2DArgs& a, int bx, int by, int bz, r
     const long long boff = (long long)bz * a.bstride;
     const real_t zero = 0, half = (real_t)0.5;
 
-    // dilated row synthesis from global: u1 = Lx(A) + Hx(V), u2 = Lx(H) + Hx(D) (pending soft threshold
-    // applied to the detail bands as they are loaded, never to A)
+    // dilated row synthesis: u1 = Lx(A) + Hx(V), u2 = Lx(H) + Hx(D) (pending soft threshold applied to the detail
+    // bands as they are loaded, never to A)
     const bool interior = bx * TX - c * f >= 0 && bx * TX + TX + (HLEN - 1 - c) * f <= a.Nc;  // see the forward tile
+    if (swt_inv_staged(HLEN, f)) {
+        // staged: per trip every row group (QX threads) loads its row of the four bands once -- tile + halo columns,
+        // periodic, whole quads (f, the tile origin and Nc are multiples of 4) -- then takes its taps from LDS
+        constexpr int SW = TX + kSwtStageHalo;            // floats per staged band row
+        constexpr int TRIPS = (RY + NG - 1) / NG;
+        const int xl = c * f, W4 = (TX + (HLEN - 1) * f) / 4;  // halo columns on the left; staged quads per band
+        real_t* stage = smem + 2 * RY * TX;
+        for (int t = 0; t < TRIPS; ++t) {
+            PDWT_FOR_THREADS(tid, NT) {
+                const int k4 = tid % QX, g = tid / QX, r = g + t * NG;
+                if (r < RY) {
+                    const int i = wrap_periodic(it * TY - c + r, M);
+                    const long long ro = boff + (long long)(ph + f * i) * a.Nc;
+                    real_t* sg = stage + g * 4 * SW;
+                    for (int q = k4; q < W4; q += QX) {
+                        const int p = wrap_periodic(bx * TX - xl + 4 * q, a.Nc);  // a multiple of 4: the quad never straddles
+                        store4(sg + 4 * q, load4(a.A + ro + p));
+                        store4(sg + SW + 4 * q, soft4(load4(a.V + ro + p), a.soft_beta));
+                        store4(sg + 2 * SW + 4 * q, soft4(load4(a.H + ro + p), a.soft_beta));
+                        store4(sg + 3 * SW + 4 * q, soft4(load4(a.D + ro + p), a.soft_beta));
+                    }
+                }
+            }
+            PDWT_SYNC();
+            PDWT_FOR_THREADS(tid, NT) {
+                const int k4 = tid % QX, g = tid / QX, r = g + t * NG;
+                if (r < RY) {
+                    const real_t* sg = stage + g * 4 * SW + 4 * k4;  // tap j of this quad sits j f columns further on
+                    rv4 r1 = {zero, zero, zero, zero}, r2 = r1;
+                    if (bx * TX + 4 * k4 < a.Nc) {
+#pragma unroll
+                        for (int j = 0; j < HLEN; ++j) {
+                            const real_t tl = a.fb.lo[HLEN - 1 - j], th = a.fb.hi[HLEN - 1 - j];
+                            fma4(r1, load4(sg + j * f), tl);
+                            fma4(r1, load4(sg + SW + j * f), th);
+                            fma4(r2, load4(sg + 2 * SW + j * f), tl);
+                            fma4(r2, load4(sg + 3 * SW + j * f), th);
+                        }
+                    }
+                    r1.x *= half; r1.y *= half; r1.z *= half; r1.w *= half;
+                    r2.x *= half; r2.y *= half; r2.z *= half; r2.w *= half;
+                    store4(u1 + r * TX + 4 * k4, r1);
+                    store4(u2 + r * TX + 4 * k4, r2);
+                }
+            }
+            PDWT_SYNC();
+        }
+    } else
     PDWT_FOR_THREADS(tid, NT) {
         const int k4 = tid % QX, x0 = bx * TX + 4 * k4;
         for (int r = tid / QX; r < RY; r += NG) {

@@ -152,7 +152,7 @@ static void run_swt2(const Swt2DArgs& a, int batch) {
 template <int HLEN, bool INV, int TX = 128>
 static void run_swt2_vec(const Swt2DArgs& a, int batch) {
     constexpr int TY = 16, NT = 256;
-    std::vector<float> smem(swt2d_vec_lds_floats<TX, TY>(HLEN) + 64, NAN);
+    std::vector<float> smem(swt2d_inv_vec_lds_floats<TX, TY, NT>(HLEN, true) + 64, NAN);
     const int M = a.Nr / a.f;
     for (int bz = 0; bz < batch; bz++)
         for (int by = 0; by < cdiv(M, TY) * a.f; by++)
