@@ -12,7 +12,7 @@ static hipError_t run_vec(const Swt2DArgs& a, int batch, hipStream_t s) {
     constexpr int TY = 16, NT = 256;
     static std::atomic<bool> big[64] = {};
     // the inverse stages its rows in LDS where the dilation allows it (swt_inv_staged): a larger request for those launches
-    const bool staged = INV && swt_inv_staged(HLEN, a.f);
+    const bool staged = INV && swt_inv_staged<TX, TY, NT>(HLEN, a.f);
     const size_t lds = (size_t)swt2d_inv_vec_lds_floats<TX, TY, NT>(HLEN, staged) * sizeof(real_t);
     const int M = a.Nr / a.f;
     const int total = cdiv(a.Nc, TX) * cdiv(M, TY) * a.f;

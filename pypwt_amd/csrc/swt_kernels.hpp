@@ -240,15 +240,25 @@ PDWT_DEVICE rv4 soft4(const rv4& v, real_t b) {
 template <int TX, int TY>
 constexpr int swt2d_vec_lds_floats(int hlen) { return 2 * (TY + hlen - 1) * TX; }
 
-// The inverse row pass reads hlen taps of FOUR bands per output quad.  Where the dilation is a multiple of 4 (levels
-// >= 3) the taps of a lane are other lanes' own quads: each row group then stages its row of the four bands (tile +
-// (hlen - 1) f halo columns, at most kSwtStageHalo) in LDS once -- 4 (1 + halo / TX) global loads per quad instead of
-// 4 hlen -- and takes the taps from there (16 taps at 2048^2, level 3+: 210 -> ~45 us per level).
+// The inverse row pass reads hlen taps of FOUR bands per output quad.  Each row group stages its row of the four bands
+// (tile + (hlen - 1) f halo columns, at most kSwtStageHalo, from a 4-aligned origin) in LDS once -- 4 (1 + halo / TX)
+// global loads per quad instead of 4 hlen -- and takes the taps from there: aligned 16-B LDS reads where the dilation is a
+// multiple of 4 (levels >= 3), four 4-B reads at dilation 1 and 2.
 constexpr int kSwtStageHalo = 256;
-constexpr bool swt_inv_staged(int hlen, int f) { return hlen >= 4 && (f & 3) == 0 && (hlen - 1) * f <= kSwtStageHalo; }  // host and device
+// (measured per 2048^2 level: 16 taps 193 -> 95 us at dilation 4+, 200 -> 139 us at dilation 1, 2; 8 taps 45 -> 32 and 53 -> 49 us;
+// 4 taps 25 -> 25 and 28 -> 35 us: short filters keep the direct loads)
+constexpr bool swt_inv_staged_filter(int hlen, int f) {
+    return (hlen - 1) * f <= kSwtStageHalo && ((f & 3) == 0 ? hlen >= 6 : hlen >= 10);
+}
 template <int TX, int TY, int NT>
 constexpr int swt2d_inv_vec_lds_floats(int hlen, bool staged) {
-    return swt2d_vec_lds_floats<TX, TY>(hlen) + (staged ? (NT / (TX / 4)) * 4 * (TX + kSwtStageHalo) : 0);
+    return swt2d_vec_lds_floats<TX, TY>(hlen) + (staged ? (NT / (TX / 4)) * 4 * (TX + kSwtStageHalo + 4) : 0);
+}
+// ... and only while the staged rows fit the LDS beside the (u1, u2) tile (the fp64 build's long filters do not)
+template <int TX, int TY, int NT>
+constexpr bool swt_inv_staged(int hlen, int f) {  // host (LDS request) and device (path), same answer
+    return swt_inv_staged_filter(hlen, f) &&
+           (long long)swt2d_inv_vec_lds_floats<TX, TY, NT>(hlen, true) * (long long)sizeof(real_t) <= 150 * 1024;
 }
 
 template <int HLEN, int TX, int TY, int NT>
@@ -336,12 +346,14 @@ PDWT_DEVICE void swt2_inv_vec_tile(const Swt2DArgs& a, int bx, int by, int bz, r
     // dilated row synthesis: u1 = Lx(A) + Hx(V), u2 = Lx(H) + Hx(D) (pending soft threshold applied to the detail
     // bands as they are loaded, never to A)
     const bool interior = bx * TX - c * f >= 0 && bx * TX + TX + (HLEN - 1 - c) * f <= a.Nc;  // see the forward tile
-    if (swt_inv_staged(HLEN, f)) {
+    if (swt_inv_staged<TX, TY, NT>(HLEN, f)) {
         // staged: per trip every row group (QX threads) loads its row of the four bands once -- tile + halo columns,
         // periodic, whole quads (f, the tile origin and Nc are multiples of 4) -- then takes its taps from LDS
-        constexpr int SW = TX + kSwtStageHalo;            // floats per staged band row
+        constexpr int SW = TX + kSwtStageHalo + 4;        // floats per staged band row
         constexpr int TRIPS = (RY + NG - 1) / NG;
-        const int xl = c * f, W4 = (TX + (HLEN - 1) * f) / 4;  // halo columns on the left; staged quads per band
+        const int padp = (4 - ((c * f) & 3)) & 3;          // the staged row starts at the 4-aligned column below bx TX - c f
+        const int xl = c * f + padp, W4 = (TX + (HLEN - 1) * f + padp + 3) / 4;  // columns left of the tile; staged quads per band
+        const bool aligned_taps = (f & 3) == 0;
         real_t* stage = smem + 2 * RY * TX;
         for (int t = 0; t < TRIPS; ++t) {
             PDWT_FOR_THREADS(tid, NT) {
@@ -363,16 +375,27 @@ PDWT_DEVICE void swt2_inv_vec_tile(const Swt2DArgs& a, int bx, int by, int bz, r
             PDWT_FOR_THREADS(tid, NT) {
                 const int k4 = tid % QX, g = tid / QX, r = g + t * NG;
                 if (r < RY) {
-                    const real_t* sg = stage + g * 4 * SW + 4 * k4;  // tap j of this quad sits j f columns further on
+                    const real_t* sg = stage + g * 4 * SW + 4 * k4 + padp;  // tap j of this quad sits j f columns further on
                     rv4 r1 = {zero, zero, zero, zero}, r2 = r1;
                     if (bx * TX + 4 * k4 < a.Nc) {
+                        if (aligned_taps) {
 #pragma unroll
-                        for (int j = 0; j < HLEN; ++j) {
-                            const real_t tl = a.fb.lo[HLEN - 1 - j], th = a.fb.hi[HLEN - 1 - j];
-                            fma4(r1, load4(sg + j * f), tl);
-                            fma4(r1, load4(sg + SW + j * f), th);
-                            fma4(r2, load4(sg + 2 * SW + j * f), tl);
-                            fma4(r2, load4(sg + 3 * SW + j * f), th);
+                            for (int j = 0; j < HLEN; ++j) {
+                                const real_t tl = a.fb.lo[HLEN - 1 - j], th = a.fb.hi[HLEN - 1 - j];
+                                fma4(r1, load4(sg + j * f), tl);
+                                fma4(r1, load4(sg + SW + j * f), th);
+                                fma4(r2, load4(sg + 2 * SW + j * f), tl);
+                                fma4(r2, load4(sg + 3 * SW + j * f), th);
+                            }
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < HLEN; ++j) {
+                                const real_t tl = a.fb.lo[HLEN - 1 - j], th = a.fb.hi[HLEN - 1 - j];
+                                fma4(r1, load4u(sg + j * f), tl);
+                                fma4(r1, load4u(sg + SW + j * f), th);
+                                fma4(r2, load4u(sg + 2 * SW + j * f), tl);
+                                fma4(r2, load4u(sg + 3 * SW + j * f), th);
+                            }
                         }
                     }
                     r1.x *= half; r1.y *= half; r1.z *= half; r1.w *= half;
