@@ -331,6 +331,28 @@ PDWT_DEVICE void swt2_fwd_vec_tile(const Swt2DArgs& a, int bx, int by, int bz, r
     }
 }
 
+// taps of one staged band row at dilation F = 1 or 2 for the four outputs of a lane: ONE window of aligned quads
+// (PADP + 4 + (HLEN - 1) F floats from the lane's quad on) instead of four 4-B reads per tap
+template <int HLEN, int F>
+PDWT_DEVICE void swt_inv_taps_window(const real_t* b, const real_t* taps, rv4& acc) {
+    constexpr int c = HLEN / 2, PADP = (4 - ((c * F) & 3)) & 3;
+    constexpr int NW = (PADP + 4 + (HLEN - 1) * F + 3) / 4;
+    real_t v[4 * NW];
+#pragma unroll
+    for (int q = 0; q < NW; ++q) {
+        const rv4 w = load4(b + 4 * q);
+        v[4 * q] = w.x; v[4 * q + 1] = w.y; v[4 * q + 2] = w.z; v[4 * q + 3] = w.w;
+    }
+#pragma unroll
+    for (int j = 0; j < HLEN; ++j) {
+        const real_t t = taps[HLEN - 1 - j];
+        acc.x = pdwt_fma(v[PADP + j * F], t, acc.x);
+        acc.y = pdwt_fma(v[PADP + j * F + 1], t, acc.y);
+        acc.z = pdwt_fma(v[PADP + j * F + 2], t, acc.z);
+        acc.w = pdwt_fma(v[PADP + j * F + 3], t, acc.w);
+    }
+}
+
 template <int HLEN, int TX, int TY, int NT>
 PDWT_DEVICE void swt2_inv_vec_tile(const Swt2DArgs& a, int bx, int by, int bz, real_t* smem) {
     constexpr int QX = TX / 4, NG = NT / QX, R = TY / NG;
@@ -388,13 +410,17 @@ PDWT_DEVICE void swt2_inv_vec_tile(const Swt2DArgs& a, int bx, int by, int bz, r
                                 fma4(r2, load4(sg + 3 * SW + j * f), th);
                             }
                         } else {
-#pragma unroll
-                            for (int j = 0; j < HLEN; ++j) {
-                                const real_t tl = a.fb.lo[HLEN - 1 - j], th = a.fb.hi[HLEN - 1 - j];
-                                fma4(r1, load4u(sg + j * f), tl);
-                                fma4(r1, load4u(sg + SW + j * f), th);
-                                fma4(r2, load4u(sg + 2 * SW + j * f), tl);
-                                fma4(r2, load4u(sg + 3 * SW + j * f), th);
+                            const real_t* sq = sg - padp;  // the lane's own (aligned) quad of the staged row
+                            if (f == 1) {
+                                swt_inv_taps_window<HLEN, 1>(sq, a.fb.lo, r1);
+                                swt_inv_taps_window<HLEN, 1>(sq + SW, a.fb.hi, r1);
+                                swt_inv_taps_window<HLEN, 1>(sq + 2 * SW, a.fb.lo, r2);
+                                swt_inv_taps_window<HLEN, 1>(sq + 3 * SW, a.fb.hi, r2);
+                            } else {  // f == 2 (3 does not occur: dilations are powers of two)
+                                swt_inv_taps_window<HLEN, 2>(sq, a.fb.lo, r1);
+                                swt_inv_taps_window<HLEN, 2>(sq + SW, a.fb.hi, r1);
+                                swt_inv_taps_window<HLEN, 2>(sq + 2 * SW, a.fb.lo, r2);
+                                swt_inv_taps_window<HLEN, 2>(sq + 3 * SW, a.fb.hi, r2);
                             }
                         }
                     }

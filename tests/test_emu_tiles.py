@@ -117,7 +117,7 @@ def test_emu_dwt1_levels(wname, generic):
 
 
 # ----------------------------------------------------------------------------- SWT tiles
-@pytest.mark.parametrize("wname", ["haar", "db2", "db4", "sym8", "bior3.1"])
+@pytest.mark.parametrize("wname", ["haar", "db2", "db4", "sym8", "bior3.1", "db5", "coif2", "db3"])
 @pytest.mark.parametrize("generic", [0, 1, 2, 3])
 def test_emu_swt2_levels(wname, generic):
     hlen, dlo, dhi, rlo, rhi = oracle.filters(wname)
