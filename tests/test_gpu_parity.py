@@ -367,6 +367,29 @@ def test_three_level_pyramid_on_small_images():
             assert np.abs(img[b] - want).max() <= 2e-6 * (1 + L) * 255.0 * 8, (wname, shape, b)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("wname,shape,levels", [("sym8", (512, 1024), 4), ("db5", (384, 640), 3), ("coif3", (256, 1028), 3),
+                                                ("db10", (512, 512), 2), ("db3", (640, 512), 4)])
+def test_swt_long_filters_staged_inverse(wname, shape, levels):
+    """SWT with filters of 6-20 taps at sizes with whole 128-column tiles, ragged ones and every dilation 1..8: the
+    per-level inverse stages its rows in LDS (aligned taps at dilation 4+, one window per lane at dilation 1 and 2);
+    forward bands, then soft threshold + inverse, against the oracle."""
+    from pypwt_amd import Wavelets
+    x = oracle.hash_input(shape, 99, scale=255.0)
+    w = Wavelets(x, wname, levels, do_swt=1)
+    assert w.levels == levels
+    w.forward()
+    ref = oracle.forward(x, wname, levels, do_swt=1)
+    got = [w.coeffs[0]] + [b for lvl in w.coeffs[1:] for b in lvl]
+    for k, (g, r) in enumerate(zip(got, ref)):
+        assert np.abs(g - r).max() <= 2e-5 * max(float(np.abs(r).max()), 255.0), (wname, k)
+    w.soft_threshold(4.0)
+    w.inverse()
+    thr = oracle.threshold(ref, shape, levels, "soft", 4.0, do_app=0, normalize=0, do_swt=1)
+    want = oracle.inverse(thr, shape, wname, levels, do_swt=1)
+    assert np.abs(w.image - want).max() <= 4e-3, wname
+
+
 # ---------------------------------------------------------------------------------------------
 # fp64 build (libpypwt_amd_f64.so, Wavelets64): the reference's DOUBLEPRECISION variant
 # ---------------------------------------------------------------------------------------------
