@@ -180,6 +180,12 @@ def parse_args(argv=None):
                     help="torch.distributed backend for the barrier / max-over-ranks (nccl = RCCL)")
     ap.add_argument("--dry-run", action="store_true",
                     help="CPU/gloo plumbing test: no GPU work, exercises rendezvous + aggregation only")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise torch.distributed even for WORLD_SIZE = 1 (exercises the RCCL barrier / "
+                         "all-reduce code and torch-HIP next to libpypwt_amd.so on a one-GPU box)")
+    ap.add_argument("--dry-run-barrier-skew-ms", type=float, default=0.0,
+                    help="(dry run, tests) rank r enters the CLOSING barrier r x this many ms late: the reported "
+                         "time must not change, the barrier is outside the timed interval")
     return ap.parse_args(argv)
 
 
@@ -218,7 +224,7 @@ def init_dist(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world == 1:
+    if world == 1 and not args.force_dist:
         return 0, 1, 0, None, None
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29500")
@@ -368,6 +374,26 @@ def timed_steps(step, device_sync, steps):
     return (time.perf_counter() - t0) / steps
 
 
+def timed_region(step, device_sync, steps, dist, backend, before_closing_barrier=None):
+    """The contract's timed region, the SAME code for one rank and for N: barrier + device sync, t0, exactly
+    `steps` steps, device sync, t1, then the closing barrier + device sync.  Every rank's clock stops at t1,
+    BEFORE the closing barrier: that barrier (an RCCL all-reduce kernel + a host sync, 50-100 us) only lines the
+    ranks up again and is not part of anybody's interval, so the N = 1 and N > 1 figures are the same
+    measurement.  Returns the max over ranks of t1 - t0 in seconds."""
+    barrier(dist, backend)
+    device_sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    device_sync()
+    elapsed = time.perf_counter() - t0
+    if before_closing_barrier is not None:
+        before_closing_barrier()
+    barrier(dist, backend)
+    device_sync()
+    return max_over_ranks(elapsed, dist, backend)
+
+
 def beyond_mall(cfg, device, steps):
     """The same step with 16 images per launch (2.4 GiB of plan, far beyond the 256 MiB Infinity Cache): what the
     chip sustains from HBM rather than from its last-level cache."""
@@ -397,12 +423,8 @@ def dry_run(args, rank, world, dist, backend):
     with gloo on CPU."""
     cfg = CONFIGS[args.config]
     B, first, total = rank_batch(args, world, rank)
-    barrier(dist, backend)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        time.sleep(0.001 * (1 + rank))
-    dt = max_over_ranks(time.perf_counter() - t0, dist, backend)
-    barrier(dist, backend)
+    dt = timed_region(lambda: time.sleep(0.001 * (1 + rank)), lambda: None, args.steps, dist, backend,
+                      before_closing_barrier=lambda: time.sleep(1e-3 * rank * args.dry_run_barrier_skew_ms))
     if rank == 0:
         samples = total * cfg[0] * cfg[1]
         print(json.dumps({"metric": "dry_run", "value": samples / (dt / args.steps) / 1e6, "unit": "Msamples/s",
@@ -410,7 +432,7 @@ def dry_run(args, rank, world, dist, backend):
                           "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
                           "vs_baseline": None, "dtype": "f32", "data": "none (dry run)",
                           "config": {"workload": "dry-run", "shard_rank0": [first, first + B],
-                                     "images_per_step": total}}))
+                                     "images_per_step": total, "timed_region_ms": dt * 1e3}}))
 
 
 def main():
@@ -465,15 +487,7 @@ def main():
     for _ in range(args.warmup):
         step()
     device_sync()
-    barrier(dist, backend)
-    device_sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    device_sync()
-    barrier(dist, backend)
-    device_sync()
-    dt = max_over_ranks(time.perf_counter() - t0, dist, backend)
+    dt = timed_region(step, device_sync, args.steps, dist, backend)
     cold_s = max_over_ranks(cold_s, dist, backend)
 
     step_s = dt / args.steps
@@ -556,12 +570,19 @@ def main():
         "dtype": "f32", "data": "synthetic (on-device index hash, 0..255)",
         "config": {"workload": "%s: %s" % (workload, desc), "batch_per_gpu": B, "images_per_step": total_images,
                    "wavelet": wname, "levels": L, "shape": [Nr, Nc],
-                   "parallelism": "image-sharded x%d, no collectives" % world, "preheat_ms": args.preheat_ms},
+                   "parallelism": "image-sharded x%d, no collectives" % world, "preheat_ms": args.preheat_ms,
+                   "timed_region_ms": dt * 1e3},
         "roofline": roofline, "end_to_end": e2e, "kernels": kernels[:12],
     }
-    if world > 1:
-        out["config"]["multi_gpu_note"] = "measured on this node's GPUs; one process per GPU, barrier + max over ranks via RCCL"
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if dist is not None:
+        out["config"]["multi_gpu_note"] = ("one process per GPU; barrier (%s) before t0 and after t1, value = all ranks' "
+                                           "samples / max over ranks of (t1 - t0)" % backend)
+        if dt * 1e3 < 20.0:
+            out["config"]["timed_region_warning"] = (
+                "the timed region is %.2f ms: rank-to-rank start skew after the barrier (tens of us) is a visible "
+                "share of it; use --steps >= %d or --config cfg5 (128 images per GPU and step) for a scaling figure"
+                % (dt * 1e3, int(20.0 / (step_s * 1e3)) + 1))
+    if rank == 0 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg)
     if rank == 0 and world == 1 and not args.no_extras:
         extra = {}

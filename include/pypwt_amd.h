@@ -164,6 +164,19 @@ int pdwt_synchronize(pdwt_handle h);
 int pdwt_set_stream(pdwt_handle h, void* hip_stream); /* borrow a caller stream (e.g. torch's) */
 void* pdwt_get_stream(pdwt_handle h);
 int pdwt_device(pdwt_handle h);
+/* Ordering a DEVICE-memory source with the code that produced it (the reference runs everything on the legacy
+ * default stream, so its cudaMemcpy DtoD in wt.cu:117-126,425-466 is ordered for free; a plan here owns a
+ * non-blocking stream).  pdwt_set_image / pdwt_set_coeff with mem_is_on_device = 1 and pdwt_create with
+ * mem_is_on_host = 0 copy on the plan's stream and return when the copy has finished (the source may then be
+ * reused or freed); what they cannot know is which stream WROTE the source:
+ *   pdwt_wait_for_stream(h, s)   everything submitted to the plan's stream from now on starts after the work
+ *                                already submitted to stream s (NULL = the legacy default stream): an event
+ *                                recorded on s and waited for on the plan's stream, the host does not block;
+ *   pdwt_sync_producer(dev, s, whole_device)   host-blocking form for use before a plan exists:
+ *                                hipStreamSynchronize(s), or hipDeviceSynchronize() when whole_device != 0
+ *                                (the producer's stream is unknown: a __cuda_array_interface__ without "stream"). */
+int pdwt_wait_for_stream(pdwt_handle h, void* producer_stream);
+int pdwt_sync_producer(int device_id, void* producer_stream, int whole_device);
 /* fill the plan image on the device with the deterministic test input
  * x[i] = (lowbias32((i + index_offset) ^ seed) >> 8) * 2^-24 * scale (tests/golden, oracle, bench) */
 int pdwt_fill_image_hash(pdwt_handle h, uint32_t seed, pdwt_real scale, long long index_offset);

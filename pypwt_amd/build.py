@@ -65,13 +65,26 @@ def _deps_mtime():
     return latest
 
 
+def _obj_deps_mtime(depfile):
+    """Newest mtime among the files a make-style dependency file lists (None: unreadable -> rebuild)."""
+    try:
+        txt = open(depfile).read().replace("\\\n", " ")
+        files = txt.split(":", 1)[1].split()
+        return max(os.path.getmtime(f) for f in files)
+    except Exception:
+        return None
+
+
 def _compile(job):
     src, objdir, extra = job
     obj = os.path.join(objdir, src.rsplit(".", 1)[0] + ".o")
+    dep = obj[:-2] + ".d"
     path = os.path.join(CSRC, src)
-    if os.path.exists(obj) and os.path.getmtime(obj) >= _deps_mtime():
-        return obj
-    cmd = [hipcc()] + FLAGS + extra + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", path, "-o", obj]
+    if os.path.exists(obj):  # rebuilt only when a file THIS translation unit includes has changed (-MMD)
+        newest = _obj_deps_mtime(dep)
+        if newest is not None and os.path.getmtime(obj) >= newest and os.path.getmtime(obj) >= os.path.getmtime(__file__):
+            return obj
+    cmd = [hipcc()] + FLAGS + extra + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-MMD", "-MF", dep, "-c", path, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed on %s:\n%s" % (src, r.stderr[-4000:]))

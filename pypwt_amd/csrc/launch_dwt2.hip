@@ -97,10 +97,10 @@ static std::atomic<int>& swt_fused_flag() {
 int set_swt_fused_enabled(int value) { return swt_fused_flag().exchange(value < 0 ? 0 : (value > 2 ? 2 : value)); }
 int get_swt_fused_enabled() { return swt_fused_flag().load(std::memory_order_relaxed); }
 static std::atomic<int>& reg1d_flag() {
-    static std::atomic<int> v{getenv("PDWT_REG1D") ? atoi(getenv("PDWT_REG1D")) : 3};
+    static std::atomic<int> v{getenv("PDWT_REG1D") ? (atoi(getenv("PDWT_REG1D")) & 7) : 3};
     return v;
 }
-int set_reg1d_enabled(int value) { return reg1d_flag().exchange(value); }
+int set_reg1d_enabled(int value) { return reg1d_flag().exchange(value < 0 ? 0 : (value > 7 ? 7 : value)); }  // three flag bits
 int get_reg1d_enabled() { return reg1d_flag().load(std::memory_order_relaxed); }
 int set_wave2_enabled(int value) { return wave2_flag().exchange(value ? 1 : 0); }
 int get_wave2_enabled() { return wave2_flag().load(std::memory_order_relaxed); }

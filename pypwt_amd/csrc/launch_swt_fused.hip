@@ -79,8 +79,8 @@ static hipError_t run(SwtFusedArgs& a, bool inverse, int batch, hipStream_t s) {
 // in / out: the approximation planes on either side of the group; det[3 k + {0,1,2}] = H, V, D of level l0 + k;
 // beta[k]: soft threshold the inverse applies to level l0 + k's details as it loads them (nullptr: none)
 hipError_t launch_swt2_fused(const real_t* in, real_t* out, real_t* const* det, int Nr, int Nc, int l0, int K, bool inverse,
-                             const FilterBank& fb, const real_t* beta, int batch, hipStream_t s) {
-    if (!swt2_fused_supported(2, Nr, Nc, l0, K)) return hipErrorNotSupported;
+                             int hlen, const FilterBank& fb, const real_t* beta, int batch, hipStream_t s) {
+    if (!swt2_fused_supported(hlen, Nr, Nc, l0, K)) return hipErrorNotSupported;  // a stale schedule falls back, never truncates taps
     SwtFusedArgs a;
     a.in = in; a.out = out; a.Nr = Nr; a.Nc = Nc; a.bstride = (long long)Nr * Nc;
     for (int k = 0; k < kSwtFusedMaxLevels; k++) {

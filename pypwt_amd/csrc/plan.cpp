@@ -652,7 +652,7 @@ int forward_impl(pdwt_plan* p, int only = 0) {
             Stamp st(p, "swt2_fwd_fused");
             if (!run) continue;
             e = launch_swt2_fused(approx_slot(p, l - 1), approx_slot(p, l + s.K - 1), det, p->info.Nr, p->info.Nc, l, s.K, false,
-                                  p->dec, nullptr, B, p->stream);
+                                  p->info.hlen, p->dec, nullptr, B, p->stream);
         } else if (s.kind == Step::REG1D) {
             real_t* det[kMaxFusedLevelsHost] = {};
             for (int k = 0; k < s.K; k++) det[k] = p->band(l + k);
@@ -711,7 +711,7 @@ int inverse_impl(pdwt_plan* p, int only = 0) {
             Stamp st(p, p->pend_soft ? "swt2_inv_fused+soft" : "swt2_inv_fused");
             if (!run) continue;
             e = launch_swt2_fused(approx_slot(p, l + s.K - 1), approx_slot(p, l - 1), det, p->info.Nr, p->info.Nc, l, s.K, true,
-                                  p->rec, beta, B, p->stream);
+                                  p->info.hlen, p->rec, beta, B, p->stream);
         } else if (s.kind == Step::REG1D) {
             const real_t* det[kMaxFusedLevelsHost] = {};
             for (int k = 0; k < s.K; k++) det[k] = p->band(l + k);
@@ -789,7 +789,8 @@ int materialize_consumed(pdwt_plan* p) {
 
 // can the inverse of this plan apply a soft threshold on the fly?  (fused 2D SWT kernels on every level)
 bool can_defer_soft(const pdwt_plan* p) {
-    if (!p->info.do_swt || p->info.ndims != 2 || !p->do_separable || getenv("PDWT_NO_LAZY_THRESHOLD")) return false;
+    static const bool no_lazy = getenv("PDWT_NO_LAZY_THRESHOLD") != nullptr;  // read once, like every other knob
+    if (!p->info.do_swt || p->info.ndims != 2 || !p->do_separable || no_lazy) return false;
     return p->info.Nr % (1 << (p->info.nlevels - 1)) == 0;
 }
 
@@ -883,7 +884,10 @@ int pdwt_clone(pdwt_handle src, pdwt_handle* out) {
     *out = nullptr;
     DeviceGuard guard(src->device);
     {
-        const int rc0 = materialize_pending(src);
+        // the copy must not depend on whether the source took the fused path: a deferred threshold is applied and one
+        // that the fused inverse consumed on the fly is written back before the arena is copied
+        int rc0 = materialize_pending(src);
+        if (rc0 == PDWT_OK) rc0 = materialize_consumed(src);
         if (rc0 != PDWT_OK) return rc0;
     }
     pdwt_plan* p = new pdwt_plan();
@@ -1193,7 +1197,16 @@ int pdwt_set_image(pdwt_handle h, const real_t* src, int mem_is_on_device) {  //
     const long long n = (long long)h->batch * h->info.Nr * h->info.Nc;
     HIP_TRY(hipMemcpyAsync(h->image(), src, (size_t)n * sizeof(real_t),
                            mem_is_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, h->stream));
-    if (!mem_is_on_device) HIP_TRY(hipStreamSynchronize(h->stream));  // the host buffer may be reused
+    // host AND device sources: the copy has completed when the call returns, so the caller may reuse or free the
+    // source at once (a torch temporary goes back to the caching allocator as soon as the Python call returns).
+    // Ordering of the source's PRODUCER with this copy is the caller's: pdwt_wait_for_stream / pdwt_sync_producer.
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    // a threshold the fused inverse applied on the fly is written back before the state leaves PDWT_INVERSE:
+    // get_coeff / norms / add_wavelet are legal again after set_image and must see thresholded details (wt.cu:308-315)
+    {
+        const int rc0 = materialize_consumed(h);
+        if (rc0 != PDWT_OK) return rc0;
+    }
     h->state = PDWT_INIT;
     return PDWT_OK;
 }
@@ -1211,7 +1224,7 @@ int pdwt_set_coeff(pdwt_handle h, const real_t* src, int num, int mem_is_on_devi
     const long long n = h->bands[num].elems(h->batch);
     HIP_TRY(hipMemcpyAsync(h->band(num), src, (size_t)n * sizeof(real_t),
                            mem_is_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, h->stream));
-    if (!mem_is_on_device) HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));  // see pdwt_set_image
     // The reference forbids coefficient access after inverse() because its inverse overwrites the
     // approximation band d_coeffs[0] (wt.cu:272-275); once the caller has supplied that band again the
     // coefficients are current, so a new inverse() is meaningful (the reference would still refuse it).
@@ -1397,6 +1410,31 @@ int pdwt_time_level(pdwt_handle h, int level, int inverse, int reps, float* ms_p
     HIP_TRY(hipEventElapsedTime(&ms, sc.e0, sc.e1));
     *ms_per_launch = ms / (float)reps;
     return rc;
+}
+
+int pdwt_wait_for_stream(pdwt_handle h, void* producer_stream) {
+    CHECK_HANDLE(h);
+    DeviceGuard guard(h->device);
+    hipStream_t prod = (hipStream_t)producer_stream;
+    if (prod == h->stream) return PDWT_OK;  // same queue: already ordered
+    hipEvent_t ev;
+    HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    hipError_t e = hipEventRecord(ev, prod);
+    if (e == hipSuccess) e = hipStreamWaitEvent(h->stream, ev, 0);
+    (void)hipEventDestroy(ev);  // destruction is deferred until the event has completed
+    if (e != hipSuccess) return fail(PDWT_ERR_HIP, "pdwt_wait_for_stream: %s", hipGetErrorString(e));
+    return PDWT_OK;
+}
+
+int pdwt_sync_producer(int device_id, void* producer_stream, int whole_device) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(PDWT_ERR_HIP, "no HIP device available");
+    if (device_id < 0 && hipGetDevice(&device_id) != hipSuccess) return fail(PDWT_ERR_HIP, "hipGetDevice failed");  // -1: the current device
+    if (device_id >= ndev) return fail(PDWT_ERR_ARG, "device %d out of range (%d devices)", device_id, ndev);
+    DeviceGuard guard(device_id);
+    hipError_t e = whole_device ? hipDeviceSynchronize() : hipStreamSynchronize((hipStream_t)producer_stream);
+    if (e != hipSuccess) return fail(PDWT_ERR_HIP, "pdwt_sync_producer: %s", hipGetErrorString(e));
+    return PDWT_OK;
 }
 
 int pdwt_set_tuning(const char* key, int value) {

@@ -43,7 +43,19 @@ def _device_array(obj, dtype):
             acc *= n
         if tuple(strides) != tuple(reversed(expect)):
             raise ValueError("device array must be C-contiguous")
-    return int(iface["data"][0]), shape
+    # CUDA Array Interface v3 consumer rule: the producer's stream, on which the data is (or will be) valid.
+    #   key absent (v2 producers, e.g. torch tensors): unknown -> the consumer synchronises the device
+    #   None: no synchronisation needed;  1: legacy default stream;  2: per-thread default stream;  else: a handle
+    if "stream" not in iface:
+        order = ("device",)
+    elif iface["stream"] is None:
+        order = ()
+    else:
+        st = int(iface["stream"])
+        if st == 0:
+            raise ValueError("__cuda_array_interface__: stream 0 is not allowed (1 = legacy default, 2 = per-thread default)")
+        order = ("stream", {1: 0, 2: 2}.get(st, st))  # hipStreamLegacy = 0 (NULL), hipStreamPerThread = 2
+    return int(iface["data"][0]), shape, order
 
 
 class _Shape(object):
@@ -134,6 +146,9 @@ class Wavelets(object):
         self.ndim = img.ndim
 
         h = handle_t()
+        if dev is not None and dev[2]:  # no plan (and no plan stream) yet: wait on the host for the image's producer
+            self._check(self._lib.pdwt_sync_producer(-1, C.c_void_p(dev[2][1] if dev[2][0] == "stream" else 0),
+                                                     1 if dev[2][0] == "device" else 0), "Wavelets()")
         src = self._fptr(img) if dev is None else C.cast(C.c_void_p(dev[0]), C.POINTER(self._lib.pdwt_real))
         rc = self._lib.pdwt_create(src, self.Nr, self.Nc, self._wname, self.levels, 1 if dev is None else 0,
                                    self.do_separable, self.do_cycle_spinning, self.do_swt, ndim, C.byref(h))
@@ -243,11 +258,22 @@ class Wavelets(object):
                                "got %d (%s)" % (res.size, numc, _lib.last_error(self._lib)))
         return res
 
+    def _order_after_producer(self, dev):
+        """The copy of a device array runs on the plan's own (non-blocking) stream: order it after the array's
+        producer first (an event wait when the producer's stream is known, a device synchronisation when it is not)."""
+        if not dev[2]:
+            return
+        if dev[2][0] == "stream":
+            self._check(self._lib.pdwt_wait_for_stream(self._h, C.c_void_p(dev[2][1])))
+        else:
+            self._check(self._lib.pdwt_sync_producer(self._lib.pdwt_device(self._h), None, 1))
+
     def _set_image_any(self, img, shp):
         dev = _device_array(img, self._dtype)
         if dev is not None:  # device-to-device (pdwt_set_image with mem_is_on_device = 1, wt.cu:425-431)
             if int(np.prod(dev[1])) != self.Nr * self.Nc:
                 raise ValueError("The image does not have the correct shape (expected %s, got %s)" % (str(shp), str(dev[1])))
+            self._order_after_producer(dev)
             self._check(self._lib.pdwt_set_image(self._h, C.c_void_p(dev[0]), 1))
             return
         img = self._checkarray(np.asarray(img), shp)
@@ -339,6 +365,7 @@ class Wavelets(object):
             n = self._check(int(self._lib.pdwt_coeff_count(self._h, int(num), None, None)))
             if int(np.prod(dev[1])) != n:
                 raise ValueError("set_coeff: expected %d elements for coefficient %d, got %d" % (n, num, int(np.prod(dev[1]))))
+            self._order_after_producer(dev)
             self._check(self._lib.pdwt_set_coeff(self._h, C.c_void_p(dev[0]), int(num), 1))
             return
         coeff = self._checkarray(np.asarray(coeff))

@@ -106,3 +106,23 @@ def test_world_size_mismatch_is_reported_even_for_one_rank():
                        text=True, cwd=ROOT, env=env, timeout=120)
     assert r.returncode == 0 and "--gpus 8 but WORLD_SIZE 1" in r.stderr
     assert json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])["n_gpus"] == 1
+
+
+def test_closing_barrier_is_outside_the_timed_interval():
+    """Every rank stops its clock BEFORE the closing barrier: rank 1 entering that barrier 300 ms late must not
+    show up in the reported time (4 steps of 2 ms on the slower rank)."""
+    out = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                "--master-addr", "127.0.0.1", "--master-port", "29534", "bench.py", "--gpus", "2",
+                "--steps", "4", "--warmup", "1", "--dry-run", "--dry-run-barrier-skew-ms", "300"])
+    assert out["n_gpus"] == 2
+    assert 1.9 <= out["ms_per_step"] < 20.0, out  # 2 ms per step on rank 1; 300 ms / 4 steps would read 77 ms
+    assert abs(out["config"]["timed_region_ms"] - 4 * out["ms_per_step"]) < 1e-6
+
+
+def test_force_dist_runs_the_collective_code_with_one_rank():
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29535")
+    r = subprocess.run([sys.executable, "bench.py", "--steps", "2", "--dry-run", "--force-dist"], capture_output=True,
+                       text=True, cwd=ROOT, env=env, timeout=240)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert out["n_gpus"] == 1 and out["ms_per_step"] >= 0.9

@@ -687,3 +687,116 @@ print("TORCH_OK")
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0, r.stderr[-3000:]
     assert "TORCH_OK" in r.stdout or "SKIP" in r.stdout, r.stdout
+
+
+@pytest.mark.gpu
+def test_device_sources_are_ordered_after_their_producer_stream():
+    """A device array whose producing kernels are still running on ANOTHER stream (CUDA Array Interface v3 `stream`):
+    the plan's private non-blocking stream must wait for it before it copies (constructor, set_image, set_coeff), and the
+    copy must be complete when the call returns -- the source is freed / overwritten right afterwards.  Also a v2
+    producer (no `stream` key: torch tensors) written on a side stream: the consumer synchronises the device."""
+    import subprocess
+    import sys
+    code = r"""
+import sys
+try:
+    import torch
+    assert torch.cuda.is_available()
+except Exception as e:
+    print("SKIP", e); sys.exit(0)
+import numpy as np
+from pypwt_amd import Wavelets
+
+class V3(object):  # a CUDA-array-interface v3 view of a tensor with its producer stream
+    def __init__(self, t, stream):
+        self.t = t
+        self.__cuda_array_interface__ = {"shape": tuple(t.shape), "typestr": "<f4", "data": (t.data_ptr(), False),
+                                         "version": 3, "strides": None, "stream": stream}
+
+side = torch.cuda.Stream()
+n = 1024
+def slow_producer(value):
+    # ~tens of ms of queued work on `side`, then the fill the consumer must see
+    with torch.cuda.stream(side):
+        a = torch.ones(4096, 4096, device="cuda")
+        for _ in range(40):
+            a = (a @ a) * 1e-4
+        out = torch.zeros(n, n, device="cuda")
+        out += value + 0 * a[0, 0]
+    return out
+
+# constructor
+t = slow_producer(3.0)
+w = Wavelets(V3(t, side.cuda_stream), "haar", 1)
+assert np.all(w.image == 3.0), "constructor copied before the producer stream had finished"
+# set_image, then the source is overwritten at once on the SAME side stream (write-after-read)
+t = slow_producer(5.0)
+w.set_image(V3(t, side.cuda_stream))
+with torch.cuda.stream(side):
+    t.fill_(-1.0)
+assert np.all(w.image == 5.0), "set_image raced with its producer / the source's reuse"
+# set_coeff
+w.forward()
+c = slow_producer(7.0)[: n // 2, : n // 2].contiguous()
+side.synchronize()
+c2 = None
+with torch.cuda.stream(side):
+    big = torch.ones(4096, 4096, device="cuda")
+    for _ in range(40):
+        big = (big @ big) * 1e-4
+    c2 = c * 2 + 0 * big[: n // 2, : n // 2]
+w.set_coeff(V3(c2, side.cuda_stream), 1)
+del c2
+assert np.all(w.coeffs[1][0] == 14.0), "set_coeff raced with its producer"
+# a v2 producer (torch's own __cuda_array_interface__ has no stream key) written on the side stream
+t = slow_producer(9.0)
+w.set_image(t)
+assert np.all(w.image == 9.0), "v2 device array: the consumer must synchronise the device"
+print("ORDER_OK")
+"""
+    import os
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    assert "ORDER_OK" in r.stdout or "SKIP" in r.stdout, r.stdout
+
+
+@pytest.mark.gpu
+def test_consumed_threshold_is_written_back_for_clone_and_set_image(W):
+    """A soft threshold the fused SWT inverse applied on the fly never reached the stored details; a clone of that plan
+    and the coefficient readers that are legal again after set_image must see thresholded details (pdwt/src/wt.cu:308-315
+    thresholds the stored coefficients), whether or not the fused path was taken."""
+    import ctypes as C
+    from pypwt_amd import _lib
+    lib = _lib.load()
+    x = oracle.hash_input((64, 256), 77)
+    ref = oracle.threshold(oracle.forward(x, "haar", 3, do_swt=1), x.shape, 3, "soft", 20.0, do_swt=1)
+    want = oracle.inverse(ref, x.shape, "haar", 3, do_swt=1)
+
+    def tol(r):
+        return 2e-5 * max(np.abs(r).max(), 255.0)
+
+    w = W(x, "haar", 3, do_swt=1)
+    w.forward()
+    w.soft_threshold(20.0)
+    w.inverse()                      # the fused inverse consumes the deferred threshold on the fly
+    assert np.abs(w.image - want).max() <= tol(want)
+    # clone while the write-back is still owed: re-arm the clone's inverse with the approximation band
+    h2 = _lib.handle_t()
+    assert lib.pdwt_clone(w._h, C.byref(h2)) == 0
+    a0 = np.ascontiguousarray(ref[0])
+    assert lib.pdwt_set_coeff(h2, a0.ctypes.data, 0, 0) == 0
+    for num in range(1, 10):
+        g = np.zeros(x.shape, dtype=np.float32)
+        assert lib.pdwt_get_coeff(h2, g.ctypes.data, num) == g.size
+        assert np.abs(g - ref[num]).max() <= tol(ref[num]), "clone holds un-thresholded details (band %d)" % num
+    assert lib.pdwt_inverse(h2) == 0
+    rec = np.zeros(x.shape, dtype=np.float32)
+    assert lib.pdwt_get_image(h2, rec.ctypes.data) == rec.size
+    assert np.abs(rec - want).max() <= tol(want)
+    assert lib.pdwt_destroy(h2) == 0
+    # set_image moves the state INVERSE -> INIT: the coefficient readers are legal again and must see the thresholded details
+    w.set_image(x)
+    for num in range(1, 10):
+        g = w.coeff_only(num)
+        assert np.abs(g - ref[num]).max() <= tol(ref[num]), "band %d read after set_image is not thresholded" % num
