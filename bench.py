@@ -93,6 +93,9 @@ def kernel_algorithmic_bytes(label, cfg, batch):
         # two levels in one launch: the pair's input read once, details of the first and all four bands
         # of the second level written once = 8 B per sample entering the pair
         return 8.0 * samples / (4 ** (lvl - 1))
+    if name in ("dwt2_fwd_chain", "dwt2_inv_chain"):  # K levels in one launch with in-launch hand-offs: the group's input
+        # and final coefficients once = 8 B per sample entering it (the A_l hand-offs inside are not algorithmic bytes)
+        return 8.0 * samples / (4 ** (lvl - 1))
     if name in ("dwt2_fwd_pyr3", "dwt2_inv_pyr3"):  # three levels in one launch: 8 B per sample entering the group
         return 8.0 * samples / (4 ** (lvl - 1))
     if name.startswith("dwt2"):
@@ -112,7 +115,12 @@ def kernel_algorithmic_bytes(label, cfg, batch):
     return 0.0
 
 
-def label_step_kernels(names, L):
+def chain_end(first, L, chain_levels=None):
+    """Last level of a chain launch that starts at level `first` (chain_levels = K when known, else everything left)."""
+    return min(L, first + (chain_levels if chain_levels else L) - 1)
+
+
+def label_step_kernels(names, L, chain_levels=None):
     """Launch names of ONE step, in order -> labels 'name[Ll]' with l = the (first) transform level the
     launch works on.  Forward launches count levels up from 1, inverse launches down from L; a pyramid
     launch covers two levels, a fused 1D launch all remaining ones."""
@@ -126,6 +134,8 @@ def label_step_kernels(names, L):
             out.append("%s[L%d]" % (n, f)); f += 2
         elif base == "dwt2_fwd_pyr3":
             out.append("%s[L%d]" % (n, f)); f += 3
+        elif base == "dwt2_fwd_chain":  # levels f .. min(L, f + 5) whose tiles are whole (plan.cpp: chain_at); all of cfg2's
+            out.append("%s[L%d]" % (n, f)); f = chain_end(f, L, chain_levels) + 1
         elif base == "dwt1_fwd_fused":
             out.append("%s[L%d]" % (n, f)); f = L + 1
         elif base == "swt2_fwd_fused":  # levels 1-3 / 4-6 of a 2-tap SWT in one launch (two levels when only two are left)
@@ -138,6 +148,8 @@ def label_step_kernels(names, L):
             out.append("%s[L%d]" % (n, i - 1)); i -= 2
         elif base == "dwt2_inv_pyr3":
             out.append("%s[L%d]" % (n, i - 2)); i -= 3
+        elif base == "dwt2_inv_chain":  # always starts at level 1
+            out.append("%s[L%d]" % (n, 1)); i = 0
         elif base == "dwt1_inv_fused":
             out.append("%s[L%d]" % (n, 1)); i = 0
         elif base == "swt2_inv_fused":  # groups start at levels 1 and 4

@@ -208,6 +208,13 @@ int pdwt_time_level(pdwt_handle h, int level, int inverse, int reps, float* ms_p
  *                    Infinity Cache (<= 320 MiB) run levels 1-3 and 4-6 in one launch each (swt2_fused_kernels.hpp:
  *                    11 / 8 instead of 15 / 10 planes of traffic); 2: at any size; 0: a launch per level.  Read when
  *                    a plan is created.
+ *   "chain"          levels 1..K of a 2D DWT in ONE launch with in-launch hand-offs between the levels
+ *                    (dwt2_chain_kernels.hpp; even filters of at most 8 taps, whole 16 x 128 tiles at every level):
+ *                    1 (default): one cache-resident image (2^22 < samples <= 2^24) in both directions and the inverse of
+ *                    batches of >= 2^26 samples; 2: wherever the kernel applies; 3: 2 and the forward of such batches too;
+ *                    0: never.  Read when a plan is created.
+ *   "chain_timeout"  ticks of the 100 MHz s_memrealtime counter a chained tile waits for a producer tile before it
+ *                    computes that producer itself (default 3000 = 30 us; 0 makes nearly every wait take that path: tests)
  *   "wave2"          1: eligible forward level pairs run as ONE two-level wave launch (default 0: measured
  *                    slower than two launches on MI355X, kept for tests and re-measurement) */
 int pdwt_set_tuning(const char* key, int value);

@@ -24,7 +24,7 @@ LIB_F64 = os.path.join(HERE, "libpypwt_amd_f64.so")
 VARIANTS = {
     "f32": (OBJ, LIB, [], ()),
     "f64": (os.path.join(ROOT, "build", "obj_f64"), LIB_F64, ["-DPDWT_DOUBLE"],
-            ("launch_dwt2_fast.hip", "launch_dwt2_pyramid.hip", "launch_dwt1_fused.hip")),
+            ("launch_dwt2_fast.hip", "launch_dwt2_pyramid.hip", "launch_dwt1_fused.hip", "launch_dwt2_chain.hip")),
 }
 
 SOURCES = [
@@ -32,6 +32,7 @@ SOURCES = [
     "launch_dwt2_fast.hip",
     "launch_dwt2_pyramid.hip",
     "launch_dwt2_pyr3.hip",
+    "launch_dwt2_chain.hip",
     "launch_dwt2_wave.hip",
     "launch_dwt1.hip",
     "launch_dwt1_fused.hip",

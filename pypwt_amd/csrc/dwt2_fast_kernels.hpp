@@ -106,8 +106,11 @@ PDWT_DEVICE void fwd_fast_row_pass(int tid, const float* sIn, v2f* tLH, const Fi
 
 // column analysis; (L,H) pair x tap -> (A,V) with lo, (H,D) with hi.  Each thread owns two adjacent
 // columns (one ds_read_b128 per staged row, 8-B stores).
+// coh_out (uniform): the A band has a consumer in this launch (dwt2_chain_kernels.hpp) -- written with 16-B sc1 stores,
+// an even lane taking its odd neighbour's column pair (8-B sc1 stores cost 2.7x per byte, MI355X_MICROARCH.md)
 template <int HLEN, int TX, int TY, int NT>
-PDWT_DEVICE void fwd_fast_col_pass(int tid, const v2f* tLH, const Fwd2DFastArgs& a, int bx, int by, int bz) {
+PDWT_DEVICE void fwd_fast_col_pass(int tid, const v2f* tLH, const Fwd2DFastArgs& a, int bx, int by, int bz,
+                                   bool coh_out = false) {
     constexpr int HT = TX / 2;
     constexpr int R = TY / (NT / HT);
     const int t = tid % HT;
@@ -144,6 +147,25 @@ PDWT_DEVICE void fwd_fast_col_pass(int tid, const v2f* tLH, const Fwd2DFastArgs&
         }
     }
     const long long boff = (long long)bz * a.out_bstride;
+#if !defined(PDWT_CPU_EMU)
+    if (coh_out) {  // the host guarantees whole tiles and Nc2 % 4 == 0 on this path
+        const CohPlane pa = coh_plane(a.A + boff);
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            const int oy = by * TY + ty0 + i;
+            const long long o = (long long)oy * a.Nc2 + ox;
+            f32x4 q;
+            q.x = accAV[i][0].x; q.y = accAV[i][1].x;
+            q.z = __shfl_xor(accAV[i][0].x, 1); q.w = __shfl_xor(accAV[i][1].x, 1);
+            if (!(tid & 1)) coh_store16(pa, o, q);
+            f32x2 v;
+            v.x = accAV[i][0].y; v.y = accAV[i][1].y; *reinterpret_cast<f32x2*>(a.V + boff + o) = v;
+            v.x = accHD[i][0].x; v.y = accHD[i][1].x; *reinterpret_cast<f32x2*>(a.H + boff + o) = v;
+            v.x = accHD[i][0].y; v.y = accHD[i][1].y; *reinterpret_cast<f32x2*>(a.D + boff + o) = v;
+        }
+        return;
+    }
+#endif
 #pragma unroll
     for (int i = 0; i < R; ++i) {
         const int oy = by * TY + ty0 + i;
@@ -159,8 +181,11 @@ PDWT_DEVICE void fwd_fast_col_pass(int tid, const v2f* tLH, const Fwd2DFastArgs&
 }
 
 // Requirements (checked by the host): HLEN even, Nc % 4 == 0, 16-B aligned image rows.
+// coh_in / coh_out (uniform, dwt2_chain_kernels.hpp): the input plane was written by other workgroups of THIS launch
+// (sc1 loads; needs the branch-free staging conditions) / the A band is read by other workgroups of this launch.
 template <int HLEN, int TX, int TY, int NT>
-PDWT_DEVICE void dwt2_fwd_fast_tile(const Fwd2DFastArgs& a, int bx, int by, int bz, float* smem) {
+PDWT_DEVICE void dwt2_fwd_fast_tile(const Fwd2DFastArgs& a, int bx, int by, int bz, float* smem, bool coh_in = false,
+                                    bool coh_out = false) {
     using G = FwdFastGeom<HLEN, TX>;
     constexpr int C = G::C, PADL = G::PADL, RXA = G::RXA, NV = G::NV;
     constexpr int RY = 2 * TY + HLEN - 2;
@@ -185,7 +210,21 @@ PDWT_DEVICE void dwt2_fwd_fast_tile(const Fwd2DFastArgs& a, int bx, int by, int 
     // loads are all in flight together (a loop with an exit test per trip waits for every load before the next).
     PDWT_FOR_THREADS(tid, NT) {
         constexpr int TOTAL = RY * V4, TRIPS = (TOTAL + NT - 1) / NT;
-        if (!(a.Nr & 1) && a.Nr >= RY && a.Nc >= RXA) {
+        if (coh_in) {
+            const CohPlane pin = coh_plane(in);
+#pragma unroll
+            for (int t = 0; t < TRIPS; ++t) {
+                int idx = tid + t * NT;
+                idx = idx < TOTAL ? idx : TOTAL - 1;
+                const int r = idx / V4;
+                const int g = idx - r * V4;
+                int sy = y0 + r, sx = xa + 4 * g;
+                sy = sy < 0 ? sy + a.Nr : (sy >= a.Nr ? sy - a.Nr : sy);
+                sx = sx < 0 ? sx + a.Nc : (sx >= a.Nc ? sx - a.Nc : sx);
+                const f32x4 v = coh_load16(pin, (long long)sy * a.Nc + sx);
+                *reinterpret_cast<f32x4*>(sIn + r * RXA + 4 * g) = v;
+            }
+        } else if (!(a.Nr & 1) && a.Nr >= RY && a.Nc >= RXA) {
 #pragma unroll
             for (int t = 0; t < TRIPS; ++t) {
                 int idx = tid + t * NT;
@@ -216,7 +255,7 @@ PDWT_DEVICE void dwt2_fwd_fast_tile(const Fwd2DFastArgs& a, int bx, int by, int 
     PDWT_SYNC();
 
     // ---- phase 3: column analysis -> A, H, V, D
-    PDWT_FOR_THREADS(tid, NT) { fwd_fast_col_pass<HLEN, TX, TY, NT>(tid, tLH, a, bx, by, bz); }
+    PDWT_FOR_THREADS(tid, NT) { fwd_fast_col_pass<HLEN, TX, TY, NT>(tid, tLH, a, bx, by, bz, coh_out); }
 }
 
 // Streaming variant: a workgroup walks over several tiles of its XCD's band and issues the 16-B
@@ -456,7 +495,8 @@ PDWT_DEVICE void inv_fast_col_pass(int tid, const v2f* sAV, const v2f* sHD, v2f*
 
 // row synthesis, four adjacent samples per thread, 16-B stores
 template <int HLEN, int TX, int TY, int NT>
-PDWT_DEVICE void inv_fast_row_pass(int tid, const v2f* tt, const Inv2DFastArgs& a, int bx, int by, int bz) {
+PDWT_DEVICE void inv_fast_row_pass(int tid, const v2f* tt, const Inv2DFastArgs& a, int bx, int by, int bz,
+                                   bool coh_out = false) {
     using G = InvFastGeom<HLEN, TX>;
     constexpr int H2 = G::H2, S = G::S, PADL = G::PADL, CXA = G::CXA;
     constexpr int OY = 2 * TY;
@@ -474,7 +514,8 @@ PDWT_DEVICE void inv_fast_row_pass(int tid, const v2f* tt, const Inv2DFastArgs& 
         if (oy < a.Nr && ox < a.Nc) {  // Nc % 8 == 0 (Ncc % 4 == 0): the float4 is inside and aligned
             f32x4 v;
             v.x = res[0]; v.y = res[1]; v.z = res[2]; v.w = res[3];
-            *reinterpret_cast<f32x4*>(out + (long long)oy * a.Nc + ox) = v;
+            if (coh_out) coh_store16(coh_plane(out), (long long)oy * a.Nc + ox, v);  // read by other workgroups of this launch
+            else *reinterpret_cast<f32x4*>(out + (long long)oy * a.Nc + ox) = v;
         }
     }
 }
@@ -492,8 +533,11 @@ PDWT_DEVICE void inv_fast_interleave(v2f* sAV, v2f* sHD, int pair_index, const v
 }
 
 // Requirements: HLEN even, Ncc % 4 == 0, Nc == 2*Ncc, 16-B aligned coefficient rows.
+// coh_in / coh_out (uniform, dwt2_chain_kernels.hpp): the A plane was written by other workgroups of THIS launch (sc1
+// loads) / the output plane is read by other workgroups of this launch (sc1 stores).
 template <int HLEN, int TX, int TY, int NT>
-PDWT_DEVICE void dwt2_inv_fast_tile(const Inv2DFastArgs& a, int bx, int by, int bz, float* smem) {
+PDWT_DEVICE void dwt2_inv_fast_tile(const Inv2DFastArgs& a, int bx, int by, int bz, float* smem, bool coh_in = false,
+                                    bool coh_out = false) {
     using G = InvFastGeom<HLEN, TX>;
     constexpr int H2 = G::H2, C = G::C, PADL = G::PADL, CXA = G::CXA;
     constexpr int CR = TY + H2 + 1;
@@ -512,7 +556,26 @@ PDWT_DEVICE void dwt2_inv_fast_tile(const Inv2DFastArgs& a, int bx, int by, int 
     const bool interior = cxa >= 0 && cxa + CXA <= a.Ncc && cy0 >= 0 && cy0 + CR <= a.Nrc;
     PDWT_FOR_THREADS(tid, NT) {
         constexpr int TOTAL = CR * V4, TRIPS = (TOTAL + NT - 1) / NT;
-        if (interior) {  // branch-free (see dwt2_fwd_fast_tile): all of a thread's loads in flight together
+        if (coh_in) {  // needs Nrc >= CR and Ncc >= CXA (checked by the host)
+            const CohPlane pa = coh_plane(a.A + boff);
+#pragma unroll
+            for (int t = 0; t < TRIPS; ++t) {
+                int idx = tid + t * NT;
+                idx = idx < TOTAL ? idx : TOTAL - 1;
+                const int r = idx / V4;
+                const int g = idx - r * V4;
+                int sy = cy0 + r, sx = cxa + 4 * g;
+                sy = sy < 0 ? sy + a.Nrc : (sy >= a.Nrc ? sy - a.Nrc : sy);
+                sx = sx < 0 ? sx + a.Ncc : (sx >= a.Ncc ? sx - a.Ncc : sx);
+                const long long oi = (long long)sy * a.Ncc + sx;
+                const long long o = boff + oi;
+                const f32x4 ca = coh_load16(pa, oi);
+                v4f va;
+                va.x = ca.x; va.y = ca.y; va.z = ca.z; va.w = ca.w;
+                inv_fast_interleave(sAV, sHD, r * CXA + 4 * g, va, *reinterpret_cast<const v4f*>(a.V + o),
+                                    *reinterpret_cast<const v4f*>(a.H + o), *reinterpret_cast<const v4f*>(a.D + o));
+            }
+        } else if (interior) {  // branch-free (see dwt2_fwd_fast_tile): all of a thread's loads in flight together
             const long long o0 = boff + (long long)cy0 * a.Ncc + cxa;
 #pragma unroll
             for (int t = 0; t < TRIPS; ++t) {
@@ -555,7 +618,7 @@ PDWT_DEVICE void dwt2_inv_fast_tile(const Inv2DFastArgs& a, int bx, int by, int 
     PDWT_SYNC();
     PDWT_FOR_THREADS(tid, NT) { inv_fast_col_pass<HLEN, TX, TY, NT>(tid, sAV, sHD, tt, a.fb); }
     PDWT_SYNC();
-    PDWT_FOR_THREADS(tid, NT) { inv_fast_row_pass<HLEN, TX, TY, NT>(tid, tt, a, bx, by, bz); }
+    PDWT_FOR_THREADS(tid, NT) { inv_fast_row_pass<HLEN, TX, TY, NT>(tid, tt, a, bx, by, bz, coh_out); }
 }
 
 #ifndef PDWT_CPU_EMU

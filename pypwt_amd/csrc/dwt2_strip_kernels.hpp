@@ -256,9 +256,15 @@ PDWT_DEVICE void dwt2_fwd_strip2_wg(const FwdStrip2Args& a, int strip, int seg, 
 template <int HLEN, int TX2, int NT, int PF = 2, int CHUNK2 = 4>
 __global__ void __launch_bounds__(NT) dwt2_fwd_strip2_kernel(const FwdStrip2Args a) {
     extern __shared__ __attribute__((aligned(16))) float pdwt_smem[];
-    // consecutive workgroup ids = consecutive column strips of one row segment (neighbours share x-halo in L2)
-    const int seg = blockIdx.x / a.strips;
-    dwt2_fwd_strip2_wg<HLEN, TX2, NT, PF, CHUNK2>(a, blockIdx.x - seg * a.strips, seg, blockIdx.y, pdwt_smem);
+    // Consecutive workgroup ids land on DIFFERENT XCDs (round-robin), ids b and b + 8 on the same one: XCD x takes the
+    // contiguous range [x total/8, (x+1) total/8) of (segment, strip) pairs, i.e. neighbouring column strips of one row
+    // segment, which walk down their strips together and share the lines that hold their x-halo in that XCD's L2.
+    // With consecutive ids every strip's two border lines per row were fetched by two XCDs: rocprofv3 FETCH_SIZE
+    // 1711 MB per 16 images of 4096^2 against 1074 MB read (profiles/r03a_rocprofv3_summary_cfg2_b16.txt).
+    const int total = a.strips * a.segs;
+    const int lin = (total & 7) ? (int)blockIdx.x : (int)(blockIdx.x & 7) * (total >> 3) + (int)(blockIdx.x >> 3);
+    const int seg = lin / a.strips;
+    dwt2_fwd_strip2_wg<HLEN, TX2, NT, PF, CHUNK2>(a, lin - seg * a.strips, seg, blockIdx.y, pdwt_smem);
 }
 #endif
 
@@ -481,8 +487,10 @@ PDWT_DEVICE void dwt2_inv_strip2_wg(const InvStrip2Args& a, int bx, int sg, int 
 template <int HLEN, int TX, int NT>
 __global__ void __launch_bounds__(NT) dwt2_inv_strip2_kernel(const InvStrip2Args a) {
     extern __shared__ __attribute__((aligned(16))) float pdwt_smem[];
-    const int sg = blockIdx.x / a.strips;
-    dwt2_inv_strip2_wg<HLEN, TX, NT>(a, blockIdx.x - sg * a.strips, sg, blockIdx.y, pdwt_smem);
+    const int total = a.strips * a.segs;  // XCD-contiguous (segment, strip) ranges, see the forward kernel
+    const int lin = (total & 7) ? (int)blockIdx.x : (int)(blockIdx.x & 7) * (total >> 3) + (int)(blockIdx.x >> 3);
+    const int sg = lin / a.strips;
+    dwt2_inv_strip2_wg<HLEN, TX, NT>(a, lin - sg * a.strips, sg, blockIdx.y, pdwt_smem);
 }
 #endif
 

@@ -118,6 +118,44 @@ PDWT_DEVICE real_t soft_shrink(real_t x, real_t b) {
 #endif
 }
 
+// ---- agent-coherent 16-B accesses ----------------------------------------
+// Data handed from one workgroup to another INSIDE a launch (dwt2_chain_kernels.hpp) is written with `sc1`
+// (write-through) stores and read with `sc1` loads, which bypass the CU's L1 and do not rely on another XCD's
+// L2 (MI355X_MICROARCH.md, "Workgroup dispatch, XCD placement & inter-workgroup visibility", valid forms).
+// Raw-buffer intrinsics carry the cache-policy bits (aux bit 4 = sc1) and are tracked by the compiler's
+// s_waitcnt insertion, unlike inline asm.  The emulation build has one memory: plain accesses.
+#if !defined(PDWT_CPU_EMU) && !defined(PDWT_DOUBLE)
+typedef unsigned pdwt_u32x4 __attribute__((ext_vector_type(4)));
+struct CohPlane {
+    __amdgpu_buffer_rsrc_t rsrc;
+};
+PDWT_DEVICE CohPlane coh_plane(const void* base) {
+    CohPlane c;
+    c.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), (short)0, (int)0xffffffffu, 0x00020000);
+    return c;
+}
+PDWT_DEVICE f32x4 coh_load16(const CohPlane& c, long long elem) {
+    // whole-vector bit cast: with the four components extracted one by one hipcc 7.2 narrows the load to
+    // buffer_load_dword and leaves three of the four registers undefined
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(c.rsrc, (int)(elem * 4), 0, 16));
+}
+PDWT_DEVICE void coh_store16(const CohPlane& c, long long elem, const f32x4& v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pdwt_u32x4, v), c.rsrc, (int)(elem * 4), 0, 16);
+}
+#else
+#ifdef PDWT_DOUBLE
+typedef real4_t coh4_t;
+#else
+typedef f32x4 coh4_t;
+#endif
+struct CohPlane {
+    real_t* base;
+};
+PDWT_DEVICE CohPlane coh_plane(const void* base) { return CohPlane{const_cast<real_t*>(static_cast<const real_t*>(base))}; }
+PDWT_DEVICE coh4_t coh_load16(const CohPlane& c, long long elem) { return *reinterpret_cast<const coh4_t*>(c.base + elem); }
+PDWT_DEVICE void coh_store16(const CohPlane& c, long long elem, const coh4_t& v) { *reinterpret_cast<coh4_t*>(c.base + elem) = v; }
+#endif
+
 // ---- argument blocks -----------------------------------------------------
 
 // one decimated 2D analysis level: in (Nr,Nc) -> A,H,V,D (Nr2,Nc2)

@@ -49,6 +49,19 @@ hipError_t launch_dwt2_inv_strip2(const real_t* const band2[4], const real_t* co
                                   int N0c, int hlen, const FilterBank& fb, int batch, hipStream_t s);
 hipError_t launch_dwt2_inv_pyr2(const real_t* const band2[4], const real_t* const det1[3], real_t* out, int N0r, int N0c,
                                 int hlen, const FilterBank& fb, int batch, hipStream_t s);
+// K consecutive 2D levels in ONE launch with in-launch hand-offs between levels (dwt2_chain_kernels.hpp): (Nr, Nc) enter the
+// finest level of the group; det[3 k + b] = band b (H, V, D) of the group's k-th level (finest first), app[k] its approximation
+// plane (forward: outputs; inverse: app[K-1] is the input, app[K-2..0] are intermediates); flags: batch x dwt2_chain_tiles()
+// zero-initialised words owned by the plan; epoch: a counter that grows with every launch on those flags
+bool dwt2_chain_supported(int hlen, int Nr, int Nc, int K);
+int dwt2_chain_tiles(int Nr, int Nc, int K);
+hipError_t launch_dwt2_fwd_chain(const real_t* in, real_t* const* det, real_t* const* app, int Nr, int Nc, int K, int hlen,
+                                 const FilterBank& fb, int batch, unsigned* flags, unsigned epoch, hipStream_t s);
+hipError_t launch_dwt2_inv_chain(real_t* out, real_t* const* det, real_t* const* app, int Nr, int Nc, int K, int hlen,
+                                 const FilterBank& fb, int batch, unsigned* flags, unsigned epoch, hipStream_t s);
+int set_chain_enabled(int value);  // 0 never, 1 where measured faster (default), 2 wherever supported (tests), 3 = 2 + batches too
+int get_chain_enabled();
+int set_chain_timeout(int ticks);  // s_memrealtime ticks (100 MHz) a chained tile waits for a producer before computing it itself
 // three consecutive 2D levels in one launch, small images (launch_dwt2_pyr3.hip): det[3 k + b] = band b (H, V, D) of the
 // k-th level of the group (finest first); rows and columns multiples of 8, even filters of at most 16 taps (fp64: 8)
 bool dwt2_pyr3_supported(int hlen, int N0r, int N0c);

@@ -55,6 +55,13 @@ hipError_t launch_dwt2_inv_strip2(const real_t* const[4], const real_t* const[3]
                                   const FilterBank&, int, hipStream_t) { return hipErrorNotSupported; }
 hipError_t launch_dwt2_inv_pyr2(const real_t* const[4], const real_t* const[3], real_t*, int, int, int,
                                 const FilterBank&, int, hipStream_t) { return hipErrorNotSupported; }
+bool dwt2_chain_supported(int, int, int, int) { return false; }
+int dwt2_chain_tiles(int, int, int) { return 0; }
+int set_chain_timeout(int) { return 0; }
+hipError_t launch_dwt2_fwd_chain(const real_t*, real_t* const*, real_t* const*, int, int, int, int, const FilterBank&, int, unsigned*,
+                                 unsigned, hipStream_t) { return hipErrorNotSupported; }
+hipError_t launch_dwt2_inv_chain(real_t*, real_t* const*, real_t* const*, int, int, int, int, const FilterBank&, int, unsigned*,
+                                 unsigned, hipStream_t) { return hipErrorNotSupported; }
 int dwt1_fused_max_levels(int) { return 1; }
 bool dwt1_fused_supported(int, int, int) { return false; }
 hipError_t launch_dwt1_fwd_fused(const real_t*, real_t* const*, real_t*, int, int, int, int, const FilterBank&,
@@ -102,6 +109,12 @@ static std::atomic<int>& reg1d_flag() {
 }
 int set_reg1d_enabled(int value) { return reg1d_flag().exchange(value < 0 ? 0 : (value > 7 ? 7 : value)); }  // three flag bits
 int get_reg1d_enabled() { return reg1d_flag().load(std::memory_order_relaxed); }
+static std::atomic<int>& chain_flag() {
+    static std::atomic<int> v{getenv("PDWT_CHAIN") ? atoi(getenv("PDWT_CHAIN")) : 1};
+    return v;
+}
+int set_chain_enabled(int value) { return chain_flag().exchange(value < 0 ? 0 : (value > 3 ? 3 : value)); }
+int get_chain_enabled() { return chain_flag().load(std::memory_order_relaxed); }
 int set_wave2_enabled(int value) { return wave2_flag().exchange(value ? 1 : 0); }
 int get_wave2_enabled() { return wave2_flag().load(std::memory_order_relaxed); }
 static bool wave_kernels_for(long long samples) {

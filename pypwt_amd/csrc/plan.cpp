@@ -297,6 +297,7 @@ int create_impl(const real_t* img, int batch, int Nr, int Nc, const char* wname,
 // answer hipErrorNotSupported, the step's levels run through the per-level kernels instead.
 
 constexpr int kMaxFusedLevelsHost = 10;  // == kMaxFusedLevels of dwt1_fused_kernels.hpp
+constexpr int kChainMaxLevelsHost = 6;  // == kChainMaxLevels of dwt2_chain_kernels.hpp
 
 // Where the approximation of level l lives: l = 0 the image, l = L band 0, otherwise its slot in the
 // arena (SWT: two ping-pong planes).  Forward level l reads slot l-1 and writes slot l; inverse level l
@@ -374,10 +375,49 @@ void build_schedule(pdwt_plan* p) {
             }
             return 0;
         };
+        // Levels 1..K in ONE launch with in-launch hand-offs between the levels (dwt2_chain_kernels.hpp): the level-per-launch
+        // data flow without the launch boundaries.  (a) ONE cache-resident image (2^22 < samples <= 2^24, filters of at
+        // most 8 taps): the step of levels 2..L is a chain of dependent, latency-bound launches (13 of the forward's 35 us
+        // for 25 % of the bytes at 4096^2).  (b) the INVERSE of a batch beyond the Infinity Cache (>= 2^26 samples): the
+        // chain's stagger hands A_1 from level 2 to level 1 through the Infinity Cache instead of HBM (the forward keeps the
+        // streaming strips, which never write A_1 at all).  "chain" knob (PDWT_CHAIN): 0 never, 1 these two, 2 wherever the
+        // kernel applies (tests), 3 = 2 and the batch forward too.
+        const int chain_mode = get_chain_enabled();
+        auto chain_at = [&](int l, bool inverse) {
+            if (!fusable || chain_mode == 0 || l != 1 || L < 2) return 0;
+            const long long per_image = (long long)p->lr[0] * p->lc[0];
+            const bool one_image = per_image > (1LL << 22) && samples(1) <= (1LL << 24);
+            const bool big_batch = samples(1) >= (1LL << 26) && (inverse || chain_mode >= 3);
+            if (!(chain_mode >= 2 || one_image || big_batch)) return 0;
+            int K = L < kChainMaxLevelsHost ? L : kChainMaxLevelsHost;
+            if (const char* e = getenv("PDWT_CHAIN_K")) K = atoi(e) < K ? atoi(e) : K;  // A/B measurements
+            while (K >= 2 && !dwt2_chain_supported(hlen, p->lr[0], p->lc[0], K)) --K;
+            return K >= 2 ? K : 0;
+        };
+        {   // flag memory of the chains: batch x tiles words per direction, zeroed once (epochs only grow)
+            const int Kf = chain_at(1, false), Ki = chain_at(1, true);
+            const int K = Kf > Ki ? Kf : Ki;
+            const long long words = K ? (long long)p->batch * dwt2_chain_tiles(p->lr[0], p->lc[0], K) : 0;
+            if (words > p->chain_words) {
+                if (p->chain_flags) (void)hipFree(p->chain_flags);
+                p->chain_flags = nullptr;
+                p->chain_words = 0;
+                if (hipMalloc((void**)&p->chain_flags, (size_t)(2 * words) * sizeof(unsigned)) == hipSuccess &&
+                    hipMemsetAsync(p->chain_flags, 0, (size_t)(2 * words) * sizeof(unsigned), p->stream) == hipSuccess) {
+                    p->chain_words = words;
+                    p->chain_epoch = 0;
+                } else {
+                    (void)hipGetLastError();
+                    if (p->chain_flags) (void)hipFree(p->chain_flags);
+                    p->chain_flags = nullptr;
+                }
+            }
+        }
         for (int dir = 0; dir < 2; dir++) {
             std::vector<Step>& out = dir ? p->sched_inv : p->sched_fwd;
             for (int l = 1; l <= L; l++) {
                 if (const int K = swt_group(l)) { out.push_back({Step::SWTF, l, K}); l += K - 1; continue; }
+                if (const int K = p->chain_flags ? chain_at(l, dir != 0) : 0) { out.push_back({Step::CHAIN, l, K}); l += K - 1; continue; }
                 if (strip_at(l, dir != 0)) { out.push_back({Step::STRIP2, l, 2}); l++; }
                 else if (wave2_at(l, dir != 0)) { out.push_back({Step::WAVE2, l, 2}); l++; }
                 else if (pyr3_at(l)) { out.push_back({Step::PYR3, l, 3}); l += 2; }
@@ -639,6 +679,17 @@ int forward_impl(pdwt_plan* p, int only = 0) {
             e = s.kind == Step::STRIP2  ? launch_dwt2_fwd_strip2(src, det1, band2, r0, c0, hlen, p->dec, B, p->stream)
                 : s.kind == Step::WAVE2 ? launch_dwt2_fwd_wave2(src, det1, band2, r0, c0, hlen, p->dec, B, p->stream)
                                         : launch_dwt2_fwd_pyr2(src, det1, band2, r0, c0, hlen, p->dec, B, p->stream);
+        } else if (s.kind == Step::CHAIN) {
+            real_t* det[3 * kChainMaxLevelsHost] = {};
+            real_t* app[kChainMaxLevelsHost] = {};
+            for (int k = 0; k < s.K; k++) {
+                app[k] = approx_slot(p, l + k);
+                for (int b = 0; b < 3; b++) det[3 * k + b] = p->band(3 * (l + k - 1) + 1 + b);
+            }
+            Stamp st(p, "dwt2_fwd_chain");
+            if (!run) continue;
+            e = launch_dwt2_fwd_chain(approx_slot(p, l - 1), det, app, p->lr[l - 1], p->lc[l - 1], s.K, hlen, p->dec, B,
+                                      p->chain_flags, ++p->chain_epoch, p->stream);
         } else if (s.kind == Step::PYR3) {
             real_t* det[9];
             for (int k = 0; k < 9; k++) det[k] = p->band(3 * (l - 1) + 1 + k);
@@ -695,6 +746,17 @@ int inverse_impl(pdwt_plan* p, int only = 0) {
             e = s.kind == Step::STRIP2
                     ? launch_dwt2_inv_strip2(band2, det1, approx_slot(p, l - 1), p->lr[l - 1], p->lc[l - 1], hlen, p->rec, B, p->stream)
                     : launch_dwt2_inv_pyr2(band2, det1, approx_slot(p, l - 1), p->lr[l - 1], p->lc[l - 1], hlen, p->rec, B, p->stream);
+        } else if (s.kind == Step::CHAIN) {
+            real_t* det[3 * kChainMaxLevelsHost] = {};
+            real_t* app[kChainMaxLevelsHost] = {};
+            for (int k = 0; k < s.K; k++) {
+                app[k] = approx_slot(p, l + k);
+                for (int b = 0; b < 3; b++) det[3 * k + b] = p->band(3 * (l + k - 1) + 1 + b);
+            }
+            Stamp st(p, "dwt2_inv_chain");
+            if (!run) continue;
+            e = launch_dwt2_inv_chain(approx_slot(p, l - 1), det, app, p->lr[l - 1], p->lc[l - 1], s.K, hlen, p->rec, B,
+                                      p->chain_flags + p->chain_words, ++p->chain_epoch, p->stream);
         } else if (s.kind == Step::PYR3) {
             real_t* det[9];
             for (int k = 0; k < 9; k++) det[k] = p->band(3 * (l - 1) + 1 + k);
@@ -907,8 +969,7 @@ int pdwt_clone(pdwt_handle src, pdwt_handle* out) {
     p->own_stream = true;
     int rc = build_layout(p);
     if (rc != PDWT_OK) { pdwt_destroy(p); return rc; }
-    p->sched_fwd = src->sched_fwd;
-    p->sched_inv = src->sched_inv;
+    build_schedule(p);  // not copied: a chain step needs the clone's own hand-off flags
     e = hipStreamSynchronize(src->stream);
     if (e == hipSuccess)
         e = hipMemcpyAsync(p->arena, src->arena, (size_t)p->arena_elems * sizeof(real_t), hipMemcpyDeviceToDevice,
@@ -935,6 +996,7 @@ int pdwt_destroy(pdwt_handle h) {
     if (h->tmp) (void)hipFree(h->tmp);
     if (h->d_red) (void)hipFree(h->d_red);
     if (h->d_f2d) (void)hipFree(h->d_f2d);
+    if (h->chain_flags) (void)hipFree(h->chain_flags);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return PDWT_OK;
@@ -1443,6 +1505,8 @@ int pdwt_set_tuning(const char* key, int value) {
     if (key && !strcmp(key, "wave2")) return set_wave2_enabled(value);
     if (key && !strcmp(key, "reg1d")) return set_reg1d_enabled(value);
     if (key && !strcmp(key, "swt_fused")) return set_swt_fused_enabled(value);
+    if (key && !strcmp(key, "chain")) return set_chain_enabled(value);
+    if (key && !strcmp(key, "chain_timeout")) return set_chain_timeout(value);
     return fail(PDWT_ERR_ARG, "pdwt_set_tuning: unknown key %s", key ? key : "(null)");
 }
 

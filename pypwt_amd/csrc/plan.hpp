@@ -34,7 +34,7 @@ struct Band {
 
 // one launch of a plan's forward / inverse launch list (plan.cpp: build_schedule)
 struct Step {
-    enum Kind { LEVEL = 0, PYR2 = 1, STRIP2 = 2, FUSED1D = 3, WAVE2 = 4, REG1D = 5, SWTF = 6, PYR3 = 7 };
+    enum Kind { LEVEL = 0, PYR2 = 1, STRIP2 = 2, FUSED1D = 3, WAVE2 = 4, REG1D = 5, SWTF = 6, PYR3 = 7, CHAIN = 8 };
     int kind;
     int level;  // first (finest) level the launch works on
     int K;      // number of levels it covers
@@ -89,6 +89,11 @@ struct pdwt_plan {
     int consumed_normalize = 0;
 
     std::vector<pdwt::Step> sched_fwd, sched_inv;  // launch lists, in execution order
+    // Step::CHAIN (several levels in one launch, dwt2_chain_kernels.hpp): per-tile hand-off flags of the forward and of the
+    // inverse chain, batch x chain_tiles words each, zeroed once; every launch stamps them with a new epoch
+    unsigned* chain_flags = nullptr;
+    long long chain_words = 0;  // per direction
+    unsigned chain_epoch = 0;
 
     bool timing = false;
     std::vector<pdwt::KernelStamp> stamps;
