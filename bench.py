@@ -386,12 +386,22 @@ def timed_steps(step, device_sync, steps):
     return (time.perf_counter() - t0) / steps
 
 
-def timed_region(step, device_sync, steps, dist, backend, before_closing_barrier=None):
+def timed_region(step, device_sync, steps, dist, backend, before_closing_barrier=None, reheat=None):
     """The contract's timed region, the SAME code for one rank and for N: barrier + device sync, t0, exactly
     `steps` steps, device sync, t1, then the closing barrier + device sync.  Every rank's clock stops at t1,
     BEFORE the closing barrier: that barrier (an RCCL all-reduce kernel + a host sync, 50-100 us) only lines the
     ranks up again and is not part of anybody's interval, so the N = 1 and N > 1 figures are the same
-    measurement.  Returns the max over ranks of t1 - t0 in seconds."""
+    measurement.  Returns the max over ranks of t1 - t0 in seconds.
+
+    `reheat`: a rank that reaches the opening barrier first idles its GPU until the last one arrives (the very first
+    barrier also builds the RCCL communicator: hundreds of ms), and an MI355X that has idled for ~20 ms runs the next
+    milliseconds 10 % slower (profiles/r03c_distgap.txt: 70.1 -> 77.4 us per step after a 20 ms sleep).  So the ranks
+    are lined up TWICE: barrier, the same untimed re-heat on every rank (they stay together), then the barrier that
+    opens the interval, which nobody waits in for more than its own latency."""
+    if dist is not None and reheat is not None:
+        barrier(dist, backend)
+        device_sync()
+        reheat()
     barrier(dist, backend)
     device_sync()
     t0 = time.perf_counter()
@@ -485,6 +495,7 @@ def main():
             import torch
             torch.cuda.synchronize()
 
+    barrier(dist, backend)  # builds the RCCL communicator now, not inside the measurement
     # cold figure: W warm-up steps after an idle period, then K steps (no pre-heat): what a one-shot caller sees
     for _ in range(args.warmup):
         step()
@@ -499,7 +510,15 @@ def main():
     for _ in range(args.warmup):
         step()
     device_sync()
-    dt = timed_region(step, device_sync, args.steps, dist, backend)
+
+    def reheat():  # ~50 ms of untimed steps, the same on every rank
+        t = time.perf_counter()
+        while (time.perf_counter() - t) * 1e3 < min(50.0, args.preheat_ms):
+            for _ in range(20):
+                step()
+            device_sync()
+
+    dt = timed_region(step, device_sync, args.steps, dist, backend, reheat=reheat)
     cold_s = max_over_ranks(cold_s, dist, backend)
 
     step_s = dt / args.steps

@@ -210,9 +210,10 @@ int pdwt_time_level(pdwt_handle h, int level, int inverse, int reps, float* ms_p
  *                    a plan is created.
  *   "chain"          levels 1..K of a 2D DWT in ONE launch with in-launch hand-offs between the levels
  *                    (dwt2_chain_kernels.hpp; even filters of at most 8 taps, whole 16 x 128 tiles at every level):
- *                    1 (default): one cache-resident image (2^22 < samples <= 2^24) in both directions and the inverse of
- *                    batches of >= 2^26 samples; 2: wherever the kernel applies; 3: 2 and the forward of such batches too;
- *                    0: never.  Read when a plan is created.
+ *                    0 (default): never -- measured break-even for two levels and slower beyond on MI355X; 1: one
+ *                    cache-resident image (2^22 < samples <= 2^24) in both directions and the inverse of batches of
+ *                    >= 2^26 samples; 2: wherever the kernel applies; 3: 2 and the forward of such batches too.  Read when
+ *                    a plan is created.
  *   "chain_timeout"  ticks of the 100 MHz s_memrealtime counter a chained tile waits for a producer tile before it
  *                    computes that producer itself (default 3000 = 30 us; 0 makes nearly every wait take that path: tests)
  *   "wave2"          1: eligible forward level pairs run as ONE two-level wave launch (default 0: measured

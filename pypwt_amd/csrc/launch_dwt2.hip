@@ -110,7 +110,7 @@ static std::atomic<int>& reg1d_flag() {
 int set_reg1d_enabled(int value) { return reg1d_flag().exchange(value < 0 ? 0 : (value > 7 ? 7 : value)); }  // three flag bits
 int get_reg1d_enabled() { return reg1d_flag().load(std::memory_order_relaxed); }
 static std::atomic<int>& chain_flag() {
-    static std::atomic<int> v{getenv("PDWT_CHAIN") ? atoi(getenv("PDWT_CHAIN")) : 1};
+    static std::atomic<int> v{getenv("PDWT_CHAIN") ? atoi(getenv("PDWT_CHAIN")) : 0};  // opt-in: measured no faster, see plan.cpp
     return v;
 }
 int set_chain_enabled(int value) { return chain_flag().exchange(value < 0 ? 0 : (value > 3 ? 3 : value)); }

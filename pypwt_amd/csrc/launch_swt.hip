@@ -1,4 +1,6 @@
 // launch_swt.hip -- instantiations + launchers of the undecimated (a-trous) kernels (gfx950).
+#include <cstdlib>
+
 #include "launch.hpp"
 #include "launch_util.hpp"
 #include "swt_kernels.hpp"
@@ -70,13 +72,43 @@ hipError_t launch_swt2_inv(const Swt2DArgs& a, int batch, hipStream_t s) {
     }
 }
 
+// four samples per work item (swt1_*_vec_kernel): rows filtered along x, Nc % 4 == 0, even compile-time filter length
+static bool swt1_vec_ok(const SwtPassArgs& a) {
+    auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & (4 * sizeof(real_t) - 1)) == 0; };
+    static const bool off = getenv("PDWT_NO_SWT1_VEC") != nullptr;  // A/B measurements
+    return !off && !a.along_y && !(a.Nc & 3) && !(a.hlen & 1) && a.hlen >= 2 && a.hlen <= kMaxTaps && al(a.in0) &&
+           (!a.in1 || al(a.in1)) && al(a.out0) && (!a.out1 || al(a.out1));
+}
+
 hipError_t launch_swt_pass_fwd(const SwtPassArgs& a, hipStream_t s) {
+    if (swt1_vec_ok(a)) {
+        const unsigned grid = (unsigned)cdivll((long long)a.Nr * (a.Nc >> 2), 256);
+        switch (a.hlen) {
+#define X(h)                                                                                      \
+    case h:                                                                                       \
+        hipLaunchKernelGGL((swt1_fwd_vec_kernel<h, 256>), dim3(grid), dim3(256), 0, s, a);        \
+        return hipGetLastError();
+            PDWT_EVEN_HLENS(X)
+#undef X
+        }
+    }
     const long long total = (long long)a.Nr * a.Nc;
     hipLaunchKernelGGL((swt_pass_fwd_kernel<256>), dim3((unsigned)cdivll(total, 256)), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
 hipError_t launch_swt_pass_inv(const SwtPassArgs& a, hipStream_t s) {
+    if (swt1_vec_ok(a)) {
+        const unsigned grid = (unsigned)cdivll((long long)a.Nr * (a.Nc >> 2), 256);
+        switch (a.hlen) {
+#define X(h)                                                                                      \
+    case h:                                                                                       \
+        hipLaunchKernelGGL((swt1_inv_vec_kernel<h, 256>), dim3(grid), dim3(256), 0, s, a);        \
+        return hipGetLastError();
+            PDWT_EVEN_HLENS(X)
+#undef X
+        }
+    }
     const long long total = (long long)a.Nr * a.Nc;
     hipLaunchKernelGGL((swt_pass_inv_kernel<256>), dim3((unsigned)cdivll(total, 256)), dim3(256), 0, s, a);
     return hipGetLastError();

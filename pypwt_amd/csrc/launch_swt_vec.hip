@@ -1,5 +1,7 @@
 // launch_swt_vec.hip -- launchers of the vectorised a-trous level kernels (gfx950); a translation unit of
 // its own so that the 20 unrolled filter lengths compile in parallel with the scalar kernels.
+#include <cstdlib>
+
 #include "launch.hpp"
 #include "launch_util.hpp"
 #include "swt_kernels.hpp"
@@ -7,9 +9,9 @@
 namespace pdwt {
 
 // vectorised twins: 128 columns x 16 rows of one phase, four columns per thread (16-B accesses)
-template <int HLEN, bool INV, int TX = 128>
+template <int HLEN, bool INV, int TX = 128, int TY = 16>
 static hipError_t run_vec(const Swt2DArgs& a, int batch, hipStream_t s) {
-    constexpr int TY = 16, NT = 256;
+    constexpr int NT = 256;
     static std::atomic<bool> big[64] = {};
     // the inverse stages its rows in LDS where the dilation allows it (swt_inv_staged): a larger request for those launches
     const bool staged = INV && swt_inv_staged<TX, TY, NT>(HLEN, a.f);
@@ -45,9 +47,16 @@ hipError_t try_launch_swt2_vec(const Swt2DArgs& a, bool inverse, int batch, hipS
     // a level repeated on cache-resident data is faster with 128: 16.5 vs 18.4 us)
     if (a.Nc >= 512 && a.hlen == 2) return inverse ? run_vec<2, true, 256>(a, batch, s) : run_vec<2, false, 256>(a, batch, s);
     if (a.Nc >= 512 && a.hlen == 4) return inverse ? run_vec<4, true, 256>(a, batch, s) : run_vec<4, false, 256>(a, batch, s);
+    // Tile height (profiles/r03l_swt_tile_height.txt, 2048^2, three levels forward): 16 rows are best up to 24 taps (db5 95 us
+    // against 100 / 103 with 32 / 64 rows, sym8 123 / 142 / 137, db12 212 / 238 / 357); 40 taps re-filter 39 halo rows per
+    // tile and gain with 32 rows (910 -> 773 us).
     switch (a.hlen) {
-#define X(h) \
-    case h:  \
+#define X(h)                                                                                                   \
+    case h:                                                                                                    \
+        if constexpr (h > 24) {                                                                                \
+            if (a.Nr / a.f >= 32)                                                                              \
+                return inverse ? run_vec<h, true, 128, 32>(a, batch, s) : run_vec<h, false, 128, 32>(a, batch, s); \
+        }                                                                                                      \
         return inverse ? run_vec<h, true>(a, batch, s) : run_vec<h, false>(a, batch, s);
         PDWT_EVEN_HLENS(X)
 #undef X

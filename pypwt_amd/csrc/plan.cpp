@@ -376,12 +376,13 @@ void build_schedule(pdwt_plan* p) {
             return 0;
         };
         // Levels 1..K in ONE launch with in-launch hand-offs between the levels (dwt2_chain_kernels.hpp): the level-per-launch
-        // data flow without the launch boundaries.  (a) ONE cache-resident image (2^22 < samples <= 2^24, filters of at
-        // most 8 taps): the step of levels 2..L is a chain of dependent, latency-bound launches (13 of the forward's 35 us
-        // for 25 % of the bytes at 4096^2).  (b) the INVERSE of a batch beyond the Infinity Cache (>= 2^26 samples): the
-        // chain's stagger hands A_1 from level 2 to level 1 through the Infinity Cache instead of HBM (the forward keeps the
-        // streaming strips, which never write A_1 at all).  "chain" knob (PDWT_CHAIN): 0 never, 1 these two, 2 wherever the
-        // kernel applies (tests), 3 = 2 and the batch forward too.
+        // data flow without the launch boundaries.  Correct (tests/test_gpu_chain.py) and OPT-IN: measured on MI355X it is
+        // break-even at K = 2 and slower beyond -- 4096^2 db4, rocprofv3: levels 1+2 31.4 us as one launch against 21.6 + 7.7
+        // + a 1.8 us boundary, every further level +5 us (a poll round trip before the tile's loads and a store drain behind
+        // them cost what a launch boundary costs; the two-level tile pyramid does levels 3+4 in 5.3 us); the inverse of a
+        // batch loses 16 % (every level-1 tile polls before it may load).  profiles/r03h_chain_sweep.txt.  "chain" knob
+        // (PDWT_CHAIN): 0 never (default), 1 one cache-resident image (2^22 < samples <= 2^24) and the inverse of batches
+        // of >= 2^26 samples, 2 wherever the kernel applies (tests), 3 = 2 and the batch forward too.
         const int chain_mode = get_chain_enabled();
         auto chain_at = [&](int l, bool inverse) {
             if (!fusable || chain_mode == 0 || l != 1 || L < 2) return 0;

@@ -237,6 +237,12 @@ PDWT_DEVICE rv4 soft4(const rv4& v, real_t b) {
     return r;
 }
 
+// Tap loops are fully unrolled up to 24 taps (taps in SGPRs, all of a row's loads in flight); beyond, hipcc hoists every
+// load of the unrolled body -- 4 bands x 40 taps x 4 registers in the inverse -- caps at 256 VGPRs and spills to scratch
+// (620 B per lane at 40 taps): those filters unroll 8 taps at a time.
+template <int HLEN>
+constexpr int kSwtTapUnroll = HLEN > 24 ? 8 : (HLEN > 0 ? HLEN : 1);
+
 template <int TX, int TY>
 constexpr int swt2d_vec_lds_floats(int hlen) { return 2 * (TY + hlen - 1) * TX; }
 
@@ -282,7 +288,7 @@ PDWT_DEVICE void swt2_fwd_vec_tile(const Swt2DArgs& a, int bx, int by, int bz, r
         // test between the trips, so the next row's HLEN loads are issued while this row is summed: 16 taps at 2048^2
         // 49 -> 41 us per level; 2-8 taps unchanged, and unrolling them only grows the binary (tools/ktimes.py).
         constexpr int TRIPS = (RY + NG - 1) / NG;
-#pragma unroll(HLEN >= 10 ? TRIPS : 1)
+#pragma unroll((HLEN >= 10 && HLEN <= 24) ? TRIPS : 1)
         for (int t = 0; t < TRIPS; ++t) {
             int r = tid / QX + t * NG;
             if (HLEN < 10 && r >= RY) break;
@@ -291,7 +297,7 @@ PDWT_DEVICE void swt2_fwd_vec_tile(const Swt2DArgs& a, int bx, int by, int bz, r
             if (x0 < a.Nc) {
                 const int i = wrap_periodic(it * TY - c + r, M);
                 const real_t* row = in + (long long)(ph + f * i) * a.Nc;
-#pragma unroll
+#pragma unroll(kSwtTapUnroll<HLEN>)
                 for (int j = 0; j < HLEN; ++j) {
                     const rv4 v = interior ? load4u(row + x0 + (j - c) * f) : load4_periodic(row, x0 + (j - c) * f, a.Nc);
                     fma4(aL, v, a.fb.lo[HLEN - 1 - j]);
@@ -309,7 +315,7 @@ PDWT_DEVICE void swt2_fwd_vec_tile(const Swt2DArgs& a, int bx, int by, int bz, r
 #pragma unroll
         for (int i = 0; i < R; ++i) {
             rv4 rA = {zero, zero, zero, zero}, rH = rA, rV = rA, rD = rA;
-#pragma unroll
+#pragma unroll(kSwtTapUnroll<HLEN>)
             for (int j = 0; j < HLEN; ++j) {
                 const rv4 l = load4(tL + (ty0 + i + j) * TX + 4 * k4);
                 const rv4 h = load4(tH + (ty0 + i + j) * TX + 4 * k4);
@@ -401,7 +407,7 @@ PDWT_DEVICE void swt2_inv_vec_tile(const Swt2DArgs& a, int bx, int by, int bz, r
                     rv4 r1 = {zero, zero, zero, zero}, r2 = r1;
                     if (bx * TX + 4 * k4 < a.Nc) {
                         if (aligned_taps) {
-#pragma unroll
+#pragma unroll(kSwtTapUnroll<HLEN>)
                             for (int j = 0; j < HLEN; ++j) {
                                 const real_t tl = a.fb.lo[HLEN - 1 - j], th = a.fb.hi[HLEN - 1 - j];
                                 fma4(r1, load4(sg + j * f), tl);
@@ -441,7 +447,7 @@ PDWT_DEVICE void swt2_inv_vec_tile(const Swt2DArgs& a, int bx, int by, int bz, r
                 const int i = wrap_periodic(it * TY - c + r, M);
                 const long long ro = boff + (long long)(ph + f * i) * a.Nc;
                 if (interior) {
-#pragma unroll
+#pragma unroll(kSwtTapUnroll<HLEN>)
                     for (int j = 0; j < HLEN; ++j) {
                         const long long o = ro + x0 + (j - c) * f;
                         const real_t tl = a.fb.lo[HLEN - 1 - j], th = a.fb.hi[HLEN - 1 - j];
@@ -451,7 +457,7 @@ PDWT_DEVICE void swt2_inv_vec_tile(const Swt2DArgs& a, int bx, int by, int bz, r
                         fma4(r2, soft4(load4u(a.D + o), a.soft_beta), th);
                     }
                 } else {
-#pragma unroll
+#pragma unroll(kSwtTapUnroll<HLEN>)
                     for (int j = 0; j < HLEN; ++j) {
                         const int p = x0 + (j - c) * f;
                         const real_t tl = a.fb.lo[HLEN - 1 - j], th = a.fb.hi[HLEN - 1 - j];
@@ -474,7 +480,7 @@ PDWT_DEVICE void swt2_inv_vec_tile(const Swt2DArgs& a, int bx, int by, int bz, r
 #pragma unroll
         for (int i = 0; i < R; ++i) {
             rv4 r = {zero, zero, zero, zero};
-#pragma unroll
+#pragma unroll(kSwtTapUnroll<HLEN>)
             for (int j = 0; j < HLEN; ++j) {
                 fma4(r, load4(u1 + (ty0 + i + j) * TX + 4 * k4), a.fb.lo[HLEN - 1 - j]);
                 fma4(r, load4(u2 + (ty0 + i + j) * TX + 4 * k4), a.fb.hi[HLEN - 1 - j]);
@@ -540,7 +546,109 @@ PDWT_DEVICE void swt_pass_inv_tile(const SwtPassArgs& a, long long block, real_t
     }
 }
 
+// ---------------------------------------------------------------------------
+// Vectorised one-pass kernels for the (batched) 1D SWT (rows filtered along x; reference drivers
+// pdwt/src/separable.cu:496-537,629-672 `_1d`): a work item owns FOUR consecutive samples of a row.  Tap j of the
+// a-trous filter is the same four-sample window shifted by (j - c) f: one 16-B load per tap (4-B alignment suffices
+// on gfx950, so every dilation takes the same path), all HLEN loads of a work item issued before the first is used
+// (compile-time filter length, taps in SGPRs).  Neighbouring taps and neighbouring work items overlap and are served
+// by L1 / L2: HBM sees each sample once (forward: 4 B read + 8 B written per sample; inverse 8 + 4).  Work items
+// whose window crosses a row end (the periodic wrap) gather their taps element by element.
+// Against the one-output-per-thread kernel above: a quarter of the memory instructions, none of the per-tap index
+// arithmetic.  Needs Nc % 4 == 0 and an even filter length.
+// ---------------------------------------------------------------------------
+template <int HLEN, int NT>
+PDWT_DEVICE void swt1_fwd_vec_tile(const SwtPassArgs& a, long long block) {
+    PDWT_FOR_THREADS(tid, NT) {
+        const int q4 = a.Nc >> 2;
+        const long long idx = block * NT + tid;
+        if (idx < (long long)a.Nr * q4) {
+            const int y = (int)(idx / q4);
+            const int x = 4 * (int)(idx - (long long)y * q4);
+            constexpr int c = HLEN / 2 - 1;
+            const real_t* PDWT_RESTRICT row = a.in0 + (long long)y * a.Nc;
+            const int lo = x - c * a.f, hi = x + 3 + (HLEN - 1 - c) * a.f;
+            rv4 v[HLEN];
+            if (lo >= 0 && hi < a.Nc) {
+#pragma unroll
+                for (int j = 0; j < HLEN; ++j) v[j] = load4u(row + lo + j * a.f);
+            } else {
+#pragma unroll
+                for (int j = 0; j < HLEN; ++j) {
+                    const int s = lo + j * a.f;
+                    v[j].x = row[wrap_periodic(s, a.Nc)];
+                    v[j].y = row[wrap_periodic(s + 1, a.Nc)];
+                    v[j].z = row[wrap_periodic(s + 2, a.Nc)];
+                    v[j].w = row[wrap_periodic(s + 3, a.Nc)];
+                }
+            }
+            rv4 L, H;
+            L.x = L.y = L.z = L.w = real_t(0);
+            H = L;
+#pragma unroll
+            for (int j = 0; j < HLEN; ++j) {
+                fma4(L, v[j], a.fb.lo[HLEN - 1 - j]);
+                fma4(H, v[j], a.fb.hi[HLEN - 1 - j]);
+            }
+            store4(a.out0 + (long long)y * a.Nc + x, L);
+            store4(a.out1 + (long long)y * a.Nc + x, H);
+        }
+    }
+}
+
+template <int HLEN, int NT>
+PDWT_DEVICE void swt1_inv_vec_tile(const SwtPassArgs& a, long long block) {
+    PDWT_FOR_THREADS(tid, NT) {
+        const int q4 = a.Nc >> 2;
+        const long long idx = block * NT + tid;
+        if (idx < (long long)a.Nr * q4) {
+            const int y = (int)(idx / q4);
+            const int x = 4 * (int)(idx - (long long)y * q4);
+            constexpr int c = HLEN / 2;
+            const real_t* PDWT_RESTRICT rA = a.in0 + (long long)y * a.Nc;
+            const real_t* PDWT_RESTRICT rD = a.in1 + (long long)y * a.Nc;
+            const int lo = x - c * a.f, hi = x + 3 + (HLEN - 1 - c) * a.f;
+            rv4 va[HLEN], vd[HLEN];
+            if (lo >= 0 && hi < a.Nc) {
+#pragma unroll
+                for (int j = 0; j < HLEN; ++j) {
+                    va[j] = load4u(rA + lo + j * a.f);
+                    vd[j] = load4u(rD + lo + j * a.f);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < HLEN; ++j) {
+                    const int s = lo + j * a.f;
+                    const int s0 = wrap_periodic(s, a.Nc), s1 = wrap_periodic(s + 1, a.Nc), s2 = wrap_periodic(s + 2, a.Nc),
+                              s3 = wrap_periodic(s + 3, a.Nc);
+                    va[j].x = rA[s0]; va[j].y = rA[s1]; va[j].z = rA[s2]; va[j].w = rA[s3];
+                    vd[j].x = rD[s0]; vd[j].y = rD[s1]; vd[j].z = rD[s2]; vd[j].w = rD[s3];
+                }
+            }
+            rv4 r;
+            r.x = r.y = r.z = r.w = real_t(0);
+#pragma unroll
+            for (int j = 0; j < HLEN; ++j) {
+                fma4(r, va[j], a.fb.lo[HLEN - 1 - j]);
+                fma4(r, vd[j], a.fb.hi[HLEN - 1 - j]);
+            }
+            const real_t half = real_t(0.5);
+            r.x *= half; r.y *= half; r.z *= half; r.w *= half;
+            store4(a.out0 + (long long)y * a.Nc + x, r);
+        }
+    }
+}
+
 #ifndef PDWT_CPU_EMU
+template <int HLEN, int NT>
+__global__ void __launch_bounds__(NT) swt1_fwd_vec_kernel(const SwtPassArgs a) {
+    swt1_fwd_vec_tile<HLEN, NT>(a, blockIdx.x);
+}
+template <int HLEN, int NT>
+__global__ void __launch_bounds__(NT) swt1_inv_vec_kernel(const SwtPassArgs a) {
+    swt1_inv_vec_tile<HLEN, NT>(a, blockIdx.x);
+}
+
 template <int HLEN, int TX, int TY, int NT>
 __global__ void __launch_bounds__(NT) swt2_fwd_kernel(const Swt2DArgs a) {
     extern __shared__ __attribute__((aligned(16))) real_t pdwt_smem[];
