@@ -49,7 +49,7 @@ static hipError_t run_inv(SwtFusedArgs& a, int batch, hipStream_t s) {
     a.seg_rows = fused_seg_rows(K, F0, rows_phase, a.strips, batch);
     a.segs = cdiv(rows_phase, a.seg_rows);
     const long long waves = (long long)batch * F0 * a.segs * a.strips;
-    hipLaunchKernelGGL((swt2_inv_fused_kernel<K, F0, 4, C, NT>), dim3((unsigned)waves), dim3(NT), 0, s, a, waves);
+    hipLaunchKernelGGL((swt2_inv_fused_kernel<K, F0, 4, C, NT>), dim3(8u * (unsigned)cdivll(waves, 8)), dim3(NT), 0, s, a, waves);  // swt_fused_wave
     return hipGetLastError();
 }
 
@@ -71,7 +71,7 @@ static hipError_t run(SwtFusedArgs& a, bool inverse, int batch, hipStream_t s) {
     a.seg_rows = fused_seg_rows(K, F0, rows_phase, a.strips, batch);
     a.segs = cdiv(rows_phase, a.seg_rows);
     const long long waves = (long long)batch * F0 * a.segs * a.strips;
-    const unsigned grid = (unsigned)cdivll(waves, NT / 64);
+    const unsigned grid = 8u * (unsigned)cdivll(cdivll(waves, NT / 64), 8);  // XCD-contiguous wavefront ranges (swt_fused_wave)
     hipLaunchKernelGGL((swt2_fwd_fused_kernel<K, F0, NT>), dim3(grid), dim3(NT), 0, s, a, waves);
     return hipGetLastError();
 }

@@ -315,10 +315,17 @@ struct SwtInvState {
     RowBuf bo;                                          // the output plane of this wavefront's image
 };
 
-// all planes of input row `ro` (byte offset of the row in a plane of this image) into load slot SLOT
+// all planes of input row `ro` (byte offset of the row in a plane of this image) into load slot SLOT.
+// `wrow` = the row's position in the walk.  The W = 2^K - 1 warm-up rows in front of a segment only feed the recursion:
+// level m of the group (m = 1 finest, dilation 2^(m-1) rows) needs its details from walk row W - (2^m - 1) on, so of the
+// 7 x 10 plane-rows in front of a three-level segment only 40 are used.  A warm-up row's unused detail loads are
+// redirected (a uniform pointer select: no branch around a load, the vmcnt bookkeeping stays exact) to the approximation
+// plane's row, which the same step loads anyway: they hit in cache instead of fetching 30 rows per segment nobody reads.
+// The values they deliver are finite and only reach ring slots that are overwritten before the first owned row.
 template <int K, int F0, int NRI, int C, int SLOT>
-PDWT_DEVICE void swt_inv_load(const SwtFusedArgs& a, SwtInvState<K, F0, NRI, C>& st, long long boff, unsigned ro) {
+PDWT_DEVICE void swt_inv_load(const SwtFusedArgs& a, SwtInvState<K, F0, NRI, C>& st, long long boff, unsigned ro, int wrow) {
     constexpr int NP = 1 + 3 * K;
+    using G = SwtFusedGeom<K, F0>;
     PDWT_WAVE_LANES(lane) {
         const unsigned o = st.off.mine(lane)[0] + ro;
         real_t* base = st.ld.mine(lane) + C * NP * SLOT;
@@ -336,9 +343,10 @@ PDWT_DEVICE void swt_inv_load(const SwtFusedArgs& a, SwtInvState<K, F0, NRI, C>&
 #pragma unroll
         for (int k = K - 1; k >= 0; --k) {  // deepest level first
             const int p = 1 + 3 * (K - 1 - k);
-            put(p, a.H[k]);
-            put(p + 1, a.V[k]);
-            put(p + 2, a.D[k]);
+            const bool used = wrow >= G::W - ((2 << k) - 1);  // uniform; always true once the warm-up rows are behind
+            put(p, used ? a.H[k] : a.in);
+            put(p + 1, used ? a.V[k] : a.in);
+            put(p + 2, used ? a.D[k] : a.in);
         }
     }
 }
@@ -396,9 +404,10 @@ PDWT_DEVICE void swt_inv_step(const SwtFusedArgs& a, SwtInvState<K, F0, NRI, C>&
     {
         int rr = r + S::NRI - 1;
         rr = rr < a.seg_rows + G::W ? rr : a.seg_rows + G::W - 1;  // see swt_fwd_step
+        const int wrow = rr;
         rr = i0 - G::W + rr;
         rr = ((rr % rows_phase) + rows_phase) % rows_phase;
-        swt_inv_load<K, F0, NRI, C, (R + S::NRI - 1) % S::NRI>(a, st, boff, kRealBytes * (unsigned)(py + F0 * rr) * (unsigned)a.Nc);
+        swt_inv_load<K, F0, NRI, C, (R + S::NRI - 1) % S::NRI>(a, st, boff, kRealBytes * (unsigned)(py + F0 * rr) * (unsigned)a.Nc, wrow);
     }
     PDWT_ROW_FENCE();
     WaveReg<real_t, C> cur, nxt;
@@ -456,7 +465,7 @@ PDWT_DEVICE void swt_inv_group(const SwtFusedArgs& a, SwtInvState<K, F0, NRI, C>
 template <int K, int F0, int NRI, int C, int I, class RowBytes>
 PDWT_DEVICE void swt_inv_preload(const SwtFusedArgs& a, SwtInvState<K, F0, NRI, C>& st, long long boff, const RowBytes& rowbytes) {
     if constexpr (I < NRI - 1) {
-        swt_inv_load<K, F0, NRI, C, I>(a, st, boff, rowbytes(I));
+        swt_inv_load<K, F0, NRI, C, I>(a, st, boff, rowbytes(I), I);
         swt_inv_preload<K, F0, NRI, C, I + 1>(a, st, boff, rowbytes);
     }
 }
@@ -497,16 +506,27 @@ PDWT_DEVICE void swt2_inv_fused(const SwtFusedArgs& a, long long w) {
 }
 
 #ifndef PDWT_CPU_EMU
+// Workgroup -> wavefront number.  Consecutive workgroup ids sit on DIFFERENT XCDs (ids b and b + 8 share one), and
+// consecutive wavefront numbers are neighbouring column strips of one row segment, which read the same halo lines at the
+// same time: XCD x takes the contiguous eighth [x chunk, (x + 1) chunk) of the wavefronts so that the neighbours meet in
+// one L2 (the launcher rounds the grid up to 8 chunk workgroups; surplus ones return).
+PDWT_DEVICE long long swt_fused_wave(unsigned block, int waves_per_block, int wave, long long waves) {
+    const long long blocks = (waves + waves_per_block - 1) / waves_per_block;
+    const long long chunk = (blocks + 7) >> 3;
+    const long long b = (long long)(block & 7) * chunk + (block >> 3);
+    return (block >> 3) < chunk && b < blocks ? b * waves_per_block + wave : waves;
+}
+
 template <int K, int F0, int NT>
 __global__ void __launch_bounds__(NT, 1) swt2_fwd_fused_kernel(const SwtFusedArgs a, long long waves) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const long long w = (long long)blockIdx.x * (NT / 64) + wave;
+    const long long w = swt_fused_wave(blockIdx.x, NT / 64, wave, waves);
     if (w < waves) swt2_fwd_fused<K, F0>(a, w);
 }
 template <int K, int F0, int NRI, int C, int NT>
 __global__ void __launch_bounds__(NT, 1) swt2_inv_fused_kernel(const SwtFusedArgs a, long long waves) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const long long w = (long long)blockIdx.x * (NT / 64) + wave;
+    const long long w = swt_fused_wave(blockIdx.x, NT / 64, wave, waves);
     if (w < waves) swt2_inv_fused<K, F0, NRI, C>(a, w);
 }
 #endif
