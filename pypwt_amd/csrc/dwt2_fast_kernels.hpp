@@ -39,6 +39,19 @@ struct Inv2DFastArgs {
     FilterBankI fb;  // (rec_lo, rec_hi)
 };
 
+// 16-B load at 4-B alignment (rows of images whose width is not a multiple of 4): one global_load_dwordx4 on gfx950
+#ifdef PDWT_CPU_EMU
+static inline f32x4 ld_f4_unaligned(const float* p) { return f32x4{p[0], p[1], p[2], p[3]}; }
+#else
+typedef float pdwt_f4u __attribute__((ext_vector_type(4), aligned(4)));
+static __device__ __forceinline__ f32x4 ld_f4_unaligned(const float* p) {
+    const pdwt_f4u v = *reinterpret_cast<const pdwt_f4u*>(p);
+    f32x4 r;
+    r.x = v.x; r.y = v.y; r.z = v.z; r.w = v.w;
+    return r;
+}
+#endif
+
 // Block renumbering: hardware deals consecutive workgroup ids round-robin over the 8 XCDs, so
 // ids b and b+8 share an L2.  Give XCD x the contiguous tile range [x*chunk, (x+1)*chunk) (row-major),
 // i.e. a horizontal band of the image, so vertically adjacent tiles (which share halo rows) meet
@@ -166,6 +179,23 @@ PDWT_DEVICE void fwd_fast_col_pass(int tid, const v2f* tLH, const Fwd2DFastArgs&
         return;
     }
 #endif
+    if ((a.Nc2 & 1) || (a.out_bstride & 1)) {  // odd coefficient rows: 8-B stores would straddle / run past the row end
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            const int oy = by * TY + ty0 + i;
+            if (oy < a.Nr2) {
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    if (ox + e < a.Nc2) {
+                        const long long o = boff + (long long)oy * a.Nc2 + ox + e;
+                        a.A[o] = accAV[i][e].x; a.V[o] = accAV[i][e].y;
+                        a.H[o] = accHD[i][e].x; a.D[o] = accHD[i][e].y;
+                    }
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < R; ++i) {
         const int oy = by * TY + ty0 + i;
@@ -224,7 +254,7 @@ PDWT_DEVICE void dwt2_fwd_fast_tile(const Fwd2DFastArgs& a, int bx, int by, int 
                 const f32x4 v = coh_load16(pin, (long long)sy * a.Nc + sx);
                 *reinterpret_cast<f32x4*>(sIn + r * RXA + 4 * g) = v;
             }
-        } else if (!(a.Nr & 1) && a.Nr >= RY && a.Nc >= RXA) {
+        } else if (!(a.Nr & 1) && !(a.Nc & 3) && a.Nr >= RY && a.Nc >= RXA) {
 #pragma unroll
             for (int t = 0; t < TRIPS; ++t) {
                 int idx = tid + t * NT;
@@ -237,13 +267,38 @@ PDWT_DEVICE void dwt2_fwd_fast_tile(const Fwd2DFastArgs& a, int bx, int by, int 
                 const f32x4 v = *reinterpret_cast<const f32x4*>(in + (long long)sy * a.Nc + sx);
                 *reinterpret_cast<f32x4*>(sIn + r * RXA + 4 * g) = v;
             }
-        } else {
+        } else if (!(a.Nc & 3)) {
             for (int idx = tid; idx < RY * V4; idx += NT) {
                 const int r = idx / V4;
                 const int g = idx - r * V4;
                 const int sy = wrap_analysis(y0 + r, a.Nr);
                 const int sx = wrap_periodic(xa + 4 * g, a.Nc);
                 const f32x4 v = *reinterpret_cast<const f32x4*>(in + (long long)sy * a.Nc + sx);
+                *reinterpret_cast<f32x4*>(sIn + r * RXA + 4 * g) = v;
+            }
+        } else {
+            // Row length not a multiple of 4 (odd images, the reference takes them at no extra cost,
+            // pdwt/src/separable.cu:116-121): rows start at any 4-B offset.  Groups inside the row are ONE 16-B load at
+            // 4-B alignment; only the groups that touch the row ends gather element by element through the analysis
+            // extension (last sample repeated for an odd length, then periodic).  Constant trip count, clamped index: a
+            // thread's loads are in flight together.
+#pragma unroll
+            for (int t = 0; t < TRIPS; ++t) {
+                int idx = tid + t * NT;
+                idx = idx < TOTAL ? idx : TOTAL - 1;
+                const int r = idx / V4;
+                const int g = idx - r * V4;
+                const float* PDWT_RESTRICT rowp = in + (long long)wrap_analysis(y0 + r, a.Nr) * a.Nc;
+                const int sx = xa + 4 * g;
+                f32x4 v;
+                if (sx >= 0 && sx + 3 < a.Nc) {
+                    v = ld_f4_unaligned(rowp + sx);
+                } else {
+                    v.x = rowp[wrap_analysis(sx, a.Nc)];
+                    v.y = rowp[wrap_analysis(sx + 1, a.Nc)];
+                    v.z = rowp[wrap_analysis(sx + 2, a.Nc)];
+                    v.w = rowp[wrap_analysis(sx + 3, a.Nc)];
+                }
                 *reinterpret_cast<f32x4*>(sIn + r * RXA + 4 * g) = v;
             }
         }
@@ -511,7 +566,14 @@ PDWT_DEVICE void inv_fast_row_pass(int tid, const v2f* tt, const Inv2DFastArgs& 
         inv_row_synth4<HLEN, PADL>(tt + gy * CXA + (PADL - PE) + k, a.fb, res);
         const int oy = 2 * by * TY + gy;
         const int ox = 2 * (bx * TX + k);
-        if (oy < a.Nr && ox < a.Nc) {  // Nc % 8 == 0 (Ncc % 4 == 0): the float4 is inside and aligned
+        if ((a.Nc & 3) || (a.out_bstride & 3)) {  // output rows of any length: element stores, each inside the row
+            if (oy < a.Nr) {
+                float* PDWT_RESTRICT orow = out + (long long)oy * a.Nc;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (ox + e < a.Nc) orow[ox + e] = res[e];
+            }
+        } else if (oy < a.Nr && ox < a.Nc) {  // Nc % 4 == 0: the float4 is inside and aligned
             f32x4 v;
             v.x = res[0]; v.y = res[1]; v.z = res[2]; v.w = res[3];
             if (coh_out) coh_store16(coh_plane(out), (long long)oy * a.Nc + ox, v);  // read by other workgroups of this launch
@@ -553,7 +615,8 @@ PDWT_DEVICE void dwt2_inv_fast_tile(const Inv2DFastArgs& a, int bx, int by, int 
 
     // ---- phase 1: stage the four coefficient tiles, interleaved as (A,V) and (H,D)
     // interior tiles (all but the border ring) skip the periodic-wrap arithmetic (a uniform branch)
-    const bool interior = cxa >= 0 && cxa + CXA <= a.Ncc && cy0 >= 0 && cy0 + CR <= a.Nrc;
+    const bool quads = !(a.Ncc & 3) && !(a.in_bstride & 3);  // coefficient rows start 16-B aligned, groups never straddle
+    const bool interior = quads && cxa >= 0 && cxa + CXA <= a.Ncc && cy0 >= 0 && cy0 + CR <= a.Nrc;
     PDWT_FOR_THREADS(tid, NT) {
         constexpr int TOTAL = CR * V4, TRIPS = (TOTAL + NT - 1) / NT;
         if (coh_in) {  // needs Nrc >= CR and Ncc >= CXA (checked by the host)
@@ -588,7 +651,7 @@ PDWT_DEVICE void dwt2_inv_fast_tile(const Inv2DFastArgs& a, int bx, int by, int 
                                     *reinterpret_cast<const v4f*>(a.V + o), *reinterpret_cast<const v4f*>(a.H + o),
                                     *reinterpret_cast<const v4f*>(a.D + o));
             }
-        } else if (a.Nrc >= CR && a.Ncc >= CXA) {
+        } else if (quads && a.Nrc >= CR && a.Ncc >= CXA) {
 #pragma unroll
             for (int t = 0; t < TRIPS; ++t) {
                 int idx = tid + t * NT;
@@ -602,6 +665,36 @@ PDWT_DEVICE void dwt2_inv_fast_tile(const Inv2DFastArgs& a, int bx, int by, int 
                 inv_fast_interleave(sAV, sHD, r * CXA + 4 * g, *reinterpret_cast<const v4f*>(a.A + o),
                                     *reinterpret_cast<const v4f*>(a.V + o), *reinterpret_cast<const v4f*>(a.H + o),
                                     *reinterpret_cast<const v4f*>(a.D + o));
+            }
+        } else if (!quads) {
+            // coefficient rows of any length / alignment (odd image sizes): groups inside the row are one 16-B load at 4-B
+            // alignment per band, groups at the row ends gather element by element (periodic); constant trip count
+#pragma unroll
+            for (int t = 0; t < TRIPS; ++t) {
+                int idx = tid + t * NT;
+                idx = idx < TOTAL ? idx : TOTAL - 1;
+                const int r = idx / V4;
+                const int g = idx - r * V4;
+                const long long ro = boff + (long long)wrap_periodic(cy0 + r, a.Nrc) * a.Ncc;
+                const int sx = cxa + 4 * g;
+                f32x4 qa, qv, qh, qd;
+                if (sx >= 0 && sx + 3 < a.Ncc) {
+                    qa = ld_f4_unaligned(a.A + ro + sx); qv = ld_f4_unaligned(a.V + ro + sx);
+                    qh = ld_f4_unaligned(a.H + ro + sx); qd = ld_f4_unaligned(a.D + ro + sx);
+                } else {
+                    const int s0 = wrap_periodic(sx, a.Ncc), s1 = wrap_periodic(sx + 1, a.Ncc), s2 = wrap_periodic(sx + 2, a.Ncc),
+                              s3 = wrap_periodic(sx + 3, a.Ncc);
+                    qa.x = a.A[ro + s0]; qa.y = a.A[ro + s1]; qa.z = a.A[ro + s2]; qa.w = a.A[ro + s3];
+                    qv.x = a.V[ro + s0]; qv.y = a.V[ro + s1]; qv.z = a.V[ro + s2]; qv.w = a.V[ro + s3];
+                    qh.x = a.H[ro + s0]; qh.y = a.H[ro + s1]; qh.z = a.H[ro + s2]; qh.w = a.H[ro + s3];
+                    qd.x = a.D[ro + s0]; qd.y = a.D[ro + s1]; qd.z = a.D[ro + s2]; qd.w = a.D[ro + s3];
+                }
+                v4f va, vv, vh, vd;
+                va.x = qa.x; va.y = qa.y; va.z = qa.z; va.w = qa.w;
+                vv.x = qv.x; vv.y = qv.y; vv.z = qv.z; vv.w = qv.w;
+                vh.x = qh.x; vh.y = qh.y; vh.z = qh.z; vh.w = qh.w;
+                vd.x = qd.x; vd.y = qd.y; vd.z = qd.z; vd.w = qd.w;
+                inv_fast_interleave(sAV, sHD, r * CXA + 4 * g, va, vv, vh, vd);
             }
         } else {
             for (int idx = tid; idx < CR * V4; idx += NT) {

@@ -100,7 +100,10 @@ static hipError_t run_inv_fast(const Inv2DArgs& g, int batch, hipStream_t s) {
 
 hipError_t try_launch_dwt2_fwd_fast(const Fwd2DArgs& a, int batch, hipStream_t s) {
     if ((a.hlen & 1) || a.hlen < 2 || a.hlen > kMaxTaps) return hipErrorNotSupported;
-    if ((a.Nc & 3) || (a.in_bstride & 3) || (a.out_bstride & 1)) return hipErrorNotSupported;
+    // any row length: rows that are not whole, aligned quads take the unaligned staging / element-store branches of the
+    // tile; the streaming form (more than 20 taps) stages whole aligned quads only
+    const bool quads = !(a.Nc & 3) && !(a.in_bstride & 3) && !(a.out_bstride & 1);
+    if (a.hlen > 20 && !quads) return hipErrorNotSupported;
     if (!aligned16(a.in) || !aligned16(a.A) || !aligned16(a.H) || !aligned16(a.V) || !aligned16(a.D))
         return hipErrorNotSupported;
     // One tile per workgroup everywhere.  Since the staging loops are branch-free (all of a thread's loads in flight
@@ -130,7 +133,7 @@ hipError_t try_launch_dwt2_fwd_fast(const Fwd2DArgs& a, int batch, hipStream_t s
 
 hipError_t try_launch_dwt2_inv_fast(const Inv2DArgs& a, int batch, hipStream_t s) {
     if ((a.hlen & 1) || a.hlen < 2 || a.hlen > kMaxTaps) return hipErrorNotSupported;
-    if ((a.Ncc & 3) || a.Nc != 2 * a.Ncc || (a.in_bstride & 3) || (a.out_bstride & 3)) return hipErrorNotSupported;
+    if (a.Nc > 2 * a.Ncc || a.Nc < 2 * a.Ncc - 1 || a.Nr > 2 * a.Nrc) return hipErrorNotSupported;  // any row length / alignment
     if (!aligned16(a.out) || !aligned16(a.A) || !aligned16(a.H) || !aligned16(a.V) || !aligned16(a.D))
         return hipErrorNotSupported;
     if (a.hlen <= 8 && mid_size((long long)batch * a.Nr * a.Nc)) {  // 128x16 tiles, 512 threads: 8.0 vs 8.8 us at 2048^2

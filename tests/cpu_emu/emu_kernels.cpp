@@ -270,10 +270,10 @@ EMU_API int emu_dwt2_fwd_stream(const float* in, int batch, int Nr, int Nc, cons
 
 EMU_API int emu_dwt2_fwd_fast(const float* in, int batch, int Nr, int Nc, const float* lo, const float* hi, int hlen,
                               int tile, float* A, float* H, float* V, float* D) {
-    if ((hlen & 1) || (Nc & 3)) return -2;
+    if (hlen & 1) return -2;  // any width: rows that are not whole quads take the unaligned staging / element stores
     Fwd2DFastArgs a;
     a.in = in; a.A = A; a.H = H; a.V = V; a.D = D;
-    a.Nr = Nr; a.Nc = Nc; a.Nr2 = (Nr + 1) / 2; a.Nc2 = Nc / 2;
+    a.Nr = Nr; a.Nc = Nc; a.Nr2 = (Nr + 1) / 2; a.Nc2 = (Nc + 1) / 2;
     a.in_bstride = (long long)Nr * Nc; a.out_bstride = (long long)a.Nr2 * a.Nc2;
     set_bank_i(a.fb, lo, hi, hlen);
     switch (hlen) {
@@ -286,7 +286,7 @@ EMU_API int emu_dwt2_fwd_fast(const float* in, int batch, int Nr, int Nc, const 
 
 EMU_API int emu_dwt2_inv_fast(const float* A, const float* H, const float* V, const float* D, int batch, int Nrc,
                               int Ncc, int Nr, int Nc, const float* lo, const float* hi, int hlen, int tile, float* out) {
-    if ((hlen & 1) || (Ncc & 3) || Nc != 2 * Ncc) return -2;
+    if ((hlen & 1) || Nc > 2 * Ncc || Nc < 2 * Ncc - 1) return -2;
     Inv2DFastArgs a;
     a.A = A; a.H = H; a.V = V; a.D = D; a.out = out;
     a.Nrc = Nrc; a.Ncc = Ncc; a.Nr = Nr; a.Nc = Nc;
