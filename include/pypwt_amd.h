@@ -148,6 +148,10 @@ int pdwt_set_filters_inverse(pdwt_handle h, const pdwt_real* filter1, const pdwt
 int pdwt_get_info(pdwt_handle h, pdwt_info* info, int* do_separable, int* do_cycle_spinning, int* state,
                   int* batch);
 int pdwt_print_info(pdwt_handle h);                       /* print_informations, wt.cu:511-550 */
+/* NEW: the plan's launch lists as text, one line per direction: "fwd: LEVEL[1] LEVEL[2] PYR2[3-4]" (kind[levels]); what the
+ * reference decides with if/else at every call (wt.cu:236-305) is decided once per plan here (plan.cpp: build_schedule).
+ * Returns the length written (excluding the terminator) or a negative status. */
+int pdwt_schedule_string(pdwt_handle h, char* buf, size_t n);
 int pdwt_info_string(pdwt_handle h, char* buf, size_t n); /* same text into a buffer */
 int pdwt_current_shift(pdwt_handle h, int* sr, int* sc);
 const char* pdwt_last_error(void);

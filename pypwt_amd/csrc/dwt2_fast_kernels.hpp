@@ -52,6 +52,24 @@ static __device__ __forceinline__ f32x4 ld_f4_unaligned(const float* p) {
 }
 #endif
 
+// 16-B / 8-B stores at 4-B alignment
+#ifdef PDWT_CPU_EMU
+static inline void st_f4_unaligned(float* p, float a, float b, float c, float d) { p[0] = a; p[1] = b; p[2] = c; p[3] = d; }
+static inline void st_f2_unaligned(float* p, float a, float b) { p[0] = a; p[1] = b; }
+#else
+typedef float pdwt_f2u __attribute__((ext_vector_type(2), aligned(4)));
+static __device__ __forceinline__ void st_f4_unaligned(float* p, float a, float b, float c, float d) {
+    pdwt_f4u v;
+    v.x = a; v.y = b; v.z = c; v.w = d;
+    *reinterpret_cast<pdwt_f4u*>(p) = v;
+}
+static __device__ __forceinline__ void st_f2_unaligned(float* p, float a, float b) {
+    pdwt_f2u v;
+    v.x = a; v.y = b;
+    *reinterpret_cast<pdwt_f2u*>(p) = v;
+}
+#endif
+
 // Block renumbering: hardware deals consecutive workgroup ids round-robin over the 8 XCDs, so
 // ids b and b+8 share an L2.  Give XCD x the contiguous tile range [x*chunk, (x+1)*chunk) (row-major),
 // i.e. a horizontal band of the image, so vertically adjacent tiles (which share halo rows) meet
@@ -183,15 +201,16 @@ PDWT_DEVICE void fwd_fast_col_pass(int tid, const v2f* tLH, const Fwd2DFastArgs&
 #pragma unroll
         for (int i = 0; i < R; ++i) {
             const int oy = by * TY + ty0 + i;
-            if (oy < a.Nr2) {
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    if (ox + e < a.Nc2) {
-                        const long long o = boff + (long long)oy * a.Nc2 + ox + e;
-                        a.A[o] = accAV[i][e].x; a.V[o] = accAV[i][e].y;
-                        a.H[o] = accHD[i][e].x; a.D[o] = accHD[i][e].y;
-                    }
-                }
+            if (oy < a.Nr2 && ox + 1 < a.Nc2) {  // both columns inside: 8-B stores at 4-B alignment
+                const long long o = boff + (long long)oy * a.Nc2 + ox;
+                st_f2_unaligned(a.A + o, accAV[i][0].x, accAV[i][1].x);
+                st_f2_unaligned(a.V + o, accAV[i][0].y, accAV[i][1].y);
+                st_f2_unaligned(a.H + o, accHD[i][0].x, accHD[i][1].x);
+                st_f2_unaligned(a.D + o, accHD[i][0].y, accHD[i][1].y);
+            } else if (oy < a.Nr2 && ox < a.Nc2) {  // the last column of an odd row
+                const long long o = boff + (long long)oy * a.Nc2 + ox;
+                a.A[o] = accAV[i][0].x; a.V[o] = accAV[i][0].y;
+                a.H[o] = accHD[i][0].x; a.D[o] = accHD[i][0].y;
             }
         }
         return;
@@ -569,9 +588,13 @@ PDWT_DEVICE void inv_fast_row_pass(int tid, const v2f* tt, const Inv2DFastArgs& 
         if ((a.Nc & 3) || (a.out_bstride & 3)) {  // output rows of any length: element stores, each inside the row
             if (oy < a.Nr) {
                 float* PDWT_RESTRICT orow = out + (long long)oy * a.Nc;
+                if (ox + 3 < a.Nc) {
+                    st_f4_unaligned(orow + ox, res[0], res[1], res[2], res[3]);  // 16 B at 4-B alignment
+                } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (ox + e < a.Nc) orow[ox + e] = res[e];
+                    for (int e = 0; e < 4; ++e)
+                        if (ox + e < a.Nc) orow[ox + e] = res[e];
+                }
             }
         } else if (oy < a.Nr && ox < a.Nc) {  // Nc % 4 == 0: the float4 is inside and aligned
             f32x4 v;

@@ -1475,6 +1475,27 @@ int pdwt_time_level(pdwt_handle h, int level, int inverse, int reps, float* ms_p
     return rc;
 }
 
+int pdwt_schedule_string(pdwt_handle h, char* buf, size_t n) {
+    CHECK_HANDLE(h);
+    if (!buf || n == 0) return fail(PDWT_ERR_ARG, "pdwt_schedule_string: no buffer");
+    static const char* kind[] = {"LEVEL", "PYR2", "STRIP2", "FUSED1D", "WAVE2", "REG1D", "SWTF", "PYR3", "CHAIN"};
+    std::string out;
+    for (int dir = 0; dir < 2; dir++) {
+        out += dir ? "inv:" : "fwd:";
+        for (const pdwt::Step& s : dir ? h->sched_inv : h->sched_fwd) {
+            char t[64];
+            if (s.K > 1) snprintf(t, sizeof t, " %s[%d-%d]", kind[s.kind], s.level, s.level + s.K - 1);
+            else snprintf(t, sizeof t, " %s[%d]", kind[s.kind], s.level);
+            out += t;
+        }
+        out += "\n";
+    }
+    const size_t m = out.size() < n - 1 ? out.size() : n - 1;
+    memcpy(buf, out.data(), m);
+    buf[m] = 0;
+    return (int)m;
+}
+
 int pdwt_wait_for_stream(pdwt_handle h, void* producer_stream) {
     CHECK_HANDLE(h);
     DeviceGuard guard(h->device);

@@ -574,6 +574,12 @@ class BatchedWavelets(object):
     def set_stream(self, stream_ptr):
         check(self._lib.pdwt_set_stream(self._h, C.c_void_p(stream_ptr)))
 
+    def schedule(self):
+        """The plan's launch lists ("fwd: ...", "inv: ..."), decided once at creation (plan.cpp: build_schedule)."""
+        buf = C.create_string_buffer(4096)
+        check(self._lib.pdwt_schedule_string(self._h, buf, len(buf)))
+        return buf.value.decode()
+
     def enable_kernel_timing(self, on=True):
         check(self._lib.pdwt_enable_kernel_timing(self._h, 1 if on else 0))
 
