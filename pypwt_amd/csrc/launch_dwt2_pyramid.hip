@@ -9,6 +9,8 @@
 //      4096^2        33.6 us           40.3 us  (slower: 1.9x recomputed halo, half the occupancy)
 #include "dwt2_pyramid_kernels.hpp"
 #include "dwt2_strip_kernels.hpp"
+#include <cstdlib>
+
 #include "launch.hpp"
 #include "launch_util.hpp"
 
@@ -144,6 +146,8 @@ static hipError_t run_inv_strip(InvStrip2Args& a, int batch, hipStream_t s) {
     static_assert(lds <= 64 * 1024, "fits the default dynamic-LDS limit");
     a.strips = cdiv(a.N0c / 2, TX);
     int seg = 512;  // output rows per workgroup; one 16-row warm-up chunk per segment
+    static const int forced = getenv("PDWT_ISTRIP_SEG") ? atoi(getenv("PDWT_ISTRIP_SEG")) : 0;  // A/B measurements
+    if (forced > 0) seg = forced;
     while (seg > 64 && (long long)a.strips * cdiv(a.N0r, seg) * batch < 1024) seg >>= 1;
     a.seg_rows = seg;
     a.segs = cdiv(a.N0r, seg);
