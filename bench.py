@@ -440,7 +440,7 @@ def beyond_mall(cfg, device, steps):
             "frac_of_hbm_peak": bytes_step / dt / 1e9 / HBM_PEAK_GBPS}
 
 
-def dry_run(args, rank, world, dist, backend):
+def dry_run(args, rank, world, dist, backend, out_stream=None):
     """No GPU: sleep-based steps so the launch / barrier / max-over-ranks / JSON path is testable
     with gloo on CPU."""
     cfg = CONFIGS[args.config]
@@ -449,24 +449,35 @@ def dry_run(args, rank, world, dist, backend):
                       before_closing_barrier=lambda: time.sleep(1e-3 * rank * args.dry_run_barrier_skew_ms))
     if rank == 0:
         samples = total * cfg[0] * cfg[1]
-        print(json.dumps({"metric": "dry_run", "value": samples / (dt / args.steps) / 1e6, "unit": "Msamples/s",
+        print(file=out_stream or sys.stdout, flush=True, *[json.dumps({"metric": "dry_run", "value": samples / (dt / args.steps) / 1e6, "unit": "Msamples/s",
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
                           "vs_baseline": None, "dtype": "f32", "data": "none (dry run)",
                           "config": {"workload": "dry-run", "shard_rank0": [first, first + B],
-                                     "images_per_step": total, "timed_region_ms": dt * 1e3}}))
+                                     "images_per_step": total, "timed_region_ms": dt * 1e3}})])
+
+
+def claim_stdout():
+    """Rank 0 must print ONE JSON line.  Libraries write to file descriptor 1 behind Python's back (RCCL prints a
+    version banner when the communicator is built, the HIP runtime an occasional warning): point fd 1 at stderr for
+    the whole run and return a file object on the ORIGINAL stdout for the JSON line."""
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    return os.fdopen(saved, "w")
 
 
 def main():
     args = parse_args()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(self_launch(args))  # before any GPU / torch activity in this process
+    out_stream = claim_stdout()
     rank, world, local_rank, dist, backend = init_dist(args)
     if args.gpus != world and rank == 0:
         print("warning: --gpus %d but WORLD_SIZE %d; running %d rank(s) and reporting n_gpus = %d"
               % (args.gpus, world, world, world), file=sys.stderr)
     if args.dry_run:
-        dry_run(args, rank, world, dist, backend)
+        dry_run(args, rank, world, dist, backend, out_stream)
         if dist is not None:
             dist.destroy_process_group()
         return
@@ -565,7 +576,7 @@ def main():
     # HBM bytes per launch of that kernel from the rocprofv3 PMC passes of this same command
     # (FETCH_SIZE x2 + WRITE_SIZE, collected separately; tools/prof.sh + tools/summarize_pmc.py).
     # Counters cannot be read from inside the process, so the committed measurement is quoted.
-    for tag in ("r02", "r01"):
+    for tag in ("r03", "r02", "r01"):
         tpath = os.path.join(ROOT, "profiles", "%s_traffic_%s.json" % (tag, args.config))
         if B == 1 and os.path.exists(tpath):
             try:
@@ -631,7 +642,7 @@ def main():
                 extra["beyond_infinity_cache"] = {"error": repr(e)}
         out["extra"] = extra
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), file=out_stream, flush=True)
     plan.cleanup()
     if dist is not None:
         dist.destroy_process_group()

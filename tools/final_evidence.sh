@@ -16,10 +16,18 @@ done
 timeout 400 python3 bench.py --config cfg5 --no-extras > "$OUT/bench_cfg5_shard.json" 2> "$OUT/bench_cfg5.err" || echo "bench cfg5 exit $?"
 timeout 400 python3 bench.py --config cfg2 --batch 16 --no-extras > "$OUT/bench_cfg2_b16.json" 2> "$OUT/bench_cfg2_b16.err" || echo "bench b16 exit $?"
 timeout 300 python3 bench.py > "$OUT/bench_default.json" 2> "$OUT/bench_default.err" || echo "bench default exit $?"
+WORLD_SIZE=1 RANK=0 LOCAL_RANK=0 MASTER_ADDR=127.0.0.1 MASTER_PORT=29544 timeout 300 python3 bench.py --force-dist --dist-backend nccl --no-extras > "$OUT/bench_nccl_world1.json" 2> "$OUT/bench_nccl_world1.err" || echo "nccl world1 exit $?"
+timeout 900 python3 tools/refbench.py > "$OUT/refbench.txt" 2> "$OUT/refbench.err" || echo "refbench exit $?"
+timeout 300 python3 tools/dispatch_table.py > "$OUT/dispatch_table.md" 2> /dev/null || echo "dispatch table exit $?"
+timeout 300 python3 tools/oddtime.py > "$OUT/oddtime.txt" 2> /dev/null || echo "oddtime exit $?"
 export TMPDIR=/tmp
+tools/prof.sh "${TAG}_cfg2_b16" --config cfg2 --batch 16 > "$OUT/prof_cfg2_b16.log" 2>&1 || echo "prof b16 exit $?"
+python3 tools/summarize_pmc.py "gpurun_out/prof_${TAG}_cfg2_b16" "$OUT/traffic_cfg2_b16.json" cfg2 > "$OUT/rocprofv3_summary_cfg2_b16.txt" 2>&1 || echo "summarize b16 exit $?"
+rm -rf "gpurun_out/prof_${TAG}_cfg2_b16"
 for c in cfg2 cfg3 cfg4; do
     tools/prof.sh "${TAG}_$c" --config $c > "$OUT/prof_$c.log" 2>&1 || echo "prof $c exit $?"
     python3 tools/summarize_pmc.py "gpurun_out/prof_${TAG}_$c" "$OUT/traffic_$c.json" $c > "$OUT/rocprofv3_summary_$c.txt" 2>&1 || echo "summarize $c exit $?"
     cp "$(ls gpurun_out/prof_${TAG}_$c/stats/*/*kernel_stats.csv | head -1)" "$OUT/kernel_stats_$c.csv" || true
+    rm -rf "gpurun_out/prof_${TAG}_$c"
 done
 echo done
