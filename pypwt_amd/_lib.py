@@ -9,6 +9,18 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libpypwt_amd.so")          # fp32 build (pdwt_real = float)
 LIB_PATH_F64 = os.path.join(HERE, "libpypwt_amd_f64.so")  # fp64 build (-DPDWT_DOUBLE, pdwt_real = double)
+# test-only fp32 build that also holds the experiment kernels the product does not ship (-DPDWT_LAB_KERNELS, build.py)
+LIB_PATH_LAB = os.path.join(HERE, "libpypwt_amd_lab.so")
+_f32_alias = "f32"
+
+
+def use_lab_kernels(on=True):
+    """Tests of the experiment kernels: every later request for the fp32 library (``load()``, ``Wavelets``,
+    ``BatchedWavelets``) is served by libpypwt_amd_lab.so.  Returns the previous setting."""
+    global _f32_alias
+    prev = _f32_alias == "lab"
+    _f32_alias = "lab" if on else "f32"
+    return prev
 
 f32p = C.POINTER(C.c_float)
 handle_t = C.c_void_p
@@ -92,9 +104,11 @@ _libs = {}
 def load(variant="f32"):
     """Load libpypwt_amd.so ("f32") or libpypwt_amd_f64.so ("f64") and declare every prototype.
     Raises if the library is absent."""
+    if variant == "f32":
+        variant = _f32_alias
     if variant in _libs:
         return _libs[variant]
-    path, real = {"f32": (LIB_PATH, C.c_float), "f64": (LIB_PATH_F64, C.c_double)}[variant]
+    path, real = {"f32": (LIB_PATH, C.c_float), "f64": (LIB_PATH_F64, C.c_double), "lab": (LIB_PATH_LAB, C.c_float)}[variant]
     if not os.path.exists(path):
         raise ImportError(
             "pypwt_amd: %s is missing. Build it with `python -m pypwt_amd.build` (needs hipcc). "

@@ -19,10 +19,15 @@ ROOT = os.path.dirname(HERE)
 OBJ = os.path.join(ROOT, "build", "obj")
 LIB = os.path.join(HERE, "libpypwt_amd.so")
 LIB_F64 = os.path.join(HERE, "libpypwt_amd_f64.so")
+# the product libraries hold what is dispatched; kernels that were built, tested and measured slower (two levels per
+# wavefront, inverse streaming strips, 8-B-lane SWT inverse, levels chained inside one launch) are compiled into a third,
+# test-only library so that their parity tests keep running and they can be re-measured: -DPDWT_LAB_KERNELS
+LIB_LAB = os.path.join(HERE, "libpypwt_amd_lab.so")
 # (object directory, library, extra flags, sources left out) per variant; of the tuned kernels the fp64 build
 # has the register kernels only (2D DWT levels, 1D DWT level triples, fused 2-tap SWT groups) and the small-image pyramid
 VARIANTS = {
-    "f32": (OBJ, LIB, [], ()),
+    "f32": (OBJ, LIB, [], ("launch_dwt2_chain.hip",)),
+    "lab": (os.path.join(ROOT, "build", "obj_lab"), LIB_LAB, ["-DPDWT_LAB_KERNELS"], ()),
     "f64": (os.path.join(ROOT, "build", "obj_f64"), LIB_F64, ["-DPDWT_DOUBLE"],
             ("launch_dwt2_fast.hip", "launch_dwt2_pyramid.hip", "launch_dwt1_fused.hip", "launch_dwt2_chain.hip")),
 }
@@ -101,7 +106,7 @@ def build_library(force=False, verbose=True, variant="f32"):
     if force:
         for f in os.listdir(objdir):
             os.remove(os.path.join(objdir, f))
-    with ThreadPoolExecutor(max_workers=min(os.cpu_count() or 4, len(srcs))) as ex:
+    with ThreadPoolExecutor(max_workers=min(max(2, (os.cpu_count() or 4) // 2), len(srcs))) as ex:
         objs = list(ex.map(_compile, [(s, objdir, extra) for s in srcs]))
     cmd = [hipcc(), "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", lib] + objs
     r = subprocess.run(cmd, capture_output=True, text=True)
@@ -114,8 +119,8 @@ def build_library(force=False, verbose=True, variant="f32"):
 
 def build_all(force=False, verbose=True):
     """Both variants; their translation units share one pool of compiler processes."""
-    with ThreadPoolExecutor(max_workers=2) as ex:
-        return list(ex.map(lambda v: build_library(force, verbose, v), ("f32", "f64")))
+    with ThreadPoolExecutor(max_workers=3) as ex:
+        return list(ex.map(lambda v: build_library(force, verbose, v), ("f32", "f64", "lab")))
 
 
 if __name__ == "__main__":

@@ -55,13 +55,6 @@ hipError_t launch_dwt2_inv_strip2(const real_t* const[4], const real_t* const[3]
                                   const FilterBank&, int, hipStream_t) { return hipErrorNotSupported; }
 hipError_t launch_dwt2_inv_pyr2(const real_t* const[4], const real_t* const[3], real_t*, int, int, int,
                                 const FilterBank&, int, hipStream_t) { return hipErrorNotSupported; }
-bool dwt2_chain_supported(int, int, int, int) { return false; }
-int dwt2_chain_tiles(int, int, int) { return 0; }
-int set_chain_timeout(int) { return 0; }
-hipError_t launch_dwt2_fwd_chain(const real_t*, real_t* const*, real_t* const*, int, int, int, int, const FilterBank&, int, unsigned*,
-                                 unsigned, hipStream_t) { return hipErrorNotSupported; }
-hipError_t launch_dwt2_inv_chain(real_t*, real_t* const*, real_t* const*, int, int, int, int, const FilterBank&, int, unsigned*,
-                                 unsigned, hipStream_t) { return hipErrorNotSupported; }
 int dwt1_fused_max_levels(int) { return 1; }
 bool dwt1_fused_supported(int, int, int) { return false; }
 hipError_t launch_dwt1_fwd_fused(const real_t*, real_t* const*, real_t*, int, int, int, int, const FilterBank&,
@@ -71,6 +64,17 @@ hipError_t launch_dwt1_inv_fused(const real_t*, const real_t* const*, real_t*, i
 constexpr int kTyLong = 8;   // long filters: a 32-row tile of doubles would not fit the 160 KB of LDS
 #else
 constexpr int kTyLong = 32;
+#endif
+
+#if defined(PDWT_DOUBLE) || !defined(PDWT_LAB_KERNELS)
+// levels chained inside one launch (launch_dwt2_chain.hip): an experiment that measured no faster, LAB build only
+bool dwt2_chain_supported(int, int, int, int) { return false; }
+int dwt2_chain_tiles(int, int, int) { return 0; }
+int set_chain_timeout(int) { return 0; }
+hipError_t launch_dwt2_fwd_chain(const real_t*, real_t* const*, real_t* const*, int, int, int, int, const FilterBank&, int, unsigned*,
+                                 unsigned, hipStream_t) { return hipErrorNotSupported; }
+hipError_t launch_dwt2_inv_chain(real_t*, real_t* const*, real_t* const*, int, int, int, int, const FilterBank&, int, unsigned*,
+                                 unsigned, hipStream_t) { return hipErrorNotSupported; }
 #endif
 
 // The wave-per-tile kernels take the levels that are large enough to be bandwidth-bound (>= 2^22 samples

@@ -139,6 +139,7 @@ hipError_t launch_dwt2_fwd_strip2(const float* in, float* const det1[3], float* 
     return hipErrorNotSupported;
 }
 
+#ifdef PDWT_LAB_KERNELS  // the inverse strips never beat two launches: LAB build only
 template <int HLEN>
 static hipError_t run_inv_strip(InvStrip2Args& a, int batch, hipStream_t s) {
     constexpr int TX = 64, NT = 256;
@@ -178,6 +179,11 @@ hipError_t launch_dwt2_inv_strip2(const float* const band2[4], const float* cons
     }
     return hipErrorNotSupported;
 }
+
+#else
+hipError_t launch_dwt2_inv_strip2(const float* const[4], const float* const[3], float*, int, int, int, const FilterBank&, int,
+                                  hipStream_t) { return hipErrorNotSupported; }
+#endif  // PDWT_LAB_KERNELS
 
 hipError_t launch_dwt2_inv_pyr2(const float* const band2[4], const float* const det1[3], float* out, int N0r, int N0c,
                                 int hlen, const FilterBank& fb, int batch, hipStream_t s) {

@@ -92,8 +92,9 @@ static hipError_t run_inv(const Inv2DArgs& g, int batch, int seg_hint, hipStream
     return hipGetLastError();
 }
 
-#ifndef PDWT_DOUBLE
-// ---- two forward levels per wavefront (dwt2_fwd2_wave): same contract as launch_dwt2_fwd_pyr2
+#if !defined(PDWT_DOUBLE) && defined(PDWT_LAB_KERNELS)
+// ---- two forward levels per wavefront (dwt2_fwd2_wave): same contract as launch_dwt2_fwd_pyr2.  An experiment that measured
+// slower than two launches: compiled into the LAB build only (libpypwt_amd_lab.so, -DPDWT_LAB_KERNELS), not into the product
 bool dwt2_wave2_supported(int hlen, int N0r, int N0c) {
     return !(hlen & 1) && hlen >= 2 && hlen <= 8 && (N0r % 4) == 0 && (N0c % 16) == 0 && N0r >= 4 && N0c >= 16 &&
            (long long)N0r * N0c < (1LL << 30);  // 32-bit byte offsets inside one image
@@ -137,7 +138,11 @@ hipError_t launch_dwt2_fwd_wave2(const float* in, float* const det1[3], float* c
     }
     return hipErrorNotSupported;
 }
-#endif  // !PDWT_DOUBLE
+#elif !defined(PDWT_DOUBLE)
+bool dwt2_wave2_supported(int, int, int) { return false; }
+hipError_t launch_dwt2_fwd_wave2(const float*, float* const[3], float* const[4], int, int, int, const FilterBank&, int, hipStream_t,
+                                 int) { return hipErrorNotSupported; }
+#endif
 
 hipError_t try_launch_dwt2_fwd_wave(const Fwd2DArgs& a, int batch, hipStream_t s, int seg_hint) {
     if ((a.hlen & 1) || a.hlen < 2 || a.hlen > 8) return hipErrorNotSupported;

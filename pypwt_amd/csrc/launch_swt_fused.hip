@@ -62,9 +62,14 @@ static hipError_t run(SwtFusedArgs& a, bool inverse, int batch, hipStream_t s) {
         // built to afford longer segments for ONE image and measured no better: 2048^2 levels 1-3 49.1-51.8 us at
         // 24-64 rows against 47.8 us (16-B lanes, 24 rows), levels 4-5 39.9-42.1 against 35.1-37.0 us
         // (profiles/r02y_bench_cfg4_lanes_sweep.txt).  PDWT_SWT_CPL=2 selects them for re-measurement.
+#if defined(PDWT_DOUBLE)
+        return run_inv<K, F0, 2>(a, batch, s);  // fp64: two doubles per lane (the four-column lanes need > 512 registers)
+#elif defined(PDWT_LAB_KERNELS)
         static const int forced = [] { const char* e = getenv("PDWT_SWT_CPL"); return e ? atoi(e) : 0; }();
-        const bool narrow = forced == 2 || sizeof(real_t) == 8;  // fp64: two doubles per lane (the four-column lanes need > 512 registers)
-        return narrow ? run_inv<K, F0, 2>(a, batch, s) : run_inv<K, F0, 4>(a, batch, s);
+        return forced == 2 ? run_inv<K, F0, 2>(a, batch, s) : run_inv<K, F0, 4>(a, batch, s);
+#else
+        return run_inv<K, F0, 4>(a, batch, s);
+#endif
     }
     a.strips = cdiv(a.Nc, 4 * G::V);
     const int rows_phase = a.Nr / F0;

@@ -305,7 +305,8 @@ def test_cfg4_swt_2048_haar_L5_soft_threshold_full_size(W):
 def test_strip_paths_match_oracle(wname, monkeypatch):
     """The streaming-strip kernels (two levels per launch, used for batches of large images) forced on
     small inputs: coefficients and reconstruction must equal the oracle's and the per-level path's."""
-    from pypwt_amd import BatchedWavelets
+    from pypwt_amd import BatchedWavelets, _lib
+    was_lab = _lib.use_lab_kernels(True)  # the inverse strips are an experiment: libpypwt_amd_lab.so
     monkeypatch.setenv("PDWT_FORCE_STRIP", "1")
     B, shape, L = 3, (136, 272), 3
     x = oracle.hash_input((B,) + shape, 4242, scale=255.0)
@@ -328,6 +329,7 @@ def test_strip_paths_match_oracle(wname, monkeypatch):
             assert np.abs(got[k][b] - r).max() <= tol, (wname, b, k)
             assert np.abs(got[k][b] - w2.coeff(k)[b]).max() <= tol, (wname, b, k)
     w2.inverse()
+    _lib.use_lab_kernels(was_lab)
     assert np.abs(rec - x).max() <= 2e-3
     assert np.abs(rec - w2.image).max() <= 1e-3
 
@@ -513,3 +515,26 @@ def test_cfg5_shard(B):
     bw.forward()
     check_image_against_digests(B - 1)
     bw.cleanup()
+
+
+@pytest.mark.gpu
+def test_cfg2_default_dispatch_every_element_vs_oracle():
+    """BASELINE config 2 at full size with the DEFAULT dispatch of the PRODUCT library (whatever it is this round): every
+    coefficient of every band against the oracle, then the reconstruction."""
+    from pypwt_amd import BatchedWavelets, _lib
+    was_lab = _lib.use_lab_kernels(False)  # the PRODUCT library, whatever another module's fixture selected
+    oracle.build()
+    plan = BatchedWavelets(1, 4096, 4096, "db4", 4)
+    _lib.use_lab_kernels(was_lab)
+    plan.fill_hash(20242, 255.0)
+    x = oracle.hash_input((4096, 4096), 20242)
+    names = plan.schedule()
+    plan.forward()
+    ref = oracle.forward(x, "db4", 4)
+    for num, r in enumerate(ref):
+        g = plan.coeff_at(num, 0)
+        err = np.abs(g - r).max()
+        assert err <= 1.5e-6 * 5 * max(np.abs(r).max(), 1.0), (names, num, err)
+    plan.inverse()
+    assert np.abs(plan.image_at(0) - x).max() <= 2e-5 * 255, names
+    plan.cleanup()

@@ -25,6 +25,7 @@ def _short_wavelets():
 @pytest.fixture(scope="module", autouse=True)
 def forced_wave():
     from pypwt_amd import _lib
+    was_lab = _lib.use_lab_kernels(True)  # the two-levels-per-wavefront kernel is an experiment: libpypwt_amd_lab.so
     lib = _lib.load()
     import os
     prev = lib.pdwt_set_tuning(b"wave_min_log2", 0)
@@ -37,6 +38,7 @@ def forced_wave():
     lib.pdwt_set_tuning(b"wave_min_log2", prev)
     lib.pdwt_set_tuning(b"lds_max_log2", prev_lds)
     lib.pdwt_set_tuning(b"wave2", prev2)
+    _lib.use_lab_kernels(was_lab)
 
 
 def _flat(c):
