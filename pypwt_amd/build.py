@@ -29,7 +29,7 @@ VARIANTS = {
     "f32": (OBJ, LIB, [], ("launch_dwt2_chain.hip",)),
     "lab": (os.path.join(ROOT, "build", "obj_lab"), LIB_LAB, ["-DPDWT_LAB_KERNELS"], ()),
     "f64": (os.path.join(ROOT, "build", "obj_f64"), LIB_F64, ["-DPDWT_DOUBLE"],
-            ("launch_dwt2_fast.hip", "launch_dwt2_pyramid.hip", "launch_dwt1_fused.hip", "launch_dwt2_chain.hip")),
+            ("launch_dwt2_pyramid.hip", "launch_dwt1_fused.hip", "launch_dwt2_chain.hip")),
 }
 
 SOURCES = [

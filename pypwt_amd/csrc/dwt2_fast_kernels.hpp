@@ -22,8 +22,8 @@
 namespace pdwt {
 
 struct Fwd2DFastArgs {
-    const float* in;
-    float *A, *H, *V, *D;
+    const real_t* in;
+    real_t *A, *H, *V, *D;
     int Nr, Nc, Nr2, Nc2;
     long long in_bstride, out_bstride;
     int tiles_x, tiles_y;  // tile grid of one image
@@ -31,8 +31,8 @@ struct Fwd2DFastArgs {
 };
 
 struct Inv2DFastArgs {
-    const float *A, *H, *V, *D;
-    float* out;
+    const real_t *A, *H, *V, *D;
+    real_t* out;
     int Nrc, Ncc, Nr, Nc;
     long long in_bstride, out_bstride;
     int tiles_x, tiles_y;
@@ -41,12 +41,12 @@ struct Inv2DFastArgs {
 
 // 16-B load at 4-B alignment (rows of images whose width is not a multiple of 4): one global_load_dwordx4 on gfx950
 #ifdef PDWT_CPU_EMU
-static inline f32x4 ld_f4_unaligned(const float* p) { return f32x4{p[0], p[1], p[2], p[3]}; }
+static inline real4_t ld_f4_unaligned(const real_t* p) { return real4_t{p[0], p[1], p[2], p[3]}; }
 #else
-typedef float pdwt_f4u __attribute__((ext_vector_type(4), aligned(4)));
-static __device__ __forceinline__ f32x4 ld_f4_unaligned(const float* p) {
+typedef real_t pdwt_f4u __attribute__((ext_vector_type(4), aligned(sizeof(real_t))));
+static __device__ __forceinline__ real4_t ld_f4_unaligned(const real_t* p) {
     const pdwt_f4u v = *reinterpret_cast<const pdwt_f4u*>(p);
-    f32x4 r;
+    real4_t r;
     r.x = v.x; r.y = v.y; r.z = v.z; r.w = v.w;
     return r;
 }
@@ -54,16 +54,16 @@ static __device__ __forceinline__ f32x4 ld_f4_unaligned(const float* p) {
 
 // 16-B / 8-B stores at 4-B alignment
 #ifdef PDWT_CPU_EMU
-static inline void st_f4_unaligned(float* p, float a, float b, float c, float d) { p[0] = a; p[1] = b; p[2] = c; p[3] = d; }
-static inline void st_f2_unaligned(float* p, float a, float b) { p[0] = a; p[1] = b; }
+static inline void st_f4_unaligned(real_t* p, real_t a, real_t b, real_t c, real_t d) { p[0] = a; p[1] = b; p[2] = c; p[3] = d; }
+static inline void st_f2_unaligned(real_t* p, real_t a, real_t b) { p[0] = a; p[1] = b; }
 #else
-typedef float pdwt_f2u __attribute__((ext_vector_type(2), aligned(4)));
-static __device__ __forceinline__ void st_f4_unaligned(float* p, float a, float b, float c, float d) {
+typedef real_t pdwt_f2u __attribute__((ext_vector_type(2), aligned(sizeof(real_t))));
+static __device__ __forceinline__ void st_f4_unaligned(real_t* p, real_t a, real_t b, real_t c, real_t d) {
     pdwt_f4u v;
     v.x = a; v.y = b; v.z = c; v.w = d;
     *reinterpret_cast<pdwt_f4u*>(p) = v;
 }
-static __device__ __forceinline__ void st_f2_unaligned(float* p, float a, float b) {
+static __device__ __forceinline__ void st_f2_unaligned(real_t* p, real_t a, real_t b) {
     pdwt_f2u v;
     v.x = a; v.y = b;
     *reinterpret_cast<pdwt_f2u*>(p) = v;
@@ -99,15 +99,15 @@ constexpr int fwd2d_fast_lds_floats() {
 
 // row analysis of the staged tile: two adjacent outputs per thread, packed (L,H) accumulators
 template <int HLEN, int TX, int TY, int NT>
-PDWT_DEVICE void fwd_fast_row_pass(int tid, const float* sIn, v2f* tLH, const FilterBankI& fb) {
+PDWT_DEVICE void fwd_fast_row_pass(int tid, const real_t* sIn, v2f* tLH, const FilterBankI& fb) {
     using G = FwdFastGeom<HLEN, TX>;
     constexpr int PADL = G::PADL, RXA = G::RXA, NV = G::NV;
     constexpr int RY = 2 * TY + HLEN - 2;
     constexpr int HT = TX / 2;
     const int t = tid % HT;
     for (int r = tid / HT; r < RY; r += NT / HT) {
-        float v[NV];
-        const float* p4 = sIn + r * RXA + 4 * t;
+        real_t v[NV];
+        const real_t* p4 = sIn + r * RXA + 4 * t;
         v4f w[NV / 4];
 #pragma unroll
         for (int q = 0; q < NV / 4; ++q) w[q] = lds_load16(p4 + 4 * q);
@@ -119,19 +119,19 @@ PDWT_DEVICE void fwd_fast_row_pass(int tid, const float* sIn, v2f* tLH, const Fi
             v[4 * q + 2] = w[q].z;
             v[4 * q + 3] = w[q].w;
         }
-        v2f acc0 = mk2(0.f, 0.f), acc1 = mk2(0.f, 0.f);
+        v2f acc0 = mk2(real_t(0), real_t(0)), acc1 = mk2(real_t(0), real_t(0));
 #pragma unroll
         for (int j = 0; j < HLEN; ++j) {
             const v2f tap = fb.t[HLEN - 1 - j];
             acc0 = fma2(bc(v[PADL + j]), tap, acc0);
             acc1 = fma2(bc(v[PADL + 2 + j]), tap, acc1);
         }
-        f32x4 o;
+        real4_t o;
         o.x = acc0.x;
         o.y = acc0.y;
         o.z = acc1.x;
         o.w = acc1.y;
-        *reinterpret_cast<f32x4*>(&tLH[r * TX + 2 * t]) = o;
+        *reinterpret_cast<real4_t*>(&tLH[r * TX + 2 * t]) = o;
     }
 }
 
@@ -149,7 +149,7 @@ PDWT_DEVICE void fwd_fast_col_pass(int tid, const v2f* tLH, const Fwd2DFastArgs&
     const int ox = bx * TX + 2 * t;
     v2f accAV[R][2], accHD[R][2];
 #pragma unroll
-    for (int i = 0; i < R; ++i) accAV[i][0] = accAV[i][1] = accHD[i][0] = accHD[i][1] = mk2(0.f, 0.f);
+    for (int i = 0; i < R; ++i) accAV[i][0] = accAV[i][1] = accHD[i][0] = accHD[i][1] = mk2(real_t(0), real_t(0));
     constexpr int NRW = 2 * R + HLEN - 2, GB = 12;  // LDS loads are issued GB at a time, then consumed
 #pragma unroll
     for (int r0 = 0; r0 < NRW; r0 += GB) {
@@ -185,14 +185,14 @@ PDWT_DEVICE void fwd_fast_col_pass(int tid, const v2f* tLH, const Fwd2DFastArgs&
         for (int i = 0; i < R; ++i) {
             const int oy = by * TY + ty0 + i;
             const long long o = (long long)oy * a.Nc2 + ox;
-            f32x4 q;
+            real4_t q;
             q.x = accAV[i][0].x; q.y = accAV[i][1].x;
             q.z = __shfl_xor(accAV[i][0].x, 1); q.w = __shfl_xor(accAV[i][1].x, 1);
             if (!(tid & 1)) coh_store16(pa, o, q);
-            f32x2 v;
-            v.x = accAV[i][0].y; v.y = accAV[i][1].y; *reinterpret_cast<f32x2*>(a.V + boff + o) = v;
-            v.x = accHD[i][0].x; v.y = accHD[i][1].x; *reinterpret_cast<f32x2*>(a.H + boff + o) = v;
-            v.x = accHD[i][0].y; v.y = accHD[i][1].y; *reinterpret_cast<f32x2*>(a.D + boff + o) = v;
+            real2_t v;
+            v.x = accAV[i][0].y; v.y = accAV[i][1].y; *reinterpret_cast<real2_t*>(a.V + boff + o) = v;
+            v.x = accHD[i][0].x; v.y = accHD[i][1].x; *reinterpret_cast<real2_t*>(a.H + boff + o) = v;
+            v.x = accHD[i][0].y; v.y = accHD[i][1].y; *reinterpret_cast<real2_t*>(a.D + boff + o) = v;
         }
         return;
     }
@@ -220,11 +220,11 @@ PDWT_DEVICE void fwd_fast_col_pass(int tid, const v2f* tLH, const Fwd2DFastArgs&
         const int oy = by * TY + ty0 + i;
         if (oy < a.Nr2 && ox < a.Nc2) {  // Nc2 is even: ox + 1 is inside too
             const long long o = boff + (long long)oy * a.Nc2 + ox;
-            f32x2 v;
-            v.x = accAV[i][0].x; v.y = accAV[i][1].x; *reinterpret_cast<f32x2*>(a.A + o) = v;
-            v.x = accAV[i][0].y; v.y = accAV[i][1].y; *reinterpret_cast<f32x2*>(a.V + o) = v;
-            v.x = accHD[i][0].x; v.y = accHD[i][1].x; *reinterpret_cast<f32x2*>(a.H + o) = v;
-            v.x = accHD[i][0].y; v.y = accHD[i][1].y; *reinterpret_cast<f32x2*>(a.D + o) = v;
+            real2_t v;
+            v.x = accAV[i][0].x; v.y = accAV[i][1].x; *reinterpret_cast<real2_t*>(a.A + o) = v;
+            v.x = accAV[i][0].y; v.y = accAV[i][1].y; *reinterpret_cast<real2_t*>(a.V + o) = v;
+            v.x = accHD[i][0].x; v.y = accHD[i][1].x; *reinterpret_cast<real2_t*>(a.H + o) = v;
+            v.x = accHD[i][0].y; v.y = accHD[i][1].y; *reinterpret_cast<real2_t*>(a.D + o) = v;
         }
     }
 }
@@ -233,7 +233,7 @@ PDWT_DEVICE void fwd_fast_col_pass(int tid, const v2f* tLH, const Fwd2DFastArgs&
 // coh_in / coh_out (uniform, dwt2_chain_kernels.hpp): the input plane was written by other workgroups of THIS launch
 // (sc1 loads; needs the branch-free staging conditions) / the A band is read by other workgroups of this launch.
 template <int HLEN, int TX, int TY, int NT>
-PDWT_DEVICE void dwt2_fwd_fast_tile(const Fwd2DFastArgs& a, int bx, int by, int bz, float* smem, bool coh_in = false,
+PDWT_DEVICE void dwt2_fwd_fast_tile(const Fwd2DFastArgs& a, int bx, int by, int bz, real_t* smem, bool coh_in = false,
                                     bool coh_out = false) {
     using G = FwdFastGeom<HLEN, TX>;
     constexpr int C = G::C, PADL = G::PADL, RXA = G::RXA, NV = G::NV;
@@ -246,10 +246,10 @@ PDWT_DEVICE void dwt2_fwd_fast_tile(const Fwd2DFastArgs& a, int bx, int by, int 
     constexpr int R = TY / NG;         // output rows per thread (x 2 columns)
     static_assert(2 * TX - 4 + NV <= RXA, "row-pass reads stay inside the staged row");
 
-    float* sIn = smem;                                   // RY x RXA floats
+    real_t* sIn = smem;                                   // RY x RXA floats
     v2f* tLH = reinterpret_cast<v2f*>(smem + RY * RXA);  // RY x TX (L,H) pairs
 
-    const float* PDWT_RESTRICT in = a.in + (long long)bz * a.in_bstride;
+    const real_t* PDWT_RESTRICT in = a.in + (long long)bz * a.in_bstride;
     const int xa = 2 * bx * TX - C - PADL;  // multiple of 4
     const int y0 = 2 * by * TY - C;
 
@@ -270,8 +270,8 @@ PDWT_DEVICE void dwt2_fwd_fast_tile(const Fwd2DFastArgs& a, int bx, int by, int 
                 int sy = y0 + r, sx = xa + 4 * g;
                 sy = sy < 0 ? sy + a.Nr : (sy >= a.Nr ? sy - a.Nr : sy);
                 sx = sx < 0 ? sx + a.Nc : (sx >= a.Nc ? sx - a.Nc : sx);
-                const f32x4 v = coh_load16(pin, (long long)sy * a.Nc + sx);
-                *reinterpret_cast<f32x4*>(sIn + r * RXA + 4 * g) = v;
+                const real4_t v = coh_load16(pin, (long long)sy * a.Nc + sx);
+                *reinterpret_cast<real4_t*>(sIn + r * RXA + 4 * g) = v;
             }
         } else if (!(a.Nr & 1) && !(a.Nc & 3) && a.Nr >= RY && a.Nc >= RXA) {
 #pragma unroll
@@ -283,8 +283,8 @@ PDWT_DEVICE void dwt2_fwd_fast_tile(const Fwd2DFastArgs& a, int bx, int by, int 
                 int sy = y0 + r, sx = xa + 4 * g;  // Nc % 4 == 0: the group never straddles
                 sy = sy < 0 ? sy + a.Nr : (sy >= a.Nr ? sy - a.Nr : sy);
                 sx = sx < 0 ? sx + a.Nc : (sx >= a.Nc ? sx - a.Nc : sx);
-                const f32x4 v = *reinterpret_cast<const f32x4*>(in + (long long)sy * a.Nc + sx);
-                *reinterpret_cast<f32x4*>(sIn + r * RXA + 4 * g) = v;
+                const real4_t v = *reinterpret_cast<const real4_t*>(in + (long long)sy * a.Nc + sx);
+                *reinterpret_cast<real4_t*>(sIn + r * RXA + 4 * g) = v;
             }
         } else if (!(a.Nc & 3)) {
             for (int idx = tid; idx < RY * V4; idx += NT) {
@@ -292,8 +292,8 @@ PDWT_DEVICE void dwt2_fwd_fast_tile(const Fwd2DFastArgs& a, int bx, int by, int 
                 const int g = idx - r * V4;
                 const int sy = wrap_analysis(y0 + r, a.Nr);
                 const int sx = wrap_periodic(xa + 4 * g, a.Nc);
-                const f32x4 v = *reinterpret_cast<const f32x4*>(in + (long long)sy * a.Nc + sx);
-                *reinterpret_cast<f32x4*>(sIn + r * RXA + 4 * g) = v;
+                const real4_t v = *reinterpret_cast<const real4_t*>(in + (long long)sy * a.Nc + sx);
+                *reinterpret_cast<real4_t*>(sIn + r * RXA + 4 * g) = v;
             }
         } else {
             // Row length not a multiple of 4 (odd images, the reference takes them at no extra cost,
@@ -307,9 +307,9 @@ PDWT_DEVICE void dwt2_fwd_fast_tile(const Fwd2DFastArgs& a, int bx, int by, int 
                 idx = idx < TOTAL ? idx : TOTAL - 1;
                 const int r = idx / V4;
                 const int g = idx - r * V4;
-                const float* PDWT_RESTRICT rowp = in + (long long)wrap_analysis(y0 + r, a.Nr) * a.Nc;
+                const real_t* PDWT_RESTRICT rowp = in + (long long)wrap_analysis(y0 + r, a.Nr) * a.Nc;
                 const int sx = xa + 4 * g;
-                f32x4 v;
+                real4_t v;
                 if (sx >= 0 && sx + 3 < a.Nc) {
                     v = ld_f4_unaligned(rowp + sx);
                 } else {
@@ -318,7 +318,7 @@ PDWT_DEVICE void dwt2_fwd_fast_tile(const Fwd2DFastArgs& a, int bx, int by, int 
                     v.z = rowp[wrap_analysis(sx + 2, a.Nc)];
                     v.w = rowp[wrap_analysis(sx + 3, a.Nc)];
                 }
-                *reinterpret_cast<f32x4*>(sIn + r * RXA + 4 * g) = v;
+                *reinterpret_cast<real4_t*>(sIn + r * RXA + 4 * g) = v;
             }
         }
     }
@@ -346,11 +346,11 @@ PDWT_DEVICE void fwd_fast_issue_loads(int tid, const Fwd2DFastArgs& a, int bx, i
     constexpr int C = G::C, PADL = G::PADL, RXA = G::RXA;
     constexpr int RY = 2 * TY + HLEN - 2;
     constexpr int V4 = RXA / 4;
-    const float* PDWT_RESTRICT in = a.in + (long long)bz * a.in_bstride;
+    const real_t* PDWT_RESTRICT in = a.in + (long long)bz * a.in_bstride;
     const int xa = 2 * bx * TX - C - PADL, y0 = 2 * by * TY - C;
     const bool interior = xa >= 0 && xa + RXA <= a.Nc && y0 >= 0 && y0 + RY <= a.Nr;
     if (interior) {
-        const float* base = in + (long long)y0 * a.Nc + xa;
+        const real_t* base = in + (long long)y0 * a.Nc + xa;
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             const int idx = (tid + i * NT < RY * V4) ? tid + i * NT : RY * V4 - 1;
@@ -388,14 +388,14 @@ PDWT_DEVICE bool stream_pos(int q, int xcd, int chunk, int total, int batch, int
 }
 
 template <int HLEN, int TX, int TY, int NT>
-PDWT_DEVICE void dwt2_fwd_fast_stream(const Fwd2DFastArgs& a, int wg, int nwg, int batch, float* smem) {
+PDWT_DEVICE void dwt2_fwd_fast_stream(const Fwd2DFastArgs& a, int wg, int nwg, int batch, real_t* smem) {
     using G = FwdFastGeom<HLEN, TX>;
     constexpr int C = G::C, PADL = G::PADL, RXA = G::RXA;
     constexpr int RY = 2 * TY + HLEN - 2;
     constexpr int V4 = RXA / 4;
     constexpr int NLD = (RY * V4 + NT - 1) / NT;  // float4 loads per thread per tile
 
-    float* sIn = smem;
+    real_t* sIn = smem;
     v2f* tLH = reinterpret_cast<v2f*>(smem + RY * RXA);
 
     const int total = a.tiles_x * a.tiles_y;
@@ -469,7 +469,7 @@ template <int HLEN>
 PDWT_DEVICE void inv_col_synth2(const v2f* pAV, const v2f* pHD, int stride, const FilterBankI& fb, v2f& e0, v2f& o0,
                                 v2f& e1, v2f& o1) {
     constexpr int H2 = HLEN / 2;
-    e0 = mk2(0.f, 0.f);
+    e0 = mk2(real_t(0), real_t(0));
     o0 = e0; e1 = e0; o1 = e0;
     constexpr int GB = 6;  // 2 GB LDS loads are issued, then consumed
 #pragma unroll
@@ -503,7 +503,7 @@ PDWT_DEVICE void inv_col_synth2(const v2f* pAV, const v2f* pHD, int stride, cons
 // Row synthesis core: the (t1,t2) pairs from `base` (16-B aligned, PE = PADL & 1 pairs before the first
 // one used) -> the four samples 2k .. 2k+3 of coefficient columns k, k+1.
 template <int HLEN, int PADL>
-PDWT_DEVICE void inv_row_synth4(const v2f* base, const FilterBankI& fb, float res[4]) {
+PDWT_DEVICE void inv_row_synth4(const v2f* base, const FilterBankI& fb, real_t res[4]) {
     constexpr int H2 = HLEN / 2, S = (H2 & 1) ? 0 : 1;
     constexpr int PE = PADL & 1;
     constexpr int NP = (PE + H2 + 2 + 1) & ~1;
@@ -519,7 +519,7 @@ PDWT_DEVICE void inv_row_synth4(const v2f* base, const FilterBankI& fb, float re
     }
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {  // coefficient column k + kk -> samples 2(k+kk), 2(k+kk)+1
-        v2f r0 = mk2(0.f, 0.f), r1 = mk2(0.f, 0.f);
+        v2f r0 = mk2(real_t(0), real_t(0)), r1 = mk2(real_t(0), real_t(0));
         if (S == 0) {
 #pragma unroll
             for (int j = 0; j < H2; ++j) {
@@ -555,14 +555,14 @@ PDWT_DEVICE void inv_fast_col_pass(int tid, const v2f* sAV, const v2f* sHD, v2f*
         v2f e0, o0, e1, o1;  // p even / p odd, columns q / q+1
         inv_col_synth2<HLEN>(&sAV[m * CXA + q], &sHD[m * CXA + q], CXA, fb, e0, o0, e1, o1);
         const int ge = 2 * m - S, go = 2 * m + 1 - S;  // local output rows
-        f32x4 w;
+        real4_t w;
         if (ge >= 0 && ge < OY) {
             w.x = e0.x; w.y = e0.y; w.z = e1.x; w.w = e1.y;
-            *reinterpret_cast<f32x4*>(&tt[ge * CXA + q]) = w;
+            *reinterpret_cast<real4_t*>(&tt[ge * CXA + q]) = w;
         }
         if (go >= 0 && go < OY) {
             w.x = o0.x; w.y = o0.y; w.z = o1.x; w.w = o1.y;
-            *reinterpret_cast<f32x4*>(&tt[go * CXA + q]) = w;
+            *reinterpret_cast<real4_t*>(&tt[go * CXA + q]) = w;
         }
     }
 }
@@ -577,17 +577,17 @@ PDWT_DEVICE void inv_fast_row_pass(int tid, const v2f* tt, const Inv2DFastArgs& 
     constexpr int HT = TX / 2;
     constexpr int PE = PADL & 1;                // read origin rounded down to an even pair index
     constexpr int NP = (PE + H2 + 2 + 1) & ~1;  // (t1,t2) pairs read per thread
-    float* PDWT_RESTRICT out = a.out + (long long)bz * a.out_bstride;
+    real_t* PDWT_RESTRICT out = a.out + (long long)bz * a.out_bstride;
     for (int idx = tid; idx < OY * HT; idx += NT) {
         const int gy = idx / HT;
         const int k = 2 * (idx - gy * HT);
-        float res[4];
+        real_t res[4];
         inv_row_synth4<HLEN, PADL>(tt + gy * CXA + (PADL - PE) + k, a.fb, res);
         const int oy = 2 * by * TY + gy;
         const int ox = 2 * (bx * TX + k);
         if ((a.Nc & 3) || (a.out_bstride & 3)) {  // output rows of any length: element stores, each inside the row
             if (oy < a.Nr) {
-                float* PDWT_RESTRICT orow = out + (long long)oy * a.Nc;
+                real_t* PDWT_RESTRICT orow = out + (long long)oy * a.Nc;
                 if (ox + 3 < a.Nc) {
                     st_f4_unaligned(orow + ox, res[0], res[1], res[2], res[3]);  // 16 B at 4-B alignment
                 } else {
@@ -597,10 +597,10 @@ PDWT_DEVICE void inv_fast_row_pass(int tid, const v2f* tt, const Inv2DFastArgs& 
                 }
             }
         } else if (oy < a.Nr && ox < a.Nc) {  // Nc % 4 == 0: the float4 is inside and aligned
-            f32x4 v;
+            real4_t v;
             v.x = res[0]; v.y = res[1]; v.z = res[2]; v.w = res[3];
             if (coh_out) coh_store16(coh_plane(out), (long long)oy * a.Nc + ox, v);  // read by other workgroups of this launch
-            else *reinterpret_cast<f32x4*>(out + (long long)oy * a.Nc + ox) = v;
+            else *reinterpret_cast<real4_t*>(out + (long long)oy * a.Nc + ox) = v;
         }
     }
 }
@@ -608,9 +608,9 @@ PDWT_DEVICE void inv_fast_row_pass(int tid, const v2f* tt, const Inv2DFastArgs& 
 // interleave one float4 of A,V and of H,D into the (A,V) / (H,D) pair planes
 PDWT_DEVICE void inv_fast_interleave(v2f* sAV, v2f* sHD, int pair_index, const v4f& vA, const v4f& vV,
                                      const v4f& vH, const v4f& vD) {
-    f32x4 w;
-    f32x4* dAV = reinterpret_cast<f32x4*>(sAV + pair_index);
-    f32x4* dHD = reinterpret_cast<f32x4*>(sHD + pair_index);
+    real4_t w;
+    real4_t* dAV = reinterpret_cast<real4_t*>(sAV + pair_index);
+    real4_t* dHD = reinterpret_cast<real4_t*>(sHD + pair_index);
     w.x = vA.x; w.y = vV.x; w.z = vA.y; w.w = vV.y; dAV[0] = w;
     w.x = vA.z; w.y = vV.z; w.z = vA.w; w.w = vV.w; dAV[1] = w;
     w.x = vH.x; w.y = vD.x; w.z = vH.y; w.w = vD.y; dHD[0] = w;
@@ -621,7 +621,7 @@ PDWT_DEVICE void inv_fast_interleave(v2f* sAV, v2f* sHD, int pair_index, const v
 // coh_in / coh_out (uniform, dwt2_chain_kernels.hpp): the A plane was written by other workgroups of THIS launch (sc1
 // loads) / the output plane is read by other workgroups of this launch (sc1 stores).
 template <int HLEN, int TX, int TY, int NT>
-PDWT_DEVICE void dwt2_inv_fast_tile(const Inv2DFastArgs& a, int bx, int by, int bz, float* smem, bool coh_in = false,
+PDWT_DEVICE void dwt2_inv_fast_tile(const Inv2DFastArgs& a, int bx, int by, int bz, real_t* smem, bool coh_in = false,
                                     bool coh_out = false) {
     using G = InvFastGeom<HLEN, TX>;
     constexpr int H2 = G::H2, C = G::C, PADL = G::PADL, CXA = G::CXA;
@@ -655,7 +655,7 @@ PDWT_DEVICE void dwt2_inv_fast_tile(const Inv2DFastArgs& a, int bx, int by, int 
                 sx = sx < 0 ? sx + a.Ncc : (sx >= a.Ncc ? sx - a.Ncc : sx);
                 const long long oi = (long long)sy * a.Ncc + sx;
                 const long long o = boff + oi;
-                const f32x4 ca = coh_load16(pa, oi);
+                const real4_t ca = coh_load16(pa, oi);
                 v4f va;
                 va.x = ca.x; va.y = ca.y; va.z = ca.z; va.w = ca.w;
                 inv_fast_interleave(sAV, sHD, r * CXA + 4 * g, va, *reinterpret_cast<const v4f*>(a.V + o),
@@ -700,7 +700,7 @@ PDWT_DEVICE void dwt2_inv_fast_tile(const Inv2DFastArgs& a, int bx, int by, int 
                 const int g = idx - r * V4;
                 const long long ro = boff + (long long)wrap_periodic(cy0 + r, a.Nrc) * a.Ncc;
                 const int sx = cxa + 4 * g;
-                f32x4 qa, qv, qh, qd;
+                real4_t qa, qv, qh, qd;
                 if (sx >= 0 && sx + 3 < a.Ncc) {
                     qa = ld_f4_unaligned(a.A + ro + sx); qv = ld_f4_unaligned(a.V + ro + sx);
                     qh = ld_f4_unaligned(a.H + ro + sx); qd = ld_f4_unaligned(a.D + ro + sx);
@@ -740,7 +740,7 @@ PDWT_DEVICE void dwt2_inv_fast_tile(const Inv2DFastArgs& a, int bx, int by, int 
 #ifndef PDWT_CPU_EMU
 template <int HLEN, int TX, int TY, int NT>
 __global__ void __launch_bounds__(NT) dwt2_fwd_fast_kernel(const Fwd2DFastArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float pdwt_smem[];
+    extern __shared__ __attribute__((aligned(16))) real_t pdwt_smem[];
     int bx, by;
     if (!xcd_tile(blockIdx.x, a.tiles_x, a.tiles_y, bx, by)) return;
     dwt2_fwd_fast_tile<HLEN, TX, TY, NT>(a, bx, by, blockIdx.y, pdwt_smem);
@@ -748,13 +748,13 @@ __global__ void __launch_bounds__(NT) dwt2_fwd_fast_kernel(const Fwd2DFastArgs a
 
 template <int HLEN, int TX, int TY, int NT>
 __global__ void __launch_bounds__(NT) dwt2_fwd_fast_stream_kernel(const Fwd2DFastArgs a, int batch) {
-    extern __shared__ __attribute__((aligned(16))) float pdwt_smem[];
+    extern __shared__ __attribute__((aligned(16))) real_t pdwt_smem[];
     dwt2_fwd_fast_stream<HLEN, TX, TY, NT>(a, blockIdx.x, gridDim.x, batch, pdwt_smem);
 }
 
 template <int HLEN, int TX, int TY, int NT>
 __global__ void __launch_bounds__(NT) dwt2_inv_fast_kernel(const Inv2DFastArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float pdwt_smem[];
+    extern __shared__ __attribute__((aligned(16))) real_t pdwt_smem[];
     int bx, by;
     if (!xcd_tile(blockIdx.x, a.tiles_x, a.tiles_y, bx, by)) return;
     dwt2_inv_fast_tile<HLEN, TX, TY, NT>(a, bx, by, blockIdx.y, pdwt_smem);

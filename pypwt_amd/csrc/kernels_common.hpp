@@ -39,10 +39,15 @@ typedef pdwt_float2 f32x2;
 typedef pdwt_float4 f32x4;
 static inline float pdwt_fma(float a, float b, float c) { return a * b + c; }
 static inline double pdwt_fma(double a, double b, double c) { return a * b + c; }
+#ifdef PDWT_DOUBLE
 struct pdwt_real2 { real_t x, y; };
 struct pdwt_real4 { real_t x, y, z, w; };
 typedef pdwt_real2 real2_t;
 typedef pdwt_real4 real4_t;
+#else
+typedef pdwt_float2 real2_t;  // the same structs as f32x2 / f32x4: the fp32 tile functions mix both spellings
+typedef pdwt_float4 real4_t;
+#endif
 #else
 #include <hip/hip_runtime.h>
 #define PDWT_DEVICE __device__ __forceinline__

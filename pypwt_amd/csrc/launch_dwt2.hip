@@ -40,8 +40,6 @@ static hipError_t run_inv(const Inv2DArgs& a, int batch, hipStream_t s) {
 // fp64 build: of the tuned kernels only the register kernels of dwt2_wave_kernels.hpp and dwt1_reg_kernels.hpp are
 // compiled (they are written over real_t); the LDS-tiled packed-fp32 kernels (tuned single-level, tile pyramid, streaming strips, fused
 // 1D pyramids, fused SWT groups) are not: those levels run through the generic kernels of this file / launch_dwt1.hip
-hipError_t try_launch_dwt2_fwd_fast(const Fwd2DArgs&, int, hipStream_t) { return hipErrorNotSupported; }
-hipError_t try_launch_dwt2_inv_fast(const Inv2DArgs&, int, hipStream_t) { return hipErrorNotSupported; }
 bool dwt2_wave2_supported(int, int, int) { return false; }
 hipError_t launch_dwt2_fwd_wave2(const real_t*, real_t* const[3], real_t* const[4], int, int, int, const FilterBank&, int,
                                  hipStream_t, int) { return hipErrorNotSupported; }

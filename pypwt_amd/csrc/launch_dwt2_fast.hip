@@ -7,6 +7,8 @@
 // Tile shape per filter length (kbench on MI355X, profiles/r01b_kbench_*.txt): 64 output columns;
 // short filters want SMALL tiles (8 output rows, ~23 KB LDS, 6 workgroups per CU): occupancy beats
 // the larger halo; longer filters amortise their halo over 16 / 32 rows.
+#include <cstdlib>
+
 #include "dwt2_fast_kernels.hpp"
 #include "launch.hpp"
 #include "launch_util.hpp"
@@ -40,7 +42,7 @@ static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 template <int HLEN, int TX, int TY, int NT>
 static hipError_t run_fwd_fast(const Fwd2DArgs& g, int batch, hipStream_t s) {
     static std::atomic<bool> big[64] = {};
-    constexpr size_t lds = (size_t)fwd2d_fast_lds_floats<HLEN, TX, TY>() * sizeof(float);
+    constexpr size_t lds = (size_t)fwd2d_fast_lds_floats<HLEN, TX, TY>() * sizeof(real_t);
     hipError_t e = allow_big_lds(dwt2_fwd_fast_stream_kernel<HLEN, TX, TY, NT>, lds, big);
     if (e != hipSuccess) return e;
     Fwd2DFastArgs a;
@@ -60,7 +62,7 @@ static hipError_t run_fwd_fast(const Fwd2DArgs& g, int batch, hipStream_t s) {
 template <int HLEN, int TX, int TY, int NT>
 static hipError_t run_fwd_fast_tile(const Fwd2DArgs& g, int batch, hipStream_t s) {
     static std::atomic<bool> big[64] = {};
-    constexpr size_t lds = (size_t)fwd2d_fast_lds_floats<HLEN, TX, TY>() * sizeof(float);
+    constexpr size_t lds = (size_t)fwd2d_fast_lds_floats<HLEN, TX, TY>() * sizeof(real_t);
     hipError_t e = allow_big_lds(dwt2_fwd_fast_kernel<HLEN, TX, TY, NT>, lds, big);
     if (e != hipSuccess) return e;
     Fwd2DFastArgs a;
@@ -80,7 +82,7 @@ static bool mid_size(long long samples) { return samples > (1LL << 20) && sample
 template <int HLEN, int TX, int TY, int NT>
 static hipError_t run_inv_fast(const Inv2DArgs& g, int batch, hipStream_t s) {
     static std::atomic<bool> big[64] = {};
-    constexpr size_t lds = (size_t)inv2d_fast_lds_floats<HLEN, TX, TY>() * sizeof(float);
+    constexpr size_t lds = (size_t)inv2d_fast_lds_floats<HLEN, TX, TY>() * sizeof(real_t);
     hipError_t e = allow_big_lds(dwt2_inv_fast_kernel<HLEN, TX, TY, NT>, lds, big);
     if (e != hipSuccess) return e;
     Inv2DFastArgs a;
@@ -98,7 +100,13 @@ static hipError_t run_inv_fast(const Inv2DArgs& g, int batch, hipStream_t s) {
     return hipGetLastError();
 }
 
+static bool lds_tiles_off() {  // A/B measurements: every level through the wave / generic kernels
+    static const bool off = getenv("PDWT_NO_LDS_TILES") != nullptr;
+    return off;
+}
+
 hipError_t try_launch_dwt2_fwd_fast(const Fwd2DArgs& a, int batch, hipStream_t s) {
+    if (lds_tiles_off()) return hipErrorNotSupported;
     if ((a.hlen & 1) || a.hlen < 2 || a.hlen > kMaxTaps) return hipErrorNotSupported;
     // any row length: rows that are not whole, aligned quads take the unaligned staging / element-store branches of the
     // tile; the streaming form (more than 20 taps) stages whole aligned quads only
@@ -124,6 +132,7 @@ hipError_t try_launch_dwt2_fwd_fast(const Fwd2DArgs& a, int batch, hipStream_t s
     case h:                                                                 \
         if constexpr (h <= 8) return run_fwd_fast_tile<h, 64, 8, 256>(a, batch, s);   \
         else if constexpr (h <= 20) return run_fwd_fast_tile<h, 64, 16, 512>(a, batch, s); \
+        else if constexpr (sizeof(real_t) == 8) return hipErrorNotSupported; /* 32-row tiles of doubles exceed 160 KB */ \
         else return run_fwd_fast<h, 64, 32, 256>(a, batch, s);
         PDWT_EVEN_HLENS(X)
 #undef X
@@ -132,6 +141,7 @@ hipError_t try_launch_dwt2_fwd_fast(const Fwd2DArgs& a, int batch, hipStream_t s
 }
 
 hipError_t try_launch_dwt2_inv_fast(const Inv2DArgs& a, int batch, hipStream_t s) {
+    if (lds_tiles_off()) return hipErrorNotSupported;
     if ((a.hlen & 1) || a.hlen < 2 || a.hlen > kMaxTaps) return hipErrorNotSupported;
     if (a.Nc > 2 * a.Ncc || a.Nc < 2 * a.Ncc - 1 || a.Nr > 2 * a.Nrc) return hipErrorNotSupported;  // any row length / alignment
     if (!aligned16(a.out) || !aligned16(a.A) || !aligned16(a.H) || !aligned16(a.V) || !aligned16(a.D))
@@ -149,6 +159,7 @@ hipError_t try_launch_dwt2_inv_fast(const Inv2DArgs& a, int batch, hipStream_t s
     case h:                                                                 \
         if constexpr (h <= 8) return run_inv_fast<h, 64, 8, 256>(a, batch, s);   \
         else if constexpr (h <= 20) return run_inv_fast<h, 64, 16, 512>(a, batch, s); \
+        else if constexpr (sizeof(real_t) == 8) return hipErrorNotSupported;     \
         else return run_inv_fast<h, 64, 32, 256>(a, batch, s);
         PDWT_EVEN_HLENS(X)
 #undef X

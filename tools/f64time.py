@@ -20,3 +20,8 @@ run(Wavelets, (1, 1 << 24), 'sym8', 6, ndim=1)
 run(Wavelets64, (1, 1 << 24), 'sym8', 6, ndim=1, dt=np.float64)
 run(Wavelets, (2048, 2048), 'haar', 5, swt=1)
 run(Wavelets64, (2048, 2048), 'haar', 5, swt=1, dt=np.float64)
+# filters of 10-20 taps in 2D: LDS tiles over real_t since round 3 (generic kernels before)
+run(Wavelets, (4096, 4096), 'sym8', 4)
+run(Wavelets64, (4096, 4096), 'sym8', 4, dt=np.float64)
+run(Wavelets64, (4096, 4096), 'db6', 4, dt=np.float64)
+run(Wavelets64, (4095, 4095), 'db4', 4, dt=np.float64)
