@@ -129,6 +129,14 @@ long long pdwt_get_coeff(pdwt_handle h, pdwt_real* dst, int num); /* 0 if refuse
 int pdwt_set_image(pdwt_handle h, const pdwt_real* src, int mem_is_on_device);
 int pdwt_set_coeff(pdwt_handle h, const pdwt_real* src, int num, int mem_is_on_device);
 long long pdwt_coeff_count(pdwt_handle h, int num, int* rows, int* cols); /* elements incl. batch */
+/* NEW: ALL coefficient bands in ONE device-to-host copy.  The reference's `coeffs` is 3 L + 1 blocking cudaMemcpy calls
+ * (pypwt.pyx:287-305, wt.cu:473-506): 28 round trips for a 512^2 haar transform, which dominate its own benchmark method
+ * (test/benchmark.py:141-162).  The plan keeps its bands back to back in `num` order, each padded to a multiple of 64
+ * elements: pdwt_coeff_region writes the offset of every band (elements from the start of the region) into band_offsets
+ * (capacity entries) and returns the region's length; pdwt_get_coeff_region copies the whole region into dst (that many
+ * elements) and returns the count, 0 when refused after inverse() like pdwt_get_coeff. */
+long long pdwt_coeff_region(pdwt_handle h, long long* band_offsets, int capacity);
+long long pdwt_get_coeff_region(pdwt_handle h, pdwt_real* dst);
 /* NEW (batched plans): one image / one image's sub-band of a batch, so that a 128-image shard can be
  * inspected without a host buffer for the whole batch; same refusal rule as pdwt_get_coeff (wt.cu:473-477) */
 long long pdwt_get_image_at(pdwt_handle h, pdwt_real* dst, int image_index);

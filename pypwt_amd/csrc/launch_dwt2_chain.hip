@@ -53,6 +53,7 @@ int set_chain_timeout(int ticks) { return timeout_ticks().exchange(ticks < 0 ? 0
 // (Nr, Nc): dims entering the FINEST level of the group
 bool dwt2_chain_supported(int hlen, int Nr, int Nc, int K) {
     if ((hlen & 1) || hlen < 2 || hlen > 8 || K < 2 || K > kChainMaxLevels) return false;
+    if ((long long)Nr * Nc >= (1LL << 29)) return false;  // 32-bit byte offsets inside one plane (raw-buffer accesses)
     for (int k = 0; k < K; k++) {
         const int r = Nr >> k, c = Nc >> k;
         if ((r << k) != Nr || (c << k) != Nc) return false;

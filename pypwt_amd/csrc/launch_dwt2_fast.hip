@@ -146,6 +146,15 @@ hipError_t try_launch_dwt2_inv_fast(const Inv2DArgs& a, int batch, hipStream_t s
     if (a.Nc > 2 * a.Ncc || a.Nc < 2 * a.Ncc - 1 || a.Nr > 2 * a.Nrc) return hipErrorNotSupported;  // any row length / alignment
     if (!aligned16(a.out) || !aligned16(a.A) || !aligned16(a.H) || !aligned16(a.V) || !aligned16(a.D))
         return hipErrorNotSupported;
+    {   // A/B measurements (db4 only): PDWT_INV_TILE = 1: 128x16 / 512 threads, 2: 128x8 / 256, 3: 64x16 / 512, 4: 64x32 / 512
+        static const int forced = getenv("PDWT_INV_TILE") ? atoi(getenv("PDWT_INV_TILE")) : 0;
+        if (forced && a.hlen == 8) {
+            if (forced == 1) return run_inv_fast<8, 128, 16, 512>(a, batch, s);
+            if (forced == 2) return run_inv_fast<8, 128, 8, 256>(a, batch, s);
+            if (forced == 3) return run_inv_fast<8, 64, 16, 512>(a, batch, s);
+            if (forced == 4) return run_inv_fast<8, 64, 32, 512>(a, batch, s);
+        }
+    }
     if (a.hlen <= 8 && mid_size((long long)batch * a.Nr * a.Nc)) {  // 128x16 tiles, 512 threads: 8.0 vs 8.8 us at 2048^2
         switch (a.hlen) {
             case 2: return run_inv_fast<2, 128, 16, 512>(a, batch, s);

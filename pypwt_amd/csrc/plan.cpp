@@ -1222,6 +1222,30 @@ long long pdwt_get_coeff(pdwt_handle h, real_t* dst, int num) {  // wt.cu:473-50
     return n;
 }
 
+long long pdwt_coeff_region(pdwt_handle h, long long* band_offsets, int capacity) {
+    if (!h) return fail(PDWT_ERR_ARG, "pdwt_coeff_region: null handle");
+    if (band_offsets)
+        for (int i = 0; i < (int)h->bands.size() && i < capacity; i++) band_offsets[i] = h->bands[i].off - h->bands[0].off;
+    return h->coeff_elems - h->bands[0].off;
+}
+
+long long pdwt_get_coeff_region(pdwt_handle h, real_t* dst) {
+    if (!h || !dst) return fail(PDWT_ERR_ARG, "pdwt_get_coeff_region: null argument");
+    if (h->state == PDWT_INVERSE) {
+        fail(PDWT_ERR_STATE, "get_coeff(): inverse() has been performed, the coefficients has been modified and do not make sense anymore.");
+        return 0;
+    }
+    DeviceGuard guard(h->device);
+    {
+        const int rc0 = materialize_pending(h);
+        if (rc0 != PDWT_OK) return rc0;
+    }
+    const long long n = h->coeff_elems - h->bands[0].off;
+    HIP_TRY(hipMemcpyAsync(dst, h->band(0), (size_t)n * sizeof(real_t), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return n;
+}
+
 long long pdwt_get_image_at(pdwt_handle h, real_t* dst, int image_index) {  // wt.cu:419-422, one image of a batch
     if (!h || !dst) return fail(PDWT_ERR_ARG, "pdwt_get_image_at: null argument");
     if (image_index < 0 || image_index >= h->batch)

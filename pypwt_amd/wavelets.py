@@ -162,13 +162,25 @@ class Wavelets(object):
         self.do_separable = int(sep.value)
         self.sizes = self._compute_sizes()
 
-        # host-side coefficient list (src/pypwt.pyx:187-205)
-        self._coeffs = [np.zeros(self.sizes[-1], dtype=self._dtype)]
+        # host-side coefficient list (src/pypwt.pyx:187-205).  The arrays are views of ONE host buffer laid out like the
+        # plan's coefficient region (bands back to back in `num` order, each padded to 64 elements), so that `coeffs` is a
+        # single device-to-host copy instead of one blocking copy per band (28 for a 512^2 haar transform)
+        two_d = not ((self.ndim < 2) or self.batched1d)
+        nb = 1 + (3 if two_d else 1) * self.levels
+        offs = (C.c_longlong * nb)()
+        region = int(self._lib.pdwt_coeff_region(self._h, offs, nb))
+        self._cbuf = np.zeros(max(region, 1), dtype=self._dtype)
+
+        def view(num, shape):
+            n = int(shape[0]) * int(shape[1])
+            return self._cbuf[int(offs[num]):int(offs[num]) + n].reshape(shape)
+
+        self._coeffs = [view(0, self.sizes[-1])]
         for i in range(self.levels):
-            if (self.ndim < 2) or self.batched1d:
-                self._coeffs.append(np.zeros(self.sizes[i], dtype=self._dtype))
+            if two_d:
+                self._coeffs.append([view(1 + 3 * i + k, self.sizes[i]) for k in range(3)])
             else:
-                self._coeffs.append([np.zeros(self.sizes[i], dtype=self._dtype) for _ in range(3)])
+                self._coeffs.append(view(1 + i, self.sizes[i]))
 
     # -- reference: info / __repr__ / __str__ (src/pypwt.pyx:209-221)
     def info(self):
@@ -243,10 +255,10 @@ class Wavelets(object):
         Get all the coefficients from the device.
         Returns the list [A, [H1, V1, D1], [H2, V2, D2], ...] (2D) or [A, D1, ...] (1D).
         """
-        self.coeff_only(0)
-        i_end = 3 * self.levels if (self.ndim == 2 and not self.batched1d) else self.levels
-        for cnt in range(1, i_end + 1):
-            self.coeff_only(cnt)
+        numc = self._lib.pdwt_get_coeff_region(self._h, _ptr(self._cbuf))  # ONE copy: the arrays are views of _cbuf
+        if numc != self._cbuf.size:  # src/pypwt.pyx:284-285 (0 when refused after inverse())
+            raise RuntimeError("Wavelets.coeffs: something went wrong when retrieving coefficients, expected %d coeffs, "
+                               "got %d (%s)" % (self._cbuf.size, numc, _lib.last_error(self._lib)))
         return self._coeffs
 
     @property
