@@ -109,7 +109,9 @@ def main(root, traffic_out=None, config=None):
             for k, v in by.items():
                 v = sorted(v)
                 tot += sum(v) / len(v)
-                print("  %-28s n=%4d mean=%8.2f med=%8.2f min=%8.2f" % (k, len(v), sum(v) / len(v), v[len(v) // 2], v[0]))
+                print("  %-28s n=%4d mean=%8.2f med=%8.2f min=%8.2f p99=%8.2f max=%8.2f over 1.3x median: %d" % (
+                    k, len(v), sum(v) / len(v), v[len(v) // 2], v[0], v[min(len(v) - 1, int(0.99 * len(v)))], v[-1],
+                    sum(1 for t in v if t > 1.3 * v[len(v) // 2])))
             print("  sum of the means: %.2f us per step" % tot)
     traffic = defaultdict(dict)
     for d in sorted(glob.glob(os.path.join(root, "pmc_*"))):
