@@ -216,10 +216,11 @@ int pdwt_time_level(pdwt_handle h, int level, int inverse, int reps, float* ms_p
  *                    are multiples of 32); default 3; 0 = the workgroup-wide LDS pyramids (57.6 vs 69.5 us per
  *                    forward+inverse on 2^24 samples); the forward uses them up to 2^25 samples per plan (a batch of
  *                    long rows is faster through the LDS pyramid), bit 2 lifts that limit.  Read when a plan is created.
- *   "swt_fused"      1 (default): 2D SWT plans with a 2-tap filter bank (haar) whose 3L+2 planes about fit the
- *                    Infinity Cache (<= 320 MiB) run levels 1-3 and 4-6 in one launch each (swt2_fused_kernels.hpp:
- *                    11 / 8 instead of 15 / 10 planes of traffic); 2: at any size; 0: a launch per level.  Read when
- *                    a plan is created.
+ *   "swt_fused"      1 (default): 2D SWT plans whose 3L+2 planes about fit the Infinity Cache (<= 320 MiB) run several
+ *                    levels per launch in registers: 2-tap banks (haar) levels 1-3 and 4-6 (swt2_fused_kernels.hpp: 11 / 8
+ *                    instead of 15 / 10 planes of traffic), 4-tap banks (db2, sym2, custom) levels (1, 2) and (3, 4)
+ *                    (swt2_fused4_kernels.hpp: 8 instead of 10 planes per pair); 2: at any size; 0: a launch per level.
+ *                    Read when a plan is created.
  *   "chain"          levels 1..K of a 2D DWT in ONE launch with in-launch hand-offs between the levels
  *                    (dwt2_chain_kernels.hpp; even filters of at most 8 taps, whole 16 x 128 tiles at every level):
  *                    0 (default): never -- measured break-even for two levels and slower beyond on MI355X; 1: one

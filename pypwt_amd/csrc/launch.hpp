@@ -88,7 +88,7 @@ hipError_t launch_dwt1_inv_fused(const real_t* app, const real_t* const* det, re
 hipError_t launch_swt2_fwd(const Swt2DArgs& a, int batch, hipStream_t s);
 hipError_t launch_swt2_inv(const Swt2DArgs& a, int batch, hipStream_t s);
 // levels l0 .. l0+K-1 (K = 2, 3; l0 = 1 or 4) of a 2-tap 2D SWT in one launch (swt2_fused_kernels.hpp)
-bool swt2_fused_supported(int hlen, int Nr, int Nc, int l0, int K);
+bool swt2_fused_supported(int hlen, int Nr, int Nc, int l0, int K, bool inverse = false);
 hipError_t launch_swt2_fused(const real_t* in, real_t* out, real_t* const* det, int Nr, int Nc, int l0, int K, bool inverse,
                              int hlen, const FilterBank& fb, const real_t* beta, int batch, hipStream_t s);
 hipError_t launch_swt_pass_fwd(const SwtPassArgs& a, hipStream_t s);

@@ -2,6 +2,7 @@
 #include "launch.hpp"
 #include "launch_util.hpp"
 #include "swt2_fused_kernels.hpp"
+#include "swt2_fused4_kernels.hpp"
 
 #include <cstdlib>
 
@@ -11,7 +12,14 @@ namespace pdwt {
 // first dilation 1 or 8 (levels 1.. or 4..: the lane shifts of a group must stay inside a wavefront), the dilation
 // dividing the row count (whole phases), at least one unrolled group of rows per phase, planes of at most 1 GiB (the
 // dropped-store offsets of swt2_fused_kernels.hpp start at 2^30).
-bool swt2_fused_supported(int hlen, int Nr, int Nc, int l0, int K) {
+// 4-tap banks (swt2_fused4_kernels.hpp): pairs of levels (1, 2) and (3, 4); `inverse` selects the direction asked about.
+static bool swt4_inverse_built() { return true; }
+bool swt2_fused_supported(int hlen, int Nr, int Nc, int l0, int K, bool inverse) {
+    if (hlen == 4) {
+        if (K != 2 || (l0 != 1 && l0 != 3) || (inverse && !swt4_inverse_built())) return false;
+        const int f0 = 1 << (l0 - 1);
+        return (Nc % 4) == 0 && Nc >= 256 && (long long)Nr * Nc * (long long)sizeof(real_t) <= (1LL << 30) && (Nr % f0) == 0 && Nr / f0 >= 8;
+    }
     if (hlen != 2 || K < 2 || K > kSwtFusedMaxLevels || (l0 != 1 && l0 != 4)) return false;
     const int f0 = 1 << (l0 - 1);
     return (Nc % 4) == 0 && Nc >= 256 && (long long)Nr * Nc * (long long)sizeof(real_t) <= (1LL << 30) && (Nr % f0) == 0 && Nr / f0 >= (1 << K);
@@ -81,11 +89,52 @@ static hipError_t run(SwtFusedArgs& a, bool inverse, int batch, hipStream_t s) {
     return hipGetLastError();
 }
 
+template <int F0>
+static hipError_t run4(Swt4Args& a, bool inverse, int batch, hipStream_t s) {
+    using G = Swt4Geom<F0>;
+    constexpr int NT = 64;
+    a.strips = cdiv(a.Nc, 4 * (inverse ? G::Vi : G::Vf));
+    const int rows_phase = a.Nr / F0;
+    // phase rows per wavefront: a segment walks 9 rows it does not own (one input plane: cheap), a wavefront wants ~1 us per
+    // row: the longest multiple of 8 that still gives ~768 wavefronts
+    static const int forced = [] { const char* e = getenv("PDWT_SWT_SEG"); return e ? atoi(e) : 0; }();
+    int seg = 256;
+    auto waves_of = [&](int sg) { return (long long)batch * F0 * a.strips * cdiv(rows_phase, sg); };
+    while (seg > 8 && waves_of(seg) < 768) seg -= 8;
+    if (forced > 0) seg = (forced + 7) / 8 * 8;
+    if (seg > rows_phase) seg = (rows_phase + 7) / 8 * 8;
+    a.seg_rows = seg;
+    a.segs = cdiv(rows_phase, seg);
+    const long long waves = waves_of(seg);
+    const unsigned grid = 8u * (unsigned)cdivll(cdivll(waves, NT / 64), 8);
+    if (inverse) {
+        static const int nri = [] { const char* e = getenv("PDWT_SWT4_NRI"); return e ? atoi(e) : 4; }();  // load slots (A/B measurements)
+        if (nri == 2) hipLaunchKernelGGL((swt4_inv_fused_kernel<F0, 2, NT>), dim3(grid), dim3(NT), 0, s, a, waves);
+        else hipLaunchKernelGGL((swt4_inv_fused_kernel<F0, 4, NT>), dim3(grid), dim3(NT), 0, s, a, waves);
+    } else {
+        hipLaunchKernelGGL((swt4_fwd_fused_kernel<F0, NT>), dim3(grid), dim3(NT), 0, s, a, waves);
+    }
+    return hipGetLastError();
+}
+
 // in / out: the approximation planes on either side of the group; det[3 k + {0,1,2}] = H, V, D of level l0 + k;
 // beta[k]: soft threshold the inverse applies to level l0 + k's details as it loads them (nullptr: none)
 hipError_t launch_swt2_fused(const real_t* in, real_t* out, real_t* const* det, int Nr, int Nc, int l0, int K, bool inverse,
                              int hlen, const FilterBank& fb, const real_t* beta, int batch, hipStream_t s) {
-    if (!swt2_fused_supported(hlen, Nr, Nc, l0, K)) return hipErrorNotSupported;  // a stale schedule falls back, never truncates taps
+    if (!swt2_fused_supported(hlen, Nr, Nc, l0, K, inverse)) return hipErrorNotSupported;  // a stale schedule falls back, never truncates taps
+    for (int k = 0; k < 3 * K; k++)
+        if (reinterpret_cast<uintptr_t>(det[k]) & 15) return hipErrorNotSupported;
+    if ((reinterpret_cast<uintptr_t>(in) & 15) || (reinterpret_cast<uintptr_t>(out) & 15)) return hipErrorNotSupported;
+    if (hlen == 4) {
+        Swt4Args b;
+        b.in = in; b.out = out; b.Nr = Nr; b.Nc = Nc; b.bstride = (long long)Nr * Nc;
+        for (int k = 0; k < 2; k++) {
+            b.H[k] = det[3 * k]; b.V[k] = det[3 * k + 1]; b.D[k] = det[3 * k + 2];
+            b.beta[k] = beta ? beta[k] : real_t(0);
+        }
+        for (int j = 0; j < 4; j++) { b.lo[j] = fb.lo[j]; b.hi[j] = fb.hi[j]; }
+        return l0 == 1 ? run4<1>(b, inverse, batch, s) : run4<4>(b, inverse, batch, s);
+    }
     SwtFusedArgs a;
     a.in = in; a.out = out; a.Nr = Nr; a.Nc = Nc; a.bstride = (long long)Nr * Nc;
     for (int k = 0; k < kSwtFusedMaxLevels; k++) {

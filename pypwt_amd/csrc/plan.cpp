@@ -368,12 +368,12 @@ void build_schedule(pdwt_plan* p) {
         // planes are cold -- two 2048^2 images: 343 us fused against 329 us level by level, four: 746 against 715 us,
         // one: 137 against 183 us (profiles/r02y_bench_cfg4_batch.txt).
         const long long swt_bytes = (long long)sizeof(real_t) * (3 * L + 2) * p->batch * p->info.Nr * p->info.Nc;
-        auto swt_group = [&](int l) {
-            if (!swt || !p->do_separable || !get_swt_fused_enabled() || (l != 1 && l != 4)) return 0;
+        auto swt_group = [&](int l, bool inverse) {
+            if (!swt || !p->do_separable || !get_swt_fused_enabled()) return 0;
             if (swt_bytes > (320LL << 20) && get_swt_fused_enabled() < 2) return 0;  // "swt_fused" = 2 forces (tests)
             for (int K = (L - l + 1 < 3 ? L - l + 1 : 3); K >= 2; --K) {
                 const bool same_plane = K == 2 && l - 1 >= 1 && l + K - 1 <= L - 1;
-                if (!same_plane && swt2_fused_supported(hlen, p->info.Nr, p->info.Nc, l, K)) return K;
+                if (!same_plane && swt2_fused_supported(hlen, p->info.Nr, p->info.Nc, l, K, inverse)) return K;
             }
             return 0;
         };
@@ -419,7 +419,7 @@ void build_schedule(pdwt_plan* p) {
         for (int dir = 0; dir < 2; dir++) {
             std::vector<Step>& out = dir ? p->sched_inv : p->sched_fwd;
             for (int l = 1; l <= L; l++) {
-                if (const int K = swt_group(l)) { out.push_back({Step::SWTF, l, K}); l += K - 1; continue; }
+                if (const int K = swt_group(l, dir != 0)) { out.push_back({Step::SWTF, l, K}); l += K - 1; continue; }
                 if (const int K = p->chain_flags ? chain_at(l, dir != 0) : 0) { out.push_back({Step::CHAIN, l, K}); l += K - 1; continue; }
                 if (strip_at(l, dir != 0)) { out.push_back({Step::STRIP2, l, 2}); l++; }
                 else if (wave2_at(l, dir != 0)) { out.push_back({Step::WAVE2, l, 2}); l++; }

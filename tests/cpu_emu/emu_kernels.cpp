@@ -11,6 +11,7 @@
 #include "../../pypwt_amd/csrc/dwt1_kernels.hpp"
 #include "../../pypwt_amd/csrc/dwt1_reg_kernels.hpp"
 #include "../../pypwt_amd/csrc/swt2_fused_kernels.hpp"
+#include "../../pypwt_amd/csrc/swt2_fused4_kernels.hpp"
 #include "../../pypwt_amd/csrc/dwt2_fast_kernels.hpp"
 #include "../../pypwt_amd/csrc/dwt2_kernels.hpp"
 #include "../../pypwt_amd/csrc/dwt2_pyramid_kernels.hpp"
@@ -708,4 +709,37 @@ EMU_API int emu_swt2_fused(const float* in, float* det, float* out, int batch, i
     Y(2, 1) Y(3, 1) Y(2, 8) Y(3, 8)
 #undef Y
     return -1;
+}
+
+// ---- 4-tap fused SWT pairs (swt2_fused4_kernels.hpp): planes as in emu_swt2_fused with K = 2
+template <int F0>
+static void run_swt4(Swt4Args& a, int batch, bool inverse) {
+    using G = Swt4Geom<F0>;
+    const int V = inverse ? G::Vi : G::Vf;
+    a.strips = (a.Nc + 4 * V - 1) / (4 * V);
+    const long long waves = (long long)batch * F0 * a.segs * a.strips;
+    for (long long w = 0; w < waves; w++) {
+        if (!inverse) swt4_fwd_fused<F0>(a, w);
+        else swt4_inv_fused<F0, 4>(a, w);
+    }
+}
+
+EMU_API int emu_swt4_fused(const float* in, float* det, float* out, int batch, int Nr, int Nc, int f0, int seg_rows,
+                           const float* lo, const float* hi, const float* beta, int inverse) {
+    if ((f0 != 1 && f0 != 4) || (Nc % 4) || Nc < 64 || (Nr % f0) || seg_rows % 8) return -2;
+    Swt4Args a;
+    const long long plane = (long long)Nr * Nc;
+    a.in = in; a.out = out; a.Nr = Nr; a.Nc = Nc; a.bstride = plane;
+    for (int k = 0; k < 2; k++) {
+        a.H[k] = det + (3 * k + 0) * batch * plane;
+        a.V[k] = det + (3 * k + 1) * batch * plane;
+        a.D[k] = det + (3 * k + 2) * batch * plane;
+        a.beta[k] = beta ? beta[k] : 0.f;
+    }
+    for (int j = 0; j < 4; j++) { a.lo[j] = lo[j]; a.hi[j] = hi[j]; }
+    a.seg_rows = seg_rows;
+    a.segs = (Nr / f0 + seg_rows - 1) / seg_rows;
+    if (f0 == 1) run_swt4<1>(a, batch, inverse != 0);
+    else run_swt4<4>(a, batch, inverse != 0);
+    return 0;
 }

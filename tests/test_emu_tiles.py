@@ -627,3 +627,56 @@ def test_emu_swt2_fused_forward_and_inverse():
                         want[py::f0, px::f0] = oracle.inverse(sub, sub[0].shape, "haar", K, do_swt=1)
                 assert np.isfinite(rec[b]).all(), (si, "inverse")
                 assert np.abs(rec[b] - want).max() <= 4e-6 * (1 + K), (si, "inverse", beta is not None, cpl)
+
+
+# ----------------------------------------------------------------------------- 4-tap fused SWT pairs
+def _swt4_cases():
+    # (batch, Nr, Nc, l0, seg_rows): whole and ragged strips, partial last segments, phase rows (l0 = 3 -> f0 = 4)
+    return [(1, 32, 256, 1, 8), (2, 24, 512, 1, 16), (1, 40, 260, 1, 8), (1, 64, 256, 3, 8), (1, 96, 744, 3, 8), (1, 16, 1024, 1, 8),
+            (1, 8, 64, 1, 8)]
+
+
+@pytest.mark.parametrize("wname", ["db2", "sym2"])
+def test_emu_swt4_fused_forward_and_inverse(wname):
+    """swt4_fwd_fused / swt4_inv_fused (levels l0, l0+1 of a 4-tap SWT in one launch: rings of 4 and 8 rows, halo lanes on
+    both sides) vs the oracle's level-by-level SWT"""
+    hlen, dlo, dhi, rlo, rhi = oracle.filters(wname)
+    assert hlen == 4
+    for si, (B, Nr, Nc, l0, seg) in enumerate(_swt4_cases()):
+        L = l0 + 1
+        f0 = 1 << (l0 - 1)
+        x = oracle.hash_input((B, Nr, Nc), 9500 + si)
+        refs = [oracle.forward(x[b], wname, L, do_swt=1) for b in range(B)]          # [A_L, H1, V1, D1, ...]
+        prev = [oracle.forward(x[b], wname, l0 - 1, do_swt=1)[0] if l0 > 1 else x[b] for b in range(B)]
+        ain = np.stack(prev).astype(np.float32)
+        det = np.full((6, B, Nr, Nc), np.nan, dtype=np.float32)
+        out = np.full((B, Nr, Nc), np.nan, dtype=np.float32)
+        assert lib().emu_swt4_fused(P(ain), P(det), P(out), B, Nr, Nc, f0, seg, P(dlo), P(dhi), None, 0) == 0
+        for b in range(B):
+            assert np.isfinite(out[b]).all(), (si, "A")
+            assert np.abs(out[b] - refs[b][0]).max() <= _tol(refs[b][0]) * 3, (si, "A")
+            for k in range(2):
+                for j in range(3):
+                    want = refs[b][1 + 3 * (l0 - 1 + k) + j]
+                    got = det[3 * k + j, b]
+                    assert np.isfinite(got).all(), (si, k, j)
+                    assert np.abs(got - want).max() <= _tol(want) * 3, (wname, si, k, j)
+        # inverse of arbitrary coefficients, with and without a pending soft threshold
+        for beta in (None, np.array([0.3, 0.2], dtype=np.float32)):
+            aK = (oracle.hash_input((B, Nr, Nc), 9600 + si, 2.0) - 1.0).astype(np.float32)
+            dets = (oracle.hash_input((6, B, Nr, Nc), 9700 + si, 2.0) - 1.0).astype(np.float32)
+            rec = np.full((B, Nr, Nc), np.nan, dtype=np.float32)
+            assert lib().emu_swt4_fused(P(aK), P(dets), P(rec), B, Nr, Nc, f0, seg, P(rlo), P(rhi),
+                                        P(beta) if beta is not None else None, 1) == 0
+            for b in range(B):
+                d = dets[:, b]
+                if beta is not None:
+                    d = np.stack([d[3 * k + j] - np.clip(d[3 * k + j], -beta[k], beta[k]) for k in range(2) for j in range(3)])
+                want = np.zeros((Nr, Nc), dtype=np.float32)
+                for py in range(f0):      # dilation f0 = the same transform on each of the f0 x f0 phase sub-images
+                    for px in range(f0):
+                        sub = [np.ascontiguousarray(aK[b][py::f0, px::f0])]
+                        sub += [np.ascontiguousarray(d[i][py::f0, px::f0]) for i in range(6)]
+                        want[py::f0, px::f0] = oracle.inverse(sub, sub[0].shape, wname, 2, do_swt=1)
+                assert np.isfinite(rec[b]).all(), (si, "inverse")
+                assert np.abs(rec[b] - want).max() <= 4e-6 * 3 * max(1.0, float(np.abs(want).max())), (wname, si, "inverse", beta is not None)

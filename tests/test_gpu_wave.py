@@ -276,7 +276,9 @@ def test_fp64_swt_fused_groups_vs_the_fp64_oracle():
     was = lib.pdwt_set_tuning(b"swt_fused", 2)
     try:
         for shape, lv, wname in (((64, 256), 3, "haar"), ((128, 520), 5, "db1"), ((96, 1024), 2, "haar"), ((256, 256), 6, "bior1.1"),
-                                 ((64, 260), 4, "haar")):
+                                 ((64, 260), 4, "haar"),
+                                 # 4-tap pairs (swt2_fused4_kernels.hpp) over doubles: levels (1, 2) and (3, 4)
+                                 ((64, 256), 2, "db2"), ((96, 520), 4, "sym2"), ((64, 1024), 3, "db2")):
             x = oracle.hash_input(shape, 8750 + lv, scale=255.0).astype(np.float64)
             x += 1e-9 * np.arange(x.size).reshape(x.shape)
             w = Wavelets64(x, wname, lv, do_swt=1)
@@ -295,3 +297,34 @@ def test_fp64_swt_fused_groups_vs_the_fp64_oracle():
             assert np.abs(w.image - want).max() <= 1e-11 * 255, (shape, lv, "soft")
     finally:
         lib.pdwt_set_tuning(b"swt_fused", was)
+
+
+@pytest.mark.parametrize("wname", ["db2", "sym2", "bior1.3"])
+def test_swt_four_tap_pairs_fused_per_launch_on_the_gpu(wname):
+    """4-tap 2D SWT (the reference's documentation example, doc/denoising.rst:85): levels (1, 2) and (3, 4) as one launch
+    each where the plan allows it (swt2_fused4_kernels.hpp); every band vs the oracle, then threshold + inverse vs the
+    oracle's sequence.  bior1.3 has 6 taps: the same shapes on the per-level kernels."""
+    from pypwt_amd import Wavelets, BatchedWavelets
+    for si, (shape, lv) in enumerate([((64, 512), 2), ((64, 512), 3), ((96, 260), 4), ((32, 1024), 4), ((128, 256), 5), ((8, 256), 2)]):
+        x = oracle.hash_input(shape, 6100 + si)
+        w = Wavelets(x, wname, lv, do_swt=1)
+        w.forward()
+        ref = oracle.forward(x, wname, w.levels, do_swt=1)
+        for k, (g, r) in enumerate(zip(_flat(w.coeffs), ref)):
+            assert np.abs(g - r).max() <= 3e-6 * (1 + w.levels) * max(1.0, float(np.abs(r).max())), (wname, shape, lv, k)
+        w.soft_threshold(7.0)
+        w.inverse()
+        thr = oracle.threshold(ref, shape, w.levels, "soft", 7.0, do_swt=1)
+        want = oracle.inverse(thr, shape, wname, w.levels, do_swt=1)
+        assert np.abs(w.image - want).max() <= 3e-5 * 255, (wname, shape, lv)
+    xb = oracle.hash_input((3, 64, 512), 6200)
+    bw = BatchedWavelets(3, 64, 512, wname, 4, do_swt=1, img=xb)
+    if oracle.filters(wname)[0] == 4:
+        assert "SWTF[1-2]" in bw.schedule().splitlines()[0], bw.schedule()
+    bw.forward()
+    for b in range(3):
+        ref = oracle.forward(xb[b], wname, bw.levels, do_swt=1)  # 6 taps: clamped to 3 levels on 64 rows
+        for k, r in enumerate(ref):
+            assert np.abs(bw.coeff(k)[b] - r).max() <= 3e-6 * 5 * max(1.0, float(np.abs(r).max())), (wname, b, k)
+    bw.inverse()
+    assert np.abs(bw.image - xb).max() <= 2e-3
