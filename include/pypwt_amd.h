@@ -156,6 +156,11 @@ int pdwt_set_filters_inverse(pdwt_handle h, const pdwt_real* filter1, const pdwt
 int pdwt_get_info(pdwt_handle h, pdwt_info* info, int* do_separable, int* do_cycle_spinning, int* state,
                   int* batch);
 int pdwt_print_info(pdwt_handle h);                       /* print_informations, wt.cu:511-550 */
+/* NEW: destroyed plans hand their device memory and stream to a small process-wide pool (at most PDWT_POOL_MB, default
+ * 1024 MiB, and 8 streams) that new plans draw from: creating + destroying a plan costs 3.4 ms of hipMalloc / hipFree /
+ * stream calls otherwise, twenty times the transform of a 512^2 image (the reference's tests and tutorials build one
+ * Wavelets object per image).  pdwt_trim_pool() releases everything the pool holds; returns the number of blocks freed. */
+int pdwt_trim_pool(void);
 /* NEW: the plan's launch lists as text, one line per direction: "fwd: LEVEL[1] LEVEL[2] PYR2[3-4]" (kind[levels]); what the
  * reference decides with if/else at every call (wt.cu:236-305) is decided once per plan here (plan.cpp: build_schedule).
  * Returns the length written (excluding the terminator) or a negative status. */

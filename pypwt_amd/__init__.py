@@ -9,4 +9,12 @@ libpypwt_amd_f64.so).  There is no CPU fallback.
 """
 from .wavelets import BatchedWavelets, DeviceArray, Wavelets, Wavelets64  # noqa: F401
 
+
+
+def trim_pool():
+    """Release the device memory and streams that destroyed plans left in the library's pool (all loaded variants)."""
+    from . import _lib
+    return sum(lib.pdwt_trim_pool() for lib in list(_lib._libs.values()))
+
+
 __version__ = "0.1.0"

@@ -77,6 +77,7 @@ def signatures(real=C.c_float):
         "pdwt_print_info": (C.c_int, [handle_t]),
         "pdwt_info_string": (C.c_int, [handle_t, C.c_char_p, C.c_size_t]),
         "pdwt_schedule_string": (C.c_int, [handle_t, C.c_char_p, C.c_size_t]),
+        "pdwt_trim_pool": (C.c_int, []),
         "pdwt_current_shift": (C.c_int, [handle_t, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
         "pdwt_last_error": (C.c_char_p, []),
         "pdwt_version": (C.c_char_p, []),

@@ -6,6 +6,8 @@
 // that touches data fails with PDWT_ERR_HIP.
 #include "plan.hpp"
 
+#include <mutex>
+
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -72,6 +74,96 @@ struct DeviceGuard {
         if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) (void)hipSetDevice(prev);
     }
 };
+
+// ---------------------------------------------------------------- device-memory / stream pool
+// The reference's users often build one Wavelets object per image (its tests and tutorials do); hipMalloc + hipFree +
+// hipStreamCreate/Destroy then cost 3.4 ms per object (tools/createtime.py) -- twenty times the transform of a 512^2
+// image.  Destroyed plans therefore hand their device blocks and their stream to a small process-wide pool (at most
+// PDWT_POOL_MB, default 1024 MiB, of cached memory and 8 streams; a plan has been synchronised before it gets here) and
+// new plans take a block of at least their size and at most 1.25x of it from there.  pdwt_trim_pool() releases everything.
+struct DevicePool {
+    struct Block { int dev; size_t bytes; void* p; };
+    std::mutex m;
+    std::vector<Block> blocks;
+    std::vector<std::pair<int, hipStream_t>> streams;
+    size_t cached = 0;
+    size_t limit = [] { const char* e = getenv("PDWT_POOL_MB"); return (size_t)(e ? atoll(e) : 1024) << 20; }();
+};
+DevicePool& device_pool() {
+    static DevicePool* p = new DevicePool();  // intentionally leaked: no HIP calls from static destructors
+    return *p;
+}
+hipError_t pool_alloc(int dev, void** out, size_t bytes, size_t* got) {
+    DevicePool& P = device_pool();
+    {
+        std::lock_guard<std::mutex> g(P.m);
+        int best = -1;
+        for (int i = 0; i < (int)P.blocks.size(); i++) {
+            const auto& b = P.blocks[i];
+            if (b.dev == dev && b.bytes >= bytes && b.bytes <= bytes + bytes / 4 + 4096 &&
+                (best < 0 || b.bytes < P.blocks[best].bytes))
+                best = i;
+        }
+        if (best >= 0) {
+            *out = P.blocks[best].p;
+            *got = P.blocks[best].bytes;
+            P.cached -= P.blocks[best].bytes;
+            P.blocks.erase(P.blocks.begin() + best);
+            return hipSuccess;
+        }
+    }
+    *got = bytes;
+    hipError_t e = hipMalloc(out, bytes);
+    if (e != hipSuccess) {  // out of memory: give the cached blocks back and try once more
+        (void)hipGetLastError();
+        std::vector<DevicePool::Block> drop;
+        {
+            std::lock_guard<std::mutex> g(P.m);
+            drop.swap(P.blocks);
+            P.cached = 0;
+        }
+        for (auto& b : drop) (void)hipFree(b.p);
+        e = hipMalloc(out, bytes);
+    }
+    return e;
+}
+void pool_free(int dev, void* p, size_t bytes) {
+    if (!p) return;
+    DevicePool& P = device_pool();
+    {
+        std::lock_guard<std::mutex> g(P.m);
+        if (bytes > 0 && P.cached + bytes <= P.limit && P.blocks.size() < 64) {
+            P.blocks.push_back({dev, bytes, p});
+            P.cached += bytes;
+            return;
+        }
+    }
+    (void)hipFree(p);
+}
+hipError_t pool_stream(int dev, hipStream_t* s) {
+    DevicePool& P = device_pool();
+    {
+        std::lock_guard<std::mutex> g(P.m);
+        for (size_t i = 0; i < P.streams.size(); i++)
+            if (P.streams[i].first == dev) {
+                *s = P.streams[i].second;
+                P.streams.erase(P.streams.begin() + i);
+                return hipSuccess;
+            }
+    }
+    return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+}
+void pool_return_stream(int dev, hipStream_t s) {
+    DevicePool& P = device_pool();
+    {
+        std::lock_guard<std::mutex> g(P.m);
+        if (P.streams.size() < 8) {
+            P.streams.push_back({dev, s});
+            return;
+        }
+    }
+    (void)hipStreamDestroy(s);
+}
 
 // Per-kernel timing: ONE event is recorded on the plan's stream in front of every launch; a
 // launch's duration is the distance to the next event (the next launch's, or the closing event
@@ -158,9 +250,12 @@ int build_layout(pdwt_plan* p) {
     p->image_off = off;
     off += pad64((long long)B * p->info.Nr * p->info.Nc);
     p->arena_elems = off;
-    HIP_TRY(hipMalloc((void**)&p->arena, (size_t)off * sizeof(real_t)));
+    HIP_TRY(pool_alloc(p->device, (void**)&p->arena, (size_t)off * sizeof(real_t), &p->arena_bytes));
     HIP_TRY(hipMemsetAsync(p->arena, 0, (size_t)off * sizeof(real_t), p->stream));
-    HIP_TRY(hipMalloc((void**)&p->d_red, 2 * sizeof(double)));
+    {
+        size_t got = 0;
+        HIP_TRY(pool_alloc(p->device, (void**)&p->d_red, 256, &got));  // two fp64 accumulators
+    }
     return PDWT_OK;
 }
 
@@ -267,7 +362,7 @@ int create_impl(const real_t* img, int batch, int Nr, int Nc, const char* wname,
         p->stream = (hipStream_t)stream;
         p->own_stream = false;
     } else {
-        hipError_t e = hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking);
+        hipError_t e = pool_stream(p->device, &p->stream);
         if (e != hipSuccess) { delete p; return fail(PDWT_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
         p->own_stream = true;
     }
@@ -967,7 +1062,7 @@ int pdwt_clone(pdwt_handle src, pdwt_handle* out) {
     p->shift_c = src->shift_c;
     p->dec = src->dec;
     p->rec = src->rec;
-    hipError_t e = hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking);
+    hipError_t e = pool_stream(p->device, &p->stream);
     if (e != hipSuccess) { delete p; return fail(PDWT_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
     p->own_stream = true;
     int rc = build_layout(p);
@@ -995,12 +1090,12 @@ int pdwt_destroy(pdwt_handle h) {
     DeviceGuard guard(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     clear_stamps(h);
-    if (h->arena) (void)hipFree(h->arena);
+    pool_free(h->device, h->arena, h->arena_bytes);
     if (h->tmp) (void)hipFree(h->tmp);
-    if (h->d_red) (void)hipFree(h->d_red);
+    pool_free(h->device, h->d_red, 256);
     if (h->d_f2d) (void)hipFree(h->d_f2d);
     if (h->chain_flags) (void)hipFree(h->chain_flags);
-    if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+    if (h->own_stream && h->stream) pool_return_stream(h->device, h->stream);
     delete h;
     return PDWT_OK;
 }
@@ -1451,7 +1546,10 @@ int pdwt_set_stream(pdwt_handle h, void* hip_stream) {
     CHECK_HANDLE(h);
     DeviceGuard guard(h->device);
     HIP_TRY(hipStreamSynchronize(h->stream));
-    if (h->own_stream && h->stream) HIP_TRY(hipStreamDestroy(h->stream));
+    if (h->own_stream && h->stream) {
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        pool_return_stream(h->device, h->stream);
+    }
     h->stream = (hipStream_t)hip_stream;
     h->own_stream = false;
     return PDWT_OK;
@@ -1499,6 +1597,27 @@ int pdwt_time_level(pdwt_handle h, int level, int inverse, int reps, float* ms_p
     HIP_TRY(hipEventElapsedTime(&ms, sc.e0, sc.e1));
     *ms_per_launch = ms / (float)reps;
     return rc;
+}
+
+int pdwt_trim_pool(void) {
+    DevicePool& P = device_pool();
+    std::vector<DevicePool::Block> drop;
+    std::vector<std::pair<int, hipStream_t>> st;
+    {
+        std::lock_guard<std::mutex> g(P.m);
+        drop.swap(P.blocks);
+        st.swap(P.streams);
+        P.cached = 0;
+    }
+    for (auto& b : drop) {
+        DeviceGuard guard(b.dev);
+        (void)hipFree(b.p);
+    }
+    for (auto& x : st) {
+        DeviceGuard guard(x.first);
+        (void)hipStreamDestroy(x.second);
+    }
+    return (int)drop.size();
 }
 
 int pdwt_schedule_string(pdwt_handle h, char* buf, size_t n) {

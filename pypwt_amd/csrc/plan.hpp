@@ -62,6 +62,7 @@ struct pdwt_plan {
 
     real_t* arena = nullptr;
     long long arena_elems = 0;
+    size_t arena_bytes = 0;  // size of the device block behind `arena` (it may come from the pool, up to 1.25x larger)
     std::vector<pdwt::Band> bands;      // coefficient bands, index = `num`
     long long coeff_elems = 0;          // size of the (padded) coefficient region
     std::vector<long long> approx_off;  // DWT: [l] for 1 <= l < L ; SWT: [0], [1] ping-pong
