@@ -319,7 +319,8 @@ def test_swt_four_tap_pairs_fused_per_launch_on_the_gpu(wname):
         assert np.abs(w.image - want).max() <= 3e-5 * 255, (wname, shape, lv)
     xb = oracle.hash_input((3, 64, 512), 6200)
     bw = BatchedWavelets(3, 64, 512, wname, 4, do_swt=1, img=xb)
-    if oracle.filters(wname)[0] == 4:
+    import os
+    if oracle.filters(wname)[0] == 4 and os.environ.get("PDWT_SWT_FUSED", "1") != "0":
         assert "SWTF[1-2]" in bw.schedule().splitlines()[0], bw.schedule()
     bw.forward()
     for b in range(3):
