@@ -126,6 +126,9 @@ int pdwt_add_wavelet(pdwt_handle dst, pdwt_handle src, pdwt_real alpha);
 /* ---- data movement (pdwt/src/wt.cu:419-506) ---- */
 long long pdwt_get_image(pdwt_handle h, pdwt_real* dst);          /* returns element count, <0 on error */
 long long pdwt_get_coeff(pdwt_handle h, pdwt_real* dst, int num); /* 0 if refused after inverse */
+/* In place: with mem_is_on_device = 1 and src == pdwt_image_ptr(h) (pdwt_coeff_ptr(h, num)) nothing is copied and the
+ * host does not block -- the caller has written the buffer itself (on the plan's stream, or ordered with it by
+ * pdwt_wait_for_stream) and the call only makes the image (the coefficients) current. */
 int pdwt_set_image(pdwt_handle h, const pdwt_real* src, int mem_is_on_device);
 int pdwt_set_coeff(pdwt_handle h, const pdwt_real* src, int num, int mem_is_on_device);
 long long pdwt_coeff_count(pdwt_handle h, int num, int* rows, int* cols); /* elements incl. batch */

@@ -1379,12 +1379,17 @@ int pdwt_set_image(pdwt_handle h, const real_t* src, int mem_is_on_device) {  //
     if (!src) return fail(PDWT_ERR_ARG, "pdwt_set_image: src is null");
     DeviceGuard guard(h->device);
     const long long n = (long long)h->batch * h->info.Nr * h->info.Nc;
-    HIP_TRY(hipMemcpyAsync(h->image(), src, (size_t)n * sizeof(real_t),
-                           mem_is_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, h->stream));
+    // the plan's own image buffer (the caller filled it through pdwt_image_ptr, on the plan's stream or ordered with it
+    // by pdwt_wait_for_stream): nothing to copy, nothing to wait for -- the call only makes the image current
+    const bool in_place = mem_is_on_device && src == h->image();
+    if (!in_place) {
+        HIP_TRY(hipMemcpyAsync(h->image(), src, (size_t)n * sizeof(real_t),
+                               mem_is_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+    }
     // host AND device sources: the copy has completed when the call returns, so the caller may reuse or free the
     // source at once (a torch temporary goes back to the caching allocator as soon as the Python call returns).
     // Ordering of the source's PRODUCER with this copy is the caller's: pdwt_wait_for_stream / pdwt_sync_producer.
-    HIP_TRY(hipStreamSynchronize(h->stream));
     // a threshold the fused inverse applied on the fly is written back before the state leaves PDWT_INVERSE:
     // get_coeff / norms / add_wavelet are legal again after set_image and must see thresholded details (wt.cu:308-315)
     {
@@ -1406,9 +1411,11 @@ int pdwt_set_coeff(pdwt_handle h, const real_t* src, int num, int mem_is_on_devi
         if (rc0 != PDWT_OK) return rc0;
     }
     const long long n = h->bands[num].elems(h->batch);
-    HIP_TRY(hipMemcpyAsync(h->band(num), src, (size_t)n * sizeof(real_t),
-                           mem_is_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));  // see pdwt_set_image
+    if (!(mem_is_on_device && src == h->band(num))) {  // the band's own buffer: in place, see pdwt_set_image
+        HIP_TRY(hipMemcpyAsync(h->band(num), src, (size_t)n * sizeof(real_t),
+                               mem_is_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));  // see pdwt_set_image
+    }
     // The reference forbids coefficient access after inverse() because its inverse overwrites the
     // approximation band d_coeffs[0] (wt.cu:272-275); once the caller has supplied that band again the
     // coefficients are current, so a new inverse() is meaningful (the reference would still refuse it).

@@ -45,8 +45,57 @@ class _DeviceView(object):
                                          "version": 2, "strides": None}
 
 
+class _LevelPlan(object):
+    """One single-GPU plan on an extended slab, with cached zero-copy views of its device buffers."""
+
+    def __init__(self, owner, rows, cols, levels, do_swt):
+        lib = owner._lib
+        h = handle_t()
+        rc = lib.pdwt_create_batched(None, 1, rows, cols, owner.wname.encode("ASCII"), levels, 1, 1, 0, do_swt, 2,
+                                     owner.device.index, C.c_void_p(owner._stream.cuda_stream), C.byref(h))
+        check(rc, "TiledWavelets plan", lib)
+        info = PdwtInfo()
+        check(lib.pdwt_get_info(h, C.byref(info), None, None, None, None), lib=lib)
+        self.h, self.levels, self.lib = h, int(info.nlevels), lib
+        self.img = owner._view(lib.pdwt_image_ptr(h), (rows, cols))
+        # the coefficient bands lie back to back in one region (pdwt_coeff_region): one flat view, one view per band, and --
+        # when all bands have one shape (a single decimated level, every undecimated plan) -- one (band, row, column) view
+        # whose row ranges are the halos of ALL bands: one message per neighbour instead of one per band
+        nb = 3 * self.levels + 1
+        offs = (C.c_longlong * nb)()
+        total = int(lib.pdwt_coeff_region(h, offs, nb))
+        region = owner._view(lib.pdwt_coeff_ptr(h, 0), (total,))
+        self.co, shapes = [], []
+        r, c = C.c_int(), C.c_int()
+        for num in range(nb):
+            lib.pdwt_coeff_count(h, num, C.byref(r), C.byref(c))
+            shapes.append((r.value, c.value))
+            self.co.append(region[offs[num]:offs[num] + r.value * c.value].view(r.value, c.value))
+        step = int(offs[1] - offs[0])
+        same = all(sh == shapes[0] for sh in shapes) and all(int(offs[k]) == k * step for k in range(nb))
+        self.stack = region.as_strided((nb,) + shapes[0], (step, shapes[0][1], 1)) if same else None
+
+    @staticmethod
+    def halo_pieces(t, h, m):
+        """rows [h, h + m) of `t` (rows on its last-but-one axis) are this rank's; the four row ranges of an exchange:
+        (top rows, bottom rows, halo above, halo below)"""
+        return (t[..., h:2 * h, :], t[..., m:m + h, :], t[..., :h, :], t[..., h + m:, :])
+
+    def destroy(self):
+        if self.h is not None:
+            self.lib.pdwt_destroy(self.h)
+            self.h = None
+
+
 class TiledWavelets(object):
-    def __init__(self, slab, wname, levels, group=None, do_swt=0):
+    """Data layout: the slab and every band slab live INSIDE the buffers of the single-GPU plans that work on them
+    (the interior rows of an extended slab); the halo rows around them are received straight into the same buffers.
+    A level therefore costs its kernel, one halo exchange and (from level 2 on) one copy of the approximation slab
+    into the next plan -- no staging tensors.  `coeffs` / `image` copy to the host when asked."""
+
+    def __init__(self, slab, wname, levels, group=None, do_swt=0, loopback=False):
+        """loopback: with ONE rank, still send the halos / gather / broadcast through the process group (the rank
+        is its own neighbour) instead of copying them -- the way to run the RCCL transport on a one-GPU box."""
         import sys
         if "torch" not in sys.modules and _lib._libs:
             # PyTorch-ROCm bundles its own libamdhip64 under the same soname as /opt/rocm's: whichever is
@@ -63,12 +112,12 @@ class TiledWavelets(object):
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self._via_host = dist.is_initialized() and dist.get_backend(group) != "nccl"  # gloo: stage halos on the host
+        self._loopback = bool(loopback) and dist.is_initialized() and self.world == 1
         self.device = torch.device("cuda", torch.cuda.current_device())
-        self.slab = torch.as_tensor(np.ascontiguousarray(slab, dtype=np.float32) if isinstance(slab, np.ndarray)
-                                    else slab, dtype=torch.float32, device=self.device).contiguous().clone()
-        if self.slab.dim() != 2:
+        src = torch.as_tensor(np.ascontiguousarray(slab, dtype=np.float32) if isinstance(slab, np.ndarray) else slab)
+        if src.dim() != 2:
             raise ValueError("TiledWavelets: the slab must be a 2D array (rows of this rank x all columns)")
-        self.n, self.Nc = int(self.slab.shape[0]), int(self.slab.shape[1])
+        self.n, self.Nc = int(src.shape[0]), int(src.shape[1])
         self.wname = str(wname)
         buf = (C.c_float * 160)()
         hlen = self._lib.pdwt_wavelet_filters(self.wname.encode("ASCII"), buf, 160)
@@ -78,7 +127,9 @@ class TiledWavelets(object):
         self.do_swt = int(bool(do_swt))
         self._deep = None    # rank 0: the single-GPU plan of the gathered approximation
         self._plans = {}
-        self._bands = None   # after forward(): [A_L, (H1,V1,D1), ...] torch slabs
+        self._piece_cache = {}
+        self._bands = None   # after forward(): [A_L, (H1,V1,D1), ...] views of the plans' buffers
+        self._in_coeff_domain = False
         # every plan runs on ONE side stream that torch also uses for its copies (a NULL stream handle would
         # mean "private stream" to pdwt_create_batched, unordered with torch's default stream)
         self._stream = torch.cuda.Stream(device=self.device)
@@ -90,68 +141,101 @@ class TiledWavelets(object):
                 raise ValueError("TiledWavelets: a slab of %d rows is thinner than the halo of a %d-level SWT with %s (%d rows)"
                                  % (self.n, self.levels, self.wname, self._hs))
             self.tiled_levels, self.deep_levels = self.levels, 0
-            return
-        if self.levels < 1 or self.Nc % (1 << self.levels):
-            raise ValueError("TiledWavelets: columns (%d) must be divisible by 2^levels" % self.Nc)
-        c = self.hlen // 2 - 1
-        self._hp = c + (c & 1)                        # analysis halo rows (even)
-        H2 = self.hlen // 2
-        C2, S = H2 // 2, (0 if (H2 & 1) else 1)
-        self._hq = max(C2, H2 - 1 - C2 + S)           # synthesis halo rows (coefficient rows)
-        # levels that run as slabs: the slab entering the level is even, at least as tall as the analysis halo,
-        # and its half at least as tall as the synthesis halo; the rest runs on rank 0 after the gather
-        t, m = 0, self.n
-        while t < self.levels and m % 2 == 0 and m >= self._hp and (m >> 1) >= self._hq and m >= 2:
-            t, m = t + 1, m >> 1
-        if t < 1:
-            raise ValueError("TiledWavelets: a slab of %d rows is too thin (or odd) for one level of %s (halo %d)"
-                             % (self.n, self.wname, max(self._hp, 2 * self._hq)))
-        self.tiled_levels, self.deep_levels = t, self.levels - t
+            P = self._swt_plan()
+            self.slab = P.img[self._hs:self._hs + self.n]
+        else:
+            if self.levels < 1 or self.Nc % (1 << self.levels):
+                raise ValueError("TiledWavelets: columns (%d) must be divisible by 2^levels" % self.Nc)
+            c = self.hlen // 2 - 1
+            self._hp = c + (c & 1)                        # analysis halo rows (even)
+            H2 = self.hlen // 2
+            C2, S = H2 // 2, (0 if (H2 & 1) else 1)
+            self._hq = max(C2, H2 - 1 - C2 + S)           # synthesis halo rows (coefficient rows); always hp / 2
+            assert 2 * self._hq == self._hp
+            # levels that run as slabs: the slab entering the level is even, at least as tall as the analysis halo,
+            # and its half at least as tall as the synthesis halo; the rest runs on rank 0 after the gather
+            t, m = 0, self.n
+            while t < self.levels and m % 2 == 0 and m >= self._hp and (m >> 1) >= self._hq and m >= 2:
+                t, m = t + 1, m >> 1
+            if t < 1:
+                raise ValueError("TiledWavelets: a slab of %d rows is too thin (or odd) for one level of %s (halo %d)"
+                                 % (self.n, self.wname, max(self._hp, 2 * self._hq)))
+            self.tiled_levels, self.deep_levels = t, self.levels - t
+            P = self._level(1)
+            self.slab = P.img[self._hp:self._hp + self.n]   # the slab lives in the interior of level 1's plan
+        with self._on_stream():
+            self.slab.copy_(src.to(self.device, dtype=torch.float32, non_blocking=False))
 
-    # ---- single-level plans on the extended slab, cached per shape
+    # ---- plans, cached per extended shape.  Level l (1-based) of the decimated transform works on the slab of
+    # n / 2^(l-1) rows extended by hp rows per side; its four outputs are (that / 2 + 2 hq) rows -- and since
+    # hp = 2 hq the SAME plan undoes the level: one plan per level holds the slab's interior and halos of both
+    # directions.
     def _plan(self, rows, cols):
         key = (rows, cols)
         if key not in self._plans:
-            h = handle_t()
-            stream = self._stream.cuda_stream
-            rc = self._lib.pdwt_create_batched(None, 1, rows, cols, self.wname.encode("ASCII"), 1, 1, 1, 0, 0, 2,
-                                               self.device.index, C.c_void_p(stream), C.byref(h))
-            check(rc, "TiledWavelets plan", self._lib)
-            info = PdwtInfo()
-            check(self._lib.pdwt_get_info(h, C.byref(info), None, None, None, None), lib=self._lib)
-            if info.nlevels != 1:
+            P = _LevelPlan(self, rows, cols, 1, 0)
+            if P.levels != 1:
+                P.destroy()
                 raise ValueError("TiledWavelets: %d x %d is too small for one level of %s" % (rows, cols, self.wname))
-            self._plans[key] = h
+            self._plans[key] = P
         return self._plans[key]
+
+    def _level(self, l):
+        return self._plan((self.n >> (l - 1)) + 2 * self._hp, self.Nc >> (l - 1))
+
+    def _pieces(self, P, what, h, m):
+        """cached halo row ranges of a plan's image ("img") or band stack ("stack")"""
+        key = (id(P), what)
+        if key not in self._piece_cache:
+            self._piece_cache[key] = _LevelPlan.halo_pieces(getattr(P, what), h, m)
+        return self._piece_cache[key]
 
     def _view(self, ptr, shape):
         return self._torch.as_tensor(_DeviceView(ptr, shape), device=self.device)
 
-    # ---- ring exchange: returns (rows from the previous rank's bottom, rows from the next rank's top)
-    def _exchange(self, top, bottom):
+    # ---- ring exchange, in place.  pieces = [(top rows, bottom rows, halo above, halo below), ...]: this rank's top
+    # rows go to the previous rank's "halo below", its bottom rows to the next rank's "halo above".
+    def _exchange_into(self, pieces):
         torch, dist = self._torch, self._dist
-        if self.world == 1:
-            return bottom.clone(), top.clone()  # the ring closes on itself: periodic image
+        if self.world == 1 and not self._loopback:
+            for top, bottom, above, below in pieces:  # the ring closes on itself: periodic image
+                above.copy_(bottom)
+                below.copy_(top)
+            return
         prev, nxt = (self.rank - 1) % self.world, (self.rank + 1) % self.world
         if self._via_host:
-            top_h, bot_h = top.cpu(), bottom.cpu()
-            from_prev, from_next = torch.empty_like(bot_h), torch.empty_like(top_h)
-            reqs = [dist.isend(bot_h, nxt, group=self.group, tag=1), dist.isend(top_h, prev, group=self.group, tag=2),
+            tops = torch.cat([p[0].reshape(-1) for p in pieces]).cpu()
+            bots = torch.cat([p[1].reshape(-1) for p in pieces]).cpu()
+            from_prev, from_next = torch.empty_like(bots), torch.empty_like(tops)
+            reqs = [dist.isend(bots, nxt, group=self.group, tag=1), dist.isend(tops, prev, group=self.group, tag=2),
                     dist.irecv(from_prev, prev, group=self.group, tag=1),
                     dist.irecv(from_next, nxt, group=self.group, tag=2)]
             for r in reqs:
                 r.wait()
-            return from_prev.to(self.device), from_next.to(self.device)
-        from_prev, from_next = torch.empty_like(bottom), torch.empty_like(top)
+            o = 0
+            for top, bottom, above, below in pieces:
+                k = above.numel()
+                above.copy_(from_prev[o:o + k].view(above.shape))
+                below.copy_(from_next[o:o + k].view(below.shape))
+                o += k
+            return
         # one grouped launch (ncclGroupStart/End): with two ranks both neighbours are the same peer, and
-        # the k-th send to a peer matches its k-th receive, hence this order
-        ops = [dist.P2POp(dist.isend, bottom.contiguous(), nxt, self.group),
-               dist.P2POp(dist.isend, top.contiguous(), prev, self.group),
-               dist.P2POp(dist.irecv, from_prev, prev, self.group),
-               dist.P2POp(dist.irecv, from_next, nxt, self.group)]
+        # the k-th send to a peer matches its k-th receive, hence this order.  Every piece is a range of whole
+        # rows of a plan buffer (contiguous): sent from and received into the buffers themselves.
+        # The halos of a band STACK are strided: packed into / unpacked from one message by one copy each.
+        land = lambda t: t if t.is_contiguous() else torch.empty(t.shape, dtype=t.dtype, device=t.device)
+        above, below = [land(p[2]) for p in pieces], [land(p[3]) for p in pieces]
+        ops = [dist.P2POp(dist.isend, p[1].contiguous(), nxt, self.group) for p in pieces]
+        ops += [dist.P2POp(dist.isend, p[0].contiguous(), prev, self.group) for p in pieces]
+        ops += [dist.P2POp(dist.irecv, t, prev, self.group) for t in above]
+        ops += [dist.P2POp(dist.irecv, t, nxt, self.group) for t in below]
         for r in dist.batch_isend_irecv(ops):
             r.wait()
-        return from_prev, from_next
+        for p, a, b in zip(pieces, above, below):
+            if a is not p[2]:
+                p[2].copy_(a)
+            if b is not p[3]:
+                p[3].copy_(b)
 
     def _on_stream(self):
         """Context: torch work goes to the plans' stream, ordered after / before the caller's stream."""
@@ -184,115 +268,85 @@ class TiledWavelets(object):
     def _swt_plan(self):
         key = ("swt", self.n + 2 * self._hs, self.Nc)
         if key not in self._plans:
-            h = handle_t()
-            rc = self._lib.pdwt_create_batched(None, 1, key[1], key[2], self.wname.encode("ASCII"), self.levels, 1, 1, 0,
-                                               1, 2, self.device.index, C.c_void_p(self._stream.cuda_stream), C.byref(h))
-            check(rc, "TiledWavelets SWT plan", self._lib)
-            info = PdwtInfo()
-            check(self._lib.pdwt_get_info(h, C.byref(info), None, None, None, None), lib=self._lib)
-            if info.nlevels != self.levels:
-                self._lib.pdwt_destroy(h)
-                raise ValueError("TiledWavelets: %d SWT levels requested, the slab allows only %d" % (self.levels, info.nlevels))
-            self._plans[key] = h
+            P = _LevelPlan(self, key[1], key[2], self.levels, 1)
+            if P.levels != self.levels:
+                P.destroy()
+                raise ValueError("TiledWavelets: %d SWT levels requested, the slab allows only %d" % (self.levels, P.levels))
+            self._plans[key] = P
         return self._plans[key]
 
     def _forward_swt(self):
-        m, w, hs = self.n, self.Nc, self._hs
-        h = self._swt_plan()
-        img = self._view(self._lib.pdwt_image_ptr(h), (m + 2 * hs, w))
-        from_prev, from_next = self._exchange(self.slab[:hs], self.slab[m - hs:])
-        img[:hs].copy_(from_prev)
-        img[hs + m:].copy_(from_next)
-        img[hs:hs + m].copy_(self.slab)
-        check(self._lib.pdwt_forward(h), "TiledWavelets.forward (SWT)", self._lib)
-        flat = [self._view(self._lib.pdwt_coeff_ptr(h, k), (m + 2 * hs, w))[hs:hs + m].clone()
-                for k in range(3 * self.levels + 1)]
+        m, hs = self.n, self._hs
+        P = self._swt_plan()
+        self._exchange_into([self._pieces(P, "img", hs, m)])
+        check(self._lib.pdwt_forward(P.h), "TiledWavelets.forward (SWT)", self._lib)
+        flat = [b[hs:hs + m] for b in P.co]
         self._bands = [flat[0]] + [tuple(flat[1 + 3 * l:4 + 3 * l]) for l in range(self.levels)]
         return self
 
     def _inverse_swt(self):
-        torch = self._torch
-        m, w, hs = self.n, self.Nc, self._hs
-        h = self._swt_plan()
-        flat = [self._bands[0]] + [b for lvl in self._bands[1:] for b in lvl]
-        stack = torch.stack(flat)                                            # (3 levels + 1, m, w)
-        from_prev, from_next = self._exchange(stack[:, :hs].contiguous(), stack[:, m - hs:].contiguous())
-        ext0 = torch.cat([from_prev[0], flat[0], from_next[0]]).contiguous()
-        # band 0 through set_coeff (it makes the plan's coefficients current), the details into the plan's buffers
-        check(self._lib.pdwt_set_coeff(h, C.c_void_p(ext0.data_ptr()), 0, 1), lib=self._lib)
-        for k in range(1, len(flat)):
-            dst = self._view(self._lib.pdwt_coeff_ptr(h, k), (m + 2 * hs, w))
-            dst[:hs].copy_(from_prev[k])
-            dst[hs:hs + m].copy_(flat[k])
-            dst[hs + m:].copy_(from_next[k])
-        check(self._lib.pdwt_inverse(h), "TiledWavelets.inverse (SWT)", self._lib)
-        self.slab = self._view(self._lib.pdwt_image_ptr(h), (m + 2 * hs, w))[hs:hs + m].clone()
+        m, hs = self.n, self._hs
+        P = self._swt_plan()
+        # the halo rows of all 3 levels + 1 bands, received into the bands' own buffers: one message per neighbour
+        self._exchange_into([self._pieces(P, "stack", hs, m)])
+        check(self._lib.pdwt_inverse(P.h), "TiledWavelets.inverse (SWT)", self._lib)
         return self
 
     def _forward(self, slab=None):
         torch = self._torch
         if slab is not None:
-            self.slab.copy_(torch.as_tensor(slab, dtype=torch.float32, device=self.device))
+            self.slab.copy_(torch.as_tensor(slab).to(self.device, dtype=torch.float32))
         if self.do_swt:
-            return self._forward_swt()
-        cur, hp = self.slab, self._hp
+            self._forward_swt()
+            self._in_coeff_domain = True
+            return self
+        hp, hq = self._hp, self._hq
         bands = [None]
-        for _ in range(self.tiled_levels):
-            m, w = int(cur.shape[0]), int(cur.shape[1])
-            h = self._plan(m + 2 * hp, w)
-            img = self._view(self._lib.pdwt_image_ptr(h), (m + 2 * hp, w))
+        P = None
+        for l in range(1, self.tiled_levels + 1):
+            m = self.n >> (l - 1)
+            Q = self._level(l)
+            if P is not None:
+                Q.img[hp:hp + m].copy_(P.co[0][hq:hq + m])   # A of the level above: the interior rows of its plan's band 0
+            P = Q
             if hp:
-                from_prev, from_next = self._exchange(cur[:hp], cur[m - hp:])
-                img[:hp].copy_(from_prev)
-                img[hp + m:].copy_(from_next)
-            img[hp:hp + m].copy_(cur)
-            check(self._lib.pdwt_forward(h), "TiledWavelets.forward", self._lib)
-            rows2, w2 = (m + 2 * hp) // 2, w // 2
-            out = [self._view(self._lib.pdwt_coeff_ptr(h, k), (rows2, w2))[hp // 2:hp // 2 + m // 2].clone()
-                   for k in range(4)]
-            bands.append((out[1], out[2], out[3]))
-            cur = out[0]
+                self._exchange_into([self._pieces(P, "img", hp, m)])
+            check(self._lib.pdwt_forward(P.h), "TiledWavelets.forward", self._lib)
+            bands.append(tuple(P.co[k][hq:hq + m // 2] for k in (1, 2, 3)))
+        cur = P.co[0][hq:hq + (self.n >> self.tiled_levels)]
         bands[0] = cur
         if self.deep_levels:
             bands[0] = None
             self._a_slab_shape = tuple(cur.shape)
             full = self._gather_rows(cur)            # every rank receives it (all-gather); rank 0 uses it
             if self.rank == 0:
-                h = self._deep_plan(int(full.shape[0]), int(full.shape[1]))
-                check(self._lib.pdwt_set_image(h, C.c_void_p(full.contiguous().data_ptr()), 1), lib=self._lib)
-                check(self._lib.pdwt_forward(h), "TiledWavelets.forward (gathered levels)", self._lib)
-                rows, cols = C.c_int(), C.c_int()
-                deep = []
-                for num in range(3 * self.deep_levels + 1):
-                    self._lib.pdwt_coeff_count(h, num, C.byref(rows), C.byref(cols))
-                    deep.append(self._view(self._lib.pdwt_coeff_ptr(h, num), (rows.value, cols.value)).clone())
-                bands[0] = deep[0]
+                D = self._deep_plan(int(full.shape[0]), int(full.shape[1]))
+                D.img.copy_(full)
+                check(self._lib.pdwt_set_image(D.h, C.c_void_p(D.img.data_ptr()), 1), lib=self._lib)  # marks the image current
+                check(self._lib.pdwt_forward(D.h), "TiledWavelets.forward (gathered levels)", self._lib)
+                bands[0] = D.co[0]
                 for l in range(self.deep_levels):
-                    bands.append(tuple(deep[1 + 3 * l:4 + 3 * l]))
+                    bands.append(tuple(D.co[1 + 3 * l:4 + 3 * l]))
             else:
                 bands += [None] * self.deep_levels
         self._bands = bands
+        self._in_coeff_domain = True
         return self
 
     def _deep_plan(self, rows, cols):
         if self._deep is None:
-            h = handle_t()
-            rc = self._lib.pdwt_create_batched(None, 1, rows, cols, self.wname.encode("ASCII"), self.deep_levels, 1, 1, 0,
-                                               0, 2, self.device.index, C.c_void_p(self._stream.cuda_stream), C.byref(h))
-            check(rc, "TiledWavelets gathered plan", self._lib)
-            info = PdwtInfo()
-            check(self._lib.pdwt_get_info(h, C.byref(info), None, None, None, None), lib=self._lib)
-            if info.nlevels != self.deep_levels:
-                self._lib.pdwt_destroy(h)
+            D = _LevelPlan(self, rows, cols, self.deep_levels, 0)
+            if D.levels != self.deep_levels:
+                D.destroy()
                 raise ValueError("TiledWavelets: %d levels requested, the image allows only %d"
-                                 % (self.levels, self.tiled_levels + info.nlevels))
-            self._deep = h
+                                 % (self.levels, self.tiled_levels + D.levels))
+            self._deep = D
         return self._deep
 
     # ---- the ONE collective of the path: all ranks' slabs stacked in rank order
     def _gather_rows(self, slab):
         torch, dist = self._torch, self._dist
-        if self.world == 1:
+        if self.world == 1 and not self._loopback:
             return slab
         if self._via_host:
             parts = [torch.empty(slab.shape, dtype=slab.dtype) for _ in range(self.world)]
@@ -305,7 +359,7 @@ class TiledWavelets(object):
     def _scatter_rows(self, full, slab_shape):
         """rank 0 holds `full`; every rank gets its slab (one broadcast, each rank slices)."""
         torch, dist = self._torch, self._dist
-        if self.world == 1:
+        if self.world == 1 and not self._loopback:
             return full
         rows = slab_shape[0] * self.world
         if self._via_host:
@@ -315,45 +369,37 @@ class TiledWavelets(object):
         buf = full.contiguous() if self.rank == 0 else torch.empty((rows, slab_shape[1]), dtype=torch.float32,
                                                                     device=self.device)
         dist.broadcast(buf, 0, group=self.group)
-        return buf[self.rank * slab_shape[0]:(self.rank + 1) * slab_shape[0]].clone()
+        return buf[self.rank * slab_shape[0]:(self.rank + 1) * slab_shape[0]]
 
     def _inverse(self):
         if self._bands is None:
             raise RuntimeError("TiledWavelets.inverse: call forward() first")
+        if not self._in_coeff_domain:
+            return self  # the image is current (the reference's W_INVERSE state: a second inverse does nothing)
         if self.do_swt:
-            return self._inverse_swt()
-        torch, hq = self._torch, self._hq
-        cur = self._bands[0]
+            self._inverse_swt()
+            self._in_coeff_domain = False
+            return self
+        hp, hq = self._hp, self._hq
+        t = self.tiled_levels
+        P = self._level(t)
+        m2 = self.n >> t
         if self.deep_levels:
             full = None
             if self.rank == 0:  # undo the gathered levels, then hand the slabs of A_t back
-                h = self._deep
-                check(self._lib.pdwt_set_coeff(h, C.c_void_p(self._bands[0].contiguous().data_ptr()), 0, 1), lib=self._lib)
-                for l in range(self.deep_levels):
-                    for k in range(3):
-                        b = self._bands[self.tiled_levels + 1 + l][k]
-                        self._view(self._lib.pdwt_coeff_ptr(h, 1 + 3 * l + k), tuple(b.shape)).copy_(b)
-                check(self._lib.pdwt_inverse(h), "TiledWavelets.inverse (gathered levels)", self._lib)
-                full = self._view(self._lib.pdwt_image_ptr(h), (self._a_slab_shape[0] * self.world, self._a_slab_shape[1]))
-            cur = self._scatter_rows(full, self._a_slab_shape)
-        for lvl in range(self.tiled_levels, 0, -1):
-            H, V, D = self._bands[lvl]
-            m2, w2 = int(cur.shape[0]), int(cur.shape[1])
-            h = self._plan(2 * (m2 + 2 * hq), 2 * w2)
-            ext = [cur, H, V, D]
+                D = self._deep
+                check(self._lib.pdwt_inverse(D.h), "TiledWavelets.inverse (gathered levels)", self._lib)
+                full = D.img
+            P.co[0][hq:hq + m2].copy_(self._scatter_rows(full, self._a_slab_shape))
+        for l in range(t, 0, -1):
+            m2 = self.n >> l
+            P = self._level(l)
             if hq:
-                stack = torch.stack(ext)                                     # (4, m2, w2)
-                from_prev, from_next = self._exchange(stack[:, :hq].contiguous(), stack[:, m2 - hq:].contiguous())
-                ext = [torch.cat([from_prev[k], ext[k], from_next[k]]) for k in range(4)]
-            # band 0 through set_coeff (it also makes the plan's coefficients current again after the
-            # previous inverse), the details straight into the plan's buffers
-            check(self._lib.pdwt_set_coeff(h, C.c_void_p(ext[0].contiguous().data_ptr()), 0, 1), lib=self._lib)
-            for k in (1, 2, 3):
-                self._view(self._lib.pdwt_coeff_ptr(h, k), (m2 + 2 * hq, w2)).copy_(ext[k])
-            check(self._lib.pdwt_inverse(h), "TiledWavelets.inverse", self._lib)
-            img = self._view(self._lib.pdwt_image_ptr(h), (2 * (m2 + 2 * hq), 2 * w2))
-            cur = img[2 * hq:2 * hq + 2 * m2].clone()
-        self.slab = cur
+                self._exchange_into([self._pieces(P, "stack", hq, m2)])
+            check(self._lib.pdwt_inverse(P.h), "TiledWavelets.inverse", self._lib)
+            if l > 1:  # the interior of the reconstruction is A of the level above
+                self._level(l - 1).co[0][hq:hq + 2 * m2].copy_(P.img[hp:hp + 2 * m2])
+        self._in_coeff_domain = False
         return self
 
     # ---- results (this rank's slabs)
@@ -372,12 +418,23 @@ class TiledWavelets(object):
         A = None if self._bands[0] is None else self._bands[0].cpu().numpy()
         return [A] + [None if lvl is None else [b.cpu().numpy() for b in lvl] for lvl in self._bands[1:]]
 
+    @property
+    def device_coeffs(self):
+        """the same structure as zero-copy torch views of the plans' device buffers (valid until the next forward /
+        inverse; writing to them -- thresholding, say -- before inverse() is the intended use)"""
+        if self._bands is None:
+            raise RuntimeError("TiledWavelets.device_coeffs: call forward() first")
+        return [self._bands[0]] + [None if lvl is None else list(lvl) for lvl in self._bands[1:]]
+
     def cleanup(self):
-        for h in self._plans.values():
-            self._lib.pdwt_destroy(h)
+        self._bands = None
+        self.slab = None
+        self._piece_cache = {}
+        for P in self._plans.values():
+            P.destroy()
         self._plans = {}
         if getattr(self, "_deep", None):
-            self._lib.pdwt_destroy(self._deep)
+            self._deep.destroy()
             self._deep = None
 
     def __del__(self):

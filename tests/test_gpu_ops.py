@@ -553,6 +553,21 @@ def test_c_abi_device_memory_create_set_image_set_coeff_clone_and_stream(W):
     assert lib.pdwt_synchronize(h) == 0
     assert hip.hipMemcpy(back.ctypes.data, C.c_void_p(lib.pdwt_image_ptr(h)), 4 * n, D2H) == 0
     assert np.array_equal(back, rec)
+    # 6. in place: buffers the caller filled through pdwt_image_ptr / pdwt_coeff_ptr, made current without a copy
+    assert hip.hipMemcpy(C.c_void_p(lib.pdwt_image_ptr(h)), y.ctypes.data, 4 * n, H2D) == 0
+    assert lib.pdwt_set_image(h, C.c_void_p(lib.pdwt_image_ptr(h)), 1) == 0
+    assert lib.pdwt_forward(h) == 0
+    close(coeffs_of(h), ry)
+    assert lib.pdwt_inverse(h) == 0
+    assert lib.pdwt_inverse(h) != 0  # a second inverse is refused: state PDWT_INVERSE (wt.cu:271-275)
+    A_x = np.ascontiguousarray(rx[0])
+    assert lib.pdwt_synchronize(h) == 0
+    assert hip.hipMemcpy(C.c_void_p(lib.pdwt_coeff_ptr(h, 0)), A_x.ctypes.data, A_x.nbytes, H2D) == 0
+    assert lib.pdwt_set_coeff(h, C.c_void_p(lib.pdwt_coeff_ptr(h, 0)), 0, 1) == 0  # re-arms the inverse
+    assert lib.pdwt_inverse(h) == 0
+    assert lib.pdwt_get_image(h, rec.ctypes.data) == n
+    want = oracle.inverse([rx[0]] + ry[1:], shape, wname, lv)
+    assert np.abs(rec - want).max() <= 3e-6 * 255 * 3
     assert lib.pdwt_destroy(h) == 0 and lib.pdwt_destroy(h2) == 0
     hip.hipStreamDestroy(st)
     for p in (dx, dy, dA):

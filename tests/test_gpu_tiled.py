@@ -25,7 +25,7 @@ def _free_port():
     return p
 
 
-def _run_ranks(world, wname, levels, shape, swt=0):
+def _run_ranks(world, wname, levels, shape, swt=0, backend="gloo"):
     """Each rank is a child process (torch must be imported before libpypwt_amd.so in a process, and the
     pytest process has long loaded the library): tests/tiled_worker.py compares its slabs itself."""
     port = _free_port()
@@ -34,7 +34,7 @@ def _run_ranks(world, wname, levels, shape, swt=0):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port))
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "tiled_worker.py"), wname,
-                                       str(levels), str(shape[0]), str(shape[1]), "gloo", str(swt)],
+                                       str(levels), str(shape[0]), str(shape[1]), backend, str(swt)],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = []
     for p in procs:
@@ -47,6 +47,7 @@ def _run_ranks(world, wname, levels, shape, swt=0):
         outs.append(out)
     for r, (p, out) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and ("OK %d" % r) in out, "rank %d failed:\n%s" % (r, out[-3000:])
+    return outs
 
 
 @pytest.mark.parametrize("wname,levels,shape", [("haar", 3, (64, 96)), ("db2", 2, (64, 64)), ("db4", 3, (192, 160)),
@@ -79,6 +80,16 @@ def test_swt_slabs_with_one_halo_exchange(world, wname, levels, shape):
     """undecimated transform: ONE exchange of hlen (2^levels - 1) rows per side, the whole multi-level SWT plan on the
     extended slab, interiors kept; every band's slab and the reconstruction against the oracle"""
     _run_ranks(world, wname, levels, shape, swt=1)
+
+
+@pytest.mark.parametrize("wname,levels,shape,swt", [("db4", 3, (192, 160), 0), ("db2", 4, (40, 64), 0), ("sym8", 2, (128, 256), 0),
+                                                    ("haar", 3, (64, 96), 1), ("db2", 3, (128, 100), 1)])
+def test_rccl_transport_with_one_rank_as_its_own_neighbour(wname, levels, shape, swt):
+    """backend nccl (= RCCL), world size 1, loopback: the halos go through grouped device-to-device send / recv, the
+    gathered levels through all_gather and broadcast -- the code the ranks of a multi-GPU node run, on the one GPU of
+    this box (tiled.py, `loopback`)"""
+    outs = _run_ranks(1, wname, levels, shape, swt=swt, backend="nccl")
+    assert "rccl-loopback" in outs[0]
 
 
 def test_import_order_is_checked():

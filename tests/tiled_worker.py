@@ -24,11 +24,12 @@ def main():
     backend = sys.argv[5] if len(sys.argv) > 5 else "gloo"
     swt = int(sys.argv[6]) if len(sys.argv) > 6 else 0
     torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1))
-    if world > 1:  # world 1 runs WITHOUT a process group: the ring closes on the rank itself
+    loopback = world == 1 and backend == "nccl"  # one rank over RCCL: its own neighbour, halos through send/recv
+    if world > 1 or loopback:  # otherwise world 1 runs WITHOUT a process group: the ring closes on the rank itself
         dist.init_process_group(backend, rank=rank, world_size=world)
     x = oracle.hash_input((Nr, Nc), 555, scale=255.0)
     n = Nr // world
-    tw = TiledWavelets(x[rank * n:(rank + 1) * n], wname, levels, do_swt=swt)
+    tw = TiledWavelets(x[rank * n:(rank + 1) * n], wname, levels, do_swt=swt, loopback=loopback)
     tw.forward()
     flat = oracle.forward(x, wname, levels, do_swt=swt)  # [A, H1, V1, D1, H2, ...] from the CPU oracle
     ref = [flat[0]] + [flat[1 + 3 * l:4 + 3 * l] for l in range(levels)]
@@ -55,18 +56,33 @@ def main():
         assert got[0].shape == ref[0].shape and np.abs(got[0] - ref[0]).max() <= tol, "A (gathered)"
     else:
         assert got[0] is None
+    tw.forward()  # a forward does not consume the slab: the same coefficients again
+    again = tw.coeffs
+    for a, b in zip(got[1], again[1]):
+        assert np.array_equal(a, b), "second forward"
     tw.inverse()
     if swt:  # the reconstruction against the oracle's inverse of the oracle's coefficients too
         rec = oracle.inverse(flat, x.shape, wname, levels, do_swt=1)
         assert np.abs(tw.image - rec[rank * n:(rank + 1) * n]).max() <= 2e-3, "reconstruction vs oracle"
     assert np.abs(tw.image - x[rank * n:(rank + 1) * n]).max() <= 2e-3, "reconstruction"
+    tw.inverse()  # the image is current: a second inverse changes nothing (the reference's W_INVERSE state)
     tw.forward()
-    tw.inverse()  # plans are reused: a second round trip must work too
-    assert np.abs(tw.image - x[rank * n:(rank + 1) * n]).max() <= 4e-3, "second round trip"
-    if world > 1:
+    for lvl in tw.device_coeffs[1:tw.tiled_levels + 1]:  # zero-copy views of the plans' buffers: shrink the details in place
+        for b in lvl:
+            b.mul_(0.5)
+    tw.inverse()
+    flat2 = [f.copy() for f in flat]
+    for k in range(1, 3 * tw.tiled_levels + 1):
+        flat2[k] *= np.float32(0.5)
+    rec2 = oracle.inverse(flat2, x.shape, wname, levels, do_swt=swt)[rank * n:(rank + 1) * n]
+    assert np.abs(tw.image - rec2).max() <= 2e-3, "inverse of coefficients modified in place"
+    tw.forward()
+    tw.inverse()  # plans are reused: another round trip must work too
+    assert np.abs(tw.image - rec2).max() <= 4e-3, "second round trip"
+    if world > 1 or loopback:
         dist.barrier()
         dist.destroy_process_group()
-    print("OK %d tiled=%d deep=%d" % (rank, tw.tiled_levels, tw.deep_levels))
+    print("OK %d tiled=%d deep=%d%s" % (rank, tw.tiled_levels, tw.deep_levels, " rccl-loopback" if loopback else ""))
 
 
 if __name__ == "__main__":
