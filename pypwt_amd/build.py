@@ -45,6 +45,7 @@ SOURCES = [
     "launch_swt.hip",
     "launch_swt_vec.hip",
     "launch_swt_fused.hip",
+    "launch_swt_split.hip",
     "launch_ops.hip",
     "launch_nonsep.hip",
     "plan.cpp",

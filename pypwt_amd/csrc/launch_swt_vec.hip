@@ -9,9 +9,8 @@
 namespace pdwt {
 
 // vectorised twins: 128 columns x 16 rows of one phase, four columns per thread (16-B accesses)
-template <int HLEN, bool INV, int TX = 128, int TY = 16>
+template <int HLEN, bool INV, int TX = 128, int TY = 16, int NT = 256>
 static hipError_t run_vec(const Swt2DArgs& a, int batch, hipStream_t s) {
-    constexpr int NT = 256;
     static std::atomic<bool> big[64] = {};
     // the inverse stages its rows in LDS where the dilation allows it (swt_inv_staged): a larger request for those launches
     const bool staged = INV && swt_inv_staged<TX, TY, NT>(HLEN, a.f);

@@ -29,6 +29,40 @@ static __device__ __forceinline__ v2f fma2(v2f a, v2f b, v2f c) { return __built
 #endif
 static PDWT_DEVICE v2f bc(real_t a) { return mk2(a, a); }
 
+// Packed multiply-adds with ONE HALF of an operand pair broadcast, spelled out: hipcc broadcasts the low half of a
+// register pair through op_sel_hi but copies the high half into a fresh pair first (two v_mov_b32 per use, and the copies
+// stay live: the 16-tap split SWT column kernel went to 294 VGPRs with 409 moves beside its 512 packed FMAs).
+//   fma2_bx / fma2_by (p, t, acc):  acc + (p.x, p.x) * t   /   acc + (p.y, p.y) * t      t: a (uniform) tap pair in SGPRs
+//   fma2_tx / fma2_ty (p, t, acc):  acc + p * (t.x, t.x)   /   acc + p * (t.y, t.y)
+#if !defined(PDWT_CPU_EMU) && !defined(PDWT_DOUBLE)
+static __device__ __forceinline__ v2f fma2_bx(v2f p, v2f t, v2f acc) {
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(p), "s"(t));
+    return acc;
+}
+static __device__ __forceinline__ v2f fma2_by(v2f p, v2f t, v2f acc) {
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(p), "s"(t));
+    return acc;
+}
+static __device__ __forceinline__ v2f fma2_tx(v2f p, v2f t, v2f acc) {
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(p), "s"(t));
+    return acc;
+}
+static __device__ __forceinline__ v2f fma2_ty(v2f p, v2f t, v2f acc) {
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(p), "s"(t));
+    return acc;
+}
+static __device__ __forceinline__ v2f fma2_s(v2f p, v2f t, v2f acc) {  // element-wise, the tap pair from SGPRs
+    asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(p), "s"(t));
+    return acc;
+}
+#else
+static PDWT_DEVICE v2f fma2_bx(v2f p, v2f t, v2f acc) { return fma2(bc(p.x), t, acc); }
+static PDWT_DEVICE v2f fma2_by(v2f p, v2f t, v2f acc) { return fma2(bc(p.y), t, acc); }
+static PDWT_DEVICE v2f fma2_tx(v2f p, v2f t, v2f acc) { return fma2(p, bc(t.x), acc); }
+static PDWT_DEVICE v2f fma2_ty(v2f p, v2f t, v2f acc) { return fma2(p, bc(t.y), acc); }
+static PDWT_DEVICE v2f fma2_s(v2f p, v2f t, v2f acc) { return fma2(p, t, acc); }
+#endif
+
 // Reads 16 B from LDS as ONE ds_read_b128 (256 B/clk) even when only some components are used
 // afterwards; without the barrier hipcc narrows it to ds_read2_b32 / ds_read2_b64 pairs, which
 // run at half the LDS rate (MI355X_MICROARCH.md, LDS table).

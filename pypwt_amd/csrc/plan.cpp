@@ -599,7 +599,8 @@ int fwd_level_2d(pdwt_plan* p, int l, bool run) {
     } else {
         const int f = 1 << (l - 1);
         const int Nr = p->info.Nr, Nc = p->info.Nc;
-        if (Nr % f == 0) {
+        const bool split = swt2_split_supported(hlen, Nr, Nc, f, false) && ensure_tmp(p, 2LL * Nr * Nc * B) == PDWT_OK;
+        if (split || Nr % f == 0) {
             Swt2DArgs a;
             a.in = src; a.A = dstA; a.H = H; a.V = V; a.D = D; a.out = nullptr;
             a.Nr = Nr; a.Nc = Nc; a.f = f;
@@ -607,8 +608,8 @@ int fwd_level_2d(pdwt_plan* p, int l, bool run) {
             a.hlen = hlen;
             a.soft_beta = 0.f;
             a.fb = p->dec;
-            Stamp st(p, "swt2_fwd_level");
-            if (run) HIP_TRY(launch_swt2_fwd(a, B, p->stream));
+            Stamp st(p, split ? "swt2_fwd_split" : "swt2_fwd_level");
+            if (run) HIP_TRY(split ? launch_swt2_split(a, p->tmp, false, B, p->stream) : launch_swt2_fwd(a, B, p->stream));
         } else {
             // dilation does not divide the row count: two direct passes through scratch
             const long long plane = (long long)Nr * Nc;
@@ -674,7 +675,8 @@ int inv_level_2d(pdwt_plan* p, int l, bool run) {
     } else {
         const int f = 1 << (l - 1);
         const int Nr = p->info.Nr, Nc = p->info.Nc;
-        if (Nr % f == 0) {
+        const bool split = swt2_split_supported(hlen, Nr, Nc, f, true) && ensure_tmp(p, 2LL * Nr * Nc * B) == PDWT_OK;
+        if (split || Nr % f == 0) {
             Swt2DArgs a;
             a.in = nullptr;
             a.A = const_cast<real_t*>(cur); a.H = const_cast<real_t*>(H);
@@ -686,8 +688,9 @@ int inv_level_2d(pdwt_plan* p, int l, bool run) {
             a.soft_beta = 0.f;
             if (p->pend_soft) a.soft_beta = pending_beta_of_level(p, l);
             a.fb = p->rec;
-            Stamp st(p, p->pend_soft ? "swt2_inv_level+soft" : "swt2_inv_level");
-            if (run) HIP_TRY(launch_swt2_inv(a, B, p->stream));
+            Stamp st(p, split ? (p->pend_soft ? "swt2_inv_split+soft" : "swt2_inv_split")
+                              : (p->pend_soft ? "swt2_inv_level+soft" : "swt2_inv_level"));
+            if (run) HIP_TRY(split ? launch_swt2_split(a, p->tmp, true, B, p->stream) : launch_swt2_inv(a, B, p->stream));
         } else {
             const long long plane = (long long)Nr * Nc;
             int rc = ensure_tmp(p, 2 * plane);
@@ -1680,6 +1683,8 @@ int pdwt_set_tuning(const char* key, int value) {
     if (key && !strcmp(key, "reg1d")) return set_reg1d_enabled(value);
     if (key && !strcmp(key, "swt_fused")) return set_swt_fused_enabled(value);
     if (key && !strcmp(key, "chain")) return set_chain_enabled(value);
+    if (key && !strcmp(key, "swt_split_fwd")) return set_swt_split_min(0, value);
+    if (key && !strcmp(key, "swt_split_inv")) return set_swt_split_min(1, value);
     if (key && !strcmp(key, "chain_timeout")) return set_chain_timeout(value);
     return fail(PDWT_ERR_ARG, "pdwt_set_tuning: unknown key %s", key ? key : "(null)");
 }

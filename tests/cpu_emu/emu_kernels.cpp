@@ -20,6 +20,7 @@
 #include "../../pypwt_amd/csrc/dwt2_wave_kernels.hpp"
 #include "../../pypwt_amd/csrc/nonsep_kernels.hpp"
 #include "../../pypwt_amd/csrc/swt_kernels.hpp"
+#include "../../pypwt_amd/csrc/swt_split_kernels.hpp"
 
 using namespace pdwt;
 
@@ -742,4 +743,55 @@ EMU_API int emu_swt4_fused(const float* in, float* det, float* out, int batch, i
     if (f0 == 1) run_swt4<1>(a, batch, inverse != 0);
     else run_swt4<4>(a, batch, inverse != 0);
     return 0;
+}
+
+// ---- one a-trous level as a row pass + a column pass through scratch (swt_split_kernels.hpp); planes as in emu_swt2
+template <int HLEN>
+static void run_swt_split(const Swt2DArgs& a, int batch, bool inverse, float* tmp) {
+    constexpr int NT = 256, R = 4;
+    const long long plane = (long long)a.Nr * a.Nc;
+    SwtSplitArgs k{};
+    k.Nr = a.Nr; k.Nc = a.Nc; k.f = a.f; k.batch = batch; k.soft_beta = a.soft_beta;
+    for (int j = 0; j < HLEN; ++j) k.t.t[j] = mk2(a.fb.lo[HLEN - 1 - j], a.fb.hi[HLEN - 1 - j]);
+    const int f = a.f;
+    const long long col_items = split_col_waves(batch, a.Nr, a.Nc, f, R);
+    const long long row_items4 = f >= 4 ? split_row_waves(batch, a.Nr, split_row_items4(a.Nc, f, R)) : 0;
+    const long long row_items1 = split_row_waves(batch, a.Nr, split_row_items1(a.Nc));
+    auto blocks = [](long long waves) { return (waves + NT / 64 - 1) / (NT / 64); };
+    if (!inverse) {
+        SwtSplitArgs r = k;
+        r.in[0] = a.in; r.in_bstride = a.bstride; r.out[0] = tmp; r.out[1] = tmp + plane; r.out_bstride = 2 * plane;
+        if (f == 1) for (long long b = 0; b < blocks(row_items1); ++b) swt_row_fwd1_tile<HLEN, 1, NT>(r, b);
+        else if (f == 2) for (long long b = 0; b < blocks(row_items1); ++b) swt_row_fwd1_tile<HLEN, 2, NT>(r, b);
+        else for (long long b = 0; b < blocks(row_items4); ++b) swt_row_fwd4_tile<HLEN, R, NT>(r, b);
+        SwtSplitArgs c = k;
+        c.in[0] = tmp; c.in[1] = tmp + plane; c.in_bstride = 2 * plane;
+        c.out[0] = a.A; c.out[1] = a.H; c.out[2] = a.V; c.out[3] = a.D; c.out_bstride = a.bstride;
+        for (long long b = 0; b < blocks(col_items); ++b) swt_col_fwd_tile<HLEN, R, NT>(c, b);
+        return;
+    }
+    SwtSplitArgs c = k;
+    c.in[0] = a.A; c.in[1] = a.H; c.in[2] = a.V; c.in[3] = a.D; c.in_bstride = a.bstride; c.out[0] = tmp; c.out_bstride = 2 * plane;
+    for (long long b = 0; b < blocks(col_items); ++b) swt_col_inv_tile<HLEN, R, NT>(c, b);
+    SwtSplitArgs r = k;
+    r.in[0] = tmp; r.in_bstride = 2 * plane; r.out[0] = a.out; r.out_bstride = a.bstride;
+    if (f == 1) for (long long b = 0; b < blocks(row_items1); ++b) swt_row_inv1_tile<HLEN, 1, NT>(r, b);
+    else if (f == 2) for (long long b = 0; b < blocks(row_items1); ++b) swt_row_inv1_tile<HLEN, 2, NT>(r, b);
+    else for (long long b = 0; b < blocks(row_items4); ++b) swt_row_inv4_tile<HLEN, R, NT>(r, b);
+}
+
+EMU_API int emu_swt2_split(int inverse, float* io, int batch, int Nr, int Nc, int level, const float* lo, const float* hi,
+                           int hlen, float soft_beta, float* A, float* H, float* V, float* D) {
+    Swt2DArgs a;
+    a.in = io; a.out = io; a.A = A; a.H = H; a.V = V; a.D = D;
+    a.Nr = Nr; a.Nc = Nc; a.f = 1 << (level - 1); a.bstride = (long long)Nr * Nc; a.hlen = hlen; a.soft_beta = soft_beta;
+    if ((Nc & 3) || Nc < 16 || a.f >= Nr || a.f >= Nc) return -2;
+    set_bank(a.fb, lo, hi, hlen);
+    std::vector<float> tmp((size_t)2 * Nr * Nc * batch + 16, NAN);
+    switch (hlen) {
+#define X(h) case h: run_swt_split<h>(a, batch, inverse != 0, tmp.data()); return 0;
+        X(10) X(12) X(16) X(20) X(26) X(40)
+#undef X
+    }
+    return -1;
 }

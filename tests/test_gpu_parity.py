@@ -369,10 +369,22 @@ def test_three_level_pyramid_on_small_images():
             assert np.abs(img[b] - want).max() <= 2e-6 * (1 + L) * 255.0 * 8, (wname, shape, b)
 
 
+@pytest.fixture
+def swt_split_off():
+    """the LDS-tiled per-level SWT kernels for every filter length (by default filters of >= 18 / 12 taps take the
+    two-launch path of swt_split_kernels.hpp)"""
+    from pypwt_amd import _lib
+    lib = _lib.load()
+    prev = lib.pdwt_set_tuning(b"swt_split_fwd", 0), lib.pdwt_set_tuning(b"swt_split_inv", 0)
+    yield
+    lib.pdwt_set_tuning(b"swt_split_fwd", prev[0])
+    lib.pdwt_set_tuning(b"swt_split_inv", prev[1])
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("wname,shape,levels", [("sym8", (512, 1024), 4), ("db5", (384, 640), 3), ("coif3", (256, 1028), 3),
                                                 ("db10", (512, 512), 2), ("db3", (640, 512), 4)])
-def test_swt_long_filters_staged_inverse(wname, shape, levels):
+def test_swt_long_filters_staged_inverse(wname, shape, levels, swt_split_off):
     """SWT with filters of 6-20 taps at sizes with whole 128-column tiles, ragged ones and every dilation 1..8: the
     per-level inverse stages its rows in LDS (aligned taps at dilation 4+, one window per lane at dilation 1 and 2);
     forward bands, then soft threshold + inverse, against the oracle."""
@@ -390,6 +402,49 @@ def test_swt_long_filters_staged_inverse(wname, shape, levels):
     thr = oracle.threshold(ref, shape, levels, "soft", 4.0, do_app=0, normalize=0, do_swt=1)
     want = oracle.inverse(thr, shape, wname, levels, do_swt=1)
     assert np.abs(w.image - want).max() <= 4e-3, wname
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("wname,shape,levels,batch", [("sym8", (512, 1024), 4, 1), ("db5", (384, 640), 3, 1), ("db6", (250, 260), 3, 2),
+                                                      ("coif3", (256, 1028), 3, 1), ("db10", (512, 512), 4, 1), ("db13", (333, 400), 3, 1),
+                                                      ("db20", (1024, 768), 4, 1), ("db20", (200, 1200), 2, 3), ("sym8", (77, 68), 2, 1)])
+def test_swt_two_launch_levels(wname, shape, levels, batch):
+    """The two-launch SWT levels (swt_split_kernels.hpp) forced on for every filter of >= 10 taps: dilations 1, 2 (16
+    consecutive columns per work item) and 4..16 (quads a dilation step apart), row counts the dilation does not divide
+    (250, 333, 77: these took three direct passes before), ragged last blocks, batches; forward bands, then a deferred soft
+    threshold + inverse, and the inverse of arbitrary coefficients, against the oracle.  The launch names must say that
+    the path ran."""
+    from pypwt_amd import BatchedWavelets, _lib
+    lib = _lib.load()
+    prev = lib.pdwt_set_tuning(b"swt_split_fwd", 10), lib.pdwt_set_tuning(b"swt_split_inv", 10)
+    try:
+        x = np.stack([oracle.hash_input(shape, 140 + b, scale=255.0) for b in range(batch)])
+        bw = BatchedWavelets(batch, shape[0], shape[1], wname, levels, do_swt=1, img=x)
+        assert bw.levels == levels
+        bw.enable_kernel_timing(True)
+        bw.forward()
+        names = [n for n, _ in bw.kernel_times(cap=64)]
+        assert names and all(n == "swt2_fwd_split" for n in names), names
+        bw.reset_kernel_times()
+        for b in range(batch):
+            ref = oracle.forward(x[b], wname, levels, do_swt=1)
+            for k, r in enumerate(ref):
+                g = bw.coeff(k)[b]
+                assert np.abs(g - r).max() <= 2e-5 * max(float(np.abs(r).max()), 255.0), (wname, b, k)
+        bw.soft_threshold(4.0)
+        bw.inverse()
+        # (row counts the coarsest dilation does not divide threshold in a sweep of their own: plan.cpp, can_defer_soft)
+        names = [n for n, _ in bw.kernel_times(cap=64) if n != "soft_threshold"]
+        assert names and all(n.startswith("swt2_inv_split") for n in names), names
+        img = bw.image
+        for b in range(batch):
+            ref = oracle.forward(x[b], wname, levels, do_swt=1)
+            thr = oracle.threshold(ref, shape, levels, "soft", 4.0, do_app=0, normalize=0, do_swt=1)
+            want = oracle.inverse(thr, shape, wname, levels, do_swt=1)
+            assert np.abs(img[b] - want).max() <= 4e-3, (wname, b)
+    finally:
+        lib.pdwt_set_tuning(b"swt_split_fwd", prev[0])
+        lib.pdwt_set_tuning(b"swt_split_inv", prev[1])
 
 
 # ---------------------------------------------------------------------------------------------
