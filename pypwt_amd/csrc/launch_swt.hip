@@ -80,7 +80,14 @@ static bool swt1_vec_ok(const SwtPassArgs& a) {
            (!a.in1 || al(a.in1)) && al(a.out0) && (!a.out1 || al(a.out1));
 }
 
+// register-blocked row kernels of swt_split_kernels.hpp (launch_swt_split.hip) for filters of >= 10 taps
+hipError_t try_launch_swt1_split(const SwtPassArgs& a, bool inverse, hipStream_t s);
+
 hipError_t launch_swt_pass_fwd(const SwtPassArgs& a, hipStream_t s) {
+    {
+        const hipError_t e = try_launch_swt1_split(a, false, s);
+        if (e != hipErrorNotSupported) return e;
+    }
     if (swt1_vec_ok(a)) {
         const unsigned grid = (unsigned)cdivll((long long)a.Nr * (a.Nc >> 2), 256);
         switch (a.hlen) {
@@ -98,6 +105,10 @@ hipError_t launch_swt_pass_fwd(const SwtPassArgs& a, hipStream_t s) {
 }
 
 hipError_t launch_swt_pass_inv(const SwtPassArgs& a, hipStream_t s) {
+    {
+        const hipError_t e = try_launch_swt1_split(a, true, s);
+        if (e != hipErrorNotSupported) return e;
+    }
     if (swt1_vec_ok(a)) {
         const unsigned grid = (unsigned)cdivll((long long)a.Nr * (a.Nc >> 2), 256);
         switch (a.hlen) {

@@ -5,6 +5,7 @@
 
 #include "launch.hpp"
 #include "launch_util.hpp"
+#include "swt_kernels_args.hpp"
 #ifndef PDWT_DOUBLE
 #include "swt_split_kernels.hpp"
 #endif
@@ -13,6 +14,7 @@ namespace pdwt {
 
 #ifdef PDWT_DOUBLE
 bool swt2_split_supported(int, int, int, int, bool) { return false; }
+hipError_t try_launch_swt1_split(const SwtPassArgs&, bool, hipStream_t) { return hipErrorNotSupported; }
 int set_swt_split_min(int, int) { return 0; }
 hipError_t launch_swt2_split(const Swt2DArgs&, real_t*, bool, int, hipStream_t) { return hipErrorNotSupported; }
 #else
@@ -52,48 +54,93 @@ bool swt2_split_supported(int hlen, int Nr, int Nc, int f, bool inverse) {
 }
 
 template <int NT, typename K>
-static hipError_t go(K kernel, const SwtSplitArgs& a, long long waves, hipStream_t s) {
-    hipLaunchKernelGGL(kernel, dim3((unsigned)cdivll(waves, NT / 64)), dim3(NT), 0, s, a);
+static hipError_t go(K kernel, const SwtSplitArgs& a, long long waves, hipStream_t s, size_t lds_bytes = 0) {
+    hipLaunchKernelGGL(kernel, dim3((unsigned)cdivll(waves, NT / 64)), dim3(NT), lds_bytes, s, a);
     return hipGetLastError();
 }
 
 template <int HLEN>
 static hipError_t run_split(const Swt2DArgs& a, real_t* tmp, bool inverse, int batch, hipStream_t s) {
-    constexpr int NT = 256, NTC = 1024, R = 4;  // NTC: wavefronts of a column workgroup share their rows (split_col_work)
+    // column workgroups of 16 wavefronts x 4 rows share their input rows on one CU (split_col_work).  8 rows per wavefront
+    // with 8 wavefronts (the same 64 rows, half the L1 traffic) measured no better: 16 taps 31.1 / 21.5 us against 30.5 / 20.0
+    constexpr int NT = 256, R = 4, RC = 4, NTC = 1024;  // NTC: wavefronts of a column workgroup share their rows (split_col_work)
     const long long plane = (long long)a.Nr * a.Nc;
     SwtSplitArgs k{};
     k.Nr = a.Nr; k.Nc = a.Nc; k.f = a.f; k.batch = batch;
     k.soft_beta = a.soft_beta;
     for (int j = 0; j < HLEN; ++j) k.t.t[j] = mk2h(a.fb.lo[HLEN - 1 - j], a.fb.hi[HLEN - 1 - j]);
     const int f = a.f;
-    const long long col_items = split_col_waves(batch, a.Nr, a.Nc, f, R);
+    const long long col_items = split_col_waves(batch, a.Nr, a.Nc, f, RC);
     const long long row_items4 = f >= 4 ? split_row_waves(batch, a.Nr, split_row_items4(a.Nc, f, R)) : 0;
-    const long long row_items1 = split_row_waves(batch, a.Nr, split_row_items1(a.Nc));
+    const long long row_lds = split_row_lds_waves(batch, a.Nr, a.Nc);
     hipError_t e;
     if (!inverse) {
         SwtSplitArgs r = k;  // in -> lo, hi (scratch: two planes per image)
         r.in[0] = a.in; r.in_bstride = a.bstride;
         r.out[0] = tmp; r.out[1] = tmp + plane; r.out_bstride = 2 * plane;
-        if (f == 1) e = go<NT>(swt_row_fwd1_kernel<HLEN, 1, NT>, r, row_items1, s);
-        else if (f == 2) e = go<NT>(swt_row_fwd1_kernel<HLEN, 2, NT>, r, row_items1, s);
+        // dilation 1, 2, 4: staged through LDS (coalesced loads and stores); beyond, the runs of f / 4 lanes are whole lines
+        if (f == 1) e = go<NT>(swt_row_fwd_lds_kernel<HLEN, 1, NT>, r, row_lds, s, sizeof(real_t) * swt_row_lds_floats<HLEN, 1>(false, NT));
+        else if (f == 2) e = go<NT>(swt_row_fwd_lds_kernel<HLEN, 2, NT>, r, row_lds, s, sizeof(real_t) * swt_row_lds_floats<HLEN, 2>(false, NT));
+        else if (f == 4) e = go<NT>(swt_row_fwd_lds_kernel<HLEN, 4, NT>, r, row_lds, s, sizeof(real_t) * swt_row_lds_floats<HLEN, 4>(false, NT));
         else e = go<NT>(swt_row_fwd4_kernel<HLEN, R, NT>, r, row_items4, s);
         if (e != hipSuccess) return e;
         SwtSplitArgs c = k;
         c.in[0] = tmp; c.in[1] = tmp + plane; c.in_bstride = 2 * plane;
         c.out[0] = a.A; c.out[1] = a.H; c.out[2] = a.V; c.out[3] = a.D; c.out_bstride = a.bstride;
-        return go<NTC>(swt_col_fwd_kernel<HLEN, R, NTC>, c, col_items, s);
+        return go<NTC>(swt_col_fwd_kernel<HLEN, RC, NTC>, c, col_items, s);
     }
     SwtSplitArgs c = k;  // A, H, V, D -> interleaved (L', H') (scratch: two planes per image)
     c.in[0] = a.A; c.in[1] = a.H; c.in[2] = a.V; c.in[3] = a.D; c.in_bstride = a.bstride;
     c.out[0] = tmp; c.out_bstride = 2 * plane;
-    e = go<NTC>(swt_col_inv_kernel<HLEN, R, NTC>, c, col_items, s);
+    e = go<NTC>(swt_col_inv_kernel<HLEN, RC, NTC>, c, col_items, s);
     if (e != hipSuccess) return e;
     SwtSplitArgs r = k;
     r.in[0] = tmp; r.in_bstride = 2 * plane;
     r.out[0] = a.out; r.out_bstride = a.bstride;
-    if (f == 1) return go<NT>(swt_row_inv1_kernel<HLEN, 1, NT>, r, row_items1, s);
-    if (f == 2) return go<NT>(swt_row_inv1_kernel<HLEN, 2, NT>, r, row_items1, s);
+    if (f == 1) return go<NT>(swt_row_inv_lds_kernel<HLEN, 1, 1, NT>, r, row_lds, s, sizeof(real_t) * swt_row_lds_floats<HLEN, 1>(true, NT));
+    if (f == 2) return go<NT>(swt_row_inv_lds_kernel<HLEN, 2, 1, NT>, r, row_lds, s, sizeof(real_t) * swt_row_lds_floats<HLEN, 2>(true, NT));
+    if (f == 4) return go<NT>(swt_row_inv_lds_kernel<HLEN, 4, 1, NT>, r, row_lds, s, sizeof(real_t) * swt_row_lds_floats<HLEN, 4>(true, NT));
     return go<NT>(swt_row_inv4_kernel<HLEN, R, NT>, r, row_items4, s);
+}
+
+// The row kernels are the (batched) 1D transform as they stand: rows of Nc samples, approximation and detail planes
+// separate (the inverse interleaves them while staging, or packs over column pairs at dilation >= 8).
+template <int HLEN>
+static hipError_t run_split1(const SwtPassArgs& a, bool inverse, hipStream_t s) {
+    constexpr int NT = 256, R = 4;
+    SwtSplitArgs k{};
+    k.Nr = a.Nr; k.Nc = a.Nc; k.f = a.f; k.batch = 1;
+    for (int j = 0; j < HLEN; ++j) k.t.t[j] = mk2h(a.fb.lo[HLEN - 1 - j], a.fb.hi[HLEN - 1 - j]);
+    const int f = a.f;
+    const long long row_items4 = f >= 4 ? split_row_waves(1, a.Nr, split_row_items4(a.Nc, f, R)) : 0;
+    const long long row_lds = split_row_lds_waves(1, a.Nr, a.Nc);
+    k.in[0] = a.in0; k.in[1] = a.in1; k.out[0] = a.out0; k.out[1] = a.out1;
+    if (!inverse) {
+        if (f == 1) return go<NT>(swt_row_fwd_lds_kernel<HLEN, 1, NT>, k, row_lds, s, sizeof(real_t) * swt_row_lds_floats<HLEN, 1>(false, NT));
+        if (f == 2) return go<NT>(swt_row_fwd_lds_kernel<HLEN, 2, NT>, k, row_lds, s, sizeof(real_t) * swt_row_lds_floats<HLEN, 2>(false, NT));
+        if (f == 4) return go<NT>(swt_row_fwd_lds_kernel<HLEN, 4, NT>, k, row_lds, s, sizeof(real_t) * swt_row_lds_floats<HLEN, 4>(false, NT));
+        return go<NT>(swt_row_fwd4_kernel<HLEN, R, NT>, k, row_items4, s);
+    }
+    if (f == 1) return go<NT>(swt_row_inv_lds_kernel<HLEN, 1, 2, NT>, k, row_lds, s, sizeof(real_t) * swt_row_lds_floats<HLEN, 1, 2>(true, NT));
+    if (f == 2) return go<NT>(swt_row_inv_lds_kernel<HLEN, 2, 2, NT>, k, row_lds, s, sizeof(real_t) * swt_row_lds_floats<HLEN, 2, 2>(true, NT));
+    if (f == 4) return go<NT>(swt_row_inv_lds_kernel<HLEN, 4, 2, NT>, k, row_lds, s, sizeof(real_t) * swt_row_lds_floats<HLEN, 4, 2>(true, NT));
+    return go<NT>(swt_row_inv4p_kernel<HLEN, R, NT>, k, row_items4, s);
+}
+
+hipError_t try_launch_swt1_split(const SwtPassArgs& a, bool inverse, hipStream_t s) {
+    static const int min_taps = env_int("PDWT_SWT1_SPLIT", 10);  // shortest filter on this path, 0 = never (A/B measurements)
+    if (a.along_y || min_taps <= 0 || (a.hlen & 1) || a.hlen < 10 || a.hlen < min_taps || a.hlen > kMaxTaps) return hipErrorNotSupported;
+    if ((a.Nc & 3) || a.Nc < 16 || a.f < 1 || a.f >= a.Nc || (a.f != 1 && a.f != 2 && (a.f & 3))) return hipErrorNotSupported;
+    auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    if (!al16(a.in0) || !al16(a.out0) || (inverse ? !al16(a.in1) : !al16(a.out1))) return hipErrorNotSupported;
+    switch (a.hlen) {
+#define X(h) \
+    case h:  \
+        return run_split1<h>(a, inverse, s);
+        PDWT_SPLIT_HLENS(X)
+#undef X
+    }
+    return hipErrorNotSupported;
 }
 
 // scratch: 2 * Nr * Nc * batch elements, 16-B aligned

@@ -527,6 +527,74 @@ PDWT_DEVICE void swt_row_inv4_tile(const SwtSplitArgs& a, long long block) {
     }
 }
 
+// the same from TWO separate planes (the 1D transform's approximation and detail rows): packed over two adjacent
+// columns with the tap broadcast, like the column kernel of the inverse
+template <int HLEN, int R, int NT>
+PDWT_DEVICE void swt_row_inv4p_tile(const SwtSplitArgs& a, long long block) {
+    constexpr int c = HLEN / 2, NIN = R + HLEN - 1, CH = kSplitChunk, NCH = (NIN + CH - 1) / CH;
+    const int f = a.f, G = f >> 2, span = R * f;
+    const int trow = split_row_items4(a.Nc, f, R);
+    PDWT_FOR_THREADS(tid, NT) {
+        SplitRowWork w;
+        if (!split_row_work<NT>(a, trow, block, tid, w)) continue;
+        const int x0 = (w.tr / G) * span + 4 * (w.tr % G);
+        const real_t* PDWT_RESTRICT rowA = a.in[0] + w.bz * a.in_bstride + (long long)w.y * a.Nc;
+        const real_t* PDWT_RESTRICT rowD = a.in[1] + w.bz * a.in_bstride + (long long)w.y * a.Nc;
+        const real_t zero = 0, half = (real_t)0.5;
+        v2f acc[R][2];
+#pragma unroll
+        for (int m = 0; m < R; ++m) acc[m][0] = acc[m][1] = mk2(zero, zero);
+        unsigned p = (unsigned)true_mod(x0 - c * f, a.Nc);
+        rv4 b[2][CH][2];
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+            if (u < NIN) {
+                b[0][u][0] = load4(rowA + p);
+                b[0][u][1] = load4(rowD + p);
+                p = step_wrap_u(p, (unsigned)f, (unsigned)a.Nc);
+            }
+        }
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+#pragma unroll
+            for (int u = 0; u < CH; ++u) {
+                if ((ch + 1) * CH + u < NIN) {
+                    b[(ch + 1) & 1][u][0] = load4(rowA + p);
+                    b[(ch + 1) & 1][u][1] = load4(rowD + p);
+                    p = step_wrap_u(p, (unsigned)f, (unsigned)a.Nc);
+                }
+            }
+            PDWT_SCHED_FENCE();
+#pragma unroll
+            for (int u = 0; u < CH; ++u) {
+                const int r = ch * CH + u;
+                if (r < NIN) {
+                    const rv4 &vA = b[ch & 1][u][0], &vD = b[ch & 1][u][1];
+#pragma unroll
+                    for (int m = 0; m < R; ++m) {
+                        const int j = r - m;
+                        if (j >= 0 && j < HLEN) {
+                            acc[m][0] = fma2_tx(mk2(vA.x, vA.y), a.t.t[j], acc[m][0]);
+                            acc[m][1] = fma2_tx(mk2(vA.z, vA.w), a.t.t[j], acc[m][1]);
+                            acc[m][0] = fma2_ty(mk2(vD.x, vD.y), a.t.t[j], acc[m][0]);
+                            acc[m][1] = fma2_ty(mk2(vD.z, vD.w), a.t.t[j], acc[m][1]);
+                        }
+                    }
+                }
+            }
+            PDWT_SCHED_FENCE();
+            PDWT_ORDER_AFTER(p, acc[0][0], acc[R - 1][0], acc[0][1], acc[R - 1][1]);
+        }
+        if (!w.active) continue;
+        const long long ob = w.bz * a.out_bstride + (long long)w.y * a.Nc;
+#pragma unroll
+        for (int m = 0; m < R; ++m) {
+            const int xm = x0 + m * f;
+            if (xm < a.Nc) store4(a.out[0] + ob + xm, mk4(half * acc[m][0].x, half * acc[m][0].y, half * acc[m][1].x, half * acc[m][1].y));
+        }
+    }
+}
+
 // inverse, row pass, dilation F = 1 or 2: 16 consecutive columns per work item, the window streamed as (L', H') pairs
 template <int HLEN, int F, int NT>
 PDWT_DEVICE void swt_row_inv1_tile(const SwtSplitArgs& a, long long block) {
@@ -593,6 +661,256 @@ PDWT_DEVICE void swt_row_inv1_tile(const SwtSplitArgs& a, long long block) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Row passes at dilation F = 1, 2, 4 through LDS.  In the kernels above a work item owns 16 consecutive columns (at
+// F = 4 the four quads f apart ARE 16 consecutive columns): every lane of a load or store touches its own 64-B piece --
+// 64 cache-line requests per wavefront instruction instead of 16, and partial-line stores (rocprofv3, 2048^2, 40 taps:
+// 21 us per launch for 50 MB and 5 us of arithmetic).  Here a wavefront stages its row segment (1024 outputs + the window
+// halo) in LDS with coalesced 16-B loads, the lanes read their windows from LDS (4 pad floats per 16 -- per 32 for the
+// interleaved input of the inverse -- make the 8 lanes of an LDS pass hit 32 different banks), and the results go back
+// through the same LDS region so that the global stores are whole 1-KiB rows.  Workgroup = NT / 64 independent
+// wavefronts with a private region each; the barriers only separate the phases.
+constexpr int kRowSpan = 1024;
+
+template <int HLEN, int F>
+struct RowFwdLds {
+    static constexpr int c = HLEN / 2 - 1, LEAD = (c * F + 3) / 4 * 4, OFF = LEAD - c * F;
+    static constexpr int NQ = (LEAD + kRowSpan + (HLEN - 1 - c) * F + 3) / 4;  // staged quads per wavefront
+    static constexpr int NWQ = (LEAD + 16 + (HLEN - 1 - c) * F + 3) / 4;       // window quads per lane
+    static constexpr int WAVE_FLOATS = (NQ + 3) / 4 * 20;
+};
+template <int HLEN, int F, int PLANES>
+struct RowInvLds {
+    static constexpr int AL = PLANES == 2 ? 4 : 2;  // separate planes are staged with 16-B loads of four columns
+    static constexpr int c = HLEN / 2, LEAD = (c * F + AL - 1) / AL * AL, OFF = LEAD - c * F;
+    static constexpr int NQ = (2 * (LEAD + kRowSpan + (HLEN - 1 - c) * F) + 3) / 4;  // staged quads (two (L', H') pairs each)
+    static constexpr int NWQ = (LEAD + 16 + (HLEN - 1 - c) * F + 1) / 2;
+    static constexpr int WAVE_FLOATS = (NQ + 7) / 8 * 36;
+};
+template <int HLEN, int F, int PLANES = 1>
+constexpr int swt_row_lds_floats(bool inverse, int NT) {
+    return (NT / 64) * (inverse ? RowInvLds<HLEN, F, PLANES>::WAVE_FLOATS : RowFwdLds<HLEN, F>::WAVE_FLOATS);
+}
+
+struct RowLdsWork {
+    int y, xs, lane;
+    long long bz;
+    real_t* reg;
+    bool valid;
+};
+template <int NT>
+PDWT_DEVICE RowLdsWork row_lds_work(const SwtSplitArgs& a, long long block, int tid, real_t* smem, int wave_floats) {
+    RowLdsWork w;
+    const int TG = (a.Nc + kRowSpan - 1) / kRowSpan;
+    const int wv = PDWT_UNIFORM(tid >> 6);
+    const long long wave = block * (NT / 64) + wv;
+    w.valid = wave < (long long)a.batch * a.Nr * TG;
+    const long long ty = wave / TG;
+    w.xs = (int)(wave % TG) * kRowSpan;
+    w.y = (int)(ty % a.Nr);
+    w.bz = ty / a.Nr;
+    w.lane = tid & 63;
+    w.reg = smem + wv * wave_floats;
+    return w;
+}
+constexpr long long split_row_lds_waves(int batch, int Nr, int Nc) { return (long long)batch * Nr * ((Nc + kRowSpan - 1) / kRowSpan); }
+
+template <int HLEN, int F, int NT>
+PDWT_DEVICE void swt_row_fwd_lds_tile(const SwtSplitArgs& a, long long block, real_t* smem) {
+    using G = RowFwdLds<HLEN, F>;
+    constexpr int CH = kSplitChunk, NCH = (G::NWQ + CH - 1) / CH;
+    PDWT_PER_THREAD(v2f, acc, 16, NT);
+    PDWT_FOR_THREADS(tid, NT) {  // phase 1: the row segment, coalesced, into the wavefront's region
+        const RowLdsWork w = row_lds_work<NT>(a, block, tid, smem, G::WAVE_FLOATS);
+        if (w.valid) {
+            const real_t* PDWT_RESTRICT row = a.in[0] + w.bz * a.in_bstride + (long long)w.y * a.Nc;
+#pragma unroll
+            for (int k = 0; k < (G::NQ + 63) / 64; ++k) {
+                const int qq = w.lane + 64 * k;
+                if (qq < G::NQ) store4(w.reg + 20 * (qq >> 2) + 4 * (qq & 3), load4(row + true_mod(w.xs - G::LEAD + 4 * qq, a.Nc)));
+            }
+        }
+    }
+    PDWT_SYNC();
+    PDWT_FOR_THREADS(tid, NT) {  // phase 2: 16 outputs per lane from its window
+        const RowLdsWork w = row_lds_work<NT>(a, block, tid, smem, G::WAVE_FLOATS);
+        v2f* acc = PDWT_MINE(acc, tid);
+        const real_t zero = 0;
+#pragma unroll
+        for (int pp = 0; pp < 16; ++pp) acc[pp] = mk2(zero, zero);
+        if (w.valid) {
+            unsigned lbo = 20u * (unsigned)w.lane;
+            rv4 b[2][CH];
+#pragma unroll
+            for (int u = 0; u < CH; ++u)
+                if (u < G::NWQ) b[0][u] = load4(w.reg + lbo + 20 * (u >> 2) + 4 * (u & 3));
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch) {
+#pragma unroll
+                for (int u = 0; u < CH; ++u) {
+                    const int n = (ch + 1) * CH + u;
+                    if (n < G::NWQ) b[(ch + 1) & 1][u] = load4(w.reg + lbo + 20 * (n >> 2) + 4 * (n & 3));
+                }
+                PDWT_SCHED_FENCE();
+#pragma unroll
+                for (int u = 0; u < CH; ++u) {
+                    const int wq = ch * CH + u;
+                    if (wq < G::NWQ) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int k = 4 * wq + i;
+#pragma unroll
+                            for (int pp = 0; pp < 16; ++pp) {
+                                const int d = k - G::OFF - pp;
+                                if (d >= 0 && d % F == 0 && d / F < HLEN) {
+                                    const rv4& v = b[ch & 1][u];
+                                    const v2f pr = i < 2 ? mk2(v.x, v.y) : mk2(v.z, v.w);
+                                    acc[pp] = (i & 1) ? fma2_by(pr, a.t.t[d / F], acc[pp]) : fma2_bx(pr, a.t.t[d / F], acc[pp]);
+                                }
+                            }
+                        }
+                    }
+                }
+                PDWT_SCHED_FENCE();
+                PDWT_ORDER_AFTER(lbo, acc[0], acc[1], acc[14], acc[15]);
+            }
+        }
+    }
+    PDWT_SYNC();
+#pragma unroll
+    for (int plane = 0; plane < 2; ++plane) {  // phase 3: lo, then hi, through the region to whole-row stores
+        PDWT_FOR_THREADS(tid, NT) {
+            const RowLdsWork w = row_lds_work<NT>(a, block, tid, smem, G::WAVE_FLOATS);
+            const v2f* acc = PDWT_MINE(acc, tid);
+            if (w.valid) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+                    store4(w.reg + 20 * w.lane + 4 * m,
+                           plane == 0 ? mk4(acc[4 * m].x, acc[4 * m + 1].x, acc[4 * m + 2].x, acc[4 * m + 3].x)
+                                      : mk4(acc[4 * m].y, acc[4 * m + 1].y, acc[4 * m + 2].y, acc[4 * m + 3].y));
+            }
+        }
+        PDWT_SYNC();
+        PDWT_FOR_THREADS(tid, NT) {
+            const RowLdsWork w = row_lds_work<NT>(a, block, tid, smem, G::WAVE_FLOATS);
+            if (w.valid) {
+                real_t* PDWT_RESTRICT orow = a.out[plane] + w.bz * a.out_bstride + (long long)w.y * a.Nc;
+#pragma unroll
+                for (int k = 0; k < kRowSpan / 256; ++k) {
+                    const int qq = w.lane + 64 * k, col = w.xs + 4 * qq;
+                    if (col < a.Nc) store4(orow + col, load4(w.reg + 20 * (qq >> 2) + 4 * (qq & 3)));
+                }
+            }
+        }
+        PDWT_SYNC();
+    }
+}
+
+// inverse twin.  PLANES = 1: a.in[0] is the interleaved (L', H') plane of the column kernel; PLANES = 2: a.in[0], a.in[1]
+// are separate planes (the 1D transform's approximation and detail rows), interleaved while they are staged.
+template <int HLEN, int F, int PLANES, int NT>
+PDWT_DEVICE void swt_row_inv_lds_tile(const SwtSplitArgs& a, long long block, real_t* smem) {
+    using G = RowInvLds<HLEN, F, PLANES>;
+    constexpr int CH = 2 * kSplitChunk, NCH = (G::NWQ + CH - 1) / CH;
+    PDWT_PER_THREAD(v2f, acc, 16, NT);
+    PDWT_FOR_THREADS(tid, NT) {
+        const RowLdsWork w = row_lds_work<NT>(a, block, tid, smem, G::WAVE_FLOATS);
+        if (w.valid) {
+            if (PLANES == 1) {
+                const real_t* PDWT_RESTRICT row = a.in[0] + w.bz * a.in_bstride + (long long)w.y * 2 * a.Nc;
+#pragma unroll
+                for (int k = 0; k < (G::NQ + 63) / 64; ++k) {
+                    const int qq = w.lane + 64 * k;  // pairs 2 qq, 2 qq + 1 of the window
+                    if (qq < G::NQ)
+                        store4(w.reg + 36 * (qq >> 3) + 4 * (qq & 7), load4(row + 2 * true_mod(w.xs - G::LEAD + 2 * qq, a.Nc)));
+                }
+            } else {
+                const real_t* PDWT_RESTRICT r0 = a.in[0] + w.bz * a.in_bstride + (long long)w.y * a.Nc;
+                const real_t* PDWT_RESTRICT r1 = a.in[1] + w.bz * a.in_bstride + (long long)w.y * a.Nc;
+#pragma unroll
+                for (int k = 0; k < (G::NQ / 2 + 1 + 63) / 64; ++k) {
+                    const int q4i = w.lane + 64 * k;  // columns 4 q4i .. 4 q4i + 3 of the window: staged quads 2 q4i, 2 q4i + 1
+                    if (2 * q4i < G::NQ) {
+                        const int p = true_mod(w.xs - G::LEAD + 4 * q4i, a.Nc);  // LEAD is a multiple of 4 here (RowInvLds::AL)
+                        const rv4 v0 = load4(r0 + p), v1 = load4(r1 + p);
+                        const int qa = 2 * q4i, qb = 2 * q4i + 1;
+                        store4(w.reg + 36 * (qa >> 3) + 4 * (qa & 7), mk4(v0.x, v1.x, v0.y, v1.y));
+                        if (qb < G::NQ) store4(w.reg + 36 * (qb >> 3) + 4 * (qb & 7), mk4(v0.z, v1.z, v0.w, v1.w));
+                    }
+                }
+            }
+        }
+    }
+    PDWT_SYNC();
+    PDWT_FOR_THREADS(tid, NT) {
+        const RowLdsWork w = row_lds_work<NT>(a, block, tid, smem, G::WAVE_FLOATS);
+        v2f* acc = PDWT_MINE(acc, tid);
+        const real_t zero = 0;
+#pragma unroll
+        for (int pp = 0; pp < 16; ++pp) acc[pp] = mk2(zero, zero);
+        if (w.valid) {
+            unsigned lbo = 36u * (unsigned)w.lane;  // the lane's 16 columns = 32 floats = one padded block
+            rv4 b[2][CH];
+#pragma unroll
+            for (int u = 0; u < CH; ++u)
+                if (u < G::NWQ) b[0][u] = load4(w.reg + lbo + 36 * (u >> 3) + 4 * (u & 7));
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch) {
+#pragma unroll
+                for (int u = 0; u < CH; ++u) {
+                    const int n = (ch + 1) * CH + u;
+                    if (n < G::NWQ) b[(ch + 1) & 1][u] = load4(w.reg + lbo + 36 * (n >> 3) + 4 * (n & 7));
+                }
+                PDWT_SCHED_FENCE();
+#pragma unroll
+                for (int u = 0; u < CH; ++u) {
+                    const int wq = ch * CH + u;
+                    if (wq < G::NWQ) {
+                        const rv4& v = b[ch & 1][u];
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) {
+                            const int k = 2 * wq + i;
+                            const v2f pr = i == 0 ? mk2(v.x, v.y) : mk2(v.z, v.w);
+#pragma unroll
+                            for (int pp = 0; pp < 16; ++pp) {
+                                const int d = k - G::OFF - pp;
+                                if (d >= 0 && d % F == 0 && d / F < HLEN) acc[pp] = fma2_s(pr, a.t.t[d / F], acc[pp]);
+                            }
+                        }
+                    }
+                }
+                PDWT_SCHED_FENCE();
+                PDWT_ORDER_AFTER(lbo, acc[0], acc[1], acc[14], acc[15]);
+            }
+        }
+    }
+    PDWT_SYNC();
+    PDWT_FOR_THREADS(tid, NT) {
+        const RowLdsWork w = row_lds_work<NT>(a, block, tid, smem, G::WAVE_FLOATS);
+        const v2f* acc = PDWT_MINE(acc, tid);
+        const real_t half = (real_t)0.5;
+        if (w.valid) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+                store4(w.reg + 20 * w.lane + 4 * m,
+                       mk4(half * (acc[4 * m].x + acc[4 * m].y), half * (acc[4 * m + 1].x + acc[4 * m + 1].y),
+                           half * (acc[4 * m + 2].x + acc[4 * m + 2].y), half * (acc[4 * m + 3].x + acc[4 * m + 3].y)));
+        }
+    }
+    PDWT_SYNC();
+    PDWT_FOR_THREADS(tid, NT) {
+        const RowLdsWork w = row_lds_work<NT>(a, block, tid, smem, G::WAVE_FLOATS);
+        if (w.valid) {
+            real_t* PDWT_RESTRICT orow = a.out[0] + w.bz * a.out_bstride + (long long)w.y * a.Nc;
+#pragma unroll
+            for (int k = 0; k < kRowSpan / 256; ++k) {
+                const int qq = w.lane + 64 * k, col = w.xs + 4 * qq;
+                if (col < a.Nc) store4(orow + col, load4(w.reg + 20 * (qq >> 2) + 4 * (qq & 3)));
+            }
+        }
+    }
+}
+
 #ifndef PDWT_CPU_EMU
 template <int HLEN, int R, int NT>
 __global__ void __launch_bounds__(NT) swt_col_fwd_kernel(const SwtSplitArgs a) { swt_col_fwd_tile<HLEN, R, NT>(a, blockIdx.x); }
@@ -606,6 +924,18 @@ template <int HLEN, int R, int NT>
 __global__ void __launch_bounds__(NT) swt_row_inv4_kernel(const SwtSplitArgs a) { swt_row_inv4_tile<HLEN, R, NT>(a, blockIdx.x); }
 template <int HLEN, int F, int NT>
 __global__ void __launch_bounds__(NT) swt_row_inv1_kernel(const SwtSplitArgs a) { swt_row_inv1_tile<HLEN, F, NT>(a, blockIdx.x); }
+template <int HLEN, int R, int NT>
+__global__ void __launch_bounds__(NT) swt_row_inv4p_kernel(const SwtSplitArgs a) { swt_row_inv4p_tile<HLEN, R, NT>(a, blockIdx.x); }
+template <int HLEN, int F, int NT>
+__global__ void __launch_bounds__(NT) swt_row_fwd_lds_kernel(const SwtSplitArgs a) {
+    extern __shared__ __attribute__((aligned(16))) real_t pdwt_smem[];
+    swt_row_fwd_lds_tile<HLEN, F, NT>(a, blockIdx.x, pdwt_smem);
+}
+template <int HLEN, int F, int PLANES, int NT>
+__global__ void __launch_bounds__(NT) swt_row_inv_lds_kernel(const SwtSplitArgs a) {
+    extern __shared__ __attribute__((aligned(16))) real_t pdwt_smem[];
+    swt_row_inv_lds_tile<HLEN, F, PLANES, NT>(a, blockIdx.x, pdwt_smem);
+}
 #endif
 
 }  // namespace pdwt

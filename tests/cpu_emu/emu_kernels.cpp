@@ -757,12 +757,18 @@ static void run_swt_split(const Swt2DArgs& a, int batch, bool inverse, float* tm
     const long long col_items = split_col_waves(batch, a.Nr, a.Nc, f, R);
     const long long row_items4 = f >= 4 ? split_row_waves(batch, a.Nr, split_row_items4(a.Nc, f, R)) : 0;
     const long long row_items1 = split_row_waves(batch, a.Nr, split_row_items1(a.Nc));
+    const long long row_lds = split_row_lds_waves(batch, a.Nr, a.Nc);
+    std::vector<float> smem(16384, NAN);  // one workgroup's LDS
+    const bool direct = getenv("EMU_SPLIT_DIRECT") != nullptr;  // the kernels without LDS staging (dilation 1, 2)
     auto blocks = [](long long waves) { return (waves + NT / 64 - 1) / (NT / 64); };
     if (!inverse) {
         SwtSplitArgs r = k;
         r.in[0] = a.in; r.in_bstride = a.bstride; r.out[0] = tmp; r.out[1] = tmp + plane; r.out_bstride = 2 * plane;
-        if (f == 1) for (long long b = 0; b < blocks(row_items1); ++b) swt_row_fwd1_tile<HLEN, 1, NT>(r, b);
-        else if (f == 2) for (long long b = 0; b < blocks(row_items1); ++b) swt_row_fwd1_tile<HLEN, 2, NT>(r, b);
+        if (f == 1 && direct) for (long long b = 0; b < blocks(row_items1); ++b) swt_row_fwd1_tile<HLEN, 1, NT>(r, b);
+        else if (f == 2 && direct) for (long long b = 0; b < blocks(row_items1); ++b) swt_row_fwd1_tile<HLEN, 2, NT>(r, b);
+        else if (f == 1) for (long long b = 0; b < blocks(row_lds); ++b) swt_row_fwd_lds_tile<HLEN, 1, NT>(r, b, smem.data());
+        else if (f == 2) for (long long b = 0; b < blocks(row_lds); ++b) swt_row_fwd_lds_tile<HLEN, 2, NT>(r, b, smem.data());
+        else if (f == 4 && !direct) for (long long b = 0; b < blocks(row_lds); ++b) swt_row_fwd_lds_tile<HLEN, 4, NT>(r, b, smem.data());
         else for (long long b = 0; b < blocks(row_items4); ++b) swt_row_fwd4_tile<HLEN, R, NT>(r, b);
         SwtSplitArgs c = k;
         c.in[0] = tmp; c.in[1] = tmp + plane; c.in_bstride = 2 * plane;
@@ -775,8 +781,11 @@ static void run_swt_split(const Swt2DArgs& a, int batch, bool inverse, float* tm
     for (long long b = 0; b < blocks(col_items); ++b) swt_col_inv_tile<HLEN, R, NT>(c, b);
     SwtSplitArgs r = k;
     r.in[0] = tmp; r.in_bstride = 2 * plane; r.out[0] = a.out; r.out_bstride = a.bstride;
-    if (f == 1) for (long long b = 0; b < blocks(row_items1); ++b) swt_row_inv1_tile<HLEN, 1, NT>(r, b);
-    else if (f == 2) for (long long b = 0; b < blocks(row_items1); ++b) swt_row_inv1_tile<HLEN, 2, NT>(r, b);
+    if (f == 1 && direct) for (long long b = 0; b < blocks(row_items1); ++b) swt_row_inv1_tile<HLEN, 1, NT>(r, b);
+    else if (f == 2 && direct) for (long long b = 0; b < blocks(row_items1); ++b) swt_row_inv1_tile<HLEN, 2, NT>(r, b);
+    else if (f == 1) for (long long b = 0; b < blocks(row_lds); ++b) swt_row_inv_lds_tile<HLEN, 1, 1, NT>(r, b, smem.data());
+    else if (f == 2) for (long long b = 0; b < blocks(row_lds); ++b) swt_row_inv_lds_tile<HLEN, 2, 1, NT>(r, b, smem.data());
+    else if (f == 4 && !direct) for (long long b = 0; b < blocks(row_lds); ++b) swt_row_inv_lds_tile<HLEN, 4, 1, NT>(r, b, smem.data());
     else for (long long b = 0; b < blocks(row_items4); ++b) swt_row_inv4_tile<HLEN, R, NT>(r, b);
 }
 
@@ -790,6 +799,45 @@ EMU_API int emu_swt2_split(int inverse, float* io, int batch, int Nr, int Nc, in
     std::vector<float> tmp((size_t)2 * Nr * Nc * batch + 16, NAN);
     switch (hlen) {
 #define X(h) case h: run_swt_split<h>(a, batch, inverse != 0, tmp.data()); return 0;
+        X(10) X(12) X(16) X(20) X(26) X(40)
+#undef X
+    }
+    return -1;
+}
+
+// ---- the row kernels as the (batched) 1D transform: separate approximation / detail planes
+template <int HLEN>
+static void run_swt1_split(const float* in0, const float* in1, int Nr, int Nc, int f, const FilterBank& fb, bool inverse, float* out0, float* out1) {
+    constexpr int NT = 256, R = 4;
+    SwtSplitArgs k{};
+    k.Nr = Nr; k.Nc = Nc; k.f = f; k.batch = 1;
+    for (int j = 0; j < HLEN; ++j) k.t.t[j] = mk2(fb.lo[HLEN - 1 - j], fb.hi[HLEN - 1 - j]);
+    k.in[0] = in0; k.in[1] = in1; k.out[0] = out0; k.out[1] = out1;
+    const long long row_items4 = f >= 4 ? split_row_waves(1, Nr, split_row_items4(Nc, f, R)) : 0;
+    const long long row_lds = split_row_lds_waves(1, Nr, Nc);
+    std::vector<float> smem(16384, NAN);
+    auto blocks = [](long long waves) { return (waves + NT / 64 - 1) / (NT / 64); };
+    if (!inverse) {
+        if (f == 1) for (long long b = 0; b < blocks(row_lds); ++b) swt_row_fwd_lds_tile<HLEN, 1, NT>(k, b, smem.data());
+        else if (f == 2) for (long long b = 0; b < blocks(row_lds); ++b) swt_row_fwd_lds_tile<HLEN, 2, NT>(k, b, smem.data());
+        else if (f == 4) for (long long b = 0; b < blocks(row_lds); ++b) swt_row_fwd_lds_tile<HLEN, 4, NT>(k, b, smem.data());
+        else for (long long b = 0; b < blocks(row_items4); ++b) swt_row_fwd4_tile<HLEN, R, NT>(k, b);
+        return;
+    }
+    if (f == 1) for (long long b = 0; b < blocks(row_lds); ++b) swt_row_inv_lds_tile<HLEN, 1, 2, NT>(k, b, smem.data());
+    else if (f == 2) for (long long b = 0; b < blocks(row_lds); ++b) swt_row_inv_lds_tile<HLEN, 2, 2, NT>(k, b, smem.data());
+    else if (f == 4) for (long long b = 0; b < blocks(row_lds); ++b) swt_row_inv_lds_tile<HLEN, 4, 2, NT>(k, b, smem.data());
+    else for (long long b = 0; b < blocks(row_items4); ++b) swt_row_inv4p_tile<HLEN, R, NT>(k, b);
+}
+
+EMU_API int emu_swt1_split(int inverse, const float* in0, const float* in1, int Nr, int Nc, int level, const float* lo, const float* hi,
+                           int hlen, float* out0, float* out1) {
+    const int f = 1 << (level - 1);
+    if ((Nc & 3) || Nc < 16 || f >= Nc) return -2;
+    FilterBank fb;
+    set_bank(fb, lo, hi, hlen);
+    switch (hlen) {
+#define X(h) case h: run_swt1_split<h>(in0, in1, Nr, Nc, f, fb, inverse != 0, out0, out1); return 0;
         X(10) X(12) X(16) X(20) X(26) X(40)
 #undef X
     }

@@ -682,15 +682,20 @@ def test_emu_swt4_fused_forward_and_inverse(wname):
                 assert np.abs(rec[b] - want).max() <= 4e-6 * 3 * max(1.0, float(np.abs(want).max())), (wname, si, "inverse", beta is not None)
 
 
+@pytest.mark.parametrize("direct", [0, 1])
 @pytest.mark.parametrize("wname", ["db5", "db6", "sym8", "db10", "db13", "db20"])
-def test_emu_swt_split_row_and_column_launches(wname):
+def test_emu_swt_split_row_and_column_launches(wname, direct, monkeypatch):
     """swt_split_kernels.hpp (one a-trous level as a register-blocked row launch + column launch through scratch) vs the
     oracle's per-pass functions: dilations 1, 2 (16 consecutive columns per work item) and 4, 8, 16 (quads one dilation
     step apart), row counts the dilation does not divide, ragged last blocks, batches, the pending soft threshold"""
     import ctypes as C
+    if direct:  # dilation 1, 2, 4 through the kernels without LDS staging (the 16-consecutive-column work items / quads f apart)
+        monkeypatch.setenv("EMU_SPLIT_DIRECT", "1")
+    else:
+        monkeypatch.delenv("EMU_SPLIT_DIRECT", raising=False)
     hlen, dlo, dhi, rlo, rhi = oracle.filters(wname)
     lib_o = oracle.load()
-    cases = [((32, 32), 1, 1), ((33, 48), 2, 2), ((64, 136), 3, 1), ((50, 260), 4, 1), ((40, 20), 2, 1), ((96, 100), 5, 1),
+    cases = [((32, 32), 1, 1), ((33, 48), 2, 2), ((5, 2064), 1, 1), ((3, 1040), 3, 2), ((64, 136), 3, 1), ((50, 260), 4, 1), ((40, 20), 2, 1), ((96, 100), 5, 1),
              ((24, 16), 1, 3), ((45, 72), 3, 1)]
     for si, (shape, level, B) in enumerate(cases):
         f = 1 << (level - 1)
@@ -723,3 +728,26 @@ def test_emu_swt_split_row_and_column_launches(wname):
                 lib_o.oracle_swt_synthesis_rows(P(t1), P(t2), shape[0], shape[1], P(rlo), P(rhi), hlen, level, P(want))
                 assert np.isfinite(rec[b]).all(), (wname, shape, level, "inverse")
                 assert np.abs(rec[b] - want).max() <= _tol(want), (wname, shape, level, "inverse", beta)
+
+
+@pytest.mark.parametrize("wname", ["db5", "sym8", "db13", "db20"])
+def test_emu_swt_row_kernels_as_the_1d_transform(wname):
+    """the row kernels of swt_split_kernels.hpp on separate approximation / detail planes (the batched 1D SWT): the inverse
+    interleaves the two planes while staging them in LDS (dilation 1, 2, 4) or packs over column pairs (dilation >= 8)"""
+    hlen, dlo, dhi, rlo, rhi = oracle.filters(wname)
+    lib_o = oracle.load()
+    for si, (shape, level) in enumerate([((3, 64), 1), ((2, 1100), 2), ((1, 2080), 3), ((4, 400), 4), ((1, 4096), 5), ((2, 52), 1)]):
+        f = 1 << (level - 1)
+        if f * 2 >= shape[1]:
+            continue
+        x = oracle.hash_input(shape, 6100 + si)
+        y = oracle.hash_input(shape, 6200 + si)
+        r0 = np.zeros(shape, np.float32); r1 = np.zeros(shape, np.float32)
+        lib_o.oracle_swt_analysis_rows(P(x), shape[0], shape[1], P(dlo), P(dhi), hlen, level, P(r0), P(r1))
+        o0 = np.full(shape, np.nan, np.float32); o1 = np.full(shape, np.nan, np.float32)
+        assert lib().emu_swt1_split(0, P(x), None, shape[0], shape[1], level, P(dlo), P(dhi), hlen, P(o0), P(o1)) == 0
+        assert np.abs(o0 - r0).max() <= _tol(r0) and np.abs(o1 - r1).max() <= _tol(r1), (wname, shape, level)
+        lib_o.oracle_swt_synthesis_rows(P(x), P(y), shape[0], shape[1], P(rlo), P(rhi), hlen, level, P(r0))
+        o0 = np.full(shape, np.nan, np.float32)
+        assert lib().emu_swt1_split(1, P(x), P(y), shape[0], shape[1], level, P(rlo), P(rhi), hlen, P(o0), None) == 0
+        assert np.abs(o0 - r0).max() <= _tol(r0), (wname, shape, level, "inverse")

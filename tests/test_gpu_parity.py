@@ -447,6 +447,27 @@ def test_swt_two_launch_levels(wname, shape, levels, batch):
         lib.pdwt_set_tuning(b"swt_split_inv", prev[1])
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("wname,shape,levels", [("db5", (3, 5000), 5), ("sym8", (1, 1 << 16), 6), ("db13", (2, 8192), 4),
+                                                ("db20", (5, 4100), 5), ("coif3", (1, 1036), 3)])
+def test_swt_1d_long_filters_on_the_row_kernels(wname, shape, levels):
+    """(batched) 1D SWT with filters of >= 10 taps: the register-blocked row kernels of swt_split_kernels.hpp on separate
+    approximation / detail planes -- LDS-staged at dilation 1, 2, 4 (the inverse interleaves the two planes while
+    staging), quads a dilation step apart beyond; rows that are not whole 1024-column spans; vs the oracle"""
+    from pypwt_amd import Wavelets
+    x = oracle.hash_input(shape, 171, scale=255.0)
+    w = Wavelets(x if shape[0] > 1 else x[0], wname, levels, do_swt=1, ndim=1)
+    assert w.levels == levels
+    w.forward()
+    ref = oracle.forward(x, wname, levels, ndim=1, do_swt=1)
+    got = w.coeffs
+    for k, (g, r) in enumerate(zip(got, ref)):
+        assert np.abs(np.asarray(g).reshape(r.shape) - r).max() <= 2e-5 * max(float(np.abs(r).max()), 255.0), (wname, k)
+    w.inverse()
+    want = oracle.inverse(ref, shape, wname, levels, ndim=1, do_swt=1)
+    assert np.abs(np.asarray(w.image).reshape(shape) - want).max() <= 4e-3, wname
+
+
 # ---------------------------------------------------------------------------------------------
 # fp64 build (libpypwt_amd_f64.so, Wavelets64): the reference's DOUBLEPRECISION variant
 # ---------------------------------------------------------------------------------------------
