@@ -35,12 +35,12 @@ static int env_int(const char* name, int dflt) {
 }
 
 // Where the two launches beat the LDS-tiled level kernel (2048^2 levels, tools/swtsweep.py, profiles/r03_swt_split_sweep.txt):
-// the inverse from 12 taps on (12 taps 80 -> 47 us per level, 16 taps 93 -> 51, 40 taps 150-290 -> 72-87; at 10 taps both
-// take 45), the forward from 18 taps on (18 taps 47-61 -> 41, 26 taps 91-111 -> 43, 40 taps 127-158 -> 50; at 16 taps the
-// tiled kernel's 35-42 is level with the 40 of two launches).  Tuning keys "swt_split_fwd" / "swt_split_inv" (environment
+// the inverse from 10 taps on (10 taps 46 -> 41 us per level, 12 taps 80 -> 43, 16 taps 93 -> 40, 40 taps 150-290 -> 57-60),
+// the forward from 18 taps on (18 taps 47-61 -> 40, 26 taps 91-111 -> 42, 40 taps 127-158 -> 45-47; at 16 taps the
+// tiled kernel's 35-45 is level with the 36-39 of two launches).  Tuning keys "swt_split_fwd" / "swt_split_inv" (environment
 // PDWT_SWT_SPLIT_FWD / _INV): the shortest filter that takes this path, 0 = never.
 static std::atomic<int>& split_min(bool inverse) {
-    static std::atomic<int> fwd{env_int("PDWT_SWT_SPLIT_FWD", 18)}, inv{env_int("PDWT_SWT_SPLIT_INV", 12)};
+    static std::atomic<int> fwd{env_int("PDWT_SWT_SPLIT_FWD", 18)}, inv{env_int("PDWT_SWT_SPLIT_INV", 10)};
     return inverse ? inv : fwd;
 }
 int set_swt_split_min(int inverse, int taps) { return split_min(inverse != 0).exchange(taps < 0 ? 0 : taps); }
@@ -63,7 +63,7 @@ template <int HLEN>
 static hipError_t run_split(const Swt2DArgs& a, real_t* tmp, bool inverse, int batch, hipStream_t s) {
     // column workgroups of 16 wavefronts x 4 rows share their input rows on one CU (split_col_work).  8 rows per wavefront
     // with 8 wavefronts (the same 64 rows, half the L1 traffic) measured no better: 16 taps 31.1 / 21.5 us against 30.5 / 20.0
-    constexpr int NT = 256, R = 4, RC = 4, NTC = 1024;  // NTC: wavefronts of a column workgroup share their rows (split_col_work)
+    constexpr int NT = 256, R = 4, RC = 4, NTC = PDWT_SPLIT_NTC;  // NTC: wavefronts of a column workgroup share their rows (split_col_work)
     const long long plane = (long long)a.Nr * a.Nc;
     SwtSplitArgs k{};
     k.Nr = a.Nr; k.Nc = a.Nc; k.f = a.f; k.batch = batch;

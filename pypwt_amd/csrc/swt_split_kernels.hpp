@@ -80,6 +80,11 @@ PDWT_DEVICE unsigned step_wrap_u(unsigned p, unsigned step, unsigned n) {
 
 // rows per chunk of loads in flight (a chunk is issued while the previous one is consumed)
 constexpr int kSplitChunk = 4;
+#ifndef PDWT_SPLIT_CH_COLF
+#define PDWT_SPLIT_CH_COLF 2
+#define PDWT_SPLIT_CH_COLI 2
+#define PDWT_SPLIT_NTC 1024
+#endif
 
 // Work decomposition of the column kernels: a WAVEFRONT owns 64 adjacent quad columns of (image, phase, block of R phase
 // rows); rows of a phase are f apart.  Returns false for wavefronts beyond the work.
@@ -118,7 +123,7 @@ constexpr long long split_col_waves(int batch, int Nr, int Nc, int f, int R) {
 // output rows f apart (phase ph, rows ph + f (blk R + m)); lanes = adjacent quads of a row (1 KiB per wavefront and load).
 template <int HLEN, int R, int NT>
 PDWT_DEVICE void swt_col_fwd_tile(const SwtSplitArgs& a, long long block) {
-    constexpr int c = HLEN / 2 - 1, NIN = R + HLEN - 1, CH = 2, NCH = (NIN + CH - 1) / CH;
+    constexpr int c = HLEN / 2 - 1, NIN = R + HLEN - 1, CH = PDWT_SPLIT_CH_COLF, NCH = (NIN + CH - 1) / CH;
     const int f = a.f;
     PDWT_FOR_THREADS(tid, NT) {
         SplitColWork w;
@@ -198,7 +203,7 @@ PDWT_DEVICE void swt_col_fwd_tile(const SwtSplitArgs& a, long long block) {
 // threshold (uniform: one branch per row) is applied to the detail rows when they are consumed.
 template <int HLEN, int R, int NT>
 PDWT_DEVICE void swt_col_inv_tile(const SwtSplitArgs& a, long long block) {
-    constexpr int c = HLEN / 2, NIN = R + HLEN - 1, CH = 2, NCH = (NIN + CH - 1) / CH;
+    constexpr int c = HLEN / 2, NIN = R + HLEN - 1, CH = PDWT_SPLIT_CH_COLI, NCH = (NIN + CH - 1) / CH;
     const int f = a.f;
     PDWT_FOR_THREADS(tid, NT) {
         SplitColWork w;

@@ -371,7 +371,7 @@ def test_three_level_pyramid_on_small_images():
 
 @pytest.fixture
 def swt_split_off():
-    """the LDS-tiled per-level SWT kernels for every filter length (by default filters of >= 18 / 12 taps take the
+    """the LDS-tiled per-level SWT kernels for every filter length (by default filters of >= 18 / 10 taps take the
     two-launch path of swt_split_kernels.hpp)"""
     from pypwt_amd import _lib
     lib = _lib.load()
