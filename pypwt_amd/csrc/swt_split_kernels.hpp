@@ -319,7 +319,6 @@ PDWT_DEVICE bool split_row_work(const SwtSplitArgs& a, int trow, long long block
 }
 constexpr long long split_row_waves(int batch, int Nr, int trow) { return (long long)batch * Nr * ((trow + 63) >> 6); }
 constexpr int split_row_items4(int Nc, int f, int R) { return ((Nc + R * f - 1) / (R * f)) * (f >> 2); }
-constexpr int split_row_items1(int Nc) { return (Nc + 15) >> 4; }
 
 // forward, row pass, dilation a multiple of 4: in -> lo = Lx in, hi = Hx in.  Work item: R quads f apart,
 // x = b R f + 4 g + m f (block b of R f columns, quad g of the f / 4 quads of a dilation period).
@@ -386,75 +385,6 @@ PDWT_DEVICE void swt_row_fwd4_tile(const SwtSplitArgs& a, long long block) {
             if (xm < a.Nc) {
                 store4(a.out[0] + ob + xm, mk4(acc[m][0].x, acc[m][1].x, acc[m][2].x, acc[m][3].x));
                 store4(a.out[1] + ob + xm, mk4(acc[m][0].y, acc[m][1].y, acc[m][2].y, acc[m][3].y));
-            }
-        }
-    }
-}
-
-// forward, row pass, dilation F = 1 or 2: a work item owns 16 consecutive columns and streams the quads of its window
-// [x0 - LEAD, x0 + 16 + (hlen - 1 - c) F): sample k of the window feeds output p with tap (k - OFF - p) / F.
-template <int HLEN, int F, int NT>
-PDWT_DEVICE void swt_row_fwd1_tile(const SwtSplitArgs& a, long long block) {
-    constexpr int c = HLEN / 2 - 1, LEAD = (c * F + 3) / 4 * 4, OFF = LEAD - c * F;
-    constexpr int NWQ = (LEAD + 16 + (HLEN - 1 - c) * F + 3) / 4, CH = kSplitChunk, NCH = (NWQ + CH - 1) / CH;
-    const int trow = split_row_items1(a.Nc);
-    PDWT_FOR_THREADS(tid, NT) {
-        SplitRowWork w;
-        if (!split_row_work<NT>(a, trow, block, tid, w)) continue;
-        const int x0 = 16 * w.tr;
-        const real_t* PDWT_RESTRICT row = a.in[0] + w.bz * a.in_bstride + (long long)w.y * a.Nc;
-        const real_t zero = 0;
-        v2f acc[16];
-#pragma unroll
-        for (int pp = 0; pp < 16; ++pp) acc[pp] = mk2(zero, zero);
-        unsigned p = (unsigned)true_mod(x0 - LEAD, a.Nc);
-        rv4 b[2][CH];
-#pragma unroll
-        for (int u = 0; u < CH; ++u) {
-            if (u < NWQ) {
-                b[0][u] = load4(row + p);
-                p = step_wrap_u(p, 4u, (unsigned)a.Nc);
-            }
-        }
-#pragma unroll
-        for (int ch = 0; ch < NCH; ++ch) {
-#pragma unroll
-            for (int u = 0; u < CH; ++u) {
-                if ((ch + 1) * CH + u < NWQ) {
-                    b[(ch + 1) & 1][u] = load4(row + p);
-                    p = step_wrap_u(p, 4u, (unsigned)a.Nc);
-                }
-            }
-            PDWT_SCHED_FENCE();
-#pragma unroll
-            for (int u = 0; u < CH; ++u) {
-                const int wq = ch * CH + u;
-                if (wq < NWQ) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int k = 4 * wq + i;
-#pragma unroll
-                        for (int pp = 0; pp < 16; ++pp) {
-                            const int d = k - OFF - pp;
-                            if (d >= 0 && d % F == 0 && d / F < HLEN) {
-                                const rv4& v = b[ch & 1][u];
-                                const v2f pr = i < 2 ? mk2(v.x, v.y) : mk2(v.z, v.w);
-                                acc[pp] = (i & 1) ? fma2_by(pr, a.t.t[d / F], acc[pp]) : fma2_bx(pr, a.t.t[d / F], acc[pp]);
-                            }
-                        }
-                    }
-                }
-            }
-            PDWT_SCHED_FENCE();
-            PDWT_ORDER_AFTER(p, acc[0], acc[1], acc[14], acc[15]);
-        }
-        if (!w.active) continue;
-        const long long ob = w.bz * a.out_bstride + (long long)w.y * a.Nc + x0;
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            if (x0 + 4 * m < a.Nc) {
-                store4(a.out[0] + ob + 4 * m, mk4(acc[4 * m].x, acc[4 * m + 1].x, acc[4 * m + 2].x, acc[4 * m + 3].x));
-                store4(a.out[1] + ob + 4 * m, mk4(acc[4 * m].y, acc[4 * m + 1].y, acc[4 * m + 2].y, acc[4 * m + 3].y));
             }
         }
     }
@@ -600,77 +530,12 @@ PDWT_DEVICE void swt_row_inv4p_tile(const SwtSplitArgs& a, long long block) {
     }
 }
 
-// inverse, row pass, dilation F = 1 or 2: 16 consecutive columns per work item, the window streamed as (L', H') pairs
-template <int HLEN, int F, int NT>
-PDWT_DEVICE void swt_row_inv1_tile(const SwtSplitArgs& a, long long block) {
-    constexpr int c = HLEN / 2, LEAD = (c * F + 1) / 2 * 2, OFF = LEAD - c * F;
-    constexpr int NWQ = (LEAD + 16 + (HLEN - 1 - c) * F + 1) / 2, CH = 2 * kSplitChunk, NCH = (NWQ + CH - 1) / CH;  // loads of 2 pairs
-    const int trow = split_row_items1(a.Nc);
-    PDWT_FOR_THREADS(tid, NT) {
-        SplitRowWork w;
-        if (!split_row_work<NT>(a, trow, block, tid, w)) continue;
-        const int x0 = 16 * w.tr;
-        const real_t* PDWT_RESTRICT row = a.in[0] + w.bz * a.in_bstride + (long long)w.y * 2 * a.Nc;
-        const real_t zero = 0, half = (real_t)0.5;
-        v2f acc[16];
-#pragma unroll
-        for (int pp = 0; pp < 16; ++pp) acc[pp] = mk2(zero, zero);
-        unsigned p = (unsigned)true_mod(x0 - LEAD, a.Nc);  // even: x0, LEAD and Nc are
-        rv4 b[2][CH];
-#pragma unroll
-        for (int u = 0; u < CH; ++u) {
-            if (u < NWQ) {
-                b[0][u] = load4(row + 2 * p);
-                p = step_wrap_u(p, 2u, (unsigned)a.Nc);
-            }
-        }
-#pragma unroll
-        for (int ch = 0; ch < NCH; ++ch) {
-#pragma unroll
-            for (int u = 0; u < CH; ++u) {
-                if ((ch + 1) * CH + u < NWQ) {
-                    b[(ch + 1) & 1][u] = load4(row + 2 * p);
-                    p = step_wrap_u(p, 2u, (unsigned)a.Nc);
-                }
-            }
-            PDWT_SCHED_FENCE();
-#pragma unroll
-            for (int u = 0; u < CH; ++u) {
-                const int wq = ch * CH + u;
-                if (wq < NWQ) {
-                    const rv4& v = b[ch & 1][u];
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) {
-                        const int k = 2 * wq + i;
-                        const v2f pr = i == 0 ? mk2(v.x, v.y) : mk2(v.z, v.w);
-#pragma unroll
-                        for (int pp = 0; pp < 16; ++pp) {
-                            const int d = k - OFF - pp;
-                            if (d >= 0 && d % F == 0 && d / F < HLEN) acc[pp] = fma2_s(pr, a.t.t[d / F], acc[pp]);
-                        }
-                    }
-                }
-            }
-            PDWT_SCHED_FENCE();
-            PDWT_ORDER_AFTER(p, acc[0], acc[1], acc[14], acc[15]);
-        }
-        if (!w.active) continue;
-        const long long ob = w.bz * a.out_bstride + (long long)w.y * a.Nc + x0;
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            if (x0 + 4 * m < a.Nc)
-                store4(a.out[0] + ob + 4 * m,
-                       mk4(half * (acc[4 * m].x + acc[4 * m].y), half * (acc[4 * m + 1].x + acc[4 * m + 1].y),
-                           half * (acc[4 * m + 2].x + acc[4 * m + 2].y), half * (acc[4 * m + 3].x + acc[4 * m + 3].y)));
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------------------------------------
-// Row passes at dilation F = 1, 2, 4 through LDS.  In the kernels above a work item owns 16 consecutive columns (at
-// F = 4 the four quads f apart ARE 16 consecutive columns): every lane of a load or store touches its own 64-B piece --
-// 64 cache-line requests per wavefront instruction instead of 16, and partial-line stores (rocprofv3, 2048^2, 40 taps:
-// 21 us per launch for 50 MB and 5 us of arithmetic).  Here a wavefront stages its row segment (1024 outputs + the window
+// Row passes at dilation F = 1, 2, 4 through LDS.  At these dilations a work item owns 16 CONSECUTIVE columns (at
+// F = 4 the four quads f apart ARE 16 consecutive columns; at 1 and 2 it streams its window of 16 + (hlen - 1) F samples:
+// sample k feeds output p with tap (k - OFF - p) / F).  Straight from global memory every lane of a load or store would
+// touch its own 64-B piece -- 64 cache-line requests per wavefront instruction instead of 16, and partial-line stores
+// (measured: 21 us per 2048^2 launch of 40 taps, 17.6-18.9 through LDS).  Here a wavefront stages its row segment (1024 outputs + the window
 // halo) in LDS with coalesced 16-B loads, the lanes read their windows from LDS (4 pad floats per 16 -- per 32 for the
 // interleaved input of the inverse -- make the 8 lanes of an LDS pass hit 32 different banks), and the results go back
 // through the same LDS region so that the global stores are whole 1-KiB rows.  Workgroup = NT / 64 independent
@@ -923,12 +788,8 @@ template <int HLEN, int R, int NT>
 __global__ void __launch_bounds__(NT) swt_col_inv_kernel(const SwtSplitArgs a) { swt_col_inv_tile<HLEN, R, NT>(a, blockIdx.x); }
 template <int HLEN, int R, int NT>
 __global__ void __launch_bounds__(NT) swt_row_fwd4_kernel(const SwtSplitArgs a) { swt_row_fwd4_tile<HLEN, R, NT>(a, blockIdx.x); }
-template <int HLEN, int F, int NT>
-__global__ void __launch_bounds__(NT) swt_row_fwd1_kernel(const SwtSplitArgs a) { swt_row_fwd1_tile<HLEN, F, NT>(a, blockIdx.x); }
 template <int HLEN, int R, int NT>
 __global__ void __launch_bounds__(NT) swt_row_inv4_kernel(const SwtSplitArgs a) { swt_row_inv4_tile<HLEN, R, NT>(a, blockIdx.x); }
-template <int HLEN, int F, int NT>
-__global__ void __launch_bounds__(NT) swt_row_inv1_kernel(const SwtSplitArgs a) { swt_row_inv1_tile<HLEN, F, NT>(a, blockIdx.x); }
 template <int HLEN, int R, int NT>
 __global__ void __launch_bounds__(NT) swt_row_inv4p_kernel(const SwtSplitArgs a) { swt_row_inv4p_tile<HLEN, R, NT>(a, blockIdx.x); }
 template <int HLEN, int F, int NT>

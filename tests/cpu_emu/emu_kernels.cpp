@@ -756,17 +756,14 @@ static void run_swt_split(const Swt2DArgs& a, int batch, bool inverse, float* tm
     const int f = a.f;
     const long long col_items = split_col_waves(batch, a.Nr, a.Nc, f, R);
     const long long row_items4 = f >= 4 ? split_row_waves(batch, a.Nr, split_row_items4(a.Nc, f, R)) : 0;
-    const long long row_items1 = split_row_waves(batch, a.Nr, split_row_items1(a.Nc));
     const long long row_lds = split_row_lds_waves(batch, a.Nr, a.Nc);
     std::vector<float> smem(16384, NAN);  // one workgroup's LDS
-    const bool direct = getenv("EMU_SPLIT_DIRECT") != nullptr;  // the kernels without LDS staging (dilation 1, 2)
+    const bool direct = getenv("EMU_SPLIT_DIRECT") != nullptr;  // dilation 4 through the kernel of the dilations >= 8 (quads f apart, no LDS)
     auto blocks = [](long long waves) { return (waves + NT / 64 - 1) / (NT / 64); };
     if (!inverse) {
         SwtSplitArgs r = k;
         r.in[0] = a.in; r.in_bstride = a.bstride; r.out[0] = tmp; r.out[1] = tmp + plane; r.out_bstride = 2 * plane;
-        if (f == 1 && direct) for (long long b = 0; b < blocks(row_items1); ++b) swt_row_fwd1_tile<HLEN, 1, NT>(r, b);
-        else if (f == 2 && direct) for (long long b = 0; b < blocks(row_items1); ++b) swt_row_fwd1_tile<HLEN, 2, NT>(r, b);
-        else if (f == 1) for (long long b = 0; b < blocks(row_lds); ++b) swt_row_fwd_lds_tile<HLEN, 1, NT>(r, b, smem.data());
+        if (f == 1) for (long long b = 0; b < blocks(row_lds); ++b) swt_row_fwd_lds_tile<HLEN, 1, NT>(r, b, smem.data());
         else if (f == 2) for (long long b = 0; b < blocks(row_lds); ++b) swt_row_fwd_lds_tile<HLEN, 2, NT>(r, b, smem.data());
         else if (f == 4 && !direct) for (long long b = 0; b < blocks(row_lds); ++b) swt_row_fwd_lds_tile<HLEN, 4, NT>(r, b, smem.data());
         else for (long long b = 0; b < blocks(row_items4); ++b) swt_row_fwd4_tile<HLEN, R, NT>(r, b);
@@ -781,9 +778,7 @@ static void run_swt_split(const Swt2DArgs& a, int batch, bool inverse, float* tm
     for (long long b = 0; b < blocks(col_items); ++b) swt_col_inv_tile<HLEN, R, NT>(c, b);
     SwtSplitArgs r = k;
     r.in[0] = tmp; r.in_bstride = 2 * plane; r.out[0] = a.out; r.out_bstride = a.bstride;
-    if (f == 1 && direct) for (long long b = 0; b < blocks(row_items1); ++b) swt_row_inv1_tile<HLEN, 1, NT>(r, b);
-    else if (f == 2 && direct) for (long long b = 0; b < blocks(row_items1); ++b) swt_row_inv1_tile<HLEN, 2, NT>(r, b);
-    else if (f == 1) for (long long b = 0; b < blocks(row_lds); ++b) swt_row_inv_lds_tile<HLEN, 1, 1, NT>(r, b, smem.data());
+    if (f == 1) for (long long b = 0; b < blocks(row_lds); ++b) swt_row_inv_lds_tile<HLEN, 1, 1, NT>(r, b, smem.data());
     else if (f == 2) for (long long b = 0; b < blocks(row_lds); ++b) swt_row_inv_lds_tile<HLEN, 2, 1, NT>(r, b, smem.data());
     else if (f == 4 && !direct) for (long long b = 0; b < blocks(row_lds); ++b) swt_row_inv_lds_tile<HLEN, 4, 1, NT>(r, b, smem.data());
     else for (long long b = 0; b < blocks(row_items4); ++b) swt_row_inv4_tile<HLEN, R, NT>(r, b);

@@ -689,7 +689,7 @@ def test_emu_swt_split_row_and_column_launches(wname, direct, monkeypatch):
     oracle's per-pass functions: dilations 1, 2 (16 consecutive columns per work item) and 4, 8, 16 (quads one dilation
     step apart), row counts the dilation does not divide, ragged last blocks, batches, the pending soft threshold"""
     import ctypes as C
-    if direct:  # dilation 1, 2, 4 through the kernels without LDS staging (the 16-consecutive-column work items / quads f apart)
+    if direct:  # dilation 4 through the kernel of the dilations >= 8 (quads f apart, straight from global memory)
         monkeypatch.setenv("EMU_SPLIT_DIRECT", "1")
     else:
         monkeypatch.delenv("EMU_SPLIT_DIRECT", raising=False)
