@@ -232,7 +232,9 @@ int pdwt_time_level(pdwt_handle h, int level, int inverse, int reps, float* ms_p
  *   "swt_split_fwd" / "swt_split_inv"   the shortest (even) filter whose 2D SWT levels run as a register-blocked row
  *                    launch + column launch through scratch (swt_split_kernels.hpp) instead of one LDS-tiled launch:
  *                    defaults 18 / 10 taps (where the two launches are faster on MI355X: 40 taps 127-158 -> 46 us per 2048^2
- *                    forward level, 16 taps 93 -> 40 us per inverse level); 0 = never.  Read at every level launch.
+ *                    forward level, 16 taps 93 -> 40 us per inverse level); the inverse of images below 1024^2 / 2048^2 starts at 24 / 12 taps
+ *                    (two one-round launches cost more than they save there); 0 = never; 100 + n = n taps at every size (tests).
+ *                    Read at every level launch.
  *   "chain"          levels 1..K of a 2D DWT in ONE launch with in-launch hand-offs between the levels
  *                    (dwt2_chain_kernels.hpp; even filters of at most 8 taps, whole 16 x 128 tiles at every level):
  *                    0 (default): never -- measured break-even for two levels and slower beyond on MI355X; 1: one

@@ -88,7 +88,7 @@ hipError_t launch_dwt1_inv_fused(const real_t* app, const real_t* const* det, re
 hipError_t launch_swt2_fwd(const Swt2DArgs& a, int batch, hipStream_t s);
 hipError_t launch_swt2_inv(const Swt2DArgs& a, int batch, hipStream_t s);
 // one a-trous level as a row launch + a column launch through scratch (2 Nr Nc batch elements): swt_split_kernels.hpp
-bool swt2_split_supported(int hlen, int Nr, int Nc, int f, bool inverse);
+bool swt2_split_supported(int hlen, int Nr, int Nc, int f, bool inverse, long long samples_per_launch);
 int set_swt_split_min(int inverse, int taps);  // shortest filter on the split path (0: never); returns the previous value
 hipError_t launch_swt2_split(const Swt2DArgs& a, real_t* scratch, bool inverse, int batch, hipStream_t s);
 // levels l0 .. l0+K-1 (K = 2, 3; l0 = 1 or 4) of a 2-tap 2D SWT in one launch (swt2_fused_kernels.hpp)

@@ -13,7 +13,7 @@
 namespace pdwt {
 
 #ifdef PDWT_DOUBLE
-bool swt2_split_supported(int, int, int, int, bool) { return false; }
+bool swt2_split_supported(int, int, int, int, bool, long long) { return false; }
 hipError_t try_launch_swt1_split(const SwtPassArgs&, bool, hipStream_t) { return hipErrorNotSupported; }
 int set_swt_split_min(int, int) { return 0; }
 hipError_t launch_swt2_split(const Swt2DArgs&, real_t*, bool, int, hipStream_t) { return hipErrorNotSupported; }
@@ -38,16 +38,28 @@ static int env_int(const char* name, int dflt) {
 // the inverse from 10 taps on (10 taps 46 -> 41 us per level, 12 taps 80 -> 43, 16 taps 93 -> 40, 40 taps 150-290 -> 57-60),
 // the forward from 18 taps on (18 taps 47-61 -> 40, 26 taps 91-111 -> 42, 40 taps 127-158 -> 45-47; at 16 taps the
 // tiled kernel's 35-45 is level with the 36-39 of two launches).  Tuning keys "swt_split_fwd" / "swt_split_inv" (environment
-// PDWT_SWT_SPLIT_FWD / _INV): the shortest filter that takes this path, 0 = never.
+// PDWT_SWT_SPLIT_FWD / _INV): the shortest filter that takes this path at full size, 0 = never, 100 + n = n taps at EVERY size.
 static std::atomic<int>& split_min(bool inverse) {
     static std::atomic<int> fwd{env_int("PDWT_SWT_SPLIT_FWD", 18)}, inv{env_int("PDWT_SWT_SPLIT_INV", 10)};
     return inverse ? inv : fwd;
 }
 int set_swt_split_min(int inverse, int taps) { return split_min(inverse != 0).exchange(taps < 0 ? 0 : taps); }
 
-bool swt2_split_supported(int hlen, int Nr, int Nc, int f, bool inverse) {
-    const int min_taps = split_min(inverse).load(std::memory_order_relaxed);
-    if (min_taps <= 0 || (hlen & 1) || hlen < 10 || hlen > kMaxTaps || hlen < min_taps) return false;
+bool swt2_split_supported(int hlen, int Nr, int Nc, int f, bool inverse, long long samples) {
+    int min_taps = split_min(inverse).load(std::memory_order_relaxed);
+    if (min_taps <= 0) return false;
+    if (Nr % f) {
+        min_taps = 10;  // rows the dilation does not divide: the alternative is three direct passes (one load per tap and output)
+    } else if (min_taps >= 100) {
+        min_taps -= 100;  // forced: the same threshold at every size (tests)
+    } else if (inverse) {
+        // small launches: two launches of one round each cost more than they save until the filter is long -- inverse levels of
+        // 256^2 / 512^2: 10 taps 13 | 17-18 us (tiled | split), 16 taps 16 | 21-22, 26 taps 33 | 26-27, 40 taps 31-44 | 22-35;
+        // 1024^2: 12 taps 24 | 23, 16 taps 28 | 25, 20 taps 35 | 28 (profiles/r03_swt_split_sweep.txt)
+        if (samples < (1LL << 20) && min_taps < 24) min_taps = 24;
+        else if (samples < (1LL << 22) && min_taps < 12) min_taps = 12;
+    }
+    if ((hlen & 1) || hlen < 10 || hlen > kMaxTaps || hlen < min_taps) return false;
     if ((Nc & 3) || f < 1 || f >= Nr || f >= Nc || Nc < 16) return false;
     if (f != 1 && f != 2 && (f & 3)) return false;
     return true;
@@ -145,7 +157,7 @@ hipError_t try_launch_swt1_split(const SwtPassArgs& a, bool inverse, hipStream_t
 
 // scratch: 2 * Nr * Nc * batch elements, 16-B aligned
 hipError_t launch_swt2_split(const Swt2DArgs& a, real_t* tmp, bool inverse, int batch, hipStream_t s) {
-    if (!swt2_split_supported(a.hlen, a.Nr, a.Nc, a.f, inverse) || !tmp) return hipErrorNotSupported;
+    if (!swt2_split_supported(a.hlen, a.Nr, a.Nc, a.f, inverse, (long long)batch * a.Nr * a.Nc) || !tmp) return hipErrorNotSupported;
     auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     if (!al16(tmp) || !al16(a.A) || !al16(a.H) || !al16(a.V) || !al16(a.D) || (a.bstride & 3)) return hipErrorNotSupported;
     if (!al16(inverse ? (const void*)a.out : (const void*)a.in)) return hipErrorNotSupported;

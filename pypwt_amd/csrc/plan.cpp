@@ -599,7 +599,7 @@ int fwd_level_2d(pdwt_plan* p, int l, bool run) {
     } else {
         const int f = 1 << (l - 1);
         const int Nr = p->info.Nr, Nc = p->info.Nc;
-        const bool split = swt2_split_supported(hlen, Nr, Nc, f, false) && ensure_tmp(p, 2LL * Nr * Nc * B) == PDWT_OK;
+        const bool split = swt2_split_supported(hlen, Nr, Nc, f, false, (long long)B * Nr * Nc) && ensure_tmp(p, 2LL * Nr * Nc * B) == PDWT_OK;
         if (split || Nr % f == 0) {
             Swt2DArgs a;
             a.in = src; a.A = dstA; a.H = H; a.V = V; a.D = D; a.out = nullptr;
@@ -675,7 +675,7 @@ int inv_level_2d(pdwt_plan* p, int l, bool run) {
     } else {
         const int f = 1 << (l - 1);
         const int Nr = p->info.Nr, Nc = p->info.Nc;
-        const bool split = swt2_split_supported(hlen, Nr, Nc, f, true) && ensure_tmp(p, 2LL * Nr * Nc * B) == PDWT_OK;
+        const bool split = swt2_split_supported(hlen, Nr, Nc, f, true, (long long)B * Nr * Nc) && ensure_tmp(p, 2LL * Nr * Nc * B) == PDWT_OK;
         if (split || Nr % f == 0) {
             Swt2DArgs a;
             a.in = nullptr;

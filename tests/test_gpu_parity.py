@@ -416,7 +416,7 @@ def test_swt_two_launch_levels(wname, shape, levels, batch):
     the path ran."""
     from pypwt_amd import BatchedWavelets, _lib
     lib = _lib.load()
-    prev = lib.pdwt_set_tuning(b"swt_split_fwd", 10), lib.pdwt_set_tuning(b"swt_split_inv", 10)
+    prev = lib.pdwt_set_tuning(b"swt_split_fwd", 110), lib.pdwt_set_tuning(b"swt_split_inv", 110)  # 10 taps, at every size
     try:
         x = np.stack([oracle.hash_input(shape, 140 + b, scale=255.0) for b in range(batch)])
         bw = BatchedWavelets(batch, shape[0], shape[1], wname, levels, do_swt=1, img=x)

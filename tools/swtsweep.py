@@ -21,9 +21,10 @@ def run(w, r, c, L, env):
 def main():
     r, c, L = (int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (2048, 2048, 4)
     print("# %dx%d, %d levels: per-level us (levels 1..L forward, L..1 inverse), tiled kernel | split kernels" % (r, c, L))
-    for w in ("db5", "db6", "db7", "sym8", "db9", "db10", "db11", "db12", "db13", "db14", "db15", "db16", "db17", "db18", "db19", "db20"):
+    names = sys.argv[4].split(",") if len(sys.argv) > 4 else ["db5", "db6", "db7", "sym8", "db9", "db10", "db11", "db12", "db13", "db14", "db15", "db16", "db17", "db18", "db19", "db20"]
+    for w in names:
         fo, io = run(w, r, c, L, {"PDWT_SWT_SPLIT_FWD": "0", "PDWT_SWT_SPLIT_INV": "0"})
-        fn, inn = run(w, r, c, L, {"PDWT_SWT_SPLIT_FWD": "10", "PDWT_SWT_SPLIT_INV": "10"})
+        fn, inn = run(w, r, c, L, {"PDWT_SWT_SPLIT_FWD": "110", "PDWT_SWT_SPLIT_INV": "110"})
         fmt = lambda v: " ".join("%6.1f" % x for x in v)
         print("%-5s fwd %s | %s   inv %s | %s   sum fwd %.0f | %.0f  inv %.0f | %.0f" % (w, fmt(fo), fmt(fn), fmt(io), fmt(inn), sum(fo), sum(fn), sum(io), sum(inn)), flush=True)
 
