@@ -490,7 +490,10 @@ def main():
         raise SystemExit("bench.py: rank %d has no image (--scaling strong with --batch %s over %d ranks)"
                          % (rank, args.batch, world))
 
-    plan = BatchedWavelets(B, Nr, Nc, wname, L, do_swt=swt, ndim=ndim, device=local_rank)
+    # PDWT_BENCH_SHARE_GPU=1 (tests on a one-GPU box, gloo backend): every rank on GPU 0 -- exercises the rank start-up, the
+    # barriers and the aggregation on real hardware; the figure it prints is NOT a multi-GPU measurement and says so
+    shared_gpu = world > 1 and os.environ.get("PDWT_BENCH_SHARE_GPU") == "1"
+    plan = BatchedWavelets(B, Nr, Nc, wname, L, do_swt=swt, ndim=ndim, device=0 if shared_gpu else local_rank)
     # deterministic synthetic input generated ON the device; every rank gets different images
     plan.fill_hash(20240 + 2, 255.0, index_offset=first_image * Nr * Nc)
 
@@ -617,6 +620,8 @@ def main():
         "roofline": roofline, "end_to_end": e2e, "kernels": kernels[:12],
     }
     if dist is not None:
+        if shared_gpu:
+            out["config"]["shared_gpu_test_run"] = "all ranks ran on GPU 0 (PDWT_BENCH_SHARE_GPU=1): not a multi-GPU measurement"
         out["config"]["multi_gpu_note"] = ("one process per GPU; barrier (%s) before t0 and after t1, value = all ranks' "
                                            "samples / max over ranks of (t1 - t0)" % backend)
         if dt * 1e3 < 20.0:

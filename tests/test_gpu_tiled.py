@@ -102,3 +102,26 @@ def test_import_order_is_checked():
             "except RuntimeError as e:\n    print('REFUSED' if 'import torch before' in str(e) else e)\n" % ROOT)
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert "REFUSED" in out.stdout, out.stdout + out.stderr
+
+
+@pytest.mark.parametrize("config,extra", [("cfg1", []), ("cfg2", ["--batch", "2", "--scaling", "strong"])])
+def test_bench_two_ranks_on_the_gpu_box(config, extra):
+    """`python bench.py --gpus 2` on real hardware as far as a one-GPU box allows: the parent starts two ranks, torch is
+    imported before libpypwt_amd.so in each, both run their shard on GPU 0 (PDWT_BENCH_SHARE_GPU=1) behind gloo barriers,
+    rank 0 prints ONE JSON line with the aggregate over both ranks.  (RCCL itself runs in bench.py --force-dist with one
+    rank: profiles/r03z_bench_cfg2_nccl_world1.json.)"""
+    import json
+    env = dict(os.environ, PDWT_BENCH_SHARE_GPU="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--config", config,
+                        "--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--no-extras", "--preheat-ms", "20"] + extra,
+                       capture_output=True, text=True, env=env, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 5 and out["value"] > 0
+    assert "shared_gpu_test_run" in out["config"] and "multi_gpu_note" in out["config"]
+    assert out["config"]["images_per_step"] == 2 and out["scaling"] == ("strong" if extra else "weak")
+    assert "cpu_baseline" not in out or out["cpu_baseline"] is None or isinstance(out["cpu_baseline"], dict)
