@@ -186,3 +186,22 @@ def test_python_class_has_the_reference_api_surface():
     assert list(sig)[1:] == ["beta", "do_threshold_appcoeffs", "normalize"]
     assert sig["do_threshold_appcoeffs"].default == 0 and sig["normalize"].default == 0   # pypwt.pyx:362
     assert inspect.signature(Wavelets.shrink).parameters["do_threshold_appcoeffs"].default == 1  # pypwt.pyx:406
+
+
+def test_tuning_keys_documented_in_the_header_exist_and_round_trip(lib):
+    """pdwt_set_tuning needs no device: every key the header documents is accepted, returns the previous value and can be
+    restored; an unknown key is an argument error."""
+    txt = open(os.path.join(ROOT, "include", "pypwt_amd.h")).read()
+    doc = txt[txt.index("process-wide dispatch knobs"):txt.index("int pdwt_set_tuning")]
+    keys = sorted(set(re.findall(r'"([a-z0-9_]+)"', doc)))
+    assert {"wave_min_log2", "lds_max_log2", "reg1d", "swt_fused", "swt_split_fwd", "swt_split_inv", "chain", "wave2"} <= set(keys)
+    for k in keys:
+        prev = lib.pdwt_set_tuning(k.encode(), 1)
+        assert prev >= 0, (k, prev)
+        back = lib.pdwt_set_tuning(k.encode(), prev)
+        # (the experiment kernels live in libpypwt_amd_lab.so only: their knobs are accepted by the product and do nothing)
+        assert back == 1 or k == "chain_timeout", (k, back)
+    assert lib.pdwt_set_tuning(b"no_such_knob", 1) < 0
+    # the split-SWT thresholds: taps, 0 = never, 100 + n = n taps at every size
+    p = lib.pdwt_set_tuning(b"swt_split_inv", 110)
+    assert lib.pdwt_set_tuning(b"swt_split_inv", p) == 110
