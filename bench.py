@@ -179,7 +179,10 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=None,
                     help="images per GPU per step (weak scaling, default 1; cfg5: 128) or in total (--scaling strong)")
-    ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
+    ap.add_argument("--config", default=None, choices=sorted(CONFIGS),
+                    help="default: cfg2 (one 4096^2 image per step) on one GPU; cfg5 (BASELINE config 5's per-GPU shard, 128 "
+                         "images of 4096^2 per GPU and step) with more than one rank, where a 70-us step is too short an "
+                         "interval to compare ranks on")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: --batch images per GPU; strong: --batch images in total, split over the ranks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -190,6 +193,9 @@ def parse_args(argv=None):
                          "the GPU needs tens of ms to ramp its clocks, and W = 10 steps last under 1 ms")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for the barrier / max-over-ranks (nccl = RCCL)")
+    ap.add_argument("--single-process", action="store_true",
+                    help="ONE process drives all --gpus devices through pypwt_amd.ShardedBatch (contiguous image blocks, "
+                         "one plan + stream + host thread per GPU, no collective, no torch) instead of one process per GPU")
     ap.add_argument("--dry-run", action="store_true",
                     help="CPU/gloo plumbing test: no GPU work, exercises rendezvous + aggregation only")
     ap.add_argument("--force-dist", action="store_true",
@@ -277,8 +283,19 @@ def shard_images(total, world, rank):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def resolve_config(args, world):
+    """--config when given; else the headline one-image configuration on one GPU and BASELINE config 5's per-GPU shard
+    (the same images, 128 per GPU and step) when the batch is sharded over several: with the driver's --steps 20 a
+    one-image step gives a 1.4 ms interval, of which the rank-to-rank start skew behind a barrier is a visible share."""
+    if args.config is None:
+        args.config = "cfg5" if world > 1 else "cfg2"
+        args.config_defaulted = True
+    return args.config
+
+
 def rank_batch(args, world, rank):
     """(images of this rank per step, first image index, total images per step)."""
+    resolve_config(args, world)
     b = args.batch if args.batch is not None else DEFAULT_BATCH.get(args.config, 1)
     if args.scaling == "strong":
         lo, hi = shard_images(b, world, rank)
@@ -440,6 +457,90 @@ def beyond_mall(cfg, device, steps):
             "frac_of_hbm_peak": bytes_step / dt / 1e9 / HBM_PEAK_GBPS}
 
 
+def kernel_profile(plan, step, cfg, config_name, B, steps):
+    """Per-launch shares of one step (HIP events on the plan's stream), the dominant kernel re-timed alone, its
+    roofline and the copy ceiling measured beside it.  Returns (kernels, roofline, names of one step's launches)."""
+    Nr, Nc, wname, L, swt, ndim, beta, desc = cfg
+    # ---- per-kernel durations from HIP events on the plan's stream (second pass, same steps)
+    plan.enable_kernel_timing(True)
+    plan.reset_kernel_times()
+    for _ in range(steps):
+        step()
+    times = plan.kernel_times(cap=64 * steps + 64)
+    plan.enable_kernel_timing(False)
+    plan.reset_kernel_times()
+    per_step = len(times) // steps
+    step_names = [n for n, _ in times[:per_step]]
+    labels = label_step_kernels(step_names, L)
+    agg = {}
+    for i, (name, ms) in enumerate(times):
+        agg.setdefault(labels[i % per_step], []).append(ms)
+    kernels = []
+    for label, v in agg.items():
+        avg_ms = sum(v) / len(v)
+        abytes = kernel_algorithmic_bytes(label, cfg, B)
+        kernels.append({"kernel": label, "avg_us": avg_ms * 1e3, "algorithmic_bytes": abytes,
+                        "GBps": abytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0})
+    kernels.sort(key=lambda k: -k["avg_us"])
+    # The per-launch events above cost ~2.5 us of stream time each (the in-step durations sum to more than the step)
+    # and the first launch behind an event absorbs its latency, so they RANK launches of similar length unreliably
+    # (round 3 named the second-longest kernel).  The three longest candidates are therefore timed again on their
+    # own -- `steps` launches of that level back to back between TWO HIP events on the plan's stream
+    # (pdwt_time_level) -- and the longest of those is the dominant kernel.  That figure agrees with
+    # rocprofv3 --kernel-trace (profiles/) and is the one the roofline uses.
+    plan.forward()  # valid data in every buffer the levels read
+    for k in kernels[:3]:
+        lvl = level_of_kernel(k["kernel"], L)
+        if lvl is not None:
+            k["isolated_us"] = plan.time_level(lvl[0], inverse=lvl[1], reps=max(steps, 20))
+    plan.inverse()
+    dom = max(kernels[:3], key=lambda k: k.get("isolated_us", k["avg_us"]))
+    dom_us = dom.get("isolated_us", dom["avg_us"])
+    dom_gbps = dom["algorithmic_bytes"] / (dom_us * 1e-6) / 1e9 if dom_us > 0 else 0.0
+    roofline = {"bound": "hbm", "achieved": dom_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": dom_gbps / HBM_PEAK_GBPS, "traffic": None, "kernel": dom["kernel"],
+                "avg_us": dom_us, "avg_us_in_step_with_event_overhead": dom["avg_us"],
+                "algorithmic_bytes_per_launch": dom["algorithmic_bytes"]}
+    # The measured ceiling next to the spec peak: a plain 16-B grid-stride copy that moves the dominant launch's
+    # bytes (half read, half written) out of this plan's own buffers, in this run, in the same cache state
+    # (pdwt_time_copy).  The guide's figure for the kernel shape is 6.29 TB/s = 0.79 of the 8 TB/s peak.
+    try:
+        copy_elems = int(min(dom["algorithmic_bytes"] / 8, B * Nr * Nc))  # fp32: 8 bytes moved per value copied
+        copy_us = plan.time_copy(copy_elems, reps=max(steps, 20))
+        copy_gbps = copy_elems * 8.0 / (copy_us * 1e-6) / 1e9
+        roofline["copy_ceiling_GBps"] = copy_gbps
+        roofline["copy_ceiling_us"] = copy_us
+        roofline["copy_ceiling_bytes"] = copy_elems * 8.0
+        roofline["frac_of_copy_ceiling"] = dom_gbps / copy_gbps if copy_gbps > 0 else None
+        # ... and the same for EVERY launch of the step: what the step would take if each launch were a flat copy of its
+        # own algorithmic bytes (small launches are bounded by the launch itself, which this includes)
+        floor = 0.0
+        for k in kernels:
+            n = int(min(max(k["algorithmic_bytes"] / 8, 4), B * Nr * Nc))
+            k["copy_us"] = plan.time_copy(n, reps=max(steps, 20)) if k["algorithmic_bytes"] > 0 else 0.0
+            floor += k["copy_us"]
+        roofline["step_copy_floor_us"] = floor
+    except Exception as e:  # an optional diagnostic must not break the line
+        roofline["copy_ceiling_error"] = repr(e)
+    # HBM bytes per launch of that kernel from the rocprofv3 PMC passes of this same command
+    # (FETCH_SIZE x2 + WRITE_SIZE, collected separately; tools/prof.sh + tools/summarize_pmc.py).
+    # Counters cannot be read from inside the process, so the committed measurement is quoted.
+    for tag in ("r04", "r03", "r02", "r01"):
+        tpath = os.path.join(ROOT, "profiles", "%s_traffic_%s.json" % (tag, config_name))
+        if B == 1 and os.path.exists(tpath):
+            try:
+                # the profile labels launches by kernel family: "+soft" (a deferred threshold folded into the SWT
+                # inverse) is a property of the plan state, not of the kernel
+                t = json.load(open(tpath))["per_launch"].get(dom["kernel"].replace("+soft", ""))
+                if t:
+                    roofline["traffic"] = t["hbm_bytes"]
+                    roofline["traffic_source"] = "profiles/" + os.path.basename(tpath)
+                    break
+            except Exception:
+                pass
+    return kernels, roofline, step_names
+
+
 def dry_run(args, rank, world, dist, backend, out_stream=None):
     """No GPU: sleep-based steps so the launch / barrier / max-over-ranks / JSON path is testable
     with gloo on CPU."""
@@ -453,7 +554,7 @@ def dry_run(args, rank, world, dist, backend, out_stream=None):
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
                           "vs_baseline": None, "dtype": "f32", "data": "none (dry run)",
-                          "config": {"workload": "dry-run", "shard_rank0": [first, first + B],
+                          "config": {"workload": "dry-run", "config": args.config, "shard_rank0": [first, first + B],
                                      "images_per_step": total, "timed_region_ms": dt * 1e3}})])
 
 
@@ -467,8 +568,80 @@ def claim_stdout():
     return os.fdopen(saved, "w")
 
 
+def single_process_main(args, out_stream):
+    """--single-process: the product's own multi-GPU entry point (pypwt_amd.ShardedBatch) under the same contract -- W
+    warm-up steps, exactly K timed steps between two synchronisations of EVERY device, one JSON line.  No torch, no
+    process group: the shards exchange nothing."""
+    from pypwt_amd import ShardedBatch
+    n = args.gpus
+    resolve_config(args, n)
+    cfg = CONFIGS[args.config]
+    Nr, Nc, wname, L, swt, ndim, beta, desc = cfg
+    b = args.batch if args.batch is not None else DEFAULT_BATCH.get(args.config, 1)
+    total = b if args.scaling == "strong" else b * n
+    shared_gpu = os.environ.get("PDWT_BENCH_SHARE_GPU") == "1"
+    S = ShardedBatch(total, Nr, Nc, wname, L, devices=[0] * n if shared_gpu else list(range(n)), do_swt=swt, ndim=ndim)
+    S.fill_hash(20240 + 2, 255.0)
+
+    def step():
+        S.forward()
+        if beta is not None:
+            S.soft_threshold(beta)
+        S.inverse()
+
+    for _ in range(args.warmup):
+        step()
+    cold_s = timed_steps(step, S.synchronize, args.steps)
+    t_pre = time.perf_counter()
+    while (time.perf_counter() - t_pre) * 1e3 < args.preheat_ms:
+        for _ in range(20):
+            step()
+        S.synchronize()
+    for _ in range(args.warmup):
+        step()
+    step_s = timed_steps(step, S.synchronize, args.steps)
+    samples = total * Nr * Nc
+    p0 = S.plans[0]
+
+    def step0():
+        p0.forward()
+        if beta is not None:
+            p0.soft_threshold(beta)
+        p0.inverse()
+
+    kernels, roofline, step_names = kernel_profile(p0, step0, cfg, args.config, p0.batch, args.steps)
+    thr_separate = any(nm.startswith("soft_threshold") for nm in step_names)
+    bps = algorithmic_bytes_per_sample(cfg, threshold_separate=thr_separate)
+    per_gpu_bytes = bps * max(hi - lo for _, lo, hi in S.shards) * Nr * Nc
+    out = {
+        "metric": "Msamples/s, 4096x4096 fp32 db4 L4 2D DWT fwd+inv" if args.config in ("cfg2", "cfg5") else "Msamples/s, " + desc,
+        "value": samples / step_s / 1e6, "unit": "Msamples/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": step_s * 1e3, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic (on-device index hash, 0..255)",
+        "config": {"workload": "%s: %s" % (args.config, desc), "images_per_step": total,
+                   "shards": [[d, lo, hi] for d, lo, hi in S.shards], "wavelet": wname, "levels": L, "shape": [Nr, Nc],
+                   "parallelism": "image-sharded x%d, ONE process (pypwt_amd.ShardedBatch: one plan + stream + host thread "
+                                  "per GPU), no collectives" % n,
+                   "preheat_ms": args.preheat_ms, "timed_region_ms": step_s * args.steps * 1e3},
+        "roofline": roofline,
+        "end_to_end": {"algorithmic_bytes_per_sample": bps, "GBps_per_gpu": per_gpu_bytes / step_s / 1e9,
+                       "frac_of_hbm_peak": per_gpu_bytes / step_s / 1e9 / HBM_PEAK_GBPS,
+                       "cold_ms_per_step": cold_s * 1e3},
+        "kernels": kernels[:12],
+    }
+    if shared_gpu:
+        out["config"]["shared_gpu_test_run"] = "all shards ran on GPU 0 (PDWT_BENCH_SHARE_GPU=1): not a multi-GPU measurement"
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(cfg)
+    print(json.dumps(out), file=out_stream, flush=True)
+    S.cleanup()
+    return 0
+
+
 def main():
     args = parse_args()
+    if args.single_process and not args.dry_run:
+        sys.exit(single_process_main(args, claim_stdout()))
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(self_launch(args))  # before any GPU / torch activity in this process
     out_stream = claim_stdout()
@@ -476,6 +649,7 @@ def main():
     if args.gpus != world and rank == 0:
         print("warning: --gpus %d but WORLD_SIZE %d; running %d rank(s) and reporting n_gpus = %d"
               % (args.gpus, world, world, world), file=sys.stderr)
+    resolve_config(args, world)
     if args.dry_run:
         dry_run(args, rank, world, dist, backend, out_stream)
         if dist is not None:
@@ -539,59 +713,7 @@ def main():
     samples_per_step = total_images * Nr * Nc
     value = samples_per_step / step_s / 1e6
 
-    # ---- per-kernel durations from HIP events on the plan's stream (second pass, same steps)
-    plan.enable_kernel_timing(True)
-    plan.reset_kernel_times()
-    for _ in range(args.steps):
-        step()
-    times = plan.kernel_times(cap=64 * args.steps + 64)
-    plan.enable_kernel_timing(False)
-    plan.reset_kernel_times()
-    per_step = len(times) // args.steps
-    step_names = [n for n, _ in times[:per_step]]
-    labels = label_step_kernels(step_names, L)
-    agg = {}
-    for i, (name, ms) in enumerate(times):
-        agg.setdefault(labels[i % per_step], []).append(ms)
-    kernels = []
-    for label, v in agg.items():
-        avg_ms = sum(v) / len(v)
-        abytes = kernel_algorithmic_bytes(label, cfg, B)
-        kernels.append({"kernel": label, "avg_us": avg_ms * 1e3, "algorithmic_bytes": abytes,
-                        "GBps": abytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0})
-    kernels.sort(key=lambda k: -k["avg_us"])
-    dom = kernels[0]
-    # The per-launch events above cost ~2.5 us of stream time each (sum of the in-step durations exceeds
-    # the step), so the dominant kernel is timed again on its own: `steps` launches of that level back
-    # to back between TWO HIP events on the plan's stream (pdwt_time_level).  That figure agrees with
-    # rocprofv3 --kernel-trace (profiles/) and is the one the roofline uses.
-    dom_us = dom["avg_us"]
-    lvl = level_of_kernel(dom["kernel"], L)
-    if lvl is not None:
-        plan.forward()  # valid data in every buffer the level reads
-        dom_us = plan.time_level(lvl[0], inverse=lvl[1], reps=max(args.steps, 20))
-        plan.inverse()
-    dom_gbps = dom["algorithmic_bytes"] / (dom_us * 1e-6) / 1e9 if dom_us > 0 else 0.0
-    roofline = {"bound": "hbm", "achieved": dom_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": dom_gbps / HBM_PEAK_GBPS, "traffic": None, "kernel": dom["kernel"],
-                "avg_us": dom_us, "avg_us_in_step_with_event_overhead": dom["avg_us"],
-                "algorithmic_bytes_per_launch": dom["algorithmic_bytes"]}
-    # HBM bytes per launch of that kernel from the rocprofv3 PMC passes of this same command
-    # (FETCH_SIZE x2 + WRITE_SIZE, collected separately; tools/prof.sh + tools/summarize_pmc.py).
-    # Counters cannot be read from inside the process, so the committed measurement is quoted.
-    for tag in ("r03", "r02", "r01"):
-        tpath = os.path.join(ROOT, "profiles", "%s_traffic_%s.json" % (tag, args.config))
-        if B == 1 and os.path.exists(tpath):
-            try:
-                # the profile labels launches by kernel family: "+soft" (a deferred threshold folded into the SWT
-                # inverse) is a property of the plan state, not of the kernel
-                t = json.load(open(tpath))["per_launch"].get(dom["kernel"].replace("+soft", ""))
-                if t:
-                    roofline["traffic"] = t["hbm_bytes"]
-                    roofline["traffic_source"] = "profiles/" + os.path.basename(tpath)
-                    break
-            except Exception:
-                pass
+    kernels, roofline, step_names = kernel_profile(plan, step, cfg, args.config, B, args.steps)
     # the soft threshold costs bytes only when it ran as its own sweep (a `soft_threshold` launch in the step)
     thr_separate = any(n.startswith("soft_threshold") for n in step_names)
     bps = algorithmic_bytes_per_sample(cfg, threshold_separate=thr_separate)
@@ -602,6 +724,13 @@ def main():
            "cold_ms_per_step": cold_s * 1e3, "cold_Msamples_s": samples_per_step / cold_s / 1e6,
            "per_level_streaming_bytes_per_sample": per_level_streaming_bytes_per_sample(cfg, thr_separate),
            "sum_kernel_us": sum(k["avg_us"] for k in kernels)}
+    if roofline.get("copy_ceiling_GBps"):
+        e2e["frac_of_copy_ceiling"] = e2e["GBps_per_gpu"] / roofline["copy_ceiling_GBps"]
+    if roofline.get("step_copy_floor_us"):
+        # every launch of the step replaced by a flat copy of its algorithmic bytes, timed in this run on these buffers:
+        # the step cannot be expected below this with one launch per level (group)
+        e2e["copy_floor_us_per_step"] = roofline["step_copy_floor_us"]
+        e2e["copy_floor_over_step"] = roofline["step_copy_floor_us"] * 1e-6 / step_s
     if swt and beta is not None:
         e2e["threshold"] = ("separate sweep" if thr_separate else
                             "folded into the inverse's loads (no launch, no bytes); as a separate sweep the step "

@@ -159,10 +159,13 @@ int pdwt_set_filters_inverse(pdwt_handle h, const pdwt_real* filter1, const pdwt
 int pdwt_get_info(pdwt_handle h, pdwt_info* info, int* do_separable, int* do_cycle_spinning, int* state,
                   int* batch);
 int pdwt_print_info(pdwt_handle h);                       /* print_informations, wt.cu:511-550 */
-/* NEW: destroyed plans hand their device memory and stream to a small process-wide pool (at most PDWT_POOL_MB, default
- * 1024 MiB, and 8 streams) that new plans draw from: creating + destroying a plan costs 3.4 ms of hipMalloc / hipFree /
- * stream calls otherwise, twenty times the transform of a 512^2 image (the reference's tests and tutorials build one
- * Wavelets object per image).  pdwt_trim_pool() releases everything the pool holds; returns the number of blocks freed. */
+/* NEW: destroyed plans hand their device memory and stream to a small process-wide pool that new plans draw from:
+ * creating + destroying a plan costs 3.4 ms of hipMalloc / hipFree / stream calls otherwise, twenty times the transform of
+ * a 512^2 image (the reference's tests and tutorials build one Wavelets object per image).  Only small blocks are kept: at
+ * most PDWT_POOL_BLOCK_MB (default 64 MiB) each and PDWT_POOL_MB (default 256 MiB) in total, 8 streams -- a large plan's
+ * memory goes back to the driver when it is destroyed.  The library releases the pool by itself when one of its own
+ * allocations fails; pdwt_trim_pool() releases everything the pool holds (call it before another allocator in the process
+ * needs the memory); returns the number of blocks freed. */
 int pdwt_trim_pool(void);
 /* NEW: the plan's launch lists as text, one line per direction: "fwd: LEVEL[1] LEVEL[2] PYR2[3-4]" (kind[levels]); what the
  * reference decides with if/else at every call (wt.cu:236-305) is decided once per plan here (plan.cpp: build_schedule).
@@ -184,6 +187,7 @@ int pdwt_synchronize(pdwt_handle h);
 int pdwt_set_stream(pdwt_handle h, void* hip_stream); /* borrow a caller stream (e.g. torch's) */
 void* pdwt_get_stream(pdwt_handle h);
 int pdwt_device(pdwt_handle h);
+int pdwt_device_count(void); /* HIP devices visible to the process (0: none -- every pdwt_create will fail, there is no CPU path) */
 /* Ordering a DEVICE-memory source with the code that produced it (the reference runs everything on the legacy
  * default stream, so its cudaMemcpy DtoD in wt.cu:117-126,425-466 is ordered for free; a plan here owns a
  * non-blocking stream).  pdwt_set_image / pdwt_set_coeff with mem_is_on_device = 1 and pdwt_create with
@@ -194,8 +198,12 @@ int pdwt_device(pdwt_handle h);
  *                                recorded on s and waited for on the plan's stream, the host does not block;
  *   pdwt_sync_producer(dev, s, whole_device)   host-blocking form for use before a plan exists:
  *                                hipStreamSynchronize(s), or hipDeviceSynchronize() when whole_device != 0
- *                                (the producer's stream is unknown: a __cuda_array_interface__ without "stream"). */
+ *                                (the producer's stream is unknown: a __cuda_array_interface__ without "stream").
+ *   pdwt_device_of_pointer(p)    the device that owns a device allocation (hipPointerGetAttributes), so that a source
+ *                                with an unknown producer stream is ordered by synchronising ITS device, which need
+ *                                not be the current one or the plan's; negative status for host / unknown addresses. */
 int pdwt_wait_for_stream(pdwt_handle h, void* producer_stream);
+int pdwt_device_of_pointer(const void* device_ptr);
 int pdwt_sync_producer(int device_id, void* producer_stream, int whole_device);
 /* fill the plan image on the device with the deterministic test input
  * x[i] = (lowbias32((i + index_offset) ^ seed) >> 8) * 2^-24 * scale (tests/golden, oracle, bench) */
@@ -212,6 +220,11 @@ int pdwt_reset_kernel_times(pdwt_handle h);
  * milliseconds per repetition.  The data the level reads is whatever the buffers hold (run a
  * forward first); nothing else of the plan's state changes. */
 int pdwt_time_level(pdwt_handle h, int level, int inverse, int reps, float* ms_per_launch);
+/* the measured ceiling beside it: a plain 16-B-per-lane grid-stride copy of `elems` values (clamped to the plan's image,
+ * rounded down to a multiple of 4) from the plan's image buffer into scratch, `reps` launches back to back between two
+ * HIP events on the plan's stream; mean milliseconds per launch.  It moves 2 * elems * sizeof(pdwt_real) bytes: a level
+ * kernel of the same footprint cannot be expected to run faster than this on the same GPU in the same cache state. */
+int pdwt_time_copy(pdwt_handle h, long long elems, int reps, float* ms_per_launch);
 /* NEW: process-wide dispatch knobs (tests and A/B measurements; no counterpart in the reference, whose
  * kernel choice is fixed at compile time, pdwt/src/wt.cu:236-305).  Returns the previous value, or
  * PDWT_ERR_ARG for an unknown key.  Keys:

@@ -7,6 +7,7 @@ The compute path is the hand-written HIP library pypwt_amd/libpypwt_amd.so (C AB
 include/pypwt_amd.h, built by `python -m pypwt_amd.build`; `Wavelets64` binds the fp64 build
 libpypwt_amd_f64.so).  There is no CPU fallback.
 """
+from .sharded import ShardedBatch, partition_images  # noqa: F401
 from .wavelets import BatchedWavelets, DeviceArray, Wavelets, Wavelets64  # noqa: F401
 
 

@@ -88,13 +88,16 @@ def signatures(real=C.c_float):
         "pdwt_set_stream": (C.c_int, [handle_t, C.c_void_p]),
         "pdwt_get_stream": (C.c_void_p, [handle_t]),
         "pdwt_device": (C.c_int, [handle_t]),
+        "pdwt_device_count": (C.c_int, []),
         "pdwt_wait_for_stream": (C.c_int, [handle_t, C.c_void_p]),
         "pdwt_sync_producer": (C.c_int, [C.c_int, C.c_void_p, C.c_int]),
+        "pdwt_device_of_pointer": (C.c_int, [C.c_void_p]),
         "pdwt_fill_image_hash": (C.c_int, [handle_t, C.c_uint32, real, C.c_longlong]),
         "pdwt_enable_kernel_timing": (C.c_int, [handle_t, C.c_int]),
         "pdwt_kernel_times": (C.c_int, [handle_t, f32p, C.c_void_p, C.c_int]),
         "pdwt_reset_kernel_times": (C.c_int, [handle_t]),
         "pdwt_time_level": (C.c_int, [handle_t, C.c_int, C.c_int, C.c_int, f32p]),
+        "pdwt_time_copy": (C.c_int, [handle_t, C.c_longlong, C.c_int, f32p]),
         "pdwt_set_tuning": (C.c_int, [C.c_char_p, C.c_int]),
     }
 

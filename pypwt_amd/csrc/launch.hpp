@@ -59,7 +59,7 @@ hipError_t launch_dwt2_fwd_chain(const real_t* in, real_t* const* det, real_t* c
                                  const FilterBank& fb, int batch, unsigned* flags, unsigned epoch, hipStream_t s);
 hipError_t launch_dwt2_inv_chain(real_t* out, real_t* const* det, real_t* const* app, int Nr, int Nc, int K, int hlen,
                                  const FilterBank& fb, int batch, unsigned* flags, unsigned epoch, hipStream_t s);
-int set_chain_enabled(int value);  // 0 never, 1 where measured faster (default), 2 wherever supported (tests), 3 = 2 + batches too
+int set_chain_enabled(int value);  // 0 never (the default: opt-in, and the product build stubs the chain kernels out), 1 one cache-resident image + batch inverses, 2 wherever supported (tests), 3 = 2 + batch forwards too
 int get_chain_enabled();
 int set_chain_timeout(int ticks);  // s_memrealtime ticks (100 MHz) a chained tile waits for a producer before computing it itself
 // three consecutive 2D levels in one launch, small images (launch_dwt2_pyr3.hip): det[3 k + b] = band b (H, V, D) of the
@@ -109,6 +109,7 @@ hipError_t launch_group_soft(real_t* d0, real_t* d1, real_t* d2, real_t* ap, lon
 hipError_t launch_axpy(real_t* dst, const real_t* src, long long n, real_t alpha, hipStream_t s);
 hipError_t launch_norms(const real_t* p, long long n, double* out2, hipStream_t s);
 hipError_t launch_circshift(const real_t* in, real_t* out, int batch, int Nr, int Nc, int sr, int sc, hipStream_t s);
+hipError_t launch_copy(const real_t* src, real_t* dst, long long n, hipStream_t s);  // 16-B grid-stride copy (n % 4 == 0)
 hipError_t launch_fill_hash(real_t* x, long long n, uint32_t seed, real_t scale, long long index_offset,
                             hipStream_t s);
 

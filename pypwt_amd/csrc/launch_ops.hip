@@ -59,4 +59,12 @@ hipError_t launch_fill_hash(real_t* x, long long n, uint32_t seed, real_t scale,
     return hipGetLastError();
 }
 
+hipError_t launch_copy(const real_t* src, real_t* dst, long long n, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    const long long n4 = n / 4;
+    hipLaunchKernelGGL(copy_kernel, dim3(stream_grid(n4, 256)), dim3(256), 0, s, reinterpret_cast<const real4_t*>(src),
+                       reinterpret_cast<real4_t*>(dst), n4);
+    return hipGetLastError();
+}
+
 }  // namespace pdwt

@@ -141,4 +141,11 @@ __global__ void __launch_bounds__(256) fill_hash_kernel(real_t* __restrict__ x, 
     }
 }
 
+// plain 16-B grid-stride copy: the measured ceiling a streaming kernel of the same footprint is compared with
+// (pdwt_time_copy; MI355X_MICROARCH.md quotes 6.29 TB/s for this kernel shape on buffers far beyond the Infinity Cache)
+__global__ void __launch_bounds__(256) copy_kernel(const real4_t* __restrict__ a, real4_t* __restrict__ b, long long n4) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) b[i] = a[i];
+}
+
 }  // namespace pdwt

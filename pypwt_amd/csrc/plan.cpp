@@ -78,20 +78,42 @@ struct DeviceGuard {
 // ---------------------------------------------------------------- device-memory / stream pool
 // The reference's users often build one Wavelets object per image (its tests and tutorials do); hipMalloc + hipFree +
 // hipStreamCreate/Destroy then cost 3.4 ms per object (tools/createtime.py) -- twenty times the transform of a 512^2
-// image.  Destroyed plans therefore hand their device blocks and their stream to a small process-wide pool (at most
-// PDWT_POOL_MB, default 1024 MiB, of cached memory and 8 streams; a plan has been synchronised before it gets here) and
-// new plans take a block of at least their size and at most 1.25x of it from there.  pdwt_trim_pool() releases everything.
+// image.  Destroyed plans therefore hand their device blocks and their stream to a small process-wide pool and new plans
+// take a block of at least their size and at most 1.25x of it from there.  Only SMALL blocks are kept -- at most
+// PDWT_POOL_BLOCK_MB (default 64 MiB: the arena of a 2048^2 plan is 37 MiB) each, PDWT_POOL_MB (default 256 MiB) and 64
+// blocks in total, 8 streams; a plan has been synchronised before it gets here: the 3.4 ms matter next to a small
+// transform only, and the arena of a large plan must go back to the driver when the plan is destroyed (another
+// allocator in the process -- torch, the caller's own hipMalloc -- never sees this pool).  Every hipMalloc of the
+// library goes through device_malloc(), which releases the pool and retries once when the driver is out of memory.
+// pdwt_trim_pool() releases everything.
 struct DevicePool {
     struct Block { int dev; size_t bytes; void* p; };
     std::mutex m;
     std::vector<Block> blocks;
     std::vector<std::pair<int, hipStream_t>> streams;
     size_t cached = 0;
-    size_t limit = [] { const char* e = getenv("PDWT_POOL_MB"); return (size_t)(e ? atoll(e) : 1024) << 20; }();
+    size_t limit = [] { const char* e = getenv("PDWT_POOL_MB"); return (size_t)(e ? atoll(e) : 256) << 20; }();
+    size_t block_limit = [] { const char* e = getenv("PDWT_POOL_BLOCK_MB"); return (size_t)(e ? atoll(e) : 64) << 20; }();
 };
 DevicePool& device_pool() {
     static DevicePool* p = new DevicePool();  // intentionally leaked: no HIP calls from static destructors
     return *p;
+}
+// hipMalloc for every allocation of the library: out of memory -> give the cached blocks back and try once more
+hipError_t device_malloc(void** out, size_t bytes) {
+    hipError_t e = hipMalloc(out, bytes);
+    if (e == hipSuccess) return e;
+    (void)hipGetLastError();
+    DevicePool& P = device_pool();
+    std::vector<DevicePool::Block> drop;
+    {
+        std::lock_guard<std::mutex> g(P.m);
+        drop.swap(P.blocks);
+        P.cached = 0;
+    }
+    if (drop.empty()) return e;
+    for (auto& b : drop) (void)hipFree(b.p);
+    return hipMalloc(out, bytes);
 }
 hipError_t pool_alloc(int dev, void** out, size_t bytes, size_t* got) {
     DevicePool& P = device_pool();
@@ -113,26 +135,14 @@ hipError_t pool_alloc(int dev, void** out, size_t bytes, size_t* got) {
         }
     }
     *got = bytes;
-    hipError_t e = hipMalloc(out, bytes);
-    if (e != hipSuccess) {  // out of memory: give the cached blocks back and try once more
-        (void)hipGetLastError();
-        std::vector<DevicePool::Block> drop;
-        {
-            std::lock_guard<std::mutex> g(P.m);
-            drop.swap(P.blocks);
-            P.cached = 0;
-        }
-        for (auto& b : drop) (void)hipFree(b.p);
-        e = hipMalloc(out, bytes);
-    }
-    return e;
+    return device_malloc(out, bytes);
 }
 void pool_free(int dev, void* p, size_t bytes) {
     if (!p) return;
     DevicePool& P = device_pool();
     {
         std::lock_guard<std::mutex> g(P.m);
-        if (bytes > 0 && P.cached + bytes <= P.limit && P.blocks.size() < 64) {
+        if (bytes > 0 && bytes <= P.block_limit && P.cached + bytes <= P.limit && P.blocks.size() < 64) {
             P.blocks.push_back({dev, bytes, p});
             P.cached += bytes;
             return;
@@ -205,7 +215,7 @@ int ensure_tmp(pdwt_plan* p, long long elems) {
         p->tmp = nullptr;
         p->tmp_elems = 0;
     }
-    HIP_TRY(hipMalloc((void**)&p->tmp, (size_t)elems * sizeof(real_t)));
+    HIP_TRY(device_malloc((void**)&p->tmp, (size_t)elems * sizeof(real_t)));
     p->tmp_elems = elems;
     return PDWT_OK;
 }
@@ -253,8 +263,7 @@ int build_layout(pdwt_plan* p) {
     HIP_TRY(pool_alloc(p->device, (void**)&p->arena, (size_t)off * sizeof(real_t), &p->arena_bytes));
     HIP_TRY(hipMemsetAsync(p->arena, 0, (size_t)off * sizeof(real_t), p->stream));
     {
-        size_t got = 0;
-        HIP_TRY(pool_alloc(p->device, (void**)&p->d_red, 256, &got));  // two fp64 accumulators
+        HIP_TRY(pool_alloc(p->device, (void**)&p->d_red, 256, &p->d_red_bytes));  // two fp64 accumulators
     }
     return PDWT_OK;
 }
@@ -281,7 +290,7 @@ int upload_builtin_f2d(pdwt_plan* p) {
                 HH[i * n + j] = fhi[d][i] * fhi[d][j];
             }
     }
-    if (!p->d_f2d) HIP_TRY(hipMalloc((void**)&p->d_f2d, (size_t)8 * kMaxTaps * kMaxTaps * sizeof(real_t)));
+    if (!p->d_f2d) HIP_TRY(device_malloc((void**)&p->d_f2d, (size_t)8 * kMaxTaps * kMaxTaps * sizeof(real_t)));
     HIP_TRY(hipMemcpyAsync(p->d_f2d, h.data(), h.size() * sizeof(real_t), hipMemcpyHostToDevice, p->stream));
     HIP_TRY(hipStreamSynchronize(p->stream));
     return PDWT_OK;
@@ -500,7 +509,7 @@ void build_schedule(pdwt_plan* p) {
                 if (p->chain_flags) (void)hipFree(p->chain_flags);
                 p->chain_flags = nullptr;
                 p->chain_words = 0;
-                if (hipMalloc((void**)&p->chain_flags, (size_t)(2 * words) * sizeof(unsigned)) == hipSuccess &&
+                if (device_malloc((void**)&p->chain_flags, (size_t)(2 * words) * sizeof(unsigned)) == hipSuccess &&
                     hipMemsetAsync(p->chain_flags, 0, (size_t)(2 * words) * sizeof(unsigned), p->stream) == hipSuccess) {
                     p->chain_words = words;
                     p->chain_epoch = 0;
@@ -599,17 +608,33 @@ int fwd_level_2d(pdwt_plan* p, int l, bool run) {
     } else {
         const int f = 1 << (l - 1);
         const int Nr = p->info.Nr, Nc = p->info.Nc;
-        const bool split = swt2_split_supported(hlen, Nr, Nc, f, false, (long long)B * Nr * Nc) && ensure_tmp(p, 2LL * Nr * Nc * B) == PDWT_OK;
-        if (split || Nr % f == 0) {
-            Swt2DArgs a;
-            a.in = src; a.A = dstA; a.H = H; a.V = V; a.D = D; a.out = nullptr;
-            a.Nr = Nr; a.Nc = Nc; a.f = f;
-            a.bstride = (long long)Nr * Nc;
-            a.hlen = hlen;
-            a.soft_beta = 0.f;
-            a.fb = p->dec;
-            Stamp st(p, split ? "swt2_fwd_split" : "swt2_fwd_level");
-            if (run) HIP_TRY(split ? launch_swt2_split(a, p->tmp, false, B, p->stream) : launch_swt2_fwd(a, B, p->stream));
+        bool split = swt2_split_supported(hlen, Nr, Nc, f, false, (long long)B * Nr * Nc) && ensure_tmp(p, 2LL * Nr * Nc * B) == PDWT_OK;
+        Swt2DArgs a;
+        a.in = src; a.A = dstA; a.H = H; a.V = V; a.D = D; a.out = nullptr;
+        a.Nr = Nr; a.Nc = Nc; a.f = f;
+        a.bstride = (long long)Nr * Nc;
+        a.hlen = hlen;
+        a.soft_beta = 0.f;
+        a.fb = p->dec;
+        if (split) {
+            // the launcher reads the (process-wide, atomic) threshold again and checks alignments the predicate does not:
+            // hipErrorNotSupported is a DECLINE (another thread may have moved the knob in between), not a failure
+            Stamp st(p, "swt2_fwd_split");
+            const hipError_t e = run ? launch_swt2_split(a, p->tmp, false, B, p->stream) : hipSuccess;
+            if (e == hipErrorNotSupported) {
+                split = false;
+                if (p->timing && !p->stamps.empty()) {
+                    (void)hipEventDestroy(p->stamps.back().start);
+                    p->stamps.pop_back();
+                }
+            } else if (e != hipSuccess) {
+                HIP_TRY(e);
+            }
+        }
+        if (split) {
+        } else if (Nr % f == 0) {
+            Stamp st(p, "swt2_fwd_level");
+            if (run) HIP_TRY(launch_swt2_fwd(a, B, p->stream));
         } else {
             // dilation does not divide the row count: two direct passes through scratch
             const long long plane = (long long)Nr * Nc;
@@ -675,22 +700,35 @@ int inv_level_2d(pdwt_plan* p, int l, bool run) {
     } else {
         const int f = 1 << (l - 1);
         const int Nr = p->info.Nr, Nc = p->info.Nc;
-        const bool split = swt2_split_supported(hlen, Nr, Nc, f, true, (long long)B * Nr * Nc) && ensure_tmp(p, 2LL * Nr * Nc * B) == PDWT_OK;
-        if (split || Nr % f == 0) {
-            Swt2DArgs a;
-            a.in = nullptr;
-            a.A = const_cast<real_t*>(cur); a.H = const_cast<real_t*>(H);
-            a.V = const_cast<real_t*>(V); a.D = const_cast<real_t*>(D);
-            a.out = dst;
-            a.Nr = Nr; a.Nc = Nc; a.f = f;
-            a.bstride = (long long)Nr * Nc;
-            a.hlen = hlen;
-            a.soft_beta = 0.f;
-            if (p->pend_soft) a.soft_beta = pending_beta_of_level(p, l);
-            a.fb = p->rec;
-            Stamp st(p, split ? (p->pend_soft ? "swt2_inv_split+soft" : "swt2_inv_split")
-                              : (p->pend_soft ? "swt2_inv_level+soft" : "swt2_inv_level"));
-            if (run) HIP_TRY(split ? launch_swt2_split(a, p->tmp, true, B, p->stream) : launch_swt2_inv(a, B, p->stream));
+        bool split = swt2_split_supported(hlen, Nr, Nc, f, true, (long long)B * Nr * Nc) && ensure_tmp(p, 2LL * Nr * Nc * B) == PDWT_OK;
+        Swt2DArgs a;
+        a.in = nullptr;
+        a.A = const_cast<real_t*>(cur); a.H = const_cast<real_t*>(H);
+        a.V = const_cast<real_t*>(V); a.D = const_cast<real_t*>(D);
+        a.out = dst;
+        a.Nr = Nr; a.Nc = Nc; a.f = f;
+        a.bstride = (long long)Nr * Nc;
+        a.hlen = hlen;
+        a.soft_beta = 0.f;
+        if (p->pend_soft) a.soft_beta = pending_beta_of_level(p, l);
+        a.fb = p->rec;
+        if (split) {  // a decline (hipErrorNotSupported) falls through to the other kernels, see fwd_level_2d
+            Stamp st(p, p->pend_soft ? "swt2_inv_split+soft" : "swt2_inv_split");
+            const hipError_t e = run ? launch_swt2_split(a, p->tmp, true, B, p->stream) : hipSuccess;
+            if (e == hipErrorNotSupported) {
+                split = false;
+                if (p->timing && !p->stamps.empty()) {
+                    (void)hipEventDestroy(p->stamps.back().start);
+                    p->stamps.pop_back();
+                }
+            } else if (e != hipSuccess) {
+                HIP_TRY(e);
+            }
+        }
+        if (split) {
+        } else if (Nr % f == 0) {
+            Stamp st(p, p->pend_soft ? "swt2_inv_level+soft" : "swt2_inv_level");
+            if (run) HIP_TRY(launch_swt2_inv(a, B, p->stream));
         } else {
             const long long plane = (long long)Nr * Nc;
             int rc = ensure_tmp(p, 2 * plane);
@@ -1076,7 +1114,7 @@ int pdwt_clone(pdwt_handle src, pdwt_handle* out) {
         e = hipMemcpyAsync(p->arena, src->arena, (size_t)p->arena_elems * sizeof(real_t), hipMemcpyDeviceToDevice,
                            p->stream);
     if (e == hipSuccess && src->d_f2d) {
-        e = hipMalloc((void**)&p->d_f2d, (size_t)8 * kMaxTaps * kMaxTaps * sizeof(real_t));
+        e = device_malloc((void**)&p->d_f2d, (size_t)8 * kMaxTaps * kMaxTaps * sizeof(real_t));
         if (e == hipSuccess)
             e = hipMemcpyAsync(p->d_f2d, src->d_f2d, (size_t)8 * kMaxTaps * kMaxTaps * sizeof(real_t),
                                hipMemcpyDeviceToDevice, p->stream);
@@ -1095,7 +1133,7 @@ int pdwt_destroy(pdwt_handle h) {
     clear_stamps(h);
     pool_free(h->device, h->arena, h->arena_bytes);
     if (h->tmp) (void)hipFree(h->tmp);
-    pool_free(h->device, h->d_red, 256);
+    pool_free(h->device, h->d_red, h->d_red_bytes);
     if (h->d_f2d) (void)hipFree(h->d_f2d);
     if (h->chain_flags) (void)hipFree(h->chain_flags);
     if (h->own_stream && h->stream) pool_return_stream(h->device, h->stream);
@@ -1453,7 +1491,7 @@ int pdwt_set_filters_forward(pdwt_handle h, const char* name, unsigned int len, 
     } else {
         if (!f3 || !f4)
             return fail(PDWT_ERR_ARG, "set_filters_forward(): expected argument 4 and 5 for non-separable filtering");
-        if (!h->d_f2d) HIP_TRY(hipMalloc((void**)&h->d_f2d, (size_t)8 * kMaxTaps * kMaxTaps * sizeof(real_t)));
+        if (!h->d_f2d) HIP_TRY(device_malloc((void**)&h->d_f2d, (size_t)8 * kMaxTaps * kMaxTaps * sizeof(real_t)));
         const real_t* f[4] = {f1, f2, f3, f4};
         for (int k = 0; k < 4; k++)
             HIP_TRY(hipMemcpyAsync(h->d_f2d + (size_t)k * len * len, f[k], (size_t)len * len * sizeof(real_t),
@@ -1480,7 +1518,7 @@ int pdwt_set_filters_inverse(pdwt_handle h, const real_t* f1, const real_t* f2, 
     } else {
         if (!f3 || !f4)
             return fail(PDWT_ERR_ARG, "set_filters_inverse(): expected argument 4 and 5 for non-separable filtering");
-        if (!h->d_f2d) HIP_TRY(hipMalloc((void**)&h->d_f2d, (size_t)8 * kMaxTaps * kMaxTaps * sizeof(real_t)));
+        if (!h->d_f2d) HIP_TRY(device_malloc((void**)&h->d_f2d, (size_t)8 * kMaxTaps * kMaxTaps * sizeof(real_t)));
         const real_t* f[4] = {f1, f2, f3, f4};
         for (int k = 0; k < 4; k++)
             HIP_TRY(hipMemcpyAsync(h->d_f2d + (size_t)(4 + k) * len * len, f[k], (size_t)len * len * sizeof(real_t),
@@ -1609,6 +1647,37 @@ int pdwt_time_level(pdwt_handle h, int level, int inverse, int reps, float* ms_p
     return rc;
 }
 
+int pdwt_time_copy(pdwt_handle h, long long elems, int reps, float* ms_per_launch) {
+    CHECK_HANDLE(h);
+    const long long cap = (long long)h->batch * h->info.Nr * h->info.Nc;
+    if (!ms_per_launch || reps < 1 || elems < 4) return fail(PDWT_ERR_ARG, "pdwt_time_copy: bad arguments");
+    if (elems > cap) elems = cap;
+    elems &= ~3LL;
+    DeviceGuard guard(h->device);
+    int rc = ensure_tmp(h, elems);
+    if (rc != PDWT_OK) return rc;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    struct Ev {
+        hipEvent_t *a, *b;
+        ~Ev() {
+            if (*a) (void)hipEventDestroy(*a);
+            if (*b) (void)hipEventDestroy(*b);
+        }
+    } ev{&e0, &e1};
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    for (int i = 0; i < 3; i++) HIP_TRY(launch_copy(h->image(), h->tmp, elems, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipEventRecord(e0, h->stream));
+    for (int i = 0; i < reps; i++) HIP_TRY(launch_copy(h->image(), h->tmp, elems, h->stream));
+    HIP_TRY(hipEventRecord(e1, h->stream));
+    HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    *ms_per_launch = ms / (float)reps;
+    return PDWT_OK;
+}
+
 int pdwt_trim_pool(void) {
     DevicePool& P = device_pool();
     std::vector<DevicePool::Block> drop;
@@ -1674,6 +1743,28 @@ int pdwt_sync_producer(int device_id, void* producer_stream, int whole_device) {
     hipError_t e = whole_device ? hipDeviceSynchronize() : hipStreamSynchronize((hipStream_t)producer_stream);
     if (e != hipSuccess) return fail(PDWT_ERR_HIP, "pdwt_sync_producer: %s", hipGetErrorString(e));
     return PDWT_OK;
+}
+
+int pdwt_device_count(void) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return ndev;
+}
+
+int pdwt_device_of_pointer(const void* ptr) {
+    if (!ptr) return fail(PDWT_ERR_ARG, "pdwt_device_of_pointer: null pointer");
+    hipPointerAttribute_t at;
+    memset(&at, 0, sizeof(at));
+    if (hipPointerGetAttributes(&at, ptr) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(PDWT_ERR_ARG, "pdwt_device_of_pointer: not an address the HIP runtime knows");
+    }
+    if (at.type != hipMemoryTypeDevice && at.type != hipMemoryTypeManaged && at.type != hipMemoryTypeArray)
+        return fail(PDWT_ERR_ARG, "pdwt_device_of_pointer: host memory");
+    return at.device;
 }
 
 int pdwt_set_tuning(const char* key, int value) {

@@ -72,6 +72,7 @@ struct pdwt_plan {
     real_t* tmp = nullptr;  // lazily allocated scratch (circshift, SWT fallback)
     long long tmp_elems = 0;
     double* d_red = nullptr;  // two fp64 accumulators for the norms
+    size_t d_red_bytes = 0;   // size of the block behind them (a pool block may be larger than the 256 B asked for)
 
     pdwt::FilterBank dec{}, rec{};
     real_t* d_f2d = nullptr;  // non-separable banks: fwd LL,LH,HL,HH then inv, each hlen*hlen

@@ -91,7 +91,13 @@ class TiledWavelets(object):
     """Data layout: the slab and every band slab live INSIDE the buffers of the single-GPU plans that work on them
     (the interior rows of an extended slab); the halo rows around them are received straight into the same buffers.
     A level therefore costs its kernel, one halo exchange and (from level 2 on) one copy of the approximation slab
-    into the next plan -- no staging tensors.  `coeffs` / `image` copy to the host when asked."""
+    into the next plan -- no staging tensors.  `coeffs` / `image` copy to the host when asked.
+
+    Aliasing: `slab` and the tensors of `device_coeffs` are zero-copy VIEWS of plan buffers.  They are overwritten by
+    the next forward() / inverse() (clone what must survive), `slab` is None after cleanup(), and editing the
+    coefficient views is the intended way to threshold between forward() and inverse().  inverse() runs once per
+    forward(): a second call warns and does nothing (the reference's W_INVERSE state) unless mark_coeffs_current()
+    has re-armed it after an in-place edit."""
 
     def __init__(self, slab, wname, levels, group=None, do_swt=0, loopback=False):
         """loopback: with ONE rank, still send the halos / gather / broadcast through the process group (the rank
@@ -375,7 +381,11 @@ class TiledWavelets(object):
         if self._bands is None:
             raise RuntimeError("TiledWavelets.inverse: call forward() first")
         if not self._in_coeff_domain:
-            return self  # the image is current (the reference's W_INVERSE state: a second inverse does nothing)
+            # the reference's W_INVERSE state: a second inverse does nothing -- but says so (wt.cu:272-275)
+            import warnings
+            warnings.warn("TiledWavelets.inverse() has already been run: the image is current and nothing was done.  "
+                          "After editing device_coeffs in place call mark_coeffs_current() to invert them.", RuntimeWarning)
+            return self
         if self.do_swt:
             self._inverse_swt()
             self._in_coeff_domain = False
@@ -400,6 +410,20 @@ class TiledWavelets(object):
             if l > 1:  # the interior of the reconstruction is A of the level above
                 self._level(l - 1).co[0][hq:hq + 2 * m2].copy_(P.img[hp:hp + 2 * m2])
         self._in_coeff_domain = False
+        return self
+
+    def mark_coeffs_current(self):
+        """After inverse(): declare the coefficient buffers current again (the caller has edited `device_coeffs` in
+        place), so that the next inverse() runs instead of being refused.  Nothing is copied: every plan is told that
+        its band 0 was written in place (pdwt_set_coeff with the plan's own pointer)."""
+        if self._bands is None:
+            raise RuntimeError("TiledWavelets.mark_coeffs_current: call forward() first")
+        plans = list(self._plans.values()) + ([self._deep] if getattr(self, "_deep", None) else [])
+        for P in plans:
+            if P.h is not None:
+                check(self._lib.pdwt_set_coeff(P.h, C.c_void_p(self._lib.pdwt_coeff_ptr(P.h, 0)), 0, 1),
+                      "TiledWavelets.mark_coeffs_current", self._lib)
+        self._in_coeff_domain = True
         return self
 
     # ---- results (this rank's slabs)

@@ -146,8 +146,10 @@ class Wavelets(object):
         self.ndim = img.ndim
 
         h = handle_t()
-        if dev is not None and dev[2]:  # no plan (and no plan stream) yet: wait on the host for the image's producer
-            self._check(self._lib.pdwt_sync_producer(-1, C.c_void_p(dev[2][1] if dev[2][0] == "stream" else 0),
+        if dev is not None and dev[2]:  # no plan (and no plan stream) yet: wait on the host for the image's producer,
+            # on the device that OWNS the array (not necessarily the current one, where the plan is about to be built)
+            self._check(self._lib.pdwt_sync_producer(self._owner_device(dev[0]),
+                                                     C.c_void_p(dev[2][1] if dev[2][0] == "stream" else 0),
                                                      1 if dev[2][0] == "device" else 0), "Wavelets()")
         src = self._fptr(img) if dev is None else C.cast(C.c_void_p(dev[0]), C.POINTER(self._lib.pdwt_real))
         rc = self._lib.pdwt_create(src, self.Nr, self.Nc, self._wname, self.levels, 1 if dev is None else 0,
@@ -270,6 +272,11 @@ class Wavelets(object):
                                "got %d (%s)" % (res.size, numc, _lib.last_error(self._lib)))
         return res
 
+    def _owner_device(self, ptr):
+        """Device ordinal that owns a device allocation, -1 (= the current device) when the runtime cannot tell."""
+        d = int(self._lib.pdwt_device_of_pointer(C.c_void_p(ptr)))
+        return d if d >= 0 else -1
+
     def _order_after_producer(self, dev):
         """The copy of a device array runs on the plan's own (non-blocking) stream: order it after the array's
         producer first (an event wait when the producer's stream is known, a device synchronisation when it is not)."""
@@ -277,8 +284,9 @@ class Wavelets(object):
             return
         if dev[2][0] == "stream":
             self._check(self._lib.pdwt_wait_for_stream(self._h, C.c_void_p(dev[2][1])))
-        else:
-            self._check(self._lib.pdwt_sync_producer(self._lib.pdwt_device(self._h), None, 1))
+        else:  # producer stream unknown (CAI v2): synchronise the device that owns the array -- the producer ran there
+            owner = self._owner_device(dev[0])
+            self._check(self._lib.pdwt_sync_producer(owner if owner >= 0 else self._lib.pdwt_device(self._h), None, 1))
 
     def _set_image_any(self, img, shp):
         dev = _device_array(img, self._dtype)
@@ -603,6 +611,13 @@ class BatchedWavelets(object):
         events on the plan's stream (pdwt_time_level)."""
         ms = C.c_float()
         check(self._lib.pdwt_time_level(self._h, int(level), 1 if inverse else 0, int(reps), C.byref(ms)))
+        return ms.value * 1e3
+
+    def time_copy(self, elems, reps=50):
+        """Mean microseconds of a plain 16-B grid-stride copy of `elems` values out of the plan's image buffer
+        (pdwt_time_copy): the measured ceiling for a streaming kernel that reads and writes that many values."""
+        ms = C.c_float()
+        check(self._lib.pdwt_time_copy(self._h, int(elems), int(reps), C.byref(ms)))
         return ms.value * 1e3
 
     def kernel_times(self, cap=4096):

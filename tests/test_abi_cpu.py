@@ -205,3 +205,33 @@ def test_tuning_keys_documented_in_the_header_exist_and_round_trip(lib):
     # the split-SWT thresholds: taps, 0 = never, 100 + n = n taps at every size
     p = lib.pdwt_set_tuning(b"swt_split_inv", 110)
     assert lib.pdwt_set_tuning(b"swt_split_inv", p) == 110
+
+
+def test_partition_of_a_sharded_batch():
+    """pypwt_amd.sharded: contiguous blocks, remainder to the first owners, every image owned exactly once (CPU only)."""
+    from pypwt_amd.sharded import owner_of, partition_images
+    assert partition_images(1024, 8) == [(128 * r, 128 * (r + 1)) for r in range(8)]  # BASELINE config 5
+    assert partition_images(5, 2) == [(0, 3), (3, 5)]
+    assert partition_images(2, 3) == [(0, 1), (1, 2), (2, 2)]
+    for total, parts in ((1, 1), (7, 3), (130, 8), (3, 8)):
+        blocks = partition_images(total, parts)
+        assert blocks[0][0] == 0 and blocks[-1][1] == total
+        assert all(a[1] == b[0] for a, b in zip(blocks, blocks[1:]))
+        assert max(hi - lo for lo, hi in blocks) - min(hi - lo for lo, hi in blocks) <= 1
+        for b in range(total):
+            i, k = owner_of(blocks, b)
+            assert blocks[i][0] + k == b
+    import pytest
+    with pytest.raises(IndexError):
+        owner_of(partition_images(4, 2), 4)
+    with pytest.raises(ValueError):
+        partition_images(4, 0)
+
+
+def test_sharded_batch_without_a_gpu_fails_loudly():
+    import pytest
+    from pypwt_amd import ShardedBatch, _lib
+    if _lib.load().pdwt_device_count() > 0:
+        pytest.skip("a HIP device is present")
+    with pytest.raises(RuntimeError):
+        ShardedBatch(4, 64, 64, "db2", 2)

@@ -85,7 +85,20 @@ def test_gpus_flag_starts_the_ranks_itself():
     assert len(lines) == 1, r.stdout
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["ms_per_step"] >= 1.9
-    assert out["config"]["images_per_step"] == 2 and out["config"]["shard_rank0"] == [0, 1]
+    # more than one rank and no --config: BASELINE config 5's per-GPU shard (128 images per GPU and step), so that the
+    # driver's --steps 20 times ~170 ms per rank instead of the 1.4 ms of twenty one-image steps
+    assert out["config"]["config"] == "cfg5"
+    assert out["config"]["images_per_step"] == 256 and out["config"]["shard_rank0"] == [0, 128]
+
+
+def test_explicit_config_wins_over_the_multi_rank_default():
+    env_clean = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "2", "--config", "cfg2", "--dry-run"],
+                       capture_output=True, text=True, cwd=ROOT, env=env_clean, timeout=240)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert out["config"]["config"] == "cfg2" and out["config"]["images_per_step"] == 2
+    assert out["config"]["shard_rank0"] == [0, 1]
 
 
 def test_strong_scaling_splits_a_fixed_batch_and_cfg5_is_128_per_gpu():
@@ -97,7 +110,9 @@ def test_strong_scaling_splits_a_fixed_batch_and_cfg5_is_128_per_gpu():
     assert [s[0] for s in spans] == [128] * 8 and [s[1] for s in spans] == list(range(0, 1024, 128))
     assert all(s[2] == 1024 for s in spans)
     a = bench.parse_args([])
-    assert bench.rank_batch(a, 1, 0) == (1, 0, 1)
+    assert bench.rank_batch(a, 1, 0) == (1, 0, 1) and a.config == "cfg2"  # one GPU: the headline one-image step
+    a = bench.parse_args([])
+    assert bench.rank_batch(a, 8, 3) == (128, 384, 1024) and a.config == "cfg5"  # several: config 5's shard
 
 
 def test_world_size_mismatch_is_reported_even_for_one_rank():

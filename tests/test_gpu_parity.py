@@ -84,10 +84,16 @@ def test_golden_small_cases_forward_and_inverse(W):
             _oracle_close(g, ora[b], (m, b), m["levels"], m["wname"])
         w.inverse()
         rec = w.image
-        _oracle_close(rec, oracle.inverse(ora, x.shape, m["wname"], m["levels"], ndim=nd, do_swt=swt), m, m["levels"], m["wname"])
+        ora_rec = oracle.inverse(ora, x.shape, m["wname"], m["levels"], ndim=nd, do_swt=swt)
+        _oracle_close(rec, ora_rec, m, m["levels"], m["wname"])
         if m["wname"] not in ("rbio3.1",):  # reference skips rbio3.1 inversion (test_wavelets.py:174-176)
-            tol = 7e-4 if m["wname"] not in ("bior3.1", "coif5", "db20", "sym20") else 5e-3
-            assert np.abs(rec - x).max() < tol, (m, np.abs(rec - x).max())
+            # The reference's 7e-4 (test_wavelets.py:545) is stated for its 512^2 image.  These cases run at the MAXIMUM
+            # level count on 0..255 data, where the fp32 round-off of the reference's own arithmetic -- measured here by
+            # the fp32 CPU restatement on the same input -- exceeds 7e-4 for the long / ill-conditioned banks (db20, sym20,
+            # coif5, bior3.1).  The bound is therefore the reference's, or twice what its arithmetic itself achieves.
+            ora_err = float(np.abs(ora_rec - x).max())
+            tol = max(7e-4, 2.0 * ora_err)
+            assert np.abs(rec - x).max() < tol, (m, np.abs(rec - x).max(), ora_err)
 
 
 KINDS = [("dwt2", (64, 64)), ("dwt2", (61, 59)), ("dwt2", (130, 33)), ("dwt1", (1, 256)), ("dwt1", (3, 251)),

@@ -65,7 +65,11 @@ def main():
         rec = oracle.inverse(flat, x.shape, wname, levels, do_swt=1)
         assert np.abs(tw.image - rec[rank * n:(rank + 1) * n]).max() <= 2e-3, "reconstruction vs oracle"
     assert np.abs(tw.image - x[rank * n:(rank + 1) * n]).max() <= 2e-3, "reconstruction"
-    tw.inverse()  # the image is current: a second inverse changes nothing (the reference's W_INVERSE state)
+    import warnings
+    with warnings.catch_warnings(record=True) as caught:  # the image is current: a second inverse changes nothing
+        warnings.simplefilter("always")                    # (the reference's W_INVERSE state) and says so
+        tw.inverse()
+    assert any("already been run" in str(w.message) for w in caught), "second inverse must warn"
     tw.forward()
     for lvl in tw.device_coeffs[1:tw.tiled_levels + 1]:  # zero-copy views of the plans' buffers: shrink the details in place
         for b in lvl:
@@ -76,9 +80,20 @@ def main():
         flat2[k] *= np.float32(0.5)
     rec2 = oracle.inverse(flat2, x.shape, wname, levels, do_swt=swt)[rank * n:(rank + 1) * n]
     assert np.abs(tw.image - rec2).max() <= 2e-3, "inverse of coefficients modified in place"
+    # forward -> inverse -> edit in place -> inverse: refused (stale image) unless mark_coeffs_current() re-arms it
+    for lvl in tw.device_coeffs[1:tw.tiled_levels + 1]:
+        for b in lvl:
+            b.mul_(0.5)
+    tw.mark_coeffs_current()
+    tw.inverse()
+    flat3 = [f.copy() for f in flat2]
+    for k in range(1, 3 * tw.tiled_levels + 1):
+        flat3[k] *= np.float32(0.5)
+    rec3 = oracle.inverse(flat3, x.shape, wname, levels, do_swt=swt)[rank * n:(rank + 1) * n]
+    assert np.abs(tw.image - rec3).max() <= 2e-3, "inverse after mark_coeffs_current"
     tw.forward()
     tw.inverse()  # plans are reused: another round trip must work too
-    assert np.abs(tw.image - rec2).max() <= 4e-3, "second round trip"
+    assert np.abs(tw.image - rec3).max() <= 4e-3, "second round trip"
     if world > 1 or loopback:
         dist.barrier()
         dist.destroy_process_group()
