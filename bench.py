@@ -102,7 +102,7 @@ def kernel_algorithmic_bytes(label, cfg, batch):
         return 8.0 * samples / (4 ** (lvl - 1))
     if name.startswith("dwt1"):
         return 8.0 * samples / (2 ** (lvl - 1))
-    if name in ("swt2_fwd_level", "swt2_inv_level"):
+    if name in ("swt2_fwd_level", "swt2_inv_level", "swt2_fwd_split", "swt2_inv_split"):
         return 4.0 * 5 * samples
     if name in ("swt2_fwd_fused", "swt2_inv_fused"):  # K levels: one plane in, 3 K + 1 planes out (or the reverse)
         K = min(3, L - lvl + 1)
@@ -128,7 +128,8 @@ def label_step_kernels(names, L, chain_levels=None):
     f, i = 1, L
     for n in names:
         base = n.replace("+soft", "")
-        if base in ("dwt2_fwd_level", "dwt1_fwd_level", "swt2_fwd_level", "swt1_fwd_level", "nonsep_fwd_level"):
+        if base in ("dwt2_fwd_level", "dwt2_fwd_split", "dwt1_fwd_level", "swt2_fwd_level", "swt2_fwd_split", "swt1_fwd_level",
+                    "nonsep_fwd_level"):
             out.append("%s[L%d]" % (n, f)); f += 1
         elif base in ("dwt2_fwd_pyr2", "dwt2_fwd_strip2", "dwt2_fwd_wave2"):
             out.append("%s[L%d]" % (n, f)); f += 2
@@ -142,7 +143,8 @@ def label_step_kernels(names, L, chain_levels=None):
             out.append("%s[L%d]" % (n, f)); f += min(3, L - f + 1)
         elif base == "dwt1_fwd_reg":  # up to three levels per launch
             out.append("%s[L%d]" % (n, f)); f = min(f + 3, L + 1)
-        elif base in ("dwt2_inv_level", "dwt1_inv_level", "swt2_inv_level", "swt1_inv_level", "nonsep_inv_level"):
+        elif base in ("dwt2_inv_level", "dwt2_inv_split", "dwt1_inv_level", "swt2_inv_level", "swt2_inv_split", "swt1_inv_level",
+                      "nonsep_inv_level"):
             out.append("%s[L%d]" % (n, i)); i -= 1
         elif base in ("dwt2_inv_pyr2", "dwt2_inv_strip2", "dwt2_inv_wave2"):
             out.append("%s[L%d]" % (n, i - 1)); i -= 2

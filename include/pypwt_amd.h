@@ -248,6 +248,12 @@ int pdwt_time_copy(pdwt_handle h, long long elems, int reps, float* ms_per_launc
  *                    forward level, 16 taps 93 -> 40 us per inverse level); the inverse of images below 1024^2 / 2048^2 starts at 24 / 12 taps
  *                    (two one-round launches cost more than they save there); 0 = never; 100 + n = n taps at every size (tests).
  *                    Read at every level launch.
+ *   "dwt_split_fwd" / "dwt_split_inv"   the shortest (even) filter whose DECIMATED 2D levels run as a register-blocked row
+ *                    launch + column launch through scratch (dwt2_split_kernels.hpp; rows and columns even, columns a
+ *                    multiple of 8) instead of one LDS-tiled launch.  Default 0 (never): measured no faster than LDS tiles
+ *                    of the right shape on MI355X (40 taps 2048^2 L5 forward 91 against 53 us), so the kernels are compiled
+ *                    into the test library libpypwt_amd_lab.so only and the product accepts the keys and does nothing;
+ *                    100 + n = n taps at every size (tests).  Read at every level launch.
  *   "chain"          levels 1..K of a 2D DWT in ONE launch with in-launch hand-offs between the levels
  *                    (dwt2_chain_kernels.hpp; even filters of at most 8 taps, whole 16 x 128 tiles at every level):
  *                    0 (default): never -- measured break-even for two levels and slower beyond on MI355X; 1: one

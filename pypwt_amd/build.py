@@ -27,7 +27,9 @@ LIB_LAB = os.path.join(HERE, "libpypwt_amd_lab.so")
 # has the register kernels only (2D DWT levels, 1D DWT level triples, fused 2-tap SWT groups) and the small-image pyramid
 VARIANTS = {
     "f32": (OBJ, LIB, [], ("launch_dwt2_chain.hip",)),
-    "lab": (os.path.join(ROOT, "build", "obj_lab"), LIB_LAB, ["-DPDWT_LAB_KERNELS"], ()),
+    # PDWT_TILE_EXPERIMENT=1 in the environment adds the tile-shape A/B switches of launch_dwt2_fast.hip (tools/tilesweep.sh)
+    "lab": (os.path.join(ROOT, "build", "obj_lab"), LIB_LAB,
+            ["-DPDWT_LAB_KERNELS"] + (["-DPDWT_TILE_EXPERIMENT"] if os.environ.get("PDWT_TILE_EXPERIMENT") else []), ()),
     "f64": (os.path.join(ROOT, "build", "obj_f64"), LIB_F64, ["-DPDWT_DOUBLE"],
             ("launch_dwt2_pyramid.hip", "launch_dwt1_fused.hip", "launch_dwt2_chain.hip")),
 }
@@ -46,6 +48,7 @@ SOURCES = [
     "launch_swt_vec.hip",
     "launch_swt_fused.hip",
     "launch_swt_split.hip",
+    "launch_dwt2_split.hip",
     "launch_ops.hip",
     "launch_nonsep.hip",
     "plan.cpp",

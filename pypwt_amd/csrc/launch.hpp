@@ -91,6 +91,12 @@ hipError_t launch_swt2_inv(const Swt2DArgs& a, int batch, hipStream_t s);
 bool swt2_split_supported(int hlen, int Nr, int Nc, int f, bool inverse, long long samples_per_launch);
 int set_swt_split_min(int inverse, int taps);  // shortest filter on the split path (0: never); returns the previous value
 hipError_t launch_swt2_split(const Swt2DArgs& a, real_t* scratch, bool inverse, int batch, hipStream_t s);
+// one DECIMATED 2D level as a row launch + a column launch through scratch (Nr Nc batch elements): dwt2_split_kernels.hpp;
+// (Nr, Nc) = the level's image side (forward: its input, inverse: its output), both even, Nc a multiple of 8
+bool dwt2_split_supported(int hlen, int Nr, int Nc, bool inverse, long long samples_per_launch);
+int set_dwt_split_min(int inverse, int taps);  // shortest filter on the split path (0: never; 100 + n: n taps at every size); returns the previous value
+hipError_t launch_dwt2_split_fwd(const Fwd2DArgs& a, real_t* scratch, int batch, hipStream_t s);
+hipError_t launch_dwt2_split_inv(const Inv2DArgs& a, real_t* scratch, int batch, hipStream_t s);
 // levels l0 .. l0+K-1 (K = 2, 3; l0 = 1 or 4) of a 2-tap 2D SWT in one launch (swt2_fused_kernels.hpp)
 bool swt2_fused_supported(int hlen, int Nr, int Nc, int l0, int K, bool inverse = false);
 hipError_t launch_swt2_fused(const real_t* in, real_t* out, real_t* const* det, int Nr, int Nc, int l0, int K, bool inverse,

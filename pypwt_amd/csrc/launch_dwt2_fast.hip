@@ -39,6 +39,7 @@ static int stream_workgroups(int tiles, int batch, size_t lds_bytes) {
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+#ifdef PDWT_TILE_EXPERIMENT  // the streaming form (persistent workgroups prefetching their next tile) is no longer dispatched
 template <int HLEN, int TX, int TY, int NT>
 static hipError_t run_fwd_fast(const Fwd2DArgs& g, int batch, hipStream_t s) {
     static std::atomic<bool> big[64] = {};
@@ -55,6 +56,8 @@ static hipError_t run_fwd_fast(const Fwd2DArgs& g, int batch, hipStream_t s) {
                        dim3(stream_workgroups(a.tiles_x * a.tiles_y, batch, lds)), dim3(NT), lds, s, a, batch);
     return hipGetLastError();
 }
+
+#endif
 
 // One tile per workgroup (no streaming), for MID-SIZE levels: at 2048^2 (one image) 512 workgroups of 512
 // threads with 64x32 tiles are all resident at once and the level takes 7.9 us instead of 8.5-9.0 us with the
@@ -109,9 +112,7 @@ hipError_t try_launch_dwt2_fwd_fast(const Fwd2DArgs& a, int batch, hipStream_t s
     if (lds_tiles_off()) return hipErrorNotSupported;
     if ((a.hlen & 1) || a.hlen < 2 || a.hlen > kMaxTaps) return hipErrorNotSupported;
     // any row length: rows that are not whole, aligned quads take the unaligned staging / element-store branches of the
-    // tile; the streaming form (more than 20 taps) stages whole aligned quads only
-    const bool quads = !(a.Nc & 3) && !(a.in_bstride & 3) && !(a.out_bstride & 1);
-    if (a.hlen > 20 && !quads) return hipErrorNotSupported;
+    // tile
     if (!aligned16(a.in) || !aligned16(a.A) || !aligned16(a.H) || !aligned16(a.V) || !aligned16(a.D))
         return hipErrorNotSupported;
     // One tile per workgroup everywhere.  Since the staging loops are branch-free (all of a thread's loads in flight
@@ -119,6 +120,25 @@ hipError_t try_launch_dwt2_fwd_fast(const Fwd2DArgs& a, int batch, hipStream_t s
     // into registers) at every size measured -- db4, one 4096^2 image: 21.0 us (64x8 tiles, 256 threads) against 23.4;
     // 2048^2: 7.0 us (64x16, 512 threads) against 8.6; 1024^2: 4.1 against 4.6; 4 x 4096^2: 107 against 116 us; 16 taps,
     // 4096^2: 29.2 us (64x16, 512 threads) against 38.5 (profiles/r02y_kbench_tiles.txt).
+#ifdef PDWT_TILE_EXPERIMENT
+    {   // A/B (16 and 40 taps only): PDWT_FWD_TILE = shape index
+        static const int forced = getenv("PDWT_FWD_TILE") ? atoi(getenv("PDWT_FWD_TILE")) : 0;
+#define PDWT_FT(h)                                                             \
+        if (forced && a.hlen == h) {                                            \
+            if (forced == 1) return run_fwd_fast<h, 64, 32, 256>(a, batch, s);       \
+            if (forced == 2) return run_fwd_fast_tile<h, 64, 16, 512>(a, batch, s);  \
+            if (forced == 3) return run_fwd_fast_tile<h, 32, 16, 256>(a, batch, s);  \
+            if (forced == 4) return run_fwd_fast_tile<h, 32, 32, 512>(a, batch, s);  \
+            if (forced == 5) return run_fwd_fast_tile<h, 64, 8, 256>(a, batch, s);   \
+            if (forced == 6) return run_fwd_fast_tile<h, 32, 8, 128>(a, batch, s);   \
+            if (forced == 7) return run_fwd_fast_tile<h, 64, 16, 256>(a, batch, s);  \
+            if (forced == 8) return run_fwd_fast_tile<h, 64, 32, 512>(a, batch, s);  \
+            if (forced == 9) return run_fwd_fast_tile<h, 64, 32, 1024>(a, batch, s); \
+        }
+        PDWT_FT(16) PDWT_FT(20) PDWT_FT(26) PDWT_FT(40)
+#undef PDWT_FT
+    }
+#endif
     if (a.hlen <= 8 && mid_size((long long)batch * a.Nr * a.Nc)) {
         switch (a.hlen) {
             case 2: return run_fwd_fast_tile<2, 64, 16, 512>(a, batch, s);
@@ -127,13 +147,25 @@ hipError_t try_launch_dwt2_fwd_fast(const Fwd2DArgs& a, int batch, hipStream_t s
             case 8: return run_fwd_fast_tile<8, 64, 16, 512>(a, batch, s);
         }
     }
+    // Filters of 10 taps and more (round 4, profiles/r04i_tilesweep.txt, r04j_tilesweep2.txt; event-timed launches):
+    //   * a level of fewer than 2^20 samples is ONE round of a few workgroups -- its time is one tile's serial chain, so
+    //     small tiles of 32 x 16 outputs (256 threads) win whatever the halo they recompute: 40 taps 15.6 -> 7.9 us per
+    //     level from 128^2 to 512^2 (the 64 x 32 streaming tiles of rounds 1-3 were sized for 4096^2), 26 taps 11.6 -> 6.9,
+    //     20 taps 7.0 -> 6.6;
+    //   * large levels of 18+ taps: 32 x 32 outputs with 512 threads (each thread one column pair of one output row):
+    //     40 taps 4096^2 87.0 -> 56.9 us, 2048^2 28.9 -> 20.4; 26 taps 58.8 -> 38.6; 20 taps 39.9 -> 34.9;
+    //   * 10-16 taps keep 64 x 16 / 512 (16 taps 4096^2: 31.4 against 32.8).
+    const bool small_level = (long long)batch * a.Nr * a.Nc < (1LL << 20);
     switch (a.hlen) {
 #define X(h)                                                                \
     case h:                                                                 \
         if constexpr (h <= 8) return run_fwd_fast_tile<h, 64, 8, 256>(a, batch, s);   \
-        else if constexpr (h <= 20) return run_fwd_fast_tile<h, 64, 16, 512>(a, batch, s); \
-        else if constexpr (sizeof(real_t) == 8) return hipErrorNotSupported; /* 32-row tiles of doubles exceed 160 KB */ \
-        else return run_fwd_fast<h, 64, 32, 256>(a, batch, s);
+        else if constexpr (sizeof(real_t) == 8) {                                     \
+            if constexpr (h <= 20) return run_fwd_fast_tile<h, 64, 16, 512>(a, batch, s); \
+            else return run_fwd_fast_tile<h, 32, 16, 256>(a, batch, s); /* 70 x 168 doubles = 94 KB */ \
+        } else if (small_level) return run_fwd_fast_tile<h, 32, 16, 256>(a, batch, s);  \
+        else if constexpr (h <= 16) return run_fwd_fast_tile<h, 64, 16, 512>(a, batch, s); \
+        else return run_fwd_fast_tile<h, 32, 32, 512>(a, batch, s);
         PDWT_EVEN_HLENS(X)
 #undef X
     }
@@ -155,6 +187,25 @@ hipError_t try_launch_dwt2_inv_fast(const Inv2DArgs& a, int batch, hipStream_t s
             if (forced == 4) return run_inv_fast<8, 64, 32, 512>(a, batch, s);
         }
     }
+#ifdef PDWT_TILE_EXPERIMENT
+    {
+        static const int forced = getenv("PDWT_INV_TILE2") ? atoi(getenv("PDWT_INV_TILE2")) : 0;
+#define PDWT_IT(h)                                                             \
+        if (forced && a.hlen == h) {                                            \
+            if (forced == 1) return run_inv_fast<h, 64, 32, 256>(a, batch, s);   \
+            if (forced == 2) return run_inv_fast<h, 64, 16, 512>(a, batch, s);   \
+            if (forced == 3) return run_inv_fast<h, 32, 16, 256>(a, batch, s);   \
+            if (forced == 4) return run_inv_fast<h, 32, 16, 512>(a, batch, s);   \
+            if (forced == 5) return run_inv_fast<h, 64, 8, 256>(a, batch, s);    \
+            if (forced == 6) return run_inv_fast<h, 32, 8, 256>(a, batch, s);    \
+            if (forced == 7) return run_inv_fast<h, 64, 16, 1024>(a, batch, s);  \
+            if (forced == 8) return run_inv_fast<h, 64, 32, 1024>(a, batch, s);  \
+            if (forced == 9) return run_inv_fast<h, 32, 32, 1024>(a, batch, s);  \
+        }
+        PDWT_IT(16) PDWT_IT(20) PDWT_IT(26) PDWT_IT(40)
+#undef PDWT_IT
+    }
+#endif
     if (a.hlen <= 8 && mid_size((long long)batch * a.Nr * a.Nc)) {  // 128x16 tiles, 512 threads: 8.0 vs 8.8 us at 2048^2
         switch (a.hlen) {
             case 2: return run_inv_fast<2, 128, 16, 512>(a, batch, s);
@@ -163,13 +214,22 @@ hipError_t try_launch_dwt2_inv_fast(const Inv2DArgs& a, int batch, hipStream_t s
             case 8: return run_inv_fast<8, 128, 16, 512>(a, batch, s);
         }
     }
+    // 10 taps and more (same sweeps as the forward): below 2^20 output samples 32 x 8 coefficient tiles of 256 threads
+    // (40 taps 20.5 -> 6.9 us per level, 26 taps 13.0 -> 6.6, 16-20 taps 8.2 -> 6.6); large levels: 10-16 taps 64 x 16 /
+    // 512 as before, 18-30 taps 32 x 16 / 512 (26 taps 4096^2 76.0 -> 46.0 us, 20 taps 47.3 -> 44-51: level with 32 x 8),
+    // 32+ taps 32 x 8 / 256 (40 taps 4096^2 131.7 -> 89.8, 2048^2 38.4 -> 29.2)
+    const bool small_level = (long long)batch * a.Nr * a.Nc < (1LL << 20);
     switch (a.hlen) {
 #define X(h)                                                                \
     case h:                                                                 \
         if constexpr (h <= 8) return run_inv_fast<h, 64, 8, 256>(a, batch, s);   \
-        else if constexpr (h <= 20) return run_inv_fast<h, 64, 16, 512>(a, batch, s); \
-        else if constexpr (sizeof(real_t) == 8) return hipErrorNotSupported;     \
-        else return run_inv_fast<h, 64, 32, 256>(a, batch, s);
+        else if constexpr (sizeof(real_t) == 8) {                                \
+            if constexpr (h <= 20) return run_inv_fast<h, 64, 16, 512>(a, batch, s); \
+            else return run_inv_fast<h, 32, 8, 256>(a, batch, s);                \
+        } else if (small_level) return run_inv_fast<h, 32, 8, 256>(a, batch, s);  \
+        else if constexpr (h <= 16) return run_inv_fast<h, 64, 16, 512>(a, batch, s); \
+        else if constexpr (h <= 30) return run_inv_fast<h, 32, 16, 512>(a, batch, s); \
+        else return run_inv_fast<h, 32, 8, 256>(a, batch, s);
         PDWT_EVEN_HLENS(X)
 #undef X
     }

@@ -603,8 +603,26 @@ int fwd_level_2d(pdwt_plan* p, int l, bool run) {
         a.out_bstride = (long long)a.Nr2 * a.Nc2;
         a.hlen = hlen;
         a.fb = p->dec;
-        Stamp st(p, "dwt2_fwd_level");
-        if (run) HIP_TRY(launch_dwt2_fwd(a, B, p->stream));
+        // long filters: a row launch + a column launch through scratch (dwt2_split_kernels.hpp); a decline falls through
+        bool done = false;
+        if (dwt2_split_supported(hlen, a.Nr, a.Nc, false, (long long)B * a.Nr * a.Nc) &&
+            ensure_tmp(p, (long long)B * a.Nr * a.Nc) == PDWT_OK) {
+            Stamp st(p, "dwt2_fwd_split");
+            const hipError_t e = run ? launch_dwt2_split_fwd(a, p->tmp, B, p->stream) : hipSuccess;
+            if (e == hipErrorNotSupported) {
+                if (p->timing && !p->stamps.empty()) {
+                    (void)hipEventDestroy(p->stamps.back().start);
+                    p->stamps.pop_back();
+                }
+            } else {
+                HIP_TRY(e);
+                done = true;
+            }
+        }
+        if (!done) {
+            Stamp st(p, "dwt2_fwd_level");
+            if (run) HIP_TRY(launch_dwt2_fwd(a, B, p->stream));
+        }
     } else {
         const int f = 1 << (l - 1);
         const int Nr = p->info.Nr, Nc = p->info.Nc;
@@ -695,8 +713,25 @@ int inv_level_2d(pdwt_plan* p, int l, bool run) {
         a.out_bstride = (long long)a.Nr * a.Nc;
         a.hlen = hlen;
         a.fb = p->rec;
-        Stamp st(p, "dwt2_inv_level");
-        if (run) HIP_TRY(launch_dwt2_inv(a, B, p->stream));
+        bool done = false;
+        if (dwt2_split_supported(hlen, a.Nr, a.Nc, true, (long long)B * a.Nr * a.Nc) &&
+            ensure_tmp(p, (long long)B * a.Nr * a.Nc) == PDWT_OK) {
+            Stamp st(p, "dwt2_inv_split");
+            const hipError_t e = run ? launch_dwt2_split_inv(a, p->tmp, B, p->stream) : hipSuccess;
+            if (e == hipErrorNotSupported) {
+                if (p->timing && !p->stamps.empty()) {
+                    (void)hipEventDestroy(p->stamps.back().start);
+                    p->stamps.pop_back();
+                }
+            } else {
+                HIP_TRY(e);
+                done = true;
+            }
+        }
+        if (!done) {
+            Stamp st(p, "dwt2_inv_level");
+            if (run) HIP_TRY(launch_dwt2_inv(a, B, p->stream));
+        }
     } else {
         const int f = 1 << (l - 1);
         const int Nr = p->info.Nr, Nc = p->info.Nc;
@@ -1769,6 +1804,8 @@ int pdwt_device_of_pointer(const void* ptr) {
 
 int pdwt_set_tuning(const char* key, int value) {
     if (key && !strcmp(key, "wave_min_log2")) return set_wave_min_log2(value);
+    if (key && !strcmp(key, "dwt_split_fwd")) return set_dwt_split_min(0, value);
+    if (key && !strcmp(key, "dwt_split_inv")) return set_dwt_split_min(1, value);
     if (key && !strcmp(key, "lds_max_log2")) return set_lds_max_log2(value);
     if (key && !strcmp(key, "wave2")) return set_wave2_enabled(value);
     if (key && !strcmp(key, "reg1d")) return set_reg1d_enabled(value);

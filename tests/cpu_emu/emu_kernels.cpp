@@ -21,6 +21,7 @@
 #include "../../pypwt_amd/csrc/nonsep_kernels.hpp"
 #include "../../pypwt_amd/csrc/swt_kernels.hpp"
 #include "../../pypwt_amd/csrc/swt_split_kernels.hpp"
+#include "../../pypwt_amd/csrc/dwt2_split_kernels.hpp"
 
 using namespace pdwt;
 
@@ -834,6 +835,60 @@ EMU_API int emu_swt1_split(int inverse, const float* in0, const float* in1, int 
     switch (hlen) {
 #define X(h) case h: run_swt1_split<h>(in0, in1, Nr, Nc, f, fb, inverse != 0, out0, out1); return 0;
         X(10) X(12) X(16) X(20) X(26) X(40)
+#undef X
+    }
+    return -1;
+}
+
+
+// ---- one DECIMATED level as a row pass + a column pass through scratch (dwt2_split_kernels.hpp).  forward: in (Nr, Nc) ->
+// A, H, V, D (Nr/2, Nc/2); inverse: A, H, V, D -> io (Nr, Nc).  R = output rows per work item of the column kernels.
+template <int HLEN, int R>
+static void run_dwt_split(bool inverse, float* io, int batch, int Nr, int Nc, const FilterBank& fb, float* A, float* H, float* V,
+                          float* D, float* tmp) {
+    constexpr int NT = 256;
+    const int Nr2 = Nr / 2, Nc2 = Nc / 2;
+    DwtSplitArgs k{};
+    k.batch = batch;
+    for (int j = 0; j < HLEN; ++j) k.t.t[j] = mk2(fb.lo[HLEN - 1 - j], fb.hi[HLEN - 1 - j]);
+    std::vector<float> smem(16384, NAN);  // one workgroup's LDS
+    auto blocks = [](long long waves) { return (waves + NT / 64 - 1) / (NT / 64); };
+    const long long img = (long long)Nr * Nc, band = (long long)Nr2 * Nc2;
+    if (!inverse) {
+        const long long plane = (long long)Nr * Nc2;
+        DwtSplitArgs r = k;
+        r.rows = Nr; r.cols = Nc; r.in[0] = io; r.in_bstride = img;
+        r.out[0] = tmp; r.out[1] = tmp + plane; r.out_bstride = 2 * plane;
+        for (long long b = 0; b < blocks(dwt_row_waves(batch, Nr, Nc)); ++b) dwt_row_fwd_tile<HLEN, NT>(r, b, smem.data());
+        DwtSplitArgs c = k;
+        c.rows = Nr; c.cols = Nc2; c.in[0] = tmp; c.in[1] = tmp + plane; c.in_bstride = 2 * plane;
+        c.out[0] = A; c.out[1] = H; c.out[2] = V; c.out[3] = D; c.out_bstride = band;
+        for (long long b = 0; b < blocks(dwt_col_waves(batch, Nr2, Nc2, R)); ++b) dwt_col_fwd_tile<HLEN, R, NT, (R == 4 ? 8 : 2)>(c, b);
+        return;
+    }
+    DwtSplitArgs c = k;
+    c.rows = Nr2; c.cols = Nc2; c.in[0] = A; c.in[1] = H; c.in[2] = V; c.in[3] = D; c.in_bstride = band;
+    c.out[0] = tmp; c.out_bstride = img;
+    for (long long b = 0; b < blocks(dwt_col_waves(batch, Nr, Nc2, R)); ++b) dwt_col_inv_tile<HLEN, R, NT, (R == 4 ? 4 : (R == 2 ? 3 : 2))>(c, b);
+    DwtSplitArgs r = k;
+    r.rows = Nr; r.cols = Nc2; r.in[0] = tmp; r.in_bstride = img; r.out[0] = io; r.out_bstride = img;
+    for (long long b = 0; b < blocks(dwt_row_waves(batch, Nr, Nc)); ++b) dwt_row_inv_tile<HLEN, NT>(r, b, smem.data());
+}
+
+EMU_API int emu_dwt2_split(int inverse, float* io, int batch, int Nr, int Nc, const float* lo, const float* hi, int hlen, int R,
+                           float* A, float* H, float* V, float* D) {
+    if ((Nr & 1) || (Nc & 7) || Nc < 16) return -2;
+    FilterBank fb;
+    set_bank(fb, lo, hi, hlen);
+    std::vector<float> tmp((size_t)Nr * Nc * batch + 16, NAN);
+    switch (hlen) {
+#define X(h)                                                                                              \
+    case h:                                                                                               \
+        if (R == 2) run_dwt_split<h, 2>(inverse != 0, io, batch, Nr, Nc, fb, A, H, V, D, tmp.data());      \
+        else if (R == 4) run_dwt_split<h, 4>(inverse != 0, io, batch, Nr, Nc, fb, A, H, V, D, tmp.data()); \
+        else run_dwt_split<h, 8>(inverse != 0, io, batch, Nr, Nc, fb, A, H, V, D, tmp.data());             \
+        return 0;
+        X(10) X(12) X(14) X(16) X(20) X(22) X(26) X(38) X(40)
 #undef X
     }
     return -1;

@@ -751,3 +751,43 @@ def test_emu_swt_row_kernels_as_the_1d_transform(wname):
         o0 = np.full(shape, np.nan, np.float32)
         assert lib().emu_swt1_split(1, P(x), P(y), shape[0], shape[1], level, P(rlo), P(rhi), hlen, P(o0), None) == 0
         assert np.abs(o0 - r0).max() <= _tol(r0), (wname, shape, level, "inverse")
+
+
+@pytest.mark.parametrize("R", [2, 4, 8])
+@pytest.mark.parametrize("wname", ["db5", "db6", "db7", "sym8", "db10", "db11", "db13", "db19", "db20"])
+def test_emu_dwt_split_row_and_column_launches(wname, R):
+    """dwt2_split_kernels.hpp (one DECIMATED level as a register-blocked row launch + column launch through scratch) vs the
+    oracle's per-pass functions (oracle/pdwt_oracle.c: analysis rows -> columns, synthesis columns -> rows): both parities
+    of hlen / 2 (the synthesis shift), rows shorter and longer than a wavefront's 1024-sample segment, ragged last column
+    groups and row blocks, images smaller than the filter (multiple periodic wraps), batches."""
+    hlen, dlo, dhi, rlo, rhi = oracle.filters(wname)
+    lib_o = oracle.load()
+    cases = [((32, 32), 1), ((34, 48), 2), ((6, 2064), 1), ((2, 1040), 2), ((64, 136), 1), ((50, 264), 1), ((40, 24), 1),
+             ((96, 104), 1), ((24, 16), 3), ((46, 72), 1), ((18, 1024), 1)]
+    for si, (shape, B) in enumerate(cases):
+        Nr, Nc = shape
+        half = (Nr // 2, Nc // 2)
+        x = np.stack([oracle.hash_input(shape, 5100 + 10 * si + b) for b in range(B)]).astype(np.float32)
+        outs = [np.full((B,) + half, np.nan, dtype=np.float32) for _ in range(4)]
+        xin = x.copy()
+        assert lib().emu_dwt2_split(0, P(xin), B, Nr, Nc, P(dlo), P(dhi), hlen, R, *[P(o) for o in outs]) == 0
+        assert np.array_equal(xin, x), "the forward must not touch its input"
+        bands = [(oracle.hash_input((B,) + half, 5500 + si * 4 + k, 2.0) - 1.0).astype(np.float32) for k in range(4)]
+        rec = np.full((B,) + shape, np.nan, dtype=np.float32)
+        assert lib().emu_dwt2_split(1, P(rec), B, Nr, Nc, P(rlo), P(rhi), hlen, R, *[P(b) for b in bands]) == 0
+        for b in range(B):
+            t1 = np.zeros((Nr, half[1]), np.float32); t2 = np.zeros((Nr, half[1]), np.float32)
+            ref = [np.zeros(half, np.float32) for _ in range(4)]
+            lib_o.oracle_analysis_rows(P(x[b]), Nr, Nc, P(dlo), P(dhi), hlen, P(t1), P(t2))
+            lib_o.oracle_analysis_cols(P(t1), Nr, half[1], P(dlo), P(dhi), hlen, P(ref[0]), P(ref[1]))
+            lib_o.oracle_analysis_cols(P(t2), Nr, half[1], P(dlo), P(dhi), hlen, P(ref[2]), P(ref[3]))
+            for k in range(4):
+                assert np.isfinite(outs[k][b]).all(), (wname, shape, k)
+                assert np.abs(outs[k][b] - ref[k]).max() <= _tol(ref[k]), (wname, shape, R, "forward", k)
+            d = [np.ascontiguousarray(bands[k][b]) for k in range(4)]
+            lib_o.oracle_synthesis_cols(P(d[0]), P(d[1]), half[0], half[1], Nr, P(rlo), P(rhi), hlen, P(t1))
+            lib_o.oracle_synthesis_cols(P(d[2]), P(d[3]), half[0], half[1], Nr, P(rlo), P(rhi), hlen, P(t2))
+            want = np.zeros(shape, np.float32)
+            lib_o.oracle_synthesis_rows(P(t1), P(t2), Nr, half[1], Nc, P(rlo), P(rhi), hlen, P(want))
+            assert np.isfinite(rec[b]).all(), (wname, shape, "inverse")
+            assert np.abs(rec[b] - want).max() <= _tol(want), (wname, shape, R, "inverse")

@@ -454,6 +454,86 @@ def test_swt_two_launch_levels(wname, shape, levels, batch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("wname,shape,levels,batch", [("db20", (2048, 2048), 5, 1), ("db20", (1024, 4096), 4, 1), ("db13", (2048, 1024), 5, 1),
+                                                      ("db10", (1024, 1024), 4, 2), ("db16", (4096, 512), 3, 1), ("db9", (1030, 2050), 4, 1),
+                                                      ("db11", (700, 900), 3, 3), ("sym8", (2048, 2048), 5, 1), ("db20", (333, 517), 2, 1)])
+def test_long_filter_tile_shapes_by_level_size(wname, shape, levels, batch, monkeypatch):
+    """Round 4: filters of 10-40 taps pick their LDS tile by level size (launch_dwt2_fast.hip: 32 x 16 / 32 x 8 tiles below
+    2^20 samples, 32 x 32 / 32 x 16 / 64 x 16 above, by filter length).  Plans whose levels cross the threshold, with every
+    level a launch of its own (no pyramids), odd and unaligned sizes, batches: every band and the reconstruction vs the oracle."""
+    from pypwt_amd import BatchedWavelets
+    monkeypatch.setenv("PDWT_NO_PYRAMID", "1")  # read when a plan is built
+    x = np.stack([oracle.hash_input(shape, 340 + b, scale=255.0) for b in range(batch)])
+    bw = BatchedWavelets(batch, shape[0], shape[1], wname, levels, img=x)
+    assert bw.levels == levels and "PYR" not in bw.schedule()
+    bw.forward()
+    refs = [oracle.forward(x[b], wname, levels) for b in range(batch)]
+    for k in range(bw.nbands):
+        g = bw.coeff(k)
+        for b in range(batch):
+            r = refs[b][k]
+            assert np.abs(g[b] - r).max() <= 2e-6 * (levels + 1) * max(float(np.abs(r).max()), 255.0), (wname, b, k)
+    bw.inverse()
+    img = bw.image
+    for b in range(batch):
+        want = oracle.inverse(refs[b], shape, wname, levels)
+        assert np.abs(img[b] - want).max() <= 2e-6 * (levels + 1) * 255.0 * 4, (wname, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("wname,shape,levels,batch", [("sym8", (512, 1024), 4, 1), ("db5", (384, 640), 3, 1), ("db6", (256, 264), 2, 2),
+                                                      ("coif3", (256, 1032), 3, 1), ("db10", (512, 512), 4, 1), ("db13", (336, 400), 2, 1),
+                                                      ("db20", (2048, 2048), 5, 1), ("db20", (160, 1200), 1, 3), ("db7", (96, 80), 2, 1),
+                                                      ("db11", (1024, 4096), 3, 1), ("db16", (4096, 2048), 6, 1)])
+def test_dwt_two_launch_levels(wname, shape, levels, batch):
+    """The two-launch DECIMATED levels (dwt2_split_kernels.hpp: register-blocked row launch + column launch through scratch)
+    forced on for every filter of >= 10 taps at every size: both parities of hlen / 2, rows of less and more than a
+    wavefront's 1024-sample segment, 8 / 4 / 2 output rows per work item (the launcher picks by level size), ragged column
+    groups, levels smaller than the filter, batches; every band and the reconstruction against the oracle.  The launch
+    names must say that the path ran.  (An experiment that measured no faster than LDS tiles of the right shape: the kernels
+    live in the test-only library libpypwt_amd_lab.so -- launch_dwt2_split.hip has the numbers.)"""
+    from pypwt_amd import BatchedWavelets, _lib
+    was_lab = _lib.use_lab_kernels(True)
+    lib = _lib.load()
+    prev = lib.pdwt_set_tuning(b"dwt_split_fwd", 110), lib.pdwt_set_tuning(b"dwt_split_inv", 110)  # 10 taps, at every size
+    os_env = __import__("os").environ
+    had = os_env.get("PDWT_NO_PYRAMID")
+    os_env["PDWT_NO_PYRAMID"] = "1"  # read when a plan is built: every level a LEVEL step
+    try:
+        x = np.stack([oracle.hash_input(shape, 240 + b, scale=255.0) for b in range(batch)])
+        bw = BatchedWavelets(batch, shape[0], shape[1], wname, levels, img=x)
+        assert bw.levels == levels
+        bw.enable_kernel_timing(True)
+        bw.forward()
+        names = [n for n, _ in bw.kernel_times(cap=64)]
+        # a level whose sides stop being (even, multiple of 8) falls back to the tiled kernel
+        assert names and names[0] == "dwt2_fwd_split" and all(n in ("dwt2_fwd_split", "dwt2_fwd_level") for n in names), names
+        bw.reset_kernel_times()
+        refs = []
+        for b in range(batch):
+            ref = oracle.forward(x[b], wname, levels)
+            refs.append(ref)
+            for k, r in enumerate(ref):
+                g = bw.coeff(k)[b]
+                assert np.abs(g - r).max() <= 2e-6 * (levels + 1) * max(float(np.abs(r).max()), 255.0), (wname, b, k)
+        bw.inverse()
+        names = [n for n, _ in bw.kernel_times(cap=64)]
+        assert names and names[-1] == "dwt2_inv_split" and all(n in ("dwt2_inv_split", "dwt2_inv_level") for n in names), names
+        img = bw.image
+        for b in range(batch):
+            want = oracle.inverse(refs[b], shape, wname, levels)
+            assert np.abs(img[b] - want).max() <= 2e-6 * (levels + 1) * 255.0 * 4, (wname, b)
+    finally:
+        lib.pdwt_set_tuning(b"dwt_split_fwd", prev[0])
+        lib.pdwt_set_tuning(b"dwt_split_inv", prev[1])
+        _lib.use_lab_kernels(was_lab)
+        if had is None:
+            os_env.pop("PDWT_NO_PYRAMID", None)
+        else:
+            os_env["PDWT_NO_PYRAMID"] = had
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("wname,shape,levels", [("db5", (3, 5000), 5), ("sym8", (1, 1 << 16), 6), ("db13", (2, 8192), 4),
                                                 ("db20", (5, 4100), 5), ("coif3", (1, 1036), 3)])
 def test_swt_1d_long_filters_on_the_row_kernels(wname, shape, levels):
