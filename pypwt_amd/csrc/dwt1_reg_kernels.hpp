@@ -69,8 +69,20 @@ constexpr Reg1Geom reg1_fwd_geom(int hlen, int K) {
     g.V = 64;
     for (int k = 1; k <= K; ++k) {
         const int n = 16 >> (k - 1);
-        g.e[k] = (c + g.d[k - 1]) & 1;
-        g.d[k] = (g.e[k] + g.d[k - 1] + c) / 2;
+        // Output q of the lane is global output (n/2) L + d[k] + q and reads the lane's window from e[k] = 2 d[k] - c - d[k-1]
+        // on.  The smallest admissible d[k] (e[k] = 0 or 1) leaves the lane's n/2 outputs at an ODD offset for half of the
+        // filter lengths, i.e. 4-B stores: levels 1-3 of 2^24 samples took 37.9 / 33.4 / 35.8 / 40.2 / 42.8 us for 4 / 6 /
+        // 12 / 14 / 20 taps next to 28.1 / 27.9 / 27.0 / 27.4 for 8 / 10 / 16 / 18 (found in round 4, tools/cliffs.py).
+        // d[1] is therefore rounded up to a multiple of 4 (16-B stores of the level-1 details, half of all bytes written): the
+        // window moves up by at most 7 samples (a few more lane shifts) and no filter length loses a valid lane except 6
+        // taps (61 -> 60).  Aligning levels 2 and 3 as well costs one or two valid lanes and measured SLOWER in the step
+        // (sym8 2^24 L6 forward+inverse 57.4 -> 60.2 us, db2 54.4 -> 56.6; profiles/r04o_reg1_align_ab.txt).
+#ifndef PDWT_REG1_ALIGN
+#define PDWT_REG1_ALIGN 1  // 0: smallest offset (rounds 2-3), 1: level 1 only, 2: every level
+#endif
+        const int al = PDWT_REG1_ALIGN == 0 ? 1 : ((PDWT_REG1_ALIGN == 1 && k > 1) ? 1 : (n / 2 < 4 ? n / 2 : 4));
+        g.d[k] = ((c + g.d[k - 1] + 1) / 2 + al - 1) / al * al;
+        g.e[k] = 2 * g.d[k] - c - g.d[k - 1];
         g.E[k] = hlen - 2 + g.e[k];
         g.m[k] = (g.E[k] + n - 1) / n;
         g.V -= g.m[k];

@@ -152,7 +152,12 @@ hipError_t launch_dwt2_fwd(const Fwd2DArgs& a, int batch, hipStream_t s) {
         const hipError_t e = try_launch_dwt2_fwd_fast(a, batch, s);
         if (e != hipErrorNotSupported) return e;
     }
-    if (wave_kernels_for((long long)batch * a.Nr * a.Nc)) {
+    // (fp32, 4 taps: hipcc schedules the wave forward kernel's row loop with an s_waitcnt vmcnt(1) behind its stores, i.e. one
+    // store round trip per four rows -- db2 2048^2 22.6 us against 9.8 us on the LDS tiles, found in round 4 by the reference's
+    // own benchmark plan dwt2 db2 2048^2 L9: 44.7 us; the other lengths are level with the tiles there)
+    // (a threshold forced below its default -- tests -- still takes it)
+    const bool slow4 = sizeof(real_t) == 4 && a.hlen == 4 && get_wave_min_log2() >= kWaveMinDefault;
+    if (wave_kernels_for((long long)batch * a.Nr * a.Nc) && !slow4) {
         const hipError_t e = try_launch_dwt2_fwd_wave(a, batch, s);
         if (e != hipErrorNotSupported) return e;
     }

@@ -135,7 +135,7 @@ hipError_t try_launch_dwt2_fwd_fast(const Fwd2DArgs& a, int batch, hipStream_t s
             if (forced == 8) return run_fwd_fast_tile<h, 64, 32, 512>(a, batch, s);  \
             if (forced == 9) return run_fwd_fast_tile<h, 64, 32, 1024>(a, batch, s); \
         }
-        PDWT_FT(16) PDWT_FT(20) PDWT_FT(26) PDWT_FT(40)
+        PDWT_FT(12) PDWT_FT(16) PDWT_FT(18) PDWT_FT(20) PDWT_FT(22) PDWT_FT(24) PDWT_FT(26) PDWT_FT(28) PDWT_FT(30) PDWT_FT(32) PDWT_FT(36) PDWT_FT(40)
 #undef PDWT_FT
     }
 #endif
@@ -202,7 +202,7 @@ hipError_t try_launch_dwt2_inv_fast(const Inv2DArgs& a, int batch, hipStream_t s
             if (forced == 8) return run_inv_fast<h, 64, 32, 1024>(a, batch, s);  \
             if (forced == 9) return run_inv_fast<h, 32, 32, 1024>(a, batch, s);  \
         }
-        PDWT_IT(16) PDWT_IT(20) PDWT_IT(26) PDWT_IT(40)
+        PDWT_IT(12) PDWT_IT(16) PDWT_IT(18) PDWT_IT(20) PDWT_IT(22) PDWT_IT(24) PDWT_IT(26) PDWT_IT(28) PDWT_IT(30) PDWT_IT(32) PDWT_IT(36) PDWT_IT(40)
 #undef PDWT_IT
     }
 #endif
@@ -215,9 +215,10 @@ hipError_t try_launch_dwt2_inv_fast(const Inv2DArgs& a, int batch, hipStream_t s
         }
     }
     // 10 taps and more (same sweeps as the forward): below 2^20 output samples 32 x 8 coefficient tiles of 256 threads
-    // (40 taps 20.5 -> 6.9 us per level, 26 taps 13.0 -> 6.6, 16-20 taps 8.2 -> 6.6); large levels: 10-16 taps 64 x 16 /
-    // 512 as before, 18-30 taps 32 x 16 / 512 (26 taps 4096^2 76.0 -> 46.0 us, 20 taps 47.3 -> 44-51: level with 32 x 8),
-    // 32+ taps 32 x 8 / 256 (40 taps 4096^2 131.7 -> 89.8, 2048^2 38.4 -> 29.2)
+    // (40 taps 20.5 -> 6.9 us per level, 26 taps 13.0 -> 6.6, 16-20 taps 8.2 -> 6.6); large levels: 10-18 taps 64 x 16 /
+    // 512 as before (18 taps 4096^2: 38.4 against 39.5-40.0); 26 and 30 taps 32 x 16 / 512 (76.0 -> 46.0, 30 taps 52.9
+    // against 55.2); every other length 32 x 8 / 256 (20 taps 47.3 -> 44.0, 22: 47.8 -> 43.0, 24: 57.6 -> 52.1, 28: 65.3 ->
+    // 60.6, 32: 97.3 -> 73.2, 36: 105.7 -> 73.8, 40: 131.7 -> 89.8, 2048^2 38.4 -> 29.2); profiles/r04p_tilesweep3.txt
     const bool small_level = (long long)batch * a.Nr * a.Nc < (1LL << 20);
     switch (a.hlen) {
 #define X(h)                                                                \
@@ -227,8 +228,8 @@ hipError_t try_launch_dwt2_inv_fast(const Inv2DArgs& a, int batch, hipStream_t s
             if constexpr (h <= 20) return run_inv_fast<h, 64, 16, 512>(a, batch, s); \
             else return run_inv_fast<h, 32, 8, 256>(a, batch, s);                \
         } else if (small_level) return run_inv_fast<h, 32, 8, 256>(a, batch, s);  \
-        else if constexpr (h <= 16) return run_inv_fast<h, 64, 16, 512>(a, batch, s); \
-        else if constexpr (h <= 30) return run_inv_fast<h, 32, 16, 512>(a, batch, s); \
+        else if constexpr (h <= 18) return run_inv_fast<h, 64, 16, 512>(a, batch, s); \
+        else if constexpr (h == 26 || h == 30) return run_inv_fast<h, 32, 16, 512>(a, batch, s); \
         else return run_inv_fast<h, 32, 8, 256>(a, batch, s);
         PDWT_EVEN_HLENS(X)
 #undef X

@@ -20,7 +20,7 @@ hipError_t launch_swt2_split(const Swt2DArgs&, real_t*, bool, int, hipStream_t) 
 #else
 
 // filter lengths the split kernels are built for
-#define PDWT_SPLIT_HLENS(X) X(10) X(12) X(14) X(16) X(18) X(20) X(22) X(24) X(26) X(28) X(30) X(32) X(34) X(36) X(38) X(40)
+#define PDWT_SPLIT_HLENS(X) X(4) X(6) X(8) X(10) X(12) X(14) X(16) X(18) X(20) X(22) X(24) X(26) X(28) X(30) X(32) X(34) X(36) X(38) X(40)
 
 static inline v2f mk2h(real_t a, real_t b) {
     v2f r;
@@ -58,8 +58,13 @@ bool swt2_split_supported(int hlen, int Nr, int Nc, int f, bool inverse, long lo
         // 1024^2: 12 taps 24 | 23, 16 taps 28 | 25, 20 taps 35 | 28 (profiles/r03_swt_split_sweep.txt)
         if (samples < (1LL << 20) && min_taps < 24) min_taps = 24;
         else if (samples < (1LL << 22) && min_taps < 12) min_taps = 12;
+        // 8 taps (db4, sym4, bior2.4 ...), dilation 1 and 2, from 2048^2 on: the tiled inverse issues one 16-B load per band and
+        // tap at 4-B / 8-B alignment there (52-55 us per 2048^2 level against 33 at dilation 4, where the loads are aligned);
+        // the two launches stage aligned quads through LDS: 35.6 / 33.4 us, 4096^2 190.8 / 199.2 -> 140.8 / 164.6
+        // (profiles/r04m_swt_short_sweep2.txt).  6 taps: level (2048^2) or behind (4096^2, 1024^2); 4 taps: behind.
+        else if (hlen == 8 && f <= 2 && min_taps <= 10) min_taps = 8;
     }
-    if ((hlen & 1) || hlen < 10 || hlen > kMaxTaps || hlen < min_taps) return false;
+    if ((hlen & 1) || hlen < 4 || hlen > kMaxTaps || hlen < min_taps) return false;
     if ((Nc & 3) || f < 1 || f >= Nr || f >= Nc || Nc < 16) return false;
     if (f != 1 && f != 2 && (f & 3)) return false;
     return true;
@@ -140,8 +145,14 @@ static hipError_t run_split1(const SwtPassArgs& a, bool inverse, hipStream_t s) 
 }
 
 hipError_t try_launch_swt1_split(const SwtPassArgs& a, bool inverse, hipStream_t s) {
-    static const int min_taps = env_int("PDWT_SWT1_SPLIT", 10);  // shortest filter on this path, 0 = never (A/B measurements)
-    if (a.along_y || min_taps <= 0 || (a.hlen & 1) || a.hlen < 10 || a.hlen < min_taps || a.hlen > kMaxTaps) return hipErrorNotSupported;
+    // shortest filter on this path, 0 = never (A/B measurements): forward from 10 taps, inverse from PDWT_SWT1_SPLIT_INV
+    static const int min_fwd = env_int("PDWT_SWT1_SPLIT", 10), min_inv = env_int("PDWT_SWT1_SPLIT_INV", 10);
+    int min_taps = inverse ? min_inv : min_fwd;
+    // the (batched) 1D inverse of 6 and 8 taps from 2^22 samples on: 2^24 samples x 4 levels db4 208 -> 167 us, db3 176 -> 162;
+    // 4096 rows of 4096: db4 252 -> 156, db3 219 -> 155; at 2^20 samples the vec kernels stay ahead (21 against 29 us); 4 taps:
+    // behind on one long row (129 -> 147)
+    if (inverse && min_taps == 10 && a.hlen >= 6 && (long long)a.Nr * a.Nc >= (1LL << 22)) min_taps = 6;
+    if (a.along_y || min_taps <= 0 || (a.hlen & 1) || a.hlen < 4 || a.hlen < min_taps || a.hlen > kMaxTaps) return hipErrorNotSupported;
     if ((a.Nc & 3) || a.Nc < 16 || a.f < 1 || a.f >= a.Nc || (a.f != 1 && a.f != 2 && (a.f & 3))) return hipErrorNotSupported;
     auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     if (!al16(a.in0) || !al16(a.out0) || (inverse ? !al16(a.in1) : !al16(a.out1))) return hipErrorNotSupported;

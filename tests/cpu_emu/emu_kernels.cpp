@@ -795,7 +795,7 @@ EMU_API int emu_swt2_split(int inverse, float* io, int batch, int Nr, int Nc, in
     std::vector<float> tmp((size_t)2 * Nr * Nc * batch + 16, NAN);
     switch (hlen) {
 #define X(h) case h: run_swt_split<h>(a, batch, inverse != 0, tmp.data()); return 0;
-        X(10) X(12) X(16) X(20) X(26) X(40)
+        X(4) X(6) X(8) X(10) X(12) X(16) X(20) X(26) X(40)
 #undef X
     }
     return -1;
@@ -834,7 +834,7 @@ EMU_API int emu_swt1_split(int inverse, const float* in0, const float* in1, int 
     set_bank(fb, lo, hi, hlen);
     switch (hlen) {
 #define X(h) case h: run_swt1_split<h>(in0, in1, Nr, Nc, f, fb, inverse != 0, out0, out1); return 0;
-        X(10) X(12) X(16) X(20) X(26) X(40)
+        X(4) X(6) X(8) X(10) X(12) X(16) X(20) X(26) X(40)
 #undef X
     }
     return -1;

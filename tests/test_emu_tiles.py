@@ -683,7 +683,7 @@ def test_emu_swt4_fused_forward_and_inverse(wname):
 
 
 @pytest.mark.parametrize("direct", [0, 1])
-@pytest.mark.parametrize("wname", ["db5", "db6", "sym8", "db10", "db13", "db20"])
+@pytest.mark.parametrize("wname", ["db2", "db3", "db4", "db5", "db6", "sym8", "db10", "db13", "db20"])
 def test_emu_swt_split_row_and_column_launches(wname, direct, monkeypatch):
     """swt_split_kernels.hpp (one a-trous level as a register-blocked row launch + column launch through scratch) vs the
     oracle's per-pass functions: dilations 1, 2 (16 consecutive columns per work item) and 4, 8, 16 (quads one dilation
@@ -730,7 +730,7 @@ def test_emu_swt_split_row_and_column_launches(wname, direct, monkeypatch):
                 assert np.abs(rec[b] - want).max() <= _tol(want), (wname, shape, level, "inverse", beta)
 
 
-@pytest.mark.parametrize("wname", ["db5", "sym8", "db13", "db20"])
+@pytest.mark.parametrize("wname", ["db2", "db3", "db4", "db5", "sym8", "db13", "db20"])
 def test_emu_swt_row_kernels_as_the_1d_transform(wname):
     """the row kernels of swt_split_kernels.hpp on separate approximation / detail planes (the batched 1D SWT): the inverse
     interleaves the two planes while staging them in LDS (dilation 1, 2, 4) or packs over column pairs (dilation >= 8)"""

@@ -1,0 +1,91 @@
+#!/usr/bin/env python3
+"""Performance-cliff hunt: forward and forward+inverse times (pipelined, device-resident) of a grid of plans -- transform x
+wavelet x size x levels -- with the fraction of the per-level streaming rate each amounts to, so that a dispatch choice that
+is 2x off its neighbours stands out (round 4 found the 4-tap forward wave kernel that way: db2 2048^2 22.6 us next to
+db1 8.5 and db3 11.1).
+
+    python3 tools/cliffs.py [dwt2] [swt2] [dwt1] [swt1] > profiles/r04_cliffs.txt
+"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pypwt_amd import BatchedWavelets  # noqa: E402
+
+PEAK = 8.0e12
+WAVELETS = ["haar", "db2", "db3", "db4", "db5", "db6", "db7", "sym8", "db10", "db13", "db16", "db20", "bior2.2", "bior3.5", "coif3"]
+
+
+def streaming_bytes(what, n, levels):
+    if what == "dwt2":
+        return sum(8.0 * n / 4 ** l for l in range(levels))
+    if what == "swt2":
+        return 20.0 * n * levels
+    if what == "swt1":
+        return 12.0 * n * levels
+    return sum(8.0 * n / 2 ** l for l in range(levels))
+
+
+def timed(fn, sync, n):
+    for _ in range(3):
+        fn()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    sync()
+    return (time.perf_counter() - t0) / n
+
+
+def case(what, wname, shape, levels, batch=1):
+    swt = 1 if what.startswith("swt") else 0
+    ndim = 1 if what.endswith("1") else 2
+    try:
+        p = BatchedWavelets(batch, shape[0], shape[1], wname, levels, do_swt=swt, ndim=ndim)
+    except Exception as e:  # noqa: BLE001
+        print("%-5s %-8s %-12s  FAILED %r" % (what, wname, "%dx%d" % shape, e))
+        return
+    p.fill_hash(5)
+    n = shape[0] * shape[1] * batch
+    reps = 200 if n <= (1 << 22) else 40
+
+    def fi():
+        p.forward()
+        p.inverse()
+    tf = timed(p.forward, p.synchronize, reps)
+    tfi = timed(fi, p.synchronize, reps)
+    b = streaming_bytes(what, float(n), p.levels)
+    print("%-5s %-8s %-12s B=%-2d L=%-2d  fwd %8.1f us (%.3f)  fwd+inv %8.1f us (%.3f)  inv ~%7.1f us   %s"
+          % (what, wname, "%dx%d" % shape, batch, p.levels, tf * 1e6, b / tf / PEAK, tfi * 1e6, 2 * b / tfi / PEAK, (tfi - tf) * 1e6,
+             p.schedule().replace("\n", " | ")), flush=True)
+    p.cleanup()
+
+
+def main():
+    which = [a for a in sys.argv[1:] if not a.startswith("-")] or ["dwt2", "swt2", "dwt1", "swt1"]
+    print("# tools/cliffs.py: pipelined kernel time per call, (fraction of the per-level streaming rate at 8 TB/s)")
+    if "dwt2" in which:
+        for shape, L in (((512, 512), 3), ((1024, 1024), 3), ((2048, 2048), 3), ((4096, 4096), 3), ((2048, 2048), 1), ((4096, 4096), 1),
+                         ((1000, 1000), 3), ((3000, 2000), 3)):
+            for w in WAVELETS:
+                case("dwt2", w, shape, L)
+        for w in ("haar", "db2", "db4", "sym8"):
+            case("dwt2", w, (4096, 4096), 4, batch=4)
+            case("dwt2", w, (2048, 2048), 4, batch=16)
+    if "swt2" in which:
+        for shape, L in (((512, 512), 3), ((1024, 1024), 3), ((2048, 2048), 3), ((2048, 2048), 1)):
+            for w in WAVELETS:
+                case("swt2", w, shape, L)
+    if "dwt1" in which:
+        for shape, L in (((1, 1 << 20), 5), ((1, 1 << 24), 6), ((4096, 4096), 5), ((512, 2048), 4)):
+            for w in WAVELETS:
+                case("dwt1", w, shape, L)
+    if "swt1" in which:
+        for shape, L in (((1, 1 << 20), 4), ((1, 1 << 24), 4), ((4096, 4096), 4)):
+            for w in WAVELETS:
+                case("swt1", w, shape, L)
+
+
+if __name__ == "__main__":
+    main()

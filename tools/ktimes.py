@@ -2,7 +2,10 @@
 python tools/ktimes.py wname rows cols levels [batch [do_swt]]"""
 import sys
 sys.path.insert(0, '.')
-from pypwt_amd import BatchedWavelets
+import os
+from pypwt_amd import BatchedWavelets, _lib
+if os.environ.get("PDWT_USE_LAB"):
+    _lib.use_lab_kernels(True)
 wname, r, c, L = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
 B = int(sys.argv[5]) if len(sys.argv) > 5 else 1
 swt = int(sys.argv[6]) if len(sys.argv) > 6 else 0

@@ -24,7 +24,8 @@ def main():
     names = sys.argv[4].split(",") if len(sys.argv) > 4 else ["db5", "db6", "db7", "sym8", "db9", "db10", "db11", "db12", "db13", "db14", "db15", "db16", "db17", "db18", "db19", "db20"]
     for w in names:
         fo, io = run(w, r, c, L, {"PDWT_SWT_SPLIT_FWD": "0", "PDWT_SWT_SPLIT_INV": "0"})
-        fn, inn = run(w, r, c, L, {"PDWT_SWT_SPLIT_FWD": "110", "PDWT_SWT_SPLIT_INV": "110"})
+        force = os.environ.get("SWTSWEEP_FORCE", "110")  # 100 + n: n taps and more on the split kernels at every size
+        fn, inn = run(w, r, c, L, {"PDWT_SWT_SPLIT_FWD": force, "PDWT_SWT_SPLIT_INV": force})
         fmt = lambda v: " ".join("%6.1f" % x for x in v)
         print("%-5s fwd %s | %s   inv %s | %s   sum fwd %.0f | %.0f  inv %.0f | %.0f" % (w, fmt(fo), fmt(fn), fmt(io), fmt(inn), sum(fo), sum(fn), sum(io), sum(inn)), flush=True)
 
