@@ -227,7 +227,9 @@ int pdwt_time_level(pdwt_handle h, int level, int inverse, int reps, float* ms_p
 int pdwt_time_copy(pdwt_handle h, long long elems, int reps, float* ms_per_launch);
 /* NEW: process-wide dispatch knobs (tests and A/B measurements; no counterpart in the reference, whose
  * kernel choice is fixed at compile time, pdwt/src/wt.cu:236-305).  Returns the previous value, or
- * PDWT_ERR_ARG for an unknown key.  Keys:
+ * PDWT_ERR_ARG for an unknown key.  Every key is read ONCE PER PLAN, when the plan is created (pdwt_create*, pdwt_clone
+ * copies its source's): a plan keeps the values it was built with, so threads driving plans with different settings -- or a
+ * thread that moves a knob -- cannot change another plan's kernel choice in mid-transform.  Keys:
  *   "wave_min_log2"  a 2D DWT level runs on the wave-per-tile kernels when at least 2^value samples
  *                    enter it (default 22, fp64 library 16; 0 = always when eligible; 63 = never)
  *   "lds_max_log2"   a 2D DWT level of at most 2^value samples (one cache-resident image) prefers the LDS tiles to
@@ -236,18 +238,18 @@ int pdwt_time_copy(pdwt_handle h, long long elems, int reps, float* ms_per_launc
  *                    (dwt1_reg_kernels.hpp) where the rows qualify (even hlen <= 20, rows of >= 2048 samples that
  *                    are multiples of 32); default 3; 0 = the workgroup-wide LDS pyramids (57.6 vs 69.5 us per
  *                    forward+inverse on 2^24 samples); the forward uses them up to 2^25 samples per plan (a batch of
- *                    long rows is faster through the LDS pyramid), bit 2 lifts that limit.  Read when a plan is created.
+ *                    long rows is faster through the LDS pyramid), bit 2 lifts that limit.  
  *   "swt_fused"      1 (default): 2D SWT plans whose 3L+2 planes about fit the Infinity Cache (<= 320 MiB) run several
  *                    levels per launch in registers: 2-tap banks (haar) levels 1-3 and 4-6 (swt2_fused_kernels.hpp: 11 / 8
  *                    instead of 15 / 10 planes of traffic), 4-tap banks (db2, sym2, custom) levels (1, 2) and (3, 4)
  *                    (swt2_fused4_kernels.hpp: 8 instead of 10 planes per pair); 2: at any size; 0: a launch per level.
- *                    Read when a plan is created.
+ *                    
  *   "swt_split_fwd" / "swt_split_inv"   the shortest (even) filter whose 2D SWT levels run as a register-blocked row
  *                    launch + column launch through scratch (swt_split_kernels.hpp) instead of one LDS-tiled launch:
  *                    defaults 18 / 10 taps (where the two launches are faster on MI355X: 40 taps 127-158 -> 46 us per 2048^2
  *                    forward level, 16 taps 93 -> 40 us per inverse level); the inverse of images below 1024^2 / 2048^2 starts at 24 / 12 taps
  *                    (two one-round launches cost more than they save there); 0 = never; 100 + n = n taps at every size (tests).
- *                    Read at every level launch.
+ *                    Part of the plan's snapshot.
  *   "dwt_split_fwd" / "dwt_split_inv"   the shortest (even) filter whose DECIMATED 2D levels run as a register-blocked row
  *                    launch + column launch through scratch (dwt2_split_kernels.hpp; rows and columns even, columns a
  *                    multiple of 8) instead of one LDS-tiled launch.  Default 0 (never): measured no faster than LDS tiles

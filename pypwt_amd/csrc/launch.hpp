@@ -15,6 +15,24 @@ namespace pdwt {
 // element-wise operator codes of launch_ew
 enum EwOp { EW_SOFT = 0, EW_HARD = 1, EW_LINF = 2, EW_SCALE = 3 };
 
+// Dispatch knobs that a level LAUNCH consults (pdwt_set_tuning).  A plan takes a snapshot when it is created and makes it
+// the calling thread's active set around its launches, so that two threads driving plans with different settings -- or a
+// third thread calling pdwt_set_tuning -- cannot change each other's kernel choice in mid-transform; with no active set
+// (direct calls of the launchers: tools, emulation) the process-wide values apply.
+struct Tuning {
+    int wave_min_log2, lds_max_log2, swt_split_fwd, swt_split_inv, dwt_split_fwd, dwt_split_inv;
+};
+Tuning current_tuning();                  // the process-wide values now
+void set_active_tuning(const Tuning* t);  // thread-local; nullptr = the process-wide values
+const Tuning* active_tuning();
+int get_swt_split_min(int inverse);
+int get_dwt_split_min(int inverse);
+struct ActiveTuning {  // RAII: the plan's snapshot for the duration of a forward / inverse
+    const Tuning* prev;
+    explicit ActiveTuning(const Tuning* t) : prev(active_tuning()) { set_active_tuning(t); }
+    ~ActiveTuning() { set_active_tuning(prev); }
+};
+
 hipError_t launch_dwt2_fwd(const Fwd2DArgs& a, int batch, hipStream_t s);
 hipError_t launch_dwt2_inv(const Inv2DArgs& a, int batch, hipStream_t s);
 // tuned kernels; hipErrorNotSupported = preconditions not met, use the generic launcher

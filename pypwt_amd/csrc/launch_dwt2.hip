@@ -119,8 +119,12 @@ int set_chain_enabled(int value) { return chain_flag().exchange(value < 0 ? 0 : 
 int get_chain_enabled() { return chain_flag().load(std::memory_order_relaxed); }
 int set_wave2_enabled(int value) { return wave2_flag().exchange(value ? 1 : 0); }
 int get_wave2_enabled() { return wave2_flag().load(std::memory_order_relaxed); }
+static thread_local const Tuning* g_active_tuning = nullptr;
+void set_active_tuning(const Tuning* t) { g_active_tuning = t; }
+const Tuning* active_tuning() { return g_active_tuning; }
+static int eff_wave_min_log2() { return g_active_tuning ? g_active_tuning->wave_min_log2 : wave_min_log2().load(std::memory_order_relaxed); }
 static bool wave_kernels_for(long long samples) {
-    const int m = wave_min_log2().load(std::memory_order_relaxed);
+    const int m = eff_wave_min_log2();
     return m < 63 && samples >= (1LL << m);
 }
 
@@ -143,8 +147,19 @@ int get_lds_max_log2() { return lds_max_log2().load(std::memory_order_relaxed); 
 static bool lds_tiles_for(long long samples, int hlen) {
     // ... and only above 2^22 samples: in the step the 2048^2 level of cfg2 is 0.3-0.4 us faster on the wave kernels
     // (10.6 / 11.6 against 11.0 / 11.9 us event-timed), the 4096^2 level 1.0 / 0.3 us faster on the tiles
-    const int m = lds_max_log2().load(std::memory_order_relaxed);
+    const int m = g_active_tuning ? g_active_tuning->lds_max_log2 : lds_max_log2().load(std::memory_order_relaxed);
     return m > 0 && !(hlen & 1) && samples > (1LL << 22) && samples <= (1LL << m);
+}
+
+Tuning current_tuning() {
+    Tuning t;
+    t.wave_min_log2 = get_wave_min_log2();
+    t.lds_max_log2 = get_lds_max_log2();
+    t.swt_split_fwd = get_swt_split_min(0);
+    t.swt_split_inv = get_swt_split_min(1);
+    t.dwt_split_fwd = get_dwt_split_min(0);
+    t.dwt_split_inv = get_dwt_split_min(1);
+    return t;
 }
 
 hipError_t launch_dwt2_fwd(const Fwd2DArgs& a, int batch, hipStream_t s) {
@@ -156,7 +171,7 @@ hipError_t launch_dwt2_fwd(const Fwd2DArgs& a, int batch, hipStream_t s) {
     // store round trip per four rows -- db2 2048^2 22.6 us against 9.8 us on the LDS tiles, found in round 4 by the reference's
     // own benchmark plan dwt2 db2 2048^2 L9: 44.7 us; the other lengths are level with the tiles there)
     // (a threshold forced below its default -- tests -- still takes it)
-    const bool slow4 = sizeof(real_t) == 4 && a.hlen == 4 && get_wave_min_log2() >= kWaveMinDefault;
+    const bool slow4 = sizeof(real_t) == 4 && a.hlen == 4 && eff_wave_min_log2() >= kWaveMinDefault;
     if (wave_kernels_for((long long)batch * a.Nr * a.Nc) && !slow4) {
         const hipError_t e = try_launch_dwt2_fwd_wave(a, batch, s);
         if (e != hipErrorNotSupported) return e;

@@ -134,8 +134,12 @@ hipError_t try_launch_dwt2_fwd_fast(const Fwd2DArgs& a, int batch, hipStream_t s
             if (forced == 7) return run_fwd_fast_tile<h, 64, 16, 256>(a, batch, s);  \
             if (forced == 8) return run_fwd_fast_tile<h, 64, 32, 512>(a, batch, s);  \
             if (forced == 9) return run_fwd_fast_tile<h, 64, 32, 1024>(a, batch, s); \
+            if (forced == 10) return run_fwd_fast_tile<h, 64, 8, 128>(a, batch, s);  \
+            if (forced == 11) return run_fwd_fast_tile<h, 32, 8, 64>(a, batch, s);   \
+            if (forced == 12) return run_fwd_fast_tile<h, 128, 8, 512>(a, batch, s); \
+            if (forced == 13) return run_fwd_fast_tile<h, 128, 16, 1024>(a, batch, s); \
         }
-        PDWT_FT(12) PDWT_FT(16) PDWT_FT(18) PDWT_FT(20) PDWT_FT(22) PDWT_FT(24) PDWT_FT(26) PDWT_FT(28) PDWT_FT(30) PDWT_FT(32) PDWT_FT(36) PDWT_FT(40)
+        PDWT_FT(4) PDWT_FT(8) PDWT_FT(12) PDWT_FT(16) PDWT_FT(18) PDWT_FT(20) PDWT_FT(22) PDWT_FT(24) PDWT_FT(26) PDWT_FT(28) PDWT_FT(30) PDWT_FT(32) PDWT_FT(36) PDWT_FT(40)
 #undef PDWT_FT
     }
 #endif
@@ -201,8 +205,12 @@ hipError_t try_launch_dwt2_inv_fast(const Inv2DArgs& a, int batch, hipStream_t s
             if (forced == 7) return run_inv_fast<h, 64, 16, 1024>(a, batch, s);  \
             if (forced == 8) return run_inv_fast<h, 64, 32, 1024>(a, batch, s);  \
             if (forced == 9) return run_inv_fast<h, 32, 32, 1024>(a, batch, s);  \
+            if (forced == 10) return run_inv_fast<h, 64, 8, 128>(a, batch, s);   \
+            if (forced == 11) return run_inv_fast<h, 32, 8, 128>(a, batch, s);   \
+            if (forced == 12) return run_inv_fast<h, 128, 8, 256>(a, batch, s);  \
+            if (forced == 13) return run_inv_fast<h, 128, 16, 512>(a, batch, s); \
         }
-        PDWT_IT(12) PDWT_IT(16) PDWT_IT(18) PDWT_IT(20) PDWT_IT(22) PDWT_IT(24) PDWT_IT(26) PDWT_IT(28) PDWT_IT(30) PDWT_IT(32) PDWT_IT(36) PDWT_IT(40)
+        PDWT_IT(4) PDWT_IT(8) PDWT_IT(12) PDWT_IT(16) PDWT_IT(18) PDWT_IT(20) PDWT_IT(22) PDWT_IT(24) PDWT_IT(26) PDWT_IT(28) PDWT_IT(30) PDWT_IT(32) PDWT_IT(36) PDWT_IT(40)
 #undef PDWT_IT
     }
 #endif

@@ -37,6 +37,7 @@ static std::atomic<int>& dsplit_min(bool inverse) {
     return inverse ? inv : fwd;
 }
 int set_dwt_split_min(int inverse, int taps) { return dsplit_min(inverse != 0).exchange(taps < 0 ? 0 : taps); }
+int get_dwt_split_min(int inverse) { return dsplit_min(inverse != 0).load(std::memory_order_relaxed); }
 
 #if defined(PDWT_DOUBLE) || !defined(PDWT_LAB_KERNELS)
 bool dwt2_split_supported(int, int, int, bool, long long) { return false; }
@@ -56,7 +57,8 @@ static inline v2f mk2d(real_t a, real_t b) {
 
 // (Nr, Nc): the level's image side (forward: its input, inverse: its output); samples: over the whole batch
 bool dwt2_split_supported(int hlen, int Nr, int Nc, bool inverse, long long samples) {
-    int min_taps = dsplit_min(inverse).load(std::memory_order_relaxed);
+    const Tuning* at = active_tuning();
+    int min_taps = at ? (inverse ? at->dwt_split_inv : at->dwt_split_fwd) : dsplit_min(inverse).load(std::memory_order_relaxed);
     if (min_taps <= 0) return false;
     if (min_taps >= 100) {
         min_taps -= 100;  // forced: the same threshold at every size (tests)

@@ -16,6 +16,7 @@ namespace pdwt {
 bool swt2_split_supported(int, int, int, int, bool, long long) { return false; }
 hipError_t try_launch_swt1_split(const SwtPassArgs&, bool, hipStream_t) { return hipErrorNotSupported; }
 int set_swt_split_min(int, int) { return 0; }
+int get_swt_split_min(int) { return 0; }
 hipError_t launch_swt2_split(const Swt2DArgs&, real_t*, bool, int, hipStream_t) { return hipErrorNotSupported; }
 #else
 
@@ -44,9 +45,11 @@ static std::atomic<int>& split_min(bool inverse) {
     return inverse ? inv : fwd;
 }
 int set_swt_split_min(int inverse, int taps) { return split_min(inverse != 0).exchange(taps < 0 ? 0 : taps); }
+int get_swt_split_min(int inverse) { return split_min(inverse != 0).load(std::memory_order_relaxed); }
 
 bool swt2_split_supported(int hlen, int Nr, int Nc, int f, bool inverse, long long samples) {
-    int min_taps = split_min(inverse).load(std::memory_order_relaxed);
+    const Tuning* at = active_tuning();  // the calling plan's snapshot, else the process-wide value
+    int min_taps = at ? (inverse ? at->swt_split_inv : at->swt_split_fwd) : split_min(inverse).load(std::memory_order_relaxed);
     if (min_taps <= 0) return false;
     if (Nr % f) {
         min_taps = 10;  // rows the dilation does not divide: the alternative is three direct passes (one load per tap and output)

@@ -376,6 +376,7 @@ int create_impl(const real_t* img, int batch, int Nr, int Nc, const char* wname,
         p->own_stream = true;
     }
     if ((rc = build_layout(p)) != PDWT_OK) return bail(rc);
+    p->tune = current_tuning();
     build_schedule(p);
     if (img) {
         hipError_t e = hipMemcpyAsync(p->image(), img, (size_t)batch * Nr * Nc * sizeof(real_t),
@@ -445,8 +446,12 @@ void build_schedule(pdwt_plan* p) {
         // 18.4 us, 64 x 128^2 db4 L3: 27.0 -> 20.3 us; at 1024^2 the pairs are ahead (db4 L3: 18.6 against 20.4 us).  Four levels left stay two tile
         // pyramids.  PDWT_NO_PYR3=1 keeps the pairs (A/B measurements).
         const bool no_pyr3 = no_pyr || getenv("PDWT_NO_PYR3") != nullptr;
-        auto pyr3_at = [&](int l) {
+        auto pyr3_at = [&](int l, bool inverse) {
             const int left = L - l + 1;
+            // (round 4: the FORWARD three-level kernel of 10-16 taps is behind three launches of the small LDS tiles of
+            // launch_dwt2_fast.hip -- sym8 256^2: 11.0 against 9-10 us, 16 images of 256^2: 44.8 against 15.6 us; the inverse
+            // stays ahead: 5.3 against 12.1 us; profiles/r04r_cliffs_batch_odd.txt)
+            if (!inverse && hlen > 8 && getenv("PDWT_PYR3_FWD_LONG") == nullptr) return false;  // (the knob: tests keep the kernel covered)
             // filters of 10-16 taps recompute a 16x larger halo: ahead up to 512^2 only (sym8 512^2 L3: 21.6 against 25.0 us,
             // 1024 x 512: 37.3 against 25.4 us; profiles/r02y_pyr3_sweep.txt)
             const long long per_image = hlen <= 8 ? (1LL << 19) : (1LL << 18);
@@ -459,7 +464,7 @@ void build_schedule(pdwt_plan* p) {
         // issue-bound, and the second level's shifts, descriptors and 4-B stores add 50 % instructions for 20 %
         // fewer bytes.  Opt-in only: PDWT_WAVE2=1 or pdwt_set_tuning("wave2", 1) (tests keep it covered).
         const bool wave2_on = get_wave2_enabled() != 0;
-        const int wmin = get_wave_min_log2();
+        const int wmin = p->tune.wave_min_log2;
         auto wave2_at = [&](int l, bool inverse) {
             return fusable && !inverse && wave2_on && wmin < 63 && l + 1 <= L && samples(l) >= (1LL << wmin) &&
                    dwt2_wave2_supported(hlen, p->lr[l - 1], p->lc[l - 1]);
@@ -527,7 +532,7 @@ void build_schedule(pdwt_plan* p) {
                 if (const int K = p->chain_flags ? chain_at(l, dir != 0) : 0) { out.push_back({Step::CHAIN, l, K}); l += K - 1; continue; }
                 if (strip_at(l, dir != 0)) { out.push_back({Step::STRIP2, l, 2}); l++; }
                 else if (wave2_at(l, dir != 0)) { out.push_back({Step::WAVE2, l, 2}); l++; }
-                else if (pyr3_at(l)) { out.push_back({Step::PYR3, l, 3}); l += 2; }
+                else if (pyr3_at(l, dir != 0)) { out.push_back({Step::PYR3, l, 3}); l += 2; }
                 else if ((pyr_at(l) && !strip_at(l + 1, dir != 0)) || (inv_pyr_l1 && dir == 1 && l == 1 && fusable && pair_ok(l))) { out.push_back({Step::PYR2, l, 2}); l++; }
                 else out.push_back({Step::LEVEL, l, 1});
             }
@@ -836,6 +841,7 @@ int inv_level_1d(pdwt_plan* p, int l, bool run) {
 // only == 0: every step; only == l: just the launch whose first (finest) level is l (pdwt_time_level)
 int forward_impl(pdwt_plan* p, int only = 0) {
     using pdwt::Step;
+    const ActiveTuning tuning_guard(&p->tune);
     const int L = p->info.nlevels, B = p->batch, hlen = p->info.hlen;
     const bool two_d = p->info.ndims == 2;
     for (const Step& s : p->sched_fwd) {
@@ -906,6 +912,7 @@ int forward_impl(pdwt_plan* p, int only = 0) {
 
 int inverse_impl(pdwt_plan* p, int only = 0) {
     using pdwt::Step;
+    const ActiveTuning tuning_guard(&p->tune);
     const int B = p->batch, hlen = p->info.hlen;
     const bool two_d = p->info.ndims == 2;
     for (const Step& s : p->sched_inv) {
@@ -1143,6 +1150,7 @@ int pdwt_clone(pdwt_handle src, pdwt_handle* out) {
     p->own_stream = true;
     int rc = build_layout(p);
     if (rc != PDWT_OK) { pdwt_destroy(p); return rc; }
+    p->tune = src->tune;
     build_schedule(p);  // not copied: a chain step needs the clone's own hand-off flags
     e = hipStreamSynchronize(src->stream);
     if (e == hipSuccess)

@@ -23,6 +23,7 @@
 
 #include "../../include/pypwt_amd.h"
 #include "kernels_common.hpp"
+#include "launch.hpp"
 
 namespace pdwt {
 
@@ -91,6 +92,7 @@ struct pdwt_plan {
     int consumed_normalize = 0;
 
     std::vector<pdwt::Step> sched_fwd, sched_inv;  // launch lists, in execution order
+    pdwt::Tuning tune{};  // the dispatch knobs as they stood when the plan was created (launch.hpp: ActiveTuning)
     // Step::CHAIN (several levels in one launch, dwt2_chain_kernels.hpp): per-tile hand-off flags of the forward and of the
     // inverse chain, batch x chain_tiles words each, zeroed once; every launch stamps them with a new epoch
     unsigned* chain_flags = nullptr;

@@ -815,3 +815,40 @@ def test_consumed_threshold_is_written_back_for_clone_and_set_image(W):
     for num in range(1, 10):
         g = w.coeff_only(num)
         assert np.abs(g - ref[num]).max() <= tol(ref[num]), "band %d read after set_image is not thresholded" % num
+
+
+@pytest.mark.gpu
+def test_plan_keeps_the_tuning_it_was_created_with():
+    """dispatch knobs are snapshotted per plan.  Plan A is built with the two-launch SWT levels
+    forced on, plan B with them off; then the knob is moved again and both plans run concurrently from two threads: A still
+    takes the split kernels, B the tiled ones, and both match the oracle."""
+    import threading
+    from pypwt_amd import BatchedWavelets, _lib
+    lib = _lib.load()
+    x = oracle.hash_input((128, 192), 911, scale=255.0)
+    prev = lib.pdwt_set_tuning(b"swt_split_fwd", 110)
+    try:
+        A = BatchedWavelets(1, 128, 192, "db6", 2, do_swt=1, img=x[None])
+        lib.pdwt_set_tuning(b"swt_split_fwd", 0)
+        B = BatchedWavelets(1, 128, 192, "db6", 2, do_swt=1, img=x[None])
+        lib.pdwt_set_tuning(b"swt_split_fwd", 130)  # neither plan's value
+        names = {}
+
+        def run(tag, plan):
+            plan.enable_kernel_timing(True)
+            for _ in range(20):
+                plan.forward()
+            names[tag] = {n for n, _ in plan.kernel_times(cap=256)}
+        ts = [threading.Thread(target=run, args=("A", A)), threading.Thread(target=run, args=("B", B))]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        assert names["A"] == {"swt2_fwd_split"}, names
+        assert names["B"] == {"swt2_fwd_level"}, names
+        ref = oracle.forward(x, "db6", 2, do_swt=1)
+        for plan in (A, B):
+            for k, r in enumerate(ref):
+                assert np.abs(plan.coeff(k)[0] - r).max() <= 2e-5 * max(float(np.abs(r).max()), 255.0)
+    finally:
+        lib.pdwt_set_tuning(b"swt_split_fwd", prev)

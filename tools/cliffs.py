@@ -4,7 +4,7 @@ wavelet x size x levels -- with the fraction of the per-level streaming rate eac
 is 2x off its neighbours stands out (round 4 found the 4-tap forward wave kernel that way: db2 2048^2 22.6 us next to
 db1 8.5 and db3 11.1).
 
-    python3 tools/cliffs.py [dwt2] [swt2] [dwt1] [swt1] > profiles/r04_cliffs.txt
+    python3 tools/cliffs.py [dwt2] [swt2] [dwt1] [swt1] [batch] [odd] > profiles/r04_cliffs.txt
 """
 import os
 import sys
@@ -81,6 +81,24 @@ def main():
         for shape, L in (((1, 1 << 20), 5), ((1, 1 << 24), 6), ((4096, 4096), 5), ((512, 2048), 4)):
             for w in WAVELETS:
                 case("dwt1", w, shape, L)
+    if "batch" in which:  # batches of images: where the dispatch changes regime (cache-resident -> HBM, strips, wave kernels)
+        for w in ("haar", "db2", "db4", "sym8", "db13"):
+            for shape, L, Bs in (((4096, 4096), 4, (1, 2, 3, 4, 8, 16)), ((2048, 2048), 4, (1, 2, 4, 8, 16, 64)), ((1024, 1024), 3, (1, 4, 16, 64, 256)),
+                                 ((512, 512), 3, (1, 8, 64, 512)), ((256, 256), 3, (1, 16, 256, 2048))):
+                for B in Bs:
+                    case("dwt2", w, shape, L, batch=B)
+        for w in ("haar", "db2", "db4", "sym8"):
+            for shape, L, Bs in (((2048, 2048), 3, (1, 2, 4, 8)), ((512, 512), 3, (1, 4, 16, 64))):
+                for B in Bs:
+                    case("swt2", w, shape, L, batch=B)
+    if "odd" in which:  # sizes that are not multiples of 2^L / 4 / 8
+        for w in ("haar", "db2", "db4", "sym8", "db13"):
+            for shape in ((4095, 4095), (4094, 4094), (4092, 4096), (4096, 4092), (3000, 3000), (2047, 2049), (1025, 1023), (1500, 700), (513, 513), (130, 4100)):
+                case("dwt2", w, shape, 3)
+            for shape in ((2047, 2047), (1000, 1000), (1002, 1002), (513, 515)):
+                case("swt2", w, shape, 2)
+            for shape in ((1, (1 << 24) - 1), (1, (1 << 24) - 2), (1, 10000000), (4095, 4095), (1000, 5000)):
+                case("dwt1", w, shape, 4)
     if "swt1" in which:
         for shape, L in (((1, 1 << 20), 4), ((1, 1 << 24), 4), ((4096, 4096), 4)):
             for w in WAVELETS:
