@@ -165,6 +165,32 @@ def label_step_kernels(names, L, chain_levels=None):
     return out
 
 
+def labels_from_schedule(names, schedule):
+    """Launch names of ONE step + the plan's schedule text ("fwd: REG1D[1-3] FUSED1D[4-6]\ninv: ...", pdwt_schedule_string)
+    -> labels 'name[Ll]' with l = the first level of the schedule step each launch belongs to.  One launch list entry per
+    schedule step, in order (operator launches such as soft_threshold are not steps); None when the counts do not match
+    (a step that fell back to a launch per level) -- the caller then labels by counting (label_step_kernels)."""
+    import re
+    steps = {"fwd": [], "inv": []}
+    for line in schedule.splitlines():
+        d = line.split(":", 1)[0].strip()
+        if d in steps:
+            steps[d] = [int(m) for m in re.findall(r"[A-Z0-9]+\[(\d+)", line)]
+    out, fi, ii = [], 0, 0
+    for n in names:
+        if "_fwd_" in n:
+            if fi >= len(steps["fwd"]):
+                return None
+            out.append("%s[L%d]" % (n, steps["fwd"][fi])); fi += 1
+        elif "_inv_" in n:
+            if ii >= len(steps["inv"]):
+                return None
+            out.append("%s[L%d]" % (n, steps["inv"][ii])); ii += 1
+        else:
+            out.append("%s[-]" % n)
+    return out if (fi == len(steps["fwd"]) and ii == len(steps["inv"])) else None
+
+
 def level_of_kernel(kernel, L):
     """'dwt2_inv_level[L1]' -> (level, is_inverse) for pdwt_time_level; None when the launch is not a
     single-level one that pdwt_time_level can repeat."""
@@ -473,7 +499,13 @@ def kernel_profile(plan, step, cfg, config_name, B, steps):
     plan.reset_kernel_times()
     per_step = len(times) // steps
     step_names = [n for n, _ in times[:per_step]]
-    labels = label_step_kernels(step_names, L)
+    labels = None
+    try:
+        labels = labels_from_schedule(step_names, plan.schedule())
+    except Exception:
+        labels = None
+    if labels is None:
+        labels = label_step_kernels(step_names, L)
     agg = {}
     for i, (name, ms) in enumerate(times):
         agg.setdefault(labels[i % per_step], []).append(ms)

@@ -238,7 +238,10 @@ int pdwt_time_copy(pdwt_handle h, long long elems, int reps, float* ms_per_launc
  *                    (dwt1_reg_kernels.hpp) where the rows qualify (even hlen <= 20, rows of >= 2048 samples that
  *                    are multiples of 32); default 3; 0 = the workgroup-wide LDS pyramids (57.6 vs 69.5 us per
  *                    forward+inverse on 2^24 samples); the forward uses them up to 2^25 samples per plan (a batch of
- *                    long rows is faster through the LDS pyramid), bit 2 lifts that limit.  
+ *                    long rows is faster through the LDS pyramid), bit 2 lifts that limit.  fp32: only where at least 2^23
+ *                    samples in rows of at least 16384 enter the launch -- shorter rows and smaller transforms are faster
+ *                    through the one-launch LDS pyramid (4096 rows of 4096, db4 L5: 79.6 vs 70.6 us; 2^20 samples: 16.2 vs
+ *                    14.2) --, bit 3 lifts those limits (tests).  
  *   "swt_fused"      1 (default): 2D SWT plans whose 3L+2 planes about fit the Infinity Cache (<= 320 MiB) run several
  *                    levels per launch in registers: 2-tap banks (haar) levels 1-3 and 4-6 (swt2_fused_kernels.hpp: 11 / 8
  *                    instead of 15 / 10 planes of traffic), 4-tap banks (db2, sym2, custom) levels (1, 2) and (3, 4)

@@ -50,7 +50,9 @@ namespace pdwt {
 #endif
 
 constexpr int kReg1MaxLevels = 3;
-constexpr int kReg1MaxHlen = 20;          // E_k <= 19: at most five lanes ahead at level 3
+constexpr int kReg1MaxHlen = 20;          // E_k <= 19: at most five lanes ahead at level 3.  (Round 4 instantiated 22-40 taps too -- the code is
+                                          // generic --: 8-10 % ahead of the LDS pyramids on ONE row of 2^24 samples, 3-15 % behind on
+                                          // 4096 rows of 4096 and on rows of <= 2^20: not dispatched, profiles/r04u_reg1d_long.txt)
 constexpr int kReg1LdsStride = 20;            // floats per lane of the wavefront-private transposition tile
 constexpr int kReg1LdsFloats = 64 * kReg1LdsStride;
 constexpr unsigned kReg1Dropped = 0x80000000u;  // byte offset >= any row (rows are < 2 GiB); stays out of range

@@ -106,10 +106,10 @@ static std::atomic<int>& swt_fused_flag() {
 int set_swt_fused_enabled(int value) { return swt_fused_flag().exchange(value < 0 ? 0 : (value > 2 ? 2 : value)); }
 int get_swt_fused_enabled() { return swt_fused_flag().load(std::memory_order_relaxed); }
 static std::atomic<int>& reg1d_flag() {
-    static std::atomic<int> v{getenv("PDWT_REG1D") ? (atoi(getenv("PDWT_REG1D")) & 7) : 3};
+    static std::atomic<int> v{getenv("PDWT_REG1D") ? (atoi(getenv("PDWT_REG1D")) & 15) : 3};
     return v;
 }
-int set_reg1d_enabled(int value) { return reg1d_flag().exchange(value < 0 ? 0 : (value > 7 ? 7 : value)); }  // three flag bits
+int set_reg1d_enabled(int value) { return reg1d_flag().exchange(value < 0 ? 0 : (value > 15 ? 15 : value)); }  // four flag bits
 int get_reg1d_enabled() { return reg1d_flag().load(std::memory_order_relaxed); }
 static std::atomic<int>& chain_flag() {
     static std::atomic<int> v{getenv("PDWT_CHAIN") ? atoi(getenv("PDWT_CHAIN")) : 0};  // opt-in: measured no faster, see plan.cpp

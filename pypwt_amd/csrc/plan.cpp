@@ -555,8 +555,22 @@ void build_schedule(pdwt_plan* p) {
                 // 513 + 71 us -- while the inverse register kernels stay ahead, 440 + 53 against 607 us;
                 // profiles/r02y_bench_cfg3_batch.txt.  Bit 2 of the knob forces the forward too.)
                 // (The fp64 build has no LDS pyramid to prefer.)
-                const bool reg_here = ((reg >> dir) & 1) && (dir == 1 || ((reg >> 2) & 1) || sizeof(real_t) == 8 ||
-                                                             (long long)p->batch * p->info.Nr * p->info.Nc <= (1LL << 25));
+                bool reg_here = ((reg >> dir) & 1) && (dir == 1 || ((reg >> 2) & 1) || sizeof(real_t) == 8 ||
+                                                       (long long)p->batch * p->info.Nr * p->info.Nc <= (1LL << 25));
+                // Round 4 (tools/reg1d_rows.sh, profiles/r04v_reg1d_rows.txt): the register kernels' overlapping 1024-sample
+                // blocks and their launch per three levels only pay on LONG rows of a LARGE transform -- rows of 4096 samples
+                // lose a quarter of every row's blocks to the overlap (4096 x 4096 sym8 L5 forward+inverse 86.6 us against 83.6
+                // for the LDS pyramids, db4 79.6 against 70.6), and below ~2^23 samples one launch of the pyramid beats two
+                // (2^20 samples: db4 16.2 against 14.2 us, 256 rows of 4096: 18.0 against 13.8).  fp32 only (the fp64 build has
+                // no LDS pyramid); bit 3 of the "reg1d" knob lifts the limits (tests).
+                static const int min_log2 = getenv("PDWT_REG1D_MIN_LOG2") ? atoi(getenv("PDWT_REG1D_MIN_LOG2")) : 23;
+                static const int min_row = getenv("PDWT_REG1D_MIN_ROW") ? atoi(getenv("PDWT_REG1D_MIN_ROW")) : 16384;
+                // Decided for the PLAN, not per launch: a register first stage followed by a pyramid on the remaining 2^21
+                // samples measured slower than either pure schedule (2^24 samples, db4 L5: 64.6 us against 54.5 / 60.3).
+                if (reg_here && sizeof(real_t) == 4 && !((reg >> 3) & 1)) {
+                    const long long total = (long long)p->batch * p->info.Nr * p->info.Nc;
+                    if (total < (1LL << min_log2) || p->lc[0] < min_row) reg_here = false;
+                }
                 int K = reg_here ? (L - l < 3 ? L - l : 3) : 0;
                 while (K >= 1 && !dwt1_reg_supported(hlen, p->lc[l], K)) --K;
                 if (K >= 1) {

@@ -188,7 +188,7 @@ def test_reg_1d_three_levels_in_registers_on_the_gpu():
     oracle: rows that are and are not whole numbers of blocks, several filter lengths, batched rows, 1-6 levels."""
     from pypwt_amd import Wavelets, _lib
     lib = _lib.load()
-    was = lib.pdwt_set_tuning(b"reg1d", 7)  # bit 2: the forward register kernels at any size
+    was = lib.pdwt_set_tuning(b"reg1d", 15)  # bit 2: the forward register kernels at any batch size; bit 3: on short rows and small transforms too
     try:
         for wname, N, lv, rows in (("sym8", 1 << 16, 6, 1), ("db4", 1 << 14, 5, 3), ("haar", 1 << 13, 4, 2),
                                    ("db10", 1 << 15, 3, 1), ("coif2", 3 * (1 << 13), 4, 1), ("sym8", 1 << 20, 6, 1),
