@@ -271,6 +271,32 @@ int pdwt_time_copy(pdwt_handle h, long long elems, int reps, float* ms_per_launc
  *                    slower than two launches on MI355X, kept for tests and re-measurement) */
 int pdwt_set_tuning(const char* key, int value);
 
+/* ---- NEW: neighbour exchange for ONE image tiled over several GPUs (the reference has no multi-GPU code,
+ * pdwt/TODO.txt:15).  A communicator wraps an RCCL communicator (librccl is dlopen'ed on first use: single-GPU callers never
+ * touch it).  One process per GPU: rank 0 calls pdwt_comm_unique_id and hands the PDWT_COMM_ID_BYTES bytes to the other
+ * ranks by any means (a socket, a file, MPI: pypwt_amd/comm.py uses TCP), then every rank calls pdwt_comm_create.  All
+ * transfers are enqueued on the given HIP stream -- the plan's, so that they are ordered with its level kernels -- and do
+ * not block the host.  Counts are in pdwt_real values.  pdwt_comm_last_error() has the message of the last failure on the
+ * calling thread; PDWT_ERR_UNSUPPORTED: librccl could not be loaded. */
+typedef struct pdwt_comm* pdwt_comm_handle;
+#define PDWT_COMM_ID_BYTES 128
+int pdwt_comm_unique_id(void* id);
+int pdwt_comm_create(const void* id, int nranks, int rank, int device_id, pdwt_comm_handle* out);
+int pdwt_comm_destroy(pdwt_comm_handle c);
+int pdwt_comm_rank(pdwt_comm_handle c);
+int pdwt_comm_size(pdwt_comm_handle c);
+/* ONE grouped point-to-point exchange (ncclGroupStart / Send / Recv / GroupEnd): message i sends send_count[i] values from
+ * send_ptr[i] to rank send_peer[i] and receives recv_count[i] values into recv_ptr[i] from rank recv_peer[i]; a null
+ * pointer or a zero count skips that half.  The halo rows of every band of a level are one call: neighbour traffic only
+ * (xGMI links), no collective.  A rank may name itself (a ring of one: the periodic image). */
+int pdwt_comm_exchange(pdwt_comm_handle c, int n, const void* const* send_ptr, const long long* send_count, const int* send_peer,
+                       void* const* recv_ptr, const long long* recv_count, const int* recv_peer, void* hip_stream);
+/* the two collectives of the gather step (the approximation that has become thinner than the halo goes to rank 0 and comes
+ * back): recv holds size x count_per_rank values; broadcast in place from `root` */
+int pdwt_comm_all_gather(pdwt_comm_handle c, const void* send, void* recv, long long count_per_rank, void* hip_stream);
+int pdwt_comm_broadcast(pdwt_comm_handle c, void* buf, long long count, int root, void* hip_stream);
+const char* pdwt_comm_last_error(void);
+
 #ifdef __cplusplus
 }
 #endif

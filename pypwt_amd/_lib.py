@@ -99,6 +99,16 @@ def signatures(real=C.c_float):
         "pdwt_time_level": (C.c_int, [handle_t, C.c_int, C.c_int, C.c_int, f32p]),
         "pdwt_time_copy": (C.c_int, [handle_t, C.c_longlong, C.c_int, f32p]),
         "pdwt_set_tuning": (C.c_int, [C.c_char_p, C.c_int]),
+        "pdwt_comm_unique_id": (C.c_int, [C.c_void_p]),
+        "pdwt_comm_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(handle_t)]),
+        "pdwt_comm_destroy": (C.c_int, [handle_t]),
+        "pdwt_comm_rank": (C.c_int, [handle_t]),
+        "pdwt_comm_size": (C.c_int, [handle_t]),
+        "pdwt_comm_exchange": (C.c_int, [handle_t, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_longlong), C.POINTER(C.c_int),
+                                         C.POINTER(C.c_void_p), C.POINTER(C.c_longlong), C.POINTER(C.c_int), C.c_void_p]),
+        "pdwt_comm_all_gather": (C.c_int, [handle_t, C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p]),
+        "pdwt_comm_broadcast": (C.c_int, [handle_t, C.c_void_p, C.c_longlong, C.c_int, C.c_void_p]),
+        "pdwt_comm_last_error": (C.c_char_p, []),
     }
 
 

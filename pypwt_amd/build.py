@@ -52,6 +52,7 @@ SOURCES = [
     "launch_ops.hip",
     "launch_nonsep.hip",
     "plan.cpp",
+    "comm.cpp",
     "wavelet_table.cpp",
 ]
 

@@ -1,0 +1,124 @@
+"""Communicator -- RCCL point-to-point exchange through the C ABI (pdwt_comm_*, include/pypwt_amd.h), no torch.
+
+One process per GPU.  `Communicator.from_env()` reads RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT (the
+variables torch.distributed.run and bench.py's self-launch export) and passes rank 0's RCCL unique id to the other ranks
+over one TCP connection each; `Communicator.single()` is a ring of one (the rank is its own neighbour: how the transport
+runs on a one-GPU box).  Used by pypwt_amd.tiled.TiledWavelets(comm=...) for the halo rows of a tiled image.
+"""
+import ctypes as C
+import os
+import socket
+import time
+
+from . import _lib
+from ._lib import handle_t
+
+ID_BYTES = 128
+
+
+def _check(lib, rc, what):
+    if rc < 0:
+        msg = lib.pdwt_comm_last_error()
+        raise RuntimeError("%s: %s" % (what, msg.decode("utf-8", "replace") if msg else "error %d" % rc))
+    return rc
+
+
+def _share_id(rank, size, unique_id, addr, port, timeout=120.0):
+    """rank 0 -> every other rank: the 128 bytes of the RCCL unique id, one TCP connection per rank"""
+    if size == 1:
+        return unique_id
+    if rank == 0:
+        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as srv:
+            srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            srv.bind((addr, port))
+            srv.listen(size)
+            srv.settimeout(timeout)
+            for _ in range(size - 1):
+                conn, _ = srv.accept()
+                with conn:
+                    conn.sendall(unique_id)
+        return unique_id
+    deadline = time.time() + timeout
+    while True:
+        try:
+            with socket.create_connection((addr, port), timeout=5.0) as s:
+                buf = b""
+                while len(buf) < ID_BYTES:
+                    chunk = s.recv(ID_BYTES - len(buf))
+                    if not chunk:
+                        raise ConnectionError("rank 0 closed the connection early")
+                    buf += chunk
+                return buf
+        except (ConnectionRefusedError, socket.timeout, ConnectionError, OSError):
+            if time.time() > deadline:
+                raise
+            time.sleep(0.05)
+
+
+class Communicator(object):
+    def __init__(self, rank, size, unique_id, device=-1):
+        self._lib = _lib.load()
+        self._h = None
+        if len(unique_id) != ID_BYTES:
+            raise ValueError("Communicator: the unique id is %d bytes" % ID_BYTES)
+        h = handle_t()
+        idbuf = (C.c_char * ID_BYTES).from_buffer_copy(unique_id)
+        _check(self._lib, self._lib.pdwt_comm_create(C.cast(idbuf, C.c_void_p), int(size), int(rank), int(device), C.byref(h)),
+               "pdwt_comm_create")
+        self._h = h
+        self.rank, self.size = int(rank), int(size)
+
+    @staticmethod
+    def unique_id():
+        lib = _lib.load()
+        buf = (C.c_char * ID_BYTES)()
+        _check(lib, lib.pdwt_comm_unique_id(C.cast(buf, C.c_void_p)), "pdwt_comm_unique_id")
+        return bytes(buf)
+
+    @classmethod
+    def single(cls, device=-1):
+        """a ring of one rank: it is its own neighbour (the periodic image closes on itself through RCCL)"""
+        return cls(0, 1, cls.unique_id(), device)
+
+    @classmethod
+    def from_env(cls, device=None, port_offset=17):
+        rank, size = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+        if device is None:
+            device = int(os.environ.get("LOCAL_RANK", "0"))
+        addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
+        port = int(os.environ.get("MASTER_PORT", "29500")) + port_offset  # next to, not on, the launcher's own port
+        uid = cls.unique_id() if rank == 0 else None
+        uid = _share_id(rank, size, uid, addr, port)
+        return cls(rank, size, uid, device)
+
+    # ---- transfers, all enqueued on `stream` (an integer HIP stream handle; 0 / None = the legacy default stream)
+    def exchange(self, sends, recvs, stream=None):
+        """sends: [(device pointer, count of values, peer)], recvs: the same -- ONE grouped RCCL call"""
+        n = max(len(sends), len(recvs))
+        sp, sc, sr = (C.c_void_p * n)(), (C.c_longlong * n)(), (C.c_int * n)()
+        rp, rc_, rr = (C.c_void_p * n)(), (C.c_longlong * n)(), (C.c_int * n)()
+        for i, (p, cnt, peer) in enumerate(sends):
+            sp[i], sc[i], sr[i] = p, cnt, peer
+        for i, (p, cnt, peer) in enumerate(recvs):
+            rp[i], rc_[i], rr[i] = p, cnt, peer
+        _check(self._lib, self._lib.pdwt_comm_exchange(self._h, n, sp, sc, sr, rp, rc_, rr, C.c_void_p(stream or 0)),
+               "pdwt_comm_exchange")
+
+    def all_gather(self, send_ptr, recv_ptr, count_per_rank, stream=None):
+        _check(self._lib, self._lib.pdwt_comm_all_gather(self._h, C.c_void_p(send_ptr), C.c_void_p(recv_ptr), int(count_per_rank),
+                                                         C.c_void_p(stream or 0)), "pdwt_comm_all_gather")
+
+    def broadcast(self, ptr, count, root=0, stream=None):
+        _check(self._lib, self._lib.pdwt_comm_broadcast(self._h, C.c_void_p(ptr), int(count), int(root), C.c_void_p(stream or 0)),
+               "pdwt_comm_broadcast")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.pdwt_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

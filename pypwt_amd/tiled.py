@@ -99,9 +99,13 @@ class TiledWavelets(object):
     forward(): a second call warns and does nothing (the reference's W_INVERSE state) unless mark_coeffs_current()
     has re-armed it after an in-place edit."""
 
-    def __init__(self, slab, wname, levels, group=None, do_swt=0, loopback=False):
+    def __init__(self, slab, wname, levels, group=None, do_swt=0, loopback=False, comm=None):
         """loopback: with ONE rank, still send the halos / gather / broadcast through the process group (the rank
-        is its own neighbour) instead of copying them -- the way to run the RCCL transport on a one-GPU box."""
+        is its own neighbour) instead of copying them -- the way to run the RCCL transport on a one-GPU box.
+        comm: a pypwt_amd.comm.Communicator -- the halos, the gather and the broadcast then go through the library's own
+        RCCL calls on the plans' stream (pdwt_comm_exchange: one grouped send / receive per level, a few microseconds of host
+        time instead of the ~100 us of torch.distributed.batch_isend_irecv); rank and world size are the communicator's
+        and no torch process group is needed.  A communicator of one rank is its own neighbour (loopback)."""
         import sys
         if "torch" not in sys.modules and _lib._libs:
             # PyTorch-ROCm bundles its own libamdhip64 under the same soname as /opt/rocm's: whichever is
@@ -115,10 +119,16 @@ class TiledWavelets(object):
         if not torch.cuda.is_available():
             raise RuntimeError("TiledWavelets needs a HIP device (there is no CPU implementation)")
         self.group = group
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
-        self._via_host = dist.is_initialized() and dist.get_backend(group) != "nccl"  # gloo: stage halos on the host
-        self._loopback = bool(loopback) and dist.is_initialized() and self.world == 1
+        self._comm = comm
+        if comm is not None:
+            self.world, self.rank = comm.size, comm.rank
+            self._via_host = False
+            self._loopback = self.world == 1
+        else:
+            self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+            self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+            self._via_host = dist.is_initialized() and dist.get_backend(group) != "nccl"  # gloo: stage halos on the host
+            self._loopback = bool(loopback) and dist.is_initialized() and self.world == 1
         self.device = torch.device("cuda", torch.cuda.current_device())
         src = torch.as_tensor(np.ascontiguousarray(slab, dtype=np.float32) if isinstance(slab, np.ndarray) else slab)
         if src.dim() != 2:
@@ -209,6 +219,18 @@ class TiledWavelets(object):
                 below.copy_(top)
             return
         prev, nxt = (self.rank - 1) % self.world, (self.rank + 1) % self.world
+        if self._comm is not None:
+            # the library's own RCCL calls on the plans' stream.  Every message is a range of whole rows of ONE plane of a plan
+            # buffer (contiguous): the halos of a band stack go as one message per band inside the same group -- sent from
+            # and received into the buffers themselves, nothing packed, nothing copied.
+            def msgs(t):
+                if t.is_contiguous():
+                    return [(t.data_ptr(), t.numel())]
+                return [(t[k].data_ptr(), t[k].numel()) for k in range(t.shape[0])]  # (band, rows, columns): rows are whole
+            sends = [(p_, n_, nxt) for pc in pieces for p_, n_ in msgs(pc[1])] + [(p_, n_, prev) for pc in pieces for p_, n_ in msgs(pc[0])]
+            recvs = [(p_, n_, prev) for pc in pieces for p_, n_ in msgs(pc[2])] + [(p_, n_, nxt) for pc in pieces for p_, n_ in msgs(pc[3])]
+            self._comm.exchange(sends, recvs, stream=torch.cuda.current_stream(self.device).cuda_stream)
+            return
         if self._via_host:
             tops = torch.cat([p[0].reshape(-1) for p in pieces]).cpu()
             bots = torch.cat([p[1].reshape(-1) for p in pieces]).cpu()
@@ -354,6 +376,11 @@ class TiledWavelets(object):
         torch, dist = self._torch, self._dist
         if self.world == 1 and not self._loopback:
             return slab
+        if self._comm is not None:
+            src = slab.contiguous()
+            full = torch.empty((self.world * slab.shape[0],) + tuple(slab.shape[1:]), dtype=slab.dtype, device=self.device)
+            self._comm.all_gather(src.data_ptr(), full.data_ptr(), src.numel(), stream=torch.cuda.current_stream(self.device).cuda_stream)
+            return full
         if self._via_host:
             parts = [torch.empty(slab.shape, dtype=slab.dtype) for _ in range(self.world)]
             dist.all_gather(parts, slab.cpu().contiguous(), group=self.group)
@@ -368,6 +395,10 @@ class TiledWavelets(object):
         if self.world == 1 and not self._loopback:
             return full
         rows = slab_shape[0] * self.world
+        if self._comm is not None:
+            buf = full.contiguous() if self.rank == 0 else torch.empty((rows, slab_shape[1]), dtype=torch.float32, device=self.device)
+            self._comm.broadcast(buf.data_ptr(), buf.numel(), 0, stream=torch.cuda.current_stream(self.device).cuda_stream)
+            return buf[self.rank * slab_shape[0]:(self.rank + 1) * slab_shape[0]]
         if self._via_host:
             buf = full.cpu().contiguous() if self.rank == 0 else torch.empty((rows, slab_shape[1]), dtype=torch.float32)
             dist.broadcast(buf, 0, group=self.group)

@@ -92,6 +92,53 @@ def test_rccl_transport_with_one_rank_as_its_own_neighbour(wname, levels, shape,
     assert "rccl-loopback" in outs[0]
 
 
+@pytest.mark.parametrize("wname,levels,shape,swt", [("db4", 3, (192, 160), 0), ("db2", 4, (40, 64), 0), ("sym8", 2, (128, 256), 0),
+                                                    ("haar", 3, (64, 96), 1), ("db2", 3, (128, 100), 1)])
+def test_library_rccl_transport_with_one_rank_as_its_own_neighbour(wname, levels, shape, swt):
+    """The library's OWN transport (pdwt_comm_*, pypwt_amd/comm.py: RCCL dlopen'ed by the C library, grouped send / recv on
+    the plans' stream, all_gather + broadcast for the gathered levels), one rank as its own neighbour: every slab of every
+    band and the reconstruction against the CPU oracle, with no torch process group."""
+    outs = _run_ranks(1, wname, levels, shape, swt=swt, backend="comm")
+    assert "comm-loopback" in outs[0]
+
+
+def test_communicator_without_torch():
+    """pypwt_amd.comm.Communicator in a process that never imports torch: a ring of one exchanges rows between two plans'
+    buffers (send to self / receive from self in ONE group), gathers and broadcasts, all on a plan's stream."""
+    code = """
+import sys
+sys.path.insert(0, %r)
+import numpy as np
+from pypwt_amd import BatchedWavelets
+from pypwt_amd.comm import Communicator
+c = Communicator.single()
+assert (c.rank, c.size) == (0, 1)
+x = (np.arange(64 * 96, dtype=np.float32).reshape(1, 64, 96) %% 251) - 100
+A = BatchedWavelets(1, 64, 96, "haar", 1, img=x)
+B = BatchedWavelets(1, 64, 96, "haar", 1)
+import ctypes as C
+lib = A._lib
+s = lib.pdwt_get_stream(A._h)
+B.set_stream(s)                     # both plans on one stream: the transfers are ordered with their kernels
+pa, pb = lib.pdwt_image_ptr(A._h), lib.pdwt_image_ptr(B._h)
+row = 96 * 4
+# rows 8..15 of A -> rows 0..7 of B, rows 40..47 of A -> rows 56..63 of B: two messages in one group
+c.exchange([(pa + 8 * row, 8 * 96, 0), (pa + 40 * row, 8 * 96, 0)], [(pb, 8 * 96, 0), (pb + 56 * row, 8 * 96, 0)], stream=s)
+c.all_gather(pa + 16 * row, pb + 16 * row, 4 * 96, stream=s)
+c.broadcast(pb + 32 * row, 96, 0, stream=s)
+A.synchronize()
+got = B.image_at(0)
+assert np.array_equal(got[0:8], x[0, 8:16]) and np.array_equal(got[56:64], x[0, 40:48]), "exchange"
+assert np.array_equal(got[16:20], x[0, 16:20]), "all_gather"
+assert not got[8:16].any() and not got[20:56].any()
+c.close()
+assert "torch" not in sys.modules
+print("COMM-OK")
+""" % ROOT
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert "COMM-OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
 def test_import_order_is_checked():
     """In a process that already loaded libpypwt_amd.so without torch, TiledWavelets refuses loudly instead
     of running on a HIP runtime torch cannot initialise."""

@@ -25,11 +25,16 @@ def main():
     swt = int(sys.argv[6]) if len(sys.argv) > 6 else 0
     torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1))
     loopback = world == 1 and backend == "nccl"  # one rank over RCCL: its own neighbour, halos through send/recv
-    if world > 1 or loopback:  # otherwise world 1 runs WITHOUT a process group: the ring closes on the rank itself
+    comm = None
+    if backend == "comm":  # the library's own RCCL transport (pdwt_comm_*): no torch process group at all
+        from pypwt_amd.comm import Communicator
+        comm = Communicator.from_env(device=torch.cuda.current_device())
+        assert comm.size == world and comm.rank == rank
+    elif world > 1 or loopback:  # otherwise world 1 runs WITHOUT a process group: the ring closes on the rank itself
         dist.init_process_group(backend, rank=rank, world_size=world)
     x = oracle.hash_input((Nr, Nc), 555, scale=255.0)
     n = Nr // world
-    tw = TiledWavelets(x[rank * n:(rank + 1) * n], wname, levels, do_swt=swt, loopback=loopback)
+    tw = TiledWavelets(x[rank * n:(rank + 1) * n], wname, levels, do_swt=swt, loopback=loopback, comm=comm)
     tw.forward()
     flat = oracle.forward(x, wname, levels, do_swt=swt)  # [A, H1, V1, D1, H2, ...] from the CPU oracle
     ref = [flat[0]] + [flat[1 + 3 * l:4 + 3 * l] for l in range(levels)]
@@ -94,10 +99,15 @@ def main():
     tw.forward()
     tw.inverse()  # plans are reused: another round trip must work too
     assert np.abs(tw.image - rec3).max() <= 4e-3, "second round trip"
-    if world > 1 or loopback:
+    if comm is not None:
+        assert not dist.is_initialized()
+        torch.cuda.synchronize()
+        comm.close()
+    elif world > 1 or loopback:
         dist.barrier()
         dist.destroy_process_group()
-    print("OK %d tiled=%d deep=%d%s" % (rank, tw.tiled_levels, tw.deep_levels, " rccl-loopback" if loopback else ""))
+    print("OK %d tiled=%d deep=%d%s" % (rank, tw.tiled_levels, tw.deep_levels,
+                                        " rccl-loopback" if loopback else (" comm-loopback" if comm is not None else "")))
 
 
 if __name__ == "__main__":

@@ -74,9 +74,21 @@ def one_size(torch, dist, Wavelets, TiledWavelets, rows, cols, wname, levels):
         t_rccl_fi = timed(lambda: (tw.forward(), tw.inverse()), sync)
         tw.cleanup()
         del tw
+        # (c) round 4: the library's own RCCL calls (pdwt_comm_exchange on the plans' stream), one rank as its own neighbour
+        from pypwt_amd.comm import Communicator
+        comm = Communicator.single(0)
+        tw = TiledWavelets(x, wname, lv, do_swt=swt, comm=comm)
+        t_c_f = timed(tw.forward, sync)
+        t_c_fi = timed(lambda: (tw.forward(), tw.inverse()), sync)
+        tw.cleanup()
+        del tw
+        sync()
+        comm.close()
         print("%s L=%d (slab levels %d, gathered %d): plain plan fwd %8.1f  fwd+inv %8.1f | tiled, halos copied fwd %8.1f  fwd+inv %8.1f"
-              " | tiled, halos through RCCL (loopback) fwd %8.1f  fwd+inv %8.1f" % (
-                  "swt2" if swt else "dwt2", lv, tiled, deep, t_plain_f, t_plain_fi, t_copy_f, t_copy_fi, t_rccl_f, t_rccl_fi), flush=True)
+              " | tiled, halos through torch.distributed RCCL (loopback) fwd %8.1f  fwd+inv %8.1f"
+              " | tiled, halos through the library's RCCL calls (loopback) fwd %8.1f  fwd+inv %8.1f" % (
+                  "swt2" if swt else "dwt2", lv, tiled, deep, t_plain_f, t_plain_fi, t_copy_f, t_copy_fi, t_rccl_f, t_rccl_fi,
+                  t_c_f, t_c_fi), flush=True)
 
 
 if __name__ == "__main__":
