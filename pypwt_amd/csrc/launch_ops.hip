@@ -35,13 +35,17 @@ hipError_t launch_axpy(real_t* dst, const real_t* src, long long n, real_t alpha
     return hipGetLastError();
 }
 
+// out2: 2 + 2 * kNormsMaxBlocks doubles: [0], [1] = the results, the rest = per-block partial sums (scratch)
 hipError_t launch_norms(const real_t* p, long long n, double* out2, hipStream_t s) {
-    if (n <= 0) return hipSuccess;
+    if (n <= 0) return hipMemsetAsync(out2, 0, 2 * sizeof(double), s);
     const long long n4 = n / 4;
-    hipLaunchKernelGGL(norms_kernel, dim3(stream_grid(n4, 256)), dim3(256), 0, s,
-                       reinterpret_cast<const real4_t*>(p), n4, out2);
+    int grid = stream_grid(n4, 256);
+    if (grid > kNormsMaxBlocks) grid = kNormsMaxBlocks;
+    hipLaunchKernelGGL(norms_partial_kernel, dim3(grid), dim3(256), 0, s, reinterpret_cast<const real4_t*>(p), n4, out2 + 2);
+    hipLaunchKernelGGL(norms_final_kernel, dim3(1), dim3(256), 0, s, out2 + 2, grid, out2);
     return hipGetLastError();
 }
+int norms_scratch_doubles() { return 2 + 2 * kNormsMaxBlocks; }
 
 hipError_t launch_circshift(const real_t* in, real_t* out, int batch, int Nr, int Nc, int sr, int sc,
                             hipStream_t s) {

@@ -81,10 +81,13 @@ __global__ void __launch_bounds__(256) axpy_kernel(real4_t* __restrict__ dst, co
     }
 }
 
-// out[0] += sum|x| ; out[1] += sum x^2   (fp64 accumulation: one wave-shuffle
-// reduction per wavefront, one LDS step per block, two atomics per block)
-__global__ void __launch_bounds__(256) norms_kernel(const real4_t* __restrict__ p, long long n4,
-                                                    double* __restrict__ out) {
+// sum|x| and sum x^2 in two launches without atomics (fp64 accumulation: one wave-shuffle reduction per wavefront, one LDS
+// step per block): every block writes its two partial sums to its own slot, one block adds the slots up.  (Rounds 1-3 had
+// every block add to ONE pair of doubles with atomicAdd: 4096 same-address fp64 atomics serialise at the memory side --
+// norm1 of 2^24 coefficients took 81 us, a twelfth of the streaming rate, found in round 4 by tools/opsbench.py.)
+constexpr int kNormsMaxBlocks = 1024;
+__global__ void __launch_bounds__(256) norms_partial_kernel(const real4_t* __restrict__ p, long long n4,
+                                                            double* __restrict__ partial) {
     double s1 = 0.0, s2 = 0.0;
     const long long stride = (long long)gridDim.x * blockDim.x;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
@@ -105,8 +108,32 @@ __global__ void __launch_bounds__(256) norms_kernel(const real4_t* __restrict__ 
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        atomicAdd(&out[0], part[0][0] + part[0][1] + part[0][2] + part[0][3]);
-        atomicAdd(&out[1], part[1][0] + part[1][1] + part[1][2] + part[1][3]);
+        partial[2 * blockIdx.x] = part[0][0] + part[0][1] + part[0][2] + part[0][3];
+        partial[2 * blockIdx.x + 1] = part[1][0] + part[1][1] + part[1][2] + part[1][3];
+    }
+}
+// one block: out[0] = sum of partial[2 b], out[1] = sum of partial[2 b + 1], b < nblocks (fixed order: deterministic)
+__global__ void __launch_bounds__(256) norms_final_kernel(const double* __restrict__ partial, int nblocks, double* __restrict__ out) {
+    double s1 = 0.0, s2 = 0.0;
+    for (int b = threadIdx.x; b < nblocks; b += 256) {
+        s1 += partial[2 * b];
+        s2 += partial[2 * b + 1];
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        s1 += __shfl_down(s1, off, 64);
+        s2 += __shfl_down(s2, off, 64);
+    }
+    __shared__ double part[2][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+        part[0][wave] = s1;
+        part[1][wave] = s2;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        out[0] = part[0][0] + part[0][1] + part[0][2] + part[0][3];
+        out[1] = part[1][0] + part[1][1] + part[1][2] + part[1][3];
     }
 }
 

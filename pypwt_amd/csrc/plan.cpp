@@ -263,7 +263,8 @@ int build_layout(pdwt_plan* p) {
     HIP_TRY(pool_alloc(p->device, (void**)&p->arena, (size_t)off * sizeof(real_t), &p->arena_bytes));
     HIP_TRY(hipMemsetAsync(p->arena, 0, (size_t)off * sizeof(real_t), p->stream));
     {
-        HIP_TRY(pool_alloc(p->device, (void**)&p->d_red, 256, &p->d_red_bytes));  // two fp64 accumulators
+        // the two fp64 results of the norms + the per-block partial sums behind them (launch_norms)
+        HIP_TRY(pool_alloc(p->device, (void**)&p->d_red, (size_t)norms_scratch_doubles() * sizeof(double), &p->d_red_bytes));
     }
     return PDWT_OK;
 }
@@ -1191,6 +1192,7 @@ int pdwt_destroy(pdwt_handle h) {
     pool_free(h->device, h->arena, h->arena_bytes);
     if (h->tmp) (void)hipFree(h->tmp);
     pool_free(h->device, h->d_red, h->d_red_bytes);
+    if (h->h_red) (void)hipHostFree(h->h_red);
     if (h->d_f2d) (void)hipFree(h->d_f2d);
     if (h->chain_flags) (void)hipFree(h->chain_flags);
     if (h->own_stream && h->stream) pool_return_stream(h->device, h->stream);
@@ -1311,13 +1313,18 @@ static int norms_impl(pdwt_handle h, double out[2]) {
         const int rc0 = materialize_pending(h);
         if (rc0 != PDWT_OK) return rc0;
     }
-    HIP_TRY(hipMemsetAsync(h->d_red, 0, 2 * sizeof(double), h->stream));
     {
         Stamp st(h, "norms");
         HIP_TRY(launch_norms(h->arena, h->coeff_elems, h->d_red, h->stream));
     }
-    HIP_TRY(hipMemcpyAsync(out, h->d_red, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (!h->h_red && hipHostMalloc((void**)&h->h_red, 2 * sizeof(double), hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        h->h_red = nullptr;
+    }
+    double* land = h->h_red ? h->h_red : out;
+    HIP_TRY(hipMemcpyAsync(land, h->d_red, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
+    if (land != out) { out[0] = land[0]; out[1] = land[1]; }
     return PDWT_OK;
 }
 

@@ -73,6 +73,7 @@ struct pdwt_plan {
     real_t* tmp = nullptr;  // lazily allocated scratch (circshift, SWT fallback)
     long long tmp_elems = 0;
     double* d_red = nullptr;  // two fp64 accumulators for the norms
+    double* h_red = nullptr;  // pinned host landing zone of the two results (a pageable destination makes the copy ~20 us slower)
     size_t d_red_bytes = 0;   // size of the block behind them (a pool block may be larger than the 256 B asked for)
 
     pdwt::FilterBank dec{}, rec{};
