@@ -220,11 +220,12 @@ int pdwt_reset_kernel_times(pdwt_handle h);
  * milliseconds per repetition.  The data the level reads is whatever the buffers hold (run a
  * forward first); nothing else of the plan's state changes. */
 int pdwt_time_level(pdwt_handle h, int level, int inverse, int reps, float* ms_per_launch);
-/* the measured ceiling beside it: a plain 16-B-per-lane grid-stride copy of `elems` values (clamped to the plan's image,
- * rounded down to a multiple of 4) from the plan's image buffer into scratch, `reps` launches back to back between two
+/* the measured ceiling beside it: a plain 16-B-per-lane grid-stride copy of `elems` values (clamped to pdwt_copy_capacity,
+ * rounded down to a multiple of 4) from the plan's image buffer (its coefficient region when elems exceeds the image) into scratch, `reps` launches back to back between two
  * HIP events on the plan's stream; mean milliseconds per launch.  It moves 2 * elems * sizeof(pdwt_real) bytes: a level
  * kernel of the same footprint cannot be expected to run faster than this on the same GPU in the same cache state. */
 int pdwt_time_copy(pdwt_handle h, long long elems, int reps, float* ms_per_launch);
+long long pdwt_copy_capacity(pdwt_handle h); /* the largest `elems` pdwt_time_copy does not clamp: max(image, coefficient region) */
 /* NEW: process-wide dispatch knobs (tests and A/B measurements; no counterpart in the reference, whose
  * kernel choice is fixed at compile time, pdwt/src/wt.cu:236-305).  Returns the previous value, or
  * PDWT_ERR_ARG for an unknown key.  Every key is read ONCE PER PLAN, when the plan is created (pdwt_create*, pdwt_clone

@@ -98,6 +98,7 @@ def signatures(real=C.c_float):
         "pdwt_reset_kernel_times": (C.c_int, [handle_t]),
         "pdwt_time_level": (C.c_int, [handle_t, C.c_int, C.c_int, C.c_int, f32p]),
         "pdwt_time_copy": (C.c_int, [handle_t, C.c_longlong, C.c_int, f32p]),
+        "pdwt_copy_capacity": (C.c_longlong, [handle_t]),
         "pdwt_set_tuning": (C.c_int, [C.c_char_p, C.c_int]),
         "pdwt_comm_unique_id": (C.c_int, [C.c_void_p]),
         "pdwt_comm_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(handle_t)]),

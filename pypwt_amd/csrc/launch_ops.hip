@@ -66,7 +66,11 @@ hipError_t launch_fill_hash(real_t* x, long long n, uint32_t seed, real_t scale,
 hipError_t launch_copy(const real_t* src, real_t* dst, long long n, hipStream_t s) {
     if (n <= 0) return hipSuccess;
     const long long n4 = n / 4;
-    hipLaunchKernelGGL(copy_kernel, dim3(stream_grid(n4, 256)), dim3(256), 0, s, reinterpret_cast<const real4_t*>(src),
+    // 1024 workgroups: the best grid for this copy on MI355X at every footprint measured (profiles/r02t_pbench_b{1,8}.txt:
+    // 134 MB 16.4 us against 17.8 with 2048; 1 GB 186.5 us = 5.76 TB/s against 216.3 = 4.96)
+    int grid = stream_grid(n4, 256);
+    if (grid > 1024) grid = 1024;
+    hipLaunchKernelGGL(copy_kernel, dim3(grid), dim3(256), 0, s, reinterpret_cast<const real4_t*>(src),
                        reinterpret_cast<real4_t*>(dst), n4);
     return hipGetLastError();
 }

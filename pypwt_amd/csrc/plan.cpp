@@ -1713,8 +1713,16 @@ int pdwt_time_level(pdwt_handle h, int level, int inverse, int reps, float* ms_p
 
 int pdwt_time_copy(pdwt_handle h, long long elems, int reps, float* ms_per_launch) {
     CHECK_HANDLE(h);
-    const long long cap = (long long)h->batch * h->info.Nr * h->info.Nc;
+    // source: the image buffer, or -- for a footprint larger than the image (an SWT launch moves several planes) -- the
+    // coefficient region, which the copy only reads
+    const long long img = (long long)h->batch * h->info.Nr * h->info.Nc;
     if (!ms_per_launch || reps < 1 || elems < 4) return fail(PDWT_ERR_ARG, "pdwt_time_copy: bad arguments");
+    const real_t* src = h->image();
+    long long cap = img;
+    if (elems > img && h->coeff_elems > img) {
+        src = h->arena;
+        cap = h->coeff_elems;
+    }
     if (elems > cap) elems = cap;
     elems &= ~3LL;
     DeviceGuard guard(h->device);
@@ -1730,16 +1738,22 @@ int pdwt_time_copy(pdwt_handle h, long long elems, int reps, float* ms_per_launc
     } ev{&e0, &e1};
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
-    for (int i = 0; i < 3; i++) HIP_TRY(launch_copy(h->image(), h->tmp, elems, h->stream));
+    for (int i = 0; i < 3; i++) HIP_TRY(launch_copy(src, h->tmp, elems, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     HIP_TRY(hipEventRecord(e0, h->stream));
-    for (int i = 0; i < reps; i++) HIP_TRY(launch_copy(h->image(), h->tmp, elems, h->stream));
+    for (int i = 0; i < reps; i++) HIP_TRY(launch_copy(src, h->tmp, elems, h->stream));
     HIP_TRY(hipEventRecord(e1, h->stream));
     HIP_TRY(hipEventSynchronize(e1));
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
     *ms_per_launch = ms / (float)reps;
     return PDWT_OK;
+}
+
+long long pdwt_copy_capacity(pdwt_handle h) {
+    if (!h) return 0;
+    const long long img = (long long)h->batch * h->info.Nr * h->info.Nc;
+    return h->coeff_elems > img ? h->coeff_elems : img;
 }
 
 int pdwt_trim_pool(void) {

@@ -620,6 +620,10 @@ class BatchedWavelets(object):
         check(self._lib.pdwt_time_copy(self._h, int(elems), int(reps), C.byref(ms)))
         return ms.value * 1e3
 
+    def copy_capacity(self):
+        """largest element count time_copy copies without clamping"""
+        return int(self._lib.pdwt_copy_capacity(self._h))
+
     def kernel_times(self, cap=4096):
         """[(name, milliseconds)] of every launch recorded since the last reset."""
         ms = (C.c_float * cap)()

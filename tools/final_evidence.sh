@@ -1,9 +1,9 @@
 #!/bin/bash
-# Round-end evidence run on the GPU box:   gpurun -- 'bash tools/final_evidence.sh r03z'
+# Round-end evidence run on the GPU box:   gpurun -- 'bash tools/final_evidence.sh r04z'
 # GPU tests, every bench line, rocprofv3 kernel-trace summaries + PMC traffic per configuration -> gpurun_out/<tag>/
 # (copy what is to be judged into profiles/).
 set -euo pipefail
-TAG="${1:-r03z}"
+TAG="${1:-r04z}"
 ROOT="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"
 cd "$ROOT"
 OUT="gpurun_out/$TAG"
@@ -20,6 +20,10 @@ WORLD_SIZE=1 RANK=0 LOCAL_RANK=0 MASTER_ADDR=127.0.0.1 MASTER_PORT=29544 timeout
 timeout 900 python3 tools/refbench.py > "$OUT/refbench.txt" 2> "$OUT/refbench.err" || echo "refbench exit $?"
 timeout 300 python3 tools/dispatch_table.py > "$OUT/dispatch_table.md" 2> /dev/null || echo "dispatch table exit $?"
 timeout 300 python3 tools/oddtime.py > "$OUT/oddtime.txt" 2> /dev/null || echo "oddtime exit $?"
+timeout 900 python3 tools/cliffs.py dwt2 swt2 dwt1 swt1 > "$OUT/cliffs.txt" 2> /dev/null || echo "cliffs exit $?"
+timeout 300 python3 tools/opsbench.py > "$OUT/opsbench.txt" 2> /dev/null || echo "opsbench exit $?"
+PDWT_BENCH_SHARE_GPU=1 timeout 400 python3 bench.py --gpus 2 --single-process --config cfg2 --batch 8 --no-cpu-baseline > "$OUT/bench_single_process_two_shards_one_gpu.json" 2> "$OUT/bench_single_process.err" || echo "single-process exit $?"
+timeout 600 python3 tools/tiledbench.py > "$OUT/tiledbench.txt" 2> "$OUT/tiledbench.err" || echo "tiledbench exit $?"
 export TMPDIR=/tmp
 tools/prof.sh "${TAG}_cfg2_b16" --config cfg2 --batch 16 > "$OUT/prof_cfg2_b16.log" 2>&1 || echo "prof b16 exit $?"
 python3 tools/summarize_pmc.py "gpurun_out/prof_${TAG}_cfg2_b16" "$OUT/traffic_cfg2_b16.json" cfg2 > "$OUT/rocprofv3_summary_cfg2_b16.txt" 2>&1 || echo "summarize b16 exit $?"
