@@ -233,8 +233,9 @@ long long pdwt_copy_capacity(pdwt_handle h); /* the largest `elems` pdwt_time_co
  * thread that moves a knob -- cannot change another plan's kernel choice in mid-transform.  Keys:
  *   "wave_min_log2"  a 2D DWT level runs on the wave-per-tile kernels when at least 2^value samples
  *                    enter it (default 22, fp64 library 16; 0 = always when eligible; 63 = never)
- *   "lds_max_log2"   a 2D DWT level of at most 2^value samples (one cache-resident image) prefers the LDS tiles to
- *                    the wave-per-tile kernels (default 24; fp64 library 0 = never)
+ *   "lds_max_log2"   a 2D DWT level of at most 2^value samples prefers the LDS tiles to the wave-per-tile kernels
+ *                    (default 25 since round 4, 24 before: one cache-resident image and the first doubling of it; at the
+ *                    default, forward levels of images below 2^24 samples stay on the tiles up to 2^26; fp64 library 0 = never)
  *   "reg1d"          bit 0 / bit 1: the forward / inverse 1D DWT levels run three at a time in registers
  *                    (dwt1_reg_kernels.hpp) where the rows qualify (even hlen <= 20, rows of >= 2048 samples that
  *                    are multiples of 32); default 3; 0 = the workgroup-wide LDS pyramids (57.6 vs 69.5 us per

@@ -133,10 +133,15 @@ static bool wave_kernels_for(long long samples) {
 // 2048^2: 7.0 / 8.1 against 7.8 / 8.8 (profiles/r02y_kbench_tiles.txt) -- while a batch streamed from HBM keeps the
 // wave kernels' forward (4 x 4096^2: 99 against 107 us).  "lds_max_log2" (PDWT_LDS_MAX) moves the limit (0 = wave kernels
 // wherever they apply, as before).
+// Round 4 re-measured the range between one image and the strips (2^24 < samples < 2^26: two or three 4096^2 images, 8-12
+// of 2048^2, 32-48 of 1024^2; tools/ab_batchrange.sh, profiles/r04_ab_batchrange.txt).  Up to 2^25 samples the tiles win in both
+// directions (forward+inverse db4 2 x 4096^2 173 -> 170 us, 8 x 2048^2 170 -> 161, 32 x 1024^2 165 -> 152; haar 2 x 4096^2
+// 151 -> 139): the default limit is 25.  Above, the wave INVERSE stays ahead (3-8 %), and the wave FORWARD only on images of
+// 2^24 samples (3 x 4096^2: 110 against 117 us; 12 x 2048^2: 114 against 101, 48 x 1024^2: 116 against 97 on the tiles).
 #ifdef PDWT_DOUBLE
 constexpr int kLdsMaxDefault = 0;   // no tuned LDS tiles in the fp64 build
 #else
-constexpr int kLdsMaxDefault = 24;
+constexpr int kLdsMaxDefault = 25;
 #endif
 static std::atomic<int>& lds_max_log2() {
     static std::atomic<int> v{getenv("PDWT_LDS_MAX") ? atoi(getenv("PDWT_LDS_MAX")) : kLdsMaxDefault};
@@ -144,11 +149,14 @@ static std::atomic<int>& lds_max_log2() {
 }
 int set_lds_max_log2(int value) { return lds_max_log2().exchange(value < 0 ? 0 : (value > 62 ? 62 : value)); }
 int get_lds_max_log2() { return lds_max_log2().load(std::memory_order_relaxed); }
-static bool lds_tiles_for(long long samples, int hlen) {
+static bool lds_tiles_for(long long samples, int hlen, long long per_image = 0, bool inverse = true) {
     // ... and only above 2^22 samples: in the step the 2048^2 level of cfg2 is 0.3-0.4 us faster on the wave kernels
     // (10.6 / 11.6 against 11.0 / 11.9 us event-timed), the 4096^2 level 1.0 / 0.3 us faster on the tiles
     const int m = g_active_tuning ? g_active_tuning->lds_max_log2 : lds_max_log2().load(std::memory_order_relaxed);
-    return m > 0 && !(hlen & 1) && samples > (1LL << 22) && samples <= (1LL << m);
+    if (m <= 0 || (hlen & 1) || samples <= (1LL << 22)) return false;
+    if (samples <= (1LL << m)) return true;
+    // forward levels of smaller images, up to where the strips take over
+    return !inverse && m >= kLdsMaxDefault && kLdsMaxDefault > 0 && samples < (1LL << 26) && per_image < (1LL << 24);
 }
 
 Tuning current_tuning() {
@@ -163,7 +171,7 @@ Tuning current_tuning() {
 }
 
 hipError_t launch_dwt2_fwd(const Fwd2DArgs& a, int batch, hipStream_t s) {
-    if (lds_tiles_for((long long)batch * a.Nr * a.Nc, a.hlen)) {
+    if (lds_tiles_for((long long)batch * a.Nr * a.Nc, a.hlen, (long long)a.Nr * a.Nc, false)) {
         const hipError_t e = try_launch_dwt2_fwd_fast(a, batch, s);
         if (e != hipErrorNotSupported) return e;
     }

@@ -438,7 +438,11 @@ void build_schedule(pdwt_plan* p) {
             if (!fusable || no_strip || !pair_ok(l) || !dwt2_strip_supported(hlen, p->lr[l - 1], p->lc[l - 1]) ||
                 (inverse && !force_strip && !(inv_strip_l1 && l == 1)))
                 return false;
-            return force_strip || samples(l) >= (1LL << 26);
+            // (2-tap filters: no rows carried between chunks, the strips are ahead from 2^25 samples on -- forward of 8 x 2048^2
+            // 63 -> 56 us, 32 x 1024^2 60 -> 52, 3 x 4096^2 106 -> 88; longer filters lose there: db4 2 x 4096^2 78 -> 83)
+            static const int strip_min = getenv("PDWT_STRIP_MIN_LOG2") ? atoi(getenv("PDWT_STRIP_MIN_LOG2")) : 0;  // A/B measurements
+            const int min_log2 = strip_min > 0 ? strip_min : (hlen == 2 && sizeof(real_t) == 4 ? 25 : 26);
+            return force_strip || samples(l) >= (1LL << min_log2);
         };
         static const bool inv_pyr_l1 = getenv("PDWT_INV_PYR_L1") != nullptr;  // A/B: the tile pyramid for levels 1+2 of any inverse
         auto pyr_at = [&](int l) { return fusable && !no_pyr && pair_ok(l) && samples(l) <= (1LL << 20); };
@@ -476,11 +480,16 @@ void build_schedule(pdwt_plan* p) {
         // Only while the transform's planes (3 L + 2 of them) about fit the 256 MiB Infinity Cache: the fused kernels
         // keep 7-10 output (input) streams per wavefront going, 1 KiB per row each, which HBM serves badly once the
         // planes are cold -- two 2048^2 images: 343 us fused against 329 us level by level, four: 746 against 715 us,
-        // one: 137 against 183 us (profiles/r02y_bench_cfg4_batch.txt).
+        // one: 137 against 183 us (profiles/r02y_bench_cfg4_batch.txt).  Round 4 measured the two directions apart
+        // (profiles/r04_ab_batchrange.txt): beyond the cache it is the fused FORWARD that loses (2 x 2048^2 haar L3 98 -> 109 us,
+        // db2 102 -> 125) while the fused INVERSE wins by 15-40 % (109 -> 93, db2 158 -> 97; 64 x 512^2 haar 237 -> 174): its
+        // input streams are the ones a launch per level reads too, and it writes ONE plane instead of one per level.  fp32
+        // plans therefore keep the fused inverse at any size.
         const long long swt_bytes = (long long)sizeof(real_t) * (3 * L + 2) * p->batch * p->info.Nr * p->info.Nc;
         auto swt_group = [&](int l, bool inverse) {
             if (!swt || !p->do_separable || !get_swt_fused_enabled()) return 0;
-            if (swt_bytes > (320LL << 20) && get_swt_fused_enabled() < 2) return 0;  // "swt_fused" = 2 forces (tests)
+            if (swt_bytes > (320LL << 20) && get_swt_fused_enabled() < 2 && !(inverse && sizeof(real_t) == 4))
+                return 0;  // "swt_fused" = 2 forces both directions (tests)
             for (int K = (L - l + 1 < 3 ? L - l + 1 : 3); K >= 2; --K) {
                 const bool same_plane = K == 2 && l - 1 >= 1 && l + K - 1 <= L - 1;
                 if (!same_plane && swt2_fused_supported(hlen, p->info.Nr, p->info.Nc, l, K, inverse)) return K;

@@ -5,6 +5,7 @@ is 2x off its neighbours stands out (round 4 found the 4-tap forward wave kernel
 db1 8.5 and db3 11.1).
 
     python3 tools/cliffs.py [dwt2] [swt2] [dwt1] [swt1] [batch] [odd] > profiles/r04_cliffs.txt
+    python3 tools/cliffs.py case dwt2:db4:4096x4096:4:2 swt2:haar:2048x2048:3:4      (explicit cases, for A/B under knobs)
 """
 import os
 import sys
@@ -64,6 +65,12 @@ def case(what, wname, shape, levels, batch=1):
 
 def main():
     which = [a for a in sys.argv[1:] if not a.startswith("-")] or ["dwt2", "swt2", "dwt1", "swt1"]
+    if which[0] == "case":  # explicit cases for A/B runs under different knobs: what:wname:RxC:levels[:batch]
+        for spec in which[1:]:
+            f = spec.split(":")
+            r, c = f[2].split("x")
+            case(f[0], f[1], (int(r), int(c)), int(f[3]), int(f[4]) if len(f) > 4 else 1)
+        return
     print("# tools/cliffs.py: pipelined kernel time per call, (fraction of the per-level streaming rate at 8 TB/s)")
     if "dwt2" in which:
         for shape, L in (((512, 512), 3), ((1024, 1024), 3), ((2048, 2048), 3), ((4096, 4096), 3), ((2048, 2048), 1), ((4096, 4096), 1),
