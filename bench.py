@@ -135,6 +135,8 @@ def label_step_kernels(names, L, chain_levels=None):
             out.append("%s[L%d]" % (n, f)); f += 2
         elif base == "dwt2_fwd_pyr3":
             out.append("%s[L%d]" % (n, f)); f += 3
+        elif base == "dwt2_fwd_tail":  # all remaining levels of a small approximation in one launch
+            out.append("%s[L%d]" % (n, f)); f = L + 1
         elif base == "dwt2_fwd_chain":  # levels f .. min(L, f + 5) whose tiles are whole (plan.cpp: chain_at); all of cfg2's
             out.append("%s[L%d]" % (n, f)); f = chain_end(f, L, chain_levels) + 1
         elif base == "dwt1_fwd_fused":

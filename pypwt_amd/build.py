@@ -39,6 +39,7 @@ SOURCES = [
     "launch_dwt2_fast.hip",
     "launch_dwt2_pyramid.hip",
     "launch_dwt2_pyr3.hip",
+    "launch_dwt2_tail.hip",
     "launch_dwt2_chain.hip",
     "launch_dwt2_wave.hip",
     "launch_dwt1.hip",

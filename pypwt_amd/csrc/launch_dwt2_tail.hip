@@ -1,0 +1,67 @@
+// launch_dwt2_tail.hip -- launchers of the all-remaining-levels kernel for small approximations (dwt2_tail_kernels.hpp).
+// Compiled in both builds (the kernels are written over real_t).
+#include "dwt2_tail_kernels.hpp"
+#include "launch.hpp"
+#include "launch_util.hpp"
+
+#include <atomic>
+
+namespace pdwt {
+
+static int exact_log2(int v) {
+    int lg = 0;
+    while ((1 << lg) < v) ++lg;
+    return (1 << lg) == v ? lg : -1;
+}
+
+// (R0, C0) enter the group's finest level; K levels follow.  Even filter lengths; power-of-two sizes that halve K times;
+// the two LDS planes of the first level fit one CU.
+bool dwt2_tail_supported(int hlen, int R0, int C0, int K) {
+    if (hlen < 2 || (hlen & 1) || hlen > kMaxTaps || K < 1 || K > kTailMaxLevels || R0 < 2 || C0 < 2) return false;
+    if ((long long)R0 * C0 > kTailMaxSamples) return false;
+    const int lgR = exact_log2(R0), lgC = exact_log2(C0);
+    return lgR >= K && lgC >= K;
+}
+
+template <int HLEN, int NT>
+static hipError_t run_tail(const TailArgs& a, bool inverse, int batch, hipStream_t s) {
+    const size_t lds = tail_lds_elems(1 << (a.lgR + a.lgC)) * sizeof(real_t);
+    static std::atomic<bool> big[2][64] = {};
+    if (inverse) {
+        const hipError_t e = allow_big_lds(dwt2_inv_tail_kernel<HLEN, NT>, lds, big[1]);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((dwt2_inv_tail_kernel<HLEN, NT>), dim3(batch), dim3(NT), lds, s, a);
+    } else {
+        const hipError_t e = allow_big_lds(dwt2_fwd_tail_kernel<HLEN, NT>, lds, big[0]);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((dwt2_fwd_tail_kernel<HLEN, NT>), dim3(batch), dim3(NT), lds, s, a);
+    }
+    return hipGetLastError();
+}
+
+// a thread stages kTailTrips values: 1024 threads for planes of more than 4096 samples, 256 below (fewer idle wavefronts at
+// every barrier of the small levels)
+template <int HLEN>
+static hipError_t run_tail_nt(const TailArgs& a, bool inverse, int batch, hipStream_t s) {
+    return (a.lgR + a.lgC) > 12 ? run_tail<HLEN, 1024>(a, inverse, batch, s) : run_tail<HLEN, 256>(a, inverse, batch, s);
+}
+
+// forward: in = A_{l-1} -> det[3 k + b] (band b of the group's k-th level, finest first), out = A_L
+// inverse: in = A_L, det as above -> out = A_{l-1}
+hipError_t launch_dwt2_tail(const real_t* in, real_t* const* det, real_t* out, int R0, int C0, int K, int hlen, bool inverse,
+                            const FilterBank& fb, int batch, hipStream_t s) {
+    if (!dwt2_tail_supported(hlen, R0, C0, K)) return hipErrorNotSupported;
+    TailArgs a;
+    a.in = in; a.out = out; a.lgR = exact_log2(R0); a.lgC = exact_log2(C0); a.K = K; a.hlen = hlen; a.fb = fb;
+    for (int k = 0; k < kTailMaxLevels; k++)
+        for (int b = 0; b < 3; b++) a.det[k][b] = k < K ? det[3 * k + b] : nullptr;
+    switch (hlen) {
+        case 2: return run_tail_nt<2>(a, inverse, batch, s);
+        case 4: return run_tail_nt<4>(a, inverse, batch, s);
+        case 6: return run_tail_nt<6>(a, inverse, batch, s);
+        case 8: return run_tail_nt<8>(a, inverse, batch, s);
+    }
+    return run_tail_nt<0>(a, inverse, batch, s);  // run-time filter length
+}
+
+}  // namespace pdwt

@@ -404,6 +404,7 @@ int create_impl(const real_t* img, int batch, int Nr, int Nc, const char* wname,
 
 constexpr int kMaxFusedLevelsHost = 10;  // == kMaxFusedLevels of dwt1_fused_kernels.hpp
 constexpr int kChainMaxLevelsHost = 6;  // == kChainMaxLevels of dwt2_chain_kernels.hpp
+constexpr int kTailMaxLevelsHost = 14;  // == kTailMaxLevels of dwt2_tail_kernels.hpp
 
 // Where the approximation of level l lives: l = 0 the image, l = L band 0, otherwise its slot in the
 // arena (SWT: two ping-pong planes).  Forward level l reads slot l-1 and writes slot l; inverse level l
@@ -535,9 +536,31 @@ void build_schedule(pdwt_plan* p) {
                 }
             }
         }
+        // The tail: once one image's approximation is small enough for ONE CU, ALL remaining levels in one launch, one
+        // workgroup per image (dwt2_tail_kernels.hpp).  The reference's benchmark and test plans ask for the maximum number
+        // of levels: 2048^2 haar L11 ended in PYR3[7-9] LEVEL[10] LEVEL[11].  The launch costs about 2.5 us + 0.5 us per
+        // level + the arithmetic of its first levels on one CU (~1 us per tap at 128^2), a pyramid launch on such sizes ~3 us
+        // for at most three levels: the tail pays from four or five levels on and only on small planes (samples x taps <=
+        // 2^14: 2-tap filters from 64 x 128 on; longer filters run out of levels first).  tools/tailbench.sh, forward /
+        // forward+inverse us: haar 128^2 L7 12.3 / 36.9 -> 6.7 / 16.6, 1024^2 L10 15.6 / 44.9 -> 11.4 / 27.8, 2048^2 L11
+        // 21.5 / 51.1 -> 17.4 / 40.8, 16 x 128^2 L7 18.9 / 39.8 -> 9.7 / 18.1 (profiles/r04zb_tailbench.txt); wider rules
+        // (2^15-2^16, three levels) lose on 4-tap plans (db2 1024^2 L8 11.5 -> 15.7).
+        // PDWT_NO_TAIL / PDWT_TAIL_WORK_LOG2 / PDWT_TAIL_MIN_K: A/B measurements.
+        // (read per plan, not once per process: the parity tests widen the rule to reach every instantiation)
+        const bool no_tail = getenv("PDWT_NO_TAIL") != nullptr;
+        const int tail_work_log2 = getenv("PDWT_TAIL_WORK_LOG2") ? atoi(getenv("PDWT_TAIL_WORK_LOG2")) : 14;
+        const int tail_min_k = getenv("PDWT_TAIL_MIN_K") ? atoi(getenv("PDWT_TAIL_MIN_K")) : 5;
+        auto tail_at = [&](int l) {
+            const int K = L - l + 1;
+            const long long per_image = (long long)p->lr[l - 1] * p->lc[l - 1];
+            if (!fusable || no_tail || samples(l) > (1LL << 20) || per_image * hlen > (1LL << tail_work_log2)) return 0;
+            if (K < tail_min_k && !(K >= tail_min_k - 1 && per_image <= 1024)) return 0;
+            return dwt2_tail_supported(hlen, p->lr[l - 1], p->lc[l - 1], K) ? K : 0;
+        };
         for (int dir = 0; dir < 2; dir++) {
             std::vector<Step>& out = dir ? p->sched_inv : p->sched_fwd;
             for (int l = 1; l <= L; l++) {
+                if (const int K = tail_at(l)) { out.push_back({Step::TAIL, l, K}); break; }
                 if (const int K = swt_group(l, dir != 0)) { out.push_back({Step::SWTF, l, K}); l += K - 1; continue; }
                 if (const int K = p->chain_flags ? chain_at(l, dir != 0) : 0) { out.push_back({Step::CHAIN, l, K}); l += K - 1; continue; }
                 if (strip_at(l, dir != 0)) { out.push_back({Step::STRIP2, l, 2}); l++; }
@@ -894,6 +917,13 @@ int forward_impl(pdwt_plan* p, int only = 0) {
             if (!run) continue;
             e = launch_dwt2_fwd_chain(approx_slot(p, l - 1), det, app, p->lr[l - 1], p->lc[l - 1], s.K, hlen, p->dec, B,
                                       p->chain_flags, ++p->chain_epoch, p->stream);
+        } else if (s.kind == Step::TAIL) {
+            real_t* det[3 * kTailMaxLevelsHost] = {};
+            for (int k = 0; k < 3 * s.K; k++) det[k] = p->band(3 * (l - 1) + 1 + k);
+            Stamp st(p, "dwt2_fwd_tail");
+            if (!run) continue;
+            e = launch_dwt2_tail(approx_slot(p, l - 1), det, approx_slot(p, l + s.K - 1), p->lr[l - 1], p->lc[l - 1], s.K, hlen, false,
+                                 p->dec, B, p->stream);
         } else if (s.kind == Step::PYR3) {
             real_t* det[9];
             for (int k = 0; k < 9; k++) det[k] = p->band(3 * (l - 1) + 1 + k);
@@ -962,6 +992,13 @@ int inverse_impl(pdwt_plan* p, int only = 0) {
             if (!run) continue;
             e = launch_dwt2_inv_chain(approx_slot(p, l - 1), det, app, p->lr[l - 1], p->lc[l - 1], s.K, hlen, p->rec, B,
                                       p->chain_flags + p->chain_words, ++p->chain_epoch, p->stream);
+        } else if (s.kind == Step::TAIL) {
+            real_t* det[3 * kTailMaxLevelsHost] = {};
+            for (int k = 0; k < 3 * s.K; k++) det[k] = p->band(3 * (l - 1) + 1 + k);
+            Stamp st(p, "dwt2_inv_tail");
+            if (!run) continue;
+            e = launch_dwt2_tail(approx_slot(p, l + s.K - 1), det, approx_slot(p, l - 1), p->lr[l - 1], p->lc[l - 1], s.K, hlen, true,
+                                 p->rec, B, p->stream);
         } else if (s.kind == Step::PYR3) {
             real_t* det[9];
             for (int k = 0; k < 9; k++) det[k] = p->band(3 * (l - 1) + 1 + k);
@@ -1789,7 +1826,7 @@ int pdwt_trim_pool(void) {
 int pdwt_schedule_string(pdwt_handle h, char* buf, size_t n) {
     CHECK_HANDLE(h);
     if (!buf || n == 0) return fail(PDWT_ERR_ARG, "pdwt_schedule_string: no buffer");
-    static const char* kind[] = {"LEVEL", "PYR2", "STRIP2", "FUSED1D", "WAVE2", "REG1D", "SWTF", "PYR3", "CHAIN"};
+    static const char* kind[] = {"LEVEL", "PYR2", "STRIP2", "FUSED1D", "WAVE2", "REG1D", "SWTF", "PYR3", "CHAIN", "TAIL"};
     std::string out;
     for (int dir = 0; dir < 2; dir++) {
         out += dir ? "inv:" : "fwd:";

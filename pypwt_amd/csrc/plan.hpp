@@ -35,7 +35,7 @@ struct Band {
 
 // one launch of a plan's forward / inverse launch list (plan.cpp: build_schedule)
 struct Step {
-    enum Kind { LEVEL = 0, PYR2 = 1, STRIP2 = 2, FUSED1D = 3, WAVE2 = 4, REG1D = 5, SWTF = 6, PYR3 = 7, CHAIN = 8 };
+    enum Kind { LEVEL = 0, PYR2 = 1, STRIP2 = 2, FUSED1D = 3, WAVE2 = 4, REG1D = 5, SWTF = 6, PYR3 = 7, CHAIN = 8, TAIL = 9 };
     int kind;
     int level;  // first (finest) level the launch works on
     int K;      // number of levels it covers

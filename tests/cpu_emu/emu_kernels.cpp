@@ -16,6 +16,7 @@
 #include "../../pypwt_amd/csrc/dwt2_kernels.hpp"
 #include "../../pypwt_amd/csrc/dwt2_pyramid_kernels.hpp"
 #include "../../pypwt_amd/csrc/dwt2_pyr3_kernels.hpp"
+#include "../../pypwt_amd/csrc/dwt2_tail_kernels.hpp"
 #include "../../pypwt_amd/csrc/dwt2_strip_kernels.hpp"
 #include "../../pypwt_amd/csrc/dwt2_wave_kernels.hpp"
 #include "../../pypwt_amd/csrc/nonsep_kernels.hpp"
@@ -467,6 +468,45 @@ EMU_API int emu_dwt2_pyr3(int inverse, float* image, int batch, int N0r, int N0c
 #undef X
     }
     return -1;
+}
+
+// ------------------------------------------------------------------ all remaining levels of a small approximation in one launch
+// det: H,V,D of the group's level 1 (3 x batch x R0/2 x C0/2), then of level 2, ...; app: A_K (batch x R0>>K x C0>>K)
+template <int HLEN>
+static void run_tail_emu(const TailArgs& a, int batch, bool inverse, int threads, float* smem) {
+    for (int bz = 0; bz < batch; bz++) {
+        if (inverse) { if (threads == 1024) dwt2_inv_tail_image<HLEN, 1024>(a, bz, smem); else dwt2_inv_tail_image<HLEN, 256>(a, bz, smem); }
+        else { if (threads == 1024) dwt2_fwd_tail_image<HLEN, 1024>(a, bz, smem); else dwt2_fwd_tail_image<HLEN, 256>(a, bz, smem); }
+    }
+}
+EMU_API int emu_dwt2_tail(int inverse, float* image, int batch, int R0, int C0, int K, const float* lo, const float* hi, int hlen,
+                          int threads, int unrolled, float* det, float* app) {
+    int lgR = 0, lgC = 0;
+    while ((1 << lgR) < R0) lgR++;
+    while ((1 << lgC) < C0) lgC++;
+    if ((hlen & 1) || K < 1 || K > kTailMaxLevels || (1 << lgR) != R0 || (1 << lgC) != C0 || lgR < K || lgC < K) return -2;
+    if ((long long)R0 * C0 > kTailTrips * threads || (long long)R0 * C0 > kTailMaxSamples) return -2;
+    TailArgs a;
+    long long off = 0;
+    for (int k = 0; k < kTailMaxLevels; k++) {
+        const long long n = k < K ? (long long)batch * (R0 >> (k + 1)) * (C0 >> (k + 1)) : 0;
+        for (int b = 0; b < 3; b++) { a.det[k][b] = k < K ? det + off : nullptr; off += n; }
+    }
+    a.in = inverse ? app : image;
+    a.out = inverse ? image : app;
+    a.lgR = lgR; a.lgC = lgC; a.K = K; a.hlen = hlen;
+    set_bank(a.fb, lo, hi, hlen);
+    std::vector<float> smem(tail_lds_elems(R0 * C0) + 64, NAN);
+    if (unrolled && hlen <= 8) {
+        switch (hlen) {
+            case 2: run_tail_emu<2>(a, batch, inverse != 0, threads, smem.data()); return 0;
+            case 4: run_tail_emu<4>(a, batch, inverse != 0, threads, smem.data()); return 0;
+            case 6: run_tail_emu<6>(a, batch, inverse != 0, threads, smem.data()); return 0;
+            case 8: run_tail_emu<8>(a, batch, inverse != 0, threads, smem.data()); return 0;
+        }
+    }
+    run_tail_emu<0>(a, batch, inverse != 0, threads, smem.data());
+    return 0;
 }
 
 // ------------------------------------------------------------------ two-level streaming strips (forward)

@@ -353,6 +353,53 @@ def test_emu_dwt2_inv_pyramid(wname):
                 assert np.abs(out[b] - want).max() <= 3 * _tol(want), (wname, shape, tile)
 
 
+# ----------------------------------------------------------------------------- all remaining levels in one launch (small approximations)
+@pytest.mark.parametrize("wname", ["haar", "db2", "db3", "db4", "bior3.1", "rbio2.2", "sym8", "db10", "db20"])
+def test_emu_dwt2_tail_of_all_remaining_levels(wname):
+    """dwt2_fwd_tail_image / dwt2_inv_tail_image: one workgroup carries one image's approximation through every remaining level
+    out of LDS -- down to 1 x 1 approximations, planes smaller than the filter (the wrap goes around more than once),
+    rectangular planes, a batch, both workgroup sizes, compile-time and run-time filter length."""
+    hlen, dlo, dhi, rlo, rhi = oracle.filters(wname)
+    for si, (B, shape, K) in enumerate([(1, (128, 128), 7), (1, (64, 64), 6), (2, (32, 64), 5), (1, (16, 16), 2), (3, (8, 8), 3),
+                                        (1, (64, 256), 4), (1, (2, 2), 1), (1, (128, 32), 5), (2, (4, 64), 2), (1, (64, 64), 1)]):
+        x = oracle.hash_input((B,) + shape, 9100 + si)
+        dims = [(shape[0] >> k, shape[1] >> k) for k in range(1, K + 1)]
+        ndet = sum(3 * B * r * c for r, c in dims)
+        threads = 1024 if shape[0] * shape[1] > 4096 else (1024, 256)[si % 2]
+        unrolled = si % 3 != 2  # the instantiations with a compile-time filter length (2-8 taps) and the run-time one
+        det = np.full(ndet, np.nan, dtype=np.float32)
+        app = np.full((B,) + dims[-1], np.nan, dtype=np.float32)
+        assert lib().emu_dwt2_tail(0, P(x), B, shape[0], shape[1], K, P(dlo), P(dhi), hlen, threads, int(unrolled), P(det), P(app)) == 0
+        assert np.isfinite(det).all() and np.isfinite(app).all(), (wname, shape)
+
+        def bands_of(flat, b):
+            out, off = [], 0
+            for r, c in dims:
+                lvl = []
+                for _ in range(3):
+                    lvl.append(flat[off:off + B * r * c].reshape(B, r, c)[b])
+                    off += B * r * c
+                out.append(lvl)
+            return out
+
+        for b in range(B):
+            ref = oracle.forward(x[b], wname, K, ndim=2)  # [A_K, H1,V1,D1, ..., H_K,V_K,D_K]
+            got = [app[b]] + [band for lvl in bands_of(det, b) for band in lvl]
+            scale = float(2 ** K) * float(np.abs(x[b]).max())
+            for k, (g, r) in enumerate(zip(got, ref)):
+                assert g.shape == r.shape, (wname, shape, k)
+                assert np.abs(g - r).max() <= 3e-6 * (K + 1) * max(float(np.abs(r).max()), scale), (wname, shape, k)
+        det_in = (oracle.hash_input((ndet,), 9200 + si, 2.0) - 1.0).astype(np.float32)
+        app_in = (oracle.hash_input((B,) + dims[-1], 9250 + si, 2.0) - 1.0).astype(np.float32)
+        out = np.full((B,) + shape, np.nan, dtype=np.float32)
+        assert lib().emu_dwt2_tail(1, P(out), B, shape[0], shape[1], K, P(rlo), P(rhi), hlen, threads, int(unrolled), P(det_in), P(app_in)) == 0
+        for b in range(B):
+            bands = [app_in[b]] + [band for lvl in bands_of(det_in, b) for band in lvl]
+            want = oracle.inverse(bands, shape, wname, K, ndim=2)
+            assert np.isfinite(out[b]).all(), (wname, shape)
+            assert np.abs(out[b] - want).max() <= 4 * (K + 1) * _tol(want), (wname, shape)
+
+
 # ----------------------------------------------------------------------------- three-level pyramid (small images)
 @pytest.mark.parametrize("wname", ["haar", "db2", "db3", "db4", "sym4", "bior3.1", "rbio2.2", "db5", "coif2", "db7", "sym8"])
 def test_emu_dwt2_pyramid_of_three_levels(wname):

@@ -703,3 +703,43 @@ def test_cfg2_default_dispatch_every_element_vs_oracle():
     plan.inverse()
     assert np.abs(plan.image_at(0) - x).max() <= 2e-5 * 255, names
     plan.cleanup()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("wname,shape,levels,batch,wide,expect", [
+    ("haar", (128, 128), 7, 1, 0, 1), ("haar", (2048, 2048), 11, 1, 0, 1), ("db2", (256, 256), 6, 1, 1, 1), ("db2", (2048, 2048), 9, 1, 1, 1),
+    ("db4", (512, 512), 6, 1, 1, 1), ("db3", (128, 128), 5, 4, 1, 1), ("sym8", (1024, 1024), 6, 1, 1, 1), ("haar", (64, 256), 6, 3, 1, 1),
+    ("db20", (512, 512), 3, 1, 1, 0), ("bior2.2", (1024, 512), 8, 2, 1, 0), ("haar", (4096, 4096), 12, 1, 0, 1), ("haar", (128, 128), 7, 16, 0, 1),
+    ("db5", (128, 128), 3, 2, 1, 1), ("haar", (32, 32), 5, 1, 0, 1), ("db2", (2048, 2048), 9, 1, 0, 0)])
+def test_deep_plans_end_in_one_tail_launch(wname, shape, levels, batch, wide, expect, monkeypatch):
+    """Plans with the maximum number of levels (the reference's benchmark and test plans: test/benchmark.py:20-38 passes
+    levels = 99): once an image's approximation fits one CU every remaining level runs in ONE launch (dwt2_tail_kernels.hpp).
+    Every band against the oracle, then the reconstruction.  `wide`: the dispatch rule widened (it takes 2-tap plans only by
+    default) so that every instantiation -- 4, 6, 8 taps unrolled, the run-time length, 128 x 128 entry planes -- is compared."""
+    from pypwt_amd import BatchedWavelets
+    oracle.build()
+    if wide:
+        monkeypatch.setenv("PDWT_TAIL_WORK_LOG2", "20")
+        monkeypatch.setenv("PDWT_TAIL_MIN_K", "2")
+    plan = BatchedWavelets(batch, shape[0], shape[1], wname, levels)
+    L = plan.levels
+    sched = plan.schedule()
+    hlen = oracle.filters(wname)[0]
+    if expect:
+        assert sched.count("TAIL[") == 2, sched  # one per direction
+    plan.fill_hash(777, 255.0)
+    plan.forward()
+    for b in sorted({0, batch - 1}):
+        x = oracle.hash_input(shape, 777, index_offset=b * shape[0] * shape[1])
+        ref = oracle.forward(x, wname, L)
+        for num, r in enumerate(ref):
+            g = plan.coeff_at(num, b)
+            assert g.shape == r.shape
+            err = np.abs(g - r).max()
+            level = L if num == 0 else (num - 1) // 3 + 1  # a level-l coefficient is a combination of 4^l samples, weights 2^-l
+            assert err <= 1.5e-6 * (L + 1) * max(np.abs(r).max(), 255.0 * 2 ** level), (sched, num, err)
+    plan.inverse()
+    for b in sorted({0, batch - 1}):
+        x = oracle.hash_input(shape, 777, index_offset=b * shape[0] * shape[1])
+        assert np.abs(plan.image_at(b) - x).max() <= 7e-4 * 255 * (2 if hlen > 16 else 1), sched
+    plan.cleanup()

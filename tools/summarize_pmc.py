@@ -31,7 +31,7 @@ def short(name):
 def family(kernel):
     """Demangled kernel name -> the launch name plan.cpp stamps (what bench.py labels)."""
     k = short(kernel)
-    for sub, fam in (("fwd_chain", "dwt2_fwd_chain"), ("inv_chain", "dwt2_inv_chain"), ("fwd2_wave", "dwt2_fwd_wave2"), ("inv2_wave", "dwt2_inv_wave2"), ("fwd_pyr2", "dwt2_fwd_pyr2"), ("inv_pyr2", "dwt2_inv_pyr2"), ("fwd_pyr3", "dwt2_fwd_pyr3"), ("inv_pyr3", "dwt2_inv_pyr3"), ("fwd_strip2", "dwt2_fwd_strip2"),
+    for sub, fam in (("fwd_chain", "dwt2_fwd_chain"), ("inv_chain", "dwt2_inv_chain"), ("fwd2_wave", "dwt2_fwd_wave2"), ("inv2_wave", "dwt2_inv_wave2"), ("fwd_pyr2", "dwt2_fwd_pyr2"), ("inv_pyr2", "dwt2_inv_pyr2"), ("fwd_pyr3", "dwt2_fwd_pyr3"), ("inv_pyr3", "dwt2_inv_pyr3"), ("fwd_tail", "dwt2_fwd_tail"), ("inv_tail", "dwt2_inv_tail"), ("fwd_strip2", "dwt2_fwd_strip2"),
                      ("inv_strip2", "dwt2_inv_strip2"), ("dwt1_fwd_fused", "dwt1_fwd_fused"),
                      ("dwt1_inv_fused", "dwt1_inv_fused"), ("dwt1_fwd_reg", "dwt1_fwd_reg"), ("dwt1_inv_reg", "dwt1_inv_reg"),
                      ("swt2_fwd_fused", "swt2_fwd_fused"), ("swt2_inv_fused", "swt2_inv_fused"),
