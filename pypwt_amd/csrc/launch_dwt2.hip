@@ -159,6 +159,16 @@ static bool lds_tiles_for(long long samples, int hlen, long long per_image = 0, 
     return !inverse && m >= kLdsMaxDefault && kLdsMaxDefault > 0 && samples < (1LL << 26) && per_image < (1LL << 24);
 }
 
+// A wavefront of the wave kernels owns a strip of 256 image columns: on a batch of NARROW images most of its lanes idle and
+// every wavefront pays the hlen - 2 warm-up rows for a short walk -- 256 images of 256^2, level 2 (128 columns, 2^22 samples
+// in total): 39.8 us forward / 53.8 us inverse for 32 MiB of traffic, against ~8 us on the LDS tiles (rocprofv3,
+// tools/planprof.sh; the whole db4 L3 plan 155.7 -> see profiles/r04zc_small_batches.txt).  fp32 only (the fp64 library has
+// no tuned tile to fall back to); a threshold forced below its default -- tests -- still takes the wave kernels.
+static bool narrow_for_wave(int Nc) {
+    static const int min_nc = getenv("PDWT_WAVE_MIN_NC") ? atoi(getenv("PDWT_WAVE_MIN_NC")) : 512;  // two full strips; A/B measurements
+    return sizeof(real_t) == 4 && Nc < min_nc && eff_wave_min_log2() >= kWaveMinDefault;
+}
+
 Tuning current_tuning() {
     Tuning t;
     t.wave_min_log2 = get_wave_min_log2();
@@ -180,7 +190,7 @@ hipError_t launch_dwt2_fwd(const Fwd2DArgs& a, int batch, hipStream_t s) {
     // own benchmark plan dwt2 db2 2048^2 L9: 44.7 us; the other lengths are level with the tiles there)
     // (a threshold forced below its default -- tests -- still takes it)
     const bool slow4 = sizeof(real_t) == 4 && a.hlen == 4 && eff_wave_min_log2() >= kWaveMinDefault;
-    if (wave_kernels_for((long long)batch * a.Nr * a.Nc) && !slow4) {
+    if (wave_kernels_for((long long)batch * a.Nr * a.Nc) && !slow4 && !narrow_for_wave(a.Nc)) {
         const hipError_t e = try_launch_dwt2_fwd_wave(a, batch, s);
         if (e != hipErrorNotSupported) return e;
     }
@@ -215,7 +225,7 @@ hipError_t launch_dwt2_inv(const Inv2DArgs& a, int batch, hipStream_t s) {
 #else
     constexpr long long kInvWaveMax = 1LL << 26;
 #endif
-    if (wave_kernels_for(samples) && samples < kInvWaveMax) {
+    if (wave_kernels_for(samples) && samples < kInvWaveMax && !narrow_for_wave(a.Nc)) {
         const hipError_t e = try_launch_dwt2_inv_wave(a, batch, s);
         if (e != hipErrorNotSupported) return e;
     }

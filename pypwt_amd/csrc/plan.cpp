@@ -550,9 +550,20 @@ void build_schedule(pdwt_plan* p) {
         const bool no_tail = getenv("PDWT_NO_TAIL") != nullptr;
         const int tail_work_log2 = getenv("PDWT_TAIL_WORK_LOG2") ? atoi(getenv("PDWT_TAIL_WORK_LOG2")) : 14;
         const int tail_min_k = getenv("PDWT_TAIL_MIN_K") ? atoi(getenv("PDWT_TAIL_MIN_K")) : 5;
+        const long long tail_batch = getenv("PDWT_TAIL_BATCH") ? atoll(getenv("PDWT_TAIL_BATCH")) : 4096;  // largest image taken in batch mode (0 = off)
         auto tail_at = [&](int l) {
             const int K = L - l + 1;
             const long long per_image = (long long)p->lr[l - 1] * p->lc[l - 1];
+            // a BATCH of tiny images (<= 64 x 64) is the opposite regime, throughput: thousands of independent workgroups, four per
+            // CU, each transforming its image out of LDS with no halo and no padding, where the tile kernels launch eight mostly
+            // empty workgroups per image and level -- 4096 images of 64^2, db4 L3: forward 196 us on the level kernels
+            // (B x n^2, forward+inverse us: 4096 x 64^2 db4 L3 313 -> 121, 4096 x 32^2 db2 L3 453 -> 38, 1024 x 64^2 sym8 L2 198 -> 54;
+            // 128 x 128 images only with five levels and more: 256 x 128^2 db2 L5 43.5 -> 29.5, but 1024 x 128^2 db4 L3 102 -> 136;
+            // profiles/r04zc_small_batches.txt)
+            if (fusable && !no_tail && (per_image <= tail_batch || (per_image <= 4 * tail_batch && K >= 5)) &&
+                per_image * hlen <= 16 * tail_batch && samples(l) >= (1LL << 20) &&
+                dwt2_tail_supported(hlen, p->lr[l - 1], p->lc[l - 1], K))
+                return K;
             if (!fusable || no_tail || samples(l) > (1LL << 20) || per_image * hlen > (1LL << tail_work_log2)) return 0;
             if (K < tail_min_k && !(K >= tail_min_k - 1 && per_image <= 1024)) return 0;
             return dwt2_tail_supported(hlen, p->lr[l - 1], p->lc[l - 1], K) ? K : 0;

@@ -743,3 +743,34 @@ def test_deep_plans_end_in_one_tail_launch(wname, shape, levels, batch, wide, ex
         x = oracle.hash_input(shape, 777, index_offset=b * shape[0] * shape[1])
         assert np.abs(plan.image_at(b) - x).max() <= 7e-4 * 255 * (2 if hlen > 16 else 1), sched
     plan.cleanup()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("wname,shape,levels,batch", [("db4", (64, 64), 3, 300), ("db2", (32, 32), 3, 1100), ("sym8", (64, 64), 2, 260),
+                                                      ("haar", (16, 16), 4, 4200), ("db4", (32, 64), 2, 520), ("db2", (128, 128), 5, 70),
+                                                      ("db4", (128, 128), 3, 70), ("db3", (64, 64), 1, 256), ("db4", (256, 256), 3, 20)])
+def test_batches_of_small_images(wname, shape, levels, batch):
+    """Large batches of tiny images (at least 2^20 samples in all): every image is ONE workgroup of the tail launch, whole transform out of
+    LDS (64 x 64 and below; 128 x 128 with five levels and more), narrower tiles and no wave kernels on the levels that stay with
+    the level kernels.  First, middle and last image against the oracle, then the reconstruction."""
+    from pypwt_amd import BatchedWavelets
+    oracle.build()
+    plan = BatchedWavelets(batch, shape[0], shape[1], wname, levels)
+    L, sched = plan.levels, plan.schedule()
+    if shape[0] * shape[1] <= 4096 and batch * shape[0] * shape[1] >= (1 << 20):
+        assert sched.count("TAIL[1") == 2, sched
+    plan.fill_hash(4242, 255.0)
+    plan.forward()
+    n = shape[0] * shape[1]
+    for b in sorted({0, batch // 2, batch - 1}):
+        x = oracle.hash_input(shape, 4242, index_offset=b * n)
+        ref = oracle.forward(x, wname, L)
+        for num, r in enumerate(ref):
+            g = plan.coeff_at(num, b)
+            level = L if num == 0 else (num - 1) // 3 + 1
+            assert np.abs(g - r).max() <= 1.5e-6 * (L + 1) * max(np.abs(r).max(), 255.0 * 2 ** level), (sched, b, num)
+    plan.inverse()
+    for b in sorted({0, batch // 2, batch - 1}):
+        x = oracle.hash_input(shape, 4242, index_offset=b * n)
+        assert np.abs(plan.image_at(b) - x).max() <= 7e-4 * 255, (sched, b)
+    plan.cleanup()
