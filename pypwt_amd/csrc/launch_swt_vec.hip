@@ -49,6 +49,22 @@ hipError_t try_launch_swt2_vec(const Swt2DArgs& a, bool inverse, int batch, hipS
     // Tile height (profiles/r03l_swt_tile_height.txt, 2048^2, three levels forward): 16 rows are best up to 24 taps (db5 95 us
     // against 100 / 103 with 32 / 64 rows, sym8 123 / 142 / 137, db12 212 / 238 / 357); 40 taps re-filter 39 halo rows per
     // tile and gain with 32 rows (910 -> 773 us).
+    // Small levels (round 4): 128 x 16 tiles give a 256^2 image 32 workgroups on 256 CUs, each a long serial chain -- the time
+    // of a level is one tile's latency (db4 256^2: 7.6 us forward, 13.4 us inverse per level).  Below 256 workgroups the
+    // tiles shrink to 64 x 8 (128 threads): four times the workgroups, each a quarter of the chain.
+    static const int small_tiles = getenv("PDWT_SWT_SMALL_TILE") ? atoi(getenv("PDWT_SWT_SMALL_TILE")) : 256;  // workgroups; A/B measurements
+    const long long wgs = (long long)cdiv(a.Nc, 128) * cdiv(a.Nr / a.f, 16) * a.f * batch;
+    if (wgs < small_tiles && a.hlen <= 24 && sizeof(real_t) == 4) {
+        switch (a.hlen) {
+#define X(h)                                                                                                   \
+    case h:                                                                                                    \
+        if constexpr (h <= 24)                                                                                 \
+            return inverse ? run_vec<h, true, 64, 8, 128>(a, batch, s) : run_vec<h, false, 64, 8, 128>(a, batch, s); \
+        break;
+            PDWT_EVEN_HLENS(X)
+#undef X
+        }
+    }
     switch (a.hlen) {
 #define X(h)                                                                                                   \
     case h:                                                                                                    \
