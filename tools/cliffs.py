@@ -4,7 +4,7 @@ wavelet x size x levels -- with the fraction of the per-level streaming rate eac
 is 2x off its neighbours stands out (round 4 found the 4-tap forward wave kernel that way: db2 2048^2 22.6 us next to
 db1 8.5 and db3 11.1).
 
-    python3 tools/cliffs.py [dwt2] [swt2] [dwt1] [swt1] [batch] [odd] > profiles/r04_cliffs.txt
+    python3 tools/cliffs.py [dwt2] [swt2] [dwt1] [swt1] [batch] [odd] [small] > profiles/r04_cliffs.txt
     python3 tools/cliffs.py case dwt2:db4:4096x4096:4:2 swt2:haar:2048x2048:3:4      (explicit cases, for A/B under knobs)
 """
 import os
@@ -106,6 +106,19 @@ def main():
                 case("swt2", w, shape, 2)
             for shape in ((1, (1 << 24) - 1), (1, (1 << 24) - 2), (1, 10000000), (4095, 4095), (1000, 5000)):
                 case("dwt1", w, shape, 4)
+    if "small" in which:  # small inputs: a launch is a latency chain, the grid rarely fills the chip
+        for shape, L in (((128, 128), 3), ((256, 256), 3)):
+            for w in WAVELETS:
+                case("dwt2", w, shape, L)
+        for shape, L in (((128, 128), 2), ((256, 256), 3)):
+            for w in WAVELETS:
+                case("swt2", w, shape, L)
+        for shape, L in (((1, 1 << 14), 4), ((1, 1 << 17), 5), ((64, 1024), 4), ((16, 16384), 4)):
+            for w in WAVELETS:
+                case("dwt1", w, shape, L)
+        for shape, L in (((1, 1 << 14), 3), ((1, 1 << 17), 3), ((64, 1024), 3)):
+            for w in WAVELETS:
+                case("swt1", w, shape, L)
     if "swt1" in which:
         for shape, L in (((1, 1 << 20), 4), ((1, 1 << 24), 4), ((4096, 4096), 4)):
             for w in WAVELETS:
