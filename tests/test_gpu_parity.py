@@ -565,6 +565,7 @@ F64_CASES = [
     ("coif5", (128, 96), 1, 2, 0), ("db20", (160, 160), 2, 2, 0), ("rbio6.8", (40, 200), 2, 2, 0),
     ("sym8", (4, 4096), 5, 1, 0), ("db3", (1, 1000), 3, 1, 0),
     ("haar", (64, 64), 3, 2, 1), ("db2", (48, 80), 2, 2, 1), ("sym4", (3, 256), 3, 1, 1),
+    ("haar", (128, 64), 6, 2, 0), ("haar", (32, 32), 5, 2, 0),  # deep plans: the tail launch over doubles
 ]
 
 

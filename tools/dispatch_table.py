@@ -20,6 +20,9 @@ CASES = [
     ("2048^2 db2 SWT L3 (doc/denoising.rst)", 1, 2048, 2048, "db2", 3, 1, 2), ("4 x 2048^2 haar SWT L5", 4, 2048, 2048, "haar", 5, 1, 2),
     ("1D SWT 2^24 db4 L5", 1, 1, 1 << 24, "db4", 5, 1, 1), ("4096 rows x 4096 sym8 L6 (batched 1D)", 1, 4096, 4096, "sym8", 6, 0, 1),
     ("1D 2^24 db20 L6", 1, 1, 1 << 24, "db20", 6, 0, 1),
+    ("2048^2 haar L11 (test/benchmark.py: maximum levels)", 1, 2048, 2048, "haar", 11, 0, 2), ("128^2 haar L7", 1, 128, 128, "haar", 7, 0, 2),
+    ("2048^2 db2 L9", 1, 2048, 2048, "db2", 9, 0, 2), ("4096 x 64^2 db4 L3 (batch of tiny images)", 4096, 64, 64, "db4", 3, 0, 2),
+    ("256 x 256^2 db4 L3", 256, 256, 256, "db4", 3, 0, 2), ("2 x 4096^2 haar L4", 2, 4096, 4096, "haar", 4, 0, 2),
 ]
 
 print("| plan | forward launches | inverse launches |")
