@@ -220,6 +220,15 @@ int pdwt_reset_kernel_times(pdwt_handle h);
  * milliseconds per repetition.  The data the level reads is whatever the buffers hold (run a
  * forward first); nothing else of the plan's state changes. */
 int pdwt_time_level(pdwt_handle h, int level, int inverse, int reps, float* ms_per_launch);
+/* Bind the plan's IMAGE to device memory the caller owns: from now on forward() reads its input there and inverse()
+ * writes its reconstruction there (batch x Nr x Nc elements, row-major, on the plan's device; 16-byte aligned for the tuned
+ * kernels -- otherwise the generic ones run); pdwt_image_ptr returns it; the plan's own image buffer is unused.  NULL
+ * unbinds.  The memory must outlive the binding; nothing is copied.  Use: chaining plans without copies -- one level's
+ * approximation band (pdwt_coeff_ptr(prev, 0)) IS the next level plan's image (pypwt_amd/tiled.py keeps the row slabs of an
+ * image tiled over several GPUs that way).  No reference counterpart (the reference owns all its buffers, wt.cu:527-539).
+ * Synchronises the plan's stream. */
+int pdwt_bind_image(pdwt_handle h, void* device_ptr);
+
 /* the measured ceiling beside it: a plain 16-B-per-lane grid-stride copy of `elems` values (clamped to pdwt_copy_capacity,
  * rounded down to a multiple of 4) from the plan's image buffer (its coefficient region when elems exceeds the image) into scratch, `reps` launches back to back between two
  * HIP events on the plan's stream; mean milliseconds per launch.  It moves 2 * elems * sizeof(pdwt_real) bytes: a level

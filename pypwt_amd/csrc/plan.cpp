@@ -1587,6 +1587,16 @@ int pdwt_set_coeff(pdwt_handle h, const real_t* src, int num, int mem_is_on_devi
 
 intptr_t pdwt_image_ptr(pdwt_handle h) { return h ? (intptr_t)h->image() : 0; }
 
+int pdwt_bind_image(pdwt_handle h, void* device_ptr) {
+    CHECK_HANDLE(h);
+    if (device_ptr && (reinterpret_cast<uintptr_t>(device_ptr) & (sizeof(real_t) - 1)))
+        return fail(PDWT_ERR_ARG, "pdwt_bind_image: the pointer is not aligned for the element type");
+    DeviceGuard guard(h->device);
+    HIP_TRY(hipStreamSynchronize(h->stream));  // nothing in flight may still use the old location
+    h->image_ext = static_cast<real_t*>(device_ptr);
+    return PDWT_OK;
+}
+
 intptr_t pdwt_coeff_ptr(pdwt_handle h, int num) {
     if (!h || num < 0 || num >= (int)h->bands.size()) return 0;
     {

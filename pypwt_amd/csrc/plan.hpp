@@ -103,6 +103,7 @@ struct pdwt_plan {
     bool timing = false;
     std::vector<pdwt::KernelStamp> stamps;
 
-    real_t* image() const { return arena + image_off; }
+    real_t* image_ext = nullptr;  // pdwt_bind_image: the image lives in memory the caller owns (another plan's band, say)
+    real_t* image() const { return image_ext ? image_ext : arena + image_off; }
     real_t* band(int num) const { return arena + bands[num].off; }
 };

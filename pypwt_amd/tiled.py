@@ -76,10 +76,11 @@ class _LevelPlan(object):
         self.stack = region.as_strided((nb,) + shapes[0], (step, shapes[0][1], 1)) if same else None
 
     @staticmethod
-    def halo_pieces(t, h, m):
-        """rows [h, h + m) of `t` (rows on its last-but-one axis) are this rank's; the four row ranges of an exchange:
-        (top rows, bottom rows, halo above, halo below)"""
-        return (t[..., h:2 * h, :], t[..., m:m + h, :], t[..., :h, :], t[..., h + m:, :])
+    def halo_pieces(t, H, h, m):
+        """rows [H, H + m) of `t` (rows on its last-but-one axis) are this rank's, the h rows on either side of them the
+        halo the level needs (the margin beyond, H - h rows per side, is never read for a row that is kept); the four row
+        ranges of an exchange: (top rows, bottom rows, halo above, halo below)"""
+        return (t[..., H:H + h, :], t[..., H + m - h:H + m, :], t[..., H - h:H, :], t[..., H + m:H + m + h, :])
 
     def destroy(self):
         if self.h is not None:
@@ -90,8 +91,11 @@ class _LevelPlan(object):
 class TiledWavelets(object):
     """Data layout: the slab and every band slab live INSIDE the buffers of the single-GPU plans that work on them
     (the interior rows of an extended slab); the halo rows around them are received straight into the same buffers.
-    A level therefore costs its kernel, one halo exchange and (from level 2 on) one copy of the approximation slab
-    into the next plan -- no staging tensors.  `coeffs` / `image` copy to the host when asked.
+    A level costs its kernel and one halo exchange -- no staging tensors and (round 4) no copy of the approximation between
+    levels: the image of level l + 1's plan IS band 0 of level l's plan (pdwt_bind_image).  For that the margins shrink
+    geometrically: level l's slab is extended by H_l = hp 2^(t - l) rows per side (t = tiled levels), its bands by H_l / 2 =
+    H_(l+1), so the geometries chain; only the hp (hq) rows next to the interior are exchanged and read, the rest of the
+    margin is room.  `coeffs` / `image` copy to the host when asked.
 
     Aliasing: `slab` and the tensors of `device_coeffs` are zero-copy VIEWS of plan buffers.  They are overwritten by
     the next forward() / inverse() (clone what must survive), `slab` is None after cleanup(), and editing the
@@ -178,32 +182,42 @@ class TiledWavelets(object):
                                  % (self.n, self.wname, max(self._hp, 2 * self._hq)))
             self.tiled_levels, self.deep_levels = t, self.levels - t
             P = self._level(1)
-            self.slab = P.img[self._hp:self._hp + self.n]   # the slab lives in the interior of level 1's plan
+            H1 = self._margin(1)
+            self.slab = P.img[H1:H1 + self.n]   # the slab lives in the interior of level 1's plan
         with self._on_stream():
             self.slab.copy_(src.to(self.device, dtype=torch.float32, non_blocking=False))
 
-    # ---- plans, cached per extended shape.  Level l (1-based) of the decimated transform works on the slab of
-    # n / 2^(l-1) rows extended by hp rows per side; its four outputs are (that / 2 + 2 hq) rows -- and since
-    # hp = 2 hq the SAME plan undoes the level: one plan per level holds the slab's interior and halos of both
+    # ---- plans, one per level.  Level l (1-based) of the decimated transform works on the slab of n / 2^(l-1) rows extended by
+    # _margin(l) rows per side; its four outputs have half the rows, margins included -- and since the synthesis halo is half
+    # the analysis halo the SAME plan undoes the level: one plan per level holds the slab's interior and the halos of both
     # directions.
-    def _plan(self, rows, cols):
-        key = (rows, cols)
-        if key not in self._plans:
+    def _margin(self, l):
+        """rows by which level l's slab is extended per side: hp 2^(t - l); its bands are extended by half of that"""
+        return self._hp << (self.tiled_levels - l)
+
+    def _level(self, l):
+        """the one-level plan of level l (1-based): the slab of n / 2^(l-1) rows extended by _margin(l) rows per side.  From
+        level 2 on its image is bound to band 0 of the level above (same geometry by construction): no copy in either
+        direction."""
+        if l not in self._plans:
+            rows, cols = (self.n >> (l - 1)) + 2 * self._margin(l), self.Nc >> (l - 1)
             P = _LevelPlan(self, rows, cols, 1, 0)
             if P.levels != 1:
                 P.destroy()
                 raise ValueError("TiledWavelets: %d x %d is too small for one level of %s" % (rows, cols, self.wname))
-            self._plans[key] = P
-        return self._plans[key]
+            if l > 1:
+                up = self._level(l - 1)
+                assert tuple(up.co[0].shape) == (rows, cols), (tuple(up.co[0].shape), rows, cols)
+                check(self._lib.pdwt_bind_image(P.h, C.c_void_p(up.co[0].data_ptr())), "TiledWavelets plan", self._lib)
+                P.img = up.co[0]
+            self._plans[l] = P
+        return self._plans[l]
 
-    def _level(self, l):
-        return self._plan((self.n >> (l - 1)) + 2 * self._hp, self.Nc >> (l - 1))
-
-    def _pieces(self, P, what, h, m):
-        """cached halo row ranges of a plan's image ("img") or band stack ("stack")"""
+    def _pieces(self, P, what, H, h, m):
+        """cached halo row ranges of a plan's image ("img") or band stack ("stack"): interior rows [H, H + m), halo h"""
         key = (id(P), what)
         if key not in self._piece_cache:
-            self._piece_cache[key] = _LevelPlan.halo_pieces(getattr(P, what), h, m)
+            self._piece_cache[key] = _LevelPlan.halo_pieces(getattr(P, what), H, h, m)
         return self._piece_cache[key]
 
     def _view(self, ptr, shape):
@@ -306,7 +320,7 @@ class TiledWavelets(object):
     def _forward_swt(self):
         m, hs = self.n, self._hs
         P = self._swt_plan()
-        self._exchange_into([self._pieces(P, "img", hs, m)])
+        self._exchange_into([self._pieces(P, "img", hs, hs, m)])
         check(self._lib.pdwt_forward(P.h), "TiledWavelets.forward (SWT)", self._lib)
         flat = [b[hs:hs + m] for b in P.co]
         self._bands = [flat[0]] + [tuple(flat[1 + 3 * l:4 + 3 * l]) for l in range(self.levels)]
@@ -316,7 +330,7 @@ class TiledWavelets(object):
         m, hs = self.n, self._hs
         P = self._swt_plan()
         # the halo rows of all 3 levels + 1 bands, received into the bands' own buffers: one message per neighbour
-        self._exchange_into([self._pieces(P, "stack", hs, m)])
+        self._exchange_into([self._pieces(P, "stack", hs, hs, m)])
         check(self._lib.pdwt_inverse(P.h), "TiledWavelets.inverse (SWT)", self._lib)
         return self
 
@@ -332,16 +346,13 @@ class TiledWavelets(object):
         bands = [None]
         P = None
         for l in range(1, self.tiled_levels + 1):
-            m = self.n >> (l - 1)
-            Q = self._level(l)
-            if P is not None:
-                Q.img[hp:hp + m].copy_(P.co[0][hq:hq + m])   # A of the level above: the interior rows of its plan's band 0
-            P = Q
+            m, H = self.n >> (l - 1), self._margin(l)
+            P = self._level(l)   # its image is band 0 of the level above: A is already where it is needed
             if hp:
-                self._exchange_into([self._pieces(P, "img", hp, m)])
+                self._exchange_into([self._pieces(P, "img", H, hp, m)])
             check(self._lib.pdwt_forward(P.h), "TiledWavelets.forward", self._lib)
-            bands.append(tuple(P.co[k][hq:hq + m // 2] for k in (1, 2, 3)))
-        cur = P.co[0][hq:hq + (self.n >> self.tiled_levels)]
+            bands.append(tuple(P.co[k][H // 2:H // 2 + m // 2] for k in (1, 2, 3)))
+        cur = P.co[0][hq:hq + (self.n >> self.tiled_levels)]   # the last level's band margin is hp / 2 = hq
         bands[0] = cur
         if self.deep_levels:
             bands[0] = None
@@ -436,10 +447,8 @@ class TiledWavelets(object):
             m2 = self.n >> l
             P = self._level(l)
             if hq:
-                self._exchange_into([self._pieces(P, "stack", hq, m2)])
-            check(self._lib.pdwt_inverse(P.h), "TiledWavelets.inverse", self._lib)
-            if l > 1:  # the interior of the reconstruction is A of the level above
-                self._level(l - 1).co[0][hq:hq + 2 * m2].copy_(P.img[hp:hp + 2 * m2])
+                self._exchange_into([self._pieces(P, "stack", self._margin(l) // 2, hq, m2)])
+            check(self._lib.pdwt_inverse(P.h), "TiledWavelets.inverse", self._lib)   # writes A of the level above in place
         self._in_coeff_domain = False
         return self
 

@@ -852,3 +852,35 @@ def test_plan_keeps_the_tuning_it_was_created_with():
                 assert np.abs(plan.coeff(k)[0] - r).max() <= 2e-5 * max(float(np.abs(r).max()), 255.0)
     finally:
         lib.pdwt_set_tuning(b"swt_split_fwd", prev)
+
+
+@pytest.mark.gpu
+def test_bind_image_chains_two_plans_without_a_copy(W):
+    """pdwt_bind_image: the image of a second plan IS band 0 of the first (no reference counterpart: the reference owns all of
+    its buffers, wt.cu:527-539).  Two one-level plans chained that way equal the oracle's two-level transform; the inverse of
+    the second plan writes the first plan's approximation in place; unbinding restores the plan's own buffer."""
+    import ctypes as C
+    from pypwt_amd import _lib
+    lib = _lib.load()
+    x = oracle.hash_input((256, 192), 61)
+    ref = oracle.forward(x, "db3", 2)  # [A2, H1, V1, D1, H2, V2, D2]
+    a = W(x, "db3", 1)
+    b = W(np.zeros((128, 96), dtype=np.float32), "db3", 1)
+    own = lib.pdwt_image_ptr(b._h)
+    assert lib.pdwt_bind_image(b._h, C.c_void_p(lib.pdwt_coeff_ptr(a._h, 0))) == 0
+    assert lib.pdwt_image_ptr(b._h) == lib.pdwt_coeff_ptr(a._h, 0) != own
+    a.forward()
+    lib.pdwt_synchronize(a._h)  # the two plans run on private streams: b reads what a wrote
+    b.forward()
+    got = [b.coeffs[0]] + list(a.coeffs[1]) + list(b.coeffs[1])
+    for k, (g, r) in enumerate(zip(got, ref)):
+        assert np.abs(g - r).max() <= 1.5e-6 * 3 * max(1.0, float(np.abs(r).max())), k
+    # the inverse of the second plan reconstructs A1 INTO the first plan's band 0
+    A1 = a.coeffs[0].copy()
+    a.set_coeff(np.zeros_like(A1), 0)
+    b.inverse()
+    lib.pdwt_synchronize(b._h)
+    back = np.empty_like(A1)
+    assert lib.pdwt_get_coeff(a._h, back.ctypes.data_as(C.POINTER(C.c_float)), 0) == A1.size
+    assert np.abs(back - A1).max() <= 2e-4 * max(1.0, float(np.abs(A1).max()))
+    assert lib.pdwt_bind_image(b._h, None) == 0 and lib.pdwt_image_ptr(b._h) == own
