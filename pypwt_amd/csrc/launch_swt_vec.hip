@@ -42,6 +42,24 @@ static bool vec_ok(const Swt2DArgs& a, bool inverse) {
 
 hipError_t try_launch_swt2_vec(const Swt2DArgs& a, bool inverse, int batch, hipStream_t s) {
     if (!vec_ok(a, inverse)) return hipErrorNotSupported;
+    // Deep levels (round 4): a tile is TY rows of ONE dilation phase, and a phase has only Nr / f rows -- at the last levels of a
+    // maximum-level plan (2048^2 haar L11: f = 1024, two rows per phase) a 16-row tile is 7/8 padding: forward level 11 34 us,
+    // inverse 51 us against 16-20 us for the levels before.  Phases shorter than 16 rows take tiles of 8, 4 or 2 rows (2-8 taps).
+    {
+        static const bool deep_tiles = !(getenv("PDWT_SWT_DEEP_TILE") && atoi(getenv("PDWT_SWT_DEEP_TILE")) == 0);  // A/B measurements
+        const int M = a.Nr / a.f;
+        if (deep_tiles && M < 16 && a.hlen <= 8 && sizeof(real_t) == 4) {
+            switch (a.hlen) {
+#define X(h)                                                                                                                   \
+    case h:                                                                                                                    \
+        if (M >= 8) return inverse ? run_vec<h, true, 128, 8, 256>(a, batch, s) : run_vec<h, false, 128, 8, 256>(a, batch, s); \
+        if (M >= 4) return inverse ? run_vec<h, true, 128, 4, 128>(a, batch, s) : run_vec<h, false, 128, 4, 128>(a, batch, s); \
+        return inverse ? run_vec<h, true, 128, 2, 64>(a, batch, s) : run_vec<h, false, 128, 2, 64>(a, batch, s);
+                X(2) X(4) X(6) X(8)
+#undef X
+            }
+        }
+    }
     // short filters: 256-column tiles (1 KiB contiguous per row and band; cfg4 in-step 182 -> 176 us, although
     // a level repeated on cache-resident data is faster with 128: 16.5 vs 18.4 us)
     if (a.Nc >= 512 && a.hlen == 2) return inverse ? run_vec<2, true, 256>(a, batch, s) : run_vec<2, false, 256>(a, batch, s);
