@@ -59,8 +59,11 @@ bool swt2_split_supported(int hlen, int Nr, int Nc, int f, bool inverse, long lo
         // small launches: two launches of one round each cost more than they save until the filter is long -- inverse levels of
         // 256^2 / 512^2: 10 taps 13 | 17-18 us (tiled | split), 16 taps 16 | 21-22, 26 taps 33 | 26-27, 40 taps 31-44 | 22-35;
         // 1024^2: 12 taps 24 | 23, 16 taps 28 | 25, 20 taps 35 | 28 (profiles/r03_swt_split_sweep.txt)
+        // (8 taps at dilation 1 and 2 -- the rule below -- already from 1.5 M samples on: a 1080 x 1920 image, db4 L3 forward+inverse
+        // 121 -> 105 us, 1200 x 1600 121 -> 102; at 1024^2 and below the tiles stay ahead: 79 against 90 us)
+        const bool eight_mid = hlen == 8 && f <= 2 && min_taps <= 10 && samples >= (3LL << 19);
         if (samples < (1LL << 20) && min_taps < 24) min_taps = 24;
-        else if (samples < (1LL << 22) && min_taps < 12) min_taps = 12;
+        else if (samples < (1LL << 22) && min_taps < 12 && !eight_mid) min_taps = 12;
         // 8 taps (db4, sym4, bior2.4 ...), dilation 1 and 2, from 2048^2 on: the tiled inverse issues one 16-B load per band and
         // tap at 4-B / 8-B alignment there (52-55 us per 2048^2 level against 33 at dilation 4, where the loads are aligned);
         // the two launches stage aligned quads through LDS: 35.6 / 33.4 us, 4096^2 190.8 / 199.2 -> 140.8 / 164.6
