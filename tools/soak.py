@@ -1,0 +1,93 @@
+#!/usr/bin/env python3
+"""Randomised soak of the dispatch paths the unit-test fuzz (tests/test_gpu_fuzz.py: single images up to 384 px, batches of 2-5)
+does not reach: LARGE batches of small images (tail launch in batch mode, narrow tiles, no wave kernels on narrow levels), deep
+plans with the maximum number of levels, mid-size and HD-size SWT plans (small tiles, deep tiles, split kernels), batches between
+one image and the strips.  Every case: forward against the CPU oracle on a few images of the batch, then the reconstruction.
+
+    python3 tools/soak.py [seconds] [seed]        (oracle/ is test infrastructure: this tool is a test, not a product path)
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import oracle  # noqa: E402
+from pypwt_amd import BatchedWavelets  # noqa: E402
+
+
+def check(B, shape, wname, L, swt, rng, tag):
+    try:
+        plan = BatchedWavelets(B, shape[0], shape[1], wname, L, do_swt=swt)
+    except ValueError:
+        return 0
+    L = plan.levels
+    seed = int(rng.integers(1, 1 << 30))
+    plan.fill_hash(seed, 255.0)
+    plan.forward()
+    n = shape[0] * shape[1]
+    hlen = oracle.filters(wname)[0]
+    loose = 40.0 if wname in ("bior3.1", "rbio3.1") else 1.0
+    for b in sorted({0, int(rng.integers(0, B)), B - 1}):
+        x = oracle.hash_input(shape, seed, index_offset=b * n)
+        ref = oracle.forward(x, wname, L, do_swt=swt)
+        for num, r in enumerate(ref):
+            g = plan.coeff_at(num, b)
+            level = L if num == 0 else (num - 1) // 3 + 1
+            tol = loose * 2e-6 * (L + 1) * max(float(np.abs(r).max()), 255.0 * (2 ** level))
+            err = float(np.abs(g - r).max())
+            if not (g.shape == r.shape and err <= tol):
+                raise AssertionError("%s: B=%d %s %s L=%d swt=%d image %d band %d err %g tol %g | %s"
+                                     % (tag, B, shape, wname, L, swt, b, num, err, tol, plan.schedule().replace("\n", " | ")))
+    plan.inverse()
+    for b in sorted({0, B - 1}):
+        x = oracle.hash_input(shape, seed, index_offset=b * n)
+        err = float(np.abs(plan.image_at(b) - x).max())
+        if not err <= loose * 7e-4 * 255 * (2 if hlen > 16 else 1):
+            raise AssertionError("%s: B=%d %s %s L=%d swt=%d image %d reconstruction err %g | %s"
+                                 % (tag, B, shape, wname, L, swt, b, err, plan.schedule().replace("\n", " | ")))
+    plan.cleanup()
+    return 1
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    oracle.build()
+    names = [w for w in oracle.filter_table()["order"]]
+    short = ["haar", "db2", "db3", "db4", "sym4", "bior2.2", "bior1.3", "sym5", "db6", "sym8", "coif2", "db10"]
+    t0, done = time.time(), {}
+    while time.time() - t0 < budget:
+        kind = str(rng.choice(["tiny-batch", "tiny-batch", "small-batch", "deep", "swt-mid", "swt-hd", "mid-batch", "swt-batch"]))
+        if kind == "tiny-batch":      # images <= 64 x 64 (+ some that are not powers of two), >= 2^20 samples
+            r, c = int(rng.choice([8, 16, 32, 48, 64])), int(rng.choice([16, 32, 64, 40]))
+            B = int((1 << 20) // (r * c) * rng.choice([1, 1, 2, 5])) + int(rng.integers(0, 7))
+            done[kind] = done.get(kind, 0) + check(B, (r, c), str(rng.choice(short)), int(rng.integers(1, 7)), 0, rng, kind)
+        elif kind == "small-batch":   # 128 .. 512 px images, 2^20 .. 2^24 samples
+            r, c = int(rng.choice([128, 256, 512, 96, 200, 130])), int(rng.choice([128, 256, 512, 192, 264]))
+            B = max(2, int((1 << int(rng.integers(20, 25))) // (r * c)))
+            done[kind] = done.get(kind, 0) + check(B, (r, c), str(rng.choice(short)), int(rng.integers(1, 8)), 0, rng, kind)
+        elif kind == "deep":          # maximum levels
+            r, c = int(rng.choice([32, 64, 128, 256, 512, 1024, 2048])), int(rng.choice([32, 64, 128, 256, 512, 1024]))
+            done[kind] = done.get(kind, 0) + check(int(rng.choice([1, 1, 3, 17])), (r, c), str(rng.choice(short[:6])), 99, 0, rng, kind)
+        elif kind == "swt-mid":
+            r, c = int(rng.choice([128, 256, 384, 512, 640, 1000, 1024])), int(rng.choice([128, 256, 512, 768, 1024, 516]))
+            done[kind] = done.get(kind, 0) + check(1, (r, c), str(rng.choice(names)), int(rng.choice([1, 2, 3, 99])), 1, rng, kind)
+        elif kind == "swt-hd":
+            r, c = [(1080, 1920), (1200, 1600), (2048, 2048), (600, 800), (1440, 2560)][int(rng.integers(0, 5))]
+            done[kind] = done.get(kind, 0) + check(1, (r, c), str(rng.choice(short)), int(rng.choice([1, 2, 3])), 1, rng, kind)
+        elif kind == "mid-batch":     # between one image and the strips
+            r, c = [(1024, 1024), (2048, 2048), (1024, 2048), (4096, 4096)][int(rng.integers(0, 4))]
+            B = max(2, int((1 << int(rng.integers(24, 27))) // (r * c)))
+            done[kind] = done.get(kind, 0) + check(B, (r, c), str(rng.choice(short[:8])), int(rng.integers(2, 5)), 0, rng, kind)
+        else:                         # batches of SWT images (fused inverse beyond the cache)
+            r, c = [(512, 512), (1024, 1024), (2048, 2048), (256, 512)][int(rng.integers(0, 4))]
+            B = max(2, int((1 << int(rng.integers(21, 25))) // (r * c)))
+            done[kind] = done.get(kind, 0) + check(B, (r, c), str(rng.choice(["haar", "db2", "db3", "db4"])), int(rng.integers(2, 5)), 1, rng, kind)
+    print("soak OK: %.0f s, cases per kind: %s" % (time.time() - t0, done))
+
+
+if __name__ == "__main__":
+    main()
