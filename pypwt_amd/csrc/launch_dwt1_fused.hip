@@ -59,10 +59,28 @@ hipError_t launch_dwt1_fwd_fused(const float* in, float* const* det, float* app,
     a.in = in; a.app = app; a.rows = rows; a.N0 = N0; a.K = K;
     for (int k = 0; k < kMaxFusedLevels; k++) a.det[k] = k < K ? det[k] : nullptr;
     interleave(a.fb, fb);
-    // TF = 64 final-level outputs per workgroup (TF = 128 measured 25 % slower on 2^24 sym8 L6:
-    // 55 KB of LDS leaves 2 workgroups per CU)
+    // TF = 64 final-level outputs per workgroup at K = 6 (TF = 128 measured 25 % slower on 2^24 sym8 L6: 55 KB of LDS leaves 2
+    // workgroups per CU), i.e. a segment of 64 * 2^K = 4096 input samples.  With FEWER levels the segment of TF = 64 shrinks
+    // to 512 samples at K = 3 -- two per thread, 32768 workgroups for 4096 rows of 4096: the forward took 55-65 us where the
+    // inverse (4096 outputs per workgroup at any K) takes 22-27 (round 4, tools/cliffs.py on batched 1D).  TF grows as K
+    // shrinks so that the segment stays at 4096 samples (filters of up to 20 taps; not beyond the row).
+    static const bool wide = !(getenv("PDWT_FUSED1D_WIDE") && atoi(getenv("PDWT_FUSED1D_WIDE")) == 0);  // A/B measurements
+    int TF = 64;
+    if (wide && hlen <= 20 && K < 6) {
+        TF = 64 << (6 - K);
+        if (TF > 1024) TF = 1024;
+        while (TF > 64 && TF / 2 >= (N0 >> K)) TF /= 2;
+    }
     switch (hlen) {
-#define X(h) case h: return run_fwd<h, 64>(a, s);
+#define X(h)                                                   \
+    case h:                                                    \
+        if constexpr (h <= 20) {                               \
+            if (TF == 1024) return run_fwd<h, 1024>(a, s);     \
+            if (TF == 512) return run_fwd<h, 512>(a, s);       \
+            if (TF == 256) return run_fwd<h, 256>(a, s);       \
+            if (TF == 128) return run_fwd<h, 128>(a, s);       \
+        }                                                      \
+        return run_fwd<h, 64>(a, s);
         PDWT_EVEN_HLENS(X)
 #undef X
     }
