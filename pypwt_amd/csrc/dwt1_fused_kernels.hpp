@@ -172,7 +172,7 @@ PDWT_DEVICE void dwt1_fwd_fused_tile(const Fwd1DFusedArgs& a, int bx, int row, f
 
     // ---- stage the input segment (periodic): whole 16-B groups from the 4-aligned origin below s0,
     //      all of a thread's loads issued before its first LDS write
-    PDWT_FOR_THREADS(tid, NT) {
+    PDWT_FOR_SUBTHREADS(tid, NT) {
         const float* PDWT_RESTRICT in = a.in + (long long)row * a.N0;
         const int o4 = true_mod(s0, a.N0) - SH0;  // 4-aligned (s0 = SH0 mod 4, 4 | N0), may be -SH0 < 0 .. wraps below
         const int ngroups = (SH0 + n0 + 3) >> 2;
@@ -204,7 +204,7 @@ PDWT_DEVICE void dwt1_fwd_fused_tile(const Fwd1DFusedArgs& a, int bx, int row, f
         const int Nk = a.N0 >> k;
         const int own_lo = (bx * TF) << (K - k);
         const int own_hi = own_lo + (TF << (K - k));
-        PDWT_FOR_THREADS(tid, NT) {
+        PDWT_FOR_SUBTHREADS(tid, NT) {
             float* PDWT_RESTRICT outD = a.det[k - 1] + (long long)row * Nk;
             float* PDWT_RESTRICT outA = a.app + (long long)row * Nk;
             if (k == 1)
@@ -301,7 +301,7 @@ PDWT_DEVICE void dwt1_inv_fused_tile(const Inv1DFusedArgs& a, int bx, int row, f
 
     const int lo0 = bx * T0;
     const int hi0 = (lo0 + T0 > a.N0) ? a.N0 : lo0 + T0;
-    PDWT_FOR_THREADS(tid, NT) {
+    PDWT_FOR_SUBTHREADS(tid, NT) {
         if (tid == 0) {  // ranges once per workgroup (a per-level recomputation is O(K^2) scalar work per wave)
             int l = lo0, h = hi0;
             rng[0] = l;
@@ -345,7 +345,7 @@ PDWT_DEVICE void dwt1_inv_fused_tile(const Inv1DFusedArgs& a, int bx, int row, f
         const int ng = (hiK - lo4 + 3) >> 2;
         float* pa = ((K & 1) ? aP : aQ) + kInvFront;
         float* pd = ((K & 1) ? dP : dQ) + kInvFront;
-        PDWT_FOR_THREADS(tid, NT) {
+        PDWT_FOR_SUBTHREADS(tid, NT) {
             stage_groups<NT, 2>(tid, a.app + (long long)row * NK, NK, lo4, ng, pa);
             stage_groups<NT, 2>(tid, a.det[K - 1] + (long long)row * NK, NK, lo4, ng, pd);
         }
@@ -360,7 +360,7 @@ PDWT_DEVICE void dwt1_inv_fused_tile(const Inv1DFusedArgs& a, int bx, int row, f
         const int lok4 = floor4(rng[2 * k]);
         const int lom = rng[2 * k - 2], him = rng[2 * k - 1];
         const int lom4 = floor4(lom);
-        PDWT_FOR_THREADS(tid, NT) {
+        PDWT_FOR_SUBTHREADS(tid, NT) {
             float* PDWT_RESTRICT out = a.out + (long long)row * a.N0;
             const int m_lo = lom >> 3, m_hi = (him - 1) >> 3;  // arithmetic shifts: floor
             for (int i = tid; i <= m_hi - m_lo; i += NT) {
@@ -449,6 +449,31 @@ __global__ void __launch_bounds__(NT) dwt1_inv_fused_kernel(const Inv1DFusedArgs
     int row, bx;
     if (!fused1d_item(blockIdx.x, (long long)tiles_x * a.rows, tiles_x, row, bx)) return;
     dwt1_inv_fused_tile<HLEN, T0, NT>(a, bx, row, pdwt_smem);
+}
+
+// SHORT rows (at most 512 samples): SUBS row tiles per workgroup, each run by its own sub-group of NT threads with its own slice
+// of LDS -- a workgroup of 256 threads per 64-sample row left 3/4 of every wavefront slot and every barrier idle (65536 rows of
+// 64 samples: 100 us forward for 16 MiB).  All sub-groups run the same phases (same K, same row length), so the workgroup
+// barriers match; surplus sub-groups of the last workgroup redo the last item (identical values to identical addresses).
+template <int HLEN, int TF, int NT, int SUBS>
+__global__ void __launch_bounds__(NT * SUBS) dwt1_fwd_fused_rows_kernel(const Fwd1DFusedArgs a, int tiles_x, int lds_floats) {
+    extern __shared__ __attribute__((aligned(16))) float pdwt_smem[];
+    const long long total = (long long)tiles_x * a.rows;
+    const int sub = (int)(threadIdx.x / NT);
+    long long item = (long long)blockIdx.x * SUBS + sub;
+    if (item >= total) item = total - 1;
+    const int row = (int)(item / tiles_x), bx = (int)(item - (long long)row * tiles_x);
+    dwt1_fwd_fused_tile<HLEN, TF, NT>(a, bx, row, pdwt_smem + (size_t)sub * lds_floats);
+}
+template <int HLEN, int T0, int NT, int SUBS>
+__global__ void __launch_bounds__(NT * SUBS) dwt1_inv_fused_rows_kernel(const Inv1DFusedArgs a, int tiles_x, int lds_floats) {
+    extern __shared__ __attribute__((aligned(16))) float pdwt_smem[];
+    const long long total = (long long)tiles_x * a.rows;
+    const int sub = (int)(threadIdx.x / NT);
+    long long item = (long long)blockIdx.x * SUBS + sub;
+    if (item >= total) item = total - 1;
+    const int row = (int)(item / tiles_x), bx = (int)(item - (long long)row * tiles_x);
+    dwt1_inv_fused_tile<HLEN, T0, NT>(a, bx, row, pdwt_smem + (size_t)sub * lds_floats);
 }
 #endif
 

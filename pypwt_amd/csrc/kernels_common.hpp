@@ -28,6 +28,7 @@ typedef float real_t;
 #include <math.h>
 #define PDWT_DEVICE inline
 #define PDWT_FOR_THREADS(tid, NT) for (int tid = 0; tid < (NT); ++tid)
+#define PDWT_FOR_SUBTHREADS(tid, NT) for (int tid = 0; tid < (NT); ++tid)
 #define PDWT_SYNC() ((void)0)
 // registers that live across phases: one copy per emulated thread
 #define PDWT_PER_THREAD(type, name, count, NT) type name##_store[(NT)][(count)]
@@ -53,6 +54,9 @@ typedef pdwt_float4 real4_t;
 #define PDWT_DEVICE __device__ __forceinline__
 // one trip: the executing thread
 #define PDWT_FOR_THREADS(tid, NT) for (int tid = threadIdx.x, pdwt_once_ = 1; pdwt_once_; pdwt_once_ = 0)
+// a tile function that may run as one of SEVERAL sub-groups of NT threads inside a larger workgroup (dwt1_fused_kernels.hpp: short
+// rows, four rows per workgroup): the thread index inside the sub-group.  With blockDim.x == NT it is PDWT_FOR_THREADS.
+#define PDWT_FOR_SUBTHREADS(tid, NT) for (int tid = (int)(threadIdx.x % (NT)), pdwt_once_ = 1; pdwt_once_; pdwt_once_ = 0)
 #define PDWT_SYNC() __syncthreads()
 #define PDWT_PER_THREAD(type, name, count, NT) type name##_store[(count)]
 #define PDWT_MINE(name, tid) name##_store

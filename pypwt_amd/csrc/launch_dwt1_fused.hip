@@ -43,6 +43,32 @@ static hipError_t run_inv(const Inv1DFusedArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
+// short rows: four row tiles per workgroup of 256 threads (dwt1_*_fused_rows_kernel)
+static bool short_rows(int N0) {
+    static const bool on = !(getenv("PDWT_FUSED1D_ROWS") && atoi(getenv("PDWT_FUSED1D_ROWS")) == 0);  // A/B measurements
+    return on && N0 <= 512;
+}
+template <int HLEN>
+static hipError_t run_fwd_rows(const Fwd1DFusedArgs& a, hipStream_t s) {
+    constexpr int TF = 64, NT = 64, SUBS = 4;
+    const int lds_floats = fwd1d_fused_lds_floats(TF, HLEN, a.K);
+    const int tiles = cdiv(a.N0 >> a.K, TF);
+    const long long total = (long long)tiles * a.rows;
+    hipLaunchKernelGGL((dwt1_fwd_fused_rows_kernel<HLEN, TF, NT, SUBS>), dim3((unsigned)cdivll(total, SUBS)), dim3(NT * SUBS),
+                       (size_t)SUBS * lds_floats * sizeof(float), s, a, tiles, lds_floats);
+    return hipGetLastError();
+}
+template <int HLEN>
+static hipError_t run_inv_rows(const Inv1DFusedArgs& a, hipStream_t s) {
+    constexpr int T0 = 512, NT = 64, SUBS = 4;
+    const int lds_floats = (inv1d_fused_lds_floats(T0, HLEN, a.K) + 3) & ~3;
+    const int tiles = cdiv(a.N0, T0);
+    const long long total = (long long)tiles * a.rows;
+    hipLaunchKernelGGL((dwt1_inv_fused_rows_kernel<HLEN, T0, NT, SUBS>), dim3((unsigned)cdivll(total, SUBS)), dim3(NT * SUBS),
+                       (size_t)SUBS * lds_floats * sizeof(float), s, a, tiles, lds_floats);
+    return hipGetLastError();
+}
+
 // ONE predicate for planner (plan.cpp) and launchers: K consecutive levels starting from a row of N0
 // samples can run fused iff hlen is even, 2^(K+2) divides N0 (every level length even, every band row
 // 16-B aligned) and N0 < 2^30 (32-bit tile arithmetic)
@@ -64,6 +90,13 @@ hipError_t launch_dwt1_fwd_fused(const float* in, float* const* det, float* app,
     // to 512 samples at K = 3 -- two per thread, 32768 workgroups for 4096 rows of 4096: the forward took 55-65 us where the
     // inverse (4096 outputs per workgroup at any K) takes 22-27 (round 4, tools/cliffs.py on batched 1D).  TF grows as K
     // shrinks so that the segment stays at 4096 samples (filters of up to 20 taps; not beyond the row).
+    if (short_rows(N0) && hlen <= 20) {
+        switch (hlen) {
+#define X(h) case h: if constexpr (h <= 20) return run_fwd_rows<h>(a, s); break;
+            PDWT_EVEN_HLENS(X)
+#undef X
+        }
+    }
     static const bool wide = !(getenv("PDWT_FUSED1D_WIDE") && atoi(getenv("PDWT_FUSED1D_WIDE")) == 0);  // A/B measurements
     int TF = 64;
     if (wide && hlen <= 20 && K < 6) {
@@ -94,6 +127,13 @@ hipError_t launch_dwt1_inv_fused(const float* app, const float* const* det, floa
     a.app = app; a.out = out; a.rows = rows; a.N0 = N0; a.K = K;
     for (int k = 0; k < kMaxFusedLevels; k++) a.det[k] = k < K ? det[k] : nullptr;
     interleave(a.fb, fb);
+    if (short_rows(N0) && hlen <= 20) {
+        switch (hlen) {
+#define X(h) case h: if constexpr (h <= 20) return run_inv_rows<h>(a, s); break;
+            PDWT_EVEN_HLENS(X)
+#undef X
+        }
+    }
     // 4096 output samples per workgroup (2048: 73 us, 4096: 58 us, 8192: 61 us on 2^24 sym8 L6)
     switch (hlen) {
 #define X(h) case h: return run_inv<h, 4096>(a, s);

@@ -775,3 +775,26 @@ def test_batches_of_small_images(wname, shape, levels, batch):
         x = oracle.hash_input(shape, 4242, index_offset=b * n)
         assert np.abs(plan.image_at(b) - x).max() <= 7e-4 * 255, (sched, b)
     plan.cleanup()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("wname,rows,n,levels", [("haar", 300, 64, 3), ("db4", 1001, 128, 4), ("sym8", 77, 512, 5), ("db10", 4096, 256, 3),
+                                                 ("db2", 5, 512, 6), ("bior2.2", 2050, 64, 2), ("db4", 3, 256, 4), ("db3", 4096, 4096, 3),
+                                                 ("sym8", 1024, 2048, 2), ("db4", 256, 1024, 4)])
+def test_batched_1d_short_rows_and_few_levels(wname, rows, n, levels):
+    """Batched 1D transforms (the reference's ndim = 1 on a 2D array, separable.cu:214-236,368-395): rows of at most 512 samples run
+    four to a workgroup (dwt1_*_fused_rows_kernel), plans with few levels keep a 4096-sample segment per workgroup.  Every band of
+    a few rows against the oracle, then the reconstruction."""
+    from pypwt_amd import Wavelets
+    oracle.build()
+    x = oracle.hash_input((rows, n), 313)
+    w = Wavelets(x, wname, levels, ndim=1)
+    w.forward()
+    ref = oracle.forward(x, wname, w.levels, ndim=1)
+    got = [w.coeffs[0]] + list(w.coeffs[1:])
+    assert len(got) == len(ref)
+    for k, (g, r) in enumerate(zip(got, ref)):
+        assert g.shape == r.shape
+        assert np.abs(g - r).max() <= 2e-6 * (w.levels + 1) * max(float(np.abs(r).max()), 255.0), (wname, rows, n, k)
+    w.inverse()
+    assert np.abs(w.image - x).max() <= 7e-4 * 255
