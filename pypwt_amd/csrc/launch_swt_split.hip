@@ -158,6 +158,10 @@ hipError_t try_launch_swt1_split(const SwtPassArgs& a, bool inverse, hipStream_t
     // 4096 rows of 4096: db4 252 -> 156, db3 219 -> 155; at 2^20 samples the vec kernels stay ahead (21 against 29 us); 4 taps:
     // behind on one long row (129 -> 147)
     if (inverse && min_taps == 10 && a.hlen >= 6 && (long long)a.Nr * a.Nc >= (1LL << 22)) min_taps = 6;
+    // rows of 64 samples: a wavefront of these kernels stages 1024 outputs of ONE row -- the four-samples-per-work-item kernels
+    // stay ahead there (65536 rows of 64, three levels forward+inverse: db3 221 -> 125 us, db4 238 -> 156, db5 228 -> 148); from
+    // 256 samples on the row kernels win (profiles/r04zl_swt1_short_rows.txt)
+    if (a.Nc < 128) return hipErrorNotSupported;
     if (a.along_y || min_taps <= 0 || (a.hlen & 1) || a.hlen < 4 || a.hlen < min_taps || a.hlen > kMaxTaps) return hipErrorNotSupported;
     if ((a.Nc & 3) || a.Nc < 16 || a.f < 1 || a.f >= a.Nc || (a.f != 1 && a.f != 2 && (a.f & 3))) return hipErrorNotSupported;
     auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
