@@ -243,7 +243,7 @@ PDWT_DEVICE void dwt2_fwd_fast_tile(const Fwd2DFastArgs& a, int bx, int by, int 
     static_assert(NT % HT == 0, "thread layout");
     constexpr int NG = NT / HT;        // thread groups along y in the column pass
     static_assert(TY % NG == 0, "tile height must split over the thread groups");
-    constexpr int R = TY / NG;         // output rows per thread (x 2 columns)
+    [[maybe_unused]] constexpr int R = TY / NG;         // output rows per thread (x 2 columns)
     static_assert(2 * TX - 4 + NV <= RXA, "row-pass reads stay inside the staged row");
 
     real_t* sIn = smem;                                   // RY x RXA floats
@@ -390,7 +390,7 @@ PDWT_DEVICE bool stream_pos(int q, int xcd, int chunk, int total, int batch, int
 template <int HLEN, int TX, int TY, int NT>
 PDWT_DEVICE void dwt2_fwd_fast_stream(const Fwd2DFastArgs& a, int wg, int nwg, int batch, real_t* smem) {
     using G = FwdFastGeom<HLEN, TX>;
-    constexpr int C = G::C, PADL = G::PADL, RXA = G::RXA;
+    constexpr int RXA = G::RXA;
     constexpr int RY = 2 * TY + HLEN - 2;
     constexpr int V4 = RXA / 4;
     constexpr int NLD = (RY * V4 + NT - 1) / NT;  // float4 loads per thread per tile
@@ -545,7 +545,7 @@ PDWT_DEVICE void inv_row_synth4(const v2f* base, const FilterBankI& fb, real_t r
 template <int HLEN, int TX, int TY, int NT>
 PDWT_DEVICE void inv_fast_col_pass(int tid, const v2f* sAV, const v2f* sHD, v2f* tt, const FilterBankI& fb) {
     using G = InvFastGeom<HLEN, TX>;
-    constexpr int H2 = G::H2, S = G::S, CXA = G::CXA;
+    [[maybe_unused]] constexpr int H2 = G::H2, S = G::S, CXA = G::CXA;
     constexpr int OY = 2 * TY;
     constexpr int NM = TY + S;  // m = 0 .. TY-1+S
     constexpr int Q2 = CXA / 2;
@@ -572,11 +572,10 @@ template <int HLEN, int TX, int TY, int NT>
 PDWT_DEVICE void inv_fast_row_pass(int tid, const v2f* tt, const Inv2DFastArgs& a, int bx, int by, int bz,
                                    bool coh_out = false) {
     using G = InvFastGeom<HLEN, TX>;
-    constexpr int H2 = G::H2, S = G::S, PADL = G::PADL, CXA = G::CXA;
+    [[maybe_unused]] constexpr int H2 = G::H2, S = G::S, PADL = G::PADL, CXA = G::CXA;
     constexpr int OY = 2 * TY;
     constexpr int HT = TX / 2;
     constexpr int PE = PADL & 1;                // read origin rounded down to an even pair index
-    constexpr int NP = (PE + H2 + 2 + 1) & ~1;  // (t1,t2) pairs read per thread
     real_t* PDWT_RESTRICT out = a.out + (long long)bz * a.out_bstride;
     for (int idx = tid; idx < OY * HT; idx += NT) {
         const int gy = idx / HT;
