@@ -40,6 +40,7 @@ SOURCES = [
     "launch_dwt2_pyramid.hip",
     "launch_dwt2_pyr3.hip",
     "launch_dwt2_tail.hip",
+    "launch_swt_tail.hip",
     "launch_dwt2_chain.hip",
     "launch_dwt2_wave.hip",
     "launch_dwt1.hip",

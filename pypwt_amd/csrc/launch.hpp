@@ -93,6 +93,12 @@ hipError_t launch_dwt2_inv_pyr3(const real_t* app, real_t* const det[9], real_t*
 bool dwt2_tail_supported(int hlen, int R0, int C0, int K);
 hipError_t launch_dwt2_tail(const real_t* in, real_t* const* det, real_t* out, int R0, int C0, int K, int hlen, bool inverse,
                             const FilterBank& fb, int batch, hipStream_t s);
+// the WHOLE 2D SWT of tiny images (power-of-two sizes, at most 4096 samples), one workgroup per image (launch_swt_tail.hip):
+// det[3 (l - 1) + b] = band b of level l; forward: in = images, out = A_L; inverse: in = A_L, out = images, beta[l - 1] = the soft
+// threshold applied to level l's details as they are read (nullptr: none)
+bool swt2_tail_supported(int hlen, int Nr, int Nc, int L);
+hipError_t launch_swt2_tail(const real_t* in, real_t* const* det, real_t* out, int Nr, int Nc, int L, int hlen, bool inverse,
+                            const FilterBank& fb, const real_t* beta, int batch, hipStream_t s);
 hipError_t launch_dwt1_fwd(const Fwd1DArgs& a, hipStream_t s);
 hipError_t launch_dwt1_inv(const Inv1DArgs& a, hipStream_t s);
 // K consecutive 1D levels in one launch (2^K must divide N0, even hlen); hipErrorNotSupported otherwise

@@ -72,7 +72,8 @@ hipError_t try_launch_swt2_vec(const Swt2DArgs& a, bool inverse, int batch, hipS
     // tiles shrink to 64 x 8 (128 threads): four times the workgroups, each a quarter of the chain.
     static const int small_tiles = getenv("PDWT_SWT_SMALL_TILE") ? atoi(getenv("PDWT_SWT_SMALL_TILE")) : 256;  // workgroups; A/B measurements
     const long long wgs = (long long)cdiv(a.Nc, 128) * cdiv(a.Nr / a.f, 16) * a.f * batch;
-    if (wgs < small_tiles && a.hlen <= 24 && sizeof(real_t) == 4) {
+    // (and, whatever the batch, on images of at most 64 columns: a 128-column tile there is half padding)
+    if ((wgs < small_tiles || (a.Nc <= 64 && small_tiles > 0)) && a.hlen <= 24 && sizeof(real_t) == 4) {
         switch (a.hlen) {
 #define X(h)                                                                                                   \
     case h:                                                                                                    \

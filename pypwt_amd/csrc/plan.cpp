@@ -568,10 +568,23 @@ void build_schedule(pdwt_plan* p) {
             if (K < tail_min_k && !(K >= tail_min_k - 1 && per_image <= 1024)) return 0;
             return dwt2_tail_supported(hlen, p->lr[l - 1], p->lc[l - 1], K) ? K : 0;
         };
+        // The undecimated twin (swt2_tail_kernels.hpp), batch mode only: the whole L-level SWT of every image of a large batch of
+        // tiny images (power-of-two sizes, at most 64 x 64) in one launch per direction -- 4096 images of 64^2, db4 L2
+        // forward+inverse 1006 us through the level kernels, 16384 of 32^2 haar L3 1177 us (profiles/r04zm_swt_tiny_batches.txt)
+        auto swt_tail = [&]() {
+            const long long per_image = (long long)p->info.Nr * p->info.Nc;
+            // (64 x 64 images -- four 16 KiB planes, two workgroups per CU -- only from 8 taps on, where the level kernels' inverse reads
+            // four bands x hlen taps per output from global memory: db4 L2 1015 -> 739 us, but haar L3 458 -> 482; 32 x 32 and below
+            // always: haar L3 16384 x 32^2 1176 -> 352, 65536 x 16^2 4520 -> 674, db4 L2 8192 x 32^2 1047 -> 202)
+            if (per_image > 1024 && hlen < 8) return false;
+            return swt && p->do_separable && !no_tail && tail_batch > 0 && per_image <= 4096 && per_image * hlen <= (1LL << 17) &&
+                   (long long)p->batch * per_image >= (1LL << 20) && swt2_tail_supported(hlen, p->info.Nr, p->info.Nc, L);
+        };
         for (int dir = 0; dir < 2; dir++) {
             std::vector<Step>& out = dir ? p->sched_inv : p->sched_fwd;
             for (int l = 1; l <= L; l++) {
                 if (const int K = tail_at(l)) { out.push_back({Step::TAIL, l, K}); break; }
+                if (l == 1 && swt_tail()) { out.push_back({Step::TAIL, 1, L}); break; }
                 if (const int K = swt_group(l, dir != 0)) { out.push_back({Step::SWTF, l, K}); l += K - 1; continue; }
                 if (const int K = p->chain_flags ? chain_at(l, dir != 0) : 0) { out.push_back({Step::CHAIN, l, K}); l += K - 1; continue; }
                 if (strip_at(l, dir != 0)) { out.push_back({Step::STRIP2, l, 2}); l++; }
@@ -901,6 +914,7 @@ int forward_impl(pdwt_plan* p, int only = 0) {
     using pdwt::Step;
     const ActiveTuning tuning_guard(&p->tune);
     const int L = p->info.nlevels, B = p->batch, hlen = p->info.hlen;
+    const bool swt = p->info.do_swt != 0;
     const bool two_d = p->info.ndims == 2;
     for (const Step& s : p->sched_fwd) {
         const int l = s.level;
@@ -928,6 +942,13 @@ int forward_impl(pdwt_plan* p, int only = 0) {
             if (!run) continue;
             e = launch_dwt2_fwd_chain(approx_slot(p, l - 1), det, app, p->lr[l - 1], p->lc[l - 1], s.K, hlen, p->dec, B,
                                       p->chain_flags, ++p->chain_epoch, p->stream);
+        } else if (s.kind == Step::TAIL && swt) {
+            real_t* det[3 * kTailMaxLevelsHost] = {};
+            for (int k = 0; k < 3 * s.K; k++) det[k] = p->band(1 + k);
+            Stamp st(p, "swt2_fwd_tail");
+            if (!run) continue;
+            e = launch_swt2_tail(approx_slot(p, 0), det, approx_slot(p, s.K), p->info.Nr, p->info.Nc, s.K, hlen, false, p->dec, nullptr, B,
+                                 p->stream);
         } else if (s.kind == Step::TAIL) {
             real_t* det[3 * kTailMaxLevelsHost] = {};
             for (int k = 0; k < 3 * s.K; k++) det[k] = p->band(3 * (l - 1) + 1 + k);
@@ -980,6 +1001,7 @@ int inverse_impl(pdwt_plan* p, int only = 0) {
     const ActiveTuning tuning_guard(&p->tune);
     const int B = p->batch, hlen = p->info.hlen;
     const bool two_d = p->info.ndims == 2;
+    const bool swt = p->info.do_swt != 0;
     for (const Step& s : p->sched_inv) {
         const int l = s.level;  // the step undoes levels l+K-1 .. l and writes approximation slot l-1
         const bool run = (only == 0 || only == l);
@@ -1003,6 +1025,16 @@ int inverse_impl(pdwt_plan* p, int only = 0) {
             if (!run) continue;
             e = launch_dwt2_inv_chain(approx_slot(p, l - 1), det, app, p->lr[l - 1], p->lc[l - 1], s.K, hlen, p->rec, B,
                                       p->chain_flags + p->chain_words, ++p->chain_epoch, p->stream);
+        } else if (s.kind == Step::TAIL && swt) {
+            real_t* det[3 * kTailMaxLevelsHost] = {};
+            for (int k = 0; k < 3 * s.K; k++) det[k] = p->band(1 + k);
+            real_t beta[kTailMaxLevelsHost] = {};
+            if (p->pend_soft)  // deferred soft_threshold, applied as the details are staged (see inv_level_2d)
+                for (int k = 0; k < s.K; k++) beta[k] = pending_beta_of_level(p, 1 + k);
+            Stamp st(p, p->pend_soft ? "swt2_inv_tail+soft" : "swt2_inv_tail");
+            if (!run) continue;
+            e = launch_swt2_tail(approx_slot(p, s.K), det, approx_slot(p, 0), p->info.Nr, p->info.Nc, s.K, hlen, true, p->rec, beta, B,
+                                 p->stream);
         } else if (s.kind == Step::TAIL) {
             real_t* det[3 * kTailMaxLevelsHost] = {};
             for (int k = 0; k < 3 * s.K; k++) det[k] = p->band(3 * (l - 1) + 1 + k);

@@ -17,6 +17,7 @@
 #include "../../pypwt_amd/csrc/dwt2_pyramid_kernels.hpp"
 #include "../../pypwt_amd/csrc/dwt2_pyr3_kernels.hpp"
 #include "../../pypwt_amd/csrc/dwt2_tail_kernels.hpp"
+#include "../../pypwt_amd/csrc/swt2_tail_kernels.hpp"
 #include "../../pypwt_amd/csrc/dwt2_strip_kernels.hpp"
 #include "../../pypwt_amd/csrc/dwt2_wave_kernels.hpp"
 #include "../../pypwt_amd/csrc/nonsep_kernels.hpp"
@@ -506,6 +507,32 @@ EMU_API int emu_dwt2_tail(int inverse, float* image, int batch, int R0, int C0, 
         }
     }
     run_tail_emu<0>(a, batch, inverse != 0, threads, smem.data());
+    return 0;
+}
+
+// ------------------------------------------------------------------ the whole SWT of a tiny image in one launch
+// det: H,V,D of level 1 (3 x batch x n), then of level 2, ...; app: A_L (batch x n)
+EMU_API int emu_swt2_tail(int inverse, float* image, int batch, int Nr, int Nc, int L, const float* lo, const float* hi, int hlen,
+                          const float* beta, float* det, float* app) {
+    int lgR = 0, lgC = 0;
+    while ((1 << lgR) < Nr) lgR++;
+    while ((1 << lgC) < Nc) lgC++;
+    if (L < 1 || L > kSwtTailMaxLevels || (1 << lgR) != Nr || (1 << lgC) != Nc || (long long)Nr * Nc > kSwtTailMaxSamples) return -2;
+    const long long n = (long long)Nr * Nc;
+    SwtTailArgs a;
+    for (int l = 0; l < kSwtTailMaxLevels; l++) {
+        for (int b = 0; b < 3; b++) a.det[l][b] = l < L ? det + (3LL * l + b) * batch * n : nullptr;
+        a.beta[l] = (beta && l < L) ? beta[l] : 0.f;
+    }
+    a.in = inverse ? app : image;
+    a.out = inverse ? image : app;
+    a.lgR = lgR; a.lgC = lgC; a.L = L; a.hlen = hlen;
+    set_bank(a.fb, lo, hi, hlen);
+    std::vector<float> smem(swt_tail_lds_elems((int)n, inverse != 0) + 64, NAN);
+    for (int bz = 0; bz < batch; bz++) {
+        if (inverse) swt2_inv_tail_image<256>(a, bz, smem.data());
+        else swt2_fwd_tail_image<256>(a, bz, smem.data());
+    }
     return 0;
 }
 

@@ -400,6 +400,40 @@ def test_emu_dwt2_tail_of_all_remaining_levels(wname):
             assert np.abs(out[b] - want).max() <= 4 * (K + 1) * _tol(want), (wname, shape)
 
 
+# ----------------------------------------------------------------------------- the whole SWT of a tiny image in one launch
+@pytest.mark.parametrize("wname", ["haar", "db2", "db3", "db4", "bior1.3", "sym8", "db10"])
+def test_emu_swt2_tail_whole_transform_of_tiny_images(wname):
+    """swt2_fwd_tail_image / swt2_inv_tail_image: one workgroup carries one tiny image through every level of the undecimated
+    transform out of LDS -- dilations larger than the image (the periodic index wraps several times), rectangular images, a
+    batch, the soft threshold folded into the inverse's staging."""
+    hlen, dlo, dhi, rlo, rhi = oracle.filters(wname)
+    for si, (B, shape, L) in enumerate([(1, (64, 64), 3), (2, (32, 64), 4), (3, (16, 16), 2), (1, (8, 32), 5), (1, (64, 16), 1), (2, (4, 4), 2)]):
+        x = oracle.hash_input((B,) + shape, 9300 + si)
+        n = shape[0] * shape[1]
+        det = np.full(3 * L * B * n, np.nan, dtype=np.float32)
+        app = np.full((B,) + shape, np.nan, dtype=np.float32)
+        assert lib().emu_swt2_tail(0, P(x), B, shape[0], shape[1], L, P(dlo), P(dhi), hlen, None, P(det), P(app)) == 0
+        assert np.isfinite(det).all() and np.isfinite(app).all(), (wname, shape)
+        planes = det.reshape(L, 3, B, shape[0], shape[1])
+        for b in range(B):
+            ref = oracle.forward(x[b], wname, L, ndim=2, do_swt=1)  # [A_L, H1, V1, D1, ...]
+            got = [app[b]] + [planes[l, k, b] for l in range(L) for k in range(3)]
+            for k, (g, r) in enumerate(zip(got, ref)):
+                assert np.abs(g - r).max() <= 3e-6 * (L + 1) * max(float(np.abs(r).max()), 255.0 * 2 ** L), (wname, shape, k)
+        # inverse of arbitrary coefficients with a threshold per level
+        det_in = (oracle.hash_input((3 * L * B * n,), 9400 + si, 2.0) - 1.0).astype(np.float32)
+        app_in = (oracle.hash_input((B,) + shape, 9450 + si, 2.0) - 1.0).astype(np.float32)
+        beta = np.array([0.0 if si % 2 else 0.3 / (k + 1) for k in range(L)], dtype=np.float32)
+        out = np.full((B,) + shape, np.nan, dtype=np.float32)
+        assert lib().emu_swt2_tail(1, P(out), B, shape[0], shape[1], L, P(rlo), P(rhi), hlen, P(beta), P(det_in), P(app_in)) == 0
+        pl = det_in.reshape(L, 3, B, shape[0], shape[1])
+        for b in range(B):
+            bands = [app_in[b]] + [np.sign(pl[l, k, b]) * np.maximum(np.abs(pl[l, k, b]) - beta[l], 0) for l in range(L) for k in range(3)]
+            want = oracle.inverse(bands, shape, wname, L, ndim=2, do_swt=1)
+            assert np.isfinite(out[b]).all(), (wname, shape)
+            assert np.abs(out[b] - want).max() <= 4 * (L + 1) * _tol(want), (wname, shape)
+
+
 # ----------------------------------------------------------------------------- three-level pyramid (small images)
 @pytest.mark.parametrize("wname", ["haar", "db2", "db3", "db4", "sym4", "bior3.1", "rbio2.2", "db5", "coif2", "db7", "sym8"])
 def test_emu_dwt2_pyramid_of_three_levels(wname):

@@ -798,3 +798,36 @@ def test_batched_1d_short_rows_and_few_levels(wname, rows, n, levels):
         assert np.abs(g - r).max() <= 2e-6 * (w.levels + 1) * max(float(np.abs(r).max()), 255.0), (wname, rows, n, k)
     w.inverse()
     assert np.abs(w.image - x).max() <= 7e-4 * 255
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("wname,shape,levels,batch", [("haar", (64, 64), 3, 300), ("db2", (32, 32), 3, 1100), ("db4", (64, 64), 2, 260),
+                                                      ("sym8", (32, 64), 1, 520), ("haar", (16, 16), 4, 4200), ("db3", (64, 32), 2, 600),
+                                                      ("db4", (64, 64), 2, 100)])
+def test_swt_batches_of_tiny_images(wname, shape, levels, batch):
+    """Large batches of tiny images through the undecimated transform: at least 2^20 samples in all -> the whole SWT of an image is
+    ONE workgroup of one launch per direction (swt2_tail_kernels.hpp); the soft threshold is folded into the inverse.  First,
+    middle and last image against the oracle; then threshold + inverse against the oracle's."""
+    from pypwt_amd import BatchedWavelets
+    oracle.build()
+    plan = BatchedWavelets(batch, shape[0], shape[1], wname, levels, do_swt=1)
+    L, sched = plan.levels, plan.schedule()
+    n = shape[0] * shape[1]
+    if batch * n >= (1 << 20) and (n <= 1024 or oracle.filters(wname)[0] >= 8):
+        assert sched.count("TAIL[1") == 2, sched
+    plan.fill_hash(5151, 255.0)
+    plan.forward()
+    refs = {}
+    for b in sorted({0, batch // 2, batch - 1}):
+        x = oracle.hash_input(shape, 5151, index_offset=b * n)
+        refs[b] = oracle.forward(x, wname, L, do_swt=1)
+        for num, r in enumerate(refs[b]):
+            g = plan.coeff_at(num, b)
+            assert np.abs(g - r).max() <= 2e-6 * (L + 1) * max(float(np.abs(r).max()), 255.0 * 2 ** L), (sched, b, num)
+    plan.soft_threshold(7.0, 0, 1)
+    plan.inverse()
+    for b, ref in refs.items():
+        thr = oracle.threshold(ref, shape, L, "soft", 7.0, do_app=0, normalize=1, do_swt=1)
+        want = oracle.inverse(thr, shape, wname, L, do_swt=1)
+        assert np.abs(plan.image_at(b) - want).max() <= 1e-3 * 255, (sched, b)
+    plan.cleanup()

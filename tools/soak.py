@@ -60,11 +60,15 @@ def main():
     short = ["haar", "db2", "db3", "db4", "sym4", "bior2.2", "bior1.3", "sym5", "db6", "sym8", "coif2", "db10"]
     t0, done = time.time(), {}
     while time.time() - t0 < budget:
-        kind = str(rng.choice(["tiny-batch", "tiny-batch", "small-batch", "deep", "swt-mid", "swt-hd", "mid-batch", "swt-batch"]))
+        kind = str(rng.choice(["tiny-batch", "tiny-batch", "small-batch", "deep", "swt-mid", "swt-hd", "mid-batch", "swt-batch", "swt-tiny"]))
         if kind == "tiny-batch":      # images <= 64 x 64 (+ some that are not powers of two), >= 2^20 samples
             r, c = int(rng.choice([8, 16, 32, 48, 64])), int(rng.choice([16, 32, 64, 40]))
             B = int((1 << 20) // (r * c) * rng.choice([1, 1, 2, 5])) + int(rng.integers(0, 7))
             done[kind] = done.get(kind, 0) + check(B, (r, c), str(rng.choice(short)), int(rng.integers(1, 7)), 0, rng, kind)
+        elif kind == "swt-tiny":      # SWT of batches of tiny images (the whole transform of an image in one workgroup)
+            r, c = int(rng.choice([4, 8, 16, 32, 64])), int(rng.choice([8, 16, 32, 64, 24]))
+            B = int((1 << 20) // (r * c) * rng.choice([1, 1, 3])) + int(rng.integers(0, 5))
+            done[kind] = done.get(kind, 0) + check(B, (r, c), str(rng.choice(short)), int(rng.integers(1, 5)), 1, rng, kind)
         elif kind == "small-batch":   # 128 .. 512 px images, 2^20 .. 2^24 samples
             r, c = int(rng.choice([128, 256, 512, 96, 200, 130])), int(rng.choice([128, 256, 512, 192, 264]))
             B = max(2, int((1 << int(rng.integers(20, 25))) // (r * c)))
