@@ -576,9 +576,15 @@ void build_schedule(pdwt_plan* p) {
             // (64 x 64 images -- four 16 KiB planes, two workgroups per CU -- only from 8 taps on, where the level kernels' inverse reads
             // four bands x hlen taps per output from global memory: db4 L2 1015 -> 739 us, but haar L3 458 -> 482; 32 x 32 and below
             // always: haar L3 16384 x 32^2 1176 -> 352, 65536 x 16^2 4520 -> 674, db4 L2 8192 x 32^2 1047 -> 202)
-            if (per_image > 1024 && hlen < 8) return false;
+            const long long total = (long long)p->batch * per_image;
+            static const int few = getenv("PDWT_SWT_TAIL_FEW") ? atoi(getenv("PDWT_SWT_TAIL_FEW")) : 64;  // A/B measurements
+            // ... and the latency regime: a FEW tiny images with two levels and more -- one launch instead of one per level
+            // (32 x 32 and below: 16 x 32^2 haar L5 forward+inverse 47 -> 32 us, 8 x 16^2 db2 L2 30 -> 11; one workgroup of 256 threads is
+            // too slow for a single 64 x 64 image: haar L6 50 -> 105 us)
+            const bool latency = p->batch <= few && L >= 2 && per_image <= 1024;
+            if (!latency && per_image > 1024 && hlen < 8) return false;
             return swt && p->do_separable && !no_tail && tail_batch > 0 && per_image <= 4096 && per_image * hlen <= (1LL << 17) &&
-                   (long long)p->batch * per_image >= (1LL << 20) && swt2_tail_supported(hlen, p->info.Nr, p->info.Nc, L);
+                   (total >= (1LL << 20) || latency) && swt2_tail_supported(hlen, p->info.Nr, p->info.Nc, L);
         };
         for (int dir = 0; dir < 2; dir++) {
             std::vector<Step>& out = dir ? p->sched_inv : p->sched_fwd;
