@@ -752,7 +752,9 @@ with torch.cuda.stream(side):
 assert np.all(w.image == 5.0), "set_image raced with its producer / the source's reuse"
 # set_coeff
 w.forward()
-c = slow_producer(7.0)[: n // 2, : n // 2].contiguous()
+c = slow_producer(7.0)
+with torch.cuda.stream(side):  # on the PRODUCER's stream: torch's side streams are non-blocking, the default stream does not wait for them
+    c = c[: n // 2, : n // 2].contiguous()
 side.synchronize()
 c2 = None
 with torch.cuda.stream(side):
