@@ -241,7 +241,10 @@ PDWT_DEVICE rv4 soft4(const rv4& v, real_t b) {
 // load of the unrolled body -- 4 bands x 40 taps x 4 registers in the inverse -- caps at 256 VGPRs and spills to scratch
 // (620 B per lane at 40 taps): those filters unroll 8 taps at a time.
 template <int HLEN>
-constexpr int kSwtTapUnroll = HLEN > 24 ? 8 : (HLEN > 0 ? HLEN : 1);
+constexpr int kSwtTapUnroll = sizeof(real_t) == 8 ? (HLEN > 10 ? 4 : (HLEN > 0 ? HLEN : 1))  // fp64: see below
+                                                  : (HLEN > 24 ? 8 : (HLEN > 0 ? HLEN : 1));
+// (fp64, round 4: a value is two registers -- the fully unrolled inverse of 12-24 taps spilled 60-2120 B per lane to scratch
+// and took 700 us per 2048^2 level of 16 taps, nine times the fp32 time; four taps at a time fit)
 
 template <int TX, int TY>
 constexpr int swt2d_vec_lds_floats(int hlen) { return 2 * (TY + hlen - 1) * TX; }
