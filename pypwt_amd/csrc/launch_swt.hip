@@ -117,8 +117,11 @@ hipError_t launch_swt_pass_inv(const SwtPassArgs& a, hipStream_t s) {
         switch (a.hlen) {
 #define X(h)                                                                                      \
     case h:                                                                                       \
-        hipLaunchKernelGGL((swt1_inv_vec_kernel<h, 256>), dim3(grid), dim3(256), 0, s, a);        \
-        return hipGetLastError();
+        if constexpr (sizeof(real_t) == 4 || h <= 30) {                                           \
+            hipLaunchKernelGGL((swt1_inv_vec_kernel<h, 256>), dim3(grid), dim3(256), 0, s, a);    \
+            return hipGetLastError();                                                             \
+        }                                                                                         \
+        break;
             PDWT_EVEN_HLENS(X)
 #undef X
         }

@@ -235,3 +235,17 @@ def test_sharded_batch_without_a_gpu_fails_loudly():
         pytest.skip("a HIP device is present")
     with pytest.raises(RuntimeError):
         ShardedBatch(4, 64, 64, "db2", 2)
+
+
+def test_no_kernel_of_the_product_libraries_uses_scratch():
+    """A kernel that spills to scratch is a performance cliff (round 4: the fp64 SWT inverse of 12-24 taps ran nine times slower than
+    the fp32 one).  tools/spillscan.py reads private_segment_fixed_size of every kernel out of the built libraries."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libs = [os.path.join(here, "pypwt_amd", n) for n in ("libpypwt_amd.so", "libpypwt_amd_f64.so")]
+    if not all(os.path.exists(p) for p in libs) or not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-readelf"):
+        pytest.skip("libraries not built / llvm-readelf not available")
+    out = subprocess.run([sys.executable, os.path.join(here, "tools", "spillscan.py")] + libs, capture_output=True, text=True, timeout=600).stdout
+    lines = [l for l in out.splitlines() if l.startswith(os.path.join(here, "pypwt_amd"))]
+    assert len(lines) == 2 and all(l.endswith(" 0 with scratch") for l in lines), out
