@@ -29,7 +29,8 @@ VARIANTS = {
     "f32": (OBJ, LIB, [], ("launch_dwt2_chain.hip",)),
     # PDWT_TILE_EXPERIMENT=1 in the environment adds the tile-shape A/B switches of launch_dwt2_fast.hip (tools/tilesweep.sh)
     "lab": (os.path.join(ROOT, "build", "obj_lab"), LIB_LAB,
-            ["-DPDWT_LAB_KERNELS"] + (["-DPDWT_TILE_EXPERIMENT"] if os.environ.get("PDWT_TILE_EXPERIMENT") else []), ()),
+            ["-DPDWT_LAB_KERNELS"] + (["-DPDWT_TILE_EXPERIMENT"] if os.environ.get("PDWT_TILE_EXPERIMENT") else [])
+            + os.environ.get("PDWT_EXTRA_DEFINES", "").split(), ()),  # e.g. PDWT_EXTRA_DEFINES=-DPDWT_SWT_INV_UNROLL=8 (A/B builds)
     "f64": (os.path.join(ROOT, "build", "obj_f64"), LIB_F64, ["-DPDWT_DOUBLE"],
             ("launch_dwt2_pyramid.hip", "launch_dwt1_fused.hip", "launch_dwt2_chain.hip")),
 }

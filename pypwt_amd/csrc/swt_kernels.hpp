@@ -246,6 +246,17 @@ constexpr int kSwtTapUnroll = sizeof(real_t) == 8 ? (HLEN > 10 ? 4 : (HLEN > 0 ?
 // (fp64, round 4: a value is two registers -- the fully unrolled inverse of 12-24 taps spilled 60-2120 B per lane to scratch
 // and took 700 us per 2048^2 level of 16 taps, nine times the fp32 time; four taps at a time fit)
 
+// The tiled INVERSE keeps four bands in flight per tap: 12-24 taps fully unrolled need 282-476 VGPRs (one wavefront per SIMD).
+// On the 128-column tiles eight taps at a time are faster (768^2, two levels forward+inverse: db6 67.2 -> 53.9 us, sym8 79.5 ->
+// 64.1); on the 64 x 8 tiles of small launches the full unroll stays ahead by 3 % (profiles/r04zo_swt_inv_unroll.txt).
+// PDWT_SWT_INV_UNROLL: A/B builds (PDWT_EXTRA_DEFINES of pypwt_amd/build.py, lab variant).
+#ifndef PDWT_SWT_INV_UNROLL
+#define PDWT_SWT_INV_UNROLL 8
+#endif
+template <int HLEN, int TX>
+constexpr int kSwtInvTapUnroll = (PDWT_SWT_INV_UNROLL > 0 && TX >= 128 && HLEN >= 12 && HLEN <= 24 && sizeof(real_t) == 4)
+                                     ? PDWT_SWT_INV_UNROLL : kSwtTapUnroll<HLEN>;
+
 template <int TX, int TY>
 constexpr int swt2d_vec_lds_floats(int hlen) { return 2 * (TY + hlen - 1) * TX; }
 
@@ -410,7 +421,7 @@ PDWT_DEVICE void swt2_inv_vec_tile(const Swt2DArgs& a, int bx, int by, int bz, r
                     rv4 r1 = {zero, zero, zero, zero}, r2 = r1;
                     if (bx * TX + 4 * k4 < a.Nc) {
                         if (aligned_taps) {
-#pragma unroll(kSwtTapUnroll<HLEN>)
+#pragma unroll(kSwtInvTapUnroll<HLEN, TX>)
                             for (int j = 0; j < HLEN; ++j) {
                                 const real_t tl = a.fb.lo[HLEN - 1 - j], th = a.fb.hi[HLEN - 1 - j];
                                 fma4(r1, load4(sg + j * f), tl);
@@ -450,7 +461,7 @@ PDWT_DEVICE void swt2_inv_vec_tile(const Swt2DArgs& a, int bx, int by, int bz, r
                 const int i = wrap_periodic(it * TY - c + r, M);
                 const long long ro = boff + (long long)(ph + f * i) * a.Nc;
                 if (interior) {
-#pragma unroll(kSwtTapUnroll<HLEN>)
+#pragma unroll(kSwtInvTapUnroll<HLEN, TX>)
                     for (int j = 0; j < HLEN; ++j) {
                         const long long o = ro + x0 + (j - c) * f;
                         const real_t tl = a.fb.lo[HLEN - 1 - j], th = a.fb.hi[HLEN - 1 - j];
@@ -460,7 +471,7 @@ PDWT_DEVICE void swt2_inv_vec_tile(const Swt2DArgs& a, int bx, int by, int bz, r
                         fma4(r2, soft4(load4u(a.D + o), a.soft_beta), th);
                     }
                 } else {
-#pragma unroll(kSwtTapUnroll<HLEN>)
+#pragma unroll(kSwtInvTapUnroll<HLEN, TX>)
                     for (int j = 0; j < HLEN; ++j) {
                         const int p = x0 + (j - c) * f;
                         const real_t tl = a.fb.lo[HLEN - 1 - j], th = a.fb.hi[HLEN - 1 - j];
@@ -483,7 +494,7 @@ PDWT_DEVICE void swt2_inv_vec_tile(const Swt2DArgs& a, int bx, int by, int bz, r
 #pragma unroll
         for (int i = 0; i < R; ++i) {
             rv4 r = {zero, zero, zero, zero};
-#pragma unroll(kSwtTapUnroll<HLEN>)
+#pragma unroll(kSwtInvTapUnroll<HLEN, TX>)
             for (int j = 0; j < HLEN; ++j) {
                 fma4(r, load4(u1 + (ty0 + i + j) * TX + 4 * k4), a.fb.lo[HLEN - 1 - j]);
                 fma4(r, load4(u2 + (ty0 + i + j) * TX + 4 * k4), a.fb.hi[HLEN - 1 - j]);
