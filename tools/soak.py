@@ -18,9 +18,9 @@ from oracle import oracle  # noqa: E402
 from pypwt_amd import BatchedWavelets  # noqa: E402
 
 
-def check(B, shape, wname, L, swt, rng, tag):
+def check(B, shape, wname, L, swt, rng, tag, ndim=2):
     try:
-        plan = BatchedWavelets(B, shape[0], shape[1], wname, L, do_swt=swt)
+        plan = BatchedWavelets(B, shape[0], shape[1], wname, L, do_swt=swt, ndim=ndim)
     except ValueError:
         return 0
     L = plan.levels
@@ -32,10 +32,10 @@ def check(B, shape, wname, L, swt, rng, tag):
     loose = 40.0 if wname in ("bior3.1", "rbio3.1") else 1.0
     for b in sorted({0, int(rng.integers(0, B)), B - 1}):
         x = oracle.hash_input(shape, seed, index_offset=b * n)
-        ref = oracle.forward(x, wname, L, do_swt=swt)
+        ref = oracle.forward(x, wname, L, do_swt=swt, ndim=ndim)
         for num, r in enumerate(ref):
             g = plan.coeff_at(num, b)
-            level = L if num == 0 else (num - 1) // 3 + 1
+            level = L if num == 0 else ((num - 1) // 3 + 1 if ndim == 2 else num)
             tol = loose * 2e-6 * (L + 1) * max(float(np.abs(r).max()), 255.0 * (2 ** level))
             err = float(np.abs(g - r).max())
             if not (g.shape == r.shape and err <= tol):
@@ -60,7 +60,8 @@ def main():
     short = ["haar", "db2", "db3", "db4", "sym4", "bior2.2", "bior1.3", "sym5", "db6", "sym8", "coif2", "db10"]
     t0, done = time.time(), {}
     while time.time() - t0 < budget:
-        kind = str(rng.choice(["tiny-batch", "tiny-batch", "small-batch", "deep", "swt-mid", "swt-hd", "mid-batch", "swt-batch", "swt-tiny"]))
+        kind = str(rng.choice(["tiny-batch", "tiny-batch", "small-batch", "deep", "swt-mid", "swt-hd", "mid-batch", "swt-batch", "swt-tiny",
+                               "rows-1d", "rows-1d", "rows-swt1"]))
         if kind == "tiny-batch":      # images <= 64 x 64 (+ some that are not powers of two), >= 2^20 samples
             r, c = int(rng.choice([8, 16, 32, 48, 64])), int(rng.choice([16, 32, 64, 40]))
             B = int((1 << 20) // (r * c) * rng.choice([1, 1, 2, 5])) + int(rng.integers(0, 7))
@@ -69,6 +70,11 @@ def main():
             r, c = int(rng.choice([4, 8, 16, 32, 64])), int(rng.choice([8, 16, 32, 64, 24]))
             B = int((1 << 20) // (r * c) * rng.choice([1, 1, 3])) + int(rng.integers(0, 5))
             done[kind] = done.get(kind, 0) + check(B, (r, c), str(rng.choice(short)), int(rng.integers(1, 5)), 1, rng, kind)
+        elif kind in ("rows-1d", "rows-swt1"):   # batched 1D: many short rows, few long rows, few and many levels
+            n = int(rng.choice([64, 128, 256, 512, 1024, 2048, 4096, 16384, 65536, 1000, 96]))
+            rows = max(1, int((1 << int(rng.integers(12, 23))) // n) + int(rng.integers(0, 3)))
+            swt1 = 1 if kind == "rows-swt1" else 0
+            done[kind] = done.get(kind, 0) + check(1, (rows, n), str(rng.choice(short)), int(rng.integers(1, 7 if not swt1 else 4)), swt1, rng, kind, ndim=1)
         elif kind == "small-batch":   # 128 .. 512 px images, 2^20 .. 2^24 samples
             r, c = int(rng.choice([128, 256, 512, 96, 200, 130])), int(rng.choice([128, 256, 512, 192, 264]))
             B = max(2, int((1 << int(rng.integers(20, 25))) // (r * c)))
