@@ -634,6 +634,10 @@ void build_schedule(pdwt_plan* p) {
                     const long long total = (long long)p->batch * p->info.Nr * p->info.Nc;
                     if (total < (1LL << min_log2) || p->lc[0] < min_row) reg_here = false;
                 }
+                // A/B (PDWT_REG1D_THEN_FUSED=1): only the FIRST group in registers, the remainder through the LDS pyramid -- slower when the
+                // pyramid's forward segment shrank with the number of levels (64.6 us), re-measured after that was fixed in round 4
+                static const bool then_fused = getenv("PDWT_REG1D_THEN_FUSED") != nullptr;
+                if (then_fused && l > 0) reg_here = false;
                 int K = reg_here ? (L - l < 3 ? L - l : 3) : 0;
                 while (K >= 1 && !dwt1_reg_supported(hlen, p->lc[l], K)) --K;
                 if (K >= 1) {
