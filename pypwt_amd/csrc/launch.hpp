@@ -88,9 +88,10 @@ hipError_t launch_dwt2_fwd_pyr3(const real_t* in, real_t* const det[9], real_t* 
 hipError_t launch_dwt2_inv_pyr3(const real_t* app, real_t* const det[9], real_t* out, int N0r, int N0c, int hlen,
                                 const FilterBank& fb, int batch, hipStream_t s);
 // ALL remaining levels of small approximations in one launch, one workgroup per image (launch_dwt2_tail.hip): (R0, C0) enter
-// the group's finest level (at most 16384 samples, fp64 8192; even sizes at every level's input), det[3 k + b] = band b of the
+// the group's finest level (at most 16384 samples, fp64 8192; even sizes at every level's input: powers of two or not), det[3 k + b] = band b of the
 // group's k-th level (finest first); forward: in = A_{l-1}, out = A_L; inverse: in = A_L, out = A_{l-1}
 bool dwt2_tail_supported(int hlen, int R0, int C0, int K);
+int dwt2_tail_max_levels(int hlen, int R0, int C0, int Kmax);  // the most levels (<= Kmax) one launch can take from (R0, C0) on
 hipError_t launch_dwt2_tail(const real_t* in, real_t* const* det, real_t* out, int R0, int C0, int K, int hlen, bool inverse,
                             const FilterBank& fb, int batch, hipStream_t s);
 // the WHOLE 2D SWT of tiny images (power-of-two sizes, at most 4096 samples), one workgroup per image (launch_swt_tail.hip):

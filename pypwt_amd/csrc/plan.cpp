@@ -560,10 +560,14 @@ void build_schedule(pdwt_plan* p) {
             // (B x n^2, forward+inverse us: 4096 x 64^2 db4 L3 313 -> 121, 4096 x 32^2 db2 L3 453 -> 38, 1024 x 64^2 sym8 L2 198 -> 54;
             // 128 x 128 images only with five levels and more: 256 x 128^2 db2 L5 43.5 -> 29.5, but 1024 x 128^2 db4 L3 102 -> 136;
             // profiles/r04zc_small_batches.txt)
+            // Sizes need not be powers of two, only even through the levels the launch takes (28 x 28: two levels, 48 x 48: four, 100 x
+            // 100: two); levels beyond (an odd size) follow as level launches.  20000 x 28^2 db2 L2: 1286 us forward+inverse on the level
+            // kernels, ten times its power-of-two neighbour 16384 x 32^2.
             if (fusable && !no_tail && (per_image <= tail_batch || (per_image <= 4 * tail_batch && K >= 5)) &&
-                per_image * hlen <= 16 * tail_batch && samples(l) >= (1LL << 20) &&
-                dwt2_tail_supported(hlen, p->lr[l - 1], p->lc[l - 1], K))
-                return K;
+                per_image * hlen <= 16 * tail_batch && samples(l) >= (1LL << 20)) {
+                const int Kb = dwt2_tail_max_levels(hlen, p->lr[l - 1], p->lc[l - 1], K);
+                if (Kb >= 1 && (per_image <= tail_batch || Kb >= 5)) return Kb;
+            }
             if (!fusable || no_tail || samples(l) > (1LL << 20) || per_image * hlen > (1LL << tail_work_log2)) return 0;
             if (K < tail_min_k && !(K >= tail_min_k - 1 && per_image <= 1024)) return 0;
             return dwt2_tail_supported(hlen, p->lr[l - 1], p->lc[l - 1], K) ? K : 0;
@@ -589,7 +593,7 @@ void build_schedule(pdwt_plan* p) {
         for (int dir = 0; dir < 2; dir++) {
             std::vector<Step>& out = dir ? p->sched_inv : p->sched_fwd;
             for (int l = 1; l <= L; l++) {
-                if (const int K = tail_at(l)) { out.push_back({Step::TAIL, l, K}); break; }
+                if (const int K = tail_at(l)) { out.push_back({Step::TAIL, l, K}); l += K - 1; continue; }
                 if (l == 1 && swt_tail()) { out.push_back({Step::TAIL, 1, L}); break; }
                 if (const int K = swt_group(l, dir != 0)) { out.push_back({Step::SWTF, l, K}); l += K - 1; continue; }
                 if (const int K = p->chain_flags ? chain_at(l, dir != 0) : 0) { out.push_back({Step::CHAIN, l, K}); l += K - 1; continue; }

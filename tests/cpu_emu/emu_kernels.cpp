@@ -473,19 +473,24 @@ EMU_API int emu_dwt2_pyr3(int inverse, float* image, int batch, int N0r, int N0c
 
 // ------------------------------------------------------------------ all remaining levels of a small approximation in one launch
 // det: H,V,D of the group's level 1 (3 x batch x R0/2 x C0/2), then of level 2, ...; app: A_K (batch x R0>>K x C0>>K)
-template <int HLEN>
+template <int HLEN, bool POW2>
 static void run_tail_emu(const TailArgs& a, int batch, bool inverse, int threads, float* smem) {
     for (int bz = 0; bz < batch; bz++) {
-        if (inverse) { if (threads == 1024) dwt2_inv_tail_image<HLEN, 1024>(a, bz, smem); else dwt2_inv_tail_image<HLEN, 256>(a, bz, smem); }
-        else { if (threads == 1024) dwt2_fwd_tail_image<HLEN, 1024>(a, bz, smem); else dwt2_fwd_tail_image<HLEN, 256>(a, bz, smem); }
+        if (inverse) { if (threads == 1024) dwt2_inv_tail_image<HLEN, 1024, POW2>(a, bz, smem); else dwt2_inv_tail_image<HLEN, 256, POW2>(a, bz, smem); }
+        else { if (threads == 1024) dwt2_fwd_tail_image<HLEN, 1024, POW2>(a, bz, smem); else dwt2_fwd_tail_image<HLEN, 256, POW2>(a, bz, smem); }
     }
+}
+template <int HLEN>
+static void run_tail_emu2(const TailArgs& a, int batch, bool inverse, int threads, float* smem) {
+    if (a.lgR >= 0 && a.lgC >= 0) run_tail_emu<HLEN, true>(a, batch, inverse, threads, smem);
+    else run_tail_emu<HLEN, false>(a, batch, inverse, threads, smem);
 }
 EMU_API int emu_dwt2_tail(int inverse, float* image, int batch, int R0, int C0, int K, const float* lo, const float* hi, int hlen,
                           int threads, int unrolled, float* det, float* app) {
-    int lgR = 0, lgC = 0;
-    while ((1 << lgR) < R0) lgR++;
-    while ((1 << lgC) < C0) lgC++;
-    if ((hlen & 1) || K < 1 || K > kTailMaxLevels || (1 << lgR) != R0 || (1 << lgC) != C0 || lgR < K || lgC < K) return -2;
+    auto lg2 = [](int v) { int lg = 0; while ((1 << lg) < v) lg++; return (1 << lg) == v ? lg : -1; };
+    if ((hlen & 1) || K < 1 || K > kTailMaxLevels) return -2;
+    for (int k = 0; k < K; k++)
+        if (((R0 >> k) & 1) || ((C0 >> k) & 1)) return -2;
     if ((long long)R0 * C0 > kTailTrips * threads || (long long)R0 * C0 > kTailMaxSamples) return -2;
     TailArgs a;
     long long off = 0;
@@ -495,18 +500,19 @@ EMU_API int emu_dwt2_tail(int inverse, float* image, int batch, int R0, int C0, 
     }
     a.in = inverse ? app : image;
     a.out = inverse ? image : app;
-    a.lgR = lgR; a.lgC = lgC; a.K = K; a.hlen = hlen;
+    a.R0 = R0; a.C0 = C0; a.lgR = lg2(R0); a.lgC = lg2(C0); a.K = K; a.hlen = hlen;
+    if (unrolled == 2) a.lgR = a.lgC = -1;  // power-of-two sizes through the general instantiation too
     set_bank(a.fb, lo, hi, hlen);
     std::vector<float> smem(tail_lds_elems(R0 * C0) + 64, NAN);
     if (unrolled && hlen <= 8) {
         switch (hlen) {
-            case 2: run_tail_emu<2>(a, batch, inverse != 0, threads, smem.data()); return 0;
-            case 4: run_tail_emu<4>(a, batch, inverse != 0, threads, smem.data()); return 0;
-            case 6: run_tail_emu<6>(a, batch, inverse != 0, threads, smem.data()); return 0;
-            case 8: run_tail_emu<8>(a, batch, inverse != 0, threads, smem.data()); return 0;
+            case 2: run_tail_emu2<2>(a, batch, inverse != 0, threads, smem.data()); return 0;
+            case 4: run_tail_emu2<4>(a, batch, inverse != 0, threads, smem.data()); return 0;
+            case 6: run_tail_emu2<6>(a, batch, inverse != 0, threads, smem.data()); return 0;
+            case 8: run_tail_emu2<8>(a, batch, inverse != 0, threads, smem.data()); return 0;
         }
     }
-    run_tail_emu<0>(a, batch, inverse != 0, threads, smem.data());
+    run_tail_emu2<0>(a, batch, inverse != 0, threads, smem.data());
     return 0;
 }
 

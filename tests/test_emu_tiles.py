@@ -361,12 +361,14 @@ def test_emu_dwt2_tail_of_all_remaining_levels(wname):
     rectangular planes, a batch, both workgroup sizes, compile-time and run-time filter length."""
     hlen, dlo, dhi, rlo, rhi = oracle.filters(wname)
     for si, (B, shape, K) in enumerate([(1, (128, 128), 7), (1, (64, 64), 6), (2, (32, 64), 5), (1, (16, 16), 2), (3, (8, 8), 3),
-                                        (1, (64, 256), 4), (1, (2, 2), 1), (1, (128, 32), 5), (2, (4, 64), 2), (1, (64, 64), 1)]):
+                                        (1, (64, 256), 4), (1, (2, 2), 1), (1, (128, 32), 5), (2, (4, 64), 2), (1, (64, 64), 1),
+                                        (2, (28, 28), 2), (1, (48, 96), 4), (1, (100, 100), 2), (3, (24, 40), 3), (1, (6, 10), 1),
+                                        (1, (56, 56), 3), (1, (120, 136), 3), (2, (32, 32), 5)]):
         x = oracle.hash_input((B,) + shape, 9100 + si)
         dims = [(shape[0] >> k, shape[1] >> k) for k in range(1, K + 1)]
         ndet = sum(3 * B * r * c for r, c in dims)
         threads = 1024 if shape[0] * shape[1] > 4096 else (1024, 256)[si % 2]
-        unrolled = si % 3 != 2  # the instantiations with a compile-time filter length (2-8 taps) and the run-time one
+        unrolled = 2 if si == 17 else int(si % 3 != 2)  # compile-time filter length (2-8 taps) / run-time; 2: a power-of-two size through the general (non-mask) instantiation
         det = np.full(ndet, np.nan, dtype=np.float32)
         app = np.full((B,) + dims[-1], np.nan, dtype=np.float32)
         assert lib().emu_dwt2_tail(0, P(x), B, shape[0], shape[1], K, P(dlo), P(dhi), hlen, threads, int(unrolled), P(det), P(app)) == 0

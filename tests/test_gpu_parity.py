@@ -749,7 +749,10 @@ def test_deep_plans_end_in_one_tail_launch(wname, shape, levels, batch, wide, ex
 @pytest.mark.gpu
 @pytest.mark.parametrize("wname,shape,levels,batch", [("db4", (64, 64), 3, 300), ("db2", (32, 32), 3, 1100), ("sym8", (64, 64), 2, 260),
                                                       ("haar", (16, 16), 4, 4200), ("db4", (32, 64), 2, 520), ("db2", (128, 128), 5, 70),
-                                                      ("db4", (128, 128), 3, 70), ("db3", (64, 64), 1, 256), ("db4", (256, 256), 3, 20)])
+                                                      ("db4", (128, 128), 3, 70), ("db3", (64, 64), 1, 256), ("db4", (256, 256), 3, 20),
+                                                      ("db2", (28, 28), 2, 1500), ("db4", (48, 48), 3, 500), ("haar", (96, 96), 5, 130),
+                                                      ("db4", (100, 100), 3, 120), ("db2", (24, 40), 2, 1200), ("db3", (28, 28), 3, 1400),
+                                                      ("sym8", (56, 56), 1, 400), ("haar", (12, 20), 2, 5000)])
 def test_batches_of_small_images(wname, shape, levels, batch):
     """Large batches of tiny images (at least 2^20 samples in all): every image is ONE workgroup of the tail launch, whole transform out of
     LDS (64 x 64 and below; 128 x 128 with five levels and more), narrower tiles and no wave kernels on the levels that stay with
@@ -758,8 +761,8 @@ def test_batches_of_small_images(wname, shape, levels, batch):
     oracle.build()
     plan = BatchedWavelets(batch, shape[0], shape[1], wname, levels)
     L, sched = plan.levels, plan.schedule()
-    if shape[0] * shape[1] <= 4096 and batch * shape[0] * shape[1] >= (1 << 20):
-        assert sched.count("TAIL[1") == 2, sched
+    if shape[0] * shape[1] <= 4096 and batch * shape[0] * shape[1] >= (1 << 20) and shape[0] % 2 == 0 and shape[1] % 2 == 0:
+        assert sched.count("TAIL[1") == 2, sched  # sizes that are not powers of two too: 28 x 28, 48 x 48, 24 x 40 ...
     plan.fill_hash(4242, 255.0)
     plan.forward()
     n = shape[0] * shape[1]
