@@ -251,4 +251,203 @@ __global__ void __launch_bounds__(NT) dwt2_inv_tail_kernel(const TailArgs a) {
 }
 #endif
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// The power-of-two kernels as first written (mask / shift indexing, the flat staging order by leading-zero count).  Kept as their
+// own functions: folded into the general templates above as a POW2 flag, the SAME source ran 15-25 % slower in the inverse
+// (same-box A/B, profiles/r04zq_tail_pow2_ab.txt) -- the dispatch uses these for power-of-two sizes and the general ones otherwise.
+// ---------------------------------------------------------------------------------------------------------------------------
+template <int HLEN, int NT>
+PDWT_DEVICE void dwt2_fwd_tail_image_p2(const TailArgs& a, int bz, real_t* smem) {
+    const int hlen = HLEN ? HLEN : a.hlen, C = hlen / 2 - 1;
+    const int n0 = 1 << (a.lgR + a.lgC);
+    real_t* cur = smem;
+    real_t* tmp = smem + n0;
+    real_t* fLo = smem + 2 * n0;
+    real_t* fHi = fLo + kMaxTaps;
+    PDWT_FOR_THREADS(tid, NT) {
+        const real_t* PDWT_RESTRICT in = a.in + (long long)bz * n0;
+        real_t v[kTailTrips];
+#pragma unroll
+        for (int t = 0; t < kTailTrips; ++t) {  // constant trip count, clamped index: all loads of a thread in flight together
+            const int idx = tid + t * NT;
+            v[t] = in[idx < n0 ? idx : n0 - 1];
+        }
+#pragma unroll
+        for (int t = 0; t < kTailTrips; ++t) {
+            const int idx = tid + t * NT;
+            if (idx < n0) cur[idx] = v[t];
+        }
+        for (int j = tid; j < hlen; j += NT) {  // reversed: tap j of the window multiplies f[hlen - 1 - j]
+            fLo[j] = a.fb.lo[hlen - 1 - j];
+            fHi[j] = a.fb.hi[hlen - 1 - j];
+        }
+    }
+    PDWT_SYNC();
+    int lgr = a.lgR, lgc = a.lgC;
+    for (int k = 0; k < a.K; ++k) {
+        const int r = 1 << lgr, c = 1 << lgc, lgc2 = lgc - 1, c2 = c >> 1;
+        const int n_half = 1 << (lgr + lgc2), n_quarter = n_half >> 1;
+        real_t* tL = tmp;
+        real_t* tH = tmp + n_half;
+        PDWT_FOR_THREADS(tid, NT) {  // rows: (r x c) -> L | H, (r x c2) each
+            for (int idx = tid; idx < n_half; idx += NT) {
+                const int y = idx >> lgc2, x = idx & (c2 - 1);
+                const real_t* row = cur + (y << lgc);
+                const int base = 2 * x - C;
+                real_t l = 0, h = 0;
+#pragma unroll
+                for (int j = 0; j < hlen; ++j) {
+                    const real_t v = row[(base + j) & (c - 1)];
+                    l = pdwt_fma(v, fLo[j], l);
+                    h = pdwt_fma(v, fHi[j], h);
+                }
+                tL[idx] = l;
+                tH[idx] = h;
+            }
+        }
+        PDWT_SYNC();
+        const bool last = k == a.K - 1;
+        PDWT_FOR_THREADS(tid, NT) {  // columns: -> A (LDS, or global for the last level), H, V, D (global)
+            const long long b = (long long)bz * n_quarter;
+            real_t* PDWT_RESTRICT gA = a.out + b;
+            real_t* PDWT_RESTRICT gH = a.det[k][0] + b;
+            real_t* PDWT_RESTRICT gV = a.det[k][1] + b;
+            real_t* PDWT_RESTRICT gD = a.det[k][2] + b;
+            for (int idx = tid; idx < n_quarter; idx += NT) {
+                const int i = idx >> lgc2, x = idx & (c2 - 1);
+                const int base = 2 * i - C;
+                real_t ll = 0, lh = 0, hl = 0, hh = 0;
+#pragma unroll
+                for (int j = 0; j < hlen; ++j) {
+                    const int o = (((base + j) & (r - 1)) << lgc2) + x;
+                    const real_t vL = tL[o], vH = tH[o];
+                    ll = pdwt_fma(vL, fLo[j], ll);
+                    lh = pdwt_fma(vL, fHi[j], lh);
+                    hl = pdwt_fma(vH, fLo[j], hl);
+                    hh = pdwt_fma(vH, fHi[j], hh);
+                }
+                if (last) gA[idx] = ll;
+                else cur[idx] = ll;
+                gH[idx] = lh;  // (row low, column high), (row high, column low), (row high, column high): separable.cu:135-176
+                gV[idx] = hl;
+                gD[idx] = hh;
+            }
+        }
+        PDWT_SYNC();
+        --lgr;
+        --lgc;
+    }
+}
+
+// Flat order of everything the inverse reads, from the coarse end: with sL = samples of A_L, positions [0, sL) are A_L and
+// [4^m sL, 4^(m+1) sL) the three detail planes (4^m sL each) of the group's level K-1-m -- together exactly n0 values.
+// LDS homes: positions below sL and from n0/4 on (the finest level's details) live at X[f]; the rest at U[n0/4 + f].
+PDWT_DEVICE int tail_log4(unsigned q) { return (31 - __builtin_clz(q)) >> 1; }  // floor(log4(q)), q >= 1
+
+template <int HLEN, int NT>
+PDWT_DEVICE void dwt2_inv_tail_image_p2(const TailArgs& a, int bz, real_t* smem) {
+    const int hlen = HLEN ? HLEN : a.hlen, H2 = hlen / 2, C = H2 / 2, S = (H2 & 1) ? 0 : 1;
+    const int n0 = 1 << (a.lgR + a.lgC), q0 = n0 >> 2;
+    const int lgsL = a.lgR + a.lgC - 2 * a.K, sL = 1 << lgsL;
+    real_t* X = smem;       // [0, n0/4): the approximation being rebuilt; [n0/4, n0): H, V, D of the finest level
+    real_t* U = smem + n0;  // column-synthesis results (u1 | u2); [n0/4, n0/2): the details of the coarser levels until the last step
+    real_t* fLo = smem + 2 * n0;
+    real_t* fHi = fLo + kMaxTaps;
+    PDWT_FOR_THREADS(tid, NT) {
+        // three unrolled passes so that a thread's loads are in flight TOGETHER: the plane pointers (a lane-indexed read of the
+        // kernel arguments: memory loads), then the values, then the LDS stores.  Interleaved, the in-order load counter makes
+        // every pointer wait drain the data loads before it: sixteen round trips instead of two.
+        const real_t* src[kTailTrips];
+        real_t v[kTailTrips];
+#pragma unroll
+        for (int t = 0; t < kTailTrips; ++t) {
+            int f = tid + t * NT;
+            f = f < n0 ? f : n0 - 1;
+            if (f < sL) {
+                src[t] = a.in + (long long)bz * sL + f;
+            } else {
+                const int m = tail_log4((unsigned)f >> lgsL), lgp = lgsL + 2 * m;  // plane size 2^lgp
+                const int g = f - (1 << lgp), b = g >> lgp, idx = g & ((1 << lgp) - 1);
+                src[t] = a.det[a.K - 1 - m][b] + ((long long)bz << lgp) + idx;
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < kTailTrips; ++t) v[t] = *src[t];
+#pragma unroll
+        for (int t = 0; t < kTailTrips; ++t) {
+            const int f = tid + t * NT;
+            if (f < n0) {
+                if (f < sL || f >= q0) X[f] = v[t];
+                else U[q0 + f] = v[t];
+            }
+        }
+        for (int j = tid; j < hlen; j += NT) {
+            fLo[j] = a.fb.lo[hlen - 1 - j];
+            fHi[j] = a.fb.hi[hlen - 1 - j];
+        }
+    }
+    PDWT_SYNC();
+    for (int k = a.K - 1; k >= 0; --k) {
+        const int lgri = a.lgR - k - 1, lgci = a.lgC - k - 1, ri = 1 << lgri, ci = 1 << lgci, lgco = lgci + 1;
+        const int n_in = 1 << (lgri + lgci);  // = 4^(K-1-k) sL
+        const real_t* dH = k == 0 ? X + q0 : U + q0 + n_in;
+        const real_t* dV = dH + n_in;
+        const real_t* dD = dV + n_in;
+        real_t* u1 = U;
+        real_t* u2 = U + 2 * n_in;
+        PDWT_FOR_THREADS(tid, NT) {  // column synthesis: (A, H) -> u1, (V, D) -> u2, (2 ri x ci) each
+            for (int idx = tid; idx < 2 * n_in; idx += NT) {
+                const int q = idx >> lgci, x = idx & (ci - 1);
+                const int p = q + S;
+                const int rel = (p >> 1) - C, par = 1 - (p & 1);
+                real_t r1 = 0, r2 = 0;
+#pragma unroll
+                for (int j = 0; j < H2; ++j) {
+                    const int t = 2 * j + par;  // reversed taps: f[hlen - 1 - t]
+                    const int src = (((rel + j) & (ri - 1)) << lgci) + x;
+                    r1 = pdwt_fma(X[src], fLo[t], r1);
+                    r1 = pdwt_fma(dH[src], fHi[t], r1);
+                    r2 = pdwt_fma(dV[src], fLo[t], r2);
+                    r2 = pdwt_fma(dD[src], fHi[t], r2);
+                }
+                u1[idx] = r1;
+                u2[idx] = r2;
+            }
+        }
+        PDWT_SYNC();
+        PDWT_FOR_THREADS(tid, NT) {  // row synthesis: (u1, u2) -> (2 ri x 2 ci), to LDS or (the last step) global
+            real_t* PDWT_RESTRICT gout = a.out + (long long)bz * 4 * n_in;
+            for (int idx = tid; idx < 4 * n_in; idx += NT) {
+                const int q = idx >> lgco, g = idx & (2 * ci - 1);
+                const int p = g + S;
+                const int rel = (p >> 1) - C, par = 1 - (p & 1);
+                real_t r = 0;
+#pragma unroll
+                for (int j = 0; j < H2; ++j) {
+                    const int t = 2 * j + par;
+                    const int src = (q << lgci) + ((rel + j) & (ci - 1));
+                    r = pdwt_fma(u1[src], fLo[t], r);
+                    r = pdwt_fma(u2[src], fHi[t], r);
+                }
+                if (k == 0) gout[idx] = r;
+                else X[idx] = r;
+            }
+        }
+        PDWT_SYNC();
+    }
+}
+
+#ifndef PDWT_CPU_EMU
+template <int HLEN, int NT>
+__global__ void __launch_bounds__(NT) dwt2_fwd_tail_p2_kernel(const TailArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char tail_smem[];
+    dwt2_fwd_tail_image_p2<HLEN, NT>(a, blockIdx.x, reinterpret_cast<real_t*>(tail_smem));
+}
+template <int HLEN, int NT>
+__global__ void __launch_bounds__(NT) dwt2_inv_tail_p2_kernel(const TailArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char tail_smem[];
+    dwt2_inv_tail_image_p2<HLEN, NT>(a, blockIdx.x, reinterpret_cast<real_t*>(tail_smem));
+}
+#endif
+
 }  // namespace pdwt

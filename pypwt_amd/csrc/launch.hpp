@@ -94,7 +94,7 @@ bool dwt2_tail_supported(int hlen, int R0, int C0, int K);
 int dwt2_tail_max_levels(int hlen, int R0, int C0, int Kmax);  // the most levels (<= Kmax) one launch can take from (R0, C0) on
 hipError_t launch_dwt2_tail(const real_t* in, real_t* const* det, real_t* out, int R0, int C0, int K, int hlen, bool inverse,
                             const FilterBank& fb, int batch, hipStream_t s);
-// the WHOLE 2D SWT of tiny images (power-of-two sizes, at most 4096 samples), one workgroup per image (launch_swt_tail.hip):
+// the WHOLE 2D SWT of tiny images (at most 4096 samples, any sizes), one workgroup per image (launch_swt_tail.hip):
 // det[3 (l - 1) + b] = band b of level l; forward: in = images, out = A_L; inverse: in = A_L, out = images, beta[l - 1] = the soft
 // threshold applied to level l's details as they are read (nullptr: none)
 bool swt2_tail_supported(int hlen, int Nr, int Nc, int L);

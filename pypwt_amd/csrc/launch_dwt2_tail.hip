@@ -30,29 +30,44 @@ int dwt2_tail_max_levels(int hlen, int R0, int C0, int Kmax) {
     return K;
 }
 
-template <int HLEN, int NT, bool POW2>
-static hipError_t run_tail(const TailArgs& a, bool inverse, int batch, hipStream_t s) {
+template <int HLEN, int NT>
+static hipError_t run_tail_general(const TailArgs& a, bool inverse, int batch, hipStream_t s) {
     const size_t lds = tail_lds_elems(a.R0 * a.C0) * sizeof(real_t);
     static std::atomic<bool> big[2][64] = {};
     if (inverse) {
-        const hipError_t e = allow_big_lds(dwt2_inv_tail_kernel<HLEN, NT, POW2>, lds, big[1]);
+        const hipError_t e = allow_big_lds(dwt2_inv_tail_kernel<HLEN, NT, false>, lds, big[1]);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((dwt2_inv_tail_kernel<HLEN, NT, POW2>), dim3(batch), dim3(NT), lds, s, a);
+        hipLaunchKernelGGL((dwt2_inv_tail_kernel<HLEN, NT, false>), dim3(batch), dim3(NT), lds, s, a);
     } else {
-        const hipError_t e = allow_big_lds(dwt2_fwd_tail_kernel<HLEN, NT, POW2>, lds, big[0]);
+        const hipError_t e = allow_big_lds(dwt2_fwd_tail_kernel<HLEN, NT, false>, lds, big[0]);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((dwt2_fwd_tail_kernel<HLEN, NT, POW2>), dim3(batch), dim3(NT), lds, s, a);
+        hipLaunchKernelGGL((dwt2_fwd_tail_kernel<HLEN, NT, false>), dim3(batch), dim3(NT), lds, s, a);
+    }
+    return hipGetLastError();
+}
+template <int HLEN, int NT>
+static hipError_t run_tail_p2(const TailArgs& a, bool inverse, int batch, hipStream_t s) {
+    const size_t lds = tail_lds_elems(a.R0 * a.C0) * sizeof(real_t);
+    static std::atomic<bool> big[2][64] = {};
+    if (inverse) {
+        const hipError_t e = allow_big_lds(dwt2_inv_tail_p2_kernel<HLEN, NT>, lds, big[1]);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((dwt2_inv_tail_p2_kernel<HLEN, NT>), dim3(batch), dim3(NT), lds, s, a);
+    } else {
+        const hipError_t e = allow_big_lds(dwt2_fwd_tail_p2_kernel<HLEN, NT>, lds, big[0]);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((dwt2_fwd_tail_p2_kernel<HLEN, NT>), dim3(batch), dim3(NT), lds, s, a);
     }
     return hipGetLastError();
 }
 
 // a thread stages kTailTrips values: 1024 threads for planes of more than 4096 samples, 256 below (fewer idle wavefronts at
-// every barrier of the small levels)
+// every barrier of the small levels).  Power-of-two sizes: the mask / shift kernels; any other size: the general ones.
 template <int HLEN>
 static hipError_t run_tail_nt(const TailArgs& a, bool inverse, int batch, hipStream_t s) {
     const bool big = a.R0 * a.C0 > 4096, pow2 = a.lgR >= 0 && a.lgC >= 0;
-    if (pow2) return big ? run_tail<HLEN, 1024, true>(a, inverse, batch, s) : run_tail<HLEN, 256, true>(a, inverse, batch, s);
-    return big ? run_tail<HLEN, 1024, false>(a, inverse, batch, s) : run_tail<HLEN, 256, false>(a, inverse, batch, s);
+    if (pow2) return big ? run_tail_p2<HLEN, 1024>(a, inverse, batch, s) : run_tail_p2<HLEN, 256>(a, inverse, batch, s);
+    return big ? run_tail_general<HLEN, 1024>(a, inverse, batch, s) : run_tail_general<HLEN, 256>(a, inverse, batch, s);
 }
 
 // forward: in = A_{l-1} -> det[3 k + b] (band b of the group's k-th level, finest first), out = A_{l-1+K}

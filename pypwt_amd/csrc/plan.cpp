@@ -573,7 +573,7 @@ void build_schedule(pdwt_plan* p) {
             return dwt2_tail_supported(hlen, p->lr[l - 1], p->lc[l - 1], K) ? K : 0;
         };
         // The undecimated twin (swt2_tail_kernels.hpp), batch mode only: the whole L-level SWT of every image of a large batch of
-        // tiny images (power-of-two sizes, at most 64 x 64) in one launch per direction -- 4096 images of 64^2, db4 L2
+        // tiny images (at most 4096 samples, any sizes) in one launch per direction -- 4096 images of 64^2, db4 L2
         // forward+inverse 1006 us through the level kernels, 16384 of 32^2 haar L3 1177 us (profiles/r04zm_swt_tiny_batches.txt)
         auto swt_tail = [&]() {
             const long long per_image = (long long)p->info.Nr * p->info.Nc;

@@ -481,9 +481,16 @@ static void run_tail_emu(const TailArgs& a, int batch, bool inverse, int threads
     }
 }
 template <int HLEN>
+static void run_tail_emu_p2(const TailArgs& a, int batch, bool inverse, int threads, float* smem) {
+    for (int bz = 0; bz < batch; bz++) {
+        if (inverse) { if (threads == 1024) dwt2_inv_tail_image_p2<HLEN, 1024>(a, bz, smem); else dwt2_inv_tail_image_p2<HLEN, 256>(a, bz, smem); }
+        else { if (threads == 1024) dwt2_fwd_tail_image_p2<HLEN, 1024>(a, bz, smem); else dwt2_fwd_tail_image_p2<HLEN, 256>(a, bz, smem); }
+    }
+}
+template <int HLEN>
 static void run_tail_emu2(const TailArgs& a, int batch, bool inverse, int threads, float* smem) {
-    if (a.lgR >= 0 && a.lgC >= 0) run_tail_emu<HLEN, true>(a, batch, inverse, threads, smem);
-    else run_tail_emu<HLEN, false>(a, batch, inverse, threads, smem);
+    if (a.lgR >= 0 && a.lgC >= 0) run_tail_emu_p2<HLEN>(a, batch, inverse, threads, smem);  // the mask / shift kernels
+    else run_tail_emu<HLEN, false>(a, batch, inverse, threads, smem);                       // the general ones (unrolled == 2: also for powers of two)
 }
 EMU_API int emu_dwt2_tail(int inverse, float* image, int batch, int R0, int C0, int K, const float* lo, const float* hi, int hlen,
                           int threads, int unrolled, float* det, float* app) {
@@ -520,10 +527,7 @@ EMU_API int emu_dwt2_tail(int inverse, float* image, int batch, int R0, int C0, 
 // det: H,V,D of level 1 (3 x batch x n), then of level 2, ...; app: A_L (batch x n)
 EMU_API int emu_swt2_tail(int inverse, float* image, int batch, int Nr, int Nc, int L, const float* lo, const float* hi, int hlen,
                           const float* beta, float* det, float* app) {
-    int lgR = 0, lgC = 0;
-    while ((1 << lgR) < Nr) lgR++;
-    while ((1 << lgC) < Nc) lgC++;
-    if (L < 1 || L > kSwtTailMaxLevels || (1 << lgR) != Nr || (1 << lgC) != Nc || (long long)Nr * Nc > kSwtTailMaxSamples) return -2;
+    if (L < 1 || L > kSwtTailMaxLevels || Nr < 2 || Nc < 2 || (long long)Nr * Nc > kSwtTailMaxSamples) return -2;
     const long long n = (long long)Nr * Nc;
     SwtTailArgs a;
     for (int l = 0; l < kSwtTailMaxLevels; l++) {
@@ -532,12 +536,20 @@ EMU_API int emu_swt2_tail(int inverse, float* image, int batch, int Nr, int Nc, 
     }
     a.in = inverse ? app : image;
     a.out = inverse ? image : app;
-    a.lgR = lgR; a.lgC = lgC; a.L = L; a.hlen = hlen;
+    a.R = Nr; a.C = Nc; a.L = L; a.hlen = hlen;
     set_bank(a.fb, lo, hi, hlen);
     std::vector<float> smem(swt_tail_lds_elems((int)n, inverse != 0) + 64, NAN);
+    int lgC = 0, lgR = 0;
+    while ((1 << lgC) < Nc) lgC++;
+    while ((1 << lgR) < Nr) lgR++;
+    const bool pow2 = (1 << lgC) == Nc && (1 << lgR) == Nr;
+    a.lgC = pow2 ? lgC : -1;
+    a.lgR = pow2 ? lgR : -1;
+    const bool general = !pow2 || (beta && beta[0] < 0);  // (a negative first threshold: powers of two through the general kernels too)
+    if (beta && beta[0] < 0) a.beta[0] = 0.f;
     for (int bz = 0; bz < batch; bz++) {
-        if (inverse) swt2_inv_tail_image<256>(a, bz, smem.data());
-        else swt2_fwd_tail_image<256>(a, bz, smem.data());
+        if (inverse) { if (!general) swt2_inv_tail_image_p2<256>(a, bz, smem.data()); else swt2_inv_tail_image<256, false>(a, bz, smem.data()); }
+        else { if (!general) swt2_fwd_tail_image_p2<256>(a, bz, smem.data()); else swt2_fwd_tail_image<256, false>(a, bz, smem.data()); }
     }
     return 0;
 }

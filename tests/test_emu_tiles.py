@@ -409,7 +409,8 @@ def test_emu_swt2_tail_whole_transform_of_tiny_images(wname):
     transform out of LDS -- dilations larger than the image (the periodic index wraps several times), rectangular images, a
     batch, the soft threshold folded into the inverse's staging."""
     hlen, dlo, dhi, rlo, rhi = oracle.filters(wname)
-    for si, (B, shape, L) in enumerate([(1, (64, 64), 3), (2, (32, 64), 4), (3, (16, 16), 2), (1, (8, 32), 5), (1, (64, 16), 1), (2, (4, 4), 2)]):
+    for si, (B, shape, L) in enumerate([(1, (64, 64), 3), (2, (32, 64), 4), (3, (16, 16), 2), (1, (8, 32), 5), (1, (64, 16), 1), (2, (4, 4), 2),
+                                        (2, (28, 28), 2), (1, (48, 40), 3), (1, (7, 9), 2), (1, (63, 65), 3), (2, (20, 12), 4)]):
         x = oracle.hash_input((B,) + shape, 9300 + si)
         n = shape[0] * shape[1]
         det = np.full(3 * L * B * n, np.nan, dtype=np.float32)

@@ -806,7 +806,8 @@ def test_batched_1d_short_rows_and_few_levels(wname, rows, n, levels):
 @pytest.mark.gpu
 @pytest.mark.parametrize("wname,shape,levels,batch", [("haar", (64, 64), 3, 300), ("db2", (32, 32), 3, 1100), ("db4", (64, 64), 2, 260),
                                                       ("sym8", (32, 64), 1, 520), ("haar", (16, 16), 4, 4200), ("db3", (64, 32), 2, 600),
-                                                      ("db4", (64, 64), 2, 100)])
+                                                      ("db4", (64, 64), 2, 100), ("db2", (28, 28), 2, 1500), ("haar", (48, 40), 3, 600),
+                                                      ("db4", (30, 30), 2, 1200), ("haar", (21, 33), 2, 1600), ("sym4", (60, 64), 2, 300)])
 def test_swt_batches_of_tiny_images(wname, shape, levels, batch):
     """Large batches of tiny images through the undecimated transform: at least 2^20 samples in all -> the whole SWT of an image is
     ONE workgroup of one launch per direction (swt2_tail_kernels.hpp); the soft threshold is folded into the inverse.  First,
