@@ -566,6 +566,8 @@ F64_CASES = [
     ("sym8", (4, 4096), 5, 1, 0), ("db3", (1, 1000), 3, 1, 0),
     ("haar", (64, 64), 3, 2, 1), ("db2", (48, 80), 2, 2, 1), ("sym4", (3, 256), 3, 1, 1),
     ("haar", (128, 64), 6, 2, 0), ("haar", (32, 32), 5, 2, 0),  # deep plans: the tail launch over doubles
+    ("haar", (16, 48), 4, 2, 0),  # ... its general-size instantiation (48 is not a power of two)
+    ("db2", (32, 32), 3, 2, 1), ("db3", (24, 28), 2, 2, 1),  # the SWT tail launch over doubles: power-of-two and general sizes
 ]
 
 
