@@ -87,11 +87,11 @@ static bool swt1_vec_ok(const SwtPassArgs& a) {
 hipError_t try_launch_swt1_split(const SwtPassArgs& a, bool inverse, hipStream_t s);
 
 hipError_t launch_swt_pass_fwd(const SwtPassArgs& a, hipStream_t s) {
-    {
+    if (a.images == 1) {  // (several planes per launch: the direct kernel only)
         const hipError_t e = try_launch_swt1_split(a, false, s);
         if (e != hipErrorNotSupported) return e;
     }
-    if (swt1_vec_ok(a)) {
+    if (a.images == 1 && swt1_vec_ok(a)) {
         const unsigned grid = (unsigned)cdivll((long long)a.Nr * (a.Nc >> 2), 256);
         switch (a.hlen) {
 #define X(h)                                                                                      \
@@ -102,17 +102,17 @@ hipError_t launch_swt_pass_fwd(const SwtPassArgs& a, hipStream_t s) {
 #undef X
         }
     }
-    const long long total = (long long)a.Nr * a.Nc;
+    const long long total = (long long)a.Nr * a.Nc * a.images;
     hipLaunchKernelGGL((swt_pass_fwd_kernel<256>), dim3((unsigned)cdivll(total, 256)), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
 hipError_t launch_swt_pass_inv(const SwtPassArgs& a, hipStream_t s) {
-    {
+    if (a.images == 1) {
         const hipError_t e = try_launch_swt1_split(a, true, s);
         if (e != hipErrorNotSupported) return e;
     }
-    if (swt1_vec_ok(a)) {
+    if (a.images == 1 && swt1_vec_ok(a)) {
         const unsigned grid = (unsigned)cdivll((long long)a.Nr * (a.Nc >> 2), 256);
         switch (a.hlen) {
 #define X(h)                                                                                      \
@@ -126,7 +126,7 @@ hipError_t launch_swt_pass_inv(const SwtPassArgs& a, hipStream_t s) {
 #undef X
         }
     }
-    const long long total = (long long)a.Nr * a.Nc;
+    const long long total = (long long)a.Nr * a.Nc * a.images;
     hipLaunchKernelGGL((swt_pass_inv_kernel<256>), dim3((unsigned)cdivll(total, 256)), dim3(256), 0, s, a);
     return hipGetLastError();
 }

@@ -518,16 +518,18 @@ template <int NT>
 PDWT_DEVICE void swt_pass_fwd_tile(const SwtPassArgs& a, long long block, real_t* /*smem*/) {
     PDWT_FOR_THREADS(tid, NT) {
         const long long idx = block * NT + tid;
-        const long long total = (long long)a.Nr * a.Nc;
-        if (idx < total) {
-            const int y = (int)(idx / a.Nc);
-            const int x = (int)(idx - (long long)y * a.Nc);
+        const long long plane = (long long)a.Nr * a.Nc;
+        if (idx < plane * a.images) {
+            const long long base = (idx / plane) * plane;  // the image's plane (a.images planes back to back behind every pointer)
+            const long long rem = idx - base;
+            const int y = (int)(rem / a.Nc);
+            const int x = (int)(rem - (long long)y * a.Nc);
             const int c = analysis_centre(a.hlen);
             real_t aL = 0.f, aH = 0.f;
             for (int j = 0; j < a.hlen; ++j) {
                 long long src;
-                if (a.along_y) src = (long long)wrap_periodic(y + (j - c) * a.f, a.Nr) * a.Nc + x;
-                else src = (long long)y * a.Nc + wrap_periodic(x + (j - c) * a.f, a.Nc);
+                if (a.along_y) src = base + (long long)wrap_periodic(y + (j - c) * a.f, a.Nr) * a.Nc + x;
+                else src = base + (long long)y * a.Nc + wrap_periodic(x + (j - c) * a.f, a.Nc);
                 const real_t v = a.in0[src];
                 aL = pdwt_fma(v, a.fb.lo[a.hlen - 1 - j], aL);
                 aH = pdwt_fma(v, a.fb.hi[a.hlen - 1 - j], aH);
@@ -542,16 +544,18 @@ template <int NT>
 PDWT_DEVICE void swt_pass_inv_tile(const SwtPassArgs& a, long long block, real_t* /*smem*/) {
     PDWT_FOR_THREADS(tid, NT) {
         const long long idx = block * NT + tid;
-        const long long total = (long long)a.Nr * a.Nc;
-        if (idx < total) {
-            const int y = (int)(idx / a.Nc);
-            const int x = (int)(idx - (long long)y * a.Nc);
+        const long long plane = (long long)a.Nr * a.Nc;
+        if (idx < plane * a.images) {
+            const long long base = (idx / plane) * plane;
+            const long long rem = idx - base;
+            const int y = (int)(rem / a.Nc);
+            const int x = (int)(rem - (long long)y * a.Nc);
             const int c = a.hlen / 2;
             real_t r = 0.f;
             for (int j = 0; j < a.hlen; ++j) {
                 long long src;
-                if (a.along_y) src = (long long)wrap_periodic(y + (j - c) * a.f, a.Nr) * a.Nc + x;
-                else src = (long long)y * a.Nc + wrap_periodic(x + (j - c) * a.f, a.Nc);
+                if (a.along_y) src = base + (long long)wrap_periodic(y + (j - c) * a.f, a.Nr) * a.Nc + x;
+                else src = base + (long long)y * a.Nc + wrap_periodic(x + (j - c) * a.f, a.Nc);
                 r = pdwt_fma(a.in0[src], a.fb.lo[a.hlen - 1 - j], r);
                 r = pdwt_fma(a.in1[src], a.fb.hi[a.hlen - 1 - j], r);
             }

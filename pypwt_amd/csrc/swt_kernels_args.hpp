@@ -13,6 +13,7 @@ struct SwtPassArgs {
     int Nr, Nc, f, along_y;
     int hlen;
     FilterBank fb;
+    int images = 1;     // the direct one-output-per-thread kernels only: that many (Nr, Nc) planes back to back behind every pointer
 };
 
 }  // namespace pdwt

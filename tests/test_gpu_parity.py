@@ -837,3 +837,28 @@ def test_swt_batches_of_tiny_images(wname, shape, levels, batch):
         want = oracle.inverse(thr, shape, wname, L, do_swt=1)
         assert np.abs(plan.image_at(b) - want).max() <= 1e-3 * 255, (sched, b)
     plan.cleanup()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("wname,shape,levels,batch", [("haar", (150, 132), 3, 5), ("db3", (75, 200), 2, 7), ("db2", (90, 64), 3, 40)])
+def test_swt_batches_whose_rows_the_dilation_does_not_divide(wname, shape, levels, batch):
+    """Batched SWT levels with Nr % 2^(l-1) != 0 (pywt cannot do these sizes, the reference can: separable.cu:409-493): three direct
+    passes per level, all images of the batch in each launch.  First and last image against the oracle, then the inverse."""
+    from pypwt_amd import BatchedWavelets
+    oracle.build()
+    plan = BatchedWavelets(batch, shape[0], shape[1], wname, levels, do_swt=1)
+    L = plan.levels
+    plan.fill_hash(99, 255.0)
+    plan.forward()
+    n = shape[0] * shape[1]
+    refs = {}
+    for b in sorted({0, batch // 2, batch - 1}):
+        x = oracle.hash_input(shape, 99, index_offset=b * n)
+        refs[b] = (x, oracle.forward(x, wname, L, do_swt=1))
+        for num, r in enumerate(refs[b][1]):
+            g = plan.coeff_at(num, b)
+            assert np.abs(g - r).max() <= 2e-6 * (L + 1) * max(float(np.abs(r).max()), 255.0 * 2 ** L), (b, num)
+    plan.inverse()
+    for b, (x, _) in refs.items():
+        assert np.abs(plan.image_at(b) - x).max() <= 7e-4 * 255, b
+    plan.cleanup()
