@@ -11,7 +11,8 @@
 // batch of loads up front (together exactly R0 x C0 values: one global-memory round trip for the whole launch, not one per
 // level) and then walks back up out of LDS.
 // No halo, no tile geometry: the whole plane is resident.  Power-of-two sizes: the periodic wrap is a mask and the index
-// split a shift (POW2 instantiations); any other size whose halves stay even through the group: conditional wrap + division.
+// split a shift (the _p2 kernels); any other size, odd ones included (sizes by ceil-halving, the analysis repeats the last sample
+// of an odd length, the synthesis drops it): conditional wrap + division (the general kernels).
 // Reference: w_kern_forward_pass1/2 (pdwt/src/separable.cu:91-176), w_kern_inverse_pass1/2 (:246-328), the level loops
 // w_forward_separable / w_inverse_separable (:179-236, :332-395); index conventions as in oracle/pdwt_oracle.c
 // (analysis centre hlen/2 - 1; polyphase synthesis with h2 = hlen/2, c = h2/2, s = 1 - (h2 & 1)).
@@ -27,44 +28,106 @@ constexpr int kTailMaxLevels = 14;
 // samples of one image entering the first level of the group: two buffers of that size + the taps must fit 160 KB
 constexpr int kTailMaxSamples = sizeof(real_t) == 4 ? 16384 : 8192;
 constexpr int kTailTrips = 16;  // values a thread stages: the launcher picks NT with R0 x C0 <= kTailTrips x NT
+// the inverse keeps its 3 K plane pointers in LDS (behind the taps, 8-byte aligned): elements of real_t that takes
+constexpr int kTailPtrElems = (int)(3 * kTailMaxLevels * sizeof(void*) / sizeof(real_t)) + 2;
 
 struct TailArgs {
     const real_t* in;                 // forward: A_{l-1} (R0 x C0 per image); inverse: A_L
     real_t* out;                      // forward: A_L; inverse: A_{l-1}
     real_t* det[kTailMaxLevels][3];   // det[k] = (H, V, D) of the group's k-th level, finest first: forward written, inverse read
-    int R0, C0;                       // size entering the finest level; R0 >> k and C0 >> k are even for k < K
-    int lgR, lgC;                     // their base-2 logarithms when both are powers of two (the POW2 instantiations)
+    int R0, C0;                       // size entering the finest level
+    int lgR, lgC;                     // their base-2 logarithms when both are powers of two (the _p2 kernels), else -1
     int K;                            // levels in the group
     int hlen;                         // even
+    // the general kernels' geometry (tail_geometry): sizes by ceil-halving (pdwt/src/utils.cu:24-27), LDS homes, staging order
+    int r[kTailMaxLevels + 1], c[kTailMaxLevels + 1];  // size entering level k of the group; [K] = the coarsest approximation
+    int fs[kTailMaxLevels + 1];       // inverse staging: flat positions [fs[k], fs[k+1]) = H | V | D of level k ([0, fs[0]) = A_L)
+    int doff[kTailMaxLevels];         // inverse: LDS offset of level k's H plane (V and D follow)
+    int uoff, taps;                   // LDS offsets: second buffer (forward: L | H rows; inverse: u1 | u2); the reversed taps
     FilterBank fb;                    // forward: analysis (dec_lo, dec_hi); inverse: synthesis (rec_lo, rec_hi)
 };
 
-constexpr size_t tail_lds_elems(int n0) { return (size_t)2 * n0 + 2 * kMaxTaps; }
+// LDS elements of the _p2 kernels (two planes of n0 samples + the taps)
+constexpr size_t tail_lds_elems(int n0) { return (size_t)2 * n0 + 2 * kMaxTaps + kTailPtrElems; }
 
-// One axis of a level: its length n, the periodic wrap of an index near [0, n) and the split of a flat index by n.  POW2: a
-// mask and a shift (lg = log2 n); otherwise a conditional add / subtract (the modulo only where a tiny level is shorter than the
-// filter) and a division -- sizes like 28, 48, 96, 100 (round 4: batches of such images were 3-10x slower than their power-of-two
-// neighbours on the level kernels).
-template <bool POW2>
-struct TailAxis {
-    int n, lg;
-    PDWT_DEVICE int wrap(int q) const {
-        if (POW2) return q & (n - 1);
-        q = q < 0 ? q + n : (q >= n ? q - n : q);
-        return (unsigned)q < (unsigned)n ? q : true_mod(q, n);
+// Geometry of the general kernels for a.R0, a.C0, a.K: level sizes, LDS layout, staging order.  Returns the LDS elements needed.
+//   forward: [0, n0) the approximation being reduced | [n0, n0 + 2 r0 c1) the row pass' (L | H) | taps
+//   inverse: [0, r1 c1) the approximation being rebuilt | 3 r1 c1: H, V, D of the FINEST level | U: (u1 | u2) of the step, at most
+//            2 r1 c2 elements before the last step -- behind them the details of the coarser levels, all consumed when the last
+//            step's 2 r0 c1 elements overwrite them | taps.
+// Even sizes throughout: 2 n0 elements + taps either way, exactly the _p2 layout.
+inline size_t tail_geometry(TailArgs& a, bool inverse) {
+    a.r[0] = a.R0; a.c[0] = a.C0;
+    for (int k = 0; k < a.K; k++) { a.r[k + 1] = (a.r[k] + 1) >> 1; a.c[k + 1] = (a.c[k] + 1) >> 1; }
+    for (int k = a.K + 1; k <= kTailMaxLevels; k++) { a.r[k] = a.r[a.K]; a.c[k] = a.c[a.K]; }
+    const int n0 = a.R0 * a.C0, n1 = a.r[1] * a.c[1];
+    const int u_last = 2 * a.r[0] * a.c[1];
+    for (int k = 0; k <= kTailMaxLevels; k++) a.fs[k] = 0;
+    for (int k = 0; k < kTailMaxLevels; k++) a.doff[k] = 0;
+    if (!inverse) {
+        a.uoff = n0;
+        a.taps = n0 + u_last;
+        return (size_t)a.taps + 2 * kMaxTaps;
     }
-    PDWT_DEVICE int div(int idx) const { return POW2 ? (idx >> lg) : (idx / n); }
-};
-template <bool POW2>
-PDWT_DEVICE TailAxis<POW2> tail_axis(int n, int lg) { TailAxis<POW2> a; a.n = n; a.lg = lg; return a; }
+    a.uoff = 4 * n1;
+    a.fs[0] = a.r[a.K] * a.c[a.K];
+    for (int k = 0; k < a.K; k++) a.fs[k + 1] = a.fs[k] + 3 * a.r[k + 1] * a.c[k + 1];
+    for (int k = a.K + 1; k <= kTailMaxLevels; k++) a.fs[k] = a.fs[a.K];
+    a.doff[0] = n1;
+    int coarse = a.uoff + (a.K > 1 ? 2 * a.r[1] * a.c[2] : 0);
+    for (int k = 1; k < a.K; k++) { a.doff[k] = coarse; coarse += 3 * a.r[k + 1] * a.c[k + 1]; }
+    const int u_end = a.uoff + u_last;
+    a.taps = coarse > u_end ? coarse : u_end;
+    return (size_t)a.taps + 2 * kMaxTaps + kTailPtrElems;
+}
 
-template <int HLEN, int NT, bool POW2>
+// One axis of a level: its length n and the periodic wrap of an index near it.  Analysis of an odd length: the signal is first
+// extended by one sample repeating its last (pdwt/src/separable.cu:114-121; per_src of oracle/pdwt_oracle.c), period np = n + 1.
+// A conditional add / subtract; the modulo only where a tiny level is shorter than the filter.
+struct TailAxis {
+    int n, np;
+    PDWT_DEVICE int wrap(int q) const {
+        q = q < 0 ? q + np : (q >= np ? q - np : q);
+        q = (unsigned)q < (unsigned)np ? q : true_mod(q, np);
+        return q < n ? q : n - 1;
+    }
+};
+PDWT_DEVICE TailAxis tail_axis_analysis(int n) { TailAxis a; a.n = n; a.np = n + (n & 1); return a; }
+PDWT_DEVICE TailAxis tail_axis(int n) { TailAxis a; a.n = n; a.np = n; return a; }
+
+// The detail planes' addresses as the inverse's staging looks them up: a table in LDS, written once by one thread with UNIFORM
+// indices (scalar loads of the kernel arguments).  Indexing the argument array by a per-lane level instead makes every lookup a
+// vector memory load from the argument buffer: measured, those lookups were more than half of the whole inverse launch (16384
+// images of 32 x 32, db2 L3: 92.6 us, 44.1 with the addresses computed arithmetically; 65536 of 16 x 16: 290 / 101).
+PDWT_DEVICE real_t** tail_ptr_table(real_t* smem, int after_taps) {  // smem is 16-byte aligned: an even element offset is 8-byte aligned
+    return reinterpret_cast<real_t**>(smem + ((after_taps + 1) & ~1));
+}
+
+// The reversed taps as a thread keeps them: registers for the unrolled lengths (the LDS copy cannot be hoisted out of the loops by
+// the compiler: the loops store to LDS), the LDS copy for the run-time length.
+template <int HLEN>
+struct TailTaps {
+    real_t lo[HLEN ? HLEN : 1], hi[HLEN ? HLEN : 1];
+    const real_t* sLo;
+    const real_t* sHi;
+    PDWT_DEVICE void load(const real_t* fLo, const real_t* fHi) {
+        sLo = fLo; sHi = fHi;
+#pragma unroll
+        for (int j = 0; j < HLEN; ++j) { lo[j] = fLo[j]; hi[j] = fHi[j]; }
+    }
+    PDWT_DEVICE real_t l(int t) const { return HLEN ? lo[t] : sLo[t]; }
+    PDWT_DEVICE real_t h(int t) const { return HLEN ? hi[t] : sHi[t]; }
+};
+
+// Any sizes (sizes like 28, 48, 96, 100, and the odd ones they halve into -- round 4: batches of such images were 3-10x slower
+// than their power-of-two neighbours on the level kernels).
+template <int HLEN, int NT>
 PDWT_DEVICE void dwt2_fwd_tail_image(const TailArgs& a, int bz, real_t* smem) {
     const int hlen = HLEN ? HLEN : a.hlen, C = hlen / 2 - 1;
     const int n0 = a.R0 * a.C0;
     real_t* cur = smem;
-    real_t* tmp = smem + n0;
-    real_t* fLo = smem + 2 * n0;
+    real_t* tmp = smem + a.uoff;
+    real_t* fLo = smem + a.taps;
     real_t* fHi = fLo + kMaxTaps;
     PDWT_FOR_THREADS(tid, NT) {
         const real_t* PDWT_RESTRICT in = a.in + (long long)bz * n0;
@@ -72,7 +135,7 @@ PDWT_DEVICE void dwt2_fwd_tail_image(const TailArgs& a, int bz, real_t* smem) {
 #pragma unroll
         for (int t = 0; t < kTailTrips; ++t) {  // constant trip count, clamped index: all loads of a thread in flight together
             const int idx = tid + t * NT;
-            v[t] = in[idx < n0 ? idx : n0 - 1];
+            if (t * NT < n0) v[t] = in[idx < n0 ? idx : n0 - 1];  // (a uniform test: tiny images skip the trips they do not need)
         }
 #pragma unroll
         for (int t = 0; t < kTailTrips; ++t) {
@@ -86,14 +149,14 @@ PDWT_DEVICE void dwt2_fwd_tail_image(const TailArgs& a, int bz, real_t* smem) {
     }
     PDWT_SYNC();
     for (int k = 0; k < a.K; ++k) {
-        const int r = a.R0 >> k, c = a.C0 >> k, c2 = c >> 1, r2 = r >> 1;
-        const TailAxis<POW2> ac = tail_axis<POW2>(c, a.lgC - k), ac2 = tail_axis<POW2>(c2, a.lgC - k - 1), ar = tail_axis<POW2>(r, a.lgR - k);
+        const int r = a.r[k], c = a.c[k], c2 = a.c[k + 1], r2 = a.r[k + 1];
+        const TailAxis ac = tail_axis_analysis(c), ar = tail_axis_analysis(r);
         const int n_half = r * c2, n_quarter = r2 * c2;
         real_t* tL = tmp;
         real_t* tH = tmp + n_half;
         PDWT_FOR_THREADS(tid, NT) {  // rows: (r x c) -> L | H, (r x c2) each
             for (int idx = tid; idx < n_half; idx += NT) {
-                const int y = ac2.div(idx), x = idx - y * c2;
+                const int y = idx / c2, x = idx - y * c2;
                 const real_t* row = cur + y * c;
                 const int base = 2 * x - C;
                 real_t l = 0, h = 0;
@@ -116,7 +179,7 @@ PDWT_DEVICE void dwt2_fwd_tail_image(const TailArgs& a, int bz, real_t* smem) {
             real_t* PDWT_RESTRICT gV = a.det[k][1] + b;
             real_t* PDWT_RESTRICT gD = a.det[k][2] + b;
             for (int idx = tid; idx < n_quarter; idx += NT) {
-                const int i = ac2.div(idx), x = idx - i * c2;
+                const int i = idx / c2, x = idx - i * c2;
                 const int base = 2 * i - C;
                 real_t ll = 0, lh = 0, hl = 0, hh = 0;
 #pragma unroll
@@ -139,99 +202,137 @@ PDWT_DEVICE void dwt2_fwd_tail_image(const TailArgs& a, int bz, real_t* smem) {
     }
 }
 
-// Flat order of everything the inverse reads, from the coarse end: with sL = samples of A_L, positions [0, sL) are A_L and
-// [4^m sL, 4^(m+1) sL) the three detail planes (4^m sL each) of the group's level K-1-m -- together exactly n0 values (every
-// level halves both sizes exactly).  LDS homes: positions below sL and from n0/4 on (the finest level's details) live at X[f];
-// the rest at U[n0/4 + f].
-template <int HLEN, int NT, bool POW2>
+// The inverse stages everything it reads in one batch of loads, in the flat order of TailArgs::fs (A_L, then H | V | D of the
+// finest level, the next coarser one, ...), into the LDS homes of tail_geometry.  An output size may be odd (2 n_in - 1: the virtual
+// last sample is dropped, separable.cu:296).
+template <int HLEN, int NT>
 PDWT_DEVICE void dwt2_inv_tail_image(const TailArgs& a, int bz, real_t* smem) {
     const int hlen = HLEN ? HLEN : a.hlen, H2 = hlen / 2, C = H2 / 2, S = (H2 & 1) ? 0 : 1;
-    const int n0 = a.R0 * a.C0, q0 = n0 >> 2;
-    const int sL = (a.R0 >> a.K) * (a.C0 >> a.K);
-    real_t* X = smem;       // [0, n0/4): the approximation being rebuilt; [n0/4, n0): H, V, D of the finest level
-    real_t* U = smem + n0;  // column-synthesis results (u1 | u2); [n0/4, n0/2): the details of the coarser levels until the last step
-    real_t* fLo = smem + 2 * n0;
+    const int sL = a.fs[0], total = a.fs[a.K];
+    real_t* X = smem;
+    real_t* U = smem + a.uoff;
+    real_t* fLo = smem + a.taps;
     real_t* fHi = fLo + kMaxTaps;
+    real_t** ptab = tail_ptr_table(smem, a.taps + 2 * kMaxTaps);
     PDWT_FOR_THREADS(tid, NT) {
-        // three unrolled passes so that a thread's loads are in flight TOGETHER: the plane pointers (a lane-indexed read of the
-        // kernel arguments: memory loads), then the values, then the LDS stores.  Interleaved, the in-order load counter makes
-        // every pointer wait drain the data loads before it: sixteen round trips instead of two.
-        const real_t* src[kTailTrips];
-        real_t v[kTailTrips];
-#pragma unroll
-        for (int t = 0; t < kTailTrips; ++t) {
-            int f = tid + t * NT;
-            f = f < n0 ? f : n0 - 1;
-            if (f < sL) {
-                src[t] = a.in + (long long)bz * sL + f;
-            } else {
-                int m = 0, pm = sL;  // plane size of level K-1-m: 4^m sL
-                while (f >= 4 * pm) { pm *= 4; ++m; }
-                const int g = f - pm, b = (g >= pm) + (g >= 2 * pm), idx = g - b * pm;
-                src[t] = a.det[a.K - 1 - m][b] + (long long)bz * pm + idx;
-            }
-        }
-#pragma unroll
-        for (int t = 0; t < kTailTrips; ++t) v[t] = *src[t];
-#pragma unroll
-        for (int t = 0; t < kTailTrips; ++t) {
-            const int f = tid + t * NT;
-            if (f < n0) {
-                if (f < sL || f >= q0) X[f] = v[t];
-                else U[q0 + f] = v[t];
-            }
-        }
+        if (tid == 0)
+            for (int k = 0; k < a.K; ++k)
+                for (int b = 0; b < 3; ++b) ptab[3 * k + b] = a.det[k][b];
         for (int j = tid; j < hlen; j += NT) {
             fLo[j] = a.fb.lo[hlen - 1 - j];
             fHi[j] = a.fb.hi[hlen - 1 - j];
         }
     }
     PDWT_SYNC();
+    PDWT_FOR_THREADS(tid, NT) {
+        // three unrolled passes so that a thread's loads are in flight TOGETHER: the addresses (plane pointers out of the LDS
+        // table), then the values, then the LDS stores.
+        // (the level of a flat position by walking the sizes in registers: a lane-indexed read of fs[] / doff[] would be a dependent
+        // memory load per step of the search)
+        const int n1 = a.r[1] * a.c[1], coarse0 = a.uoff + (a.K > 1 ? 2 * a.r[1] * a.c[2] : 0);
+        auto locate = [&](int f, int& home) -> const real_t* {
+            if (f < sL) { home = f; return a.in + (long long)bz * sL + f; }
+            int k = 0, rr = a.r[1], cc = a.c[1], pm = n1, start = sL, hb = n1, nxt = coarse0;
+            while (f >= start + 3 * pm) {
+                start += 3 * pm; ++k;
+                rr = (rr + 1) >> 1; cc = (cc + 1) >> 1; pm = rr * cc;
+                hb = nxt; nxt += 3 * pm;
+            }
+            const int g = f - start, b = (g >= pm) + (g >= 2 * pm);
+            home = hb + g;
+            return ptab[3 * k + b] + (long long)bz * pm + (g - b * pm);
+        };
+        const real_t* src[kTailTrips];
+        int home[kTailTrips];
+        real_t v[kTailTrips];
+#pragma unroll
+        for (int t = 0; t < kTailTrips; ++t) {
+            const int f = tid + t * NT;
+            if (t * NT < total) src[t] = locate(f < total ? f : total - 1, home[t]);  // (a uniform test: tiny images skip trips)
+        }
+#pragma unroll
+        for (int t = 0; t < kTailTrips; ++t)
+            if (t * NT < total) v[t] = *src[t];
+#pragma unroll
+        for (int t = 0; t < kTailTrips; ++t)
+            if (tid + t * NT < total) smem[home[t]] = v[t];
+        for (int f = tid + kTailTrips * NT; f < total; f += NT) {  // odd sizes: a few values more than R0 x C0
+            int h;
+            const real_t* s = locate(f, h);
+            smem[h] = *s;
+        }
+    }
+    PDWT_SYNC();
+    // A work item is a PAIR of outputs (2m, 2m + 1): with p = g + S their windows start at m - C and m - C + S, so the pair reads
+    // H2 + S sources instead of 2 H2, the tap parities are compile-time constants (even taps for one output, odd for the other:
+    // registers, where the one-output form read its taps from LDS by a run-time index) and there is one index split per pair.
+    //   out[2m]     = sum_j s[j]     f[2j + 1 - S],   out[2m + 1] = sum_j s[j + S] f[2j + S],   s[i] = in[wrap(m - C + i)]
     for (int k = a.K - 1; k >= 0; --k) {
-        const int ri = a.R0 >> (k + 1), ci = a.C0 >> (k + 1), co = 2 * ci;
-        const TailAxis<POW2> ari = tail_axis<POW2>(ri, a.lgR - k - 1), aci = tail_axis<POW2>(ci, a.lgC - k - 1), aco = tail_axis<POW2>(co, a.lgC - k);
-        const int n_in = ri * ci;  // = 4^(K-1-k) sL
-        const real_t* dH = k == 0 ? X + q0 : U + q0 + n_in;
+        const int ri = a.r[k + 1], ci = a.c[k + 1], ro = a.r[k], co = a.c[k];
+        const TailAxis ari = tail_axis(ri), aci = tail_axis(ci);
+        const int n_in = ri * ci, n_u = ro * ci, mp = (ro + 1) >> 1, cp = (co + 1) >> 1;
+        const real_t* dH = smem + a.doff[k];
         const real_t* dV = dH + n_in;
         const real_t* dD = dV + n_in;
         real_t* u1 = U;
-        real_t* u2 = U + 2 * n_in;
-        PDWT_FOR_THREADS(tid, NT) {  // column synthesis: (A, H) -> u1, (V, D) -> u2, (2 ri x ci) each
-            for (int idx = tid; idx < 2 * n_in; idx += NT) {
-                const int q = aci.div(idx), x = idx - q * ci;
-                const int p = q + S;
-                const int rel = (p >> 1) - C, par = 1 - (p & 1);
-                real_t r1 = 0, r2 = 0;
+        real_t* u2 = U + n_u;
+        PDWT_FOR_THREADS(tid, NT) {  // column synthesis: (A, H) -> u1, (V, D) -> u2, (ro x ci) each
+            TailTaps<HLEN> f;
+            f.load(fLo, fHi);
+            for (int idx = tid; idx < mp * ci; idx += NT) {
+                const int m = idx / ci, x = idx - m * ci;
+                real_t e1 = 0, e2 = 0, o1 = 0, o2 = 0;
 #pragma unroll
-                for (int j = 0; j < H2; ++j) {
-                    const int t = 2 * j + par;  // reversed taps: f[hlen - 1 - t]
-                    const int src = ari.wrap(rel + j) * ci + x;
-                    r1 = pdwt_fma(X[src], fLo[t], r1);
-                    r1 = pdwt_fma(dH[src], fHi[t], r1);
-                    r2 = pdwt_fma(dV[src], fLo[t], r2);
-                    r2 = pdwt_fma(dD[src], fHi[t], r2);
+                for (int i = 0; i < H2 + S; ++i) {
+                    const int src = ari.wrap(m - C + i) * ci + x;
+                    const real_t vA = X[src], vH = dH[src], vV = dV[src], vD = dD[src];
+                    if (i < H2) {
+                        const int t = 2 * i + 1 - S;
+                        e1 = pdwt_fma(vA, f.l(t), e1);
+                        e1 = pdwt_fma(vH, f.h(t), e1);
+                        e2 = pdwt_fma(vV, f.l(t), e2);
+                        e2 = pdwt_fma(vD, f.h(t), e2);
+                    }
+                    if (i >= S) {
+                        const int t = 2 * (i - S) + S;
+                        o1 = pdwt_fma(vA, f.l(t), o1);
+                        o1 = pdwt_fma(vH, f.h(t), o1);
+                        o2 = pdwt_fma(vV, f.l(t), o2);
+                        o2 = pdwt_fma(vD, f.h(t), o2);
+                    }
                 }
-                u1[idx] = r1;
-                u2[idx] = r2;
+                const int o = 2 * m * ci + x;
+                u1[o] = e1;
+                u2[o] = e2;
+                if (2 * m + 1 < ro) { u1[o + ci] = o1; u2[o + ci] = o2; }
             }
         }
         PDWT_SYNC();
-        PDWT_FOR_THREADS(tid, NT) {  // row synthesis: (u1, u2) -> (2 ri x 2 ci), to LDS or (the last step) global
-            real_t* PDWT_RESTRICT gout = a.out + (long long)bz * 4 * n_in;
-            for (int idx = tid; idx < 4 * n_in; idx += NT) {
-                const int q = aco.div(idx), g = idx - q * co;
-                const int p = g + S;
-                const int rel = (p >> 1) - C, par = 1 - (p & 1);
-                real_t r = 0;
+        PDWT_FOR_THREADS(tid, NT) {  // row synthesis: (u1, u2) -> (ro x co), to LDS or (the last step) global
+            TailTaps<HLEN> f;
+            f.load(fLo, fHi);
+            real_t* PDWT_RESTRICT gout = a.out + (long long)bz * ro * co;
+            for (int idx = tid; idx < ro * cp; idx += NT) {
+                const int q = idx / cp, m = idx - q * cp;
+                real_t e = 0, od = 0;
 #pragma unroll
-                for (int j = 0; j < H2; ++j) {
-                    const int t = 2 * j + par;
-                    const int src = q * ci + aci.wrap(rel + j);
-                    r = pdwt_fma(u1[src], fLo[t], r);
-                    r = pdwt_fma(u2[src], fHi[t], r);
+                for (int i = 0; i < H2 + S; ++i) {
+                    const int src = q * ci + aci.wrap(m - C + i);
+                    const real_t v1 = u1[src], v2 = u2[src];
+                    if (i < H2) {
+                        const int t = 2 * i + 1 - S;
+                        e = pdwt_fma(v1, f.l(t), e);
+                        e = pdwt_fma(v2, f.h(t), e);
+                    }
+                    if (i >= S) {
+                        const int t = 2 * (i - S) + S;
+                        od = pdwt_fma(v1, f.l(t), od);
+                        od = pdwt_fma(v2, f.h(t), od);
+                    }
                 }
-                if (k == 0) gout[idx] = r;
-                else X[idx] = r;
+                real_t* dst = (k == 0 ? gout : X) + q * co + 2 * m;
+                dst[0] = e;
+                if (2 * m + 1 < co) dst[1] = od;
             }
         }
         PDWT_SYNC();
@@ -239,15 +340,15 @@ PDWT_DEVICE void dwt2_inv_tail_image(const TailArgs& a, int bz, real_t* smem) {
 }
 
 #ifndef PDWT_CPU_EMU
-template <int HLEN, int NT, bool POW2>
+template <int HLEN, int NT>
 __global__ void __launch_bounds__(NT) dwt2_fwd_tail_kernel(const TailArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char tail_smem[];
-    dwt2_fwd_tail_image<HLEN, NT, POW2>(a, blockIdx.x, reinterpret_cast<real_t*>(tail_smem));
+    dwt2_fwd_tail_image<HLEN, NT>(a, blockIdx.x, reinterpret_cast<real_t*>(tail_smem));
 }
-template <int HLEN, int NT, bool POW2>
+template <int HLEN, int NT>
 __global__ void __launch_bounds__(NT) dwt2_inv_tail_kernel(const TailArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char tail_smem[];
-    dwt2_inv_tail_image<HLEN, NT, POW2>(a, blockIdx.x, reinterpret_cast<real_t*>(tail_smem));
+    dwt2_inv_tail_image<HLEN, NT>(a, blockIdx.x, reinterpret_cast<real_t*>(tail_smem));
 }
 #endif
 
@@ -270,7 +371,7 @@ PDWT_DEVICE void dwt2_fwd_tail_image_p2(const TailArgs& a, int bz, real_t* smem)
 #pragma unroll
         for (int t = 0; t < kTailTrips; ++t) {  // constant trip count, clamped index: all loads of a thread in flight together
             const int idx = tid + t * NT;
-            v[t] = in[idx < n0 ? idx : n0 - 1];
+            if (t * NT < n0) v[t] = in[idx < n0 ? idx : n0 - 1];  // (a uniform test: tiny images skip the trips they do not need)
         }
 #pragma unroll
         for (int t = 0; t < kTailTrips; ++t) {
@@ -353,14 +454,25 @@ PDWT_DEVICE void dwt2_inv_tail_image_p2(const TailArgs& a, int bz, real_t* smem)
     real_t* U = smem + n0;  // column-synthesis results (u1 | u2); [n0/4, n0/2): the details of the coarser levels until the last step
     real_t* fLo = smem + 2 * n0;
     real_t* fHi = fLo + kMaxTaps;
+    real_t** ptab = tail_ptr_table(smem, 2 * n0 + 2 * kMaxTaps);
     PDWT_FOR_THREADS(tid, NT) {
-        // three unrolled passes so that a thread's loads are in flight TOGETHER: the plane pointers (a lane-indexed read of the
-        // kernel arguments: memory loads), then the values, then the LDS stores.  Interleaved, the in-order load counter makes
-        // every pointer wait drain the data loads before it: sixteen round trips instead of two.
+        if (tid == 0)
+            for (int k = 0; k < a.K; ++k)
+                for (int b = 0; b < 3; ++b) ptab[3 * k + b] = a.det[k][b];
+        for (int j = tid; j < hlen; j += NT) {
+            fLo[j] = a.fb.lo[hlen - 1 - j];
+            fHi[j] = a.fb.hi[hlen - 1 - j];
+        }
+    }
+    PDWT_SYNC();
+    PDWT_FOR_THREADS(tid, NT) {
+        // three unrolled passes so that a thread's loads are in flight TOGETHER: the addresses (plane pointers out of the LDS
+        // table), then the values, then the LDS stores.
         const real_t* src[kTailTrips];
         real_t v[kTailTrips];
 #pragma unroll
         for (int t = 0; t < kTailTrips; ++t) {
+            if (t * NT >= n0) continue;  // (a uniform test: tiny images skip the trips they do not need)
             int f = tid + t * NT;
             f = f < n0 ? f : n0 - 1;
             if (f < sL) {
@@ -368,11 +480,12 @@ PDWT_DEVICE void dwt2_inv_tail_image_p2(const TailArgs& a, int bz, real_t* smem)
             } else {
                 const int m = tail_log4((unsigned)f >> lgsL), lgp = lgsL + 2 * m;  // plane size 2^lgp
                 const int g = f - (1 << lgp), b = g >> lgp, idx = g & ((1 << lgp) - 1);
-                src[t] = a.det[a.K - 1 - m][b] + ((long long)bz << lgp) + idx;
+                src[t] = ptab[3 * (a.K - 1 - m) + b] + ((long long)bz << lgp) + idx;
             }
         }
 #pragma unroll
-        for (int t = 0; t < kTailTrips; ++t) v[t] = *src[t];
+        for (int t = 0; t < kTailTrips; ++t)
+            if (t * NT < n0) v[t] = *src[t];
 #pragma unroll
         for (int t = 0; t < kTailTrips; ++t) {
             const int f = tid + t * NT;
@@ -381,12 +494,9 @@ PDWT_DEVICE void dwt2_inv_tail_image_p2(const TailArgs& a, int bz, real_t* smem)
                 else U[q0 + f] = v[t];
             }
         }
-        for (int j = tid; j < hlen; j += NT) {
-            fLo[j] = a.fb.lo[hlen - 1 - j];
-            fHi[j] = a.fb.hi[hlen - 1 - j];
-        }
     }
     PDWT_SYNC();
+    // pairs of outputs per work item, taps in registers: see dwt2_inv_tail_image
     for (int k = a.K - 1; k >= 0; --k) {
         const int lgri = a.lgR - k - 1, lgci = a.lgC - k - 1, ri = 1 << lgri, ci = 1 << lgci, lgco = lgci + 1;
         const int n_in = 1 << (lgri + lgci);  // = 4^(K-1-k) sL
@@ -396,41 +506,63 @@ PDWT_DEVICE void dwt2_inv_tail_image_p2(const TailArgs& a, int bz, real_t* smem)
         real_t* u1 = U;
         real_t* u2 = U + 2 * n_in;
         PDWT_FOR_THREADS(tid, NT) {  // column synthesis: (A, H) -> u1, (V, D) -> u2, (2 ri x ci) each
-            for (int idx = tid; idx < 2 * n_in; idx += NT) {
-                const int q = idx >> lgci, x = idx & (ci - 1);
-                const int p = q + S;
-                const int rel = (p >> 1) - C, par = 1 - (p & 1);
-                real_t r1 = 0, r2 = 0;
+            TailTaps<HLEN> f;
+            f.load(fLo, fHi);
+            for (int idx = tid; idx < n_in; idx += NT) {
+                const int m = idx >> lgci, x = idx & (ci - 1);
+                real_t e1 = 0, e2 = 0, o1 = 0, o2 = 0;
 #pragma unroll
-                for (int j = 0; j < H2; ++j) {
-                    const int t = 2 * j + par;  // reversed taps: f[hlen - 1 - t]
-                    const int src = (((rel + j) & (ri - 1)) << lgci) + x;
-                    r1 = pdwt_fma(X[src], fLo[t], r1);
-                    r1 = pdwt_fma(dH[src], fHi[t], r1);
-                    r2 = pdwt_fma(dV[src], fLo[t], r2);
-                    r2 = pdwt_fma(dD[src], fHi[t], r2);
+                for (int i = 0; i < H2 + S; ++i) {
+                    const int src = (((m - C + i) & (ri - 1)) << lgci) + x;
+                    const real_t vA = X[src], vH = dH[src], vV = dV[src], vD = dD[src];
+                    if (i < H2) {
+                        const int t = 2 * i + 1 - S;
+                        e1 = pdwt_fma(vA, f.l(t), e1);
+                        e1 = pdwt_fma(vH, f.h(t), e1);
+                        e2 = pdwt_fma(vV, f.l(t), e2);
+                        e2 = pdwt_fma(vD, f.h(t), e2);
+                    }
+                    if (i >= S) {
+                        const int t = 2 * (i - S) + S;
+                        o1 = pdwt_fma(vA, f.l(t), o1);
+                        o1 = pdwt_fma(vH, f.h(t), o1);
+                        o2 = pdwt_fma(vV, f.l(t), o2);
+                        o2 = pdwt_fma(vD, f.h(t), o2);
+                    }
                 }
-                u1[idx] = r1;
-                u2[idx] = r2;
+                const int o = (m << lgco) + x;  // row 2m of ci columns
+                u1[o] = e1;
+                u2[o] = e2;
+                u1[o + ci] = o1;
+                u2[o + ci] = o2;
             }
         }
         PDWT_SYNC();
         PDWT_FOR_THREADS(tid, NT) {  // row synthesis: (u1, u2) -> (2 ri x 2 ci), to LDS or (the last step) global
+            TailTaps<HLEN> f;
+            f.load(fLo, fHi);
             real_t* PDWT_RESTRICT gout = a.out + (long long)bz * 4 * n_in;
-            for (int idx = tid; idx < 4 * n_in; idx += NT) {
-                const int q = idx >> lgco, g = idx & (2 * ci - 1);
-                const int p = g + S;
-                const int rel = (p >> 1) - C, par = 1 - (p & 1);
-                real_t r = 0;
+            for (int idx = tid; idx < 2 * n_in; idx += NT) {
+                const int q = idx >> lgci, m = idx & (ci - 1);
+                real_t e = 0, od = 0;
 #pragma unroll
-                for (int j = 0; j < H2; ++j) {
-                    const int t = 2 * j + par;
-                    const int src = (q << lgci) + ((rel + j) & (ci - 1));
-                    r = pdwt_fma(u1[src], fLo[t], r);
-                    r = pdwt_fma(u2[src], fHi[t], r);
+                for (int i = 0; i < H2 + S; ++i) {
+                    const int src = (q << lgci) + ((m - C + i) & (ci - 1));
+                    const real_t v1 = u1[src], v2 = u2[src];
+                    if (i < H2) {
+                        const int t = 2 * i + 1 - S;
+                        e = pdwt_fma(v1, f.l(t), e);
+                        e = pdwt_fma(v2, f.h(t), e);
+                    }
+                    if (i >= S) {
+                        const int t = 2 * (i - S) + S;
+                        od = pdwt_fma(v1, f.l(t), od);
+                        od = pdwt_fma(v2, f.h(t), od);
+                    }
                 }
-                if (k == 0) gout[idx] = r;
-                else X[idx] = r;
+                real_t* dst = (k == 0 ? gout : X) + 2 * idx;  // (q, 2m) of 2 ci columns: an aligned pair
+                dst[0] = e;
+                dst[1] = od;
             }
         }
         PDWT_SYNC();

@@ -560,9 +560,9 @@ void build_schedule(pdwt_plan* p) {
             // (B x n^2, forward+inverse us: 4096 x 64^2 db4 L3 313 -> 121, 4096 x 32^2 db2 L3 453 -> 38, 1024 x 64^2 sym8 L2 198 -> 54;
             // 128 x 128 images only with five levels and more: 256 x 128^2 db2 L5 43.5 -> 29.5, but 1024 x 128^2 db4 L3 102 -> 136;
             // profiles/r04zc_small_batches.txt)
-            // Sizes need not be powers of two, only even through the levels the launch takes (28 x 28: two levels, 48 x 48: four, 100 x
-            // 100: two); levels beyond (an odd size) follow as level launches.  20000 x 28^2 db2 L2: 1286 us forward+inverse on the level
-            // kernels, ten times its power-of-two neighbour 16384 x 32^2.
+            // Any sizes (powers of two: the mask / shift kernels; the rest, odd sizes included: the general ones, sizes by ceil-halving
+            // like the level kernels).  20000 x 28^2 db2 L2: 1286 us forward+inverse on the level kernels, ten times its power-of-two
+            // neighbour 16384 x 32^2; with a third level (7 x 7 out of 14 x 14) the level kernels spent 700 of 920 us on that level alone.
             if (fusable && !no_tail && (per_image <= tail_batch || (per_image <= 4 * tail_batch && K >= 5)) &&
                 per_image * hlen <= 16 * tail_batch && samples(l) >= (1LL << 20)) {
                 const int Kb = dwt2_tail_max_levels(hlen, p->lr[l - 1], p->lc[l - 1], K);

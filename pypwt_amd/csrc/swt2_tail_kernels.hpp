@@ -23,6 +23,7 @@ namespace pdwt {
 constexpr int kSwtTailMaxLevels = 12;
 constexpr int kSwtTailMaxSamples = 4096;   // one image; the inverse keeps four planes of it in LDS
 constexpr int kSwtTailTrips = 16;          // values a thread stages per plane (256 threads x 16 = 4096)
+constexpr int kSwtTailWaveSamples = 256;  // largest image the one-wavefront launch (64 threads x 4 trips) takes
 
 struct SwtTailArgs {
     const real_t* in;                      // forward: the image; inverse: A_L
@@ -57,23 +58,26 @@ PDWT_DEVICE int swt_tail_tap(int x, int j, int c, int d, const int* off, int n) 
     return POW2 ? ((x + (j - c) * d) & (n - 1)) : swt_tail_at(x, off[j], n);
 }
 
-// global plane -> LDS plane, all of a thread's loads in flight together (constant trip count, clamped index)
-template <int NT>
+// global plane -> LDS plane, all of a thread's loads in flight together (a compile-time trip count TR with NT x TR >= the image's
+// samples, clamped index: the launcher picks 16 or 4 trips.  Skipping unneeded trips by a uniform run-time test instead made the
+// 256-thread inverse 15-25 % slower: 16384 x 32^2 haar L3 inverse 208 -> 257 us.)
+template <int NT, int kTrips>
 PDWT_DEVICE void swt_tail_stage(int tid, const real_t* PDWT_RESTRICT src, real_t* dst, int n, real_t beta) {
-    real_t v[kSwtTailTrips];
+    static_assert(kTrips >= 1 && kTrips <= kSwtTailTrips, "trips");
+    real_t v[kTrips];
 #pragma unroll
-    for (int t = 0; t < kSwtTailTrips; ++t) {
+    for (int t = 0; t < kTrips; ++t) {
         const int idx = tid + t * NT;
         v[t] = src[idx < n ? idx : n - 1];
     }
 #pragma unroll
-    for (int t = 0; t < kSwtTailTrips; ++t) {
+    for (int t = 0; t < kTrips; ++t) {
         const int idx = tid + t * NT;
         if (idx < n) dst[idx] = soft_shrink(v[t], beta);
     }
 }
 
-template <int NT, bool POW2>
+template <int NT, bool POW2, int TR = kSwtTailTrips>
 PDWT_DEVICE void swt2_fwd_tail_image(const SwtTailArgs& a, int bz, real_t* smem) {
     const int hlen = a.hlen, c = analysis_centre(hlen);
     const int C = a.C, R = a.R, n = R * C;
@@ -85,7 +89,7 @@ PDWT_DEVICE void swt2_fwd_tail_image(const SwtTailArgs& a, int bz, real_t* smem)
     int* offX = reinterpret_cast<int*>(fHi + kMaxTaps);
     int* offY = offX + kMaxTaps;
     PDWT_FOR_THREADS(tid, NT) {
-        swt_tail_stage<NT>(tid, a.in + (long long)bz * n, cur, n, (real_t)0);
+        swt_tail_stage<NT, TR>(tid, a.in + (long long)bz * n, cur, n, (real_t)0);
         for (int j = tid; j < hlen; j += NT) {  // reversed: tap j of the window multiplies f[hlen - 1 - j]
             fLo[j] = a.fb.lo[hlen - 1 - j];
             fHi[j] = a.fb.hi[hlen - 1 - j];
@@ -145,7 +149,7 @@ PDWT_DEVICE void swt2_fwd_tail_image(const SwtTailArgs& a, int bz, real_t* smem)
 
 // Inverse of one level out of four LDS planes X (A, then the result), P, U1, U2:
 //   V -> P;  U1 = 1/2 (Lx(X) + Hx(P));  H -> P, D -> X;  U2 = 1/2 (Lx(P) + Hx(X));  X = 1/2 (Ly(U1) + Hy(U2))
-template <int NT, bool POW2>
+template <int NT, bool POW2, int TR = kSwtTailTrips>
 PDWT_DEVICE void swt2_inv_tail_image(const SwtTailArgs& a, int bz, real_t* smem) {
     const int hlen = a.hlen, c = hlen / 2;  // synthesis centre
     const int C = a.C, R = a.R, n = R * C;
@@ -160,8 +164,8 @@ PDWT_DEVICE void swt2_inv_tail_image(const SwtTailArgs& a, int bz, real_t* smem)
     int* offY = offX + kMaxTaps;
     const long long b = (long long)bz * n;
     PDWT_FOR_THREADS(tid, NT) {
-        swt_tail_stage<NT>(tid, a.in + b, X, n, (real_t)0);
-        swt_tail_stage<NT>(tid, a.det[a.L - 1][1] + b, P, n, a.beta[a.L - 1]);  // V of the coarsest level
+        swt_tail_stage<NT, TR>(tid, a.in + b, X, n, (real_t)0);
+        swt_tail_stage<NT, TR>(tid, a.det[a.L - 1][1] + b, P, n, a.beta[a.L - 1]);  // V of the coarsest level
         for (int j = tid; j < hlen; j += NT) {
             fLo[j] = a.fb.lo[hlen - 1 - j];
             fHi[j] = a.fb.hi[hlen - 1 - j];
@@ -185,8 +189,8 @@ PDWT_DEVICE void swt2_inv_tail_image(const SwtTailArgs& a, int bz, real_t* smem)
         }
         PDWT_SYNC();
         PDWT_FOR_THREADS(tid, NT) {  // A and V are consumed: H -> P, D -> X
-            swt_tail_stage<NT>(tid, a.det[l - 1][0] + b, P, n, a.beta[l - 1]);
-            swt_tail_stage<NT>(tid, a.det[l - 1][2] + b, X, n, a.beta[l - 1]);
+            swt_tail_stage<NT, TR>(tid, a.det[l - 1][0] + b, P, n, a.beta[l - 1]);
+            swt_tail_stage<NT, TR>(tid, a.det[l - 1][2] + b, X, n, a.beta[l - 1]);
         }
         PDWT_SYNC();
         PDWT_FOR_THREADS(tid, NT) {  // U2 = 1/2 (Lx(H) + Hx(D))
@@ -215,7 +219,7 @@ PDWT_DEVICE void swt2_inv_tail_image(const SwtTailArgs& a, int bz, real_t* smem)
                 if (l == 1) gout[idx] = half * r;
                 else X[idx] = half * r;
             }
-            if (l > 1) swt_tail_stage<NT>(tid, a.det[l - 2][1] + b, P, n, a.beta[l - 2]);  // P (H) was consumed before the barrier
+            if (l > 1) swt_tail_stage<NT, TR>(tid, a.det[l - 2][1] + b, P, n, a.beta[l - 2]);  // P (H) was consumed before the barrier
         }
         PDWT_SYNC();
         if (!POW2 && l > 1) {  // the offsets of the next (finer) level, after every reader of this level's is done
@@ -226,22 +230,22 @@ PDWT_DEVICE void swt2_inv_tail_image(const SwtTailArgs& a, int bz, real_t* smem)
 }
 
 #ifndef PDWT_CPU_EMU
-template <int NT, bool POW2>
+template <int NT, bool POW2, int TR>
 __global__ void __launch_bounds__(NT) swt2_fwd_tail_kernel(const SwtTailArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char swt_tail_smem[];
-    swt2_fwd_tail_image<NT, POW2>(a, blockIdx.x, reinterpret_cast<real_t*>(swt_tail_smem));
+    swt2_fwd_tail_image<NT, POW2, TR>(a, blockIdx.x, reinterpret_cast<real_t*>(swt_tail_smem));
 }
-template <int NT, bool POW2>
+template <int NT, bool POW2, int TR>
 __global__ void __launch_bounds__(NT) swt2_inv_tail_kernel(const SwtTailArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char swt_tail_smem[];
-    swt2_inv_tail_image<NT, POW2>(a, blockIdx.x, reinterpret_cast<real_t*>(swt_tail_smem));
+    swt2_inv_tail_image<NT, POW2, TR>(a, blockIdx.x, reinterpret_cast<real_t*>(swt_tail_smem));
 }
 #endif
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // The power-of-two kernels as first written (mask / shift indexing), kept as their own functions: see dwt2_tail_kernels.hpp.
 // ---------------------------------------------------------------------------------------------------------------------------
-template <int NT>
+template <int NT, int TR = kSwtTailTrips>
 PDWT_DEVICE void swt2_fwd_tail_image_p2(const SwtTailArgs& a, int bz, real_t* smem) {
     const int hlen = a.hlen, c = analysis_centre(hlen);
     const int lgC = a.lgC, C = 1 << lgC, R = 1 << a.lgR, n = 1 << (a.lgR + a.lgC);
@@ -251,7 +255,7 @@ PDWT_DEVICE void swt2_fwd_tail_image_p2(const SwtTailArgs& a, int bz, real_t* sm
     real_t* fLo = smem + 3 * n;
     real_t* fHi = fLo + kMaxTaps;
     PDWT_FOR_THREADS(tid, NT) {
-        swt_tail_stage<NT>(tid, a.in + (long long)bz * n, cur, n, (real_t)0);
+        swt_tail_stage<NT, TR>(tid, a.in + (long long)bz * n, cur, n, (real_t)0);
         for (int j = tid; j < hlen; j += NT) {  // reversed: tap j of the window multiplies f[hlen - 1 - j]
             fLo[j] = a.fb.lo[hlen - 1 - j];
             fHi[j] = a.fb.hi[hlen - 1 - j];
@@ -306,7 +310,7 @@ PDWT_DEVICE void swt2_fwd_tail_image_p2(const SwtTailArgs& a, int bz, real_t* sm
 
 // Inverse of one level out of four LDS planes X (A, then the result), P, U1, U2:
 //   V -> P;  U1 = 1/2 (Lx(X) + Hx(P));  H -> P, D -> X;  U2 = 1/2 (Lx(P) + Hx(X));  X = 1/2 (Ly(U1) + Hy(U2))
-template <int NT>
+template <int NT, int TR = kSwtTailTrips>
 PDWT_DEVICE void swt2_inv_tail_image_p2(const SwtTailArgs& a, int bz, real_t* smem) {
     const int hlen = a.hlen, c = hlen / 2;  // synthesis centre
     const int lgC = a.lgC, C = 1 << lgC, R = 1 << a.lgR, n = 1 << (a.lgR + a.lgC);
@@ -319,8 +323,8 @@ PDWT_DEVICE void swt2_inv_tail_image_p2(const SwtTailArgs& a, int bz, real_t* sm
     real_t* fHi = fLo + kMaxTaps;
     const long long b = (long long)bz * n;
     PDWT_FOR_THREADS(tid, NT) {
-        swt_tail_stage<NT>(tid, a.in + b, X, n, (real_t)0);
-        swt_tail_stage<NT>(tid, a.det[a.L - 1][1] + b, P, n, a.beta[a.L - 1]);  // V of the coarsest level
+        swt_tail_stage<NT, TR>(tid, a.in + b, X, n, (real_t)0);
+        swt_tail_stage<NT, TR>(tid, a.det[a.L - 1][1] + b, P, n, a.beta[a.L - 1]);  // V of the coarsest level
         for (int j = tid; j < hlen; j += NT) {
             fLo[j] = a.fb.lo[hlen - 1 - j];
             fHi[j] = a.fb.hi[hlen - 1 - j];
@@ -343,8 +347,8 @@ PDWT_DEVICE void swt2_inv_tail_image_p2(const SwtTailArgs& a, int bz, real_t* sm
         }
         PDWT_SYNC();
         PDWT_FOR_THREADS(tid, NT) {  // A and V are consumed: H -> P, D -> X
-            swt_tail_stage<NT>(tid, a.det[l - 1][0] + b, P, n, a.beta[l - 1]);
-            swt_tail_stage<NT>(tid, a.det[l - 1][2] + b, X, n, a.beta[l - 1]);
+            swt_tail_stage<NT, TR>(tid, a.det[l - 1][0] + b, P, n, a.beta[l - 1]);
+            swt_tail_stage<NT, TR>(tid, a.det[l - 1][2] + b, X, n, a.beta[l - 1]);
         }
         PDWT_SYNC();
         PDWT_FOR_THREADS(tid, NT) {  // U2 = 1/2 (Lx(H) + Hx(D))
@@ -373,22 +377,22 @@ PDWT_DEVICE void swt2_inv_tail_image_p2(const SwtTailArgs& a, int bz, real_t* sm
                 if (l == 1) gout[idx] = half * r;
                 else X[idx] = half * r;
             }
-            if (l > 1) swt_tail_stage<NT>(tid, a.det[l - 2][1] + b, P, n, a.beta[l - 2]);  // P (H) was consumed before the barrier
+            if (l > 1) swt_tail_stage<NT, TR>(tid, a.det[l - 2][1] + b, P, n, a.beta[l - 2]);  // P (H) was consumed before the barrier
         }
         PDWT_SYNC();
     }
 }
 
 #ifndef PDWT_CPU_EMU
-template <int NT>
+template <int NT, int TR>
 __global__ void __launch_bounds__(NT) swt2_fwd_tail_p2_kernel(const SwtTailArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char swt_tail_smem[];
-    swt2_fwd_tail_image_p2<NT>(a, blockIdx.x, reinterpret_cast<real_t*>(swt_tail_smem));
+    swt2_fwd_tail_image_p2<NT, TR>(a, blockIdx.x, reinterpret_cast<real_t*>(swt_tail_smem));
 }
-template <int NT>
+template <int NT, int TR>
 __global__ void __launch_bounds__(NT) swt2_inv_tail_p2_kernel(const SwtTailArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char swt_tail_smem[];
-    swt2_inv_tail_image_p2<NT>(a, blockIdx.x, reinterpret_cast<real_t*>(swt_tail_smem));
+    swt2_inv_tail_image_p2<NT, TR>(a, blockIdx.x, reinterpret_cast<real_t*>(swt_tail_smem));
 }
 #endif
 

@@ -472,12 +472,12 @@ EMU_API int emu_dwt2_pyr3(int inverse, float* image, int batch, int N0r, int N0c
 }
 
 // ------------------------------------------------------------------ all remaining levels of a small approximation in one launch
-// det: H,V,D of the group's level 1 (3 x batch x R0/2 x C0/2), then of level 2, ...; app: A_K (batch x R0>>K x C0>>K)
-template <int HLEN, bool POW2>
+// det: H,V,D of the group's level 1 (3 x batch x ceil(R0/2) x ceil(C0/2)), then of level 2, ...; app: A_K (sizes by ceil-halving)
+template <int HLEN>
 static void run_tail_emu(const TailArgs& a, int batch, bool inverse, int threads, float* smem) {
     for (int bz = 0; bz < batch; bz++) {
-        if (inverse) { if (threads == 1024) dwt2_inv_tail_image<HLEN, 1024, POW2>(a, bz, smem); else dwt2_inv_tail_image<HLEN, 256, POW2>(a, bz, smem); }
-        else { if (threads == 1024) dwt2_fwd_tail_image<HLEN, 1024, POW2>(a, bz, smem); else dwt2_fwd_tail_image<HLEN, 256, POW2>(a, bz, smem); }
+        if (inverse) { if (threads == 1024) dwt2_inv_tail_image<HLEN, 1024>(a, bz, smem); else dwt2_inv_tail_image<HLEN, 256>(a, bz, smem); }
+        else { if (threads == 1024) dwt2_fwd_tail_image<HLEN, 1024>(a, bz, smem); else dwt2_fwd_tail_image<HLEN, 256>(a, bz, smem); }
     }
 }
 template <int HLEN>
@@ -490,27 +490,27 @@ static void run_tail_emu_p2(const TailArgs& a, int batch, bool inverse, int thre
 template <int HLEN>
 static void run_tail_emu2(const TailArgs& a, int batch, bool inverse, int threads, float* smem) {
     if (a.lgR >= 0 && a.lgC >= 0) run_tail_emu_p2<HLEN>(a, batch, inverse, threads, smem);  // the mask / shift kernels
-    else run_tail_emu<HLEN, false>(a, batch, inverse, threads, smem);                       // the general ones (unrolled == 2: also for powers of two)
+    else run_tail_emu<HLEN>(a, batch, inverse, threads, smem);                       // the general ones (unrolled == 2: also for powers of two)
 }
 EMU_API int emu_dwt2_tail(int inverse, float* image, int batch, int R0, int C0, int K, const float* lo, const float* hi, int hlen,
                           int threads, int unrolled, float* det, float* app) {
     auto lg2 = [](int v) { int lg = 0; while ((1 << lg) < v) lg++; return (1 << lg) == v ? lg : -1; };
     if ((hlen & 1) || K < 1 || K > kTailMaxLevels) return -2;
-    for (int k = 0; k < K; k++)
-        if (((R0 >> k) & 1) || ((C0 >> k) & 1)) return -2;
     if ((long long)R0 * C0 > kTailTrips * threads || (long long)R0 * C0 > kTailMaxSamples) return -2;
     TailArgs a;
+    a.R0 = R0; a.C0 = C0; a.lgR = lg2(R0); a.lgC = lg2(C0); a.K = K; a.hlen = hlen;
+    if (unrolled == 2) a.lgR = a.lgC = -1;  // power-of-two sizes through the general kernels too
+    const size_t lds = tail_geometry(a, inverse != 0);
+    if (lds * sizeof(float) > 160 * 1024) return -2;
     long long off = 0;
     for (int k = 0; k < kTailMaxLevels; k++) {
-        const long long n = k < K ? (long long)batch * (R0 >> (k + 1)) * (C0 >> (k + 1)) : 0;
+        const long long n = k < K ? (long long)batch * a.r[k + 1] * a.c[k + 1] : 0;
         for (int b = 0; b < 3; b++) { a.det[k][b] = k < K ? det + off : nullptr; off += n; }
     }
     a.in = inverse ? app : image;
     a.out = inverse ? image : app;
-    a.R0 = R0; a.C0 = C0; a.lgR = lg2(R0); a.lgC = lg2(C0); a.K = K; a.hlen = hlen;
-    if (unrolled == 2) a.lgR = a.lgC = -1;  // power-of-two sizes through the general instantiation too
     set_bank(a.fb, lo, hi, hlen);
-    std::vector<float> smem(tail_lds_elems(R0 * C0) + 64, NAN);
+    std::vector<float> smem((lds > tail_lds_elems(R0 * C0) ? lds : tail_lds_elems(R0 * C0)) + 64, NAN);
     if (unrolled && hlen <= 8) {
         switch (hlen) {
             case 2: run_tail_emu2<2>(a, batch, inverse != 0, threads, smem.data()); return 0;

@@ -358,14 +358,20 @@ def test_emu_dwt2_inv_pyramid(wname):
 def test_emu_dwt2_tail_of_all_remaining_levels(wname):
     """dwt2_fwd_tail_image / dwt2_inv_tail_image: one workgroup carries one image's approximation through every remaining level
     out of LDS -- down to 1 x 1 approximations, planes smaller than the filter (the wrap goes around more than once),
-    rectangular planes, a batch, both workgroup sizes, compile-time and run-time filter length."""
+    rectangular planes, odd sizes, a batch, both workgroup sizes, compile-time and run-time filter length."""
     hlen, dlo, dhi, rlo, rhi = oracle.filters(wname)
     for si, (B, shape, K) in enumerate([(1, (128, 128), 7), (1, (64, 64), 6), (2, (32, 64), 5), (1, (16, 16), 2), (3, (8, 8), 3),
                                         (1, (64, 256), 4), (1, (2, 2), 1), (1, (128, 32), 5), (2, (4, 64), 2), (1, (64, 64), 1),
                                         (2, (28, 28), 2), (1, (48, 96), 4), (1, (100, 100), 2), (3, (24, 40), 3), (1, (6, 10), 1),
-                                        (1, (56, 56), 3), (1, (120, 136), 3), (2, (32, 32), 5)]):
+                                        (1, (56, 56), 3), (1, (120, 136), 3), (2, (32, 32), 5),
+                                        # sizes that turn odd on the way down, or start odd (ceil-halving; 28 -> 14 -> 7 -> 4)
+                                        (2, (28, 28), 3), (1, (7, 7), 1), (1, (63, 65), 4), (1, (100, 100), 4), (3, (30, 50), 3),
+                                        (1, (127, 129), 3), (1, (5, 9), 2), (1, (3, 2), 1), (1, (90, 181), 5)]):
         x = oracle.hash_input((B,) + shape, 9100 + si)
-        dims = [(shape[0] >> k, shape[1] >> k) for k in range(1, K + 1)]
+        dims, rc = [], shape
+        for _ in range(K):
+            rc = ((rc[0] + 1) // 2, (rc[1] + 1) // 2)
+            dims.append(rc)
         ndet = sum(3 * B * r * c for r, c in dims)
         threads = 1024 if shape[0] * shape[1] > 4096 else (1024, 256)[si % 2]
         unrolled = 2 if si == 17 else int(si % 3 != 2)  # compile-time filter length (2-8 taps) / run-time; 2: a power-of-two size through the general (non-mask) instantiation

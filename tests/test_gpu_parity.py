@@ -754,7 +754,14 @@ def test_deep_plans_end_in_one_tail_launch(wname, shape, levels, batch, wide, ex
                                                       ("db4", (128, 128), 3, 70), ("db3", (64, 64), 1, 256), ("db4", (256, 256), 3, 20),
                                                       ("db2", (28, 28), 2, 1500), ("db4", (48, 48), 3, 500), ("haar", (96, 96), 5, 130),
                                                       ("db4", (100, 100), 3, 120), ("db2", (24, 40), 2, 1200), ("db3", (28, 28), 3, 1400),
-                                                      ("sym8", (56, 56), 1, 400), ("haar", (12, 20), 2, 5000)])
+                                                      ("sym8", (56, 56), 1, 400), ("haar", (12, 20), 2, 5000),
+                                                      # sizes that are or turn odd (28 -> 14 -> 7 -> 4): the same single launch
+                                                      ("db2", (28, 28), 3, 1400), ("haar", (28, 28), 4, 1400), ("db2", (30, 50), 3, 800),
+                                                      ("haar", (7, 9), 2, 17000), ("db4", (63, 65), 3, 300), ("haar", (100, 100), 6, 110),
+                                                      ("db3", (45, 37), 2, 700),
+                                                      # one wavefront per image: <= 256 samples from 2048 images, <= 1024 from 8192
+                                                      ("db2", (16, 16), 2, 4100), ("haar", (32, 32), 5, 8200), ("db2", (28, 28), 3, 8200),
+                                                      ("db4", (8, 16), 1, 8200), ("db3", (31, 33), 2, 8200)])
 def test_batches_of_small_images(wname, shape, levels, batch):
     """Large batches of tiny images (at least 2^20 samples in all): every image is ONE workgroup of the tail launch, whole transform out of
     LDS (64 x 64 and below; 128 x 128 with five levels and more), narrower tiles and no wave kernels on the levels that stay with
@@ -763,8 +770,9 @@ def test_batches_of_small_images(wname, shape, levels, batch):
     oracle.build()
     plan = BatchedWavelets(batch, shape[0], shape[1], wname, levels)
     L, sched = plan.levels, plan.schedule()
-    if shape[0] * shape[1] <= 4096 and batch * shape[0] * shape[1] >= (1 << 20) and shape[0] % 2 == 0 and shape[1] % 2 == 0:
-        assert sched.count("TAIL[1") == 2, sched  # sizes that are not powers of two too: 28 x 28, 48 x 48, 24 x 40 ...
+    n = shape[0] * shape[1]
+    if (n <= 4096 or (n <= 16384 and L >= 5)) and n * oracle.filters(wname)[0] <= 65536 and batch * n >= (1 << 20):
+        assert sched.count("TAIL[1-%d]" % L if L > 1 else "TAIL[1]") == 2, sched  # any sizes: 28 x 28, 48 x 48, 24 x 40, 7 x 9 ...
     plan.fill_hash(4242, 255.0)
     plan.forward()
     n = shape[0] * shape[1]
@@ -809,7 +817,10 @@ def test_batched_1d_short_rows_and_few_levels(wname, rows, n, levels):
 @pytest.mark.parametrize("wname,shape,levels,batch", [("haar", (64, 64), 3, 300), ("db2", (32, 32), 3, 1100), ("db4", (64, 64), 2, 260),
                                                       ("sym8", (32, 64), 1, 520), ("haar", (16, 16), 4, 4200), ("db3", (64, 32), 2, 600),
                                                       ("db4", (64, 64), 2, 100), ("db2", (28, 28), 2, 1500), ("haar", (48, 40), 3, 600),
-                                                      ("db4", (30, 30), 2, 1200), ("haar", (21, 33), 2, 1600), ("sym4", (60, 64), 2, 300)])
+                                                      ("db4", (30, 30), 2, 1200), ("haar", (21, 33), 2, 1600), ("sym4", (60, 64), 2, 300),
+                                                      # at most 256 samples, 2048 images and more: one wavefront per image
+                                                      ("db2", (12, 20), 2, 4500), ("haar", (8, 8), 2, 17000), ("db3", (16, 16), 1, 4100),
+                                                      ("haar", (15, 17), 3, 4200)])
 def test_swt_batches_of_tiny_images(wname, shape, levels, batch):
     """Large batches of tiny images through the undecimated transform: at least 2^20 samples in all -> the whole SWT of an image is
     ONE workgroup of one launch per direction (swt2_tail_kernels.hpp); the soft threshold is folded into the inverse.  First,
