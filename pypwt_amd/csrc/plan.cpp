@@ -563,10 +563,16 @@ void build_schedule(pdwt_plan* p) {
             // Any sizes (powers of two: the mask / shift kernels; the rest, odd sizes included: the general ones, sizes by ceil-halving
             // like the level kernels).  20000 x 28^2 db2 L2: 1286 us forward+inverse on the level kernels, ten times its power-of-two
             // neighbour 16384 x 32^2; with a third level (7 x 7 out of 14 x 14) the level kernels spent 700 of 920 us on that level alone.
-            if (fusable && !no_tail && (per_image <= tail_batch || (per_image <= 4 * tail_batch && K >= 5)) &&
-                per_image * hlen <= 16 * tail_batch && samples(l) >= (1LL << 20)) {
+            // Images of 4097 .. 16384 samples (one 1024-thread workgroup per CU): with five levels and more, or with three and more when
+            // the batch is at most a round and a half of the chip's 256 CUs -- 256 x 128^2 db2 L3 42.4 -> 25.0 us, 120 x 100^2 db4 L3
+            // 43.2 -> 33.7, 300 x 80x120 db2 L4 74.1 -> 40.9; larger batches keep the level kernels (1024 x 128^2 db4 L3 95 -> 118,
+            // 4096 x 128^2 db2 L4 278 -> 361; profiles/r04zs_tail_mid_images.txt)
+            const bool tiny = per_image <= tail_batch && per_image * hlen <= 16 * tail_batch;
+            const bool deep = per_image <= 4 * tail_batch && K >= 5 && per_image * hlen <= 16 * tail_batch;
+            const bool few = per_image <= 4 * tail_batch && K >= 3 && p->batch <= 384 && per_image * hlen <= 32 * tail_batch;
+            if (fusable && !no_tail && (tiny || deep || few) && samples(l) >= (1LL << 20)) {
                 const int Kb = dwt2_tail_max_levels(hlen, p->lr[l - 1], p->lc[l - 1], K);
-                if (Kb >= 1 && (per_image <= tail_batch || Kb >= 5)) return Kb;
+                if (Kb >= 1 && (tiny || (deep && Kb >= 5) || (few && Kb >= 3))) return Kb;
             }
             if (!fusable || no_tail || samples(l) > (1LL << 20) || per_image * hlen > (1LL << tail_work_log2)) return 0;
             if (K < tail_min_k && !(K >= tail_min_k - 1 && per_image <= 1024)) return 0;
