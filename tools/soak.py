@@ -60,12 +60,25 @@ def main():
     short = ["haar", "db2", "db3", "db4", "sym4", "bior2.2", "bior1.3", "sym5", "db6", "sym8", "coif2", "db10"]
     t0, done = time.time(), {}
     while time.time() - t0 < budget:
-        kind = str(rng.choice(["tiny-batch", "tiny-batch", "small-batch", "deep", "swt-mid", "swt-hd", "mid-batch", "swt-batch", "swt-tiny",
-                               "rows-1d", "rows-1d", "rows-swt1"]))
+        kinds = ["tiny-batch", "tiny-batch", "small-batch", "deep", "swt-mid", "swt-hd", "mid-batch", "swt-batch", "swt-tiny",
+                 "rows-1d", "rows-1d", "rows-swt1", "odd-batch", "odd-batch", "few-mid"]
+        if os.environ.get("SOAK_KINDS"):  # e.g. SOAK_KINDS=odd-batch,few-mid,swt-tiny
+            kinds = os.environ["SOAK_KINDS"].split(",")
+        kind = str(rng.choice(kinds))
         if kind == "tiny-batch":      # images <= 64 x 64 (+ some that are not powers of two), >= 2^20 samples
             r, c = int(rng.choice([8, 16, 32, 48, 64])), int(rng.choice([16, 32, 64, 40]))
             B = int((1 << 20) // (r * c) * rng.choice([1, 1, 2, 5])) + int(rng.integers(0, 7))
             done[kind] = done.get(kind, 0) + check(B, (r, c), str(rng.choice(short)), int(rng.integers(1, 7)), 0, rng, kind)
+        elif kind == "odd-batch":     # tiny images of ANY size (odd ones, sizes that turn odd on the way down), DWT and SWT; also the
+            # one-wavefront-per-image launches (<= 256 samples from 2048 images on, <= 1024 from 8192)
+            r, c = int(rng.integers(5, 66)), int(rng.integers(5, 66))
+            B = int((1 << 20) // (r * c) * rng.choice([1, 1, 2])) + int(rng.integers(1, 9))
+            swt = int(rng.integers(0, 3) == 0)
+            done[kind] = done.get(kind, 0) + check(B, (r, c), str(rng.choice(short)), int(rng.integers(1, 6 if not swt else 4)), swt, rng, kind)
+        elif kind == "few-mid":       # at most 384 images of 4097 .. 16384 samples, three levels and more: one tail launch
+            r, c = int(rng.choice([72, 96, 100, 127, 128, 90])), int(rng.choice([64, 100, 120, 128, 75]))
+            B = int((1 << 20) // (r * c)) + int(rng.integers(1, 200))
+            done[kind] = done.get(kind, 0) + check(B, (r, c), str(rng.choice(short[:8])), int(rng.integers(3, 7)), 0, rng, kind)
         elif kind == "swt-tiny":      # SWT of batches of tiny images (the whole transform of an image in one workgroup)
             r, c = int(rng.choice([4, 8, 16, 32, 64])), int(rng.choice([8, 16, 32, 64, 24]))
             B = int((1 << 20) // (r * c) * rng.choice([1, 1, 3])) + int(rng.integers(0, 5))
