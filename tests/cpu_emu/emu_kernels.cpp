@@ -476,15 +476,15 @@ EMU_API int emu_dwt2_pyr3(int inverse, float* image, int batch, int N0r, int N0c
 template <int HLEN>
 static void run_tail_emu(const TailArgs& a, int batch, bool inverse, int threads, float* smem) {
     for (int bz = 0; bz < batch; bz++) {
-        if (inverse) { if (threads == 1024) dwt2_inv_tail_image<HLEN, 1024>(a, bz, smem); else dwt2_inv_tail_image<HLEN, 256>(a, bz, smem); }
-        else { if (threads == 1024) dwt2_fwd_tail_image<HLEN, 1024>(a, bz, smem); else dwt2_fwd_tail_image<HLEN, 256>(a, bz, smem); }
+        if (inverse) { if (threads == 1024) dwt2_inv_tail_image<HLEN, 1024>(a, bz, smem); else if (threads == 64) dwt2_inv_tail_image<HLEN, 64>(a, bz, smem); else dwt2_inv_tail_image<HLEN, 256>(a, bz, smem); }
+        else { if (threads == 1024) dwt2_fwd_tail_image<HLEN, 1024>(a, bz, smem); else if (threads == 64) dwt2_fwd_tail_image<HLEN, 64>(a, bz, smem); else dwt2_fwd_tail_image<HLEN, 256>(a, bz, smem); }
     }
 }
 template <int HLEN>
 static void run_tail_emu_p2(const TailArgs& a, int batch, bool inverse, int threads, float* smem) {
     for (int bz = 0; bz < batch; bz++) {
-        if (inverse) { if (threads == 1024) dwt2_inv_tail_image_p2<HLEN, 1024>(a, bz, smem); else dwt2_inv_tail_image_p2<HLEN, 256>(a, bz, smem); }
-        else { if (threads == 1024) dwt2_fwd_tail_image_p2<HLEN, 1024>(a, bz, smem); else dwt2_fwd_tail_image_p2<HLEN, 256>(a, bz, smem); }
+        if (inverse) { if (threads == 1024) dwt2_inv_tail_image_p2<HLEN, 1024>(a, bz, smem); else if (threads == 64) dwt2_inv_tail_image_p2<HLEN, 64>(a, bz, smem); else dwt2_inv_tail_image_p2<HLEN, 256>(a, bz, smem); }
+        else { if (threads == 1024) dwt2_fwd_tail_image_p2<HLEN, 1024>(a, bz, smem); else if (threads == 64) dwt2_fwd_tail_image_p2<HLEN, 64>(a, bz, smem); else dwt2_fwd_tail_image_p2<HLEN, 256>(a, bz, smem); }
     }
 }
 template <int HLEN>
@@ -547,9 +547,19 @@ EMU_API int emu_swt2_tail(int inverse, float* image, int batch, int Nr, int Nc, 
     a.lgR = pow2 ? lgR : -1;
     const bool general = !pow2 || (beta && beta[0] < 0);  // (a negative first threshold: powers of two through the general kernels too)
     if (beta && beta[0] < 0) a.beta[0] = 0.f;
+    // the launcher's three shapes: 256 threads x 16 staging trips; 256 x 4 (images of at most 1024 samples); one wavefront x 4 (at most 256)
+    const int shape = n <= kSwtTailWaveSamples ? (batch & 1 ? 2 : 1) : (n <= 1024 ? (batch & 1) : 0);
     for (int bz = 0; bz < batch; bz++) {
-        if (inverse) { if (!general) swt2_inv_tail_image_p2<256>(a, bz, smem.data()); else swt2_inv_tail_image<256, false>(a, bz, smem.data()); }
-        else { if (!general) swt2_fwd_tail_image_p2<256>(a, bz, smem.data()); else swt2_fwd_tail_image<256, false>(a, bz, smem.data()); }
+        if (shape == 2) {
+            if (inverse) { if (!general) swt2_inv_tail_image_p2<64, 4>(a, bz, smem.data()); else swt2_inv_tail_image<64, false, 4>(a, bz, smem.data()); }
+            else { if (!general) swt2_fwd_tail_image_p2<64, 4>(a, bz, smem.data()); else swt2_fwd_tail_image<64, false, 4>(a, bz, smem.data()); }
+        } else if (shape == 1) {
+            if (inverse) { if (!general) swt2_inv_tail_image_p2<256, 4>(a, bz, smem.data()); else swt2_inv_tail_image<256, false, 4>(a, bz, smem.data()); }
+            else { if (!general) swt2_fwd_tail_image_p2<256, 4>(a, bz, smem.data()); else swt2_fwd_tail_image<256, false, 4>(a, bz, smem.data()); }
+        } else {
+            if (inverse) { if (!general) swt2_inv_tail_image_p2<256>(a, bz, smem.data()); else swt2_inv_tail_image<256, false>(a, bz, smem.data()); }
+            else { if (!general) swt2_fwd_tail_image_p2<256>(a, bz, smem.data()); else swt2_fwd_tail_image<256, false>(a, bz, smem.data()); }
+        }
     }
     return 0;
 }

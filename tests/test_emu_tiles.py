@@ -374,6 +374,8 @@ def test_emu_dwt2_tail_of_all_remaining_levels(wname):
             dims.append(rc)
         ndet = sum(3 * B * r * c for r, c in dims)
         threads = 1024 if shape[0] * shape[1] > 4096 else (1024, 256)[si % 2]
+        if shape[0] * shape[1] <= 1024 and si % 3 == 0:
+            threads = 64  # one wavefront per image (large batches of tiny images)
         unrolled = 2 if si == 17 else int(si % 3 != 2)  # compile-time filter length (2-8 taps) / run-time; 2: a power-of-two size through the general (non-mask) instantiation
         det = np.full(ndet, np.nan, dtype=np.float32)
         app = np.full((B,) + dims[-1], np.nan, dtype=np.float32)
@@ -416,7 +418,10 @@ def test_emu_swt2_tail_whole_transform_of_tiny_images(wname):
     batch, the soft threshold folded into the inverse's staging."""
     hlen, dlo, dhi, rlo, rhi = oracle.filters(wname)
     for si, (B, shape, L) in enumerate([(1, (64, 64), 3), (2, (32, 64), 4), (3, (16, 16), 2), (1, (8, 32), 5), (1, (64, 16), 1), (2, (4, 4), 2),
-                                        (2, (28, 28), 2), (1, (48, 40), 3), (1, (7, 9), 2), (1, (63, 65), 3), (2, (20, 12), 4)]):
+                                        (2, (28, 28), 2), (1, (48, 40), 3), (1, (7, 9), 2), (1, (63, 65), 3), (2, (20, 12), 4),
+                                        # (the emulation runs 256 threads x 4 trips for even batches of <= 1024 samples, one wavefront x 4 trips for odd
+                                        # batches of <= 256 samples: the launcher's other two shapes)
+                                        (3, (16, 16), 3), (1, (12, 20), 2), (1, (8, 8), 2), (3, (15, 17), 2), (1, (32, 32), 2), (3, (28, 28), 1)]):
         x = oracle.hash_input((B,) + shape, 9300 + si)
         n = shape[0] * shape[1]
         det = np.full(3 * L * B * n, np.nan, dtype=np.float32)
