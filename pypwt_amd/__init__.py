@@ -8,7 +8,7 @@ include/pypwt_amd.h, built by `python -m pypwt_amd.build`; `Wavelets64` binds th
 libpypwt_amd_f64.so).  There is no CPU fallback.
 """
 from .sharded import ShardedBatch, partition_images  # noqa: F401
-from .wavelets import BatchedWavelets, DeviceArray, Wavelets, Wavelets64  # noqa: F401
+from .wavelets import BatchedWavelets, BatchedWavelets64, DeviceArray, Wavelets, Wavelets64  # noqa: F401
 
 
 

@@ -512,13 +512,17 @@ class BatchedWavelets(object):
     (``fill_hash``) so large batches never cross PCIe.
     """
 
+    _dtype = np.float32
+    _variant = "f32"
+    _single = Wavelets   # the one-image class of the same build (array checks)
+
     def __init__(self, batch, Nr, Nc, wname, levels, do_swt=0, ndim=2, device=-1, stream=None, img=None):
-        self._lib = _lib.load()
+        self._lib = _lib.load(self._variant)
         self._h = None
         h = handle_t()
         ptr = None
         if img is not None:
-            img = Wavelets._checkarray(np.asarray(img), (batch, Nr, Nc))
+            img = self._single._checkarray(np.asarray(img), (batch, Nr, Nc))
             ptr = _ptr(img)
         rc = self._lib.pdwt_create_batched(ptr, int(batch), int(Nr), int(Nc), wname.encode("ASCII"), int(levels),
                                            1, 1, 0, int(do_swt), int(ndim), int(device),
@@ -544,13 +548,13 @@ class BatchedWavelets(object):
         check(self._lib.pdwt_soft_threshold(self._h, float(beta), int(do_threshold_appcoeffs), int(normalize)))
 
     def set_image(self, img):
-        img = Wavelets._checkarray(np.asarray(img), (self.batch, self.Nr, self.Nc))
+        img = self._single._checkarray(np.asarray(img), (self.batch, self.Nr, self.Nc))
         check(self._lib.pdwt_set_image(self._h, _ptr(img), 0))
 
     def coeff(self, num):
         rows, cols = C.c_int(), C.c_int()
         n = check(int(self._lib.pdwt_coeff_count(self._h, int(num), C.byref(rows), C.byref(cols))))
-        out = np.zeros((self.batch, rows.value, cols.value), dtype=np.float32)
+        out = np.zeros((self.batch, rows.value, cols.value), dtype=self._dtype)
         got = self._lib.pdwt_get_coeff(self._h, _ptr(out), int(num))
         if got != n:
             raise RuntimeError("BatchedWavelets.coeff(%d): expected %d, got %d (%s)" % (num, n, got, _lib.last_error(self._lib)))
@@ -560,7 +564,7 @@ class BatchedWavelets(object):
         """Sub-band `num` of ONE image of the batch (a 128-image shard does not fit a host array per band)."""
         rows, cols = C.c_int(), C.c_int()
         check(int(self._lib.pdwt_coeff_count(self._h, int(num), C.byref(rows), C.byref(cols))))
-        out = np.zeros((rows.value, cols.value), dtype=np.float32)
+        out = np.zeros((rows.value, cols.value), dtype=self._dtype)
         got = self._lib.pdwt_get_coeff_at(self._h, _ptr(out), int(num), int(image_index))
         if got != out.size:
             raise RuntimeError("BatchedWavelets.coeff_at(%d, %d): expected %d, got %d (%s)"
@@ -568,7 +572,7 @@ class BatchedWavelets(object):
         return out
 
     def image_at(self, image_index):
-        out = np.zeros((self.Nr, self.Nc), dtype=np.float32)
+        out = np.zeros((self.Nr, self.Nc), dtype=self._dtype)
         got = self._lib.pdwt_get_image_at(self._h, _ptr(out), int(image_index))
         if got != out.size:
             raise RuntimeError("BatchedWavelets.image_at(%d): expected %d, got %d (%s)"
@@ -576,13 +580,13 @@ class BatchedWavelets(object):
         return out
 
     def norm2sq(self):
-        out = C.c_float()
+        out = self._lib.pdwt_real()
         check(self._lib.pdwt_norm2sq(self._h, C.byref(out)))
         return float(out.value)
 
     @property
     def image(self):
-        out = np.zeros((self.batch, self.Nr, self.Nc), dtype=np.float32)
+        out = np.zeros((self.batch, self.Nr, self.Nc), dtype=self._dtype)
         got = self._lib.pdwt_get_image(self._h, _ptr(out))
         if got != out.size:
             raise RuntimeError("BatchedWavelets.image: expected %d, got %d (%s)" % (out.size, got, _lib.last_error(self._lib)))
@@ -641,3 +645,10 @@ class BatchedWavelets(object):
             self.cleanup()
         except Exception:
             pass
+
+
+class BatchedWavelets64(BatchedWavelets):
+    """`BatchedWavelets` over the fp64 build of the library (float64 images and coefficients)."""
+    _dtype = np.float64
+    _variant = "f64"
+    _single = Wavelets64

@@ -594,6 +594,30 @@ def test_fp64_build_matches_the_fp64_oracle(wname, shape, levels, ndim, swt):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("wname,shape,levels,batch,swt", [("db2", (28, 28), 3, 1400, 0), ("haar", (12, 20), 2, 4500, 0), ("db3", (64, 64), 3, 300, 0),
+                                                          ("haar", (15, 17), 2, 4200, 1), ("db2", (32, 32), 2, 1100, 1), ("db4", (72, 100), 3, 160, 0)])
+def test_fp64_batches_of_small_images(wname, shape, levels, batch, swt):
+    """The tail launches of the fp64 library in batch mode (any sizes, one wavefront per tiny image, few mid-size images): first, middle
+    and last image against the fp64 oracle, then the reconstruction."""
+    from pypwt_amd import BatchedWavelets64
+    n = shape[0] * shape[1]
+    x = oracle.hash_input((batch,) + shape, 991, scale=255.0).astype(np.float64)
+    x += 1e-9 * (np.arange(x.size) % 1000).reshape(x.shape)
+    plan = BatchedWavelets64(batch, shape[0], shape[1], wname, levels, do_swt=swt, img=x)
+    assert "TAIL[1" in plan.schedule(), plan.schedule()
+    plan.forward()
+    for b in sorted({0, batch // 2, batch - 1}):
+        ref = oracle.forward(x[b], wname, plan.levels, do_swt=swt, double="full")
+        for num, r in enumerate(ref):
+            g = plan.coeff_at(num, b)
+            assert g.dtype == np.float64 and np.abs(g - r).max() <= 1e-12 * max(1.0, float(np.abs(r).max())), (wname, b, num)
+    plan.inverse()
+    for b in sorted({0, batch // 2, batch - 1}):
+        assert np.abs(plan.image_at(b) - x[b]).max() <= 1e-11 * 255, (wname, b)
+    plan.cleanup()
+
+
+@pytest.mark.gpu
 def test_fp64_roundtrip_is_exact_to_double_precision_and_ops_work():
     from pypwt_amd import Wavelets64
     x = oracle.hash_input((256, 256), 31, scale=255.0).astype(np.float64)
