@@ -1,5 +1,6 @@
 // launch_dwt1_fused.hip -- launchers of the multi-level fused 1D DWT kernels (gfx950).
 #include "dwt1_fused_kernels.hpp"
+#include "dwt1_rows_kernels.hpp"
 #include "launch.hpp"
 #include "launch_util.hpp"
 
@@ -69,6 +70,43 @@ static hipError_t run_inv_rows(const Inv1DFusedArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
+// Short rows in large batches (>= 2^20 samples): several rows per one-wavefront workgroup, all levels out of LDS
+// (dwt1_rows_kernels.hpp).  Forward+inverse us, one row per wavefront -> this (tools/ab_rows_tail.sh, profiles/r04zv_rows_tail.txt):
+// 65536 x 64 haar L3 81 -> 33, db4 110 -> 51, 262144 x 64 haar 307 -> 90, 131072 x 32 db2 L2 142 -> 34; rows of 128 samples up to 8
+// taps (32768 x 128 db2 L4 72 -> 44; sym8 level, db10 31 -> 38); rows of 256 samples with 2 taps only (16384 x 256 haar L5 54 -> 39;
+// db4 L3 35 -> 51); rows of 512: behind everywhere.
+// PDWT_ROWS_TAIL_ROW = longest such row (0 = never), PDWT_ROWS_TAIL_SAMPLES = samples per workgroup (A/B measurements).
+static bool rows_tail(int rows, int N0, int K, int hlen) {
+    static const int max_row = getenv("PDWT_ROWS_TAIL_ROW") ? atoi(getenv("PDWT_ROWS_TAIL_ROW")) : 256;
+    static const bool forced = getenv("PDWT_ROWS_TAIL_ROW") != nullptr;  // the knob set: every filter up to that row length
+    if (N0 > max_row || N0 > kRowsTailSamples || K > kRowsTailMaxLevels || hlen > 20 || (long long)rows * N0 < (1LL << 20)) return false;
+    return forced || N0 <= 64 || (N0 <= 128 && hlen <= 8) || (N0 <= 256 && hlen <= 2);
+}
+template <int HLEN>
+static hipError_t run_rows_tail(RowsTailArgs& a, bool inverse, hipStream_t s) {
+    static const int samples = getenv("PDWT_ROWS_TAIL_SAMPLES") ? atoi(getenv("PDWT_ROWS_TAIL_SAMPLES")) : kRowsTailSamples;
+    constexpr int NT = 64;
+    int G = (samples < kRowsTailSamples ? samples : kRowsTailSamples) / a.N0;
+    a.G = G < 1 ? 1 : G;
+    const size_t lds = rows_tail_lds_elems(a.G * a.N0) * sizeof(real_t);
+    const unsigned grid = (unsigned)cdiv(a.rows, a.G);
+    if (inverse) hipLaunchKernelGGL((dwt1_rows_tail_inv_kernel<HLEN, NT>), dim3(grid), dim3(NT), lds, s, a);
+    else hipLaunchKernelGGL((dwt1_rows_tail_fwd_kernel<HLEN, NT>), dim3(grid), dim3(NT), lds, s, a);
+    return hipGetLastError();
+}
+static hipError_t launch_rows_tail(const float* in, float* const* det, float* out, int rows, int N0, int K, int hlen, bool inverse,
+                                   const FilterBank& fb, hipStream_t s) {
+    RowsTailArgs a;
+    a.in = in; a.out = out; a.rows = rows; a.N0 = N0; a.K = K; a.G = 1; a.hlen = hlen; a.fb = fb;
+    for (int k = 0; k < kRowsTailMaxLevels; k++) a.det[k] = k < K ? det[k] : nullptr;
+    switch (hlen) {
+#define X(h) case h: if constexpr (h <= 20) return run_rows_tail<h>(a, inverse, s); break;
+        PDWT_EVEN_HLENS(X)
+#undef X
+    }
+    return hipErrorNotSupported;
+}
+
 // ONE predicate for planner (plan.cpp) and launchers: K consecutive levels starting from a row of N0
 // samples can run fused iff hlen is even, 2^(K+2) divides N0 (every level length even, every band row
 // 16-B aligned) and N0 < 2^30 (32-bit tile arithmetic)
@@ -85,6 +123,10 @@ hipError_t launch_dwt1_fwd_fused(const float* in, float* const* det, float* app,
     a.in = in; a.app = app; a.rows = rows; a.N0 = N0; a.K = K;
     for (int k = 0; k < kMaxFusedLevels; k++) a.det[k] = k < K ? det[k] : nullptr;
     interleave(a.fb, fb);
+    if (rows_tail(rows, N0, K, hlen)) {
+        const hipError_t e = launch_rows_tail(in, det, app, rows, N0, K, hlen, false, fb, s);
+        if (e != hipErrorNotSupported) return e;
+    }
     // TF = 64 final-level outputs per workgroup at K = 6 (TF = 128 measured 25 % slower on 2^24 sym8 L6: 55 KB of LDS leaves 2
     // workgroups per CU), i.e. a segment of 64 * 2^K = 4096 input samples.  With FEWER levels the segment of TF = 64 shrinks
     // to 512 samples at K = 3 -- two per thread, 32768 workgroups for 4096 rows of 4096: the forward took 55-65 us where the
@@ -127,6 +169,10 @@ hipError_t launch_dwt1_inv_fused(const float* app, const float* const* det, floa
     a.app = app; a.out = out; a.rows = rows; a.N0 = N0; a.K = K;
     for (int k = 0; k < kMaxFusedLevels; k++) a.det[k] = k < K ? det[k] : nullptr;
     interleave(a.fb, fb);
+    if (rows_tail(rows, N0, K, hlen)) {
+        const hipError_t e = launch_rows_tail(app, const_cast<float* const*>(det), out, rows, N0, K, hlen, true, fb, s);
+        if (e != hipErrorNotSupported) return e;
+    }
     if (short_rows(N0) && hlen <= 20) {
         switch (hlen) {
 #define X(h) case h: if constexpr (h <= 20) return run_inv_rows<h>(a, s); break;

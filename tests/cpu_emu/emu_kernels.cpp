@@ -10,6 +10,7 @@
 #include "../../pypwt_amd/csrc/dwt1_fused_kernels.hpp"
 #include "../../pypwt_amd/csrc/dwt1_kernels.hpp"
 #include "../../pypwt_amd/csrc/dwt1_reg_kernels.hpp"
+#include "../../pypwt_amd/csrc/dwt1_rows_kernels.hpp"
 #include "../../pypwt_amd/csrc/swt2_fused_kernels.hpp"
 #include "../../pypwt_amd/csrc/swt2_fused4_kernels.hpp"
 #include "../../pypwt_amd/csrc/dwt2_fast_kernels.hpp"
@@ -520,6 +521,41 @@ EMU_API int emu_dwt2_tail(int inverse, float* image, int batch, int R0, int C0, 
         }
     }
     run_tail_emu2<0>(a, batch, inverse != 0, threads, smem.data());
+    return 0;
+}
+
+// ------------------------------------------------------------------ all levels of G short rows per one-wavefront workgroup
+// data: forward input / inverse output (rows x N0); det: D_1 (rows x N0/2), D_2, ...; app: A_K
+template <int HLEN>
+static void run_rows_tail_emu(const RowsTailArgs& a, bool inverse, float* smem) {
+    const int blocks = (a.rows + a.G - 1) / a.G;
+    for (int b = 0; b < blocks; b++) {
+        if (inverse) dwt1_rows_tail_inv<HLEN, 64>(a, b, smem);
+        else dwt1_rows_tail_fwd<HLEN, 64>(a, b, smem);
+    }
+}
+EMU_API int emu_dwt1_rows_tail(int inverse, float* data, int rows, int N0, int K, int G, const float* lo, const float* hi, int hlen,
+                               int unrolled, float* det, float* app) {
+    if ((hlen & 1) || K < 1 || K > kRowsTailMaxLevels || G < 1 || G * N0 > kRowsTailSamples || (N0 % (1 << K))) return -2;
+    RowsTailArgs a;
+    long long off = 0;
+    for (int k = 0; k < kRowsTailMaxLevels; k++) {
+        a.det[k] = k < K ? det + off : nullptr;
+        if (k < K) off += (long long)rows * (N0 >> (k + 1));
+    }
+    a.in = inverse ? app : data;
+    a.out = inverse ? data : app;
+    a.rows = rows; a.N0 = N0; a.K = K; a.G = G; a.hlen = hlen;
+    set_bank(a.fb, lo, hi, hlen);
+    std::vector<float> smem(rows_tail_lds_elems(G * N0) + 64, NAN);
+    if (unrolled && hlen <= 20) {
+        switch (hlen) {
+#define X(h) case h: run_rows_tail_emu<h>(a, inverse != 0, smem.data()); return 0;
+            X(2) X(4) X(6) X(8) X(10) X(12) X(14) X(16) X(18) X(20)
+#undef X
+        }
+    }
+    run_rows_tail_emu<0>(a, inverse != 0, smem.data());
     return 0;
 }
 

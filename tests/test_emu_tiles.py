@@ -315,6 +315,40 @@ def test_emu_dwt1_fused_pyramid(wname):
             assert np.abs(out - want).max() <= _tol(want) * (1 + K), (wname, rows, N0, K, small)
 
 
+# ----------------------------------------------------------------------------- short rows: several rows per wavefront, all levels
+@pytest.mark.parametrize("wname", ["haar", "db2", "db3", "db4", "sym8", "db10", "bior3.1"])
+def test_emu_dwt1_rows_tail(wname):
+    """dwt1_rows_tail_fwd / _inv: G consecutive rows per one-wavefront workgroup through every level out of LDS -- a last group with
+    fewer rows, levels shorter than the filter (the wrap goes around more than once), compile-time and run-time filter length."""
+    hlen, dlo, dhi, rlo, rhi = oracle.filters(wname)
+    for si, (rows, N0, K, G) in enumerate([(37, 64, 3, 16), (5, 128, 4, 8), (9, 256, 5, 4), (3, 32, 2, 32), (70, 16, 2, 7), (4, 512, 6, 2),
+                                           (33, 64, 4, 16), (2, 1024, 8, 1), (11, 96, 3, 10)]):
+        if N0 % (1 << (K + 2)):
+            continue
+        x = oracle.hash_input((rows, N0), 7300 + si)
+        ref = oracle.forward(x, wname, K, ndim=1)  # [A_K, D_1, ..., D_K]
+        ndet = sum(rows * (N0 >> k) for k in range(1, K + 1))
+        unrolled = si % 2
+        det = np.full(ndet, np.nan, dtype=np.float32)
+        app = np.full((rows, N0 >> K), np.nan, dtype=np.float32)
+        assert lib().emu_dwt1_rows_tail(0, P(x.copy()), rows, N0, K, G, P(dlo), P(dhi), hlen, unrolled, P(det), P(app)) == 0
+        assert np.abs(app - ref[0]).max() <= _tol(ref[0]) * (1 + K), (wname, rows, N0, K)
+        off = 0
+        for k in range(1, K + 1):
+            n = rows * (N0 >> k)
+            got = det[off:off + n].reshape(rows, N0 >> k)
+            off += n
+            assert np.isfinite(got).all(), (wname, N0, K, k)
+            assert np.abs(got - ref[k]).max() <= _tol(ref[k]) * (1 + K), (wname, rows, N0, K, k)
+        bands = [oracle.hash_input(b.shape, 7400 + 9 * si + i, 2.0) - 1.0 for i, b in enumerate(ref)]
+        want = oracle.inverse(bands, (rows, N0), wname, K, ndim=1)
+        det_in = np.concatenate([b.ravel() for b in bands[1:]]).astype(np.float32)
+        out = np.full((rows, N0), np.nan, dtype=np.float32)
+        assert lib().emu_dwt1_rows_tail(1, P(out), rows, N0, K, G, P(rlo), P(rhi), hlen, unrolled, P(det_in), P(bands[0].astype(np.float32))) == 0
+        assert np.isfinite(out).all(), (wname, N0, K)
+        assert np.abs(out - want).max() <= _tol(want) * (1 + K), (wname, rows, N0, K)
+
+
 # ----------------------------------------------------------------------------- two-level pyramid
 @pytest.mark.parametrize("wname", ["haar", "db2", "db3", "db4", "sym4", "bior3.1", "db5", "coif2", "db7", "sym8"])
 def test_emu_dwt2_fwd_pyramid(wname):
