@@ -8,8 +8,10 @@
 // microsecond.  Here ONE workgroup per image keeps the approximation in LDS and walks through every remaining level:
 // row pass -> (L | H) planes in a second LDS buffer -> column pass -> the next approximation back into the first buffer,
 // details straight to global memory.  The inverse fetches the coarsest approximation and the details of ALL its levels in one
-// batch of loads up front (together exactly R0 x C0 values: one global-memory round trip for the whole launch, not one per
-// level) and then walks back up out of LDS.
+// batch of loads up front (together exactly R0 x C0 values when every size is even: one global-memory round trip for the whole
+// launch, not one per level; the planes' addresses come from a table in LDS, see tail_ptr_table) and then walks back up out of LDS,
+// a work item producing a pair of outputs.  Workgroups of 1024 / 256 threads, or ONE wavefront per image for large batches of tiny
+// images (launch_dwt2_tail.hip).
 // No halo, no tile geometry: the whole plane is resident.  Power-of-two sizes: the periodic wrap is a mask and the index
 // split a shift (the _p2 kernels); any other size, odd ones included (sizes by ceil-halving, the analysis repeats the last sample
 // of an odd length, the synthesis drops it): conditional wrap + division (the general kernels).
@@ -17,7 +19,7 @@
 // w_forward_separable / w_inverse_separable (:179-236, :332-395); index conventions as in oracle/pdwt_oracle.c
 // (analysis centre hlen/2 - 1; polyphase synthesis with h2 = hlen/2, c = h2/2, s = 1 - (h2 & 1)).
 // Written over real_t; HLEN = 0 is the run-time filter length (every even length), 2-8 are unrolled.  The taps are copied
-// to LDS once.  CPU emulation (tests/cpu_emu): PDWT_FOR_THREADS / PDWT_SYNC as in the other LDS kernels.
+// to LDS once (unrolled lengths: and from there into registers, TailTaps).  CPU emulation (tests/cpu_emu): PDWT_FOR_THREADS / PDWT_SYNC as in the other LDS kernels.
 #pragma once
 
 #include "kernels_common.hpp"
@@ -25,7 +27,8 @@
 namespace pdwt {
 
 constexpr int kTailMaxLevels = 14;
-// samples of one image entering the first level of the group: two buffers of that size + the taps must fit 160 KB
+// samples of one image entering the first level of the group: the LDS planes of tail_geometry (two of that size for even sizes)
+// + the taps must fit 160 KB
 constexpr int kTailMaxSamples = sizeof(real_t) == 4 ? 16384 : 8192;
 constexpr int kTailTrips = 16;  // values a thread stages: the launcher picks NT with R0 x C0 <= kTailTrips x NT
 // the inverse keeps its 3 K plane pointers in LDS (behind the taps, 8-byte aligned): elements of real_t that takes
