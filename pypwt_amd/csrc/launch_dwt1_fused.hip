@@ -70,16 +70,20 @@ static hipError_t run_inv_rows(const Inv1DFusedArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
-// Short rows in large batches (>= 2^20 samples): several rows per one-wavefront workgroup, all levels out of LDS
+// Short rows in batches of >= 2^16 samples: several rows per one-wavefront workgroup (1024 samples; fewer rows while the batch is too
+// small for 2048 wavefronts), all levels out of LDS
 // (dwt1_rows_kernels.hpp).  Forward+inverse us, one row per wavefront -> this (tools/ab_rows_tail.sh, profiles/r04zv_rows_tail.txt):
 // 65536 x 64 haar L3 81 -> 33, db4 110 -> 51, 262144 x 64 haar 307 -> 90, 131072 x 32 db2 L2 142 -> 34; rows of 128 samples up to 8
 // taps (32768 x 128 db2 L4 72 -> 44; sym8 level, db10 31 -> 38); rows of 256 samples with 2 taps only (16384 x 256 haar L5 54 -> 39;
 // db4 L3 35 -> 51); rows of 512: behind everywhere.
-// PDWT_ROWS_TAIL_ROW = longest such row (0 = never), PDWT_ROWS_TAIL_SAMPLES = samples per workgroup (A/B measurements).
+// Smaller batches (2^16 .. 2^20 samples): 8192 x 64 haar L3 15.2 -> 9.3, 4096 x 64 db4 13.9 -> 10.5, 16384 x 32 haar L2 18.9 -> 8.3,
+// 1024 x 64 level.  PDWT_ROWS_TAIL_ROW = longest such row (0 = never), PDWT_ROWS_TAIL_SAMPLES = samples per workgroup,
+// PDWT_ROWS_TAIL_MIN_LOG2 = smallest batch (A/B measurements).
 static bool rows_tail(int rows, int N0, int K, int hlen) {
     static const int max_row = getenv("PDWT_ROWS_TAIL_ROW") ? atoi(getenv("PDWT_ROWS_TAIL_ROW")) : 256;
     static const bool forced = getenv("PDWT_ROWS_TAIL_ROW") != nullptr;  // the knob set: every filter up to that row length
-    if (N0 > max_row || N0 > kRowsTailSamples || K > kRowsTailMaxLevels || hlen > 20 || (long long)rows * N0 < (1LL << 20)) return false;
+    static const int min_log2 = getenv("PDWT_ROWS_TAIL_MIN_LOG2") ? atoi(getenv("PDWT_ROWS_TAIL_MIN_LOG2")) : 16;  // smallest batch (log2 samples)
+    if (N0 > max_row || N0 > kRowsTailSamples || K > kRowsTailMaxLevels || hlen > 20 || (long long)rows * N0 < (1LL << min_log2)) return false;
     return forced || N0 <= 64 || (N0 <= 128 && hlen <= 8) || (N0 <= 256 && hlen <= 2);
 }
 template <int HLEN>
@@ -87,6 +91,7 @@ static hipError_t run_rows_tail(RowsTailArgs& a, bool inverse, hipStream_t s) {
     static const int samples = getenv("PDWT_ROWS_TAIL_SAMPLES") ? atoi(getenv("PDWT_ROWS_TAIL_SAMPLES")) : kRowsTailSamples;
     constexpr int NT = 64;
     int G = (samples < kRowsTailSamples ? samples : kRowsTailSamples) / a.N0;
+    while (G > 1 && a.rows / G < 2048) G >>= 1;  // smaller batches: fewer rows per wavefront rather than an idle chip
     a.G = G < 1 ? 1 : G;
     const size_t lds = rows_tail_lds_elems(a.G * a.N0) * sizeof(real_t);
     const unsigned grid = (unsigned)cdiv(a.rows, a.G);

@@ -818,9 +818,11 @@ def test_batches_of_small_images(wname, shape, levels, batch):
 @pytest.mark.parametrize("wname,rows,n,levels", [("haar", 300, 64, 3), ("db4", 1001, 128, 4), ("sym8", 77, 512, 5), ("db10", 4096, 256, 3),
                                                  ("db2", 5, 512, 6), ("bior2.2", 2050, 64, 2), ("db4", 3, 256, 4), ("db3", 4096, 4096, 3),
                                                  ("sym8", 1024, 2048, 2), ("db4", 256, 1024, 4),
-                                                 # >= 2^20 samples in rows of <= 64 samples (128 up to 8 taps, 256 with 2): several rows per wavefront
+                                                 # large batches of rows of <= 64 samples (128 up to 8 taps, 256 with 2): several rows per wavefront
                                                  ("haar", 16403, 64, 3), ("db4", 16390, 64, 2), ("db2", 8201, 128, 4), ("haar", 4100, 256, 5),
-                                                 ("db10", 33000, 32, 2), ("sym8", 17000, 64, 2), ("db3", 70000, 16, 2)])
+                                                 ("db10", 33000, 32, 2), ("sym8", 17000, 64, 2), ("db3", 70000, 16, 2),
+                                                 # ... and smaller batches (>= 2^16 samples): fewer rows per wavefront
+                                                 ("db4", 4100, 64, 3), ("db2", 1030, 128, 3), ("haar", 2050, 32, 2)])
 def test_batched_1d_short_rows_and_few_levels(wname, rows, n, levels):
     """Batched 1D transforms (the reference's ndim = 1 on a 2D array, separable.cu:214-236,368-395): rows of at most 512 samples run
     four to a workgroup (dwt1_*_fused_rows_kernel), plans with few levels keep a 4096-sample segment per workgroup.  Every band of
