@@ -79,7 +79,7 @@ static hipError_t run_inv_rows(const Inv1DFusedArgs& a, hipStream_t s) {
 // Smaller batches (2^16 .. 2^20 samples): 8192 x 64 haar L3 15.2 -> 9.3, 4096 x 64 db4 13.9 -> 10.5, 16384 x 32 haar L2 18.9 -> 8.3,
 // 1024 x 64 level.  PDWT_ROWS_TAIL_ROW = longest such row (0 = never), PDWT_ROWS_TAIL_SAMPLES = samples per workgroup,
 // PDWT_ROWS_TAIL_MIN_LOG2 = smallest batch (A/B measurements).
-static bool rows_tail(int rows, int N0, int K, int hlen) {
+bool dwt1_rows_tail_applies(int rows, int N0, int K, int hlen) {
     static const int max_row = getenv("PDWT_ROWS_TAIL_ROW") ? atoi(getenv("PDWT_ROWS_TAIL_ROW")) : 256;
     static const bool forced = getenv("PDWT_ROWS_TAIL_ROW") != nullptr;  // the knob set: every filter up to that row length
     static const int min_log2 = getenv("PDWT_ROWS_TAIL_MIN_LOG2") ? atoi(getenv("PDWT_ROWS_TAIL_MIN_LOG2")) : 16;  // smallest batch (log2 samples)
@@ -123,12 +123,13 @@ bool dwt1_fused_supported(int hlen, int N0, int K) {
 // levels: K >= 2 consecutive levels starting from `in` of length N0 per row
 hipError_t launch_dwt1_fwd_fused(const float* in, float* const* det, float* app, int rows, int N0, int K, int hlen,
                                  const FilterBank& fb, hipStream_t s) {
-    if (K < 2 || !dwt1_fused_supported(hlen, N0, K)) return hipErrorNotSupported;
+    // (a single level only through the several-rows-per-wavefront kernels: the pyramids need two levels to pay)
+    if ((K < 2 && !dwt1_rows_tail_applies(rows, N0, K, hlen)) || !dwt1_fused_supported(hlen, N0, K)) return hipErrorNotSupported;
     Fwd1DFusedArgs a;
     a.in = in; a.app = app; a.rows = rows; a.N0 = N0; a.K = K;
     for (int k = 0; k < kMaxFusedLevels; k++) a.det[k] = k < K ? det[k] : nullptr;
     interleave(a.fb, fb);
-    if (rows_tail(rows, N0, K, hlen)) {
+    if (dwt1_rows_tail_applies(rows, N0, K, hlen)) {
         const hipError_t e = launch_rows_tail(in, det, app, rows, N0, K, hlen, false, fb, s);
         if (e != hipErrorNotSupported) return e;
     }
@@ -169,12 +170,12 @@ hipError_t launch_dwt1_fwd_fused(const float* in, float* const* det, float* app,
 
 hipError_t launch_dwt1_inv_fused(const float* app, const float* const* det, float* out, int rows, int N0, int K,
                                  int hlen, const FilterBank& fb, hipStream_t s) {
-    if (!dwt1_fused_supported(hlen, N0, K)) return hipErrorNotSupported;
+    if ((K < 2 && !dwt1_rows_tail_applies(rows, N0, K, hlen)) || !dwt1_fused_supported(hlen, N0, K)) return hipErrorNotSupported;
     Inv1DFusedArgs a;
     a.app = app; a.out = out; a.rows = rows; a.N0 = N0; a.K = K;
     for (int k = 0; k < kMaxFusedLevels; k++) a.det[k] = k < K ? det[k] : nullptr;
     interleave(a.fb, fb);
-    if (rows_tail(rows, N0, K, hlen)) {
+    if (dwt1_rows_tail_applies(rows, N0, K, hlen)) {
         const hipError_t e = launch_rows_tail(app, const_cast<float* const*>(det), out, rows, N0, K, hlen, true, fb, s);
         if (e != hipErrorNotSupported) return e;
     }

@@ -822,7 +822,9 @@ def test_batches_of_small_images(wname, shape, levels, batch):
                                                  ("haar", 16403, 64, 3), ("db4", 16390, 64, 2), ("db2", 8201, 128, 4), ("haar", 4100, 256, 5),
                                                  ("db10", 33000, 32, 2), ("sym8", 17000, 64, 2), ("db3", 70000, 16, 2),
                                                  # ... and smaller batches (>= 2^16 samples): fewer rows per wavefront
-                                                 ("db4", 4100, 64, 3), ("db2", 1030, 128, 3), ("haar", 2050, 32, 2)])
+                                                 ("db4", 4100, 64, 3), ("db2", 1030, 128, 3), ("haar", 2050, 32, 2),
+                                                 # ... and single-level plans
+                                                 ("db10", 33000, 32, 1), ("haar", 17000, 64, 1), ("db3", 2100, 64, 1)])
 def test_batched_1d_short_rows_and_few_levels(wname, rows, n, levels):
     """Batched 1D transforms (the reference's ndim = 1 on a 2D array, separable.cu:214-236,368-395): rows of at most 512 samples run
     four to a workgroup (dwt1_*_fused_rows_kernel), plans with few levels keep a 4096-sample segment per workgroup.  Every band of
