@@ -32,7 +32,7 @@ VARIANTS = {
             ["-DPDWT_LAB_KERNELS"] + (["-DPDWT_TILE_EXPERIMENT"] if os.environ.get("PDWT_TILE_EXPERIMENT") else [])
             + os.environ.get("PDWT_EXTRA_DEFINES", "").split(), ()),  # e.g. PDWT_EXTRA_DEFINES=-DPDWT_SWT_INV_UNROLL=8 (A/B builds)
     "f64": (os.path.join(ROOT, "build", "obj_f64"), LIB_F64, ["-DPDWT_DOUBLE"],
-            ("launch_dwt2_pyramid.hip", "launch_dwt1_fused.hip", "launch_dwt2_chain.hip")),
+            ("launch_dwt2_pyramid.hip", "launch_dwt1_fused.hip", "launch_dwt2_chain.hip", "launch_dwt2_ring.hip")),
 }
 
 SOURCES = [
@@ -44,6 +44,7 @@ SOURCES = [
     "launch_swt_tail.hip",
     "launch_dwt2_chain.hip",
     "launch_dwt2_wave.hip",
+    "launch_dwt2_ring.hip",
     "launch_dwt1.hip",
     "launch_dwt1_fused.hip",
     "launch_dwt1_reg.hip",

@@ -20,7 +20,7 @@ enum EwOp { EW_SOFT = 0, EW_HARD = 1, EW_LINF = 2, EW_SCALE = 3 };
 // third thread calling pdwt_set_tuning -- cannot change each other's kernel choice in mid-transform; with no active set
 // (direct calls of the launchers: tools, emulation) the process-wide values apply.
 struct Tuning {
-    int wave_min_log2, lds_max_log2, swt_split_fwd, swt_split_inv, dwt_split_fwd, dwt_split_inv;
+    int wave_min_log2, lds_max_log2, swt_split_fwd, swt_split_inv, dwt_split_fwd, dwt_split_inv, ring_min_log2;
 };
 Tuning current_tuning();                  // the process-wide values now
 void set_active_tuning(const Tuning* t);  // thread-local; nullptr = the process-wide values
@@ -41,6 +41,12 @@ hipError_t try_launch_dwt2_inv_fast(const Inv2DArgs& a, int batch, hipStream_t s
 // wave-per-tile kernels (registers + DPP, no LDS): hlen <= 8; seg_hint > 0 forces the rows per wavefront
 hipError_t try_launch_dwt2_fwd_wave(const Fwd2DArgs& a, int batch, hipStream_t s, int seg_hint = 0);
 hipError_t try_launch_dwt2_inv_wave(const Inv2DArgs& a, int batch, hipStream_t s, int seg_hint = 0);
+// register-ring kernels for 10-20 taps (dwt2_ring_kernels.hpp): cpl = image columns per lane (4; 2 in the lab library only); seg_hint > 0
+// forces the rows per wavefront
+hipError_t try_launch_dwt2_fwd_ring(const Fwd2DArgs& a, int batch, hipStream_t s, int cpl = 4, int seg_hint = 0);
+hipError_t try_launch_dwt2_inv_ring(const Inv2DArgs& a, int batch, hipStream_t s, int cpl = 4, int seg_hint = 0);
+int set_ring_min_log2(int value);  // 2D DWT levels of at least 2^value samples with 12-20 taps run on them (63 = never; below the default: 10-20 taps, tests)
+int get_ring_min_log2();
 int set_wave_min_log2(int value);  // returns the previous threshold
 int get_wave_min_log2();
 int set_lds_max_log2(int value);   // 2D DWT levels of at most 2^value samples prefer the LDS tiles to the wave kernels (0 = never)

@@ -53,6 +53,10 @@ hipError_t launch_dwt2_inv_strip2(const real_t* const[4], const real_t* const[3]
                                   const FilterBank&, int, hipStream_t) { return hipErrorNotSupported; }
 hipError_t launch_dwt2_inv_pyr2(const real_t* const[4], const real_t* const[3], real_t*, int, int, int,
                                 const FilterBank&, int, hipStream_t) { return hipErrorNotSupported; }
+// the register-ring kernels for 12-20 taps keep hlen tap pairs in SGPRs and hlen/2 x 8 running sums in VGPRs: in doubles neither fits
+// (hipcc: 256 VGPRs + 300-900 B of scratch per lane), so the fp64 library does not build them
+hipError_t try_launch_dwt2_fwd_ring(const Fwd2DArgs&, int, hipStream_t, int, int) { return hipErrorNotSupported; }
+hipError_t try_launch_dwt2_inv_ring(const Inv2DArgs&, int, hipStream_t, int, int) { return hipErrorNotSupported; }
 int dwt1_fused_max_levels(int) { return 1; }
 bool dwt1_fused_supported(int, int, int) { return false; }
 hipError_t launch_dwt1_fwd_fused(const real_t*, real_t* const*, real_t*, int, int, int, int, const FilterBank&,
@@ -122,6 +126,25 @@ int get_wave2_enabled() { return wave2_flag().load(std::memory_order_relaxed); }
 static thread_local const Tuning* g_active_tuning = nullptr;
 void set_active_tuning(const Tuning* t) { g_active_tuning = t; }
 const Tuning* active_tuning() { return g_active_tuning; }
+// Register-ring kernels (dwt2_ring_kernels.hpp) for even filters of 12-20 taps: levels of at least 2^ring_min_log2 samples whose
+// rows fill a wavefront's strip.  Same-box, same-harness A/B against the LDS tiles (tools/ringbench.hip, profiles/r05b_ringbench.txt;
+// forward + inverse of one level, us): 16 taps 4096^2 50.3 -> 46.1, 4 x 4096^2 252.9 -> 224.4, 4 x 2048^2 50.6 -> 46.6;
+// 12 taps 44.5 -> 42.3; 20 taps 71.9 -> 68.9; 10 taps 42.1 -> 42.4 (stays on the tiles); one 2048^2 level 19.0 -> 22.7 (too
+// few wavefronts: stays on the tiles).  Tuning key "ring_min_log2" (default 24; 63 = never; 0 = every eligible level: tests).
+constexpr int kRingMinDefault = 24;
+static std::atomic<int>& ring_min_log2() {
+    static std::atomic<int> v{kRingMinDefault};
+    return v;
+}
+int set_ring_min_log2(int value) { return ring_min_log2().exchange(value < 0 ? 0 : (value > 63 ? 63 : value)); }
+int get_ring_min_log2() { return ring_min_log2().load(std::memory_order_relaxed); }
+static bool ring_kernels_for(long long samples, int hlen, int Nc) {
+    const int m = g_active_tuning ? g_active_tuning->ring_min_log2 : ring_min_log2().load(std::memory_order_relaxed);
+    if (m >= 63 || samples < (1LL << m)) return false;
+    if (m < kRingMinDefault) return hlen >= 10 && hlen <= 20;  // forced (tests): every length the kernels are built for, any width
+    return hlen >= 12 && hlen <= 20 && Nc >= 256;
+}
+
 static int eff_wave_min_log2() { return g_active_tuning ? g_active_tuning->wave_min_log2 : wave_min_log2().load(std::memory_order_relaxed); }
 static bool wave_kernels_for(long long samples) {
     const int m = eff_wave_min_log2();
@@ -177,10 +200,15 @@ Tuning current_tuning() {
     t.swt_split_inv = get_swt_split_min(1);
     t.dwt_split_fwd = get_dwt_split_min(0);
     t.dwt_split_inv = get_dwt_split_min(1);
+    t.ring_min_log2 = get_ring_min_log2();
     return t;
 }
 
 hipError_t launch_dwt2_fwd(const Fwd2DArgs& a, int batch, hipStream_t s) {
+    if (ring_kernels_for((long long)batch * a.Nr * a.Nc, a.hlen, a.Nc)) {
+        const hipError_t e = try_launch_dwt2_fwd_ring(a, batch, s);
+        if (e != hipErrorNotSupported) return e;
+    }
     if (lds_tiles_for((long long)batch * a.Nr * a.Nc, a.hlen, (long long)a.Nr * a.Nc, false)) {
         const hipError_t e = try_launch_dwt2_fwd_fast(a, batch, s);
         if (e != hipErrorNotSupported) return e;
@@ -216,6 +244,10 @@ hipError_t launch_dwt2_inv(const Inv2DArgs& a, int batch, hipStream_t s) {
     // 23.6 us) and loses slightly to the LDS tiles on a batch streamed from HBM (8 x 4096^2: 224-232 vs 219 us,
     // profiles/r02b_wbench_b8.txt): 2^26 samples and beyond go to the tiles
     const long long samples = (long long)batch * a.Nr * a.Nc;
+    if (ring_kernels_for(samples, a.hlen, a.Nc)) {
+        const hipError_t e = try_launch_dwt2_inv_ring(a, batch, s);
+        if (e != hipErrorNotSupported) return e;
+    }
     if (lds_tiles_for(samples, a.hlen)) {
         const hipError_t e = try_launch_dwt2_inv_fast(a, batch, s);
         if (e != hipErrorNotSupported) return e;

@@ -21,6 +21,7 @@
 #include "../../pypwt_amd/csrc/swt2_tail_kernels.hpp"
 #include "../../pypwt_amd/csrc/dwt2_strip_kernels.hpp"
 #include "../../pypwt_amd/csrc/dwt2_wave_kernels.hpp"
+#include "../../pypwt_amd/csrc/dwt2_ring_kernels.hpp"
 #include "../../pypwt_amd/csrc/nonsep_kernels.hpp"
 #include "../../pypwt_amd/csrc/swt_kernels.hpp"
 #include "../../pypwt_amd/csrc/swt_split_kernels.hpp"
@@ -722,6 +723,70 @@ EMU_API int emu_dwt2_inv_wave(const float* A, const float* H, const float* V, co
         if (!guard && ((Ncc % 128) || (seg_pairs % GRI) || (Nrc % GRI) || (Nrc % seg_pairs) || Nr != 2 * Nrc)) return -2; \
         run_inv_wave<h>(a, batch, guard); return 0; }
         X(2) X(4) X(6) X(8)
+#undef X
+    }
+    return -1;
+}
+
+// ------------------------------------------------------------------ register-ring level kernels for long filters (dwt2_ring_kernels.hpp)
+template <int HLEN, int CPL>
+static void run_fwd_ring(const FwdWaveArgs& a, int batch) {
+    std::vector<float> lds(FwdRingGeom<HLEN, CPL>::LDS_REALS, -12345.f);
+    for (int bz = 0; bz < batch; bz++)
+        for (int seg = 0; seg < a.segs; seg++)
+            for (int strip = 0; strip < a.strips; strip++) {
+                std::fill(lds.begin(), lds.end(), -12345.f);  // a wavefront never reads what another one staged
+                dwt2_fwd_ring<HLEN, CPL>(a, strip, seg, bz, lds.data());
+            }
+}
+
+// cpl = image columns per lane (2 or 4); any Nr, Nc % 4 == 0, any seg_out >= 1
+EMU_API int emu_dwt2_fwd_ring(const float* in, int batch, int Nr, int Nc, const float* lo, const float* hi, int hlen,
+                              int seg_out, int cpl, float* A, float* H, float* V, float* D) {
+    if ((hlen & 1) || hlen < kRingMinHlen || hlen > kRingMaxHlen || (Nc & 3) || (cpl != 2 && cpl != 4) || seg_out < 1) return -1;
+    FwdWaveArgs a;
+    a.in = in; a.A = A; a.H = H; a.V = V; a.D = D;
+    a.Nr = Nr; a.Nc = Nc; a.Nr2 = (Nr + 1) / 2; a.Nc2 = Nc / 2;
+    a.in_bstride = (long long)Nr * Nc; a.out_bstride = (long long)a.Nr2 * a.Nc2;
+    a.strips = cdiv(Nc, 64 * cpl); a.seg_out = seg_out; a.segs = cdiv(a.Nr2, seg_out);
+    interleave_bank(a.fb, lo, hi, hlen);
+    switch (hlen) {
+#define X(h) case h: if (cpl == 2) run_fwd_ring<h, 2>(a, batch); else run_fwd_ring<h, 4>(a, batch); return 0;
+        X(10) X(12) X(14) X(16) X(18) X(20)
+#undef X
+    }
+    return -1;
+}
+
+template <int HLEN, int CPL>
+static void run_inv_ring(const InvRingArgs& a, int batch) {
+    std::vector<float> lds(InvRingGeom<HLEN, CPL>::LDS_REALS, -12345.f);
+    for (int bz = 0; bz < batch; bz++)
+        for (int seg = 0; seg < a.segs; seg++)
+            for (int strip = 0; strip < a.strips; strip++) {
+                std::fill(lds.begin(), lds.end(), -12345.f);
+                dwt2_inv_ring<HLEN, CPL>(a, strip, seg, bz, lds.data());
+            }
+}
+
+// cpl = image columns per lane (2 or 4); Ncc even, Nc == 2 Ncc, Nr = 2 Nrc or 2 Nrc - 1, any seg_pairs >= 1
+EMU_API int emu_dwt2_inv_ring(const float* A, const float* H, const float* V, const float* D, int batch, int Nrc, int Ncc,
+                              int Nr, int Nc, const float* lo, const float* hi, int hlen, int seg_pairs, int cpl, float* out) {
+    if ((hlen & 1) || hlen < kRingMinHlen || hlen > kRingMaxHlen || (Ncc & 1) || Nc != 2 * Ncc || (cpl != 2 && cpl != 4) || seg_pairs < 1)
+        return -1;
+    InvRingArgs a;
+    a.A = A; a.H = H; a.V = V; a.D = D; a.out = out;
+    a.Nrc = Nrc; a.Ncc = Ncc; a.Nr = Nr; a.Nc = Nc;
+    a.in_bstride = (long long)Nrc * Ncc; a.out_bstride = (long long)Nr * Nc;
+    a.strips = cdiv(Ncc, 32 * cpl); a.seg_pairs = seg_pairs; a.segs = cdiv(Nrc, seg_pairs);
+    interleave_bank(a.fb, lo, hi, hlen);
+    for (int d = 0; d < hlen / 2; d++) {
+        a.pl[d].x = lo[hlen - 2 - 2 * d]; a.pl[d].y = lo[hlen - 1 - 2 * d];
+        a.ph[d].x = hi[hlen - 2 - 2 * d]; a.ph[d].y = hi[hlen - 1 - 2 * d];
+    }
+    switch (hlen) {
+#define X(h) case h: if (cpl == 2) run_inv_ring<h, 2>(a, batch); else run_inv_ring<h, 4>(a, batch); return 0;
+        X(10) X(12) X(14) X(16) X(18) X(20)
 #undef X
     }
     return -1;

@@ -920,3 +920,65 @@ def test_emu_dwt_split_row_and_column_launches(wname, R):
             lib_o.oracle_synthesis_rows(P(t1), P(t2), Nr, half[1], Nc, P(rlo), P(rhi), hlen, P(want))
             assert np.isfinite(rec[b]).all(), (wname, shape, "inverse")
             assert np.abs(rec[b] - want).max() <= _tol(want), (wname, shape, R, "inverse")
+
+
+# ----------------------------------------------------------------------------- register-ring kernels for long filters
+# (dwt2_ring_kernels.hpp: one wavefront per tile, the row halo through a wavefront-private LDS row, the column filter a
+# register ring of running sums).  cpl = image columns per lane.
+RING_WNAMES = ["db5", "sym6", "db7", "sym8", "coif3", "db10", "bior5.5", "rbio6.8"]
+RING_SHAPES = [(64, 256, 8), (96, 512, 24), (48, 128, 5), (40, 768, 16), (61, 72, 7), (32, 260, 16), (129, 8, 9),
+               (6, 12, 2), (2, 4, 1), (200, 516, 32), (50, 1028, 3), (20, 24, 10)]
+
+
+@pytest.mark.parametrize("cpl", [2, 4])
+@pytest.mark.parametrize("wname", RING_WNAMES)
+def test_emu_dwt2_ring_fwd(wname, cpl):
+    hlen, dlo, dhi, rlo, rhi = oracle.filters(wname)
+    assert 10 <= hlen <= 20
+    for si, (nr, nc, seg_out) in enumerate(RING_SHAPES):
+        x = oracle.hash_input((nr, nc), 7100 + si)
+        ref = oracle.forward(x, wname, 1, ndim=2)
+        r2, c2 = (nr + 1) // 2, nc // 2
+        outs = [np.full((r2, c2), np.nan, dtype=np.float32) for _ in range(4)]
+        rc = lib().emu_dwt2_fwd_ring(P(x), 1, nr, nc, P(dlo), P(dhi), hlen, seg_out, cpl, *[P(o) for o in outs])
+        assert rc == 0
+        for got, want in zip(outs, ref):
+            assert np.isfinite(got).all(), (wname, nr, nc)
+            assert np.abs(got - want).max() <= _tol(want), (wname, nr, nc, seg_out, cpl)
+
+
+@pytest.mark.parametrize("cpl", [2, 4])
+@pytest.mark.parametrize("wname", RING_WNAMES)
+def test_emu_dwt2_ring_inv(wname, cpl):
+    hlen, dlo, dhi, rlo, rhi = oracle.filters(wname)
+    for si, (nr, nc, seg) in enumerate(RING_SHAPES):
+        if (nc // 2) % 2:
+            continue
+        r2, c2 = (nr + 1) // 2, nc // 2
+        bands = [oracle.hash_input((r2, c2), 7900 + 7 * si + b, 2.0) - 1.0 for b in range(4)]
+        ref = oracle.inverse(bands, (nr, nc), wname, 1, ndim=2)
+        out = np.full((nr, nc), np.nan, dtype=np.float32)
+        args = [P(b) for b in bands] + [1, r2, c2, nr, nc, P(rlo), P(rhi), hlen, seg]
+        assert lib().emu_dwt2_inv_ring(*args, cpl, P(out)) == 0
+        assert np.isfinite(out).all(), (wname, nr, nc)
+        assert np.abs(out - ref).max() <= _tol(ref), (wname, nr, nc, seg, cpl)
+
+
+def test_emu_dwt2_ring_batch_and_custom_filter():
+    rng = np.random.default_rng(11)
+    lo, hi = f32(rng.standard_normal(16)), f32(rng.standard_normal(16))
+    B, nr, nc = 2, 32, 512
+    x = oracle.hash_input((B, nr, nc), 93)
+    for cpl in (2, 4):
+        outs = [np.zeros((B, nr // 2, nc // 2), dtype=np.float32) for _ in range(4)]
+        assert lib().emu_dwt2_fwd_ring(P(x), B, nr, nc, P(lo), P(hi), 16, 8, cpl, *[P(o) for o in outs]) == 0
+        for b in range(B):
+            ref = oracle.forward(x[b], "sym8", 1, ndim=2, filt=(16, lo, hi, lo, hi))
+            for got, want in zip(outs, ref):
+                assert np.abs(got[b] - want).max() <= _tol(want)
+        rec = np.zeros((B, nr, nc), dtype=np.float32)
+        assert lib().emu_dwt2_inv_ring(*[P(o) for o in outs], B, nr // 2, nc // 2, nr, nc, P(lo), P(hi), 16, 4, cpl,
+                                       P(rec)) == 0
+        for b in range(B):
+            ref = oracle.inverse([o[b] for o in outs], (nr, nc), "sym8", 1, ndim=2, filt=(16, lo, hi, lo, hi))
+            assert np.abs(rec[b] - ref).max() <= 4 * _tol(ref)
