@@ -313,6 +313,22 @@ def shard_images(total, world, rank):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def metric_name(config, desc, batch_per_gpu):
+    """The line's `metric`: BASELINE.json's metric for the db4 configurations, WITH the workload it was measured on (one image
+    per step / a batch per GPU): lines of different workloads must not be mistaken for each other."""
+    if config == "cfg2":
+        return "Msamples/s, 4096x4096 fp32 db4 L4 2D DWT fwd+inv, %s (cfg2)" % ("one image per step" if batch_per_gpu == 1 else "%d images per step" % batch_per_gpu)
+    if config == "cfg5":
+        return "Msamples/s, 4096x4096 fp32 db4 L4 2D DWT fwd+inv, batch of %d images per GPU and step (cfg5)" % batch_per_gpu
+    return "Msamples/s, " + desc
+
+
+def median(values):
+    v = sorted(values)
+    n = len(v)
+    return v[n // 2] if n % 2 else 0.5 * (v[n // 2 - 1] + v[n // 2])
+
+
 def resolve_config(args, world):
     """--config when given; else the headline one-image configuration on one GPU and BASELINE config 5's per-GPU shard
     (the same images, 128 per GPU and step) when the batch is sharded over several: with the driver's --steps 20 a
@@ -488,6 +504,47 @@ def beyond_mall(cfg, device, steps, B=16):
             "frac_of_hbm_peak": bytes_step / dt / 1e9 / HBM_PEAK_GBPS}
 
 
+def other_config(name, device, steps):
+    """One of the BASELINE configurations the line is NOT quoted on, measured in the same run on the same GPU: `steps` steps
+    after a short pre-heat, the launch profile and the copy floor (kernel_profile).  A compact record for `extra.configs`."""
+    from pypwt_amd import BatchedWavelets
+    cfg = CONFIGS[name]
+    Nr, Nc, wname, L, swt, ndim, beta, desc = cfg
+    plan = BatchedWavelets(1, Nr, Nc, wname, L, do_swt=swt, ndim=ndim, device=device)
+    try:
+        plan.fill_hash(20240 + 2, 255.0)
+
+        def step():
+            plan.forward()
+            if beta is not None:
+                plan.soft_threshold(beta)
+            plan.inverse()
+
+        t0 = time.perf_counter()
+        while (time.perf_counter() - t0) < 0.04:  # pre-heat
+            for _ in range(20):
+                step()
+            plan.synchronize()
+        regions = [timed_steps(step, plan.synchronize, steps) for _ in range(3)]
+        step_s = median(regions)
+        kernels, roofline, step_names = kernel_profile(plan, step, cfg, name, 1, steps)
+        thr_separate = any(n.startswith("soft_threshold") for n in step_names)
+        bps = algorithmic_bytes_per_sample(cfg, threshold_separate=thr_separate)
+        e2e_bytes = bps * Nr * Nc
+        rec = {"workload": desc, "steps": steps, "ms_per_step": step_s * 1e3, "timed_regions_ms_per_step": [r * 1e3 for r in regions],
+               "Msamples_s": Nr * Nc / step_s / 1e6, "algorithmic_bytes_per_sample": bps,
+               "frac_of_hbm_peak": e2e_bytes / step_s / 1e9 / HBM_PEAK_GBPS,
+               "dominant_kernel": roofline.get("kernel"), "dominant_kernel_us": roofline.get("avg_us"),
+               "dominant_kernel_frac_of_hbm_peak": roofline.get("frac"), "copy_ceiling_GBps": roofline.get("copy_ceiling_GBps"),
+               "copy_floor_us_per_step": roofline.get("step_copy_floor_us"),
+               "kernels": [{"kernel": k["kernel"], "avg_us": k["avg_us"]} for k in kernels[:8]]}
+        if roofline.get("step_copy_floor_us"):
+            rec["copy_floor_over_step"] = roofline["step_copy_floor_us"] * 1e-6 / step_s
+        return rec
+    finally:
+        plan.cleanup()
+
+
 def kernel_profile(plan, step, cfg, config_name, B, steps):
     """Per-launch shares of one step (HIP events on the plan's stream), the dominant kernel re-timed alone, its
     roofline and the copy ceiling measured beside it.  Returns (kernels, roofline, names of one step's launches)."""
@@ -589,16 +646,30 @@ def dry_run(args, rank, world, dist, backend, out_stream=None):
     with gloo on CPU."""
     cfg = CONFIGS[args.config]
     B, first, total = rank_batch(args, world, rank)
-    dt = timed_region(lambda: time.sleep(0.001 * (1 + rank)), lambda: None, args.steps, dist, backend,
-                      before_closing_barrier=lambda: time.sleep(1e-3 * rank * args.dry_run_barrier_skew_ms))
+    step = lambda: time.sleep(0.001 * (1 + rank))
+    alone_s = None
+    if dist is not None:  # the same-workload one-rank reference, as in the real run
+        barrier(dist, backend)
+        if rank == 0:
+            alone_s = median([timed_steps(step, lambda: None, args.steps) for _ in range(3)])
+        barrier(dist, backend)
+    regions = [timed_region(step, lambda: None, args.steps, dist, backend,
+                            before_closing_barrier=lambda: time.sleep(1e-3 * rank * args.dry_run_barrier_skew_ms)) for _ in range(3)]
+    dt = median(regions)
     if rank == 0:
         samples = total * cfg[0] * cfg[1]
-        print(file=out_stream or sys.stdout, flush=True, *[json.dumps({"metric": "dry_run", "value": samples / (dt / args.steps) / 1e6, "unit": "Msamples/s",
+        ref = None
+        if alone_s is not None:
+            one = B * cfg[0] * cfg[1] / alone_s / 1e6
+            ref = {"one_gpu_same_workload_Msamples_s": one, "one_gpu_same_workload_ms_per_step": alone_s * 1e3,
+                   "efficiency": samples / (dt / args.steps) / 1e6 / (world * one)}
+        print(file=out_stream or sys.stdout, flush=True, *[json.dumps({"metric": "dry_run", "scaling_reference": ref, "value": samples / (dt / args.steps) / 1e6, "unit": "Msamples/s",
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
                           "vs_baseline": None, "dtype": "f32", "data": "none (dry run)",
                           "config": {"workload": "dry-run", "config": args.config, "shard_rank0": [first, first + B],
-                                     "images_per_step": total, "timed_region_ms": dt * 1e3}})])
+                                     "images_per_step": total, "timed_region_ms": dt * 1e3,
+                                     "timed_regions_ms": [t * 1e3 for t in regions]}})])
 
 
 def claim_stdout():
@@ -657,7 +728,7 @@ def single_process_main(args, out_stream):
     bps = algorithmic_bytes_per_sample(cfg, threshold_separate=thr_separate)
     per_gpu_bytes = bps * max(hi - lo for _, lo, hi in S.shards) * Nr * Nc
     out = {
-        "metric": "Msamples/s, 4096x4096 fp32 db4 L4 2D DWT fwd+inv" if args.config in ("cfg2", "cfg5") else "Msamples/s, " + desc,
+        "metric": metric_name(args.config, desc, b),
         "value": samples / step_s / 1e6, "unit": "Msamples/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": step_s * 1e3, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
         "dtype": "f32", "data": "synthetic (on-device index hash, 0..255)",
@@ -749,17 +820,23 @@ def main():
                 step()
             device_sync()
 
-    dt = timed_region(step, device_sync, args.steps, dist, backend, reheat=reheat)
+    # Same-workload one-GPU reference for a multi-rank run: rank 0 times ITS shard alone (the other ranks wait at the barrier,
+    # their GPUs idle), so that the line carries the denominator of its own scaling efficiency -- value(N) / value(1) of two
+    # different default workloads (one image on one GPU, 128 per GPU on several) says nothing.
+    alone_s = None
+    if dist is not None:
+        barrier(dist, backend)
+        if rank == 0:
+            reheat()
+            alone_s = median([timed_steps(step, device_sync, args.steps) for _ in range(3)])
+        barrier(dist, backend)
+        reheat()
+
+    # THREE timed regions, always, each the contract's (barrier, K steps, barrier): the line's figure is their median and all
+    # three are in the line (a one-sided "time again when slow" would bias the figure downwards).
+    timed_regions = [timed_region(step, device_sync, args.steps, dist, backend, reheat=reheat) for _ in range(3)]
+    dt = median(timed_regions)
     cold_s = max_over_ranks(cold_s, dist, backend)
-    # Interference check.  The cold figure (no pre-heat) is the SLOWER of the two by construction; a timed region that comes
-    # out slower still was disturbed from outside (round 4: one cfg4 line read 149.5 us where its cold figure was 134.1 and the
-    # rocprofv3 kernel means of the same call summed to 132.8) -- or the configuration is launch-bound, where pre-heating buys nothing
-    # (cfg1: 10.4 cold, 11.2 / 11.5 hot on one box).  Then -- and only then -- the region is timed once more, the same way; both
-    # readings are reported and the smaller one is the line's figure.  Every rank sees the same maxima and takes the same decision.
-    timed_regions = [dt]
-    if dt / args.steps > 1.05 * cold_s:
-        timed_regions.append(timed_region(step, device_sync, args.steps, dist, backend, reheat=reheat))
-        dt = min(timed_regions)  # (both readings are in the line: config.timed_regions_ms)
 
     step_s = dt / args.steps
     samples_per_step = total_images * Nr * Nc
@@ -790,22 +867,24 @@ def main():
 
     workload = args.config if args.config != "cfg5" else "cfg5 (per-GPU shard of cfg2 images)"
     out = {
-        "metric": "Msamples/s, 4096x4096 fp32 db4 L4 2D DWT fwd+inv" if args.config in ("cfg2", "cfg5") else "Msamples/s, " + desc,
+        "metric": metric_name(args.config, desc, B),
         "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": step_s * 1e3, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
         "dtype": "f32", "data": "synthetic (on-device index hash, 0..255)",
         "config": {"workload": "%s: %s" % (workload, desc), "batch_per_gpu": B, "images_per_step": total_images,
                    "wavelet": wname, "levels": L, "shape": [Nr, Nc],
                    "parallelism": "image-sharded x%d, no collectives" % world, "preheat_ms": args.preheat_ms,
-                   "timed_region_ms": dt * 1e3},
+                   "timed_region_ms": dt * 1e3, "timed_regions_ms": [t * 1e3 for t in timed_regions],
+                   "timed_region_rule": "median of three regions of `steps` steps each"},
 
         "roofline": roofline, "end_to_end": e2e, "kernels": kernels[:12],
     }
-    if len(timed_regions) > 1:
-        out["config"]["retimed"] = ("the first timed region (%.4f ms per step) was slower than the un-preheated one (%.4f): timed "
-                                    "once more, the same way (%.4f); `ms_per_step` is the smaller of the two readings"
-                                    % (timed_regions[0] / args.steps * 1e3, cold_s * 1e3, timed_regions[1] / args.steps * 1e3))
-        out["config"]["timed_regions_ms"] = [t * 1e3 for t in timed_regions]
+    if alone_s is not None:
+        one = B * Nr * Nc / alone_s / 1e6
+        out["scaling_reference"] = {"one_gpu_same_workload_Msamples_s": one, "one_gpu_same_workload_ms_per_step": alone_s * 1e3,
+                                    "efficiency": value / (world * one),
+                                    "note": "rank 0 alone on its shard of %d images per step (the other ranks waiting at a barrier), median "
+                                            "of three regions; efficiency = value / (n_gpus x that)" % B}
     if dist is not None:
         if shared_gpu:
             out["config"]["shared_gpu_test_run"] = "all ranks ran on GPU 0 (PDWT_BENCH_SHARE_GPU=1): not a multi-GPU measurement"
@@ -828,6 +907,12 @@ def main():
         except Exception as e:
             extra["transfers"] = {"error": repr(e)}
         if args.config == "cfg2" and B == 1:
+            extra["configs"] = {}
+            for other in ("cfg1", "cfg3", "cfg4"):  # the BASELINE configurations the line is not quoted on, same run, same GPU
+                try:
+                    extra["configs"][other] = other_config(other, local_rank, 20)
+                except Exception as e:
+                    extra["configs"][other] = {"error": repr(e)}
             try:
                 extra["beyond_infinity_cache"] = beyond_mall(cfg, local_rank, args.steps)
             except Exception as e:

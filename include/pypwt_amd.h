@@ -245,10 +245,11 @@ long long pdwt_copy_capacity(pdwt_handle h); /* the largest `elems` pdwt_time_co
  *   "lds_max_log2"   a 2D DWT level of at most 2^value samples prefers the LDS tiles to the wave-per-tile kernels
  *                    (default 25 since round 4, 24 before: one cache-resident image and the first doubling of it; at the
  *                    default, forward levels of images below 2^24 samples stay on the tiles up to 2^26; fp64 library 0 = never)
- *   "ring_min_log2"  a 2D DWT level of 12-20 taps runs on the register-ring kernels (dwt2_ring_kernels.hpp: one wavefront per
+ *   "ring_min_log2"  a 2D DWT level of 12 or 16 taps runs on the register-ring kernels (dwt2_ring_kernels.hpp: one wavefront per
  *                    tile, row halo through LDS, column filter as running sums in registers) when at least 2^value samples
- *                    enter it and its rows have at least 256 columns (default 24: one 4096^2 image or a batch of that size;
- *                    63 = never; below 24: every level of 10-20 taps, any width -- tests)
+ *                    enter it and its rows have at least 1024 columns (default 25: batches from two 4096^2 images on, 6-15 %
+ *                    faster than the LDS tiles there; 63 = never; below 25: every level of 10-20 taps of that size on, any
+ *                    width -- tests and measurements)
  *   "reg1d"          bit 0 / bit 1: the forward / inverse 1D DWT levels run three at a time in registers
  *                    (dwt1_reg_kernels.hpp) where the rows qualify (even hlen <= 20, rows of >= 2048 samples that
  *                    are multiples of 32); default 3; 0 = the workgroup-wide LDS pyramids (57.6 vs 69.5 us per

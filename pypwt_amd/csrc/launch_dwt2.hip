@@ -126,12 +126,17 @@ int get_wave2_enabled() { return wave2_flag().load(std::memory_order_relaxed); }
 static thread_local const Tuning* g_active_tuning = nullptr;
 void set_active_tuning(const Tuning* t) { g_active_tuning = t; }
 const Tuning* active_tuning() { return g_active_tuning; }
-// Register-ring kernels (dwt2_ring_kernels.hpp) for even filters of 12-20 taps: levels of at least 2^ring_min_log2 samples whose
-// rows fill a wavefront's strip.  Same-box, same-harness A/B against the LDS tiles (tools/ringbench.hip, profiles/r05b_ringbench.txt;
-// forward + inverse of one level, us): 16 taps 4096^2 50.3 -> 46.1, 4 x 4096^2 252.9 -> 224.4, 4 x 2048^2 50.6 -> 46.6;
-// 12 taps 44.5 -> 42.3; 20 taps 71.9 -> 68.9; 10 taps 42.1 -> 42.4 (stays on the tiles); one 2048^2 level 19.0 -> 22.7 (too
-// few wavefronts: stays on the tiles).  Tuning key "ring_min_log2" (default 24; 63 = never; 0 = every eligible level: tests).
-constexpr int kRingMinDefault = 24;
+// Register-ring kernels (dwt2_ring_kernels.hpp): 38 % fewer vector instructions than the LDS tile at 16 taps (rocprofv3
+// SQ_INSTS_VALU per 4096^2 level: 11.1e6 -> 6.9e6, profiles/r05a_*), but a level is only as fast as its wavefronts are many:
+// same-box A/B inside plans (tools/ring_ab.py, profiles/r05c_ring_ab.txt; forward + inverse of the whole plan, tiles -> ring):
+//   * batches (>= 2^25 samples in the level), 16 taps: 2 / 4 / 16 x 4096^2 L4 186 -> 175 / 345 -> 316 / 1350 -> 1151 us,
+//     4 x 3000 x 4000 247 -> 217, 64 x 1024^2 333 -> 317, 16 x 2048^2 332 -> 310; 12 taps 4 x 4096^2 310 -> 295;
+//   * ONE 4096^2 image: level 1 alone 56.1 -> 53.3 us, the four-level plan 87.3 -> 88.8 (2048 wavefronts of 46 rows each: the
+//     launch ends with every wavefront's last rows at once); 14 / 18 / 20 taps lose 4-13 % in plans at every batch size
+//     (18 and 20 keep the tile's inverse, launch_dwt2_ring.hip); images of 512 columns lose 2x (two strips per image).
+// Default: levels of at least 2^25 samples, 12 or 16 taps, rows of at least 1024 columns.  Tuning key "ring_min_log2"
+// (63 = never; below the default: every level of 10-20 taps and any width of that size on -- tests and measurements).
+constexpr int kRingMinDefault = 25;
 static std::atomic<int>& ring_min_log2() {
     static std::atomic<int> v{kRingMinDefault};
     return v;
@@ -141,8 +146,8 @@ int get_ring_min_log2() { return ring_min_log2().load(std::memory_order_relaxed)
 static bool ring_kernels_for(long long samples, int hlen, int Nc) {
     const int m = g_active_tuning ? g_active_tuning->ring_min_log2 : ring_min_log2().load(std::memory_order_relaxed);
     if (m >= 63 || samples < (1LL << m)) return false;
-    if (m < kRingMinDefault) return hlen >= 10 && hlen <= 20;  // forced (tests): every length the kernels are built for, any width
-    return hlen >= 12 && hlen <= 20 && Nc >= 256;
+    if (m < kRingMinDefault) return hlen >= 10 && hlen <= 20;  // forced: every length the kernels are built for, any width
+    return (hlen == 12 || hlen == 16) && Nc >= 1024;
 }
 
 static int eff_wave_min_log2() { return g_active_tuning ? g_active_tuning->wave_min_log2 : wave_min_log2().load(std::memory_order_relaxed); }

@@ -80,8 +80,14 @@ static hipError_t run_inv(const Inv2DArgs& g, int batch, int seg_hint, hipStream
     return hipGetLastError();
 }
 
+// The inverse keeps TWO tap tables in scalar registers -- (lo, hi)[j] pairs for the row synthesis, consecutive-tap pairs of each
+// filter for the column synthesis: 4 hlen SGPRs.  Up to 16 taps they fit; at 18 / 20 hipcc spills 25 / 212 of them into VGPR
+// lanes (and 20 B of scratch at 20 taps) and the kernel is level with the LDS tile (tools/ringbench.hip: 38.5 against 39.4 us):
+// those lengths keep the tile for the inverse.
+constexpr int kRingMaxHlenInv = 16;
+
 hipError_t try_launch_dwt2_inv_ring(const Inv2DArgs& a, int batch, hipStream_t s, int cpl, int seg_hint) {
-    if ((a.hlen & 1) || a.hlen < kRingMinHlen || a.hlen > kRingMaxHlen) return hipErrorNotSupported;
+    if ((a.hlen & 1) || a.hlen < kRingMinHlen || a.hlen > kRingMaxHlenInv) return hipErrorNotSupported;
     if ((a.Ncc & 1) || a.Nc != 2 * a.Ncc || (a.in_bstride & 1) || (a.out_bstride & 3)) return hipErrorNotSupported;
     if (a.Nr > 2 * a.Nrc || a.Nr < 2 * a.Nrc - 1) return hipErrorNotSupported;
     if ((long long)a.Nc * (long long)sizeof(real_t) >= (1LL << 31)) return hipErrorNotSupported;
@@ -93,7 +99,7 @@ hipError_t try_launch_dwt2_inv_ring(const Inv2DArgs& a, int batch, hipStream_t s
 #else
 #define X(h) case h: return cpl == 4 ? run_inv<h, 4>(a, batch, seg_hint, s) : hipErrorNotSupported;
 #endif
-        X(10) X(12) X(14) X(16) X(18) X(20)
+        X(10) X(12) X(14) X(16)
 #undef X
     }
     return hipErrorNotSupported;

@@ -67,11 +67,30 @@ def test_dry_run_world2_gloo():
     assert out["n_gpus"] == 2 and out["steps"] == 4 and out["scaling"] == "weak"
     # rank 1 sleeps 2 ms per step, rank 0 1 ms: the reported time is the MAX over ranks
     assert out["ms_per_step"] >= 1.9
+    # three regions, the line's figure is their median
+    regions = out["config"]["timed_regions_ms"]
+    assert len(regions) == 3 and abs(sorted(regions)[1] - out["config"]["timed_region_ms"]) < 1e-9
+    # the same-workload one-rank reference: rank 0 alone takes 1 ms per step; two ranks at the pace of the slower one (2 ms) on
+    # twice the images are as fast as one rank alone, i.e. half of perfect scaling
+    ref = out["scaling_reference"]
+    assert 0.9 <= ref["one_gpu_same_workload_ms_per_step"] <= 1.6, ref
+    assert 0.35 <= ref["efficiency"] <= 0.75, ref
+    assert abs(ref["efficiency"] - out["value"] / (2 * ref["one_gpu_same_workload_Msamples_s"])) < 1e-9
 
 
 def test_dry_run_single():
     out = _run([sys.executable, "bench.py", "--steps", "3", "--dry-run"])
     assert out["n_gpus"] == 1 and out["vs_baseline"] is None
+    assert out["scaling_reference"] is None and len(out["config"]["timed_regions_ms"]) == 3
+
+
+def test_metric_names_the_workload():
+    import bench
+    one = bench.metric_name("cfg2", bench.CONFIGS["cfg2"][7], 1)
+    shard = bench.metric_name("cfg5", bench.CONFIGS["cfg5"][7], 128)
+    assert "4096x4096 fp32 db4 L4" in one and "4096x4096 fp32 db4 L4" in shard and one != shard
+    assert "cfg2" in one and "cfg5" in shard and "128" in shard
+    assert bench.median([3.0, 1.0, 2.0]) == 2.0 and bench.median([4.0, 1.0]) == 2.5
 
 
 def test_gpus_flag_starts_the_ranks_itself():

@@ -1,6 +1,6 @@
 """GPU parity of the register-ring level kernels for long filters (pypwt_amd/csrc/dwt2_ring_kernels.hpp; reference:
 w_kern_forward_pass1/2 and w_kern_inverse_pass1/2, pdwt/src/separable.cu:91-176, 246-328, which take every hlen <= 40).
-By default they serve levels of at least 2^24 samples with 12-20 taps; here pdwt_set_tuning("ring_min_log2", 0) sends every
+By default they serve levels of at least 2^25 samples (batches) with 12 or 16 taps; here pdwt_set_tuning("ring_min_log2", 0) sends every
 eligible level (10-20 taps, any width that is a multiple of 4) through them, every level as its own launch, and the results
 are compared with the CPU oracle element by element.  The default dispatch at full size is the last test."""
 import os
@@ -94,15 +94,42 @@ def test_ring_custom_filters_and_reconstruction():
     assert np.abs(w.image - want).max() <= 1e-5 * max(float(np.abs(want).max()), 1.0)
 
 
-def test_ring_default_dispatch_full_size_every_element():
-    """What the plan launches by itself: 4096^2 sym8 level 1 is the register-ring kernels' home ground (>= 2^24 samples)."""
-    from pypwt_amd import Wavelets, _lib
+def test_ring_full_size_every_element():
+    """One 4096^2 image, level 1 (2048 wavefronts of 16-row segments, both walking directions), every element."""
+    from pypwt_amd import _lib
     lib = _lib.load()
     was = lib.pdwt_set_tuning(b"ring_min_log2", 24)
     try:
         x = oracle.hash_input((4096, 4096), 4096)
         for wname in ("sym8", "db6", "db10"):
-            w = _check(x, wname, 1, "default")
+            w = _check(x, wname, 1, "4096")
             assert np.abs(w.image - x).max() < 7e-4 * 255, wname  # the reference's reconstruction bound (test_wavelets.py:545) on 0..255 data
     finally:
+        lib.pdwt_set_tuning(b"ring_min_log2", was)
+
+
+def test_ring_default_dispatch_of_a_batch():
+    """What the plan launches by itself: two 4096 x 2048 images of 16 taps are 2^25 samples -- the register-ring kernels' home
+    ground; every element of both images against the oracle."""
+    from pypwt_amd import BatchedWavelets, _lib
+    lib = _lib.load()
+    was = lib.pdwt_set_tuning(b"ring_min_log2", 25)
+    os.environ.pop("PDWT_NO_PYRAMID", None)
+    try:
+        B, shape, L, wname = 4, (2048, 4096), 2, "sym8"
+        x = oracle.hash_input((B,) + shape, 2025)
+        bw = BatchedWavelets(B, shape[0], shape[1], wname, L)
+        bw.set_image(x)
+        bw.forward()
+        refs = [oracle.forward(x[b], wname, L) for b in range(B)]
+        for b in range(B):
+            for k, r in enumerate(refs[b]):
+                assert np.abs(bw.coeff_at(k, b) - r).max() <= 2e-6 * (1 + L) * max(float(np.abs(r).max()), 255.0), (b, k)
+        bw.inverse()
+        for b in range(B):
+            want = oracle.inverse(refs[b], shape, wname, L)
+            assert np.abs(bw.image_at(b) - want).max() <= 2e-6 * (1 + L) * 255.0, b
+            assert np.abs(bw.image_at(b) - x[b]).max() < 7e-4 * 255
+    finally:
+        os.environ["PDWT_NO_PYRAMID"] = "1"
         lib.pdwt_set_tuning(b"ring_min_log2", was)

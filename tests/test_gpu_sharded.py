@@ -97,3 +97,23 @@ def test_bench_single_process_sharded_over_the_one_gpu():
     assert out["n_gpus"] == 2 and out["config"]["images_per_step"] == 6
     assert out["config"]["shards"] == [[0, 0, 3], [0, 3, 6]] and "ONE process" in out["config"]["parallelism"]
     assert out["value"] > 0 and "shared_gpu_test_run" in out["config"]
+
+
+def test_bench_default_line_carries_every_baseline_configuration():
+    """VERDICT round 4, task 2: the driver's own invocation (no flags but steps / warmup) puts all five BASELINE
+    configurations on ONE line -- cfg2 as the headline, cfg1 / cfg3 / cfg4 under extra.configs with their step time, roofline
+    fraction, dominant kernel and copy floor, cfg5's shard under extra.cfg5_shard_one_gpu -- within seconds."""
+    import time
+    t0 = time.time()
+    out = _bench("--steps", "20", "--warmup", "5", "--no-cpu-baseline")
+    wall = time.time() - t0
+    assert "cfg2" in out["metric"] and len(out["config"]["timed_regions_ms"]) == 3
+    cfgs = out["extra"]["configs"]
+    for name in ("cfg1", "cfg3", "cfg4"):
+        c = cfgs[name]
+        assert "error" not in c, c
+        assert c["steps"] == 20 and c["ms_per_step"] > 0 and 0 < c["frac_of_hbm_peak"] < 1.0, (name, c)
+        assert c["dominant_kernel"] and c["dominant_kernel_us"] > 0 and c["copy_floor_us_per_step"] > 0, (name, c)
+        assert len(c["timed_regions_ms_per_step"]) == 3
+    assert "cfg5_shard_one_gpu" in out["extra"]
+    assert wall < 60, wall  # python start-up + plan creation included; the measurements themselves are a few seconds

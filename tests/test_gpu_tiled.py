@@ -172,3 +172,9 @@ def test_bench_two_ranks_on_the_gpu_box(config, extra):
     assert "shared_gpu_test_run" in out["config"] and "multi_gpu_note" in out["config"]
     assert out["config"]["images_per_step"] == 2 and out["scaling"] == ("strong" if extra else "weak")
     assert "cpu_baseline" not in out or out["cpu_baseline"] is None or isinstance(out["cpu_baseline"], dict)
+    # the line carries its own one-GPU reference on the SAME workload (rank 0 alone on its shard) and three timed regions
+    ref = out["scaling_reference"]
+    assert ref["one_gpu_same_workload_Msamples_s"] > 0 and ref["one_gpu_same_workload_ms_per_step"] > 0
+    assert abs(ref["efficiency"] - out["value"] / (2 * ref["one_gpu_same_workload_Msamples_s"])) < 1e-6 * max(1.0, ref["efficiency"])
+    assert 0.2 < ref["efficiency"] < 1.3, ref  # two ranks SHARING one GPU: about half of perfect scaling, never more than all of it
+    assert len(out["config"]["timed_regions_ms"]) == 3 and config in out["metric"]
