@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "../../include/pypwt_amd.h"
+#include "../../include/pypwt_amd_bench.h"
 #include "kernels_common.hpp"
 #include "launch.hpp"
 

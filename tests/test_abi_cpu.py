@@ -19,10 +19,29 @@ def lib():
     return _lib.load()
 
 
-def header_functions():
-    txt = open(os.path.join(ROOT, "include", "pypwt_amd.h")).read()
-    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\b(pdwt_[a-z0-9_]+)\s*\(", txt)))
+def header_functions(which=("pypwt_amd.h", "pypwt_amd_bench.h")):
+    """Every function the headers declare: the contract (pypwt_amd.h) and the measurement / test hooks (pypwt_amd_bench.h)."""
+    names = set()
+    for h in which:
+        txt = open(os.path.join(ROOT, "include", h)).read()
+        txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+        names |= set(re.findall(r"\b(pdwt_[a-z0-9_]+)\s*\(", txt))
+    return sorted(names)
+
+
+BENCH_ONLY = {"pdwt_fill_image_hash", "pdwt_enable_kernel_timing", "pdwt_kernel_times", "pdwt_reset_kernel_times", "pdwt_time_level",
+              "pdwt_time_copy", "pdwt_copy_capacity", "pdwt_schedule_string", "pdwt_set_tuning"}
+
+
+def test_the_contract_header_holds_no_measurement_hook():
+    """an integrator reads pypwt_amd.h and finds the reference's members (plus the batch / stream / device
+    plumbing); timing, micro-benchmarks, the synthetic input and the dispatch knobs live in pypwt_amd_bench.h."""
+    contract, bench = set(header_functions(("pypwt_amd.h",))), set(header_functions(("pypwt_amd_bench.h",)))
+    assert not (contract & BENCH_ONLY), contract & BENCH_ONLY
+    assert bench == BENCH_ONLY, bench ^ BENCH_ONLY
+    assert '#include "pypwt_amd.h"' in open(os.path.join(ROOT, "include", "pypwt_amd_bench.h")).read()
+    src = open(os.path.join(ROOT, "tests", "c_abi", "roundtrip.c")).read()
+    assert "pypwt_amd_bench.h" not in src  # the plain-C client of the contract needs none of it
 
 
 def test_library_exports_every_header_symbol(lib):
@@ -191,7 +210,7 @@ def test_python_class_has_the_reference_api_surface():
 def test_tuning_keys_documented_in_the_header_exist_and_round_trip(lib):
     """pdwt_set_tuning needs no device: every key the header documents is accepted, returns the previous value and can be
     restored; an unknown key is an argument error."""
-    txt = open(os.path.join(ROOT, "include", "pypwt_amd.h")).read()
+    txt = open(os.path.join(ROOT, "include", "pypwt_amd_bench.h")).read()
     doc = txt[txt.index("process-wide dispatch knobs"):txt.index("int pdwt_set_tuning")]
     keys = sorted(set(re.findall(r'"([a-z0-9_]+)"', doc)))
     assert {"wave_min_log2", "lds_max_log2", "reg1d", "swt_fused", "swt_split_fwd", "swt_split_inv", "chain", "wave2"} <= set(keys)
