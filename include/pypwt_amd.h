@@ -204,9 +204,9 @@ int pdwt_wait_for_stream(pdwt_handle h, void* producer_stream);
 int pdwt_device_of_pointer(const void* device_ptr);
 int pdwt_sync_producer(int device_id, void* producer_stream, int whole_device);
 /* Bind the plan's IMAGE to device memory the caller owns: from now on forward() reads its input there and inverse()
- * writes its reconstruction there (batch x Nr x Nc elements, row-major, on the plan's device; 16-byte aligned for the tuned
- * kernels -- otherwise the generic ones run); pdwt_image_ptr returns it; the plan's own image buffer is unused.  NULL
- * unbinds.  The memory must outlive the binding; nothing is copied.  Use: chaining plans without copies -- one level's
+ * writes its reconstruction there (batch x Nr x Nc elements, row-major, on the plan's device; 16-byte aligned -- PDWT_ERR_ARG
+ * otherwise: the tuned kernels stage the image with 16-byte accesses); pdwt_image_ptr returns it; the plan's own image buffer is
+ * unused.  NULL unbinds.  pdwt_clone of a bound plan copies the image: the clone owns its copy and is not bound.  The memory must outlive the binding; nothing is copied.  Use: chaining plans without copies -- one level's
  * approximation band (pdwt_coeff_ptr(prev, 0)) IS the next level plan's image (pypwt_amd/tiled.py keeps the row slabs of an
  * image tiled over several GPUs that way).  No reference counterpart (the reference owns all its buffers, wt.cu:527-539).
  * Synchronises the plan's stream. */

@@ -25,6 +25,10 @@ int pdwt_fill_image_hash(pdwt_handle h, uint32_t seed, pdwt_real scale, long lon
 int pdwt_enable_kernel_timing(pdwt_handle h, int enable);
 int pdwt_kernel_times(pdwt_handle h, float* ms, char (*names)[48], int cap);
 int pdwt_reset_kernel_times(pdwt_handle h);
+/* which of a step's alternative kernels served each recorded launch, same order and count as pdwt_kernel_times: "tile" (LDS
+ * tiles), "wave" (registers + DPP), "ring" (register ring + LDS row halo), "generic" for the level launches of the 2D DWT, ""
+ * for steps that have one kernel.  The launch NAMES stay what they were ("dwt2_fwd_level", ...): bench.py labels by them. */
+int pdwt_kernel_families(pdwt_handle h, char (*families)[16], int cap);
 /* micro-benchmark of ONE level: the launch(es) of level `level` (1 = finest; for fused multi-level
  * 1D launches: the first level of the group) of the forward (inverse = 0) or inverse transform are
  * enqueued `reps` times back to back between two HIP events on the plan's stream; returns the mean
@@ -82,7 +86,7 @@ long long pdwt_copy_capacity(pdwt_handle h); /* the largest `elems` pdwt_time_co
  *                    multiple of 8) instead of one LDS-tiled launch.  Default 0 (never): measured no faster than LDS tiles
  *                    of the right shape on MI355X (40 taps 2048^2 L5 forward 91 against 53 us), so the kernels are compiled
  *                    into the test library libpypwt_amd_lab.so only and the product accepts the keys and does nothing;
- *                    100 + n = n taps at every size (tests).  Read at every level launch.
+ *                    100 + n = n taps at every size (tests).  Part of the plan's snapshot.
  *   "chain"          levels 1..K of a 2D DWT in ONE launch with in-launch hand-offs between the levels
  *                    (dwt2_chain_kernels.hpp; even filters of at most 8 taps, whole 16 x 128 tiles at every level):
  *                    0 (default): never -- measured break-even for two levels and slower beyond on MI355X; 1: one

@@ -96,6 +96,7 @@ def signatures(real=C.c_float):
         "pdwt_fill_image_hash": (C.c_int, [handle_t, C.c_uint32, real, C.c_longlong]),
         "pdwt_enable_kernel_timing": (C.c_int, [handle_t, C.c_int]),
         "pdwt_kernel_times": (C.c_int, [handle_t, f32p, C.c_void_p, C.c_int]),
+        "pdwt_kernel_families": (C.c_int, [handle_t, C.c_void_p, C.c_int]),
         "pdwt_reset_kernel_times": (C.c_int, [handle_t]),
         "pdwt_time_level": (C.c_int, [handle_t, C.c_int, C.c_int, C.c_int, f32p]),
         "pdwt_time_copy": (C.c_int, [handle_t, C.c_longlong, C.c_int, f32p]),

@@ -23,25 +23,60 @@ def _check(lib, rc, what):
     return rc
 
 
+HELLO = b"PDWTID1 "  # + b"<rank> <nonce>\n"
+
+
+def _nonce():
+    """Ranks of ONE job agree on it without talking: the launcher exports the same TORCHELASTIC_RUN_ID / PDWT_COMM_NONCE /
+    MASTER_PORT to all of them.  A stray connection (a port scanner, a rank of a previous run) does not know it."""
+    return (os.environ.get("PDWT_COMM_NONCE") or os.environ.get("TORCHELASTIC_RUN_ID") or "port%s" % os.environ.get("MASTER_PORT", "29500")).encode()
+
+
+def _recv_line(conn, limit=256):
+    buf = b""
+    while not buf.endswith(b"\n") and len(buf) < limit:
+        chunk = conn.recv(1)
+        if not chunk:
+            break
+        buf += chunk
+    return buf
+
+
 def _share_id(rank, size, unique_id, addr, port, timeout=120.0):
-    """rank 0 -> every other rank: the 128 bytes of the RCCL unique id, one TCP connection per rank"""
+    """rank 0 -> every other rank: the 128 bytes of the RCCL unique id, one TCP connection per rank.  A client says who it is
+    (`PDWTID1 <rank> <nonce>`); rank 0 serves each of the ranks 1 .. size-1 once and drops every connection that does not
+    say so (it does not count against the ranks it is waiting for).  IPv4 and IPv6 (socket.create_server / getaddrinfo).
+    The id can be carried by any other channel instead (a file, MPI): Communicator(rank, size, unique_id)."""
     if size == 1:
         return unique_id
+    nonce = _nonce()
     if rank == 0:
-        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as srv:
-            srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
-            srv.bind((addr, port))
-            srv.listen(size)
-            srv.settimeout(timeout)
-            for _ in range(size - 1):
+        family = socket.AF_INET6 if ":" in addr else socket.AF_INET
+        deadline = time.time() + timeout
+        with socket.create_server((addr, port), family=family, backlog=max(8, size), reuse_port=False) as srv:
+            waiting = set(range(1, size))
+            while waiting:
+                srv.settimeout(max(0.1, deadline - time.time()))
+                if time.time() > deadline:
+                    raise TimeoutError("Communicator: ranks %s never asked for the unique id" % sorted(waiting))
                 conn, _ = srv.accept()
                 with conn:
-                    conn.sendall(unique_id)
+                    conn.settimeout(5.0)
+                    try:
+                        hello = _recv_line(conn)
+                        parts = hello[len(HELLO):].split()
+                        if not hello.startswith(HELLO) or len(parts) != 2 or parts[1] != nonce or int(parts[0]) not in waiting:
+                            continue  # not one of ours (or a rank served already): dropped, nobody's turn is used up
+                        conn.sendall(unique_id)
+                        waiting.discard(int(parts[0]))
+                    except (OSError, ValueError):
+                        continue
         return unique_id
     deadline = time.time() + timeout
     while True:
         try:
             with socket.create_connection((addr, port), timeout=5.0) as s:
+                s.sendall(HELLO + b"%d " % rank + nonce + b"\n")
                 buf = b""
                 while len(buf) < ID_BYTES:
                     chunk = s.recv(ID_BYTES - len(buf))

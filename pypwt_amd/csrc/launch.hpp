@@ -21,6 +21,7 @@ enum EwOp { EW_SOFT = 0, EW_HARD = 1, EW_LINF = 2, EW_SCALE = 3 };
 // (direct calls of the launchers: tools, emulation) the process-wide values apply.
 struct Tuning {
     int wave_min_log2, lds_max_log2, swt_split_fwd, swt_split_inv, dwt_split_fwd, dwt_split_inv, ring_min_log2;
+    int wave2, swt_fused, chain, reg1d;  // read by build_schedule: a clone rebuilds its launch lists from its source's values
 };
 Tuning current_tuning();                  // the process-wide values now
 void set_active_tuning(const Tuning* t);  // thread-local; nullptr = the process-wide values
@@ -33,6 +34,11 @@ struct ActiveTuning {  // RAII: the plan's snapshot for the duration of a forwar
     ~ActiveTuning() { set_active_tuning(prev); }
 };
 
+// Which kernel FAMILY the last level launch of the calling thread went to ("tile", "wave", "ring", "generic", ...): the launch
+// names of a plan (pdwt_kernel_times) say which step ran, not which of the alternative kernels served a LEVEL step; the
+// dispatch-coverage test (tests/test_gpu_dispatch.py) reads this through pdwt_kernel_families.  Diagnostics only.
+void note_family(const char* family);
+const char* last_family();
 hipError_t launch_dwt2_fwd(const Fwd2DArgs& a, int batch, hipStream_t s);
 hipError_t launch_dwt2_inv(const Inv2DArgs& a, int batch, hipStream_t s);
 // tuned kernels; hipErrorNotSupported = preconditions not met, use the generic launcher

@@ -46,7 +46,7 @@ static hipError_t run_inv(const Inv1DFusedArgs& a, hipStream_t s) {
 
 // short rows: four row tiles per workgroup of 256 threads (dwt1_*_fused_rows_kernel)
 static bool short_rows(int N0) {
-    static const bool on = !(getenv("PDWT_FUSED1D_ROWS") && atoi(getenv("PDWT_FUSED1D_ROWS")) == 0);  // A/B measurements
+    static const bool on = !(lab_env("PDWT_FUSED1D_ROWS") && atoi(lab_env("PDWT_FUSED1D_ROWS")) == 0);  // A/B measurements
     return on && N0 <= 512;
 }
 template <int HLEN>
@@ -80,15 +80,15 @@ static hipError_t run_inv_rows(const Inv1DFusedArgs& a, hipStream_t s) {
 // 1024 x 64 level.  PDWT_ROWS_TAIL_ROW = longest such row (0 = never), PDWT_ROWS_TAIL_SAMPLES = samples per workgroup,
 // PDWT_ROWS_TAIL_MIN_LOG2 = smallest batch (A/B measurements).
 bool dwt1_rows_tail_applies(int rows, int N0, int K, int hlen) {
-    static const int max_row = getenv("PDWT_ROWS_TAIL_ROW") ? atoi(getenv("PDWT_ROWS_TAIL_ROW")) : 256;
-    static const bool forced = getenv("PDWT_ROWS_TAIL_ROW") != nullptr;  // the knob set: every filter up to that row length
-    static const int min_log2 = getenv("PDWT_ROWS_TAIL_MIN_LOG2") ? atoi(getenv("PDWT_ROWS_TAIL_MIN_LOG2")) : 16;  // smallest batch (log2 samples)
+    static const int max_row = lab_env("PDWT_ROWS_TAIL_ROW") ? atoi(lab_env("PDWT_ROWS_TAIL_ROW")) : 256;
+    static const bool forced = lab_env("PDWT_ROWS_TAIL_ROW") != nullptr;  // the knob set: every filter up to that row length
+    static const int min_log2 = lab_env("PDWT_ROWS_TAIL_MIN_LOG2") ? atoi(lab_env("PDWT_ROWS_TAIL_MIN_LOG2")) : 16;  // smallest batch (log2 samples)
     if (N0 > max_row || N0 > kRowsTailSamples || K > kRowsTailMaxLevels || hlen > 20 || (long long)rows * N0 < (1LL << min_log2)) return false;
     return forced || N0 <= 64 || (N0 <= 128 && hlen <= 8) || (N0 <= 256 && hlen <= 2);
 }
 template <int HLEN>
 static hipError_t run_rows_tail(RowsTailArgs& a, bool inverse, hipStream_t s) {
-    static const int samples = getenv("PDWT_ROWS_TAIL_SAMPLES") ? atoi(getenv("PDWT_ROWS_TAIL_SAMPLES")) : kRowsTailSamples;
+    static const int samples = lab_env("PDWT_ROWS_TAIL_SAMPLES") ? atoi(lab_env("PDWT_ROWS_TAIL_SAMPLES")) : kRowsTailSamples;
     constexpr int NT = 64;
     int G = (samples < kRowsTailSamples ? samples : kRowsTailSamples) / a.N0;
     while (G > 1 && a.rows / G < 2048) G >>= 1;  // smaller batches: fewer rows per wavefront rather than an idle chip
@@ -145,7 +145,7 @@ hipError_t launch_dwt1_fwd_fused(const float* in, float* const* det, float* app,
 #undef X
         }
     }
-    static const bool wide = !(getenv("PDWT_FUSED1D_WIDE") && atoi(getenv("PDWT_FUSED1D_WIDE")) == 0);  // A/B measurements
+    static const bool wide = !(lab_env("PDWT_FUSED1D_WIDE") && atoi(lab_env("PDWT_FUSED1D_WIDE")) == 0);  // A/B measurements
     int TF = 64;
     if (wide && hlen <= 20 && K < 6) {
         TF = 64 << (6 - K);

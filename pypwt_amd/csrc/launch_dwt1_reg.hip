@@ -18,7 +18,7 @@ static void interleave(FilterBankI& o, const FilterBank& fb) {
 // ---- up to three levels per launch in registers (dwt1_reg_kernels.hpp)
 bool dwt1_reg_supported(int hlen, int N0, int K) {
     const int q = (4 << K) > 16 ? (4 << K) : 16;  // 16-B loads of whole lanes; every store unit inside its row
-    static const int nmin = [] { const char* e = getenv("PDWT_REG1_MIN"); return e ? atoi(e) : 2048; }();  // tuning
+    static const int nmin = [] { const char* e = lab_env("PDWT_REG1_MIN"); return e ? atoi(e) : 2048; }();  // tuning
     return !(hlen & 1) && hlen >= 2 && hlen <= kReg1MaxHlen && K >= 1 && K <= kReg1MaxLevels && N0 >= nmin &&
            (N0 % q) == 0 && (long long)N0 * (long long)sizeof(real_t) < (1LL << 31);  // row byte offsets below kReg1Dropped
 }
@@ -29,7 +29,7 @@ static int reg1_blocks_per_wave(long long total_blocks) {
     // full -- while the 2300 blocks of the second launch (levels 4-6) take 9.0 us at 1, 12.3 at 9 and 18.4 at 18:
     // a launch that small wants every SIMD busy.  Hence: about 2048 wavefronts, one block each below 4096 blocks.
     // PDWT_REG1_BPW overrides (tuning).
-    static const int forced = [] { const char* e = getenv("PDWT_REG1_BPW"); return e ? atoi(e) : 0; }();
+    static const int forced = [] { const char* e = lab_env("PDWT_REG1_BPW"); return e ? atoi(e) : 0; }();
     if (forced > 0) return forced;
     if (total_blocks <= 4096) return 1;
     const long long b = (total_blocks + 2047) / 2048;

@@ -90,7 +90,7 @@ constexpr int kWaveMinDefault = 16;
 constexpr int kWaveMinDefault = 22;
 #endif
 static std::atomic<int>& wave_min_log2() {
-    static std::atomic<int> v{getenv("PDWT_NO_WAVE") ? 63 : (getenv("PDWT_WAVE_MIN") ? atoi(getenv("PDWT_WAVE_MIN")) : kWaveMinDefault)};
+    static std::atomic<int> v{lab_env("PDWT_NO_WAVE") ? 63 : (lab_env("PDWT_WAVE_MIN") ? atoi(lab_env("PDWT_WAVE_MIN")) : kWaveMinDefault)};
     return v;
 }
 int set_wave_min_log2(int value) {  // pdwt_set_tuning("wave_min_log2")
@@ -100,29 +100,38 @@ int set_wave_min_log2(int value) {  // pdwt_set_tuning("wave_min_log2")
 }
 int get_wave_min_log2() { return wave_min_log2().load(std::memory_order_relaxed); }
 static std::atomic<int>& wave2_flag() {
-    static std::atomic<int> v{getenv("PDWT_WAVE2") ? 1 : 0};
+    static std::atomic<int> v{lab_env("PDWT_WAVE2") ? 1 : 0};
     return v;
 }
 static std::atomic<int>& swt_fused_flag() {
-    static std::atomic<int> v{getenv("PDWT_SWT_FUSED") ? atoi(getenv("PDWT_SWT_FUSED")) : 1};
+    static std::atomic<int> v{lab_env("PDWT_SWT_FUSED") ? atoi(lab_env("PDWT_SWT_FUSED")) : 1};
     return v;
 }
 int set_swt_fused_enabled(int value) { return swt_fused_flag().exchange(value < 0 ? 0 : (value > 2 ? 2 : value)); }
 int get_swt_fused_enabled() { return swt_fused_flag().load(std::memory_order_relaxed); }
 static std::atomic<int>& reg1d_flag() {
-    static std::atomic<int> v{getenv("PDWT_REG1D") ? (atoi(getenv("PDWT_REG1D")) & 15) : 3};
+    static std::atomic<int> v{lab_env("PDWT_REG1D") ? (atoi(lab_env("PDWT_REG1D")) & 15) : 3};
     return v;
 }
 int set_reg1d_enabled(int value) { return reg1d_flag().exchange(value < 0 ? 0 : (value > 15 ? 15 : value)); }  // four flag bits
 int get_reg1d_enabled() { return reg1d_flag().load(std::memory_order_relaxed); }
 static std::atomic<int>& chain_flag() {
-    static std::atomic<int> v{getenv("PDWT_CHAIN") ? atoi(getenv("PDWT_CHAIN")) : 0};  // opt-in: measured no faster, see plan.cpp
+    static std::atomic<int> v{lab_env("PDWT_CHAIN") ? atoi(lab_env("PDWT_CHAIN")) : 0};  // opt-in: measured no faster, see plan.cpp
     return v;
 }
 int set_chain_enabled(int value) { return chain_flag().exchange(value < 0 ? 0 : (value > 3 ? 3 : value)); }
 int get_chain_enabled() { return chain_flag().load(std::memory_order_relaxed); }
 int set_wave2_enabled(int value) { return wave2_flag().exchange(value ? 1 : 0); }
 int get_wave2_enabled() { return wave2_flag().load(std::memory_order_relaxed); }
+static thread_local const char* g_last_family = "";
+void note_family(const char* family) { g_last_family = family; }
+const char* last_family() { return g_last_family; }
+// a launcher's verdict: hipErrorNotSupported = it declined (try the next one); anything else = it launched (or failed)
+static bool took(hipError_t e, const char* family) {
+    if (e == hipErrorNotSupported) return false;
+    note_family(family);
+    return true;
+}
 static thread_local const Tuning* g_active_tuning = nullptr;
 void set_active_tuning(const Tuning* t) { g_active_tuning = t; }
 const Tuning* active_tuning() { return g_active_tuning; }
@@ -172,7 +181,7 @@ constexpr int kLdsMaxDefault = 0;   // no tuned LDS tiles in the fp64 build
 constexpr int kLdsMaxDefault = 25;
 #endif
 static std::atomic<int>& lds_max_log2() {
-    static std::atomic<int> v{getenv("PDWT_LDS_MAX") ? atoi(getenv("PDWT_LDS_MAX")) : kLdsMaxDefault};
+    static std::atomic<int> v{lab_env("PDWT_LDS_MAX") ? atoi(lab_env("PDWT_LDS_MAX")) : kLdsMaxDefault};
     return v;
 }
 int set_lds_max_log2(int value) { return lds_max_log2().exchange(value < 0 ? 0 : (value > 62 ? 62 : value)); }
@@ -193,7 +202,7 @@ static bool lds_tiles_for(long long samples, int hlen, long long per_image = 0, 
 // tools/planprof.sh; the whole db4 L3 plan 155.7 -> see profiles/r04zc_small_batches.txt).  fp32 only (the fp64 library has
 // no tuned tile to fall back to); a threshold forced below its default -- tests -- still takes the wave kernels.
 static bool narrow_for_wave(int Nc) {
-    static const int min_nc = getenv("PDWT_WAVE_MIN_NC") ? atoi(getenv("PDWT_WAVE_MIN_NC")) : 512;  // two full strips; A/B measurements
+    static const int min_nc = lab_env("PDWT_WAVE_MIN_NC") ? atoi(lab_env("PDWT_WAVE_MIN_NC")) : 512;  // two full strips; A/B measurements
     return sizeof(real_t) == 4 && Nc < min_nc && eff_wave_min_log2() >= kWaveMinDefault;
 }
 
@@ -206,17 +215,21 @@ Tuning current_tuning() {
     t.dwt_split_fwd = get_dwt_split_min(0);
     t.dwt_split_inv = get_dwt_split_min(1);
     t.ring_min_log2 = get_ring_min_log2();
+    t.wave2 = get_wave2_enabled();
+    t.swt_fused = get_swt_fused_enabled();
+    t.chain = get_chain_enabled();
+    t.reg1d = get_reg1d_enabled();
     return t;
 }
 
 hipError_t launch_dwt2_fwd(const Fwd2DArgs& a, int batch, hipStream_t s) {
     if (ring_kernels_for((long long)batch * a.Nr * a.Nc, a.hlen, a.Nc)) {
         const hipError_t e = try_launch_dwt2_fwd_ring(a, batch, s);
-        if (e != hipErrorNotSupported) return e;
+        if (took(e, "ring")) return e;
     }
     if (lds_tiles_for((long long)batch * a.Nr * a.Nc, a.hlen, (long long)a.Nr * a.Nc, false)) {
         const hipError_t e = try_launch_dwt2_fwd_fast(a, batch, s);
-        if (e != hipErrorNotSupported) return e;
+        if (took(e, "tile")) return e;
     }
     // (fp32, 4 taps: hipcc schedules the wave forward kernel's row loop with an s_waitcnt vmcnt(1) behind its stores, i.e. one
     // store round trip per four rows -- db2 2048^2 22.6 us against 9.8 us on the LDS tiles, found in round 4 by the reference's
@@ -225,12 +238,13 @@ hipError_t launch_dwt2_fwd(const Fwd2DArgs& a, int batch, hipStream_t s) {
     const bool slow4 = sizeof(real_t) == 4 && a.hlen == 4 && eff_wave_min_log2() >= kWaveMinDefault;
     if (wave_kernels_for((long long)batch * a.Nr * a.Nc) && !slow4 && !narrow_for_wave(a.Nc)) {
         const hipError_t e = try_launch_dwt2_fwd_wave(a, batch, s);
-        if (e != hipErrorNotSupported) return e;
+        if (took(e, "wave")) return e;
     }
     {
         const hipError_t e = try_launch_dwt2_fwd_fast(a, batch, s);
-        if (e != hipErrorNotSupported) return e;
+        if (took(e, "tile")) return e;
     }
+    note_family("generic");
     if (a.hlen & 1) return run_fwd<0, 64, kTyLong < 16 ? kTyLong : 16, 256>(a, batch, s);
     switch (a.hlen) {
 #define X(h)                                                       \
@@ -251,11 +265,11 @@ hipError_t launch_dwt2_inv(const Inv2DArgs& a, int batch, hipStream_t s) {
     const long long samples = (long long)batch * a.Nr * a.Nc;
     if (ring_kernels_for(samples, a.hlen, a.Nc)) {
         const hipError_t e = try_launch_dwt2_inv_ring(a, batch, s);
-        if (e != hipErrorNotSupported) return e;
+        if (took(e, "ring")) return e;
     }
     if (lds_tiles_for(samples, a.hlen)) {
         const hipError_t e = try_launch_dwt2_inv_fast(a, batch, s);
-        if (e != hipErrorNotSupported) return e;
+        if (took(e, "tile")) return e;
     }
 #ifdef PDWT_DOUBLE
     constexpr long long kInvWaveMax = 1LL << 62;  // no tuned LDS tile to hand a large batch to
@@ -264,12 +278,13 @@ hipError_t launch_dwt2_inv(const Inv2DArgs& a, int batch, hipStream_t s) {
 #endif
     if (wave_kernels_for(samples) && samples < kInvWaveMax && !narrow_for_wave(a.Nc)) {
         const hipError_t e = try_launch_dwt2_inv_wave(a, batch, s);
-        if (e != hipErrorNotSupported) return e;
+        if (took(e, "wave")) return e;
     }
     {
         const hipError_t e = try_launch_dwt2_inv_fast(a, batch, s);
-        if (e != hipErrorNotSupported) return e;
+        if (took(e, "tile")) return e;
     }
+    note_family("generic");
     if (a.hlen & 1) return run_inv<0, 64, kTyLong < 16 ? kTyLong : 16, 256>(a, batch, s);
     switch (a.hlen) {
 #define X(h)                                                       \

@@ -25,14 +25,14 @@ bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 // 30 us: a producer that started before its consumer has long published by then (a tile lives 4-5 us).
 // pdwt_set_tuning("chain_timeout", ticks): tests set 0, which turns nearly every wait into the self-help path.
 std::atomic<int>& timeout_ticks() {
-    static std::atomic<int> v{getenv("PDWT_CHAIN_TIMEOUT") ? atoi(getenv("PDWT_CHAIN_TIMEOUT")) : 3000};
+    static std::atomic<int> v{lab_env("PDWT_CHAIN_TIMEOUT") ? atoi(lab_env("PDWT_CHAIN_TIMEOUT")) : 3000};
     return v;
 }
 
 template <int HLEN>
 hipError_t run(ChainArgs& q, bool inverse, bool stagger, hipStream_t s) {
     q.stagger = stagger ? 1 : 0;
-    static const int xcd = getenv("PDWT_CHAIN_XCD") ? atoi(getenv("PDWT_CHAIN_XCD")) : 1;
+    static const int xcd = lab_env("PDWT_CHAIN_XCD") ? atoi(lab_env("PDWT_CHAIN_XCD")) : 1;
     q.xcd_bands = xcd;
     const int steps = stagger ? q.batch + q.nl - 1 : q.batch;
     const long long blocks = (long long)steps * q.tiles_per_image;

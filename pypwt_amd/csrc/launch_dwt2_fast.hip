@@ -104,7 +104,7 @@ static hipError_t run_inv_fast(const Inv2DArgs& g, int batch, hipStream_t s) {
 }
 
 static bool lds_tiles_off() {  // A/B measurements: every level through the wave / generic kernels
-    static const bool off = getenv("PDWT_NO_LDS_TILES") != nullptr;
+    static const bool off = lab_env("PDWT_NO_LDS_TILES") != nullptr;
     return off;
 }
 
@@ -122,7 +122,7 @@ hipError_t try_launch_dwt2_fwd_fast(const Fwd2DArgs& a, int batch, hipStream_t s
     // 4096^2: 29.2 us (64x16, 512 threads) against 38.5 (profiles/r02y_kbench_tiles.txt).
 #ifdef PDWT_TILE_EXPERIMENT
     {   // A/B (16 and 40 taps only): PDWT_FWD_TILE = shape index
-        static const int forced = getenv("PDWT_FWD_TILE") ? atoi(getenv("PDWT_FWD_TILE")) : 0;
+        static const int forced = lab_env("PDWT_FWD_TILE") ? atoi(lab_env("PDWT_FWD_TILE")) : 0;
 #define PDWT_FT(h)                                                             \
         if (forced && a.hlen == h) {                                            \
             if (forced == 1) return run_fwd_fast<h, 64, 32, 256>(a, batch, s);       \
@@ -193,7 +193,7 @@ hipError_t try_launch_dwt2_inv_fast(const Inv2DArgs& a, int batch, hipStream_t s
     if (!aligned16(a.out) || !aligned16(a.A) || !aligned16(a.H) || !aligned16(a.V) || !aligned16(a.D))
         return hipErrorNotSupported;
     {   // A/B measurements (db4 only): PDWT_INV_TILE = 1: 128x16 / 512 threads, 2: 128x8 / 256, 3: 64x16 / 512, 4: 64x32 / 512
-        static const int forced = getenv("PDWT_INV_TILE") ? atoi(getenv("PDWT_INV_TILE")) : 0;
+        static const int forced = lab_env("PDWT_INV_TILE") ? atoi(lab_env("PDWT_INV_TILE")) : 0;
         if (forced && a.hlen == 8) {
             if (forced == 1) return run_inv_fast<8, 128, 16, 512>(a, batch, s);
             if (forced == 2) return run_inv_fast<8, 128, 8, 256>(a, batch, s);
@@ -203,7 +203,7 @@ hipError_t try_launch_dwt2_inv_fast(const Inv2DArgs& a, int batch, hipStream_t s
     }
 #ifdef PDWT_TILE_EXPERIMENT
     {
-        static const int forced = getenv("PDWT_INV_TILE2") ? atoi(getenv("PDWT_INV_TILE2")) : 0;
+        static const int forced = lab_env("PDWT_INV_TILE2") ? atoi(lab_env("PDWT_INV_TILE2")) : 0;
 #define PDWT_IT(h)                                                             \
         if (forced && a.hlen == h) {                                            \
             if (forced == 1) return run_inv_fast<h, 64, 32, 256>(a, batch, s);   \

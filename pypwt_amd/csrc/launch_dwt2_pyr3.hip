@@ -40,14 +40,14 @@ bool dwt2_pyr3_supported(int hlen, int N0r, int N0c) {
 // way: 15.6); 256^2 haar L3  7.9 / 8.0 / 7.3 (15.5); 64 x 128^2 db4 L3  20.3 / 24.0 / 34.6 (27.0).
 // PDWT_PYR3_T / PDWT_PYR3_NT override (tuning).
 static int pyr3_tile(int N0r, int N0c, int batch) {
-    static const int forced = [] { const char* e = getenv("PDWT_PYR3_T"); return e ? atoi(e) : 0; }();
+    static const int forced = [] { const char* e = lab_env("PDWT_PYR3_T"); return e ? atoi(e) : 0; }();
     if (forced == 2 || forced == 4 || forced == 8) return forced;
     for (int T = 8; T > 2; T /= 2)
         if ((long long)cdiv(N0c / 8, T) * cdiv(N0r / 8, T) * batch >= 200) return T;
     return 2;
 }
 static int pyr3_threads(int T) {
-    static const int forced = [] { const char* e = getenv("PDWT_PYR3_NT"); return e ? atoi(e) : 0; }();
+    static const int forced = [] { const char* e = lab_env("PDWT_PYR3_NT"); return e ? atoi(e) : 0; }();
     if (forced == 256 || forced == 512 || forced == 1024) return forced;
     return T == 8 ? 1024 : 512;
 }

@@ -147,7 +147,7 @@ static hipError_t run_inv_strip(InvStrip2Args& a, int batch, hipStream_t s) {
     static_assert(lds <= 64 * 1024, "fits the default dynamic-LDS limit");
     a.strips = cdiv(a.N0c / 2, TX);
     int seg = 512;  // output rows per workgroup; one 16-row warm-up chunk per segment
-    static const int forced = getenv("PDWT_ISTRIP_SEG") ? atoi(getenv("PDWT_ISTRIP_SEG")) : 0;  // A/B measurements
+    static const int forced = lab_env("PDWT_ISTRIP_SEG") ? atoi(lab_env("PDWT_ISTRIP_SEG")) : 0;  // A/B measurements
     if (forced > 0) seg = forced;
     while (seg > 64 && (long long)a.strips * cdiv(a.N0r, seg) * batch < 1024) seg >>= 1;
     a.seg_rows = seg;

@@ -25,7 +25,7 @@
 namespace pdwt {
 
 static int env_int_d(const char* name, int dflt) {
-    const char* e = getenv(name);
+    const char* e = lab_env(name);
     return e ? atoi(e) : dflt;
 }
 

@@ -69,7 +69,7 @@ static hipError_t run_tail_p2(const TailArgs& a, bool inverse, int batch, hipStr
 // Power-of-two sizes: the mask / shift kernels; any other size: the general ones.
 template <int HLEN>
 static hipError_t run_tail_nt(TailArgs& a, bool inverse, int batch, hipStream_t s) {
-    static const int wave_max = getenv("PDWT_TAIL_WAVE_MAX") ? atoi(getenv("PDWT_TAIL_WAVE_MAX")) : 1024;
+    static const int wave_max = lab_env("PDWT_TAIL_WAVE_MAX") ? atoi(lab_env("PDWT_TAIL_WAVE_MAX")) : 1024;
     const int n0 = a.R0 * a.C0;
     const bool big = n0 > 4096, pow2 = a.lgR >= 0 && a.lgC >= 0;
     // ... once the batch alone fills the chip's 8192 wavefront slots (earlier for images of at most 256 samples, which leave three of

@@ -75,7 +75,7 @@ hipError_t launch_swt2_inv(const Swt2DArgs& a, int batch, hipStream_t s) {
 // four samples per work item (swt1_*_vec_kernel): rows filtered along x, Nc % 4 == 0, even compile-time filter length
 static bool swt1_vec_ok(const SwtPassArgs& a) {
     auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & (4 * sizeof(real_t) - 1)) == 0; };
-    static const bool off = getenv("PDWT_NO_SWT1_VEC") != nullptr;  // A/B measurements
+    static const bool off = lab_env("PDWT_NO_SWT1_VEC") != nullptr;  // A/B measurements
     // (fp64: the kernel keeps all taps of both bands of a work item in registers -- beyond 30 taps of doubles the inverse spills
     // to scratch, tools/spillscan.py; those lengths take the one-output-per-thread kernel)
     if (sizeof(real_t) == 8 && a.hlen > 30) return false;

@@ -32,7 +32,7 @@ bool swt2_fused_supported(int hlen, int Nr, int Nc, int l0, int K, bool inverse)
 // (profiles/r02w_*).  Hence: the longest segment that still gives 768 wavefronts.  PDWT_SWT_SEG overrides (tuning).
 static int fused_seg_rows(int K, int f0, int rows_phase, int strips, int batch) {
     const int P = 1 << K;  // SwtFusedGeom::P
-    static const int forced = [] { const char* e = getenv("PDWT_SWT_SEG"); return e ? atoi(e) : 0; }();
+    static const int forced = [] { const char* e = lab_env("PDWT_SWT_SEG"); return e ? atoi(e) : 0; }();
     int seg;
     if (forced > 0) {
         seg = (forced + P - 1) / P * P;
@@ -73,7 +73,7 @@ static hipError_t run(SwtFusedArgs& a, bool inverse, int batch, hipStream_t s) {
 #if defined(PDWT_DOUBLE)
         return run_inv<K, F0, 2>(a, batch, s);  // fp64: two doubles per lane (the four-column lanes need > 512 registers)
 #elif defined(PDWT_LAB_KERNELS)
-        static const int forced = [] { const char* e = getenv("PDWT_SWT_CPL"); return e ? atoi(e) : 0; }();
+        static const int forced = [] { const char* e = lab_env("PDWT_SWT_CPL"); return e ? atoi(e) : 0; }();
         return forced == 2 ? run_inv<K, F0, 2>(a, batch, s) : run_inv<K, F0, 4>(a, batch, s);
 #else
         return run_inv<K, F0, 4>(a, batch, s);
@@ -97,7 +97,7 @@ static hipError_t run4(Swt4Args& a, bool inverse, int batch, hipStream_t s) {
     const int rows_phase = a.Nr / F0;
     // phase rows per wavefront: a segment walks 9 rows it does not own (one input plane: cheap), a wavefront wants ~1 us per
     // row: the longest multiple of 8 that still gives ~768 wavefronts
-    static const int forced = [] { const char* e = getenv("PDWT_SWT_SEG"); return e ? atoi(e) : 0; }();
+    static const int forced = [] { const char* e = lab_env("PDWT_SWT_SEG"); return e ? atoi(e) : 0; }();
     int seg = 256;
     auto waves_of = [&](int sg) { return (long long)batch * F0 * a.strips * cdiv(rows_phase, sg); };
     while (seg > 8 && waves_of(seg) < 768) seg -= 8;
@@ -108,7 +108,7 @@ static hipError_t run4(Swt4Args& a, bool inverse, int batch, hipStream_t s) {
     const long long waves = waves_of(seg);
     const unsigned grid = 8u * (unsigned)cdivll(cdivll(waves, NT / 64), 8);
     if (inverse) {
-        static const int nri = [] { const char* e = getenv("PDWT_SWT4_NRI"); return e ? atoi(e) : 4; }();  // load slots (A/B measurements)
+        static const int nri = [] { const char* e = lab_env("PDWT_SWT4_NRI"); return e ? atoi(e) : 4; }();  // load slots (A/B measurements)
         if (nri == 2) hipLaunchKernelGGL((swt4_inv_fused_kernel<F0, 2, NT>), dim3(grid), dim3(NT), 0, s, a, waves);
         else hipLaunchKernelGGL((swt4_inv_fused_kernel<F0, 4, NT>), dim3(grid), dim3(NT), 0, s, a, waves);
     } else {

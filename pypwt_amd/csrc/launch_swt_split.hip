@@ -31,7 +31,7 @@ static inline v2f mk2h(real_t a, real_t b) {
 }
 
 static int env_int(const char* name, int dflt) {
-    const char* e = getenv(name);
+    const char* e = lab_env(name);
     return e ? atoi(e) : dflt;
 }
 

@@ -36,7 +36,7 @@ hipError_t launch_swt2_tail(const real_t* in, real_t* const* det, real_t* out, i
     // times the images in flight) -- forward+inverse us: 65536 x 16^2 haar L3 737 -> 413, 262144 x 8^2 haar L2 1731 -> 535, 5000 x
     // 12x20 haar L2 57 -> 35; images of 784-1024 samples lose (every SWT level is full size: 16384 x 32^2 haar L3 401 -> 511,
     // profiles/r04zr_swt_tail_one_wavefront.txt).  PDWT_TAIL_WAVE_MAX = largest such image in samples (A/B measurements).
-    static const int wave_max = getenv("PDWT_TAIL_WAVE_MAX") ? atoi(getenv("PDWT_TAIL_WAVE_MAX")) : kSwtTailWaveSamples;
+    static const int wave_max = lab_env("PDWT_TAIL_WAVE_MAX") ? atoi(lab_env("PDWT_TAIL_WAVE_MAX")) : kSwtTailWaveSamples;
     const bool wave = n <= wave_max && n <= kSwtTailWaveSamples && batch >= 2048;
     const bool few = n <= 1024;  // 256 threads x 4 trips
     static std::atomic<bool> big[12][64] = {};

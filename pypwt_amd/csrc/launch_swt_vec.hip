@@ -46,7 +46,7 @@ hipError_t try_launch_swt2_vec(const Swt2DArgs& a, bool inverse, int batch, hipS
     // maximum-level plan (2048^2 haar L11: f = 1024, two rows per phase) a 16-row tile is 7/8 padding: forward level 11 34 us,
     // inverse 51 us against 16-20 us for the levels before.  Phases shorter than 16 rows take tiles of 8, 4 or 2 rows (2-8 taps).
     {
-        static const bool deep_tiles = !(getenv("PDWT_SWT_DEEP_TILE") && atoi(getenv("PDWT_SWT_DEEP_TILE")) == 0);  // A/B measurements
+        static const bool deep_tiles = !(lab_env("PDWT_SWT_DEEP_TILE") && atoi(lab_env("PDWT_SWT_DEEP_TILE")) == 0);  // A/B measurements
         const int M = a.Nr / a.f;
         if (deep_tiles && M < 16 && a.hlen <= 8 && sizeof(real_t) == 4) {
             switch (a.hlen) {
@@ -70,7 +70,7 @@ hipError_t try_launch_swt2_vec(const Swt2DArgs& a, bool inverse, int batch, hipS
     // Small levels (round 4): 128 x 16 tiles give a 256^2 image 32 workgroups on 256 CUs, each a long serial chain -- the time
     // of a level is one tile's latency (db4 256^2: 7.6 us forward, 13.4 us inverse per level).  Below 256 workgroups the
     // tiles shrink to 64 x 8 (128 threads): four times the workgroups, each a quarter of the chain.
-    static const int small_tiles = getenv("PDWT_SWT_SMALL_TILE") ? atoi(getenv("PDWT_SWT_SMALL_TILE")) : 256;  // workgroups; A/B measurements
+    static const int small_tiles = lab_env("PDWT_SWT_SMALL_TILE") ? atoi(lab_env("PDWT_SWT_SMALL_TILE")) : 256;  // workgroups; A/B measurements
     const long long wgs = (long long)cdiv(a.Nc, 128) * cdiv(a.Nr / a.f, 16) * a.f * batch;
     // (and, whatever the batch, on images of at most 64 columns: a 128-column tile there is half padding)
     if ((wgs < small_tiles || (a.Nc <= 64 && small_tiles > 0)) && a.hlen <= 24 && sizeof(real_t) == 4) {

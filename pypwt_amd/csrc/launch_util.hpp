@@ -3,9 +3,22 @@
 
 #include <hip/hip_runtime.h>
 
+#include <stdlib.h>
+
 #include <atomic>
 
 namespace pdwt {
+
+// Environment knobs.  The PRODUCT libraries read seven documented variables with plain getenv (the pool
+// limits, the RCCL library path and four "no fused launches" switches that tests and bug hunts use).  Everything else -- tile
+// shapes, thresholds, segment lengths of the A/B measurements -- goes through lab_env and exists only in the measurement
+// build libpypwt_amd_lab.so (-DPDWT_LAB_KERNELS): the product returns "unset" without looking, its dispatch is what the
+// sources say.  (Dispatch thresholds a caller may want to move at run time are pdwt_set_tuning keys, pypwt_amd_bench.h.)
+#ifdef PDWT_LAB_KERNELS
+static inline const char* lab_env(const char* name) { return getenv(name); }
+#else
+static inline const char* lab_env(const char*) { return nullptr; }
+#endif
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline long long cdivll(long long a, long long b) { return (a + b - 1) / b; }

@@ -19,6 +19,7 @@
 #include <strings.h>
 
 #include "launch.hpp"
+#include "launch_util.hpp"
 #include "nonsep_kernels.hpp"
 #include "wavelet_table.hpp"
 
@@ -180,14 +181,34 @@ void pool_return_stream(int dev, hipStream_t s) {
 // recorded by pdwt_kernel_times).  One event per launch instead of a start/stop pair halves the
 // perturbation (an event costs about 1 us of stream time on MI355X).
 struct Stamp {
-    Stamp(pdwt_plan* p, const char* name) {
+    pdwt_plan* plan = nullptr;
+    size_t index = 0;
+    bool pushed = false;  // this object's entry is plan->stamps[index] (a failed hipEventCreate pushes nothing)
+    const hipError_t* verdict = nullptr;  // the launcher's answer, when the caller has one: a decline takes the entry back
+    Stamp(pdwt_plan* p, const char* name, const hipError_t* launch_result = nullptr) : verdict(launch_result) {
         if (!p->timing) return;
         KernelStamp s;
         s.stop = nullptr;
+        s.family[0] = 0;
         if (hipEventCreate(&s.start) != hipSuccess) return;
         snprintf(s.name, sizeof(s.name), "%s", name);
         (void)hipEventRecord(s.start, p->stream);
+        note_family("");
+        plan = p;
+        index = p->stamps.size();
+        pushed = true;
         p->stamps.push_back(s);
+    }
+    // the launcher declined (hipErrorNotSupported) and the step falls back to other launches: take THIS entry back
+    void drop() {
+        if (!pushed || index + 1 != plan->stamps.size()) return;
+        (void)hipEventDestroy(plan->stamps.back().start);
+        plan->stamps.pop_back();
+        pushed = false;
+    }
+    ~Stamp() {  // after the launch: which kernel family served it
+        if (verdict && *verdict == hipErrorNotSupported) drop();  // the step falls back to level launches, which stamp themselves
+        if (pushed && index < plan->stamps.size()) snprintf(plan->stamps[index].family, sizeof(plan->stamps[index].family), "%s", last_family());
     }
 };
 
@@ -430,34 +451,34 @@ void build_schedule(pdwt_plan* p) {
         // bandwidth-bound and not writing + re-reading A_l pays (forward 284 -> 232 us for 8 x 4096^2,
         // profiles/r01f_kbench_strip.txt); the INVERSE strip kernel is no faster than two launches and only
         // runs under PDWT_FORCE_STRIP=1 (tests), which also drops the size threshold.
-        const bool no_pyr = getenv("PDWT_NO_PYRAMID") != nullptr, no_strip = getenv("PDWT_NO_STRIP") != nullptr;
-        const bool force_strip = getenv("PDWT_FORCE_STRIP") != nullptr;
+        const bool no_pyr = getenv("PDWT_NO_PYRAMID") != nullptr, no_strip = lab_env("PDWT_NO_STRIP") != nullptr;
+        const bool force_strip = lab_env("PDWT_FORCE_STRIP") != nullptr;
         auto samples = [&](int l) { return (long long)p->batch * p->lr[l - 1] * p->lc[l - 1]; };
         auto pair_ok = [&](int l) { return l + 1 <= L && dwt2_pyramid_supported(hlen, p->lr[l - 1], p->lc[l - 1]); };
         auto strip_at = [&](int l, bool inverse) {
-            static const bool inv_strip_l1 = getenv("PDWT_INV_STRIP") != nullptr;  // A/B: the inverse strips for levels 1+2 of a batch
+            static const bool inv_strip_l1 = lab_env("PDWT_INV_STRIP") != nullptr;  // A/B: the inverse strips for levels 1+2 of a batch
             if (!fusable || no_strip || !pair_ok(l) || !dwt2_strip_supported(hlen, p->lr[l - 1], p->lc[l - 1]) ||
                 (inverse && !force_strip && !(inv_strip_l1 && l == 1)))
                 return false;
             // (2-tap filters: no rows carried between chunks, the strips are ahead from 2^25 samples on -- forward of 8 x 2048^2
             // 63 -> 56 us, 32 x 1024^2 60 -> 52, 3 x 4096^2 106 -> 88; longer filters lose there: db4 2 x 4096^2 78 -> 83)
-            static const int strip_min = getenv("PDWT_STRIP_MIN_LOG2") ? atoi(getenv("PDWT_STRIP_MIN_LOG2")) : 0;  // A/B measurements
+            static const int strip_min = lab_env("PDWT_STRIP_MIN_LOG2") ? atoi(lab_env("PDWT_STRIP_MIN_LOG2")) : 0;  // A/B measurements
             const int min_log2 = strip_min > 0 ? strip_min : (hlen == 2 && sizeof(real_t) == 4 ? 25 : 26);
             return force_strip || samples(l) >= (1LL << min_log2);
         };
-        static const bool inv_pyr_l1 = getenv("PDWT_INV_PYR_L1") != nullptr;  // A/B: the tile pyramid for levels 1+2 of any inverse
+        static const bool inv_pyr_l1 = lab_env("PDWT_INV_PYR_L1") != nullptr;  // A/B: the tile pyramid for levels 1+2 of any inverse
         auto pyr_at = [&](int l) { return fusable && !no_pyr && pair_ok(l) && samples(l) <= (1LL << 20); };
         // Three levels per launch where a small image (at most 2^19 samples, 2^20 over the batch) has three (or five, six, ...) levels
         // left: one launch fewer per direction -- 512^2 db2 L3: 15.6 -> 9.9 us per forward+inverse, 256^2 db4 L5: 26.8 ->
         // 18.4 us, 64 x 128^2 db4 L3: 27.0 -> 20.3 us; at 1024^2 the pairs are ahead (db4 L3: 18.6 against 20.4 us).  Four levels left stay two tile
         // pyramids.  PDWT_NO_PYR3=1 keeps the pairs (A/B measurements).
-        const bool no_pyr3 = no_pyr || getenv("PDWT_NO_PYR3") != nullptr;
+        const bool no_pyr3 = no_pyr || lab_env("PDWT_NO_PYR3") != nullptr;
         auto pyr3_at = [&](int l, bool inverse) {
             const int left = L - l + 1;
             // (round 4: the FORWARD three-level kernel of 10-16 taps is behind three launches of the small LDS tiles of
             // launch_dwt2_fast.hip -- sym8 256^2: 11.0 against 9-10 us, 16 images of 256^2: 44.8 against 15.6 us; the inverse
             // stays ahead: 5.3 against 12.1 us; profiles/r04r_cliffs_batch_odd.txt)
-            if (!inverse && hlen > 8 && getenv("PDWT_PYR3_FWD_LONG") == nullptr) return false;  // (the knob: tests keep the kernel covered)
+            if (!inverse && hlen > 8 && lab_env("PDWT_PYR3_FWD_LONG") == nullptr) return false;  // (the knob: tests keep the kernel covered)
             // filters of 10-16 taps recompute a 16x larger halo: ahead up to 512^2 only (sym8 512^2 L3: 21.6 against 25.0 us,
             // 1024 x 512: 37.3 against 25.4 us; profiles/r02y_pyr3_sweep.txt)
             const long long per_image = hlen <= 8 ? (1LL << 19) : (1LL << 18);
@@ -469,7 +490,7 @@ void build_schedule(pdwt_plan* p) {
         // 21.9 + 7.9 us; 8 x 4096^2 267 us against 209 + ~50 us, streaming strips 229 us): one wavefront per SIMD is
         // issue-bound, and the second level's shifts, descriptors and 4-B stores add 50 % instructions for 20 %
         // fewer bytes.  Opt-in only: PDWT_WAVE2=1 or pdwt_set_tuning("wave2", 1) (tests keep it covered).
-        const bool wave2_on = get_wave2_enabled() != 0;
+        const bool wave2_on = p->tune.wave2 != 0;
         const int wmin = p->tune.wave_min_log2;
         auto wave2_at = [&](int l, bool inverse) {
             return fusable && !inverse && wave2_on && wmin < 63 && l + 1 <= L && samples(l) >= (1LL << wmin) &&
@@ -488,8 +509,8 @@ void build_schedule(pdwt_plan* p) {
         // plans therefore keep the fused inverse at any size.
         const long long swt_bytes = (long long)sizeof(real_t) * (3 * L + 2) * p->batch * p->info.Nr * p->info.Nc;
         auto swt_group = [&](int l, bool inverse) {
-            if (!swt || !p->do_separable || !get_swt_fused_enabled()) return 0;
-            if (swt_bytes > (320LL << 20) && get_swt_fused_enabled() < 2 && !(inverse && sizeof(real_t) == 4))
+            if (!swt || !p->do_separable || !p->tune.swt_fused) return 0;
+            if (swt_bytes > (320LL << 20) && p->tune.swt_fused < 2 && !(inverse && sizeof(real_t) == 4))
                 return 0;  // "swt_fused" = 2 forces both directions (tests)
             for (int K = (L - l + 1 < 3 ? L - l + 1 : 3); K >= 2; --K) {
                 const bool same_plane = K == 2 && l - 1 >= 1 && l + K - 1 <= L - 1;
@@ -505,7 +526,7 @@ void build_schedule(pdwt_plan* p) {
         // batch loses 16 % (every level-1 tile polls before it may load).  profiles/r03h_chain_sweep.txt.  "chain" knob
         // (PDWT_CHAIN): 0 never (default), 1 one cache-resident image (2^22 < samples <= 2^24) and the inverse of batches
         // of >= 2^26 samples, 2 wherever the kernel applies (tests), 3 = 2 and the batch forward too.
-        const int chain_mode = get_chain_enabled();
+        const int chain_mode = p->tune.chain;
         auto chain_at = [&](int l, bool inverse) {
             if (!fusable || chain_mode == 0 || l != 1 || L < 2) return 0;
             const long long per_image = (long long)p->lr[0] * p->lc[0];
@@ -513,7 +534,7 @@ void build_schedule(pdwt_plan* p) {
             const bool big_batch = samples(1) >= (1LL << 26) && (inverse || chain_mode >= 3);
             if (!(chain_mode >= 2 || one_image || big_batch)) return 0;
             int K = L < kChainMaxLevelsHost ? L : kChainMaxLevelsHost;
-            if (const char* e = getenv("PDWT_CHAIN_K")) K = atoi(e) < K ? atoi(e) : K;  // A/B measurements
+            if (const char* e = lab_env("PDWT_CHAIN_K")) K = atoi(e) < K ? atoi(e) : K;  // A/B measurements
             while (K >= 2 && !dwt2_chain_supported(hlen, p->lr[0], p->lc[0], K)) --K;
             return K >= 2 ? K : 0;
         };
@@ -548,9 +569,9 @@ void build_schedule(pdwt_plan* p) {
         // PDWT_NO_TAIL / PDWT_TAIL_WORK_LOG2 / PDWT_TAIL_MIN_K: A/B measurements.
         // (read per plan, not once per process: the parity tests widen the rule to reach every instantiation)
         const bool no_tail = getenv("PDWT_NO_TAIL") != nullptr;
-        const int tail_work_log2 = getenv("PDWT_TAIL_WORK_LOG2") ? atoi(getenv("PDWT_TAIL_WORK_LOG2")) : 14;
-        const int tail_min_k = getenv("PDWT_TAIL_MIN_K") ? atoi(getenv("PDWT_TAIL_MIN_K")) : 5;
-        const long long tail_batch = getenv("PDWT_TAIL_BATCH") ? atoll(getenv("PDWT_TAIL_BATCH")) : 4096;  // largest image taken in batch mode (0 = off)
+        const int tail_work_log2 = lab_env("PDWT_TAIL_WORK_LOG2") ? atoi(lab_env("PDWT_TAIL_WORK_LOG2")) : 14;
+        const int tail_min_k = lab_env("PDWT_TAIL_MIN_K") ? atoi(lab_env("PDWT_TAIL_MIN_K")) : 5;
+        const long long tail_batch = lab_env("PDWT_TAIL_BATCH") ? atoll(lab_env("PDWT_TAIL_BATCH")) : 4096;  // largest image taken in batch mode (0 = off)
         auto tail_at = [&](int l) {
             const int K = L - l + 1;
             const long long per_image = (long long)p->lr[l - 1] * p->lc[l - 1];
@@ -590,7 +611,7 @@ void build_schedule(pdwt_plan* p) {
             // four bands x hlen taps per output from global memory: db4 L2 1015 -> 739 us, but haar L3 458 -> 482; 32 x 32 and below
             // always: haar L3 16384 x 32^2 1176 -> 352, 65536 x 16^2 4520 -> 674, db4 L2 8192 x 32^2 1047 -> 202)
             const long long total = (long long)p->batch * per_image;
-            static const int few = getenv("PDWT_SWT_TAIL_FEW") ? atoi(getenv("PDWT_SWT_TAIL_FEW")) : 64;  // A/B measurements
+            static const int few = lab_env("PDWT_SWT_TAIL_FEW") ? atoi(lab_env("PDWT_SWT_TAIL_FEW")) : 64;  // A/B measurements
             // ... and the latency regime: a FEW tiny images with two levels and more -- one launch instead of one per level
             // (32 x 32 and below: 16 x 32^2 haar L5 forward+inverse 47 -> 32 us, 8 x 16^2 db2 L2 30 -> 11; one workgroup of 256 threads is
             // too slow for a single 64 x 64 image: haar L6 50 -> 105 us)
@@ -620,7 +641,7 @@ void build_schedule(pdwt_plan* p) {
         // 1D: runs of K >= 2 levels in ONE fused launch (dwt1_fused_kernels.hpp); the rest level by level
         const bool fuse = !swt && getenv("PDWT_NO_FUSED_1D") == nullptr;
         const int cap = dwt1_fused_max_levels(hlen);
-        const int reg = swt ? 0 : get_reg1d_enabled();  // bit 0: forward, bit 1: inverse
+        const int reg = swt ? 0 : p->tune.reg1d;  // bit 0: forward, bit 1: inverse
         for (int dir = 0; dir < 2; dir++) {
             std::vector<Step>& out = dir ? p->sched_inv : p->sched_fwd;
             int l = 0;
@@ -639,8 +660,8 @@ void build_schedule(pdwt_plan* p) {
                 // for the LDS pyramids, db4 79.6 against 70.6), and below ~2^23 samples one launch of the pyramid beats two
                 // (2^20 samples: db4 16.2 against 14.2 us, 256 rows of 4096: 18.0 against 13.8).  fp32 only (the fp64 build has
                 // no LDS pyramid); bit 3 of the "reg1d" knob lifts the limits (tests).
-                static const int min_log2 = getenv("PDWT_REG1D_MIN_LOG2") ? atoi(getenv("PDWT_REG1D_MIN_LOG2")) : 23;
-                static const int min_row = getenv("PDWT_REG1D_MIN_ROW") ? atoi(getenv("PDWT_REG1D_MIN_ROW")) : 16384;
+                static const int min_log2 = lab_env("PDWT_REG1D_MIN_LOG2") ? atoi(lab_env("PDWT_REG1D_MIN_LOG2")) : 23;
+                static const int min_row = lab_env("PDWT_REG1D_MIN_ROW") ? atoi(lab_env("PDWT_REG1D_MIN_ROW")) : 16384;
                 // Decided for the PLAN, not per launch: a register first stage followed by a pyramid on the remaining 2^21
                 // samples measured slower than either pure schedule (2^24 samples, db4 L5: 64.6 us against 54.5 / 60.3).
                 if (reg_here && sizeof(real_t) == 4 && !((reg >> 3) & 1)) {
@@ -649,7 +670,7 @@ void build_schedule(pdwt_plan* p) {
                 }
                 // A/B (PDWT_REG1D_THEN_FUSED=1): only the FIRST group in registers, the remainder through the LDS pyramid -- slower when the
                 // pyramid's forward segment shrank with the number of levels (64.6 us), re-measured after that was fixed in round 4
-                static const bool then_fused = getenv("PDWT_REG1D_THEN_FUSED") != nullptr;
+                static const bool then_fused = lab_env("PDWT_REG1D_THEN_FUSED") != nullptr;
                 if (then_fused && l > 0) reg_here = false;
                 int K = reg_here ? (L - l < 3 ? L - l : 3) : 0;
                 while (K >= 1 && !dwt1_reg_supported(hlen, p->lc[l], K)) --K;
@@ -714,10 +735,7 @@ int fwd_level_2d(pdwt_plan* p, int l, bool run) {
             Stamp st(p, "dwt2_fwd_split");
             const hipError_t e = run ? launch_dwt2_split_fwd(a, p->tmp, B, p->stream) : hipSuccess;
             if (e == hipErrorNotSupported) {
-                if (p->timing && !p->stamps.empty()) {
-                    (void)hipEventDestroy(p->stamps.back().start);
-                    p->stamps.pop_back();
-                }
+                st.drop();
             } else {
                 HIP_TRY(e);
                 done = true;
@@ -745,10 +763,7 @@ int fwd_level_2d(pdwt_plan* p, int l, bool run) {
             const hipError_t e = run ? launch_swt2_split(a, p->tmp, false, B, p->stream) : hipSuccess;
             if (e == hipErrorNotSupported) {
                 split = false;
-                if (p->timing && !p->stamps.empty()) {
-                    (void)hipEventDestroy(p->stamps.back().start);
-                    p->stamps.pop_back();
-                }
+                st.drop();
             } else if (e != hipSuccess) {
                 HIP_TRY(e);
             }
@@ -822,10 +837,7 @@ int inv_level_2d(pdwt_plan* p, int l, bool run) {
             Stamp st(p, "dwt2_inv_split");
             const hipError_t e = run ? launch_dwt2_split_inv(a, p->tmp, B, p->stream) : hipSuccess;
             if (e == hipErrorNotSupported) {
-                if (p->timing && !p->stamps.empty()) {
-                    (void)hipEventDestroy(p->stamps.back().start);
-                    p->stamps.pop_back();
-                }
+                st.drop();
             } else {
                 HIP_TRY(e);
                 done = true;
@@ -855,10 +867,7 @@ int inv_level_2d(pdwt_plan* p, int l, bool run) {
             const hipError_t e = run ? launch_swt2_split(a, p->tmp, true, B, p->stream) : hipSuccess;
             if (e == hipErrorNotSupported) {
                 split = false;
-                if (p->timing && !p->stamps.empty()) {
-                    (void)hipEventDestroy(p->stamps.back().start);
-                    p->stamps.pop_back();
-                }
+                st.drop();
             } else if (e != hipSuccess) {
                 HIP_TRY(e);
             }
@@ -949,7 +958,7 @@ int forward_impl(pdwt_plan* p, int only = 0) {
             // levels l and l+1 in one launch; A_l never reaches HBM
             real_t* det1[3] = {p->band(3 * (l - 1) + 1), p->band(3 * (l - 1) + 2), p->band(3 * (l - 1) + 3)};
             real_t* band2[4] = {approx_slot(p, l + 1), p->band(3 * l + 1), p->band(3 * l + 2), p->band(3 * l + 3)};
-            Stamp st(p, s.kind == Step::STRIP2 ? "dwt2_fwd_strip2" : (s.kind == Step::WAVE2 ? "dwt2_fwd_wave2" : "dwt2_fwd_pyr2"));
+            Stamp st(p, s.kind == Step::STRIP2 ? "dwt2_fwd_strip2" : (s.kind == Step::WAVE2 ? "dwt2_fwd_wave2" : "dwt2_fwd_pyr2"), &e);
             if (!run) continue;
             const real_t* src = approx_slot(p, l - 1);
             const int r0 = p->lr[l - 1], c0 = p->lc[l - 1];
@@ -963,49 +972,49 @@ int forward_impl(pdwt_plan* p, int only = 0) {
                 app[k] = approx_slot(p, l + k);
                 for (int b = 0; b < 3; b++) det[3 * k + b] = p->band(3 * (l + k - 1) + 1 + b);
             }
-            Stamp st(p, "dwt2_fwd_chain");
+            Stamp st(p, "dwt2_fwd_chain", &e);
             if (!run) continue;
             e = launch_dwt2_fwd_chain(approx_slot(p, l - 1), det, app, p->lr[l - 1], p->lc[l - 1], s.K, hlen, p->dec, B,
                                       p->chain_flags, ++p->chain_epoch, p->stream);
         } else if (s.kind == Step::TAIL && swt) {
             real_t* det[3 * kTailMaxLevelsHost] = {};
             for (int k = 0; k < 3 * s.K; k++) det[k] = p->band(1 + k);
-            Stamp st(p, "swt2_fwd_tail");
+            Stamp st(p, "swt2_fwd_tail", &e);
             if (!run) continue;
             e = launch_swt2_tail(approx_slot(p, 0), det, approx_slot(p, s.K), p->info.Nr, p->info.Nc, s.K, hlen, false, p->dec, nullptr, B,
                                  p->stream);
         } else if (s.kind == Step::TAIL) {
             real_t* det[3 * kTailMaxLevelsHost] = {};
             for (int k = 0; k < 3 * s.K; k++) det[k] = p->band(3 * (l - 1) + 1 + k);
-            Stamp st(p, "dwt2_fwd_tail");
+            Stamp st(p, "dwt2_fwd_tail", &e);
             if (!run) continue;
             e = launch_dwt2_tail(approx_slot(p, l - 1), det, approx_slot(p, l + s.K - 1), p->lr[l - 1], p->lc[l - 1], s.K, hlen, false,
                                  p->dec, B, p->stream);
         } else if (s.kind == Step::PYR3) {
             real_t* det[9];
             for (int k = 0; k < 9; k++) det[k] = p->band(3 * (l - 1) + 1 + k);
-            Stamp st(p, "dwt2_fwd_pyr3");
+            Stamp st(p, "dwt2_fwd_pyr3", &e);
             if (!run) continue;
             e = launch_dwt2_fwd_pyr3(approx_slot(p, l - 1), det, approx_slot(p, l + 2), p->lr[l - 1], p->lc[l - 1], hlen, p->dec, B,
                                      p->stream);
         } else if (s.kind == Step::SWTF) {
             real_t* det[9] = {};
             for (int k = 0; k < 3 * s.K; k++) det[k] = p->band(3 * (l - 1) + 1 + k);
-            Stamp st(p, "swt2_fwd_fused");
+            Stamp st(p, "swt2_fwd_fused", &e);
             if (!run) continue;
             e = launch_swt2_fused(approx_slot(p, l - 1), approx_slot(p, l + s.K - 1), det, p->info.Nr, p->info.Nc, l, s.K, false,
                                   p->info.hlen, p->dec, nullptr, B, p->stream);
         } else if (s.kind == Step::REG1D) {
             real_t* det[kMaxFusedLevelsHost] = {};
             for (int k = 0; k < s.K; k++) det[k] = p->band(l + k);
-            Stamp st(p, "dwt1_fwd_reg");
+            Stamp st(p, "dwt1_fwd_reg", &e);
             if (!run) continue;
             e = launch_dwt1_fwd_reg(approx_slot(p, l - 1), det, approx_slot(p, l + s.K - 1), B * p->info.Nr, p->lc[l - 1],
                                     s.K, hlen, p->dec, p->stream);
         } else if (s.kind == Step::FUSED1D) {
             real_t* det[kMaxFusedLevelsHost] = {};
             for (int k = 0; k < s.K; k++) det[k] = p->band(l + k);
-            Stamp st(p, "dwt1_fwd_fused");
+            Stamp st(p, "dwt1_fwd_fused", &e);
             if (!run) continue;
             e = launch_dwt1_fwd_fused(approx_slot(p, l - 1), det, approx_slot(p, l + s.K - 1), B * p->info.Nr, p->lc[l - 1],
                                       s.K, hlen, p->dec, p->stream);
@@ -1034,7 +1043,7 @@ int inverse_impl(pdwt_plan* p, int only = 0) {
         if (s.kind == Step::STRIP2 || s.kind == Step::PYR2) {
             const real_t* band2[4] = {approx_slot(p, l + 1), p->band(3 * l + 1), p->band(3 * l + 2), p->band(3 * l + 3)};
             const real_t* det1[3] = {p->band(3 * (l - 1) + 1), p->band(3 * (l - 1) + 2), p->band(3 * (l - 1) + 3)};
-            Stamp st(p, s.kind == Step::STRIP2 ? "dwt2_inv_strip2" : "dwt2_inv_pyr2");
+            Stamp st(p, s.kind == Step::STRIP2 ? "dwt2_inv_strip2" : "dwt2_inv_pyr2", &e);
             if (!run) continue;
             e = s.kind == Step::STRIP2
                     ? launch_dwt2_inv_strip2(band2, det1, approx_slot(p, l - 1), p->lr[l - 1], p->lc[l - 1], hlen, p->rec, B, p->stream)
@@ -1046,7 +1055,7 @@ int inverse_impl(pdwt_plan* p, int only = 0) {
                 app[k] = approx_slot(p, l + k);
                 for (int b = 0; b < 3; b++) det[3 * k + b] = p->band(3 * (l + k - 1) + 1 + b);
             }
-            Stamp st(p, "dwt2_inv_chain");
+            Stamp st(p, "dwt2_inv_chain", &e);
             if (!run) continue;
             e = launch_dwt2_inv_chain(approx_slot(p, l - 1), det, app, p->lr[l - 1], p->lc[l - 1], s.K, hlen, p->rec, B,
                                       p->chain_flags + p->chain_words, ++p->chain_epoch, p->stream);
@@ -1056,21 +1065,21 @@ int inverse_impl(pdwt_plan* p, int only = 0) {
             real_t beta[kTailMaxLevelsHost] = {};
             if (p->pend_soft)  // deferred soft_threshold, applied as the details are staged (see inv_level_2d)
                 for (int k = 0; k < s.K; k++) beta[k] = pending_beta_of_level(p, 1 + k);
-            Stamp st(p, p->pend_soft ? "swt2_inv_tail+soft" : "swt2_inv_tail");
+            Stamp st(p, p->pend_soft ? "swt2_inv_tail+soft" : "swt2_inv_tail", &e);
             if (!run) continue;
             e = launch_swt2_tail(approx_slot(p, s.K), det, approx_slot(p, 0), p->info.Nr, p->info.Nc, s.K, hlen, true, p->rec, beta, B,
                                  p->stream);
         } else if (s.kind == Step::TAIL) {
             real_t* det[3 * kTailMaxLevelsHost] = {};
             for (int k = 0; k < 3 * s.K; k++) det[k] = p->band(3 * (l - 1) + 1 + k);
-            Stamp st(p, "dwt2_inv_tail");
+            Stamp st(p, "dwt2_inv_tail", &e);
             if (!run) continue;
             e = launch_dwt2_tail(approx_slot(p, l + s.K - 1), det, approx_slot(p, l - 1), p->lr[l - 1], p->lc[l - 1], s.K, hlen, true,
                                  p->rec, B, p->stream);
         } else if (s.kind == Step::PYR3) {
             real_t* det[9];
             for (int k = 0; k < 9; k++) det[k] = p->band(3 * (l - 1) + 1 + k);
-            Stamp st(p, "dwt2_inv_pyr3");
+            Stamp st(p, "dwt2_inv_pyr3", &e);
             if (!run) continue;
             e = launch_dwt2_inv_pyr3(approx_slot(p, l + 2), det, approx_slot(p, l - 1), p->lr[l - 1], p->lc[l - 1], hlen, p->rec, B,
                                      p->stream);
@@ -1080,21 +1089,21 @@ int inverse_impl(pdwt_plan* p, int only = 0) {
             real_t beta[3] = {0, 0, 0};
             if (p->pend_soft)  // deferred soft_threshold, applied as the details are loaded (see inv_level_2d)
                 for (int k = 0; k < s.K; k++) beta[k] = pending_beta_of_level(p, l + k);
-            Stamp st(p, p->pend_soft ? "swt2_inv_fused+soft" : "swt2_inv_fused");
+            Stamp st(p, p->pend_soft ? "swt2_inv_fused+soft" : "swt2_inv_fused", &e);
             if (!run) continue;
             e = launch_swt2_fused(approx_slot(p, l + s.K - 1), approx_slot(p, l - 1), det, p->info.Nr, p->info.Nc, l, s.K, true,
                                   p->info.hlen, p->rec, beta, B, p->stream);
         } else if (s.kind == Step::REG1D) {
             const real_t* det[kMaxFusedLevelsHost] = {};
             for (int k = 0; k < s.K; k++) det[k] = p->band(l + k);
-            Stamp st(p, "dwt1_inv_reg");
+            Stamp st(p, "dwt1_inv_reg", &e);
             if (!run) continue;
             e = launch_dwt1_inv_reg(approx_slot(p, l + s.K - 1), det, approx_slot(p, l - 1), B * p->info.Nr, p->lc[l - 1], s.K, hlen,
                                     p->rec, p->stream);
         } else if (s.kind == Step::FUSED1D) {
             const real_t* det[kMaxFusedLevelsHost] = {};
             for (int k = 0; k < s.K; k++) det[k] = p->band(l + k);
-            Stamp st(p, "dwt1_inv_fused");
+            Stamp st(p, "dwt1_inv_fused", &e);
             if (!run) continue;
             e = launch_dwt1_inv_fused(approx_slot(p, l + s.K - 1), det, approx_slot(p, l - 1), B * p->info.Nr, p->lc[l - 1], s.K, hlen,
                                       p->rec, p->stream);
@@ -1285,6 +1294,10 @@ int pdwt_clone(pdwt_handle src, pdwt_handle* out) {
     if (e == hipSuccess)
         e = hipMemcpyAsync(p->arena, src->arena, (size_t)p->arena_elems * sizeof(real_t), hipMemcpyDeviceToDevice,
                            p->stream);
+    // a bound source (pdwt_bind_image) keeps its image outside its arena: the clone OWNS a copy of it (it is not bound)
+    if (e == hipSuccess && src->image_ext)
+        e = hipMemcpyAsync(p->arena + p->image_off, src->image_ext, (size_t)p->batch * p->info.Nr * p->info.Nc * sizeof(real_t),
+                           hipMemcpyDeviceToDevice, p->stream);
     if (e == hipSuccess && src->d_f2d) {
         e = device_malloc((void**)&p->d_f2d, (size_t)8 * kMaxTaps * kMaxTaps * sizeof(real_t));
         if (e == hipSuccess)
@@ -1646,8 +1659,9 @@ intptr_t pdwt_image_ptr(pdwt_handle h) { return h ? (intptr_t)h->image() : 0; }
 
 int pdwt_bind_image(pdwt_handle h, void* device_ptr) {
     CHECK_HANDLE(h);
-    if (device_ptr && (reinterpret_cast<uintptr_t>(device_ptr) & (sizeof(real_t) - 1)))
-        return fail(PDWT_ERR_ARG, "pdwt_bind_image: the pointer is not aligned for the element type");
+    // 16 bytes: every tuned kernel stages the image with 16-B accesses, and not every launcher checks its input's alignment
+    if (device_ptr && (reinterpret_cast<uintptr_t>(device_ptr) & 15))
+        return fail(PDWT_ERR_ARG, "pdwt_bind_image: the pointer must be 16-byte aligned");
     DeviceGuard guard(h->device);
     HIP_TRY(hipStreamSynchronize(h->stream));  // nothing in flight may still use the old location
     h->image_ext = static_cast<real_t*>(device_ptr);
@@ -1997,6 +2011,14 @@ int pdwt_reset_kernel_times(pdwt_handle h) {
     HIP_TRY(hipStreamSynchronize(h->stream));
     clear_stamps(h);
     return PDWT_OK;
+}
+
+int pdwt_kernel_families(pdwt_handle h, char (*families)[16], int cap) {
+    CHECK_HANDLE(h);
+    const int n = (int)h->stamps.size();
+    for (int i = 0; i < n && i < cap; i++)
+        if (families) memcpy(families[i], h->stamps[i].family, 16);
+    return n;
 }
 
 int pdwt_kernel_times(pdwt_handle h, float* ms, char (*names)[48], int cap) {

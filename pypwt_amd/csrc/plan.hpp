@@ -45,6 +45,7 @@ struct Step {
 struct KernelStamp {
     hipEvent_t start, stop;
     char name[48];
+    char family[16];  // which of a step's alternative kernels ran (launch.hpp: note_family); "" when the step has only one
 };
 
 }  // namespace pdwt

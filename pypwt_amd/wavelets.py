@@ -635,6 +635,13 @@ class BatchedWavelets(object):
         n = check(self._lib.pdwt_kernel_times(self._h, ms, C.cast(names, C.c_void_p), cap))
         return [(names[i].value.decode(), float(ms[i])) for i in range(min(n, cap))]
 
+    def kernel_families(self, cap=4096):
+        """Which of a step's alternative kernels served every recorded launch ("tile", "wave", "ring", "generic", "" for steps with one
+        kernel), in the order of kernel_times()."""
+        fam = ((C.c_char * 16) * cap)()
+        n = check(self._lib.pdwt_kernel_families(self._h, C.cast(fam, C.c_void_p), cap))
+        return [fam[i].value.decode() for i in range(min(n, cap))]
+
     def cleanup(self):
         if getattr(self, "_h", None):
             self._lib.pdwt_destroy(self._h)

@@ -885,4 +885,16 @@ def test_bind_image_chains_two_plans_without_a_copy(W):
     back = np.empty_like(A1)
     assert lib.pdwt_get_coeff(a._h, back.ctypes.data_as(C.POINTER(C.c_float)), 0) == A1.size
     assert np.abs(back - A1).max() <= 2e-4 * max(1.0, float(np.abs(A1).max()))
+    # a clone of a BOUND plan owns a copy of the image it was bound to (round 4 advice: it used to get the source's unused buffer)
+    a.set_coeff(A1, 0)
+    clone = C.c_void_p()
+    assert lib.pdwt_clone(b._h, C.byref(clone)) == 0
+    assert lib.pdwt_image_ptr(clone) not in (0, lib.pdwt_coeff_ptr(a._h, 0), own)
+    img = np.empty_like(A1)
+    assert lib.pdwt_get_image(clone, img.ctypes.data_as(C.POINTER(C.c_float))) == A1.size
+    assert np.array_equal(img, A1)
+    assert lib.pdwt_destroy(clone) == 0
+    # a pointer that is not 16-byte aligned is refused (the tuned kernels stage the image with 16-byte accesses)
+    assert lib.pdwt_bind_image(b._h, C.c_void_p(lib.pdwt_coeff_ptr(a._h, 0) + 4)) == _lib.ERR_ARG
+    assert lib.pdwt_image_ptr(b._h) == lib.pdwt_coeff_ptr(a._h, 0)
     assert lib.pdwt_bind_image(b._h, None) == 0 and lib.pdwt_image_ptr(b._h) == own

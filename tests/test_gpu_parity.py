@@ -346,8 +346,16 @@ def test_three_level_pyramid_on_small_images(monkeypatch):
     the launch names say so, and every band and the reconstruction equal the oracle's.  (Since round 4 the FORWARD of
     filters of 10-16 taps is dispatched to the small LDS tiles instead -- measured faster; PDWT_PYR3_FWD_LONG=1, read when
     a plan is built, keeps the three-level forward kernel of those lengths under test here.)"""
-    from pypwt_amd import BatchedWavelets
+    from pypwt_amd import BatchedWavelets, _lib
+    was_lab = _lib.use_lab_kernels(True)  # A/B knobs are read by the measurement library only (launch_util.hpp: lab_env)
     monkeypatch.setenv("PDWT_PYR3_FWD_LONG", "1")
+    try:
+        _three_level_pyramid_cases(BatchedWavelets)
+    finally:
+        _lib.use_lab_kernels(was_lab)
+
+
+def _three_level_pyramid_cases(BatchedWavelets):
     cases = (("db2", (512, 512), 3, 1), ("haar", (64, 64), 3, 2), ("db3", (256, 384), 5, 1), ("db4", (256, 256), 3, 1),
              ("sym4", (512, 1024), 6, 1), ("db2", (40, 72), 3, 3), ("bior3.1", (256, 128), 3, 1), ("haar", (8, 8), 3, 1),
              ("db4", (128, 128), 3, 64), ("db3", (264, 200), 3, 2), ("sym8", (512, 512), 3, 1), ("db5", (256, 320), 3, 2),
@@ -743,12 +751,16 @@ def test_deep_plans_end_in_one_tail_launch(wname, shape, levels, batch, wide, ex
     levels = 99): once an image's approximation fits one CU every remaining level runs in ONE launch (dwt2_tail_kernels.hpp).
     Every band against the oracle, then the reconstruction.  `wide`: the dispatch rule widened (it takes 2-tap plans only by
     default) so that every instantiation -- 4, 6, 8 taps unrolled, the run-time length, 128 x 128 entry planes -- is compared."""
-    from pypwt_amd import BatchedWavelets
+    from pypwt_amd import BatchedWavelets, _lib
     oracle.build()
+    was_lab = _lib.use_lab_kernels(bool(wide))  # the widened rule is an A/B knob: read by the measurement library only
     if wide:
         monkeypatch.setenv("PDWT_TAIL_WORK_LOG2", "20")
         monkeypatch.setenv("PDWT_TAIL_MIN_K", "2")
-    plan = BatchedWavelets(batch, shape[0], shape[1], wname, levels)
+    try:
+        plan = BatchedWavelets(batch, shape[0], shape[1], wname, levels)
+    finally:
+        _lib.use_lab_kernels(was_lab)
     L = plan.levels
     sched = plan.schedule()
     hlen = oracle.filters(wname)[0]
