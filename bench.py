@@ -320,7 +320,7 @@ def metric_name(config, desc, batch_per_gpu):
         return "Msamples/s, 4096x4096 fp32 db4 L4 2D DWT fwd+inv, %s (cfg2)" % ("one image per step" if batch_per_gpu == 1 else "%d images per step" % batch_per_gpu)
     if config == "cfg5":
         return "Msamples/s, 4096x4096 fp32 db4 L4 2D DWT fwd+inv, batch of %d images per GPU and step (cfg5)" % batch_per_gpu
-    return "Msamples/s, " + desc
+    return "Msamples/s, %s (%s)" % (desc, config)
 
 
 def median(values):

@@ -1,0 +1,46 @@
+"""Dispatch coverage (task 5): ~25 kernel families and 13 step kinds are chosen by rules in plan.cpp and
+launch_*.hip.  This test enumerates the (launch name, kernel family) pairs the DEFAULT dispatch of the product libraries can
+reach -- fp32 and fp64 -- with one plan per pair at least (tests/dispatch_cases.py), asserts through pdwt_kernel_times /
+pdwt_kernel_families that each pair RAN, and compares every plan with the CPU oracle: coefficients within a few fp32 (fp64) ulps
+per level, the reconstruction against the oracle's own.  No tuning key is moved and no environment variable is set: what is
+covered here is what a caller gets.  (tools/dispatch_discover.py prints the same run as a table.)"""
+import numpy as np
+import pytest
+
+from oracle import oracle
+from dispatch_cases import CASES, run_case
+
+pytestmark = pytest.mark.gpu
+
+# every pair the default dispatch can reach, per library: launch name (the step kind) x the family that serves a LEVEL step
+REACHABLE = {
+    "f32": {("dwt2_fwd_level", "tile"), ("dwt2_fwd_level", "wave"), ("dwt2_fwd_level", "ring"), ("dwt2_fwd_level", "generic"),
+            ("dwt2_inv_level", "tile"), ("dwt2_inv_level", "wave"), ("dwt2_inv_level", "ring"), ("dwt2_inv_level", "generic"),
+            ("dwt2_fwd_pyr2", ""), ("dwt2_inv_pyr2", ""), ("dwt2_fwd_pyr3", ""), ("dwt2_inv_pyr3", ""), ("dwt2_fwd_tail", ""),
+            ("dwt2_inv_tail", ""), ("dwt2_fwd_strip2", ""),
+            ("dwt1_fwd_level", ""), ("dwt1_inv_level", ""), ("dwt1_fwd_reg", ""), ("dwt1_inv_reg", ""), ("dwt1_fwd_fused", ""),
+            ("dwt1_inv_fused", ""),
+            ("swt2_fwd_level", ""), ("swt2_inv_level", ""), ("swt2_fwd_split", ""), ("swt2_inv_split", ""), ("swt2_fwd_fused", ""),
+            ("swt2_inv_fused", ""), ("swt2_fwd_tail", ""), ("swt2_inv_tail", ""), ("swt1_fwd_level", ""), ("swt1_inv_level", "")},
+    "f64": {("dwt2_fwd_level", "tile"), ("dwt2_fwd_level", "wave"), ("dwt2_inv_level", "tile"), ("dwt2_inv_level", "wave"),
+            ("dwt2_fwd_pyr3", ""), ("dwt2_inv_pyr3", ""), ("dwt1_fwd_reg", ""), ("dwt1_inv_reg", ""),
+            ("swt2_fwd_level", ""), ("swt2_inv_level", ""), ("swt2_fwd_fused", ""), ("swt2_inv_fused", "")},
+}
+
+
+def test_every_reachable_dispatch_pair_runs_and_matches_the_oracle():
+    reached = {"f32": set(), "f64": set()}
+    for case in CASES:
+        pairs, cerr, rerr, L = run_case(case, oracle, np)
+        prec = case[5]
+        reached[prec] |= pairs
+        eps = 1.2e-7 if prec == "f32" else 2.3e-16
+        # same arithmetic, different summation order (fma vs mul+add): a few ulps of the largest coefficient per level; deep haar
+        # plans (case 12) accumulate 4^l samples per coefficient
+        assert cerr <= 8 * eps * (1 + L) * (2 ** max(0, L - 6)), (case, cerr)
+        assert rerr <= (2e-6 if prec == "f32" else 1e-11) * (1 + L) * 255.0, (case, rerr)
+    for prec in ("f32", "f64"):
+        missing, extra = REACHABLE[prec] - reached[prec], reached[prec] - REACHABLE[prec]
+        print("dispatch coverage %s: reached %d / reachable %d" % (prec, len(reached[prec] & REACHABLE[prec]), len(REACHABLE[prec])))
+        assert not missing, (prec, "never ran", sorted(missing))
+        assert not extra, (prec, "ran but is not in the table (add it with a case of its own)", sorted(extra))
