@@ -38,3 +38,16 @@ def rel_err(a, b):
     b = np.asarray(b, dtype=np.float64)
     den = max(np.abs(b).max(), 1e-30)
     return np.abs(a - b).max() / den
+
+
+def reconstruction_tol(x, wname, levels, ndim=2, do_swt=0, ora=None):
+    """The bound on |inverse(forward(x)) - x| the GPU tests use: the reference's 7e-4 (test/test_wavelets.py:545, stated on its
+    0..255 test image), or twice what the reference's own fp32 arithmetic -- the CPU oracle on the same input -- achieves where that
+    is more (deep plans on 0..255 data, 40-tap banks, ill-conditioned biorthogonal banks).  One rule for every test: no per-test
+    constant.  `ora`: the oracle's forward coefficients of x, when the caller has them already."""
+    import numpy as np
+    from oracle import oracle
+    if ora is None:
+        ora = oracle.forward(x, wname, levels, ndim=ndim, do_swt=do_swt)
+    own = float(np.abs(oracle.inverse(ora, x.shape, wname, levels, ndim=ndim, do_swt=do_swt) - x).max())
+    return max(7e-4, 2.0 * own)

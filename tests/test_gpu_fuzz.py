@@ -187,3 +187,21 @@ def test_fuzz_three_level_pyramid(seed):
                 assert np.abs(g - r).max() <= 1e-12 * max(1.0, float(np.abs(r).max())), (wname, shape, levels, k)
             wd.inverse()
             assert np.abs(wd.image - oracle.inverse(refd, shape, wname, levels, double="full")).max() <= scale * 1e-10 * 255
+
+
+def test_soak_slice():
+    """A deterministic slice of tools/soak.py (the randomised soak that guards the dispatch regimes the
+    unit fuzz does not reach -- large batches of tiny images, deep plans, mid-size and HD SWT plans, short-row 1D batches, the
+    batch range of the register-ring kernels -- was builder-run only).  Fixed seed, 150 plans, every kind at least twice; every plan
+    against the CPU oracle (coefficients of three images, then the reconstruction)."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("soak", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "soak.py"))
+    soak = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(soak)
+    done, secs = soak.run(max_cases=150, seed=20250)
+    assert sum(done.values()) >= 150, done
+    for kind in ("tiny-batch", "small-batch", "deep", "swt-mid", "swt-hd", "mid-batch", "swt-batch", "swt-tiny", "rows-1d", "rows-swt1",
+                 "odd-batch", "few-mid", "ring-batch"):
+        assert done.get(kind, 0) >= 2, (kind, done)
+    print("soak slice: %d plans in %.0f s: %s" % (sum(done.values()), secs, done))

@@ -9,7 +9,7 @@ import os
 import numpy as np
 import pytest
 
-from golden_util import GOLDEN
+from golden_util import GOLDEN, reconstruction_tol
 from oracle import oracle
 from test_gpu_parity import flat_coeffs
 
@@ -417,7 +417,7 @@ def test_large_shapes_long_filters(W, wname, shape, lv):
         assert g.shape == r.shape
         assert np.abs(g - r).max() <= 1.5e-6 * (1 + lv) * max(np.abs(r).max(), 1.0), (wname, shape)
     w.inverse()
-    assert np.abs(w.image - x).max() < (7e-4 if wname not in ("db20", "sym20") else 5e-3)
+    assert np.abs(w.image - x).max() < reconstruction_tol(x, wname, lv)
 
 
 @pytest.mark.parametrize("wname,n,lv", [("haar", 1 << 18, 9), ("db2", 1 << 18, 8), ("sym8", 3 << 16, 6), ("db20", 1 << 17, 5),

@@ -5,6 +5,8 @@ plans with the maximum number of levels, mid-size and HD-size SWT plans (small t
 one image and the strips.  Every case: forward against the CPU oracle on a few images of the batch, then the reconstruction.
 
     python3 tools/soak.py [seconds] [seed]        (oracle/ is test infrastructure: this tool is a test, not a product path)
+
+tests/test_gpu_fuzz.py::test_soak_slice runs a deterministic slice of it (run(max_cases=..., seed=...)) inside `pytest -m gpu`.
 """
 import os
 import sys
@@ -14,6 +16,8 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from golden_util import reconstruction_tol  # noqa: E402  (the one reconstruction bound of the test suite)
 from oracle import oracle  # noqa: E402
 from pypwt_amd import BatchedWavelets  # noqa: E402
 
@@ -30,9 +34,11 @@ def check(B, shape, wname, L, swt, rng, tag, ndim=2):
     n = shape[0] * shape[1]
     hlen = oracle.filters(wname)[0]
     loose = 40.0 if wname in ("bior3.1", "rbio3.1") else 1.0
+    refs = {}
     for b in sorted({0, int(rng.integers(0, B)), B - 1}):
         x = oracle.hash_input(shape, seed, index_offset=b * n)
         ref = oracle.forward(x, wname, L, do_swt=swt, ndim=ndim)
+        refs[b] = ref
         for num, r in enumerate(ref):
             g = plan.coeff_at(num, b)
             level = L if num == 0 else ((num - 1) // 3 + 1 if ndim == 2 else num)
@@ -45,7 +51,7 @@ def check(B, shape, wname, L, swt, rng, tag, ndim=2):
     for b in sorted({0, B - 1}):
         x = oracle.hash_input(shape, seed, index_offset=b * n)
         err = float(np.abs(plan.image_at(b) - x).max())
-        if not err <= loose * 7e-4 * 255 * (2 if hlen > 16 else 1):
+        if not err <= reconstruction_tol(x, wname, L, ndim=ndim, do_swt=swt, ora=refs[b]):
             raise AssertionError("%s: B=%d %s %s L=%d swt=%d image %d reconstruction err %g | %s"
                                  % (tag, B, shape, wname, L, swt, b, err, plan.schedule().replace("\n", " | ")))
     plan.cleanup()
@@ -53,15 +59,20 @@ def check(B, shape, wname, L, swt, rng, tag, ndim=2):
 
 
 def main():
-    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
-    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    done, secs = run(budget=float(sys.argv[1]) if len(sys.argv) > 1 else 120.0, seed=int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    print("soak OK: %.0f s, cases per kind: %s" % (secs, done))
+
+
+def run(budget=None, max_cases=None, seed=1):
+    """Random plans until `budget` seconds have passed or `max_cases` plans have been checked; returns ({kind: plans}, seconds)."""
+    rng = np.random.default_rng(seed)
     oracle.build()
     names = [w for w in oracle.filter_table()["order"]]
     short = ["haar", "db2", "db3", "db4", "sym4", "bior2.2", "bior1.3", "sym5", "db6", "sym8", "coif2", "db10"]
     t0, done = time.time(), {}
-    while time.time() - t0 < budget:
+    while (budget is None or time.time() - t0 < budget) and (max_cases is None or sum(done.values()) < max_cases):
         kinds = ["tiny-batch", "tiny-batch", "small-batch", "deep", "swt-mid", "swt-hd", "mid-batch", "swt-batch", "swt-tiny",
-                 "rows-1d", "rows-1d", "rows-swt1", "odd-batch", "odd-batch", "few-mid"]
+                 "rows-1d", "rows-1d", "rows-swt1", "odd-batch", "odd-batch", "few-mid", "ring-batch"]
         if os.environ.get("SOAK_KINDS"):  # e.g. SOAK_KINDS=odd-batch,few-mid,swt-tiny
             kinds = os.environ["SOAK_KINDS"].split(",")
         kind = str(rng.choice(kinds))
@@ -101,6 +112,10 @@ def main():
         elif kind == "swt-hd":
             r, c = [(1080, 1920), (1200, 1600), (2048, 2048), (600, 800), (1440, 2560)][int(rng.integers(0, 5))]
             done[kind] = done.get(kind, 0) + check(1, (r, c), str(rng.choice(short)), int(rng.choice([1, 2, 3])), 1, rng, kind)
+        elif kind == "ring-batch":    # 12 / 16 taps, >= 2^25 samples, rows of >= 1024 columns: the register-ring level kernels
+            r, c = [(2048, 2048), (1024, 2048), (1000, 4096), (3000, 1024), (4096, 4096)][int(rng.integers(0, 5))]
+            B = max(2, int((1 << 25) // (r * c)) + int(rng.integers(0, 3)))
+            done[kind] = done.get(kind, 0) + check(B, (r, c), str(rng.choice(["sym8", "db8", "db6", "coif2", "sym6", "bior5.5"])), int(rng.integers(1, 4)), 0, rng, kind)
         elif kind == "mid-batch":     # between one image and the strips
             r, c = [(1024, 1024), (2048, 2048), (1024, 2048), (4096, 4096)][int(rng.integers(0, 4))]
             B = max(2, int((1 << int(rng.integers(24, 27))) // (r * c)))
@@ -109,7 +124,7 @@ def main():
             r, c = [(512, 512), (1024, 1024), (2048, 2048), (256, 512)][int(rng.integers(0, 4))]
             B = max(2, int((1 << int(rng.integers(21, 25))) // (r * c)))
             done[kind] = done.get(kind, 0) + check(B, (r, c), str(rng.choice(["haar", "db2", "db3", "db4"])), int(rng.integers(2, 5)), 1, rng, kind)
-    print("soak OK: %.0f s, cases per kind: %s" % (time.time() - t0, done))
+    return done, time.time() - t0
 
 
 if __name__ == "__main__":
