@@ -16,7 +16,7 @@ static hipError_t run_fwd(const Swt2DArgs& a, int batch, hipStream_t s) {
     hipError_t e = allow_big_lds(swt2_fwd_kernel<HLEN, TX, TY, NT>, lds, big);
     if (e != hipSuccess) return e;
     const size_t use = (size_t)swt2d_lds_floats<TX, TY>(a.hlen) * sizeof(real_t);
-    const int M = a.Nr / a.f;
+    const int M = cdiv(a.Nr, a.f);  // rows of the longest dilation phase (f need not divide Nr: the tiles wrap rows, not phase indices)
     dim3 grid(cdiv(a.Nc, TX), cdiv(M, TY) * a.f, batch);
     hipLaunchKernelGGL((swt2_fwd_kernel<HLEN, TX, TY, NT>), grid, dim3(NT), use, s, a);
     return hipGetLastError();
@@ -29,7 +29,7 @@ static hipError_t run_inv(const Swt2DArgs& a, int batch, hipStream_t s) {
     hipError_t e = allow_big_lds(swt2_inv_kernel<HLEN, TX, TY, NT>, lds, big);
     if (e != hipSuccess) return e;
     const size_t use = (size_t)swt2d_lds_floats<TX, TY>(a.hlen) * sizeof(real_t);
-    const int M = a.Nr / a.f;
+    const int M = cdiv(a.Nr, a.f);  // rows of the longest dilation phase (f need not divide Nr: the tiles wrap rows, not phase indices)
     dim3 grid(cdiv(a.Nc, TX), cdiv(M, TY) * a.f, batch);
     hipLaunchKernelGGL((swt2_inv_kernel<HLEN, TX, TY, NT>), grid, dim3(NT), use, s, a);
     return hipGetLastError();

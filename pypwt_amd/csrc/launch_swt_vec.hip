@@ -15,7 +15,7 @@ static hipError_t run_vec(const Swt2DArgs& a, int batch, hipStream_t s) {
     // the inverse stages its rows in LDS where the dilation allows it (swt_inv_staged): a larger request for those launches
     const bool staged = INV && swt_inv_staged<TX, TY, NT>(HLEN, a.f);
     const size_t lds = (size_t)swt2d_inv_vec_lds_floats<TX, TY, NT>(HLEN, staged) * sizeof(real_t);
-    const int M = a.Nr / a.f;
+    const int M = cdiv(a.Nr, a.f);  // rows of the longest dilation phase
     const int total = cdiv(a.Nc, TX) * cdiv(M, TY) * a.f;
     dim3 grid(8 * ((total + 7) / 8), batch);  // XCD-aware tile order, see swt_vec_tile
     if (INV) {
@@ -32,10 +32,11 @@ static hipError_t run_vec(const Swt2DArgs& a, int batch, hipStream_t s) {
 
 static bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & (4 * sizeof(real_t) - 1)) == 0; }
 
-// preconditions of the vectorised kernels: even compile-time filter length, whole 4-column groups,
-// planes aligned for 4-element accesses
+// preconditions of the vectorised kernels: even compile-time filter length, planes aligned for 4-element accesses; rows of any
+// length (round 5: rows that are not whole aligned quads take the kernels' unaligned 16-B loads / stores and element stores at
+// the row end; images narrower than a quad stay on the one-sample-per-thread kernels)
 static bool vec_ok(const Swt2DArgs& a, bool inverse) {
-    if ((a.hlen & 1) || a.hlen < 2 || a.hlen > kMaxTaps || (a.Nc & 3) || (a.bstride & 3)) return false;
+    if ((a.hlen & 1) || a.hlen < 2 || a.hlen > kMaxTaps || a.Nc < 4) return false;
     if (!al16(a.A) || !al16(a.H) || !al16(a.V) || !al16(a.D)) return false;
     return al16(inverse ? (const void*)a.out : (const void*)a.in);
 }
@@ -47,7 +48,7 @@ hipError_t try_launch_swt2_vec(const Swt2DArgs& a, bool inverse, int batch, hipS
     // inverse 51 us against 16-20 us for the levels before.  Phases shorter than 16 rows take tiles of 8, 4 or 2 rows (2-8 taps).
     {
         static const bool deep_tiles = !(lab_env("PDWT_SWT_DEEP_TILE") && atoi(lab_env("PDWT_SWT_DEEP_TILE")) == 0);  // A/B measurements
-        const int M = a.Nr / a.f;
+        const int M = cdiv(a.Nr, a.f);
         if (deep_tiles && M < 16 && a.hlen <= 8 && sizeof(real_t) == 4) {
             switch (a.hlen) {
 #define X(h)                                                                                                                   \
@@ -71,7 +72,7 @@ hipError_t try_launch_swt2_vec(const Swt2DArgs& a, bool inverse, int batch, hipS
     // of a level is one tile's latency (db4 256^2: 7.6 us forward, 13.4 us inverse per level).  Below 256 workgroups the
     // tiles shrink to 64 x 8 (128 threads): four times the workgroups, each a quarter of the chain.
     static const int small_tiles = lab_env("PDWT_SWT_SMALL_TILE") ? atoi(lab_env("PDWT_SWT_SMALL_TILE")) : 256;  // workgroups; A/B measurements
-    const long long wgs = (long long)cdiv(a.Nc, 128) * cdiv(a.Nr / a.f, 16) * a.f * batch;
+    const long long wgs = (long long)cdiv(a.Nc, 128) * cdiv(cdiv(a.Nr, a.f), 16) * a.f * batch;
     // (and, whatever the batch, on images of at most 64 columns: a 128-column tile there is half padding)
     if ((wgs < small_tiles || (a.Nc <= 64 && small_tiles > 0)) && a.hlen <= 24 && sizeof(real_t) == 4) {
         switch (a.hlen) {
@@ -88,7 +89,7 @@ hipError_t try_launch_swt2_vec(const Swt2DArgs& a, bool inverse, int batch, hipS
 #define X(h)                                                                                                   \
     case h:                                                                                                    \
         if constexpr (h > 24) {                                                                                \
-            if (a.Nr / a.f >= 32)                                                                              \
+            if (cdiv(a.Nr, a.f) >= 32)                                                                             \
                 return inverse ? run_vec<h, true, 128, 32>(a, batch, s) : run_vec<h, false, 128, 32>(a, batch, s); \
         }                                                                                                      \
         return inverse ? run_vec<h, true>(a, batch, s) : run_vec<h, false>(a, batch, s);

@@ -768,27 +768,11 @@ int fwd_level_2d(pdwt_plan* p, int l, bool run) {
                 HIP_TRY(e);
             }
         }
-        if (split) {
-        } else if (Nr % f == 0) {
+        if (!split) {
+            // (any Nr: where the dilation does not divide the row count the tiles wrap ROWS, not phase indices -- round 5; until then such
+            // levels ran as three one-sample-per-thread passes through scratch, 2047^2 at twice the time of 2048^2)
             Stamp st(p, "swt2_fwd_level");
             if (run) HIP_TRY(launch_swt2_fwd(a, B, p->stream));
-        } else {
-            // dilation does not divide the row count: three direct passes through scratch, ALL images of the batch in each launch
-            // (round 4: they were launched image by image -- 20000 images of 21 x 33, haar L2: 341 ms forward+inverse)
-            const long long plane = (long long)Nr * Nc;
-            int rc = ensure_tmp(p, 2 * plane * B);
-            if (rc != PDWT_OK) return rc;
-            SwtPassArgs r;
-            r.in0 = src; r.in1 = nullptr; r.out0 = p->tmp; r.out1 = p->tmp + plane * B;
-            r.Nr = Nr; r.Nc = Nc; r.f = f; r.along_y = 0; r.hlen = hlen; r.fb = p->dec; r.images = B;
-            Stamp st(p, "swt_pass_fwd");
-            if (run) HIP_TRY(launch_swt_pass_fwd(r, p->stream));
-            SwtPassArgs c1 = r;
-            c1.in0 = p->tmp; c1.out0 = dstA; c1.out1 = H; c1.along_y = 1;
-            if (run) HIP_TRY(launch_swt_pass_fwd(c1, p->stream));
-            SwtPassArgs c2 = c1;
-            c2.in0 = p->tmp + plane * B; c2.out0 = V; c2.out1 = D;
-            if (run) HIP_TRY(launch_swt_pass_fwd(c2, p->stream));
         }
     }
     return PDWT_OK;
@@ -872,25 +856,9 @@ int inv_level_2d(pdwt_plan* p, int l, bool run) {
                 HIP_TRY(e);
             }
         }
-        if (split) {
-        } else if (Nr % f == 0) {
+        if (!split) {
             Stamp st(p, p->pend_soft ? "swt2_inv_level+soft" : "swt2_inv_level");
             if (run) HIP_TRY(launch_swt2_inv(a, B, p->stream));
-        } else {
-            const long long plane = (long long)Nr * Nc;
-            int rc = ensure_tmp(p, 2 * plane * B);
-            if (rc != PDWT_OK) return rc;
-            SwtPassArgs c1;  // all images of the batch in each of the three launches (see fwd_level_2d)
-            c1.in0 = cur; c1.in1 = H; c1.out0 = p->tmp; c1.out1 = nullptr;
-            c1.Nr = Nr; c1.Nc = Nc; c1.f = f; c1.along_y = 1; c1.hlen = hlen; c1.fb = p->rec; c1.images = B;
-            Stamp st(p, "swt_pass_inv");
-            if (run) HIP_TRY(launch_swt_pass_inv(c1, p->stream));
-            SwtPassArgs c2 = c1;
-            c2.in0 = V; c2.in1 = D; c2.out0 = p->tmp + plane * B;
-            if (run) HIP_TRY(launch_swt_pass_inv(c2, p->stream));
-            SwtPassArgs r = c1;
-            r.in0 = p->tmp; r.in1 = p->tmp + plane * B; r.out0 = dst; r.along_y = 0;
-            if (run) HIP_TRY(launch_swt_pass_inv(r, p->stream));
         }
     }
     return PDWT_OK;
@@ -1171,8 +1139,9 @@ int materialize_consumed(pdwt_plan* p) {
 // can the inverse of this plan apply a soft threshold on the fly?  (fused 2D SWT kernels on every level)
 bool can_defer_soft(const pdwt_plan* p) {
     static const bool no_lazy = getenv("PDWT_NO_LAZY_THRESHOLD") != nullptr;  // read once, like every other knob
-    if (!p->info.do_swt || p->info.ndims != 2 || !p->do_separable || no_lazy) return false;
-    return p->info.Nr % (1 << (p->info.nlevels - 1)) == 0;
+    // (every level launch of a separable 2D SWT plan applies a pending threshold as it loads the details: tiles, split pair, fused
+    // groups, the one-workgroup launch; until round 5 levels whose dilation does not divide the rows ran as direct passes that did not)
+    return p->info.do_swt && p->info.ndims == 2 && p->do_separable && !no_lazy;
 }
 
 // soft / hard / proj_linf share one driver (pdwt/src/common.cu:219-308)

@@ -60,7 +60,8 @@ PDWT_DEVICE void swt2_fwd_tile(const Swt2DArgs& a, int bx, int by, int bz, real_
     const int hlen = HLEN ? HLEN : a.hlen;
     const int c = analysis_centre(hlen);
     const int f = a.f;
-    const int M = a.Nr / f;  // rows per phase (host guarantees f | Nr)
+    // rows of phase ph: ph, ph + f, ...; where f does not divide Nr the periodic extension of a phase runs into the other phases
+    // (the dilated taps of row y are the rows (y + (j - c) f) mod Nr), so rows are wrapped as ROWS, not as phase indices
     const int ph = by % f;
     const int it = by / f;
     const int RY = TY + hlen - 1;
@@ -78,8 +79,7 @@ PDWT_DEVICE void swt2_fwd_tile(const Swt2DArgs& a, int bx, int by, int bz, real_
         for (int r = tid / TX; r < RY; r += NG) {
             real_t aL = 0.f, aH = 0.f;
             if (x < a.Nc) {
-                const int i = wrap_periodic(it * TY - c + r, M);
-                const real_t* row = in + (long long)(ph + f * i) * a.Nc;
+                const real_t* row = in + (long long)wrap_periodic(ph + f * (it * TY - c + r), a.Nr) * a.Nc;
 #pragma unroll
                 for (int j = 0; j < (HLEN > 0 ? HLEN : hlen); ++j) {
                     const real_t v = row[wrap_periodic(x + (j - c) * f, a.Nc)];
@@ -112,7 +112,7 @@ PDWT_DEVICE void swt2_fwd_tile(const Swt2DArgs& a, int bx, int by, int bz, real_
                 rD = pdwt_fma(h, th, rD);
             }
             const int si = it * TY + ty0 + i;
-            if (si < M && x < a.Nc) {
+            if (ph + f * si < a.Nr && x < a.Nc) {
                 const long long o = boff + (long long)(ph + f * si) * a.Nc + x;
                 a.A[o] = rA;
                 a.H[o] = rH;
@@ -131,7 +131,6 @@ PDWT_DEVICE void swt2_inv_tile(const Swt2DArgs& a, int bx, int by, int bz, real_
     const int hlen = HLEN ? HLEN : a.hlen;
     const int c = hlen / 2;  // synthesis centre
     const int f = a.f;
-    const int M = a.Nr / f;
     const int ph = by % f;
     const int it = by / f;
     const int RY = TY + hlen - 1;
@@ -149,8 +148,7 @@ PDWT_DEVICE void swt2_inv_tile(const Swt2DArgs& a, int bx, int by, int bz, real_
         for (int r = tid / TX; r < RY; r += NG) {
             real_t r1 = 0.f, r2 = 0.f;
             if (x < a.Nc) {
-                const int i = wrap_periodic(it * TY - c + r, M);
-                const long long ro = boff + (long long)(ph + f * i) * a.Nc;
+                const long long ro = boff + (long long)wrap_periodic(ph + f * (it * TY - c + r), a.Nr) * a.Nc;
 #pragma unroll
                 for (int j = 0; j < (HLEN > 0 ? HLEN : hlen); ++j) {
                     const long long o = ro + wrap_periodic(x + (j - c) * f, a.Nc);
@@ -182,7 +180,7 @@ PDWT_DEVICE void swt2_inv_tile(const Swt2DArgs& a, int bx, int by, int bz, real_
                 r = pdwt_fma(u2[(ty0 + i + j) * TX + k], hi[hlen - 1 - j], r);
             }
             const int si = it * TY + ty0 + i;
-            if (si < M && x < a.Nc) a.out[boff + (long long)(ph + f * si) * a.Nc + x] = 0.5f * r;
+            if (ph + f * si < a.Nr && x < a.Nc) a.out[boff + (long long)(ph + f * si) * a.Nc + x] = 0.5f * r;
         }
     }
 }
@@ -193,7 +191,11 @@ PDWT_DEVICE void swt2_inv_tile(const Swt2DArgs& a, int bx, int by, int bz, real_
 // dwordx4 load: the shift (j-c) f need not be a multiple of 4), the LDS planes are read and written
 // 16 B at a time and the results leave with 16-B stores.  rocprofv3 on cfg4 showed the scalar
 // kernels at 55 % VALU-busy with 4x the memory instructions of a streaming kernel.
-// Requirements (host): Nc % 4 == 0, 16-B aligned planes, compile-time filter length.
+// Requirements (host): 16-B aligned planes, compile-time filter length.  Rows of ANY length (round 5; the reference's kernels
+// take any width, pdwt/src/separable.cu:409-493,553-626, and odd sizes are an option of its tests, test/test_wavelets.py:43):
+// where rows are not whole aligned quads the taps are 16-B loads at 4-B alignment, the outputs 16-B stores at 4-B alignment and
+// the last, partial quad of a row is stored element by element -- 2047^2 used to fall to the one-sample-per-thread kernels at
+// twice the time of 2048^2.
 // ---------------------------------------------------------------------------
 #ifdef PDWT_CPU_EMU
 struct rv4 { real_t x, y, z, w; };
@@ -211,6 +213,24 @@ static __device__ __forceinline__ rv4 load4u(const real_t* p) { return *reinterp
 static __device__ __forceinline__ rv4 load4(const real_t* p) { return *reinterpret_cast<const rv4*>(p); }
 static __device__ __forceinline__ void store4(real_t* p, const rv4& v) { *reinterpret_cast<rv4*>(p) = v; }
 #endif
+
+// the quad of columns x0 .. x0 + 3 of a row (p = row + x0) of Nc columns: aligned 16-B store where rows are whole aligned quads
+// (rows16), else 16 B at 4-B alignment, the partial quad at the row end element by element
+PDWT_DEVICE void store4_row(real_t* p, const rv4& v, int x0, int Nc, bool rows16) {
+    if (rows16) {
+        store4(p, v);
+    } else if (x0 + 3 < Nc) {
+#ifdef PDWT_CPU_EMU
+        store4(p, v);
+#else
+        *reinterpret_cast<rv4u*>(p) = v;
+#endif
+    } else {
+        p[0] = v.x;
+        if (x0 + 1 < Nc) p[1] = v.y;
+        if (x0 + 2 < Nc) p[2] = v.z;
+    }
+}
 
 // four consecutive samples of a periodic row starting at (possibly negative / overflowing) column p
 PDWT_DEVICE rv4 load4_periodic(const real_t* PDWT_RESTRICT row, int p, int Nc) {
@@ -287,11 +307,12 @@ PDWT_DEVICE void swt2_fwd_vec_tile(const Swt2DArgs& a, int bx, int by, int bz, r
     static_assert(HLEN > 0 && TX % 4 == 0 && NT % QX == 0 && TY % NG == 0, "tile/thread shape");
     constexpr int c = (HLEN & 1) ? HLEN / 2 : HLEN / 2 - 1;  // analysis_centre
     constexpr int RY = TY + HLEN - 1;
-    const int f = a.f, M = a.Nr / f, ph = by % f, it = by / f;
+    const int f = a.f, ph = by % f, it = by / f;
     real_t* tL = smem;
     real_t* tH = tL + RY * TX;
     const real_t* PDWT_RESTRICT in = a.in + (long long)bz * a.bstride;
     const real_t zero = 0;
+    const bool rows16 = !(a.Nc & 3) && !(a.bstride & 3);  // every row starts 16-B aligned and ends with a whole quad
 
     // tiles whose dilated taps stay inside the row (all but the first / last of a row) skip the periodic-wrap
     // arithmetic of every load: a tile-uniform branch (it was a third of the kernel's vector instructions)
@@ -309,8 +330,7 @@ PDWT_DEVICE void swt2_fwd_vec_tile(const Swt2DArgs& a, int bx, int by, int bz, r
             r = r < RY ? r : RY - 1;
             rv4 aL = {zero, zero, zero, zero}, aH = aL;
             if (x0 < a.Nc) {
-                const int i = wrap_periodic(it * TY - c + r, M);
-                const real_t* row = in + (long long)(ph + f * i) * a.Nc;
+                const real_t* row = in + (long long)wrap_periodic(ph + f * (it * TY - c + r), a.Nr) * a.Nc;
 #pragma unroll(kSwtTapUnroll<HLEN>)
                 for (int j = 0; j < HLEN; ++j) {
                     const rv4 v = interior ? load4u(row + x0 + (j - c) * f) : load4_periodic(row, x0 + (j - c) * f, a.Nc);
@@ -340,12 +360,12 @@ PDWT_DEVICE void swt2_fwd_vec_tile(const Swt2DArgs& a, int bx, int by, int bz, r
                 fma4(rD, h, th);
             }
             const int si = it * TY + ty0 + i;
-            if (si < M && x0 < a.Nc) {
+            if (ph + f * si < a.Nr && x0 < a.Nc) {
                 const long long o = boff + (long long)(ph + f * si) * a.Nc + x0;
-                store4(a.A + o, rA);
-                store4(a.H + o, rH);
-                store4(a.V + o, rV);
-                store4(a.D + o, rD);
+                store4_row(a.A + o, rA, x0, a.Nc, rows16);
+                store4_row(a.H + o, rH, x0, a.Nc, rows16);
+                store4_row(a.V + o, rV, x0, a.Nc, rows16);
+                store4_row(a.D + o, rD, x0, a.Nc, rows16);
             }
         }
     }
@@ -379,16 +399,17 @@ PDWT_DEVICE void swt2_inv_vec_tile(const Swt2DArgs& a, int bx, int by, int bz, r
     static_assert(HLEN > 0 && TX % 4 == 0 && NT % QX == 0 && TY % NG == 0, "tile/thread shape");
     constexpr int c = HLEN / 2;  // synthesis centre
     constexpr int RY = TY + HLEN - 1;
-    const int f = a.f, M = a.Nr / f, ph = by % f, it = by / f;
+    const int f = a.f, ph = by % f, it = by / f;
     real_t* u1 = smem;
     real_t* u2 = u1 + RY * TX;
     const long long boff = (long long)bz * a.bstride;
     const real_t zero = 0, half = (real_t)0.5;
+    const bool rows16 = !(a.Nc & 3) && !(a.bstride & 3);  // every row starts 16-B aligned and ends with a whole quad
 
     // dilated row synthesis: u1 = Lx(A) + Hx(V), u2 = Lx(H) + Hx(D) (pending soft threshold applied to the detail
     // bands as they are loaded, never to A)
     const bool interior = bx * TX - c * f >= 0 && bx * TX + TX + (HLEN - 1 - c) * f <= a.Nc;  // see the forward tile
-    if (swt_inv_staged<TX, TY, NT>(HLEN, f)) {
+    if (rows16 && swt_inv_staged<TX, TY, NT>(HLEN, f)) {
         // staged: per trip every row group (QX threads) loads its row of the four bands once -- tile + halo columns,
         // periodic, whole quads (f, the tile origin and Nc are multiples of 4) -- then takes its taps from LDS
         constexpr int SW = TX + kSwtStageHalo + 4;        // floats per staged band row
@@ -401,8 +422,7 @@ PDWT_DEVICE void swt2_inv_vec_tile(const Swt2DArgs& a, int bx, int by, int bz, r
             PDWT_FOR_THREADS(tid, NT) {
                 const int k4 = tid % QX, g = tid / QX, r = g + t * NG;
                 if (r < RY) {
-                    const int i = wrap_periodic(it * TY - c + r, M);
-                    const long long ro = boff + (long long)(ph + f * i) * a.Nc;
+                    const long long ro = boff + (long long)wrap_periodic(ph + f * (it * TY - c + r), a.Nr) * a.Nc;
                     real_t* sg = stage + g * 4 * SW;
                     for (int q = k4; q < W4; q += QX) {
                         const int p = wrap_periodic(bx * TX - xl + 4 * q, a.Nc);  // a multiple of 4: the quad never straddles
@@ -458,8 +478,7 @@ PDWT_DEVICE void swt2_inv_vec_tile(const Swt2DArgs& a, int bx, int by, int bz, r
         for (int r = tid / QX; r < RY; r += NG) {
             rv4 r1 = {zero, zero, zero, zero}, r2 = r1;
             if (x0 < a.Nc) {
-                const int i = wrap_periodic(it * TY - c + r, M);
-                const long long ro = boff + (long long)(ph + f * i) * a.Nc;
+                const long long ro = boff + (long long)wrap_periodic(ph + f * (it * TY - c + r), a.Nr) * a.Nc;
                 if (interior) {
 #pragma unroll(kSwtInvTapUnroll<HLEN, TX>)
                     for (int j = 0; j < HLEN; ++j) {
@@ -500,9 +519,9 @@ PDWT_DEVICE void swt2_inv_vec_tile(const Swt2DArgs& a, int bx, int by, int bz, r
                 fma4(r, load4(u2 + (ty0 + i + j) * TX + 4 * k4), a.fb.hi[HLEN - 1 - j]);
             }
             const int si = it * TY + ty0 + i;
-            if (si < M && x0 < a.Nc) {
+            if (ph + f * si < a.Nr && x0 < a.Nc) {
                 r.x *= half; r.y *= half; r.z *= half; r.w *= half;
-                store4(a.out + boff + (long long)(ph + f * si) * a.Nc + x0, r);
+                store4_row(a.out + boff + (long long)(ph + f * si) * a.Nc + x0, r, x0, a.Nc, rows16);
             }
         }
     }
@@ -685,7 +704,7 @@ __global__ void __launch_bounds__(NT) swt2_inv_kernel(const Swt2DArgs a) {
 template <int TX, int TY>
 __device__ __forceinline__ bool swt_vec_tile(const Swt2DArgs& a, int block, int& bx, int& by) {
     const int tiles_x = (a.Nc + TX - 1) / TX;
-    const int nrt = (a.Nr / a.f + TY - 1) / TY;  // row tiles per phase
+    const int nrt = ((a.Nr + a.f - 1) / a.f + TY - 1) / TY;  // row tiles per phase (the longest one)
     const int total = tiles_x * nrt * a.f;
     const int chunk = (total + 7) >> 3;
     const int tile = (block & 7) * chunk + (block >> 3);

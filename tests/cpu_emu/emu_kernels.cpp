@@ -147,7 +147,7 @@ template <int HLEN, bool INV>
 static void run_swt2(const Swt2DArgs& a, int batch) {
     constexpr int TX = 64, TY = 16, NT = 256;
     std::vector<float> smem(swt2d_lds_floats<TX, TY>(a.hlen) + 64, -12345.f);
-    const int M = a.Nr / a.f;
+    const int M = cdiv(a.Nr, a.f);  // the longest dilation phase (f need not divide Nr)
     for (int bz = 0; bz < batch; bz++)
         for (int by = 0; by < cdiv(M, TY) * a.f; by++)
             for (int bx = 0; bx < cdiv(a.Nc, TX); bx++) {
@@ -160,7 +160,7 @@ template <int HLEN, bool INV, int TX = 128>
 static void run_swt2_vec(const Swt2DArgs& a, int batch) {
     constexpr int TY = 16, NT = 256;
     std::vector<float> smem(swt2d_inv_vec_lds_floats<TX, TY, NT>(HLEN, true) + 64, NAN);
-    const int M = a.Nr / a.f;
+    const int M = cdiv(a.Nr, a.f);  // the longest dilation phase (f need not divide Nr)
     for (int bz = 0; bz < batch; bz++)
         for (int by = 0; by < cdiv(M, TY) * a.f; by++)
             for (int bx = 0; bx < cdiv(a.Nc, TX); bx++) {
@@ -176,16 +176,15 @@ EMU_API int emu_swt2(int inverse, float* io, int batch, int Nr, int Nc, int leve
     Swt2DArgs a;
     a.in = io; a.out = io; a.A = A; a.H = H; a.V = V; a.D = D;
     a.Nr = Nr; a.Nc = Nc; a.f = 1 << (level - 1); a.bstride = (long long)Nr * Nc; a.hlen = hlen; a.soft_beta = 0.f;
-    if (Nr % a.f) return -2;
     set_bank(a.fb, lo, hi, hlen);
     if (generic == 3) {  // the 256-column tiles the host uses for hlen 2 and 4
-        if ((Nc & 3) || (hlen != 2 && hlen != 4)) return -3;
+        if (Nc < 4 || (hlen != 2 && hlen != 4)) return -3;
         if (hlen == 2) { if (inverse) run_swt2_vec<2, true, 256>(a, batch); else run_swt2_vec<2, false, 256>(a, batch); }
         else { if (inverse) run_swt2_vec<4, true, 256>(a, batch); else run_swt2_vec<4, false, 256>(a, batch); }
         return 0;
     }
     if (generic == 2) {
-        if ((hlen & 1) || (Nc & 3)) return -3;
+        if ((hlen & 1) || Nc < 4) return -3;  // rows of any length (round 5)
         switch (hlen) {
 #define X(h) case h: if (inverse) run_swt2_vec<h, true>(a, batch); else run_swt2_vec<h, false>(a, batch); return 0;
             EMU_EVEN_HLENS(X)

@@ -121,11 +121,14 @@ def test_emu_dwt1_levels(wname, generic):
 @pytest.mark.parametrize("generic", [0, 1, 2, 3])
 def test_emu_swt2_levels(wname, generic):
     hlen, dlo, dhi, rlo, rhi = oracle.filters(wname)
-    shapes = [((32, 32), 1), ((32, 48), 2), ((64, 70), 3), ((48, 33), 4), ((40, 20), 2)]
-    if generic >= 2:  # vectorised tiles: columns % 4 == 0, even filter length (3: 256-column tiles, hlen 2/4)
+    # (rows the dilation does not divide -- 30 rows at dilation 4, 21 at 2 -- since round 5: the tiles wrap rows, not phase indices)
+    shapes = [((32, 32), 1), ((32, 48), 2), ((64, 70), 3), ((48, 33), 4), ((40, 20), 2), ((30, 44), 3), ((21, 33), 2), ((7, 9), 3)]
+    if generic >= 2:  # vectorised tiles: even filter length (3: 256-column tiles, hlen 2/4); rows of any length since round 5
         if (hlen & 1) or (generic == 3 and hlen > 4):
             pytest.skip("filter length without this tile shape")
-        shapes = [((32, 32), 1), ((32, 48), 2), ((64, 136), 3), ((48, 260), 4), ((40, 20), 2), ((16, 4), 1), ((64, 8), 3)]
+        shapes = [((32, 32), 1), ((32, 48), 2), ((64, 136), 3), ((48, 260), 4), ((40, 20), 2), ((16, 4), 1), ((64, 8), 3),
+                  ((32, 33), 1), ((32, 130), 2), ((64, 135), 3), ((16, 261), 1), ((24, 7), 2), ((8, 5), 1), ((32, 258), 4),
+                  ((30, 44), 3), ((21, 33), 2), ((47, 131), 4), ((2047 // 16, 36), 2), ((7, 12), 3)]
     for si, (shape, level) in enumerate(shapes):
         x = oracle.hash_input(shape, 1700 + si)
         # level-l analysis of an arbitrary plane == oracle analysis with dilation 2^(l-1)

@@ -916,3 +916,29 @@ def test_swt_batches_whose_rows_the_dilation_does_not_divide(wname, shape, level
     for b, (x, ora) in refs.items():
         assert np.abs(plan.image_at(b) - x).max() <= reconstruction_tol(x, wname, L, do_swt=1, ora=ora), b
     plan.cleanup()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("wname", ["haar", "db2", "db4", "sym8", "db10"])
+def test_swt_any_width_and_any_row_count(wname):
+    """Round 5 (missing 4): the tiled SWT kernels take rows of ANY length (16-B accesses at 4-B alignment, the
+    partial quad at the row end element by element) and ANY row count (where the dilation does not divide it the tiles wrap rows,
+    not phase indices) -- the reference's kernels take any size (pdwt/src/separable.cu:409-493, 553-626; odd sizes are an option of
+    its tests, test/test_wavelets.py:43).  Until then such planes ran on one-sample-per-thread kernels at twice the time.  Every
+    band against the oracle, the soft threshold folded into the inverse, the reconstruction against the oracle's."""
+    from pypwt_amd import Wavelets
+    for si, (shape, L) in enumerate([((2047, 2047), 2), ((1002, 1002), 2), ((513, 515), 3), ((301, 523), 2), ((64, 1001), 3), ((1023, 256), 3)]):
+        if shape[0] > 1500 and wname == "db10":
+            continue  # (the 40 MB oracle pass of the longest filter: covered at the smaller sizes)
+        x = oracle.hash_input(shape, 5150 + si)
+        w = Wavelets(x, wname, L, do_swt=1)
+        w.forward()
+        ref = oracle.forward(x, wname, w.levels, do_swt=1)
+        for k, (g, r) in enumerate(zip(flat_coeffs(w), ref)):
+            assert g.shape == r.shape
+            assert np.abs(g - r).max() <= 2e-6 * (1 + w.levels) * max(float(np.abs(r).max()), 255.0), (wname, shape, k)
+        w.soft_threshold(7.5)
+        w.inverse()
+        thr = oracle.threshold(ref, shape, w.levels, "soft", 7.5, do_swt=1)
+        want = oracle.inverse(thr, shape, wname, w.levels, do_swt=1)
+        assert np.abs(w.image - want).max() <= 4e-6 * (1 + w.levels) * 255.0, (wname, shape)
