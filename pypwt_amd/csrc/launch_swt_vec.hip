@@ -32,11 +32,17 @@ static hipError_t run_vec(const Swt2DArgs& a, int batch, hipStream_t s) {
 
 static bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & (4 * sizeof(real_t) - 1)) == 0; }
 
-// preconditions of the vectorised kernels: even compile-time filter length, planes aligned for 4-element accesses; rows of any
-// length (round 5: rows that are not whole aligned quads take the kernels' unaligned 16-B loads / stores and element stores at
-// the row end; images narrower than a quad stay on the one-sample-per-thread kernels)
+// preconditions of the vectorised kernels: even compile-time filter length, planes aligned for 4-element accesses.  Rows of any
+// length since round 5 (16-B accesses at 4-B alignment, the partial quad at a row's end element by element) -- where that
+// pays: measured on 1002^2 / 2047^2 (profiles/r05d_cliffs_swt_odd.txt) the unaligned forward is within 1.1x of the aligned one
+// from 6 taps on and the inverse where it stages its band rows in LDS; 2- and 4-tap levels and unstaged inverses are faster on
+// the one-column-per-thread tiles (haar 1002^2 forward 14.3 against 18.8 us).
 static bool vec_ok(const Swt2DArgs& a, bool inverse) {
     if ((a.hlen & 1) || a.hlen < 2 || a.hlen > kMaxTaps || a.Nc < 4) return false;
+    if ((a.Nc & 3) || (a.bstride & 3)) {
+        if (sizeof(real_t) != 4) return false;
+        if (inverse ? !swt_inv_staged_filter(a.hlen, a.f) : a.hlen < 6) return false;
+    }
     if (!al16(a.A) || !al16(a.H) || !al16(a.V) || !al16(a.D)) return false;
     return al16(inverse ? (const void*)a.out : (const void*)a.in);
 }

@@ -510,7 +510,11 @@ void build_schedule(pdwt_plan* p) {
         const long long swt_bytes = (long long)sizeof(real_t) * (3 * L + 2) * p->batch * p->info.Nr * p->info.Nc;
         auto swt_group = [&](int l, bool inverse) {
             if (!swt || !p->do_separable || !p->tune.swt_fused) return 0;
-            if (swt_bytes > (320LL << 20) && p->tune.swt_fused < 2 && !(inverse && sizeof(real_t) == 4))
+            // Round 5: the fused forward of a 2-tap batch beyond the cache runs IMAGE BY IMAGE (forward_impl): one image's 3 K + 1 output
+            // streams at a time instead of the whole batch's -- 2 / 4 x 2048^2 haar L3 forward 97.7 / 212.7 us level by level, 108.6 /
+            // 217.9 fused over the batch, 92.0 / 194.0 fused image by image; L5, 4 images: 349 / 409 / 319 (tools/swt_batch_probe.py,
+            // profiles/r05d_swt_batch_probe.txt).  4-tap pairs stay level by level there (db2: 101 against 115 us).
+            if (swt_bytes > (320LL << 20) && p->tune.swt_fused < 2 && !(inverse && sizeof(real_t) == 4) && !(hlen == 2 && sizeof(real_t) == 4))
                 return 0;  // "swt_fused" = 2 forces both directions (tests)
             for (int K = (L - l + 1 < 3 ? L - l + 1 : 3); K >= 2; --K) {
                 const bool same_plane = K == 2 && l - 1 >= 1 && l + K - 1 <= L - 1;
@@ -970,8 +974,21 @@ int forward_impl(pdwt_plan* p, int only = 0) {
             for (int k = 0; k < 3 * s.K; k++) det[k] = p->band(3 * (l - 1) + 1 + k);
             Stamp st(p, "swt2_fwd_fused", &e);
             if (!run) continue;
-            e = launch_swt2_fused(approx_slot(p, l - 1), approx_slot(p, l + s.K - 1), det, p->info.Nr, p->info.Nc, l, s.K, false,
-                                  p->info.hlen, p->dec, nullptr, B, p->stream);
+            const long long plane = (long long)p->info.Nr * p->info.Nc;
+            const bool beyond_cache = (long long)sizeof(real_t) * (3 * L + 2) * B * plane > (320LL << 20);
+            if (B > 1 && beyond_cache && p->tune.swt_fused < 2) {
+                // image by image (build_schedule: swt_group): the same kernel, one image's output streams at a time
+                for (int b = 0; b < B; b++) {
+                    real_t* db[9] = {};
+                    for (int k = 0; k < 3 * s.K; k++) db[k] = det[k] + b * plane;
+                    e = launch_swt2_fused(approx_slot(p, l - 1) + b * plane, approx_slot(p, l + s.K - 1) + b * plane, db, p->info.Nr, p->info.Nc, l,
+                                          s.K, false, p->info.hlen, p->dec, nullptr, 1, p->stream);
+                    if (e != hipSuccess) break;
+                }
+            } else {
+                e = launch_swt2_fused(approx_slot(p, l - 1), approx_slot(p, l + s.K - 1), det, p->info.Nr, p->info.Nc, l, s.K, false,
+                                      p->info.hlen, p->dec, nullptr, B, p->stream);
+            }
         } else if (s.kind == Step::REG1D) {
             real_t* det[kMaxFusedLevelsHost] = {};
             for (int k = 0; k < s.K; k++) det[k] = p->band(l + k);

@@ -409,9 +409,9 @@ PDWT_DEVICE void swt2_inv_vec_tile(const Swt2DArgs& a, int bx, int by, int bz, r
     // dilated row synthesis: u1 = Lx(A) + Hx(V), u2 = Lx(H) + Hx(D) (pending soft threshold applied to the detail
     // bands as they are loaded, never to A)
     const bool interior = bx * TX - c * f >= 0 && bx * TX + TX + (HLEN - 1 - c) * f <= a.Nc;  // see the forward tile
-    if (rows16 && swt_inv_staged<TX, TY, NT>(HLEN, f)) {
+    if (swt_inv_staged<TX, TY, NT>(HLEN, f)) {
         // staged: per trip every row group (QX threads) loads its row of the four bands once -- tile + halo columns,
-        // periodic, whole quads (f, the tile origin and Nc are multiples of 4) -- then takes its taps from LDS
+        // periodic (whole aligned quads where the rows are; else unaligned 16-B loads) -- then takes its taps from LDS
         constexpr int SW = TX + kSwtStageHalo + 4;        // floats per staged band row
         constexpr int TRIPS = (RY + NG - 1) / NG;
         const int padp = (4 - ((c * f) & 3)) & 3;          // the staged row starts at the 4-aligned column below bx TX - c f
@@ -424,12 +424,22 @@ PDWT_DEVICE void swt2_inv_vec_tile(const Swt2DArgs& a, int bx, int by, int bz, r
                 if (r < RY) {
                     const long long ro = boff + (long long)wrap_periodic(ph + f * (it * TY - c + r), a.Nr) * a.Nc;
                     real_t* sg = stage + g * 4 * SW;
-                    for (int q = k4; q < W4; q += QX) {
-                        const int p = wrap_periodic(bx * TX - xl + 4 * q, a.Nc);  // a multiple of 4: the quad never straddles
-                        store4(sg + 4 * q, load4(a.A + ro + p));
-                        store4(sg + SW + 4 * q, soft4(load4(a.V + ro + p), a.soft_beta));
-                        store4(sg + 2 * SW + 4 * q, soft4(load4(a.H + ro + p), a.soft_beta));
-                        store4(sg + 3 * SW + 4 * q, soft4(load4(a.D + ro + p), a.soft_beta));
+                    if (rows16) {
+                        for (int q = k4; q < W4; q += QX) {
+                            const int p = wrap_periodic(bx * TX - xl + 4 * q, a.Nc);  // a multiple of 4: the quad never straddles
+                            store4(sg + 4 * q, load4(a.A + ro + p));
+                            store4(sg + SW + 4 * q, soft4(load4(a.V + ro + p), a.soft_beta));
+                            store4(sg + 2 * SW + 4 * q, soft4(load4(a.H + ro + p), a.soft_beta));
+                            store4(sg + 3 * SW + 4 * q, soft4(load4(a.D + ro + p), a.soft_beta));
+                        }
+                    } else {  // rows of any length: 16-B loads at 4-B alignment, the quads at the row ends element by element
+                        for (int q = k4; q < W4; q += QX) {
+                            const int p = bx * TX - xl + 4 * q;
+                            store4(sg + 4 * q, load4_periodic(a.A + ro, p, a.Nc));
+                            store4(sg + SW + 4 * q, soft4(load4_periodic(a.V + ro, p, a.Nc), a.soft_beta));
+                            store4(sg + 2 * SW + 4 * q, soft4(load4_periodic(a.H + ro, p, a.Nc), a.soft_beta));
+                            store4(sg + 3 * SW + 4 * q, soft4(load4_periodic(a.D + ro, p, a.Nc), a.soft_beta));
+                        }
                     }
                 }
             }
