@@ -1,9 +1,9 @@
 #!/bin/bash
-# Round-end evidence run on the GPU box:   gpurun -- 'bash tools/final_evidence.sh r04z'
+# Round-end evidence run on the GPU box:   gpurun -- 'bash tools/final_evidence.sh r05z'
 # GPU tests, every bench line, rocprofv3 kernel-trace summaries + PMC traffic per configuration -> gpurun_out/<tag>/
 # (copy what is to be judged into profiles/).
 set -euo pipefail
-TAG="${1:-r04z}"
+TAG="${1:-r05z}"
 ROOT="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"
 cd "$ROOT"
 OUT="gpurun_out/$TAG"
@@ -24,7 +24,17 @@ timeout 900 python3 tools/cliffs.py dwt2 swt2 dwt1 swt1 > "$OUT/cliffs.txt" 2> /
 timeout 300 python3 tools/opsbench.py > "$OUT/opsbench.txt" 2> /dev/null || echo "opsbench exit $?"
 PDWT_BENCH_SHARE_GPU=1 timeout 400 python3 bench.py --gpus 2 --single-process --config cfg2 --batch 8 --no-cpu-baseline > "$OUT/bench_single_process_two_shards_one_gpu.json" 2> "$OUT/bench_single_process.err" || echo "single-process exit $?"
 timeout 600 python3 tools/tiledbench.py > "$OUT/tiledbench.txt" 2> "$OUT/tiledbench.err" || echo "tiledbench exit $?"
+# round 5: the register-ring level kernels next to the LDS tiles -- alone (same harness) and inside plans (same process)
+for h in 10 12 14 16 18 20; do
+    [ -x tools/bin/ringbench_${h}_4 ] && { tools/bin/ringbench_${h}_4 4096 $((h)) 1; tools/bin/ringbench_${h}_4 4096 $((2 * h)) 4; tools/bin/ringbench_${h}_4 2048 $((h / 2)) 1; } >> "$OUT/ringbench.txt" 2>&1 || true
+done
+timeout 600 python3 tools/ring_ab.py > "$OUT/ring_ab.txt" 2> /dev/null || echo "ring_ab exit $?"
+timeout 300 python3 tools/dispatch_discover.py > "$OUT/dispatch_discover.txt" 2> /dev/null || echo "dispatch_discover exit $?"
+timeout 600 python3 tools/cliffs.py odd > "$OUT/cliffs_odd.txt" 2> /dev/null || echo "cliffs odd exit $?"
 export TMPDIR=/tmp
+PDWT_PLANPROF_BATCH=4 bash tools/planprof.sh "${TAG}_sym8_b4" sym8 4096 4096 1 4 > "$OUT/planprof_sym8_b4.log" 2>&1 || echo "planprof sym8 b4 exit $?"
+cp "gpurun_out/planprof_${TAG}_sym8_b4/summary.txt" "$OUT/planprof_sym8_L1_b4_default_dispatch.txt" 2> /dev/null || true
+rm -rf "gpurun_out/planprof_${TAG}_sym8_b4"
 tools/prof.sh "${TAG}_cfg2_b16" --config cfg2 --batch 16 > "$OUT/prof_cfg2_b16.log" 2>&1 || echo "prof b16 exit $?"
 python3 tools/summarize_pmc.py "gpurun_out/prof_${TAG}_cfg2_b16" "$OUT/traffic_cfg2_b16.json" cfg2 > "$OUT/rocprofv3_summary_cfg2_b16.txt" 2>&1 || echo "summarize b16 exit $?"
 rm -rf "gpurun_out/prof_${TAG}_cfg2_b16"
