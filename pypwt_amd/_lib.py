@@ -130,6 +130,8 @@ def load(variant="f32"):
     path, real = {"f32": (LIB_PATH, C.c_float), "f64": (LIB_PATH_F64, C.c_double), "lab": (LIB_PATH_LAB, C.c_float)}[variant]
     if variant == "f32" and os.environ.get("PDWT_LIB_F32"):  # A/B measurements: another build of the fp32 library
         path = os.environ["PDWT_LIB_F32"]
+    if variant == "f64" and os.environ.get("PDWT_LIB_F64"):  # ... of the fp64 library
+        path = os.environ["PDWT_LIB_F64"]
     if not os.path.exists(path):
         raise ImportError(
             "pypwt_amd: %s is missing. Build it with `python -m pypwt_amd.build` (needs hipcc). "

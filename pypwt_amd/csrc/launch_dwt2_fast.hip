@@ -176,7 +176,8 @@ hipError_t try_launch_dwt2_fwd_fast(const Fwd2DArgs& a, int batch, hipStream_t s
         if constexpr (h <= 8) return run_fwd_fast_tile<h, 64, 8, 256>(a, batch, s);   \
         else if constexpr (sizeof(real_t) == 8) {                                     \
             if constexpr (h <= 20) return run_fwd_fast_tile<h, 64, 16, 512>(a, batch, s); \
-            else return run_fwd_fast_tile<h, 32, 16, 256>(a, batch, s); /* 70 x 168 doubles = 94 KB */ \
+            else if (small_level) return run_fwd_fast_tile<h, 32, 16, 256>(a, batch, s); /* 70 x 168 doubles = 94 KB */ \
+            else return run_fwd_fast_tile<h, 32, 32, 512>(a, batch, s); /* 137 KB: one workgroup per CU, but eight wavefronts instead of four */ \
         } else if (small_level) return run_fwd_fast_tile<h, 32, 16, 256>(a, batch, s);  \
         else if constexpr (h <= 16) return run_fwd_fast_tile<h, 64, 16, 512>(a, batch, s); \
         else return run_fwd_fast_tile<h, 32, 32, 512>(a, batch, s);

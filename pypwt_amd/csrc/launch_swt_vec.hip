@@ -91,6 +91,21 @@ hipError_t try_launch_swt2_vec(const Swt2DArgs& a, bool inverse, int batch, hipS
 #undef X
         }
     }
+    // fp64, more than 24 taps: a 128-column tile of doubles is 112-145 KB of LDS -- one workgroup of four wavefronts per CU.  64 x 16
+    // tiles of 256 threads are 56 KB: two workgroups, eight wavefronts (round 5; forward + inverse, three levels: 26 taps 1024^2
+    // 677 -> 333 us, 32 taps 547 -> 230, 40 taps 512^2 1003 -> 483 -- but 40 taps 2048^2 3288 -> 3934: images below 2^22 samples only;
+    // profiles/r05e_f64_ab.txt)
+    if (sizeof(real_t) == 8 && a.hlen > 24 && (long long)a.Nr * a.Nc * batch < (1LL << 22)) {
+        switch (a.hlen) {
+#define X(h)                                                                                                   \
+    case h:                                                                                                    \
+        if constexpr (h > 24)                                                                                  \
+            return inverse ? run_vec<h, true, 64, 16, 256>(a, batch, s) : run_vec<h, false, 64, 16, 256>(a, batch, s); \
+        break;
+            PDWT_EVEN_HLENS(X)
+#undef X
+        }
+    }
     switch (a.hlen) {
 #define X(h)                                                                                                   \
     case h:                                                                                                    \

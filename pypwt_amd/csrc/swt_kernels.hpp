@@ -284,7 +284,9 @@ constexpr int swt2d_vec_lds_floats(int hlen) { return 2 * (TY + hlen - 1) * TX; 
 // (tile + (hlen - 1) f halo columns, at most kSwtStageHalo, from a 4-aligned origin) in LDS once -- 4 (1 + halo / TX)
 // global loads per quad instead of 4 hlen -- and takes the taps from there: aligned 16-B LDS reads where the dilation is a
 // multiple of 4 (levels >= 3), four 4-B reads at dilation 1 and 2.
-constexpr int kSwtStageHalo = 256;
+// (doubles: 128 columns of halo -- with 256 the staged rows of a 128 x 16 tile are 163-171 KB from 16 taps on and the fp64 inverse of
+// 10+ taps fell back to one 32-B load per band and tap: 4.5-6x the fp32 time, round 5)
+constexpr int kSwtStageHalo = sizeof(real_t) == 8 ? 128 : 256;
 // (measured per 2048^2 level: 16 taps 193 -> 95 us at dilation 4+, 200 -> 139 us at dilation 1, 2; 8 taps 45 -> 32 and 53 -> 49 us;
 // 4 taps 25 -> 25 and 28 -> 35 us: short filters keep the direct loads)
 constexpr bool swt_inv_staged_filter(int hlen, int f) {
