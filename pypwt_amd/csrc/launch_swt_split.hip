@@ -6,18 +6,124 @@
 #include "launch.hpp"
 #include "launch_util.hpp"
 #include "swt_kernels_args.hpp"
-#ifndef PDWT_DOUBLE
+#ifdef PDWT_DOUBLE
+#include "swt_stream_kernels.hpp"
+#else
 #include "swt_split_kernels.hpp"
 #endif
 
 namespace pdwt {
 
 #ifdef PDWT_DOUBLE
-bool swt2_split_supported(int, int, int, int, bool, long long) { return false; }
-hipError_t try_launch_swt1_split(const SwtPassArgs&, bool, hipStream_t) { return hipErrorNotSupported; }
-int set_swt_split_min(int, int) { return 0; }
-int get_swt_split_min(int) { return 0; }
-hipError_t launch_swt2_split(const Swt2DArgs&, real_t*, bool, int, hipStream_t) { return hipErrorNotSupported; }
+// ---- fp64 library: the two launches are the any-length stream kernels of swt_stream_kernels.hpp (round 5) ----------------------
+static int env_int64(const char* name, int dflt) {
+    const char* e = lab_env(name);
+    return e ? atoi(e) : dflt;
+}
+// shortest filter on this path (tuning keys "swt_split_fwd" / "swt_split_inv"; 0 = never, 100 + n = n taps at every size)
+static std::atomic<int>& split_min(bool inverse) {
+    static std::atomic<int> fwd{env_int64("PDWT_SWT_SPLIT_FWD", 12)}, inv{env_int64("PDWT_SWT_SPLIT_INV", 6)};
+    return inverse ? inv : fwd;
+}
+int set_swt_split_min(int inverse, int taps) { return split_min(inverse != 0).exchange(taps < 0 ? 0 : taps); }
+int get_swt_split_min(int inverse) { return split_min(inverse != 0).load(std::memory_order_relaxed); }
+
+bool swt2_split_supported(int hlen, int Nr, int Nc, int f, bool inverse, long long samples) {
+    const Tuning* at = active_tuning();
+    int min_taps = at ? (inverse ? at->swt_split_inv : at->swt_split_fwd) : split_min(inverse).load(std::memory_order_relaxed);
+    if (min_taps <= 0) return false;
+    if (min_taps >= 100) min_taps -= 100;
+    (void)samples;
+    if (hlen < 2 || hlen > kMaxTaps || hlen < min_taps) return false;
+    return f >= 1 && f < Nr && f < Nc;
+}
+
+static void stream_taps(SwtStreamArgs& k, const FilterBank& fb, int hlen) {
+    for (int j = 0; j < kStreamTaps; ++j) k.tl[j] = k.th[j] = 0;
+    for (int j = 0; j < hlen; ++j) {
+        k.tl[kStreamPadL + j] = fb.lo[hlen - 1 - j];
+        k.th[kStreamPadL + j] = fb.hi[hlen - 1 - j];
+    }
+}
+
+template <bool SYN, bool ALONG_Y, int NC, int R, int NT>
+static hipError_t go_stream(const SwtStreamArgs& k, hipStream_t s) {
+    const long long waves = ALONG_Y ? stream_waves_y(k.problems, k.batch, k.Nr, k.Nc, k.f, R, NC)
+                                    : stream_waves_x(k.problems, k.batch, k.Nr, k.Nc, k.f, R, NC);
+    hipLaunchKernelGGL((swt_stream_kernel<SYN, ALONG_Y, NC, R, NT>), dim3((unsigned)cdivll(waves, NT / 64)), dim3(NT), 0, s, k);
+    return hipGetLastError();
+}
+// outputs per work item (A/B builds: -DPDWT_STREAM_R_...): analysis | synthesis, one column | a pair of columns per work item
+#ifndef PDWT_STREAM_R_A1
+#define PDWT_STREAM_R_A1 4
+#define PDWT_STREAM_R_A2 4
+#define PDWT_STREAM_R_S1 4
+#define PDWT_STREAM_R_S2 4
+#define PDWT_STREAM_NT_Y 512
+#endif
+// pairs of columns (16-B accesses) where rows are even and the planes 16-B aligned; along x the dilation must be even too
+template <bool SYN, bool ALONG_Y>
+static hipError_t run_stream(const SwtStreamArgs& k, bool pairs, hipStream_t s) {
+    constexpr int NT = ALONG_Y ? PDWT_STREAM_NT_Y : 256;
+    constexpr int R1 = SYN ? PDWT_STREAM_R_S1 : PDWT_STREAM_R_A1, R2 = SYN ? PDWT_STREAM_R_S2 : PDWT_STREAM_R_A2;
+    if (pairs && (ALONG_Y || !(k.f & 1))) return go_stream<SYN, ALONG_Y, 2, R2, NT>(k, s);
+    return go_stream<SYN, ALONG_Y, 1, R1, NT>(k, s);
+}
+static bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// scratch: 2 * Nr * Nc * batch elements
+hipError_t launch_swt2_split(const Swt2DArgs& a, real_t* tmp, bool inverse, int batch, hipStream_t s) {
+    if (!swt2_split_supported(a.hlen, a.Nr, a.Nc, a.f, inverse, (long long)batch * a.Nr * a.Nc) || !tmp) return hipErrorNotSupported;
+    const long long plane = (long long)a.Nr * a.Nc;
+    const bool pairs = !(a.Nc & 1) && !(a.bstride & 1) && al16(tmp) && al16(a.A) && al16(a.H) && al16(a.V) && al16(a.D) &&
+                       al16(inverse ? (const void*)a.out : (const void*)a.in);
+    SwtStreamArgs k{};
+    k.Nr = a.Nr; k.Nc = a.Nc; k.f = a.f; k.batch = batch; k.hlen = a.hlen;
+    k.scale = (real_t)0.5;
+    stream_taps(k, a.fb, a.hlen);
+    if (!inverse) {
+        SwtStreamArgs r = k;  // in -> lo, hi (scratch: two planes per image)
+        r.problems = 1;
+        r.in[0][0] = a.in; r.in_bstride = a.bstride;
+        r.out[0][0] = tmp; r.out[0][1] = tmp + plane; r.out_bstride = 2 * plane;
+        hipError_t e = run_stream<false, false>(r, pairs, s);
+        if (e != hipSuccess) return e;
+        SwtStreamArgs c = k;  // lo -> A, H ; hi -> V, D
+        c.problems = 2;
+        c.in[0][0] = tmp; c.in[1][0] = tmp + plane; c.in_bstride = 2 * plane;
+        c.out[0][0] = a.A; c.out[0][1] = a.H; c.out[1][0] = a.V; c.out[1][1] = a.D; c.out_bstride = a.bstride;
+        return run_stream<false, true>(c, pairs, s);
+    }
+    SwtStreamArgs c = k;  // (A, H) -> L' ; (V, D) -> H' (scratch), the pending soft threshold applied to H, V, D on the way in
+    c.problems = 2;
+    c.in[0][0] = a.A; c.in[0][1] = a.H; c.in[1][0] = a.V; c.in[1][1] = a.D; c.in_bstride = a.bstride;
+    c.soft[0][1] = c.soft[1][0] = c.soft[1][1] = a.soft_beta;
+    c.out[0][0] = tmp; c.out[1][0] = tmp + plane; c.out_bstride = 2 * plane;
+    hipError_t e = run_stream<true, true>(c, pairs, s);
+    if (e != hipSuccess) return e;
+    SwtStreamArgs r = k;  // (L', H') -> out
+    r.problems = 1;
+    r.in[0][0] = tmp; r.in[0][1] = tmp + plane; r.in_bstride = 2 * plane;
+    r.out[0][0] = a.out; r.out_bstride = a.bstride;
+    return run_stream<true, false>(r, pairs, s);
+}
+
+// the (batched) 1D transform: rows of Nc samples, or columns (along_y) of a plane
+hipError_t try_launch_swt1_split(const SwtPassArgs& a, bool inverse, hipStream_t s) {
+    const Tuning* at = active_tuning();  // the same thresholds as the 2D level
+    int min_taps = at ? (inverse ? at->swt_split_inv : at->swt_split_fwd) : split_min(inverse).load(std::memory_order_relaxed);
+    if (min_taps >= 100) min_taps -= 100;
+    if (min_taps <= 0 || a.hlen < min_taps || a.hlen < 2 || a.hlen > kMaxTaps) return hipErrorNotSupported;
+    if (a.f < 1 || a.f >= (a.along_y ? a.Nr : a.Nc)) return hipErrorNotSupported;
+    const bool pairs = !(a.Nc & 1) && al16(a.in0) && al16(a.out0) && (inverse ? al16(a.in1) : al16(a.out1));
+    SwtStreamArgs k{};
+    k.Nr = a.Nr; k.Nc = a.Nc; k.f = a.f; k.batch = 1; k.hlen = a.hlen; k.problems = 1;
+    k.scale = (real_t)0.5;
+    stream_taps(k, a.fb, a.hlen);
+    k.in[0][0] = a.in0; k.in[0][1] = a.in1; k.out[0][0] = a.out0; k.out[0][1] = a.out1;
+    if (a.along_y) return inverse ? run_stream<true, true>(k, pairs, s) : run_stream<false, true>(k, pairs, s);
+    return inverse ? run_stream<true, false>(k, pairs, s) : run_stream<false, false>(k, pairs, s);
+}
 #else
 
 // filter lengths the split kernels are built for

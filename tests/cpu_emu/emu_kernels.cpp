@@ -25,6 +25,7 @@
 #include "../../pypwt_amd/csrc/nonsep_kernels.hpp"
 #include "../../pypwt_amd/csrc/swt_kernels.hpp"
 #include "../../pypwt_amd/csrc/swt_split_kernels.hpp"
+#include "../../pypwt_amd/csrc/swt_stream_kernels.hpp"
 #include "../../pypwt_amd/csrc/dwt2_split_kernels.hpp"
 
 using namespace pdwt;
@@ -994,6 +995,72 @@ EMU_API int emu_swt2_split(int inverse, float* io, int batch, int Nr, int Nc, in
 #undef X
     }
     return -1;
+}
+
+// ---- one a-trous level as two launches of the any-length stream kernels (swt_stream_kernels.hpp: the fp64 library's long filters);
+// planes as in emu_swt2.  nc = columns per work item (2: pairs where rows are even), R = outputs per work item
+template <int NC, int R>
+static void run_swt_stream(const Swt2DArgs& a, int batch, bool inverse, float* tmp) {
+    constexpr int NT = 256;
+    const long long plane = (long long)a.Nr * a.Nc;
+    SwtStreamArgs k{};
+    k.Nr = a.Nr; k.Nc = a.Nc; k.f = a.f; k.batch = batch; k.hlen = a.hlen; k.scale = 0.5f;
+    for (int j = 0; j < a.hlen; ++j) {
+        k.tl[kStreamPadL + j] = a.fb.lo[a.hlen - 1 - j];
+        k.th[kStreamPadL + j] = a.fb.hi[a.hlen - 1 - j];
+    }
+    auto blocks = [](long long waves) { return (waves + NT / 64 - 1) / (NT / 64); };
+    auto rows = [&](const SwtStreamArgs& r, bool syn) {
+        const bool two = NC == 2 && !(a.f & 1);
+        const long long n = blocks(stream_waves_x(r.problems, batch, a.Nr, a.Nc, a.f, R, two ? 2 : 1));
+        for (long long b = 0; b < n; ++b) {
+            if (syn) { if (two) swt_stream_tile<true, false, NC, R, NT>(r, b); else swt_stream_tile<true, false, 1, R, NT>(r, b); }
+            else { if (two) swt_stream_tile<false, false, NC, R, NT>(r, b); else swt_stream_tile<false, false, 1, R, NT>(r, b); }
+        }
+    };
+    auto cols = [&](const SwtStreamArgs& c, bool syn) {
+        const long long n = blocks(stream_waves_y(c.problems, batch, a.Nr, a.Nc, a.f, R, NC));
+        for (long long b = 0; b < n; ++b) {
+            if (syn) swt_stream_tile<true, true, NC, R, NT>(c, b);
+            else swt_stream_tile<false, true, NC, R, NT>(c, b);
+        }
+    };
+    if (!inverse) {
+        SwtStreamArgs r = k;
+        r.problems = 1; r.in[0][0] = a.in; r.in_bstride = a.bstride;
+        r.out[0][0] = tmp; r.out[0][1] = tmp + plane; r.out_bstride = 2 * plane;
+        rows(r, false);
+        SwtStreamArgs c = k;
+        c.problems = 2; c.in[0][0] = tmp; c.in[1][0] = tmp + plane; c.in_bstride = 2 * plane;
+        c.out[0][0] = a.A; c.out[0][1] = a.H; c.out[1][0] = a.V; c.out[1][1] = a.D; c.out_bstride = a.bstride;
+        cols(c, false);
+        return;
+    }
+    SwtStreamArgs c = k;
+    c.problems = 2; c.in[0][0] = a.A; c.in[0][1] = a.H; c.in[1][0] = a.V; c.in[1][1] = a.D; c.in_bstride = a.bstride;
+    c.soft[0][1] = c.soft[1][0] = c.soft[1][1] = a.soft_beta;
+    c.out[0][0] = tmp; c.out[1][0] = tmp + plane; c.out_bstride = 2 * plane;
+    cols(c, true);
+    SwtStreamArgs r = k;
+    r.problems = 1; r.in[0][0] = tmp; r.in[0][1] = tmp + plane; r.in_bstride = 2 * plane;
+    r.out[0][0] = a.out; r.out_bstride = a.bstride;
+    rows(r, true);
+}
+
+EMU_API int emu_swt2_stream(int inverse, float* io, int batch, int Nr, int Nc, int level, const float* lo, const float* hi,
+                            int hlen, float soft_beta, float* A, float* H, float* V, float* D, int R) {
+    Swt2DArgs a;
+    a.in = io; a.out = io; a.A = A; a.H = H; a.V = V; a.D = D;
+    a.Nr = Nr; a.Nc = Nc; a.f = 1 << (level - 1); a.bstride = (long long)Nr * Nc; a.hlen = hlen; a.soft_beta = soft_beta;
+    if (a.f >= Nr || a.f >= Nc || hlen > kMaxTaps) return -2;
+    set_bank(a.fb, lo, hi, hlen);
+    std::vector<float> tmp((size_t)2 * Nr * Nc * batch + 16, NAN);
+    const bool two = !(Nc & 1);  // (the emulation's planes are 8-B aligned floats: pairs need even rows only)
+    if (R == 4) { if (two) run_swt_stream<2, 4>(a, batch, inverse != 0, tmp.data()); else run_swt_stream<1, 4>(a, batch, inverse != 0, tmp.data()); }
+    else if (R == 8) { if (two) run_swt_stream<2, 8>(a, batch, inverse != 0, tmp.data()); else run_swt_stream<1, 8>(a, batch, inverse != 0, tmp.data()); }
+    else if (R == 2) { if (two) run_swt_stream<2, 2>(a, batch, inverse != 0, tmp.data()); else run_swt_stream<1, 2>(a, batch, inverse != 0, tmp.data()); }
+    else return -1;
+    return 0;
 }
 
 // ---- the row kernels as the (batched) 1D transform: separate approximation / detail planes

@@ -862,6 +862,50 @@ def test_emu_swt_split_row_and_column_launches(wname, direct, monkeypatch):
                 assert np.abs(rec[b] - want).max() <= _tol(want), (wname, shape, level, "inverse", beta)
 
 
+@pytest.mark.parametrize("R", [2, 4, 8])
+@pytest.mark.parametrize("wname", ["haar", "db2", "db5", "sym8", "db10", "db13", "db20"])
+def test_emu_swt_stream_kernels(wname, R):
+    """swt_stream_kernels.hpp (the fp64 library's a-trous level of long filters: a row launch + a column launch of ONE kernel for
+    every filter length, taps by wave-uniform index out of a zero-padded table) vs the oracle's per-pass functions: every dilation,
+    odd row lengths (one column per work item), row counts the dilation does not divide, batches, the pending soft threshold"""
+    import ctypes as C
+    hlen, dlo, dhi, rlo, rhi = oracle.filters(wname)
+    lib_o = oracle.load()
+    cases = [((32, 32), 1, 1), ((33, 48), 2, 2), ((5, 2064), 1, 1), ((3, 1041), 2, 2), ((64, 136), 3, 1), ((50, 262), 4, 1), ((41, 21), 2, 1),
+             ((96, 100), 5, 1), ((24, 18), 1, 3), ((45, 73), 3, 1), ((130, 6), 2, 1)]
+    for si, (shape, level, B) in enumerate(cases):
+        f = 1 << (level - 1)
+        if f >= shape[0] or f >= shape[1]:
+            continue
+        x = np.stack([oracle.hash_input(shape, 4100 + 10 * si + b) for b in range(B)]).astype(np.float32)
+        outs = [np.full((B,) + shape, np.nan, dtype=np.float32) for _ in range(4)]
+        xin = x.copy()
+        assert lib().emu_swt2_stream(0, P(xin), B, shape[0], shape[1], level, P(dlo), P(dhi), hlen, C.c_float(0.0),
+                                     *[P(o) for o in outs], R) == 0
+        bands = [(oracle.hash_input((B,) + shape, 4500 + si * 4 + k, 2.0) - 1.0).astype(np.float32) for k in range(4)]
+        for beta in (0.0, 0.25):
+            rec = np.full((B,) + shape, np.nan, dtype=np.float32)
+            assert lib().emu_swt2_stream(1, P(rec), B, shape[0], shape[1], level, P(rlo), P(rhi), hlen, C.c_float(beta),
+                                         *[P(b) for b in bands], R) == 0
+            for b in range(B):
+                t1 = np.zeros(shape, np.float32); t2 = np.zeros(shape, np.float32)
+                if beta == 0.0:
+                    ref = [np.zeros(shape, np.float32) for _ in range(4)]
+                    lib_o.oracle_swt_analysis_rows(P(x[b]), shape[0], shape[1], P(dlo), P(dhi), hlen, level, P(t1), P(t2))
+                    lib_o.oracle_swt_analysis_cols(P(t1), shape[0], shape[1], P(dlo), P(dhi), hlen, level, P(ref[0]), P(ref[1]))
+                    lib_o.oracle_swt_analysis_cols(P(t2), shape[0], shape[1], P(dlo), P(dhi), hlen, level, P(ref[2]), P(ref[3]))
+                    for k in range(4):
+                        assert np.isfinite(outs[k][b]).all(), (wname, shape, level, k)
+                        assert np.abs(outs[k][b] - ref[k]).max() <= _tol(ref[k]), (wname, shape, level, k)
+                d = [np.ascontiguousarray(bands[0][b])] + [np.ascontiguousarray(bands[k][b] - np.clip(bands[k][b], -beta, beta)) for k in (1, 2, 3)]
+                lib_o.oracle_swt_synthesis_cols(P(d[0]), P(d[1]), shape[0], shape[1], P(rlo), P(rhi), hlen, level, P(t1))
+                lib_o.oracle_swt_synthesis_cols(P(d[2]), P(d[3]), shape[0], shape[1], P(rlo), P(rhi), hlen, level, P(t2))
+                want = np.zeros(shape, np.float32)
+                lib_o.oracle_swt_synthesis_rows(P(t1), P(t2), shape[0], shape[1], P(rlo), P(rhi), hlen, level, P(want))
+                assert np.isfinite(rec[b]).all(), (wname, shape, level, "inverse")
+                assert np.abs(rec[b] - want).max() <= _tol(want), (wname, shape, level, "inverse", beta)
+
+
 @pytest.mark.parametrize("wname", ["db2", "db3", "db4", "db5", "sym8", "db13", "db20"])
 def test_emu_swt_row_kernels_as_the_1d_transform(wname):
     """the row kernels of swt_split_kernels.hpp on separate approximation / detail planes (the batched 1D SWT): the inverse

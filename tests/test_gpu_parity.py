@@ -576,6 +576,10 @@ F64_CASES = [
     ("haar", (128, 64), 6, 2, 0), ("haar", (32, 32), 5, 2, 0),  # deep plans: the tail launch over doubles
     ("haar", (16, 48), 4, 2, 0),  # ... its general-size instantiation (48 is not a power of two)
     ("db2", (32, 32), 3, 2, 1), ("db3", (24, 28), 2, 2, 1),  # the SWT tail launch over doubles: power-of-two and general sizes
+    # round 5: the undecimated levels of >= 10 taps (staged inverse with the 128-column halo of doubles, 64 x 16 tiles beyond
+    # 24 taps) and the decimated 32 x 32 tiles beyond 20 taps
+    ("sym8", (96, 128), 2, 2, 1), ("db10", (128, 160), 2, 2, 1), ("db13", (128, 128), 2, 2, 1), ("db16", (256, 128), 1, 2, 1),
+    ("db20", (192, 256), 1, 2, 1), ("db12", (4, 2048), 3, 1, 1), ("db13", (256, 320), 2, 2, 0), ("db16", (320, 256), 2, 2, 0),
 ]
 
 
@@ -599,6 +603,61 @@ def test_fp64_build_matches_the_fp64_oracle(wname, shape, levels, ndim, swt):
     thr = [ref[0]] + [np.sign(b) * np.maximum(np.abs(b) - 3.0, 0.0) for b in ref[1:]]
     rec = oracle.inverse(thr, x.shape, wname, w.levels, ndim=ndim, do_swt=swt, double="full")
     assert np.abs(w.image.reshape(rec.shape) - rec).max() <= 1e-11 * 255
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("wname,shape,levels,ndim,batch", [
+    ("haar", (64, 64), 3, 2, 1), ("db2", (48, 80), 3, 2, 1), ("db4", (131, 77), 3, 2, 1), ("sym8", (96, 130), 4, 2, 2), ("db10", (61, 1000), 2, 2, 1),
+    ("db13", (200, 202), 3, 2, 1), ("db20", (257, 255), 2, 2, 3), ("db20", (3, 4100), 4, 1, 1), ("db7", (5, 1001), 3, 1, 1), ("sym8", (1, 5000), 5, 1, 1)])
+def test_fp64_stream_levels_forced_for_every_filter(wname, shape, levels, ndim, batch):
+    """The a-trous levels of the fp64 library through the stream kernels (swt_stream_kernels.hpp: a row launch + a column launch of
+    ONE kernel for every filter length) forced on from 2 taps: odd sizes (one column per work item), rows the dilation does not
+    divide, batches, 1D rows, and the pending soft threshold inside the column launch of the inverse -- against the fp64 oracle."""
+    from pypwt_amd import BatchedWavelets64, Wavelets64
+    from pypwt_amd import _lib
+    lib = _lib.load("f64")
+    prev = lib.pdwt_set_tuning(b"swt_split_fwd", 102), lib.pdwt_set_tuning(b"swt_split_inv", 102)
+    try:
+        x = oracle.hash_input((batch,) + shape, 4242, scale=255.0).astype(np.float64)
+        x += 1e-9 * (np.arange(x.size) % 997).reshape(x.shape)
+        if ndim == 2:
+            plan = BatchedWavelets64(batch, shape[0], shape[1], wname, levels, do_swt=1, img=x)
+            plan.enable_kernel_timing(True)
+            plan.forward()
+            names = [n for n, _ in plan.kernel_times()]
+            long_filter = oracle.filters(wname)[0] >= 6  # (2- and 4-tap plans keep their fused groups of levels)
+            assert not long_filter or (names and all(n == "swt2_fwd_split" for n in names)), names
+            refs = [oracle.forward(x[b], wname, plan.levels, do_swt=1, double="full") for b in range(batch)]
+            for b in range(batch):
+                for num, r in enumerate(refs[b]):
+                    g = plan.coeff_at(num, b)
+                    assert g.dtype == np.float64 and np.abs(g - r).max() <= 1e-12 * max(1.0, float(np.abs(r).max())), (wname, b, num)
+            plan.reset_kernel_times()
+            plan.soft_threshold(2.5)
+            plan.inverse()
+            names = [n for n, _ in plan.kernel_times()]
+            assert not long_filter or (names and all(n.startswith("swt2_inv_split") for n in names)), names
+            for b in range(batch):
+                thr = [refs[b][0]] + [np.sign(c) * np.maximum(np.abs(c) - 2.5, 0.0) for c in refs[b][1:]]
+                rec = oracle.inverse(thr, shape, wname, plan.levels, do_swt=1, double="full")
+                assert np.abs(plan.image_at(b) - rec).max() <= 1e-11 * 255, (wname, b)
+            plan.cleanup()
+        else:
+            xin = x[0][0] if shape[0] == 1 else x[0]
+            w = Wavelets64(xin, wname, levels, do_swt=1, ndim=1)
+            w.forward()
+            ref = oracle.forward(x[0], wname, w.levels, ndim=1, do_swt=1, double="full")
+            got = [w.coeffs[0]] + list(w.coeffs[1:])
+            for k, (g, r) in enumerate(zip(got, ref)):
+                assert np.abs(g.reshape(r.shape) - r).max() <= 1e-12 * max(1.0, float(np.abs(r).max())), (wname, k)
+            w.soft_threshold(2.5)
+            w.inverse()
+            thr = [ref[0]] + [np.sign(c) * np.maximum(np.abs(c) - 2.5, 0.0) for c in ref[1:]]
+            rec = oracle.inverse(thr, x[0].shape, wname, w.levels, ndim=1, do_swt=1, double="full")
+            assert np.abs(w.image.reshape(rec.shape) - rec).max() <= 1e-11 * 255
+    finally:
+        lib.pdwt_set_tuning(b"swt_split_fwd", prev[0])
+        lib.pdwt_set_tuning(b"swt_split_inv", prev[1])
 
 
 @pytest.mark.gpu
