@@ -6,38 +6,19 @@
 #include "launch.hpp"
 #include "launch_util.hpp"
 #include "swt_kernels_args.hpp"
-#ifdef PDWT_DOUBLE
 #include "swt_stream_kernels.hpp"
-#else
+#ifndef PDWT_DOUBLE
 #include "swt_split_kernels.hpp"
 #endif
 
 namespace pdwt {
 
-#ifdef PDWT_DOUBLE
-// ---- fp64 library: the two launches are the any-length stream kernels of swt_stream_kernels.hpp (round 5) ----------------------
-static int env_int64(const char* name, int dflt) {
+static int env_int(const char* name, int dflt) {
     const char* e = lab_env(name);
     return e ? atoi(e) : dflt;
 }
-// shortest filter on this path (tuning keys "swt_split_fwd" / "swt_split_inv"; 0 = never, 100 + n = n taps at every size)
-static std::atomic<int>& split_min(bool inverse) {
-    static std::atomic<int> fwd{env_int64("PDWT_SWT_SPLIT_FWD", 12)}, inv{env_int64("PDWT_SWT_SPLIT_INV", 6)};
-    return inverse ? inv : fwd;
-}
-int set_swt_split_min(int inverse, int taps) { return split_min(inverse != 0).exchange(taps < 0 ? 0 : taps); }
-int get_swt_split_min(int inverse) { return split_min(inverse != 0).load(std::memory_order_relaxed); }
 
-bool swt2_split_supported(int hlen, int Nr, int Nc, int f, bool inverse, long long samples) {
-    const Tuning* at = active_tuning();
-    int min_taps = at ? (inverse ? at->swt_split_inv : at->swt_split_fwd) : split_min(inverse).load(std::memory_order_relaxed);
-    if (min_taps <= 0) return false;
-    if (min_taps >= 100) min_taps -= 100;
-    (void)samples;
-    if (hlen < 2 || hlen > kMaxTaps || hlen < min_taps) return false;
-    return f >= 1 && f < Nr && f < Nc;
-}
-
+// ---- the any-length stream kernels (swt_stream_kernels.hpp, round 5): both libraries ----------------------------------------------
 static void stream_taps(SwtStreamArgs& k, const FilterBank& fb, int hlen) {
     for (int j = 0; j < kStreamTaps; ++j) k.tl[j] = k.th[j] = 0;
     for (int j = 0; j < hlen; ++j) {
@@ -69,14 +50,15 @@ static hipError_t run_stream(const SwtStreamArgs& k, bool pairs, hipStream_t s) 
     if (pairs && (ALONG_Y || !(k.f & 1))) return go_stream<SYN, ALONG_Y, 2, R2, NT>(k, s);
     return go_stream<SYN, ALONG_Y, 1, R1, NT>(k, s);
 }
-static bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+// a pair of adjacent columns per work item: planes aligned to two elements
+static bool al_pair(const void* p) { return (reinterpret_cast<uintptr_t>(p) & (2 * sizeof(real_t) - 1)) == 0; }
 
-// scratch: 2 * Nr * Nc * batch elements
-hipError_t launch_swt2_split(const Swt2DArgs& a, real_t* tmp, bool inverse, int batch, hipStream_t s) {
-    if (!swt2_split_supported(a.hlen, a.Nr, a.Nc, a.f, inverse, (long long)batch * a.Nr * a.Nc) || !tmp) return hipErrorNotSupported;
+
+// one 2D level: a row launch + a column launch through scratch (2 * Nr * Nc * batch elements)
+static hipError_t stream_level2d(const Swt2DArgs& a, real_t* tmp, bool inverse, int batch, hipStream_t s) {
     const long long plane = (long long)a.Nr * a.Nc;
-    const bool pairs = !(a.Nc & 1) && !(a.bstride & 1) && al16(tmp) && al16(a.A) && al16(a.H) && al16(a.V) && al16(a.D) &&
-                       al16(inverse ? (const void*)a.out : (const void*)a.in);
+    const bool pairs = !(a.Nc & 1) && !(a.bstride & 1) && al_pair(tmp) && al_pair(a.A) && al_pair(a.H) && al_pair(a.V) && al_pair(a.D) &&
+                       al_pair(inverse ? (const void*)a.out : (const void*)a.in);
     SwtStreamArgs k{};
     k.Nr = a.Nr; k.Nc = a.Nc; k.f = a.f; k.batch = batch; k.hlen = a.hlen;
     k.scale = (real_t)0.5;
@@ -108,14 +90,11 @@ hipError_t launch_swt2_split(const Swt2DArgs& a, real_t* tmp, bool inverse, int 
     return run_stream<true, false>(r, pairs, s);
 }
 
-// the (batched) 1D transform: rows of Nc samples, or columns (along_y) of a plane
-hipError_t try_launch_swt1_split(const SwtPassArgs& a, bool inverse, hipStream_t s) {
-    const Tuning* at = active_tuning();  // the same thresholds as the 2D level
-    int min_taps = at ? (inverse ? at->swt_split_inv : at->swt_split_fwd) : split_min(inverse).load(std::memory_order_relaxed);
-    if (min_taps >= 100) min_taps -= 100;
-    if (min_taps <= 0 || a.hlen < min_taps || a.hlen < 2 || a.hlen > kMaxTaps) return hipErrorNotSupported;
-    if (a.f < 1 || a.f >= (a.along_y ? a.Nr : a.Nc)) return hipErrorNotSupported;
-    const bool pairs = !(a.Nc & 1) && al16(a.in0) && al16(a.out0) && (inverse ? al16(a.in1) : al16(a.out1));
+
+// one pass of the (batched) 1D transform: rows of Nc samples, or columns (along_y) of a plane
+static hipError_t stream_pass1d(const SwtPassArgs& a, bool inverse, hipStream_t s) {
+    if (a.f < 1 || a.f >= (a.along_y ? a.Nr : a.Nc) || a.hlen < 2 || a.hlen > kMaxTaps) return hipErrorNotSupported;
+    const bool pairs = !(a.Nc & 1) && al_pair(a.in0) && al_pair(a.out0) && (inverse ? al_pair(a.in1) : al_pair(a.out1));
     SwtStreamArgs k{};
     k.Nr = a.Nr; k.Nc = a.Nc; k.f = a.f; k.batch = 1; k.hlen = a.hlen; k.problems = 1;
     k.scale = (real_t)0.5;
@@ -123,6 +102,41 @@ hipError_t try_launch_swt1_split(const SwtPassArgs& a, bool inverse, hipStream_t
     k.in[0][0] = a.in0; k.in[0][1] = a.in1; k.out[0][0] = a.out0; k.out[0][1] = a.out1;
     if (a.along_y) return inverse ? run_stream<true, true>(k, pairs, s) : run_stream<false, true>(k, pairs, s);
     return inverse ? run_stream<true, false>(k, pairs, s) : run_stream<false, false>(k, pairs, s);
+}
+
+#ifdef PDWT_DOUBLE
+// ---- fp64 library: the two launches are ALWAYS the stream kernels ------------------------------------------------------------------
+// shortest filter on this path (tuning keys "swt_split_fwd" / "swt_split_inv"; 0 = never, 100 + n = n taps at every size)
+static std::atomic<int>& split_min(bool inverse) {
+    static std::atomic<int> fwd{env_int("PDWT_SWT_SPLIT_FWD", 12)}, inv{env_int("PDWT_SWT_SPLIT_INV", 6)};
+    return inverse ? inv : fwd;
+}
+int set_swt_split_min(int inverse, int taps) { return split_min(inverse != 0).exchange(taps < 0 ? 0 : taps); }
+int get_swt_split_min(int inverse) { return split_min(inverse != 0).load(std::memory_order_relaxed); }
+
+bool swt2_split_supported(int hlen, int Nr, int Nc, int f, bool inverse, long long samples) {
+    const Tuning* at = active_tuning();
+    int min_taps = at ? (inverse ? at->swt_split_inv : at->swt_split_fwd) : split_min(inverse).load(std::memory_order_relaxed);
+    if (min_taps <= 0) return false;
+    if (min_taps >= 100) min_taps -= 100;
+    (void)samples;
+    if (hlen < 2 || hlen > kMaxTaps || hlen < min_taps) return false;
+    return f >= 1 && f < Nr && f < Nc;
+}
+
+// scratch: 2 * Nr * Nc * batch elements
+hipError_t launch_swt2_split(const Swt2DArgs& a, real_t* tmp, bool inverse, int batch, hipStream_t s) {
+    if (!swt2_split_supported(a.hlen, a.Nr, a.Nc, a.f, inverse, (long long)batch * a.Nr * a.Nc) || !tmp) return hipErrorNotSupported;
+    note_family("stream");
+    return stream_level2d(a, tmp, inverse, batch, s);
+}
+
+hipError_t try_launch_swt1_split(const SwtPassArgs& a, bool inverse, hipStream_t s) {
+    const Tuning* at = active_tuning();  // the same thresholds as the 2D level
+    int min_taps = at ? (inverse ? at->swt_split_inv : at->swt_split_fwd) : split_min(inverse).load(std::memory_order_relaxed);
+    if (min_taps >= 100) min_taps -= 100;
+    if (min_taps <= 0 || a.hlen < min_taps) return hipErrorNotSupported;
+    return stream_pass1d(a, inverse, s);
 }
 #else
 
@@ -134,11 +148,6 @@ static inline v2f mk2h(real_t a, real_t b) {
     r.x = a;
     r.y = b;
     return r;
-}
-
-static int env_int(const char* name, int dflt) {
-    const char* e = lab_env(name);
-    return e ? atoi(e) : dflt;
 }
 
 // Where the two launches beat the LDS-tiled level kernel (2048^2 levels, tools/swtsweep.py, profiles/r03_swt_split_sweep.txt):
@@ -153,10 +162,34 @@ static std::atomic<int>& split_min(bool inverse) {
 int set_swt_split_min(int inverse, int taps) { return split_min(inverse != 0).exchange(taps < 0 ? 0 : taps); }
 int get_swt_split_min(int inverse) { return split_min(inverse != 0).load(std::memory_order_relaxed); }
 
+// Where the any-length stream kernels (swt_stream_kernels.hpp: one or two columns per work item, plain FMAs) serve the fp32 library
+// (round 5; tools/swt_stream32_ab.py, profiles/r05g_swt_stream32_*.txt, three levels forward | inverse, same box).
+// (a) Rows that are not whole quads: the packed kernels below need Nc % 4 == 0 and the tiles' 16-B accesses at 4-B alignment pay
+//     per tap -- 2047^2 db10 L2 282 | 375 us on the tiles, 138 | 178 here; 1022^2 db10 L3 156 | 162 -> 64 | 60; 2046^2 db20 L2
+//     338 | 471 -> 143 | 232.  Shorter filters: the inverse gains from 10 taps (db5 0.94, db6 0.88, sym8 0.85 of the tiles' time),
+//     the forward is level at 16 taps and behind below (db7 1.08-1.11, db5 1.54).
+// (b) Small images with long filters: four columns per lane leave a 512^2 level 256 wavefronts of 43 dependent loads each; two
+//     columns per lane are four times the wavefronts.  From 18 taps up to 2^20 samples: 512^2 L3 db9 51 | 45 -> 33 | 38, db10
+//     54 | 48 -> 34 | 37, db20 73 | 99 -> 41 | 51; 1024^2 db10 67 | 76 -> 62 | 60, db20 90 | 111 -> 79 | 88; 16 taps: level
+//     (0.83-1.08 | 1.01-1.10).  From 1.9 M samples on the packed kernels are ahead again (1200 x 1600: 1.06-1.11 | 1.17-1.27;
+//     2048^2: 1.4-1.5 | 1.5-1.7).
+// Shortest filter per rule, 0 = never (A/B measurements in the lab library: PDWT_SWT_STREAM_RAGGED_FWD / _RAGGED / _SMALL / _SMALL_LOG2).
+static bool stream_route32(int hlen, int Nr, int Nc, int f, bool inverse, long long samples, int min_taps) {
+    static const int ragged_fwd = env_int("PDWT_SWT_STREAM_RAGGED_FWD", 16), ragged_inv = env_int("PDWT_SWT_STREAM_RAGGED", 10),
+                     small = env_int("PDWT_SWT_STREAM_SMALL", 18), small_log2 = env_int("PDWT_SWT_STREAM_SMALL_LOG2", 20);
+    if (min_taps <= 0 || min_taps >= 100) return false;  // the path is off, or the packed kernels are forced (tests)
+    if (hlen < 2 || hlen > kMaxTaps || f < 1 || f >= Nr || f >= Nc) return false;
+    const int ragged = inverse ? ragged_inv : ragged_fwd;
+    if ((Nc & 3) && ragged > 0 && hlen >= ragged) return true;
+    if (samples <= (1LL << small_log2) && small > 0 && hlen >= small) return true;
+    return false;
+}
+
 bool swt2_split_supported(int hlen, int Nr, int Nc, int f, bool inverse, long long samples) {
     const Tuning* at = active_tuning();  // the calling plan's snapshot, else the process-wide value
     int min_taps = at ? (inverse ? at->swt_split_inv : at->swt_split_fwd) : split_min(inverse).load(std::memory_order_relaxed);
     if (min_taps <= 0) return false;
+    if (stream_route32(hlen, Nr, Nc, f, inverse, samples, min_taps)) return true;
     // (narrow images keep this path too: measured, the tiled inverse is slower still there -- 4096 images of 64^2, db4 L2
     // forward+inverse 1006 us on this path against 1168 tiled, 8192 of 32^2 1047 against 2182)
     if (Nr % f) {
@@ -270,6 +303,9 @@ hipError_t try_launch_swt1_split(const SwtPassArgs& a, bool inverse, hipStream_t
     // stay ahead there (65536 rows of 64, three levels forward+inverse: db3 221 -> 125 us, db4 238 -> 156, db5 228 -> 148); from
     // 256 samples on the row kernels win (profiles/r04zl_swt1_short_rows.txt)
     if (a.Nc < 128) return hipErrorNotSupported;
+    // rows that are not whole quads: the stream kernels (one or two samples per work item), from 10 taps on
+    if (!a.along_y && (a.Nc & 3) && min_taps > 0 && a.hlen >= 10 && stream_route32(a.hlen, a.Nr, a.Nc, a.f, inverse, (long long)a.Nr * a.Nc, 10))
+        return stream_pass1d(a, inverse, s);
     if (a.along_y || min_taps <= 0 || (a.hlen & 1) || a.hlen < 4 || a.hlen < min_taps || a.hlen > kMaxTaps) return hipErrorNotSupported;
     if ((a.Nc & 3) || a.Nc < 16 || a.f < 1 || a.f >= a.Nc || (a.f != 1 && a.f != 2 && (a.f & 3))) return hipErrorNotSupported;
     auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
@@ -287,9 +323,18 @@ hipError_t try_launch_swt1_split(const SwtPassArgs& a, bool inverse, hipStream_t
 // scratch: 2 * Nr * Nc * batch elements, 16-B aligned
 hipError_t launch_swt2_split(const Swt2DArgs& a, real_t* tmp, bool inverse, int batch, hipStream_t s) {
     if (!swt2_split_supported(a.hlen, a.Nr, a.Nc, a.f, inverse, (long long)batch * a.Nr * a.Nc) || !tmp) return hipErrorNotSupported;
+    {
+        const Tuning* at = active_tuning();
+        const int min_taps = at ? (inverse ? at->swt_split_inv : at->swt_split_fwd) : split_min(inverse).load(std::memory_order_relaxed);
+        if (stream_route32(a.hlen, a.Nr, a.Nc, a.f, inverse, (long long)batch * a.Nr * a.Nc, min_taps)) {
+            note_family("stream");
+            return stream_level2d(a, tmp, inverse, batch, s);
+        }
+    }
     auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     if (!al16(tmp) || !al16(a.A) || !al16(a.H) || !al16(a.V) || !al16(a.D) || (a.bstride & 3)) return hipErrorNotSupported;
     if (!al16(inverse ? (const void*)a.out : (const void*)a.in)) return hipErrorNotSupported;
+    note_family("packed");
     switch (a.hlen) {
 #define X(h) \
     case h:  \

@@ -978,17 +978,19 @@ def test_swt_batches_whose_rows_the_dilation_does_not_divide(wname, shape, level
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("wname", ["haar", "db2", "db4", "sym8", "db10"])
+@pytest.mark.parametrize("wname", ["haar", "db2", "db4", "db5", "sym8", "db10", "db20"])
 def test_swt_any_width_and_any_row_count(wname):
     """Round 5 (missing 4): the tiled SWT kernels take rows of ANY length (16-B accesses at 4-B alignment, the
     partial quad at the row end element by element) and ANY row count (where the dilation does not divide it the tiles wrap rows,
     not phase indices) -- the reference's kernels take any size (pdwt/src/separable.cu:409-493, 553-626; odd sizes are an option of
     its tests, test/test_wavelets.py:43).  Until then such planes ran on one-sample-per-thread kernels at twice the time.  Every
-    band against the oracle, the soft threshold folded into the inverse, the reconstruction against the oracle's."""
+    band against the oracle, the soft threshold folded into the inverse, the reconstruction against the oracle's.
+    (From 16 taps forward / 10 taps inverse these rows take the stream kernels of swt_stream_kernels.hpp: one or two columns per work
+    item -- 1002 and 1022 columns in pairs, the odd widths one by one.)"""
     from pypwt_amd import Wavelets
-    for si, (shape, L) in enumerate([((2047, 2047), 2), ((1002, 1002), 2), ((513, 515), 3), ((301, 523), 2), ((64, 1001), 3), ((1023, 256), 3)]):
-        if shape[0] > 1500 and wname == "db10":
-            continue  # (the 40 MB oracle pass of the longest filter: covered at the smaller sizes)
+    for si, (shape, L) in enumerate([((2047, 2047), 2), ((300, 1022), 3), ((1002, 1002), 2), ((513, 515), 3), ((301, 523), 2), ((64, 1001), 3), ((1023, 256), 3)]):
+        if shape[0] > 1500 and wname in ("db10", "db20"):
+            continue  # (the 40 MB oracle pass of the longest filters: covered at the smaller sizes)
         x = oracle.hash_input(shape, 5150 + si)
         w = Wavelets(x, wname, L, do_swt=1)
         w.forward()
