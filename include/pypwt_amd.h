@@ -211,6 +211,12 @@ int pdwt_sync_producer(int device_id, void* producer_stream, int whole_device);
  * image tiled over several GPUs that way).  No reference counterpart (the reference owns all its buffers, wt.cu:527-539).
  * Synchronises the plan's stream. */
 int pdwt_bind_image(pdwt_handle h, void* device_ptr);
+/* Copy `count` elements (of pdwt_real) between two buffers ON THE PLAN'S STREAM, ordered with its launches.  kind 0: device ->
+ * device, enqueued -- the call returns at once; 1: host -> device and 2: device -> host return when the copy has finished.
+ * For ROW RANGES of a plan's buffers (pdwt_image_ptr / pdwt_coeff_ptr + an offset): the slab of a rank, the halo rows of a
+ * tiled image whose ring closes on the rank itself, the gathered approximation (pypwt_amd/tiled.py needs nothing else from a
+ * device runtime -- no torch, no cupy).  The reference copies whole buffers only (cudaMemcpy in pdwt/src/wt.cu:425-466,470-520). */
+int pdwt_copy(pdwt_handle h, void* dst, const void* src, long long count, int kind);
 
 /* ---- NEW: neighbour exchange for ONE image tiled over several GPUs (the reference has no multi-GPU code,
  * pdwt/TODO.txt:15).  A communicator wraps an RCCL communicator (librccl is dlopen'ed on first use: single-GPU callers never

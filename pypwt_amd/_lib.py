@@ -70,6 +70,7 @@ def signatures(real=C.c_float):
         "pdwt_get_coeff_region": (C.c_longlong, [handle_t, C.c_void_p]),
         "pdwt_image_ptr": (C.c_ssize_t, [handle_t]),
         "pdwt_bind_image": (C.c_int, [handle_t, C.c_void_p]),
+        "pdwt_copy": (C.c_int, [handle_t, C.c_void_p, C.c_void_p, C.c_longlong, C.c_int]),
         "pdwt_coeff_ptr": (C.c_ssize_t, [handle_t, C.c_int]),
         "pdwt_set_filters_forward": (C.c_int, [handle_t, C.c_char_p, C.c_uint, realp, realp, realp, realp]),
         "pdwt_set_filters_inverse": (C.c_int, [handle_t, realp, realp, realp, realp]),

@@ -1654,6 +1654,17 @@ int pdwt_bind_image(pdwt_handle h, void* device_ptr) {
     return PDWT_OK;
 }
 
+int pdwt_copy(pdwt_handle h, void* dst, const void* src, long long count, int kind) {
+    CHECK_HANDLE(h);
+    if (!dst || !src || count < 0 || kind < 0 || kind > 2) return fail(PDWT_ERR_ARG, "pdwt_copy: bad arguments");
+    if (count == 0) return PDWT_OK;
+    DeviceGuard guard(h->device);
+    const hipMemcpyKind k = kind == 0 ? hipMemcpyDeviceToDevice : (kind == 1 ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost);
+    HIP_TRY(hipMemcpyAsync(dst, src, (size_t)count * sizeof(real_t), k, h->stream));
+    if (kind != 0) HIP_TRY(hipStreamSynchronize(h->stream));  // host memory: the caller may touch it when the call returns
+    return PDWT_OK;
+}
+
 intptr_t pdwt_coeff_ptr(pdwt_handle h, int num) {
     if (!h || num < 0 || num >= (int)h->bands.size()) return 0;
     {

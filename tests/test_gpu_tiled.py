@@ -1,8 +1,9 @@
 """A single image split in row slabs over several ranks (pypwt_amd/tiled.py): the slabs of every
 sub-band and of the reconstruction must equal those of the CPU oracle's transform of the whole image;
 levels whose slabs would be thinner than the halo are gathered on rank 0 and compared whole.
-The GPU box has ONE GPU: the ranks share it and exchange their halos through gloo (staged on the host);
-with the nccl backend (RCCL) the same code path uses grouped device-to-device send/recv."""
+The GPU box has ONE GPU: the ranks share it and exchange their halos through pypwt_amd.comm.HostRing (TCP, staged on the
+host: RCCL refuses two ranks on one GPU); the library's RCCL transport runs with one rank as its own neighbour.  No torch:
+every worker asserts that it never entered sys.modules (round 5)."""
 import os
 import socket
 import subprocess
@@ -25,16 +26,15 @@ def _free_port():
     return p
 
 
-def _run_ranks(world, wname, levels, shape, swt=0, backend="gloo"):
-    """Each rank is a child process (torch must be imported before libpypwt_amd.so in a process, and the
-    pytest process has long loaded the library): tests/tiled_worker.py compares its slabs itself."""
-    port = _free_port()
+def _run_ranks(world, wname, levels, shape, swt=0, backend="ring", fuse=0):
+    """Each rank is a child process: tests/tiled_worker.py compares its slabs with the oracle itself."""
+    port, ring_port = _free_port(), _free_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port))
+                   MASTER_PORT=str(port), PDWT_COMM_NONCE="tiled%d" % port, PDWT_RING_PORT=str(ring_port))
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "tiled_worker.py"), wname,
-                                       str(levels), str(shape[0]), str(shape[1]), backend, str(swt)],
+                                       str(levels), str(shape[0]), str(shape[1]), backend, str(swt), str(fuse)],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = []
     for p in procs:
@@ -84,22 +84,27 @@ def test_swt_slabs_with_one_halo_exchange(world, wname, levels, shape):
 
 @pytest.mark.parametrize("wname,levels,shape,swt", [("db4", 3, (192, 160), 0), ("db2", 4, (40, 64), 0), ("sym8", 2, (128, 256), 0),
                                                     ("haar", 3, (64, 96), 1), ("db2", 3, (128, 100), 1)])
-def test_rccl_transport_with_one_rank_as_its_own_neighbour(wname, levels, shape, swt):
-    """backend nccl (= RCCL), world size 1, loopback: the halos go through grouped device-to-device send / recv, the
-    gathered levels through all_gather and broadcast -- the code the ranks of a multi-GPU node run, on the one GPU of
-    this box (tiled.py, `loopback`)"""
-    outs = _run_ranks(1, wname, levels, shape, swt=swt, backend="nccl")
-    assert "rccl-loopback" in outs[0]
-
-
-@pytest.mark.parametrize("wname,levels,shape,swt", [("db4", 3, (192, 160), 0), ("db2", 4, (40, 64), 0), ("sym8", 2, (128, 256), 0),
-                                                    ("haar", 3, (64, 96), 1), ("db2", 3, (128, 100), 1)])
 def test_library_rccl_transport_with_one_rank_as_its_own_neighbour(wname, levels, shape, swt):
     """The library's OWN transport (pdwt_comm_*, pypwt_amd/comm.py: RCCL dlopen'ed by the C library, grouped send / recv on
     the plans' stream, all_gather + broadcast for the gathered levels), one rank as its own neighbour: every slab of every
-    band and the reconstruction against the CPU oracle, with no torch process group."""
+    band and the reconstruction against the CPU oracle."""
     outs = _run_ranks(1, wname, levels, shape, swt=swt, backend="comm")
     assert "comm-loopback" in outs[0]
+
+
+@pytest.mark.parametrize("world,wname,levels,shape,backend,want", [
+    (1, "db4", 3, (1024, 160), "none", "1+3"), (2, "db4", 4, (2048, 128), "ring", "1+1,2+1,3+2"), (1, "sym8", 3, (2048, 256), "comm", "1+3"),
+    (4, "db2", 3, (1024, 64), "ring", "1+1,2+2"), (2, "haar", 3, (64, 64), "ring", "1+3"), (1, "db8", 2, (1024, 96), "comm", "1+2")])
+def test_last_slab_levels_run_as_one_group(world, wname, levels, shape, backend, want):
+    """Round 5: the last K slab levels are ONE K-level plan behind ONE exchange per direction (hp (2^K - 1) image rows forward; the
+    inverse: q_j rows of the j-th level's bands, q_1 = hq, q_(j+1) = hq + ceil(q_j / 2)) -- the worker reports its level groups;
+    the same cases with at most two levels per group and with every level its own group must give the same slabs."""
+    outs = _run_ranks(world, wname, levels, shape, backend=backend)
+    assert outs[0].split("groups=")[1].split()[0] == want, outs[0][-300:]
+    outs = _run_ranks(world, wname, levels, shape, backend=backend, fuse=2)
+    assert outs[0].split("groups=")[1].split()[0].endswith("+2"), outs[0][-300:]
+    outs = _run_ranks(world, wname, levels, shape, backend=backend, fuse=1)
+    assert outs[0].split("groups=")[1].split()[0].endswith("+1"), outs[0][-300:]
 
 
 def test_communicator_without_torch():
@@ -139,16 +144,17 @@ print("COMM-OK")
     assert "COMM-OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
 
 
-def test_import_order_is_checked():
-    """In a process that already loaded libpypwt_amd.so without torch, TiledWavelets refuses loudly instead
-    of running on a HIP runtime torch cannot initialise."""
+def test_tiled_path_does_not_import_torch():
+    """pypwt_amd.tiled in a process that never imports torch (round 5: DeviceRows views, pdwt_copy, Communicator / HostRing)."""
     code = ("import numpy as np, sys; sys.path.insert(0, %r)\n"
-            "from pypwt_amd import _lib; _lib.load()\n"
             "from pypwt_amd.tiled import TiledWavelets\n"
-            "try:\n    TiledWavelets(np.zeros((64, 64), dtype=np.float32), 'db2', 2)\n"
-            "except RuntimeError as e:\n    print('REFUSED' if 'import torch before' in str(e) else e)\n" % ROOT)
+            "x = (np.arange(128 * 64, dtype=np.float32).reshape(128, 64) %% 97)\n"
+            "t = TiledWavelets(x, 'db2', 3)\n"
+            "t.forward(); t.inverse()\n"
+            "assert np.abs(t.image - x).max() < 1e-3 and 'torch' not in sys.modules\n"
+            "print('NO-TORCH-OK', t.groups)\n" % ROOT)
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
-    assert "REFUSED" in out.stdout, out.stdout + out.stderr
+    assert "NO-TORCH-OK" in out.stdout, out.stdout + out.stderr[-3000:]
 
 
 @pytest.mark.parametrize("config,extra", [("cfg1", []), ("cfg2", ["--batch", "2", "--scaling", "strong"])])

@@ -2,7 +2,9 @@
 RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set).  Every rank computes the transform of the WHOLE image
 with the CPU ORACLE and compares its own row slab of every sub-band (the whole band for the levels that
 were gathered on rank 0) and of the reconstruction; prints 'OK <rank> tiled=<t> deep=<d>' on success.
-argv: wname levels Nr Nc [backend [do_swt]]."""
+No torch anywhere: the transport is pypwt_amd.comm.HostRing (TCP, staged on the host: the ranks of a test share ONE GPU, which RCCL
+refuses), pypwt_amd.comm.Communicator (the library's RCCL calls; one rank as its own neighbour on this box) or none (one rank: the
+ring closes on itself).  argv: wname levels Nr Nc [backend = ring | comm | none [do_swt [fuse_last]]]."""
 import os
 import sys
 
@@ -13,28 +15,26 @@ sys.path.insert(0, ROOT)
 
 
 def main():
-    import torch
-    import torch.distributed as dist
     from oracle import oracle
     from pypwt_amd.tiled import TiledWavelets
 
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     wname, levels = sys.argv[1], int(sys.argv[2])
     Nr, Nc = int(sys.argv[3]), int(sys.argv[4])
-    backend = sys.argv[5] if len(sys.argv) > 5 else "gloo"
+    backend = sys.argv[5] if len(sys.argv) > 5 else "ring"
     swt = int(sys.argv[6]) if len(sys.argv) > 6 else 0
-    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1))
-    loopback = world == 1 and backend == "nccl"  # one rank over RCCL: its own neighbour, halos through send/recv
-    comm = None
-    if backend == "comm":  # the library's own RCCL transport (pdwt_comm_*): no torch process group at all
+    fuse = (int(sys.argv[7]) or None) if len(sys.argv) > 7 else None
+    comm = ring = None
+    if backend == "comm":  # the library's own RCCL transport (pdwt_comm_*)
         from pypwt_amd.comm import Communicator
-        comm = Communicator.from_env(device=torch.cuda.current_device())
+        comm = Communicator.from_env(device=0)
         assert comm.size == world and comm.rank == rank
-    elif world > 1 or loopback:  # otherwise world 1 runs WITHOUT a process group: the ring closes on the rank itself
-        dist.init_process_group(backend, rank=rank, world_size=world)
+    elif world > 1:  # one rank without a transport: the ring closes on the rank itself
+        from pypwt_amd.comm import HostRing
+        ring = HostRing.from_env()
     x = oracle.hash_input((Nr, Nc), 555, scale=255.0)
     n = Nr // world
-    tw = TiledWavelets(x[rank * n:(rank + 1) * n], wname, levels, do_swt=swt, loopback=loopback, comm=comm)
+    tw = TiledWavelets(x[rank * n:(rank + 1) * n], wname, levels, do_swt=swt, comm=comm, ring=ring, device=0, fuse_last=fuse)
     tw.forward()
     flat = oracle.forward(x, wname, levels, do_swt=swt)  # [A, H1, V1, D1, H2, ...] from the CPU oracle
     ref = [flat[0]] + [flat[1 + 3 * l:4 + 3 * l] for l in range(levels)]
@@ -78,7 +78,7 @@ def main():
     tw.forward()
     for lvl in tw.device_coeffs[1:tw.tiled_levels + 1]:  # zero-copy views of the plans' buffers: shrink the details in place
         for b in lvl:
-            b.mul_(0.5)
+            b.set(b.get() * np.float32(0.5))
     tw.inverse()
     flat2 = [f.copy() for f in flat]
     for k in range(1, 3 * tw.tiled_levels + 1):
@@ -88,7 +88,7 @@ def main():
     # forward -> inverse -> edit in place -> inverse: refused (stale image) unless mark_coeffs_current() re-arms it
     for lvl in tw.device_coeffs[1:tw.tiled_levels + 1]:
         for b in lvl:
-            b.mul_(0.5)
+            b.set(b.get() * np.float32(0.5))
     tw.mark_coeffs_current()
     tw.inverse()
     flat3 = [f.copy() for f in flat2]
@@ -99,15 +99,17 @@ def main():
     tw.forward()
     tw.inverse()  # plans are reused: another round trip must work too
     assert np.abs(tw.image - rec3).max() <= 4e-3, "second round trip"
+    groups = tw.groups
+    tw.synchronize()
+    tw.cleanup()
     if comm is not None:
-        assert not dist.is_initialized()
-        torch.cuda.synchronize()
         comm.close()
-    elif world > 1 or loopback:
-        dist.barrier()
-        dist.destroy_process_group()
-    print("OK %d tiled=%d deep=%d%s" % (rank, tw.tiled_levels, tw.deep_levels,
-                                        " rccl-loopback" if loopback else (" comm-loopback" if comm is not None else "")))
+    elif ring is not None:
+        ring.barrier()
+        ring.close()
+    assert "torch" not in sys.modules, "the tiled path must not need torch"
+    print("OK %d tiled=%d deep=%d groups=%s%s" % (rank, tw.tiled_levels, tw.deep_levels, ",".join("%d+%d" % g for g in groups),
+                                                  " comm-loopback" if comm is not None else ""))
 
 
 if __name__ == "__main__":
