@@ -327,3 +327,39 @@ def test_unique_id_rendezvous_ignores_strangers_and_serves_every_rank_once():
     assert not t.is_alive()
     assert got[0] == got[1] == got[2] == uid
     os.environ.pop("PDWT_COMM_NONCE", None)
+
+
+def _host_ring_rank(rank, size, port, q):
+    os.environ["PDWT_COMM_NONCE"] = "ring-test"
+    from pypwt_amd.comm import HostRing
+    ring = HostRing(rank, size, "127.0.0.1", port, timeout=60.0)
+    big = bytes([rank]) * 300000  # larger than a socket buffer: the sends must not wait for the receives
+    from_prev, from_next = ring.sendrecv(b"P%d" % rank + big, b"N%d" % rank + big)
+    parts = ring.all_gather(b"G%d" % rank)
+    root = ring.broadcast(b"ROOT" if rank == 1 else None, 1)
+    ring.barrier()
+    ring.close()
+    q.put((rank, from_prev[:2], from_next[:2], len(from_prev), parts, root))
+
+
+@pytest.mark.parametrize("size", [2, 3])
+def test_host_ring_of_several_processes(size):
+    """pypwt_amd.comm.HostRing (the TCP ring TiledWavelets uses where ranks share a GPU: the tests of the tiled path): neighbour
+    exchange, all-gather and broadcast between `size` processes on this machine -- no GPU involved."""
+    import multiprocessing as mp
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_host_ring_rank, args=(r, size, port, q)) for r in range(size)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(30)
+    for r, fp, fn, n, parts, root in res:
+        assert fp == b"N%d" % ((r - 1) % size) and fn == b"P%d" % ((r + 1) % size) and n == 300002
+        assert parts == [b"G%d" % k for k in range(size)] and root == b"ROOT"
