@@ -24,6 +24,8 @@ timeout 900 python3 tools/cliffs.py dwt2 swt2 dwt1 swt1 > "$OUT/cliffs.txt" 2> /
 timeout 300 python3 tools/opsbench.py > "$OUT/opsbench.txt" 2> /dev/null || echo "opsbench exit $?"
 PDWT_BENCH_SHARE_GPU=1 timeout 400 python3 bench.py --gpus 2 --single-process --config cfg2 --batch 8 --no-cpu-baseline > "$OUT/bench_single_process_two_shards_one_gpu.json" 2> "$OUT/bench_single_process.err" || echo "single-process exit $?"
 timeout 600 python3 tools/tiledbench.py > "$OUT/tiledbench.txt" 2> "$OUT/tiledbench.err" || echo "tiledbench exit $?"
+timeout 900 python3 tools/f64scan.py 2> /dev/null | grep -v Warning > "$OUT/f64scan.txt" || echo "f64scan exit $?"
+timeout 600 python3 tools/swt_stream32_ab.py 2> /dev/null | grep -v Warning > "$OUT/swt_stream32_ab.txt" || echo "stream32 exit $?"
 # round 5: the register-ring level kernels next to the LDS tiles -- alone (same harness) and inside plans (same process)
 for h in 10 12 14 16 18 20; do
     [ -x tools/bin/ringbench_${h}_4 ] && { tools/bin/ringbench_${h}_4 4096 $((h)) 1; tools/bin/ringbench_${h}_4 4096 $((2 * h)) 4; tools/bin/ringbench_${h}_4 2048 $((h / 2)) 1; } >> "$OUT/ringbench.txt" 2>&1 || true
