@@ -21,6 +21,9 @@
 #if !defined(PDWT_DOUBLE) && defined(PDWT_LAB_KERNELS)
 #include "dwt2_split_kernels.hpp"
 #endif
+#ifdef PDWT_DOUBLE
+#include "dwt2_stream_kernels.hpp"
+#endif
 
 namespace pdwt {
 
@@ -32,14 +35,118 @@ static int env_int_d(const char* name, int dflt) {
 // Shortest (even) filter whose decimated 2D levels run as a row launch + a column launch through scratch instead of one
 // LDS-tiled launch.  Tuning keys "dwt_split_fwd" / "dwt_split_inv" (environment PDWT_DWT_SPLIT_FWD / _INV): 0 = never
 // (default), 100 + n = n taps at EVERY size (tests).  The product keeps the value and does nothing with it.
+#ifdef PDWT_DOUBLE
+constexpr int kDsplitDefault = 28;  // fp64 library: the any-length stream kernels (dwt2_stream_kernels.hpp), see below
+#else
+constexpr int kDsplitDefault = 0;
+#endif
 static std::atomic<int>& dsplit_min(bool inverse) {
-    static std::atomic<int> fwd{env_int_d("PDWT_DWT_SPLIT_FWD", 0)}, inv{env_int_d("PDWT_DWT_SPLIT_INV", 0)};
+    static std::atomic<int> fwd{env_int_d("PDWT_DWT_SPLIT_FWD", kDsplitDefault)}, inv{env_int_d("PDWT_DWT_SPLIT_INV", kDsplitDefault)};
     return inverse ? inv : fwd;
 }
 int set_dwt_split_min(int inverse, int taps) { return dsplit_min(inverse != 0).exchange(taps < 0 ? 0 : taps); }
 int get_dwt_split_min(int inverse) { return dsplit_min(inverse != 0).load(std::memory_order_relaxed); }
 
-#if defined(PDWT_DOUBLE) || !defined(PDWT_LAB_KERNELS)
+#if defined(PDWT_DOUBLE)
+// ---- fp64 library (round 5): a row launch + a column launch of the any-length stream kernels.  Over doubles the LDS tiles of a
+// 22-40-tap level are 32 x 32 outputs behind 38 halo rows and columns.  Measured (tools/f64dwt_ab.py, profiles/r05i_f64_dwt_stream_ab.txt,
+// three levels, tiles | stream, us): the INVERSE gains from 28 taps on large levels -- db20 4096^2 694 | 274, 2048^2 189 | 91, 1024^2
+// 62 | 50; db16 4096^2 518 | 255, 2048^2 138 | 84, 1024^2 46 | 49; db14 4096^2 275 | 258, 2048^2 80 | 84; 26 taps and below: tiles
+// (db13 4096^2 165 | 237) -- the FORWARD does not (db20 4096^2 261 | 348: its row launch reads the image one double per lane at a
+// 64-B lane stride).  Tuning keys as in the fp32 lab library: 0 = never, n = from n taps where the rule below allows, 100 + n = n taps
+// at every size and in both directions' own key (tests).
+bool dwt2_split_supported(int hlen, int Nr, int Nc, bool inverse, long long samples) {
+    const Tuning* at = active_tuning();
+    int min_taps = at ? (inverse ? at->dwt_split_inv : at->dwt_split_fwd) : dsplit_min(inverse).load(std::memory_order_relaxed);
+    if (min_taps <= 0) return false;
+    if (min_taps >= 100) {
+        min_taps -= 100;
+    } else {
+        if (!inverse) return false;
+        const int need = samples >= (1LL << 24) ? 28 : (samples >= (1LL << 22) ? 30 : (samples >= (1LL << 20) ? 36 : 99));
+        if (min_taps < need) min_taps = need;
+    }
+    if ((hlen & 1) || hlen < 2 || hlen > kMaxTaps || hlen < min_taps) return false;
+    return !(Nr & 1) && !(Nc & 1) && Nr >= 2 && Nc >= 2;
+}
+
+static void dstream_taps(DwtStreamArgs& k, const FilterBank& fb, int hlen, bool syn) {
+    for (int j = 0; j < kStreamTaps; ++j) k.t[0][j] = k.t[1][j] = k.t[2][j] = k.t[3][j] = 0;
+    if (!syn) {
+        for (int j = 0; j < hlen; ++j) {
+            k.t[0][kStreamPadL + j] = fb.lo[hlen - 1 - j];
+            k.t[1][kStreamPadL + j] = fb.hi[hlen - 1 - j];
+        }
+        return;
+    }
+    for (int j = 0; j < hlen / 2; ++j)
+        for (int par = 0; par < 2; ++par) {
+            k.t[par][kStreamPadL + j] = fb.lo[hlen - 1 - (2 * j + 1 - par)];
+            k.t[2 + par][kStreamPadL + j] = fb.hi[hlen - 1 - (2 * j + 1 - par)];
+        }
+}
+
+template <bool SYN, bool ALONG_Y, int NC>
+static hipError_t go_dstream(const DwtStreamArgs& k, hipStream_t s) {
+    constexpr int R = 4, NT = ALONG_Y ? 512 : 256;
+    const int positions = SYN ? (ALONG_Y ? k.in_rows : k.in_cols) : (ALONG_Y ? k.out_rows : k.out_cols);
+    const long long waves = dwt_stream_waves(ALONG_Y, k.problems, k.batch, k.in_rows, k.in_cols, positions, R, NC);
+    hipLaunchKernelGGL((dwt_stream_kernel<SYN, ALONG_Y, NC, R, NT>), dim3((unsigned)cdivll(waves, NT / 64)), dim3(NT), 0, s, k);
+    return hipGetLastError();
+}
+template <bool SYN>
+static hipError_t go_dstream_y(const DwtStreamArgs& k, bool pairs, hipStream_t s) {
+    return pairs ? go_dstream<SYN, true, 2>(k, s) : go_dstream<SYN, true, 1>(k, s);
+}
+static bool al_pair_d(const void* p) { return (reinterpret_cast<uintptr_t>(p) & (2 * sizeof(real_t) - 1)) == 0; }
+
+// scratch: Nr * Nc * batch elements
+hipError_t launch_dwt2_split_fwd(const Fwd2DArgs& a, real_t* tmp, int batch, hipStream_t s) {
+    if (!tmp || !dwt2_split_supported(a.hlen, a.Nr, a.Nc, false, (long long)batch * a.Nr * a.Nc)) return hipErrorNotSupported;
+    if (a.Nr2 * 2 != a.Nr || a.Nc2 * 2 != a.Nc) return hipErrorNotSupported;
+    const long long plane = (long long)a.Nr * a.Nc2;
+    DwtStreamArgs k{};
+    k.batch = batch; k.hlen = a.hlen;
+    dstream_taps(k, a.fb, a.hlen, false);
+    DwtStreamArgs r = k;  // rows: in (Nr x Nc) -> lo, hi (Nr x Nc / 2) in scratch
+    r.problems = 1;
+    r.in_rows = a.Nr; r.in_cols = a.Nc; r.out_rows = a.Nr; r.out_cols = a.Nc2;
+    r.in[0][0] = a.in; r.in_bstride = a.in_bstride;
+    r.out[0][0] = tmp; r.out[0][1] = tmp + plane; r.out_bstride = 2 * plane;
+    hipError_t e = go_dstream<false, false, 1>(r, s);
+    if (e != hipSuccess) return e;
+    DwtStreamArgs c = k;  // columns: lo -> A, H ; hi -> V, D (Nr / 2 x Nc / 2)
+    c.problems = 2;
+    c.in_rows = a.Nr; c.in_cols = a.Nc2; c.out_rows = a.Nr2; c.out_cols = a.Nc2;
+    c.in[0][0] = tmp; c.in[1][0] = tmp + plane; c.in_bstride = 2 * plane;
+    c.out[0][0] = a.A; c.out[0][1] = a.H; c.out[1][0] = a.V; c.out[1][1] = a.D; c.out_bstride = a.out_bstride;
+    const bool pairs = !(a.Nc2 & 1) && !(a.out_bstride & 1) && al_pair_d(tmp) && al_pair_d(a.A) && al_pair_d(a.H) && al_pair_d(a.V) && al_pair_d(a.D);
+    return go_dstream_y<false>(c, pairs, s);
+}
+
+hipError_t launch_dwt2_split_inv(const Inv2DArgs& a, real_t* tmp, int batch, hipStream_t s) {
+    if (!tmp || !dwt2_split_supported(a.hlen, a.Nr, a.Nc, true, (long long)batch * a.Nr * a.Nc)) return hipErrorNotSupported;
+    if (a.Nrc * 2 != a.Nr || a.Ncc * 2 != a.Nc) return hipErrorNotSupported;
+    const long long plane = (long long)a.Nr * a.Ncc;
+    DwtStreamArgs k{};
+    k.batch = batch; k.hlen = a.hlen;
+    dstream_taps(k, a.fb, a.hlen, true);
+    DwtStreamArgs c = k;  // columns: (A, H) -> L' ; (V, D) -> H' (Nr x Nc / 2) in scratch
+    c.problems = 2;
+    c.in_rows = a.Nrc; c.in_cols = a.Ncc; c.out_rows = a.Nr; c.out_cols = a.Ncc;
+    c.in[0][0] = a.A; c.in[0][1] = a.H; c.in[1][0] = a.V; c.in[1][1] = a.D; c.in_bstride = a.in_bstride;
+    c.out[0][0] = tmp; c.out[1][0] = tmp + plane; c.out_bstride = 2 * plane;
+    const bool pairs = !(a.Ncc & 1) && !(a.in_bstride & 1) && al_pair_d(tmp) && al_pair_d(a.A) && al_pair_d(a.H) && al_pair_d(a.V) && al_pair_d(a.D);
+    hipError_t e = go_dstream_y<true>(c, pairs, s);
+    if (e != hipSuccess) return e;
+    DwtStreamArgs r = k;  // rows: (L', H') -> out (Nr x Nc)
+    r.problems = 1;
+    r.in_rows = a.Nr; r.in_cols = a.Ncc; r.out_rows = a.Nr; r.out_cols = a.Nc;
+    r.in[0][0] = tmp; r.in[0][1] = tmp + plane; r.in_bstride = 2 * plane;
+    r.out[0][0] = a.out; r.out_bstride = a.out_bstride;
+    return go_dstream<true, false, 1>(r, s);
+}
+#elif !defined(PDWT_LAB_KERNELS)
 bool dwt2_split_supported(int, int, int, bool, long long) { return false; }
 hipError_t launch_dwt2_split_fwd(const Fwd2DArgs&, real_t*, int, hipStream_t) { return hipErrorNotSupported; }
 hipError_t launch_dwt2_split_inv(const Inv2DArgs&, real_t*, int, hipStream_t) { return hipErrorNotSupported; }

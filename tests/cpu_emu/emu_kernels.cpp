@@ -26,6 +26,7 @@
 #include "../../pypwt_amd/csrc/swt_kernels.hpp"
 #include "../../pypwt_amd/csrc/swt_split_kernels.hpp"
 #include "../../pypwt_amd/csrc/swt_stream_kernels.hpp"
+#include "../../pypwt_amd/csrc/dwt2_stream_kernels.hpp"
 #include "../../pypwt_amd/csrc/dwt2_split_kernels.hpp"
 
 using namespace pdwt;
@@ -1154,4 +1155,61 @@ EMU_API int emu_dwt2_split(int inverse, float* io, int batch, int Nr, int Nc, co
 #undef X
     }
     return -1;
+}
+
+
+// ---- one DECIMATED level as two launches of the any-length stream kernels (dwt2_stream_kernels.hpp: the fp64 library's long
+// filters); planes as in emu_dwt2_split.  Even sizes, even filter lengths.
+template <int NC, int R>
+static void run_dwt_stream(bool inverse, float* io, int batch, int Nr, int Nc, const FilterBank& fb, int hlen, float* A, float* H, float* V,
+                           float* D, float* tmp) {
+    constexpr int NT = 256;
+    const int Nr2 = Nr / 2, Nc2 = Nc / 2;
+    const long long plane = (long long)Nr * Nc2, img = (long long)Nr * Nc, band = (long long)Nr2 * Nc2;
+    DwtStreamArgs k{};
+    k.batch = batch; k.hlen = hlen;
+    if (!inverse) {
+        for (int j = 0; j < hlen; ++j) { k.t[0][kStreamPadL + j] = fb.lo[hlen - 1 - j]; k.t[1][kStreamPadL + j] = fb.hi[hlen - 1 - j]; }
+    } else {
+        for (int j = 0; j < hlen / 2; ++j)
+            for (int par = 0; par < 2; ++par) {
+                k.t[par][kStreamPadL + j] = fb.lo[hlen - 1 - (2 * j + 1 - par)];
+                k.t[2 + par][kStreamPadL + j] = fb.hi[hlen - 1 - (2 * j + 1 - par)];
+            }
+    }
+    auto blocks = [](long long waves) { return (waves + NT / 64 - 1) / (NT / 64); };
+    if (!inverse) {
+        DwtStreamArgs r = k;
+        r.problems = 1; r.in_rows = Nr; r.in_cols = Nc; r.out_rows = Nr; r.out_cols = Nc2;
+        r.in[0][0] = io; r.in_bstride = img; r.out[0][0] = tmp; r.out[0][1] = tmp + plane; r.out_bstride = 2 * plane;
+        for (long long b = 0; b < blocks(dwt_stream_waves(false, 1, batch, Nr, Nc, Nc2, R, 1)); ++b) dwt_stream_tile<false, false, 1, R, NT>(r, b);
+        DwtStreamArgs c = k;
+        c.problems = 2; c.in_rows = Nr; c.in_cols = Nc2; c.out_rows = Nr2; c.out_cols = Nc2;
+        c.in[0][0] = tmp; c.in[1][0] = tmp + plane; c.in_bstride = 2 * plane;
+        c.out[0][0] = A; c.out[0][1] = H; c.out[1][0] = V; c.out[1][1] = D; c.out_bstride = band;
+        for (long long b = 0; b < blocks(dwt_stream_waves(true, 2, batch, Nr, Nc2, Nr2, R, NC)); ++b) dwt_stream_tile<false, true, NC, R, NT>(c, b);
+        return;
+    }
+    DwtStreamArgs c = k;
+    c.problems = 2; c.in_rows = Nr2; c.in_cols = Nc2; c.out_rows = Nr; c.out_cols = Nc2;
+    c.in[0][0] = A; c.in[0][1] = H; c.in[1][0] = V; c.in[1][1] = D; c.in_bstride = band;
+    c.out[0][0] = tmp; c.out[1][0] = tmp + plane; c.out_bstride = 2 * plane;
+    for (long long b = 0; b < blocks(dwt_stream_waves(true, 2, batch, Nr2, Nc2, Nr2, R, NC)); ++b) dwt_stream_tile<true, true, NC, R, NT>(c, b);
+    DwtStreamArgs r = k;
+    r.problems = 1; r.in_rows = Nr; r.in_cols = Nc2; r.out_rows = Nr; r.out_cols = Nc;
+    r.in[0][0] = tmp; r.in[0][1] = tmp + plane; r.in_bstride = 2 * plane; r.out[0][0] = io; r.out_bstride = img;
+    for (long long b = 0; b < blocks(dwt_stream_waves(false, 1, batch, Nr, Nc2, Nc2, R, 1)); ++b) dwt_stream_tile<true, false, 1, R, NT>(r, b);
+}
+
+EMU_API int emu_dwt2_stream(int inverse, float* io, int batch, int Nr, int Nc, const float* lo, const float* hi, int hlen, int R,
+                            float* A, float* H, float* V, float* D) {
+    if ((Nr & 1) || (Nc & 1) || (hlen & 1) || hlen > kMaxTaps) return -2;
+    FilterBank fb;
+    set_bank(fb, lo, hi, hlen);
+    std::vector<float> tmp((size_t)Nr * Nc * batch + 16, NAN);
+    const bool two = !((Nc / 2) & 1);
+    if (R == 4) { if (two) run_dwt_stream<2, 4>(inverse != 0, io, batch, Nr, Nc, fb, hlen, A, H, V, D, tmp.data()); else run_dwt_stream<1, 4>(inverse != 0, io, batch, Nr, Nc, fb, hlen, A, H, V, D, tmp.data()); }
+    else if (R == 2) { if (two) run_dwt_stream<2, 2>(inverse != 0, io, batch, Nr, Nc, fb, hlen, A, H, V, D, tmp.data()); else run_dwt_stream<1, 2>(inverse != 0, io, batch, Nr, Nc, fb, hlen, A, H, V, D, tmp.data()); }
+    else return -1;
+    return 0;
 }

@@ -969,6 +969,45 @@ def test_emu_dwt_split_row_and_column_launches(wname, R):
             assert np.abs(rec[b] - want).max() <= _tol(want), (wname, shape, R, "inverse")
 
 
+@pytest.mark.parametrize("R", [2, 4])
+@pytest.mark.parametrize("wname", ["haar", "db2", "db3", "db5", "sym8", "db10", "db11", "db13", "db19", "db20"])
+def test_emu_dwt_stream_kernels(wname, R):
+    """dwt2_stream_kernels.hpp (the fp64 library's decimated levels of long filters: a row launch + a column launch of ONE kernel for
+    every even filter length) vs the oracle's per-pass functions: both parities of hlen / 2 (the synthesis shift), column counts
+    whose half is odd (one column per work item), images smaller than the filter (several periodic wraps), ragged blocks, batches."""
+    hlen, dlo, dhi, rlo, rhi = oracle.filters(wname)
+    lib_o = oracle.load()
+    cases = [((32, 32), 1), ((34, 50), 2), ((6, 2064), 1), ((2, 1042), 2), ((64, 136), 1), ((50, 262), 1), ((40, 24), 1),
+             ((96, 102), 1), ((24, 16), 3), ((46, 72), 1), ((18, 1024), 1), ((4, 6), 1), ((130, 10), 1)]
+    for si, (shape, B) in enumerate(cases):
+        Nr, Nc = shape
+        half = (Nr // 2, Nc // 2)
+        x = np.stack([oracle.hash_input(shape, 5100 + 10 * si + b) for b in range(B)]).astype(np.float32)
+        outs = [np.full((B,) + half, np.nan, dtype=np.float32) for _ in range(4)]
+        xin = x.copy()
+        assert lib().emu_dwt2_stream(0, P(xin), B, Nr, Nc, P(dlo), P(dhi), hlen, R, *[P(o) for o in outs]) == 0
+        assert np.array_equal(xin, x), "the forward must not touch its input"
+        bands = [(oracle.hash_input((B,) + half, 5500 + si * 4 + k, 2.0) - 1.0).astype(np.float32) for k in range(4)]
+        rec = np.full((B,) + shape, np.nan, dtype=np.float32)
+        assert lib().emu_dwt2_stream(1, P(rec), B, Nr, Nc, P(rlo), P(rhi), hlen, R, *[P(b) for b in bands]) == 0
+        for b in range(B):
+            t1 = np.zeros((Nr, half[1]), np.float32); t2 = np.zeros((Nr, half[1]), np.float32)
+            ref = [np.zeros(half, np.float32) for _ in range(4)]
+            lib_o.oracle_analysis_rows(P(x[b]), Nr, Nc, P(dlo), P(dhi), hlen, P(t1), P(t2))
+            lib_o.oracle_analysis_cols(P(t1), Nr, half[1], P(dlo), P(dhi), hlen, P(ref[0]), P(ref[1]))
+            lib_o.oracle_analysis_cols(P(t2), Nr, half[1], P(dlo), P(dhi), hlen, P(ref[2]), P(ref[3]))
+            for k in range(4):
+                assert np.isfinite(outs[k][b]).all(), (wname, shape, k)
+                assert np.abs(outs[k][b] - ref[k]).max() <= _tol(ref[k]), (wname, shape, R, "forward", k)
+            d = [np.ascontiguousarray(bands[k][b]) for k in range(4)]
+            lib_o.oracle_synthesis_cols(P(d[0]), P(d[1]), half[0], half[1], Nr, P(rlo), P(rhi), hlen, P(t1))
+            lib_o.oracle_synthesis_cols(P(d[2]), P(d[3]), half[0], half[1], Nr, P(rlo), P(rhi), hlen, P(t2))
+            want = np.zeros(shape, np.float32)
+            lib_o.oracle_synthesis_rows(P(t1), P(t2), Nr, half[1], Nc, P(rlo), P(rhi), hlen, P(want))
+            assert np.isfinite(rec[b]).all(), (wname, shape, "inverse")
+            assert np.abs(rec[b] - want).max() <= _tol(want), (wname, shape, R, "inverse")
+
+
 # ----------------------------------------------------------------------------- register-ring kernels for long filters
 # (dwt2_ring_kernels.hpp: one wavefront per tile, the row halo through a wavefront-private LDS row, the column filter a
 # register ring of running sums).  cpl = image columns per lane.

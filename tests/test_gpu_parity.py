@@ -661,6 +661,47 @@ def test_fp64_stream_levels_forced_for_every_filter(wname, shape, levels, ndim, 
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("wname,shape,levels,batch", [("haar", (64, 64), 3, 1), ("db2", (48, 80), 3, 1), ("db3", (132, 76), 2, 2), ("sym8", (96, 136), 3, 1),
+                                                      ("db11", (64, 1000), 2, 1), ("db13", (200, 204), 3, 3), ("db20", (256, 254), 2, 1), ("db16", (1024, 512), 3, 1),
+                                                      ("db3", (600, 520), 1, 1), ("db4", (1024, 1024), 1, 1)])
+def test_fp64_decimated_stream_levels_forced_for_every_filter(wname, shape, levels, batch):
+    """The decimated 2D levels of the fp64 library through the stream kernels (dwt2_stream_kernels.hpp: a row launch + a column launch
+    of ONE kernel for every even filter length) forced on from 2 taps: both parities of hlen / 2, half-widths that are odd (one
+    column per work item), batches -- every band against the fp64 oracle, then the reconstruction of soft-thresholded coefficients."""
+    from pypwt_amd import BatchedWavelets64
+    from pypwt_amd import _lib
+    lib = _lib.load("f64")
+    prev = lib.pdwt_set_tuning(b"dwt_split_fwd", 102), lib.pdwt_set_tuning(b"dwt_split_inv", 102)
+    try:
+        x = oracle.hash_input((batch,) + shape, 4343, scale=255.0).astype(np.float64)
+        x += 1e-9 * (np.arange(x.size) % 997).reshape(x.shape)
+        plan = BatchedWavelets64(batch, shape[0], shape[1], wname, levels, img=x)
+        plan.enable_kernel_timing(True)
+        plan.forward()
+        names = [n for n, _ in plan.kernel_times()]
+        long_filter = oracle.filters(wname)[0] >= 22  # (shorter filters keep their several-levels-per-launch steps where those apply)
+        assert not long_filter or "dwt2_fwd_split" in names, names
+        refs = [oracle.forward(x[b], wname, plan.levels, double="full") for b in range(batch)]
+        for b in range(batch):
+            for num, r in enumerate(refs[b]):
+                g = plan.coeff_at(num, b)
+                assert g.dtype == np.float64 and np.abs(g - r).max() <= 1e-12 * max(1.0, float(np.abs(r).max())), (wname, b, num)
+        plan.reset_kernel_times()
+        plan.soft_threshold(2.5)
+        plan.inverse()
+        names = [n for n, _ in plan.kernel_times()]
+        assert not long_filter or "dwt2_inv_split" in names, names
+        for b in range(batch):
+            thr = [refs[b][0]] + [np.sign(c) * np.maximum(np.abs(c) - 2.5, 0.0) for c in refs[b][1:]]
+            rec = oracle.inverse(thr, shape, wname, plan.levels, double="full")
+            assert np.abs(plan.image_at(b) - rec).max() <= 1e-11 * 255, (wname, b)
+        plan.cleanup()
+    finally:
+        lib.pdwt_set_tuning(b"dwt_split_fwd", prev[0])
+        lib.pdwt_set_tuning(b"dwt_split_inv", prev[1])
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("wname,shape,levels,batch,swt", [("db2", (28, 28), 3, 1400, 0), ("haar", (12, 20), 2, 4500, 0), ("db3", (64, 64), 3, 300, 0),
                                                           ("haar", (15, 17), 2, 4200, 1), ("db2", (32, 32), 2, 1100, 1), ("db4", (72, 100), 3, 160, 0)])
 def test_fp64_batches_of_small_images(wname, shape, levels, batch, swt):
