@@ -22,7 +22,12 @@ from oracle import oracle  # noqa: E402
 from pypwt_amd import BatchedWavelets  # noqa: E402
 
 
+VERBOSE = bool(os.environ.get("SOAK_VERBOSE"))
+
+
 def check(B, shape, wname, L, swt, rng, tag, ndim=2):
+    if VERBOSE:
+        print("%s B=%d %s %s L=%d swt=%d ndim=%d t=%.0f" % (tag, B, shape, wname, L, swt, ndim, time.time()), flush=True)
     try:
         plan = BatchedWavelets(B, shape[0], shape[1], wname, L, do_swt=swt, ndim=ndim)
     except ValueError:
@@ -58,6 +63,34 @@ def check(B, shape, wname, L, swt, rng, tag, ndim=2):
     return 1
 
 
+def check64(B, shape, wname, L, swt, rng, tag):
+    """the fp64 library against the oracle's fp64 arithmetic (round 5: its stream kernels for long filters)"""
+    from pypwt_amd import BatchedWavelets64
+    if VERBOSE:
+        print("%s B=%d %s %s L=%d swt=%d t=%.0f" % (tag, B, shape, wname, L, swt, time.time()), flush=True)
+    x = np.stack([oracle.hash_input(shape, int(rng.integers(1, 1 << 30)), scale=255.0) for _ in range(B)]).astype(np.float64)
+    x += 1e-9 * (np.arange(x.size) % 991).reshape(x.shape)
+    try:
+        plan = BatchedWavelets64(B, shape[0], shape[1], wname, L, do_swt=swt, img=x)
+    except ValueError:
+        return 0
+    L = plan.levels
+    plan.forward()
+    for b in sorted({0, B - 1}):
+        ref = oracle.forward(x[b], wname, L, do_swt=swt, double="full")
+        for num, r in enumerate(ref):
+            err = float(np.abs(plan.coeff_at(num, b) - r).max())
+            if not err <= 1e-12 * max(1.0, float(np.abs(r).max())) * (1 + L):
+                raise AssertionError("%s: B=%d %s %s L=%d swt=%d image %d band %d err %g | %s" % (tag, B, shape, wname, L, swt, b, num, err, plan.schedule().replace("\n", " | ")))
+    plan.inverse()
+    for b in sorted({0, B - 1}):
+        err = float(np.abs(plan.image_at(b) - x[b]).max())
+        if not err <= 1e-10 * 255:
+            raise AssertionError("%s: B=%d %s %s L=%d swt=%d image %d reconstruction err %g" % (tag, B, shape, wname, L, swt, b, err))
+    plan.cleanup()
+    return 1
+
+
 def main():
     done, secs = run(budget=float(sys.argv[1]) if len(sys.argv) > 1 else 120.0, seed=int(sys.argv[2]) if len(sys.argv) > 2 else 1)
     print("soak OK: %.0f s, cases per kind: %s" % (secs, done))
@@ -72,7 +105,7 @@ def run(budget=None, max_cases=None, seed=1):
     t0, done = time.time(), {}
     while (budget is None or time.time() - t0 < budget) and (max_cases is None or sum(done.values()) < max_cases):
         kinds = ["tiny-batch", "tiny-batch", "small-batch", "deep", "swt-mid", "swt-hd", "mid-batch", "swt-batch", "swt-tiny",
-                 "rows-1d", "rows-1d", "rows-swt1", "odd-batch", "odd-batch", "few-mid", "ring-batch"]
+                 "rows-1d", "rows-1d", "rows-swt1", "odd-batch", "odd-batch", "few-mid", "ring-batch", "swt-stream", "swt-stream", "f64-stream"]
         if os.environ.get("SOAK_KINDS"):  # e.g. SOAK_KINDS=odd-batch,few-mid,swt-tiny
             kinds = os.environ["SOAK_KINDS"].split(",")
         kind = str(rng.choice(kinds))
@@ -116,6 +149,24 @@ def run(budget=None, max_cases=None, seed=1):
             r, c = [(2048, 2048), (1024, 2048), (1000, 4096), (3000, 1024), (4096, 4096)][int(rng.integers(0, 5))]
             B = max(2, int((1 << 25) // (r * c)) + int(rng.integers(0, 3)))
             done[kind] = done.get(kind, 0) + check(B, (r, c), str(rng.choice(["sym8", "db8", "db6", "coif2", "sym6", "bior5.5"])), int(rng.integers(1, 4)), 0, rng, kind)
+        elif kind == "swt-stream":    # round 5: any-length stream kernels -- rows that are not whole quads, small images with long filters, 1D too
+            longn = [w for w in names if oracle.filters(w)[0] >= 10]
+            r, c = int(rng.integers(40, 700)), int(rng.integers(40, 1100))
+            if rng.integers(0, 3) == 0:
+                r, c = int(rng.choice([128, 256, 512, 640])), int(rng.choice([128, 256, 512, 1024]))
+            if rng.integers(0, 4) == 0:   # (batched) 1D rows of any length
+                done[kind] = done.get(kind, 0) + check(1, (int(rng.integers(1, 40)), int(rng.integers(130, 5000))), str(rng.choice(longn)), int(rng.integers(1, 4)), 1, rng, kind, ndim=1)
+            else:
+                done[kind] = done.get(kind, 0) + check(int(rng.choice([1, 1, 2, 3])), (r, c), str(rng.choice(longn)), int(rng.integers(1, 4)), 1, rng, kind)
+        elif kind == "f64-stream":    # fp64 library: a-trous levels of any size from 6 / 12 taps, decimated inverses of 28-40 taps on large levels
+            swt = int(rng.integers(0, 2))
+            if swt:
+                w = str(rng.choice([w for w in names if oracle.filters(w)[0] >= 6]))
+                shape = (int(rng.integers(40, 500)), int(rng.integers(40, 700)))
+            else:
+                w = str(rng.choice([w for w in names if oracle.filters(w)[0] >= 28]))
+                shape = [(1024, 1024), (2048, 1024), (1026, 1300), (2048, 2048)][int(rng.integers(0, 4))]
+            done[kind] = done.get(kind, 0) + check64(int(rng.choice([1, 1, 2])), shape, w, int(rng.integers(1, 4)), swt, rng, kind)
         elif kind == "mid-batch":     # between one image and the strips
             r, c = [(1024, 1024), (2048, 2048), (1024, 2048), (4096, 4096)][int(rng.integers(0, 4))]
             B = max(2, int((1 << int(rng.integers(24, 27))) // (r * c)))
