@@ -153,10 +153,14 @@ static inline v2f mk2h(real_t a, real_t b) {
 // Where the two launches beat the LDS-tiled level kernel (2048^2 levels, tools/swtsweep.py, profiles/r03_swt_split_sweep.txt):
 // the inverse from 10 taps on (10 taps 46 -> 41 us per level, 12 taps 80 -> 43, 16 taps 93 -> 40, 40 taps 150-290 -> 57-60),
 // the forward from 18 taps on (18 taps 47-61 -> 40, 26 taps 91-111 -> 42, 40 taps 127-158 -> 45-47; at 16 taps the
-// tiled kernel's 35-45 is level with the 36-39 of two launches).  Tuning keys "swt_split_fwd" / "swt_split_inv" (environment
+// tiled kernel's 35-45 is level with the 36-39 of two launches).
+// Round 5 re-measured the forward inside whole plans (tools/swt_fwd_split_ab.py, profiles/r05k_swt_fwd_split_ab.txt): from 2 M samples
+// on the two launches win from 14 taps -- sym8 2048^2 L3 forward 160 -> 102 us, L5 262 -> 173, 4096^2 L2 397 -> 320, 1080 x 1920 L3
+// 94 -> 80; db7 2048^2 L3 145 -> 100 -- at 1024^2 they lose (54 -> 61) and 12 taps are level (2048^2 107 -> 99, 4096^2 291 -> 300):
+// the default is 14 taps from 2^21 samples, 18 below.  Tuning keys "swt_split_fwd" / "swt_split_inv" (environment
 // PDWT_SWT_SPLIT_FWD / _INV): the shortest filter that takes this path at full size, 0 = never, 100 + n = n taps at EVERY size.
 static std::atomic<int>& split_min(bool inverse) {
-    static std::atomic<int> fwd{env_int("PDWT_SWT_SPLIT_FWD", 18)}, inv{env_int("PDWT_SWT_SPLIT_INV", 10)};
+    static std::atomic<int> fwd{env_int("PDWT_SWT_SPLIT_FWD", 14)}, inv{env_int("PDWT_SWT_SPLIT_INV", 10)};
     return inverse ? inv : fwd;
 }
 int set_swt_split_min(int inverse, int taps) { return split_min(inverse != 0).exchange(taps < 0 ? 0 : taps); }
@@ -196,7 +200,9 @@ bool swt2_split_supported(int hlen, int Nr, int Nc, int f, bool inverse, long lo
         min_taps = 10;  // rows the dilation does not divide: the alternative is three direct passes (one load per tap and output)
     } else if (min_taps >= 100) {
         min_taps -= 100;  // forced: the same threshold at every size (tests)
-    } else if (inverse) {
+    } else if (!inverse) {
+        if (samples < (1LL << 21) && min_taps < 18) min_taps = 18;  // 14 and 16 taps: from 2 M samples (see above)
+    } else {
         // small launches: two launches of one round each cost more than they save until the filter is long -- inverse levels of
         // 256^2 / 512^2: 10 taps 13 | 17-18 us (tiled | split), 16 taps 16 | 21-22, 26 taps 33 | 26-27, 40 taps 31-44 | 22-35;
         // 1024^2: 12 taps 24 | 23, 16 taps 28 | 25, 20 taps 35 | 28 (profiles/r03_swt_split_sweep.txt)
