@@ -175,16 +175,21 @@ int get_swt_split_min(int inverse) { return split_min(inverse != 0).load(std::me
 // (b) Small images with long filters: four columns per lane leave a 512^2 level 256 wavefronts of 43 dependent loads each; two
 //     columns per lane are four times the wavefronts.  From 18 taps up to 2^20 samples: 512^2 L3 db9 51 | 45 -> 33 | 38, db10
 //     54 | 48 -> 34 | 37, db20 73 | 99 -> 41 | 51; 1024^2 db10 67 | 76 -> 62 | 60, db20 90 | 111 -> 79 | 88; 16 taps: level
-//     (0.83-1.08 | 1.01-1.10).  From 1.9 M samples on the packed kernels are ahead again (1200 x 1600: 1.06-1.11 | 1.17-1.27;
+//     (0.83-1.08 | 1.01-1.10; the inverse of 10-16 taps alone: 1.03-1.35, r05g_swt_stream32_inv.txt).  From 1.9 M samples on the packed kernels are ahead again (1200 x 1600: 1.06-1.11 | 1.17-1.27;
 //     2048^2: 1.4-1.5 | 1.5-1.7).
 // Shortest filter per rule, 0 = never (A/B measurements in the lab library: PDWT_SWT_STREAM_RAGGED_FWD / _RAGGED / _SMALL / _SMALL_LOG2).
 static bool stream_route32(int hlen, int Nr, int Nc, int f, bool inverse, long long samples, int min_taps) {
     static const int ragged_fwd = env_int("PDWT_SWT_STREAM_RAGGED_FWD", 16), ragged_inv = env_int("PDWT_SWT_STREAM_RAGGED", 10),
-                     small = env_int("PDWT_SWT_STREAM_SMALL", 18), small_log2 = env_int("PDWT_SWT_STREAM_SMALL_LOG2", 20);
+                     small_fwd = env_int("PDWT_SWT_STREAM_SMALL", 18), small_inv = env_int("PDWT_SWT_STREAM_SMALL_INV", 18),
+                     small_log2 = env_int("PDWT_SWT_STREAM_SMALL_LOG2", 20);
     if (min_taps <= 0 || min_taps >= 100) return false;  // the path is off, or the packed kernels are forced (tests)
     if (hlen < 2 || hlen > kMaxTaps || f < 1 || f >= Nr || f >= Nc) return false;
     const int ragged = inverse ? ragged_inv : ragged_fwd;
     if ((Nc & 3) && ragged > 0 && hlen >= ragged) return true;
+    int small = inverse ? small_inv : small_fwd;
+    // rows of exactly 1024 samples (4-KiB pitch): the tiled inverse walks rows f pitches apart in four bands and loses a third there
+    // (1024^2 L3 inverse: db6 66 us, sym8 73 against 46 / 53 at 1000^2; the stream kernels 56 / 62, r05g_swt_stream32_inv.txt)
+    if (inverse && small == 18 && (Nc & 1023) == 0 && hlen >= 12) small = 12;
     if (samples <= (1LL << small_log2) && small > 0 && hlen >= small) return true;
     return false;
 }

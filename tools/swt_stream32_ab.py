@@ -17,6 +17,9 @@ CASES = [("db5", (2047, 2047), 2), ("sym8", (2047, 2047), 3), ("db10", (2047, 20
          ("db20", (1000, 1000), 3), ("db10", (768, 768), 3), ("db20", (128, 128), 2)]
 CONFIGS = [("off", {"PDWT_SWT_STREAM_RAGGED": "0", "PDWT_SWT_STREAM_RAGGED_FWD": "0", "PDWT_SWT_STREAM_SMALL": "0"}),
            ("on", {"PDWT_SWT_STREAM_RAGGED": "6", "PDWT_SWT_STREAM_RAGGED_FWD": "6", "PDWT_SWT_STREAM_SMALL": "6", "PDWT_SWT_STREAM_SMALL_LOG2": "24"})]
+if os.environ.get("STREAM32_INV"):  # the inverse of 10-16 taps on small images
+    CASES = [(w, s, 3) for w in ("db5", "db6", "db7", "sym8") for s in ((256, 256), (512, 512), (768, 768), (1000, 1000), (1024, 1024), (800, 1200))]
+    CONFIGS = [("off", {}), ("on", {"PDWT_SWT_STREAM_SMALL_INV": "10"})]
 if os.environ.get("STREAM32_LARGE"):  # where the packed kernels take over again
     CASES = [(w, s, 3) for w in ("db9", "db10", "db13", "db20") for s in ((1024, 1024), (1200, 1600), (1440, 1440), (2048, 2048))]
     CASES += [("db9", (512, 512), 3), ("db8", (512, 512), 3), ("db9", (1000, 1000), 3), ("db7", (1001, 1001), 3), ("db7", (2047, 2047), 3)]
