@@ -152,9 +152,11 @@ static std::atomic<int>& ring_min_log2() {
 }
 int set_ring_min_log2(int value) { return ring_min_log2().exchange(value < 0 ? 0 : (value > 63 ? 63 : value)); }
 int get_ring_min_log2() { return ring_min_log2().load(std::memory_order_relaxed); }
-static bool ring_kernels_for(long long samples, int hlen, int Nc) {
+static bool ring_kernels_for(long long samples, int hlen, int Nc, bool inverse) {
     const int m = g_active_tuning ? g_active_tuning->ring_min_log2 : ring_min_log2().load(std::memory_order_relaxed);
     if (m >= 63 || samples < (1LL << m)) return false;
+    static const int dirs = lab_env("PDWT_RING_DIRS") ? atoi(lab_env("PDWT_RING_DIRS")) : 3;  // A/B measurements: bit 0 forward, bit 1 inverse
+    if (!((dirs >> (inverse ? 1 : 0)) & 1)) return false;
     if (m < kRingMinDefault) return hlen >= 10 && hlen <= 20;  // forced: every length the kernels are built for, any width
     return (hlen == 12 || hlen == 16) && Nc >= 1024;
 }
@@ -223,7 +225,7 @@ Tuning current_tuning() {
 }
 
 hipError_t launch_dwt2_fwd(const Fwd2DArgs& a, int batch, hipStream_t s) {
-    if (ring_kernels_for((long long)batch * a.Nr * a.Nc, a.hlen, a.Nc)) {
+    if (ring_kernels_for((long long)batch * a.Nr * a.Nc, a.hlen, a.Nc, false)) {
         const hipError_t e = try_launch_dwt2_fwd_ring(a, batch, s);
         if (took(e, "ring")) return e;
     }
@@ -263,7 +265,7 @@ hipError_t launch_dwt2_inv(const Inv2DArgs& a, int batch, hipStream_t s) {
     // 23.6 us) and loses slightly to the LDS tiles on a batch streamed from HBM (8 x 4096^2: 224-232 vs 219 us,
     // profiles/r02b_wbench_b8.txt): 2^26 samples and beyond go to the tiles
     const long long samples = (long long)batch * a.Nr * a.Nc;
-    if (ring_kernels_for(samples, a.hlen, a.Nc)) {
+    if (ring_kernels_for(samples, a.hlen, a.Nc, true)) {
         const hipError_t e = try_launch_dwt2_inv_ring(a, batch, s);
         if (took(e, "ring")) return e;
     }
