@@ -33,3 +33,18 @@ for w, taps in (("db5", 10), ("db6", 12), ("db7", 14), ("sym8", 16), ("db9", 18)
             del W
             lib.pdwt_set_tuning(b"swt_split_fwd", prev)
         print("%-5s (%2d) %-10s L=%d | %8.1f | %8.1f | %8.1f | %8.1f" % (w, taps, "%dx%d" % s, L, *res), flush=True)
+
+# batches of smaller images at the same launch sizes (the rule counts samples per launch)
+from pypwt_amd import BatchedWavelets  # noqa: E402
+print("# batches: wavelet B x shape levels | forward us with swt_split_fwd = 18 | 14")
+for w in ("db7", "sym8"):
+    for B, s, L in ((16, (512, 512), 3), (64, (256, 256), 3), (4, (1024, 1024), 3), (256, (128, 128), 2), (8, (1024, 512), 3), (2, (2048, 2048), 3)):
+        res = []
+        for thr in (18, 14):
+            prev = lib.pdwt_set_tuning(b"swt_split_fwd", thr)
+            W = BatchedWavelets(B, s[0], s[1], w, L, do_swt=1)
+            W.fill_hash(3)
+            res.append(fwd_us(W))
+            W.cleanup()
+            lib.pdwt_set_tuning(b"swt_split_fwd", prev)
+        print("%-5s %3d x %-10s L=%d | %8.1f | %8.1f" % (w, B, "%dx%d" % s, L, *res), flush=True)
