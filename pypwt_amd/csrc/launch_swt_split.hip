@@ -175,7 +175,8 @@ int get_swt_split_min(int inverse) { return split_min(inverse != 0).load(std::me
 // (b) Small images with long filters: four columns per lane leave a 512^2 level 256 wavefronts of 43 dependent loads each; two
 //     columns per lane are four times the wavefronts.  From 18 taps up to 2^20 samples: 512^2 L3 db9 51 | 45 -> 33 | 38, db10
 //     54 | 48 -> 34 | 37, db20 73 | 99 -> 41 | 51; 1024^2 db10 67 | 76 -> 62 | 60, db20 90 | 111 -> 79 | 88; 16 taps: level
-//     (0.83-1.08 | 1.01-1.10; the inverse of 10-16 taps alone: 1.03-1.35, r05g_swt_stream32_inv.txt).  From 1.9 M samples on the packed kernels are ahead again (1200 x 1600: 1.06-1.11 | 1.17-1.27;
+//     (0.83-1.08 | 1.01-1.10; the inverse of 10-16 taps alone: 1.03-1.35 of the TILES' time, r05g_swt_stream32_inv.txt -- its 1024^2 rows,
+//     0.85-0.88, compared with the packed kernels the old rule picked at exactly 2^20 samples, not with the tiles).  From 1.9 M samples on the packed kernels are ahead again (1200 x 1600: 1.06-1.11 | 1.17-1.27;
 //     2048^2: 1.4-1.5 | 1.5-1.7).
 // Shortest filter per rule, 0 = never (A/B measurements in the lab library: PDWT_SWT_STREAM_RAGGED_FWD / _RAGGED / _SMALL / _SMALL_LOG2).
 static bool stream_route32(int hlen, int Nr, int Nc, int f, bool inverse, long long samples, int min_taps) {
@@ -186,10 +187,7 @@ static bool stream_route32(int hlen, int Nr, int Nc, int f, bool inverse, long l
     if (hlen < 2 || hlen > kMaxTaps || f < 1 || f >= Nr || f >= Nc) return false;
     const int ragged = inverse ? ragged_inv : ragged_fwd;
     if ((Nc & 3) && ragged > 0 && hlen >= ragged) return true;
-    int small = inverse ? small_inv : small_fwd;
-    // rows of exactly 1024 samples (4-KiB pitch): the tiled inverse walks rows f pitches apart in four bands and loses a third there
-    // (1024^2 L3 inverse: db6 66 us, sym8 73 against 46 / 53 at 1000^2; the stream kernels 56 / 62, r05g_swt_stream32_inv.txt)
-    if (inverse && small == 18 && (Nc & 1023) == 0 && hlen >= 12) small = 12;
+    const int small = inverse ? small_inv : small_fwd;
     if (samples <= (1LL << small_log2) && small > 0 && hlen >= small) return true;
     return false;
 }
@@ -214,7 +212,9 @@ bool swt2_split_supported(int hlen, int Nr, int Nc, int f, bool inverse, long lo
         // (8 taps at dilation 1 and 2 -- the rule below -- already from 1.5 M samples on: a 1080 x 1920 image, db4 L3 forward+inverse
         // 121 -> 105 us, 1200 x 1600 121 -> 102; at 1024^2 and below the tiles stay ahead: 79 against 90 us)
         const bool eight_mid = hlen == 8 && f <= 2 && min_taps <= 10 && samples >= (3LL << 19);
-        if (samples < (1LL << 20) && min_taps < 24) min_taps = 24;
+        // (up to AND INCLUDING 2^20 samples since round 5: a 1024^2 image is exactly that, and its 12-16-tap inverse is 46-51 us on
+        // the tiles against 66-73 on these kernels -- tools/swt_pitch_probe.py, profiles/r05k_swt_inv_at_2p20.txt)
+        if (samples <= (1LL << 20) && min_taps < 24) min_taps = 24;
         else if (samples < (1LL << 22) && min_taps < 12 && !eight_mid) min_taps = 12;
         // 8 taps (db4, sym4, bior2.4 ...), dilation 1 and 2, from 2048^2 on: the tiled inverse issues one 16-B load per band and
         // tap at 4-B / 8-B alignment there (52-55 us per 2048^2 level against 33 at dilation 4, where the loads are aligned);
