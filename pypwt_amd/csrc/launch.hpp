@@ -68,7 +68,7 @@ bool dwt2_wave2_supported(int hlen, int N0r, int N0c);
 hipError_t launch_dwt2_fwd_wave2(const real_t* in, real_t* const det1[3], real_t* const band2[4], int N0r, int N0c,
                                  int hlen, const FilterBank& fb, int batch, hipStream_t s, int seg_hint = 0);
 // two consecutive 2D levels in one launch (small levels only, see launch_dwt2_pyramid.hip)
-bool dwt2_pyramid_supported(int hlen, int N0r, int N0c);   // tile pyramid: even filters of at most 16 taps
+bool dwt2_pyramid_supported(int hlen, int N0r, int N0c, bool inverse);   // tile pyramid: even filters of at most 16 taps
 bool dwt2_strip_supported(int hlen, int N0r, int N0c);     // streaming strips: at most 8 taps
 hipError_t launch_dwt2_fwd_pyr2(const real_t* in, real_t* const det1[3], real_t* const band2[4], int N0r, int N0c,
                                 int hlen, const FilterBank& fb, int batch, hipStream_t s);

@@ -43,7 +43,7 @@ static hipError_t run_inv(const Inv2DArgs& a, int batch, hipStream_t s) {
 bool dwt2_wave2_supported(int, int, int) { return false; }
 hipError_t launch_dwt2_fwd_wave2(const real_t*, real_t* const[3], real_t* const[4], int, int, int, const FilterBank&, int,
                                  hipStream_t, int) { return hipErrorNotSupported; }
-bool dwt2_pyramid_supported(int, int, int) { return false; }
+bool dwt2_pyramid_supported(int, int, int, bool) { return false; }
 bool dwt2_strip_supported(int, int, int) { return false; }
 hipError_t launch_dwt2_fwd_pyr2(const real_t*, real_t* const[3], real_t* const[4], int, int, int, const FilterBank&, int,
                                 hipStream_t) { return hipErrorNotSupported; }

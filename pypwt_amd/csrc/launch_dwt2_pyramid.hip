@@ -25,12 +25,15 @@ static void interleave(FilterBankI& o, const FilterBank& fb) {
 
 static bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-bool dwt2_pyramid_supported(int hlen, int N0r, int N0c) {
-    // even filters of at most 16 taps (LDS), even sizes at both levels (exact periodization), 16-B aligned rows at level l+1
-    return !(hlen & 1) && hlen >= 2 && hlen <= 16 && (N0r % 4) == 0 && (N0c % 16) == 0 && N0r >= 4 && N0c >= 16;
+bool dwt2_pyramid_supported(int hlen, int N0r, int N0c, bool inverse) {
+    // even filters of at most 16 taps (LDS), even sizes at both levels (exact periodization), 16-B aligned rows at level l+1.
+    // The INVERSE stages the bands of level l+2 in quads too: rows of N0c / 4 samples must be whole quads (N0c % 16 == 0); the
+    // forward stores them in pairs (N0c % 8 == 0: a 1000 x 1000 image's forward is PYR2[1-2] LEVEL[3] since round 5, its inverse
+    // three level launches -- forward 11.5 -> 9.9 us)
+    return !(hlen & 1) && hlen >= 2 && hlen <= 16 && (N0r % 4) == 0 && (N0c % (inverse ? 16 : 8)) == 0 && N0r >= 4 && N0c >= 16;
 }
 // the streaming strips carry (hlen - 2) rows per level in LDS: filters of at most 8 taps
-bool dwt2_strip_supported(int hlen, int N0r, int N0c) { return hlen <= 8 && dwt2_pyramid_supported(hlen, N0r, N0c); }
+bool dwt2_strip_supported(int hlen, int N0r, int N0c) { return hlen <= 8 && dwt2_pyramid_supported(hlen, N0r, N0c, true); }
 
 template <int HLEN>
 static hipError_t run_fwd(FwdPyr2Args& a, int batch, hipStream_t s) {
@@ -72,7 +75,7 @@ static hipError_t run_inv(InvPyr2Args& a, int batch, hipStream_t s) {
 // in (N0r,N0c) -> details of level l (det1 = H,V,D) and all four bands of level l+1 (band2 = A,H,V,D)
 hipError_t launch_dwt2_fwd_pyr2(const float* in, float* const det1[3], float* const band2[4], int N0r, int N0c,
                                 int hlen, const FilterBank& fb, int batch, hipStream_t s) {
-    if (!dwt2_pyramid_supported(hlen, N0r, N0c)) return hipErrorNotSupported;
+    if (!dwt2_pyramid_supported(hlen, N0r, N0c, false)) return hipErrorNotSupported;
     if (!al16(in) || !al16(det1[0]) || !al16(det1[1]) || !al16(det1[2]) || !al16(band2[0]) || !al16(band2[1]) ||
         !al16(band2[2]) || !al16(band2[3]))
         return hipErrorNotSupported;
@@ -187,7 +190,7 @@ hipError_t launch_dwt2_inv_strip2(const float* const[4], const float* const[3], 
 
 hipError_t launch_dwt2_inv_pyr2(const float* const band2[4], const float* const det1[3], float* out, int N0r, int N0c,
                                 int hlen, const FilterBank& fb, int batch, hipStream_t s) {
-    if (!dwt2_pyramid_supported(hlen, N0r, N0c)) return hipErrorNotSupported;
+    if (!dwt2_pyramid_supported(hlen, N0r, N0c, true)) return hipErrorNotSupported;
     if (!al16(out) || !al16(det1[0]) || !al16(det1[1]) || !al16(det1[2]) || !al16(band2[0]) || !al16(band2[1]) ||
         !al16(band2[2]) || !al16(band2[3]))
         return hipErrorNotSupported;

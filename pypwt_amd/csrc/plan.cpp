@@ -454,7 +454,7 @@ void build_schedule(pdwt_plan* p) {
         const bool no_pyr = getenv("PDWT_NO_PYRAMID") != nullptr, no_strip = lab_env("PDWT_NO_STRIP") != nullptr;
         const bool force_strip = lab_env("PDWT_FORCE_STRIP") != nullptr;
         auto samples = [&](int l) { return (long long)p->batch * p->lr[l - 1] * p->lc[l - 1]; };
-        auto pair_ok = [&](int l) { return l + 1 <= L && dwt2_pyramid_supported(hlen, p->lr[l - 1], p->lc[l - 1]); };
+        auto pair_ok = [&](int l, bool inverse = true) { return l + 1 <= L && dwt2_pyramid_supported(hlen, p->lr[l - 1], p->lc[l - 1], inverse); };
         auto strip_at = [&](int l, bool inverse) {
             static const bool inv_strip_l1 = lab_env("PDWT_INV_STRIP") != nullptr;  // A/B: the inverse strips for levels 1+2 of a batch
             if (!fusable || no_strip || !pair_ok(l) || !dwt2_strip_supported(hlen, p->lr[l - 1], p->lc[l - 1]) ||
@@ -467,7 +467,7 @@ void build_schedule(pdwt_plan* p) {
             return force_strip || samples(l) >= (1LL << min_log2);
         };
         static const bool inv_pyr_l1 = lab_env("PDWT_INV_PYR_L1") != nullptr;  // A/B: the tile pyramid for levels 1+2 of any inverse
-        auto pyr_at = [&](int l) { return fusable && !no_pyr && pair_ok(l) && samples(l) <= (1LL << 20); };
+        auto pyr_at = [&](int l, bool inverse) { return fusable && !no_pyr && pair_ok(l, inverse) && samples(l) <= (1LL << 20); };
         // Three levels per launch where a small image (at most 2^19 samples, 2^20 over the batch) has three (or five, six, ...) levels
         // left: one launch fewer per direction -- 512^2 db2 L3: 15.6 -> 9.9 us per forward+inverse, 256^2 db4 L5: 26.8 ->
         // 18.4 us, 64 x 128^2 db4 L3: 27.0 -> 20.3 us; at 1024^2 the pairs are ahead (db4 L3: 18.6 against 20.4 us).  Four levels left stay two tile
@@ -634,7 +634,7 @@ void build_schedule(pdwt_plan* p) {
                 if (strip_at(l, dir != 0)) { out.push_back({Step::STRIP2, l, 2}); l++; }
                 else if (wave2_at(l, dir != 0)) { out.push_back({Step::WAVE2, l, 2}); l++; }
                 else if (pyr3_at(l, dir != 0)) { out.push_back({Step::PYR3, l, 3}); l += 2; }
-                else if ((pyr_at(l) && !strip_at(l + 1, dir != 0)) || (inv_pyr_l1 && dir == 1 && l == 1 && fusable && pair_ok(l))) { out.push_back({Step::PYR2, l, 2}); l++; }
+                else if ((pyr_at(l, dir != 0) && !strip_at(l + 1, dir != 0)) || (inv_pyr_l1 && dir == 1 && l == 1 && fusable && pair_ok(l))) { out.push_back({Step::PYR2, l, 2}); l++; }
                 else out.push_back({Step::LEVEL, l, 1});
             }
         }
