@@ -481,8 +481,12 @@ void build_schedule(pdwt_plan* p) {
             if (!inverse && hlen > 8 && lab_env("PDWT_PYR3_FWD_LONG") == nullptr) return false;  // (the knob: tests keep the kernel covered)
             // filters of 10-16 taps recompute a 16x larger halo: ahead up to 512^2 only (sym8 512^2 L3: 21.6 against 25.0 us,
             // 1024 x 512: 37.3 against 25.4 us; profiles/r02y_pyr3_sweep.txt)
-            const long long per_image = hlen <= 8 ? (1LL << 19) : (1LL << 18);
-            return fusable && !no_pyr3 && left >= 3 && left != 4 && samples(l) <= (1LL << 20) &&
+            // (round 5: where the two-level pyramid cannot take the rows -- N0c % 16 == 8, the inverse of a 1000 x 1000 image -- three levels
+            // in one launch are ahead of three level launches up to 2^20 samples: 1000^2 L3 forward+inverse haar 19.0 -> 15.6 us, db2
+            // 21.3 -> 18.8, db4 22.8 -> 21.1; 600 x 1000 haar 19.6 -> 14.4; L5 33.4 -> 29.6; four levels left take three + one there)
+            static const bool pyr3_wide = sizeof(real_t) == 4 && lab_env("PDWT_NO_PYR3_WIDE") == nullptr;  // (fp64: no pair pyramid at all, its limits stay)
+            const long long per_image = hlen <= 8 ? ((pyr3_wide && !pair_ok(l, inverse)) ? (1LL << 20) : (1LL << 19)) : (1LL << 18);
+            return fusable && !no_pyr3 && left >= 3 && (left != 4 || (pyr3_wide && !pair_ok(l, inverse))) && samples(l) <= (1LL << 20) &&
                    (long long)p->lr[l - 1] * p->lc[l - 1] <= per_image && dwt2_pyr3_supported(hlen, p->lr[l - 1], p->lc[l - 1]);
         };
         // Two levels per WAVEFRONT (dwt2_fwd2_wave: A_l stays in registers, overlapping strips).  Correct and
