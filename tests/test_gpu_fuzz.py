@@ -192,16 +192,16 @@ def test_fuzz_three_level_pyramid(seed):
 def test_soak_slice():
     """A deterministic slice of tools/soak.py (the randomised soak that guards the dispatch regimes the
     unit fuzz does not reach -- large batches of tiny images, deep plans, mid-size and HD SWT plans, short-row 1D batches, the
-    batch range of the register-ring kernels -- was builder-run only).  Fixed seed, 260 plans, every kind at least twice (round 5: with the stream kernels' kinds, fp32 and fp64); every plan
+    batch range of the register-ring kernels -- was builder-run only).  Fixed seed, 300 plans, every kind at least twice (round 5: with the stream kernels' kinds, fp32 and fp64); every plan
     against the CPU oracle (coefficients of three images, then the reconstruction)."""
     import importlib.util
     import os
     spec = importlib.util.spec_from_file_location("soak", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "soak.py"))
     soak = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(soak)
-    done, secs = soak.run(max_cases=260, seed=20250)
-    assert sum(done.values()) >= 260, done
+    done, secs = soak.run(max_cases=300, seed=20250)
+    assert sum(done.values()) >= 300, done
     for kind in ("tiny-batch", "small-batch", "deep", "swt-mid", "swt-hd", "mid-batch", "swt-batch", "swt-tiny", "rows-1d", "rows-swt1",
-                 "odd-batch", "few-mid", "ring-batch", "swt-stream", "f64-stream"):
+                 "odd-batch", "few-mid", "ring-batch", "swt-stream", "f64-stream", "real-sizes"):
         assert done.get(kind, 0) >= 2, (kind, done)
     print("soak slice: %d plans in %.0f s: %s" % (sum(done.values()), secs, done))

@@ -105,7 +105,7 @@ def run(budget=None, max_cases=None, seed=1):
     t0, done = time.time(), {}
     while (budget is None or time.time() - t0 < budget) and (max_cases is None or sum(done.values()) < max_cases):
         kinds = ["tiny-batch", "tiny-batch", "small-batch", "deep", "swt-mid", "swt-hd", "mid-batch", "swt-batch", "swt-tiny",
-                 "rows-1d", "rows-1d", "rows-swt1", "odd-batch", "odd-batch", "few-mid", "ring-batch", "swt-stream", "swt-stream", "f64-stream"]
+                 "rows-1d", "rows-1d", "rows-swt1", "odd-batch", "odd-batch", "few-mid", "ring-batch", "swt-stream", "swt-stream", "f64-stream", "real-sizes"]
         if os.environ.get("SOAK_KINDS"):  # e.g. SOAK_KINDS=odd-batch,few-mid,swt-tiny
             kinds = os.environ["SOAK_KINDS"].split(",")
         kind = str(rng.choice(kinds))
@@ -158,6 +158,13 @@ def run(budget=None, max_cases=None, seed=1):
                 done[kind] = done.get(kind, 0) + check(1, (int(rng.integers(1, 40)), int(rng.integers(130, 5000))), str(rng.choice(longn)), int(rng.integers(1, 4)), 1, rng, kind, ndim=1)
             else:
                 done[kind] = done.get(kind, 0) + check(int(rng.choice([1, 1, 2, 3])), (r, c), str(rng.choice(longn)), int(rng.integers(1, 4)), 1, rng, kind)
+        elif kind == "real-sizes":    # camera / video / scan formats and their neighbours: rows of 8 but not 16 samples (forward pair pyramid only,
+            # three levels per launch for the inverse), levels that turn odd on the way down, DWT and SWT
+            base = [(480, 640), (600, 800), (720, 1280), (768, 1024), (1000, 1000), (1080, 1920), (1200, 1600), (1500, 2000), (520, 1000), (904, 1000), (1000, 1048)]
+            r, c = base[int(rng.integers(0, len(base)))]
+            r, c = r + 4 * int(rng.integers(-2, 3)), c + 8 * int(rng.integers(-2, 3))
+            swt = int(rng.integers(0, 4) == 0)
+            done[kind] = done.get(kind, 0) + check(int(rng.choice([1, 1, 1, 2])), (r, c), str(rng.choice(short)), int(rng.integers(2, 7 if not swt else 4)), swt, rng, kind)
         elif kind == "f64-stream":    # fp64 library: a-trous levels of any size from 6 / 12 taps, decimated inverses of 28-40 taps on large levels
             swt = int(rng.integers(0, 2))
             if swt:
