@@ -338,9 +338,26 @@ PDWT_DEVICE void dwt2_inv_pyr2_tile(const InvPyr2Args& a, int bx, int by, int bz
     PDWT_FOR_THREADS(tid, NT) {
         const long long b2 = (long long)bz * a.l2_bstride, b1 = (long long)bz * a.l1_bstride;
         const int g4 = nc2 >> 2;
-        const int n2 = nr2 * g4;
+        // rows of level l+1 that are not whole quads (N2c % 4 == 2: a 1000-column image, round 5): its bands are staged in PAIRS (the
+        // window start and N2c are even: a pair never straddles the periodic wrap) by plain loops, the quad path below takes none
+        const bool pairs2 = (N2c & 2) != 0;
+        const int n2 = pairs2 ? 0 : nr2 * g4;
         constexpr int n1 = CR * V4;
-        {
+        const int first = pairs2 ? 0 : NT;  // the quad path's first trip is taken together with level l's (below)
+        if (pairs2) {
+            const int g2 = nc2 >> 1;
+            for (int idx = tid; idx < nr2 * g2; idx += NT) {
+                const int r = idx / g2, g = idx - r * g2;
+                const long long o = b2 + (long long)wrap_periodic(c2y0 + r, N2r) * N2c + wrap_periodic(c2xa + 2 * g, N2c);
+                const f32x2 qA = *reinterpret_cast<const f32x2*>(a.A2 + o), qV = *reinterpret_cast<const f32x2*>(a.V2 + o);
+                const f32x2 qH = *reinterpret_cast<const f32x2*>(a.H2 + o), qD = *reinterpret_cast<const f32x2*>(a.D2 + o);
+                f32x4 w;
+                w.x = qA.x; w.y = qV.x; w.z = qA.y; w.w = qV.y;
+                *reinterpret_cast<f32x4*>(sAV2 + r * W2 + 2 * g) = w;
+                w.x = qH.x; w.y = qD.x; w.z = qH.y; w.w = qD.y;
+                *reinterpret_cast<f32x4*>(sHD2 + r * W2 + 2 * g) = w;
+            }
+        } else {
             const int i2 = tid < n2 ? tid : n2 - 1, i1 = tid < n1 ? tid : n1 - 1;
             const int r2 = i2 / g4, gg2 = i2 - r2 * g4;
             const int r1 = i1 / V4, gg1 = i1 - r1 * V4;
@@ -361,14 +378,14 @@ PDWT_DEVICE void dwt2_inv_pyr2_tile(const InvPyr2Args& a, int bx, int by, int bz
                 w.x = vH.z; w.y = vD.z; w.z = vH.w; w.w = vD.w; dHD[1] = w;
             }
         }
-        for (int idx = tid + NT; idx < n2; idx += NT) {
+        for (int idx = tid + NT; idx < n2; idx += NT) {  // (n2 == 0 with pairs)
             const int r = idx / g4, g = idx - r * g4;
             const long long o = b2 + (long long)wrap_periodic(c2y0 + r, N2r) * N2c + wrap_periodic(c2xa + 4 * g, N2c);
             inv_fast_interleave(sAV2, sHD2, r * W2 + 4 * g, *reinterpret_cast<const v4f*>(a.A2 + o),
                                 *reinterpret_cast<const v4f*>(a.V2 + o), *reinterpret_cast<const v4f*>(a.H2 + o),
                                 *reinterpret_cast<const v4f*>(a.D2 + o));
         }
-        for (int idx = tid + NT; idx < n1; idx += NT) {
+        for (int idx = tid + first; idx < n1; idx += NT) {
             const int r = idx / V4, g = idx - r * V4;
             const long long o = b1 + (long long)wrap_periodic(cy0 + r, N1r) * N1c + wrap_periodic(cxa + 4 * g, N1c);
             const v4f vV = *reinterpret_cast<const v4f*>(a.V1 + o);

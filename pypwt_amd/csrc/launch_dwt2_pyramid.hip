@@ -26,14 +26,15 @@ static void interleave(FilterBankI& o, const FilterBank& fb) {
 static bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 bool dwt2_pyramid_supported(int hlen, int N0r, int N0c, bool inverse) {
-    // even filters of at most 16 taps (LDS), even sizes at both levels (exact periodization), 16-B aligned rows at level l+1.
-    // The INVERSE stages the bands of level l+2 in quads too: rows of N0c / 4 samples must be whole quads (N0c % 16 == 0); the
-    // forward stores them in pairs (N0c % 8 == 0: a 1000 x 1000 image's forward is PYR2[1-2] LEVEL[3] since round 5, its inverse
-    // three level launches -- forward 11.5 -> 9.9 us)
-    return !(hlen & 1) && hlen >= 2 && hlen <= 16 && (N0r % 4) == 0 && (N0c % (inverse ? 16 : 8)) == 0 && N0r >= 4 && N0c >= 16;
+    // even filters of at most 16 taps (LDS), even sizes at both levels (exact periodization), 16-B aligned rows at level l+1: rows
+    // of N0c % 8 == 0 samples.  (Until round 5: N0c % 16 == 0 -- the forward always stored the bands of level l+2 in pairs, and the
+    // inverse now stages them in pairs where their rows are not whole quads: a 1000 x 1000 image ran level launches for want of it,
+    // dwt2 db4 1000^2 L3 forward+inverse 25.9 us against 18.5 for 1024^2.)
+    (void)inverse;
+    return !(hlen & 1) && hlen >= 2 && hlen <= 16 && (N0r % 4) == 0 && (N0c % 8) == 0 && N0r >= 4 && N0c >= 16;
 }
 // the streaming strips carry (hlen - 2) rows per level in LDS: filters of at most 8 taps
-bool dwt2_strip_supported(int hlen, int N0r, int N0c) { return hlen <= 8 && dwt2_pyramid_supported(hlen, N0r, N0c, true); }
+bool dwt2_strip_supported(int hlen, int N0r, int N0c) { return hlen <= 8 && (N0c % 16) == 0 && dwt2_pyramid_supported(hlen, N0r, N0c, true); }
 
 template <int HLEN>
 static hipError_t run_fwd(FwdPyr2Args& a, int batch, hipStream_t s) {

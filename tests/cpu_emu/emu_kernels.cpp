@@ -416,7 +416,7 @@ static void run_inv_pyr2(InvPyr2Args a, int batch) {
 
 EMU_API int emu_dwt2_inv_pyr2(const float* l1, const float* l2, int batch, int N0r, int N0c, const float* lo,
                               const float* hi, int hlen, int tile, float* out) {
-    if ((hlen & 1) || hlen > 16 || (N0c & 15) || (N0r & 3)) return -2;
+    if ((hlen & 1) || hlen > 16 || (N0c & 7) || (N0r & 3)) return -2;
     InvPyr2Args a;
     const long long n1 = (long long)batch * (N0r / 2) * (N0c / 2), n2 = (long long)batch * (N0r / 4) * (N0c / 4);
     a.H1 = l1; a.V1 = l1 + n1; a.D1 = l1 + 2 * n1;

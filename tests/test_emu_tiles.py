@@ -375,7 +375,8 @@ def test_emu_dwt2_fwd_pyramid(wname):
 @pytest.mark.parametrize("wname", ["haar", "db2", "db3", "db4", "sym4", "bior3.1", "db5", "coif2", "db7", "sym8"])
 def test_emu_dwt2_inv_pyramid(wname):
     hlen, dlo, dhi, rlo, rhi = oracle.filters(wname)
-    for si, (B, shape) in enumerate([(1, (64, 64)), (1, (32, 144)), (2, (40, 80)), (1, (128, 512)), (1, (4, 16)), (1, (260, 272))]):
+    for si, (B, shape) in enumerate([(1, (64, 64)), (1, (32, 144)), (2, (40, 80)), (1, (128, 512)), (1, (4, 16)), (1, (260, 272)),
+                                     (1, (32, 136)), (2, (40, 72)), (1, (260, 264)), (1, (8, 8)), (1, (64, 1000))]):  # ... rows of 8 but not 16 samples: level l+1 staged in pairs
         n1 = (shape[0] // 2, shape[1] // 2)
         n2 = (shape[0] // 4, shape[1] // 4)
         l1 = np.stack([oracle.hash_input((B,) + n1, 8500 + 10 * si + k, 2.0) - 1.0 for k in range(3)])  # H1,V1,D1

@@ -1049,18 +1049,19 @@ def test_swt_any_width_and_any_row_count(wname):
 @pytest.mark.gpu
 @pytest.mark.parametrize("wname,shape,levels", [("haar", (1000, 1000), 3), ("db4", (1000, 1000), 3), ("sym8", (200, 72), 2), ("db2", (260, 264), 2),
                                                 ("db4", (500, 1000), 4), ("coif2", (96, 1192), 3)])
-def test_forward_pyramid_on_rows_of_eight_but_not_sixteen(wname, shape, levels):
-    """Round 5: the two-level tile pyramid's FORWARD needs N0c % 8 == 0 only (it stores the bands of its second level in pairs); its
-    inverse stages them in quads and keeps N0c % 16 == 0.  A 1000 x 1000 image ran three level launches per direction for want of
-    the stricter rule (dwt2 db4 1000^2 L3 forward+inverse 25.9 us against 18.5 for 1024^2): forward PYR2 + LEVEL now, inverse LEVELs.
-    Every band against the oracle, then the reconstruction."""
+def test_pyramid_on_rows_of_eight_but_not_sixteen(wname, shape, levels):
+    """Round 5: the two-level tile pyramid needs rows of N0c % 8 == 0 samples, not 16: the forward stores the bands of its second level
+    in pairs, the inverse stages them in pairs where their rows are not whole quads.  A 1000 x 1000 image ran three level launches per
+    direction for want of it (dwt2 db4 1000^2 L3 forward+inverse 25.9 us against 18.5 for 1024^2).  Every band against the oracle,
+    then the reconstruction."""
     from pypwt_amd import BatchedWavelets
     B = 1 if shape[0] * shape[1] > (1 << 19) else 2  # (the pyramid serves launches of at most 2^20 samples)
     x = oracle.hash_input((B,) + shape, 9090)
     plan = BatchedWavelets(B, shape[0], shape[1], wname, levels, img=x)
     sched = plan.schedule()
     fwd, inv = sched.split("inv:")
-    assert "PYR2[1-2]" in fwd and "PYR2[1-2]" not in inv, sched
+    # a several-levels step starts at level 1 in both directions (the pair; or three levels in one launch where that rule applies)
+    assert ("PYR2[1-2]" in fwd or "PYR3[1-3]" in fwd) and ("PYR2[1-2]" in inv or "PYR3[1-3]" in inv), sched
     plan.forward()
     for b in range(B):
         ref = oracle.forward(x[b], wname, plan.levels)
