@@ -481,10 +481,13 @@ void build_schedule(pdwt_plan* p) {
             if (!inverse && hlen > 8 && lab_env("PDWT_PYR3_FWD_LONG") == nullptr) return false;  // (the knob: tests keep the kernel covered)
             // filters of 10-16 taps recompute a 16x larger halo: ahead up to 512^2 only (sym8 512^2 L3: 21.6 against 25.0 us,
             // 1024 x 512: 37.3 against 25.4 us; profiles/r02y_pyr3_sweep.txt)
-            // (round 5: 2- and 4-tap plans with exactly three levels left take the launch up to 2^20 samples -- haar L3 forward+inverse
+            // (round 5: 2- and 4-tap plans with three levels left take the launch up to 2^20 samples -- haar L3 forward+inverse
             // 1024^2 14.2 -> 9.1 us, 1000^2 16.8 -> 12.6, 768 x 1024 14.4 -> 10.3; db2 1000^2 18.8 -> 16.4, 600 x 1000 18.8 -> 14.8, 1024^2
             // 16.0 -> 16.4; with five levels left the pair first stays ahead: 1024^2 L5 haar 15.1 against 16.7, db2 17.1 against 25.6)
-            const long long per_image = (hlen <= 4 && left == 3) ? (1LL << 20) : (hlen <= 8 ? (1LL << 19) : (1LL << 18));
+            // ... and six or nine levels left likewise (whole groups of three): 1024^2 L6 haar 23.9 -> 15.6 us, db2 27.4 -> 23.5; 2048^2 L7
+            // (behind its level-1 launch) haar 36.5 -> 29.3, db2 41.6 -> 37.1
+            const bool short_whole = hlen <= 4 && left % 3 == 0;
+            const long long per_image = short_whole ? (1LL << 20) : (hlen <= 8 ? (1LL << 19) : (1LL << 18));
             return fusable && !no_pyr3 && left >= 3 && left != 4 && samples(l) <= (1LL << 20) &&
                    (long long)p->lr[l - 1] * p->lc[l - 1] <= per_image && dwt2_pyr3_supported(hlen, p->lr[l - 1], p->lc[l - 1]);
         };
