@@ -486,7 +486,9 @@ void build_schedule(pdwt_plan* p) {
             // 16.0 -> 16.4; with five levels left the pair first stays ahead: 1024^2 L5 haar 15.1 against 16.7, db2 17.1 against 25.6)
             // ... and six or nine levels left likewise (whole groups of three): 1024^2 L6 haar 23.9 -> 15.6 us, db2 27.4 -> 23.5; 2048^2 L7
             // (behind its level-1 launch) haar 36.5 -> 29.3, db2 41.6 -> 37.1
-            const bool short_whole = hlen <= 4 && left % 3 == 0;
+            // 6- and 8-tap plans with six or nine levels left too (with three left their pair + level stays ahead: 1024^2 db4 L3 18.6
+            // against 20.4 us): 1024^2 L6 db3 29.7 -> 26.4, db4 31.7 -> 29.0; 2048^2 L7 47.5 -> 42.2, 47.7 -> 43.4
+            const bool short_whole = (hlen <= 4 && left % 3 == 0) || (hlen <= 8 && left % 3 == 0 && left >= 6);
             const long long per_image = short_whole ? (1LL << 20) : (hlen <= 8 ? (1LL << 19) : (1LL << 18));
             return fusable && !no_pyr3 && left >= 3 && left != 4 && samples(l) <= (1LL << 20) &&
                    (long long)p->lr[l - 1] * p->lc[l - 1] <= per_image && dwt2_pyr3_supported(hlen, p->lr[l - 1], p->lc[l - 1]);
