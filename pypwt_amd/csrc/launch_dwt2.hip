@@ -58,7 +58,7 @@ hipError_t launch_dwt2_inv_pyr2(const real_t* const[4], const real_t* const[3], 
 hipError_t try_launch_dwt2_fwd_ring(const Fwd2DArgs&, int, hipStream_t, int, int) { return hipErrorNotSupported; }
 hipError_t try_launch_dwt2_inv_ring(const Inv2DArgs&, int, hipStream_t, int, int) { return hipErrorNotSupported; }
 int dwt1_fused_max_levels(int) { return 1; }
-bool dwt1_fused_supported(int, int, int) { return false; }
+bool dwt1_fused_supported(int, int, int, bool) { return false; }
 hipError_t launch_dwt1_fwd_fused(const real_t*, real_t* const*, real_t*, int, int, int, int, const FilterBank&,
                                  hipStream_t) { return hipErrorNotSupported; }
 hipError_t launch_dwt1_inv_fused(const real_t*, const real_t* const*, real_t*, int, int, int, int, const FilterBank&,

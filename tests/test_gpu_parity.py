@@ -1072,3 +1072,23 @@ def test_pyramid_on_rows_of_eight_but_not_sixteen(wname, shape, levels):
     for b in range(B):
         assert np.abs(plan.image_at(b) - x[b]).max() <= reconstruction_tol(x[b], wname, plan.levels), (wname, b)
     plan.cleanup()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("wname,shape,levels", [("haar", (1, 1000000), 5), ("db4", (1, 1000000), 5), ("sym8", (1000, 1000), 2), ("db2", (3, 1504), 4),
+                                                ("db10", (64, 10000), 3), ("db4", (1, 1500000), 4)])
+def test_forward_1d_pyramid_on_rows_of_half_the_alignment(wname, shape, levels):
+    """Round 5: the fused 1D pyramid's FORWARD takes rows of 2^(K+1) samples (it stores its deepest level in pairs); the inverse stages
+    every level in quads and keeps 2^(K+2).  A signal of 10^6 samples lost its fifth level to a launch of its own for want of it.
+    Every band against the oracle, then the reconstruction."""
+    from pypwt_amd import Wavelets
+    x = oracle.hash_input(shape, 8181)
+    w = Wavelets(x[0] if shape[0] == 1 else x, wname, levels, ndim=1)
+    assert w.levels == levels
+    w.forward()
+    ref = oracle.forward(x, wname, levels, ndim=1)
+    got = [w.coeffs[0]] + list(w.coeffs[1:])
+    for k, (g, r) in enumerate(zip(got, ref)):
+        assert np.abs(g.reshape(r.shape) - r).max() <= 2e-6 * (levels + 1) * max(float(np.abs(r).max()), 255.0), (wname, shape, k)
+    w.inverse()
+    assert np.abs(w.image.reshape(x.shape) - x).max() <= reconstruction_tol(x, wname, levels, ndim=1), (wname, shape)
