@@ -282,6 +282,27 @@ PDWT_DEVICE void stage_groups(int tid, const float* PDWT_RESTRICT row, int N, in
     }
 }
 
+// the same in PAIRS, for a row of N % 4 == 2 samples (the deepest level of a pyramid on rows of 2^(K+1) but not 2^(K+2) samples, round 5):
+// first2 and N are even, a pair never straddles the periodic wrap; dst holds the logical window like stage_groups'
+template <int NT, int UN>
+PDWT_DEVICE void stage_pairs(int tid, const float* PDWT_RESTRICT row, int N, int first2, int npairs, float* dst) {
+    const int w0 = true_mod(first2, N);
+    for (int base = tid; base < npairs; base += NT * UN) {
+        f32x2 v[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            int g = base + u * NT;
+            if (g >= npairs) g = npairs - 1;
+            v[u] = *reinterpret_cast<const f32x2*>(row + true_mod(w0 + 2 * g, N));
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int g = base + u * NT;
+            if (g < npairs) *reinterpret_cast<f32x2*>(dst + 2 * g) = v[u];
+        }
+    }
+}
+
 PDWT_DEVICE int floor4(int x) { return x - true_mod(x, 4); }
 
 template <int HLEN, int T0, int NT>
@@ -346,8 +367,13 @@ PDWT_DEVICE void dwt1_inv_fused_tile(const Inv1DFusedArgs& a, int bx, int row, f
         float* pa = ((K & 1) ? aP : aQ) + kInvFront;
         float* pd = ((K & 1) ? dP : dQ) + kInvFront;
         PDWT_FOR_SUBTHREADS(tid, NT) {
-            stage_groups<NT, 2>(tid, a.app + (long long)row * NK, NK, lo4, ng, pa);
-            stage_groups<NT, 2>(tid, a.det[K - 1] + (long long)row * NK, NK, lo4, ng, pd);
+            if (NK & 2) {  // (uniform) rows of the deepest level that are not whole quads
+                stage_pairs<NT, 4>(tid, a.app + (long long)row * NK, NK, lo4, 2 * ng, pa);
+                stage_pairs<NT, 4>(tid, a.det[K - 1] + (long long)row * NK, NK, lo4, 2 * ng, pd);
+            } else {
+                stage_groups<NT, 2>(tid, a.app + (long long)row * NK, NK, lo4, ng, pa);
+                stage_groups<NT, 2>(tid, a.det[K - 1] + (long long)row * NK, NK, lo4, ng, pd);
+            }
         }
     }
     PDWT_SYNC();

@@ -116,7 +116,7 @@ hipError_t launch_dwt1_fwd(const Fwd1DArgs& a, hipStream_t s);
 hipError_t launch_dwt1_inv(const Inv1DArgs& a, hipStream_t s);
 // K consecutive 1D levels in one launch (2^K must divide N0, even hlen); hipErrorNotSupported otherwise
 int dwt1_fused_max_levels(int hlen);
-bool dwt1_fused_supported(int hlen, int N0, int K, bool inverse);
+bool dwt1_fused_supported(int hlen, int N0, int K, bool strict);  // strict: rows of 2^(K+2) samples (the several-rows-per-wavefront kernels), else 2^(K+1)
 // batches of short rows: several rows per one-wavefront workgroup, any number of levels from one on (dwt1_rows_kernels.hpp)
 bool dwt1_rows_tail_applies(int rows, int N0, int K, int hlen);
 // up to three levels per launch in registers (dwt1_reg_kernels.hpp): even hlen <= 20, rows of >= 2048 samples

@@ -115,12 +115,12 @@ static hipError_t launch_rows_tail(const float* in, float* const* det, float* ou
 // ONE predicate for planner (plan.cpp) and launchers: K consecutive levels starting from a row of N0
 // samples can run fused iff hlen is even, 2^(K+2) divides N0 (every level length even, every band row
 // 16-B aligned) and N0 < 2^30 (32-bit tile arithmetic)
-// Rows of 2^(K+2) samples: every level is staged in whole quads.  The FORWARD stores its deepest level in pairs and takes rows of
-// 2^(K+1) samples (and whole quads of input) since round 5: a signal of 10^6 samples, five levels, ran REG1D / FUSED1D[1-4] + a level
-// launch for want of the stricter rule (17.4 us forward+inverse against 12.4 for 2^20).
-bool dwt1_fused_supported(int hlen, int N0, int K, bool inverse) {
+// Rows of 2^(K+1) samples (and whole quads of input) since round 5: the forward stores its deepest level in pairs, the inverse stages it
+// in pairs where its rows are not whole quads.  Until then 2^(K+2): a signal of 10^6 samples, five levels, ran FUSED1D[1-4] + a level
+// launch (17.4 us forward+inverse against 12.4 for 2^20).  (`inverse` = the several-rows-per-wavefront kernels' rule: 2^(K+2).)
+bool dwt1_fused_supported(int hlen, int N0, int K, bool strict) {
     return !(hlen & 1) && hlen >= 2 && hlen <= kMaxTaps && K >= 1 && K <= kMaxFusedLevels && (N0 & 3) == 0 &&
-           (N0 % (1 << (K + (inverse ? 2 : 1)))) == 0 && N0 < (1 << 30);
+           (N0 % (1 << (K + (strict ? 2 : 1)))) == 0 && N0 < (1 << 30);
 }
 
 // levels: K >= 2 consecutive levels starting from `in` of length N0 per row
@@ -174,12 +174,13 @@ hipError_t launch_dwt1_fwd_fused(const float* in, float* const* det, float* app,
 
 hipError_t launch_dwt1_inv_fused(const float* app, const float* const* det, float* out, int rows, int N0, int K,
                                  int hlen, const FilterBank& fb, hipStream_t s) {
-    if ((K < 2 && !dwt1_rows_tail_applies(rows, N0, K, hlen)) || !dwt1_fused_supported(hlen, N0, K, true)) return hipErrorNotSupported;
+    const bool rows_tail = dwt1_rows_tail_applies(rows, N0, K, hlen) && dwt1_fused_supported(hlen, N0, K, true);  // (those kernels: 2^(K+2))
+    if ((K < 2 && !rows_tail) || !dwt1_fused_supported(hlen, N0, K, false)) return hipErrorNotSupported;
     Inv1DFusedArgs a;
     a.app = app; a.out = out; a.rows = rows; a.N0 = N0; a.K = K;
     for (int k = 0; k < kMaxFusedLevels; k++) a.det[k] = k < K ? det[k] : nullptr;
     interleave(a.fb, fb);
-    if (dwt1_rows_tail_applies(rows, N0, K, hlen)) {
+    if (rows_tail) {
         const hipError_t e = launch_rows_tail(app, const_cast<float* const*>(det), out, rows, N0, K, hlen, true, fb, s);
         if (e != hipErrorNotSupported) return e;
     }

@@ -693,7 +693,7 @@ void build_schedule(pdwt_plan* p) {
                 }
                 // ... else runs of K >= 2 levels out of LDS (dwt1_fused_kernels.hpp), else level by level
                 K = fuse ? (L - l < cap ? L - l : cap) : 1;
-                while (K >= 2 && !dwt1_fused_supported(hlen, p->lc[l], K, dir != 0)) --K;
+                while (K >= 2 && !dwt1_fused_supported(hlen, p->lc[l], K, false)) --K;
                 // (a single level too where the several-rows-per-wavefront kernels take the batch: 131072 rows of 32 samples, db10 L1
                 // forward+inverse 209 us on the level kernels)
                 const bool rows1 = K < 2 && fuse && sizeof(real_t) == 4 && dwt1_fused_supported(hlen, p->lc[l], 1, true) &&

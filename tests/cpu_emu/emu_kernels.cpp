@@ -346,8 +346,8 @@ static void run_inv1d_fused(Inv1DFusedArgs a) {
 
 EMU_API int emu_dwt1_fused(int inverse, float* io, int rows, int N0, int K, const float* lo, const float* hi, int hlen,
                            int small, float* det, float* app) {
-    // (the forward stores its deepest level in pairs: rows of N0 % 2^(K+1) == 0; the inverse stages it in quads: 2^(K+2))
-    if ((hlen & 1) || (N0 & 3) || (N0 % (1 << (K + (inverse ? 2 : 1)))) || K > kMaxFusedLevels) return -2;
+    // (rows of N0 % 2^(K+1) == 0: the forward stores its deepest level in pairs, the inverse stages it in pairs where it must)
+    if ((hlen & 1) || (N0 & 3) || (N0 % (1 << (K + 1))) || K > kMaxFusedLevels) return -2;
     float* dptr[kMaxFusedLevels] = {};
     size_t off = 0;
     for (int k = 1; k <= K; k++) { dptr[k - 1] = det + off; off += (size_t)rows * (N0 >> k); }

@@ -1076,11 +1076,12 @@ def test_pyramid_on_rows_of_eight_but_not_sixteen(wname, shape, levels):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("wname,shape,levels", [("haar", (1, 1000000), 5), ("db4", (1, 1000000), 5), ("sym8", (1000, 1000), 2), ("db2", (3, 1504), 4),
-                                                ("db10", (64, 10000), 3), ("db4", (1, 1500000), 4)])
-def test_forward_1d_pyramid_on_rows_of_half_the_alignment(wname, shape, levels):
-    """Round 5: the fused 1D pyramid's FORWARD takes rows of 2^(K+1) samples (it stores its deepest level in pairs); the inverse stages
-    every level in quads and keeps 2^(K+2).  A signal of 10^6 samples lost its fifth level to a launch of its own for want of it.
-    Every band against the oracle, then the reconstruction."""
+                                                ("db10", (64, 10000), 3), ("db4", (1, 1500000), 4), ("db2", (1000, 200), 2), ("haar", (700, 96), 4), ("sym4", (700, 104), 2), ("haar", (300, 480), 4)])
+def test_1d_pyramid_on_rows_of_half_the_alignment(wname, shape, levels):
+    """Round 5: the fused 1D pyramid takes rows of 2^(K+1) samples, not 2^(K+2): the forward stores its deepest level in pairs, the
+    inverse stages it in pairs where its rows are not whole quads.  A signal of 10^6 samples lost its fifth level to a launch of its
+    own for want of it.  Long rows, short rows (four row tiles per workgroup), batches.  Every band against the oracle, then the
+    reconstruction."""
     from pypwt_amd import Wavelets
     x = oracle.hash_input(shape, 8181)
     w = Wavelets(x[0] if shape[0] == 1 else x, wname, levels, ndim=1)
