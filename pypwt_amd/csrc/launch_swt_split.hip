@@ -314,8 +314,11 @@ hipError_t try_launch_swt1_split(const SwtPassArgs& a, bool inverse, hipStream_t
     // stay ahead there (65536 rows of 64, three levels forward+inverse: db3 221 -> 125 us, db4 238 -> 156, db5 228 -> 148); from
     // 256 samples on the row kernels win (profiles/r04zl_swt1_short_rows.txt)
     if (a.Nc < 128) return hipErrorNotSupported;
-    // rows that are not whole quads: the stream kernels (one or two samples per work item), from 10 taps on
-    if (!a.along_y && (a.Nc & 3) && min_taps > 0 && a.hlen >= 10 && stream_route32(a.hlen, a.Nr, a.Nc, a.f, inverse, (long long)a.Nr * a.Nc, 10))
+    // rows that are not whole quads: the stream kernels (one or two samples per work item)
+    // (rows are filtered along x: the row COUNT does not bound the dilation -- one long row is Nr = 1)
+    // (1D, three levels forward | inverse, a row of 2^20 + 1 samples: sym8 44.8 | 46.1 -> 26.6 | 32.3 us, db10 52.5 | 53.5 -> 28.1 | 36.5, db20
+    // 86 | 88 -> 39 | 56; 10 taps: level | 7 % behind -- from 12 taps)
+    if (!a.along_y && (a.Nc & 3) && min_taps > 0 && a.hlen >= 12 && stream_route32(a.hlen, 1 << 30, a.Nc, a.f, inverse, (long long)a.Nr * a.Nc, 10))
         return stream_pass1d(a, inverse, s);
     if (a.along_y || min_taps <= 0 || (a.hlen & 1) || a.hlen < 4 || a.hlen < min_taps || a.hlen > kMaxTaps) return hipErrorNotSupported;
     if ((a.Nc & 3) || a.Nc < 16 || a.f < 1 || a.f >= a.Nc || (a.f != 1 && a.f != 2 && (a.f & 3))) return hipErrorNotSupported;

@@ -1093,3 +1093,24 @@ def test_1d_pyramid_on_rows_of_half_the_alignment(wname, shape, levels):
         assert np.abs(g.reshape(r.shape) - r).max() <= 2e-6 * (levels + 1) * max(float(np.abs(r).max()), 255.0), (wname, shape, k)
     w.inverse()
     assert np.abs(w.image.reshape(x.shape) - x).max() <= reconstruction_tol(x, wname, levels, ndim=1), (wname, shape)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("wname,shape,levels", [("sym8", (1, 100001), 3), ("db10", (1, 65538), 4), ("db20", (3, 5003), 2), ("db6", (1, 40001), 3)])
+def test_swt1_on_single_rows_that_are_not_whole_quads(wname, shape, levels):
+    """1D SWT of long rows whose length is not a multiple of 4 (ONE row included: the row count does not bound the dilation of a
+    transform along x): from 12 taps the stream kernels, one or two samples per work item.  Every band against the oracle, then the
+    reconstruction of soft-thresholded coefficients."""
+    from pypwt_amd import Wavelets
+    x = oracle.hash_input(shape, 6161)
+    w = Wavelets(x[0] if shape[0] == 1 else x, wname, levels, do_swt=1, ndim=1)
+    w.forward()
+    ref = oracle.forward(x, wname, w.levels, ndim=1, do_swt=1)
+    got = [w.coeffs[0]] + list(w.coeffs[1:])
+    for k, (g, r) in enumerate(zip(got, ref)):
+        assert np.abs(g.reshape(r.shape) - r).max() <= 2e-6 * (w.levels + 1) * max(float(np.abs(r).max()), 255.0), (wname, shape, k)
+    w.soft_threshold(5.0)
+    w.inverse()
+    thr = oracle.threshold(ref, x.shape, w.levels, "soft", 5.0, do_swt=1, ndim=1)
+    want = oracle.inverse(thr, x.shape, wname, w.levels, ndim=1, do_swt=1)
+    assert np.abs(w.image.reshape(want.shape) - want).max() <= 4e-6 * (1 + w.levels) * 255.0, (wname, shape)
