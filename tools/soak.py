@@ -128,7 +128,7 @@ def run(budget=None, max_cases=None, seed=1):
             B = int((1 << 20) // (r * c) * rng.choice([1, 1, 3])) + int(rng.integers(0, 5))
             done[kind] = done.get(kind, 0) + check(B, (r, c), str(rng.choice(short)), int(rng.integers(1, 5)), 1, rng, kind)
         elif kind in ("rows-1d", "rows-swt1"):   # batched 1D: many short rows, few long rows, few and many levels
-            n = int(rng.choice([64, 128, 256, 512, 1024, 2048, 4096, 16384, 65536, 1000, 96]))
+            n = int(rng.choice([64, 128, 256, 512, 1024, 2048, 4096, 16384, 65536, 1000, 96, 10000, 100000, 1000000, 1504, 6000, 44100]))  # (round 5: rows of 2^(K+1) but not 2^(K+2) samples)
             rows = max(1, int((1 << int(rng.integers(12, 23))) // n) + int(rng.integers(0, 3)))
             swt1 = 1 if kind == "rows-swt1" else 0
             done[kind] = done.get(kind, 0) + check(1, (rows, n), str(rng.choice(short)), int(rng.integers(1, 7 if not swt1 else 4)), swt1, rng, kind, ndim=1)
