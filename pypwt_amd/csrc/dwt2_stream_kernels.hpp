@@ -113,6 +113,20 @@ PDWT_DEVICE void dwt_stream_tile(const DwtStreamArgs& a, long long block) {
                 for (int i = 0; i < NC; ++i) acc[m][o].v[i] = zero;
         svec<NC> b0[R][P], b1[R][P];
         auto fetch = [&](svec<NC>(&b)[R][P]) {
+            if constexpr (!ALONG_Y && R % 2 == 0) {  // along x the stream is R consecutive samples: wide loads (swt_stream_kernels.hpp)
+                if (pos.p + R <= pos.n) {
+#pragma unroll
+                    for (int k = 0; k < P; ++k) {
+                        real_t run[R];
+                        stream_ld_run<R>(src[k] + pos.p, run);
+#pragma unroll
+                        for (int u = 0; u < R; ++u) b[u][k].v[0] = run[u];
+                    }
+                    pos.p += R;
+                    if (pos.p >= pos.n) pos.p -= pos.n;
+                    return;
+                }
+            }
 #pragma unroll
             for (int u = 0; u < R; ++u) {
                 const long long o = (long long)pos.p * in_pitch;

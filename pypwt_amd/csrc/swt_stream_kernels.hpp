@@ -74,6 +74,33 @@ PDWT_DEVICE void stream_st(real_t* p, const svec<NC>& s) {
     }
 }
 
+// R CONSECUTIVE samples of a row with wide loads at element alignment (a work item that streams single elements along x at
+// dilation 1 reads R of them per chunk: one 16-B load of floats, two of doubles, instead of R loads of one element at a lane stride
+// of R elements -- rocprofv3 on a 2047-column image showed the synthesis row launch, all 4-B loads, as the slowest of the four)
+template <int R>
+PDWT_DEVICE void stream_ld_run(const real_t* p, real_t (&out)[R]) {
+#ifdef PDWT_CPU_EMU
+    for (int i = 0; i < R; ++i) out[i] = p[i];
+#else
+    static_assert(R % 2 == 0, "pairs");
+    if constexpr (sizeof(real_t) == 4 && R % 4 == 0) {
+        typedef real_t v4u __attribute__((ext_vector_type(4), aligned(sizeof(real_t))));
+#pragma unroll
+        for (int i = 0; i < R; i += 4) {
+            const v4u v = *reinterpret_cast<const v4u*>(p + i);
+            out[i] = v.x; out[i + 1] = v.y; out[i + 2] = v.z; out[i + 3] = v.w;
+        }
+    } else {
+        typedef real_t v2u __attribute__((ext_vector_type(2), aligned(sizeof(real_t))));
+#pragma unroll
+        for (int i = 0; i < R; i += 2) {
+            const v2u v = *reinterpret_cast<const v2u*>(p + i);
+            out[i] = v.x; out[i + 1] = v.y;
+        }
+    }
+#endif
+}
+
 // where a work item stands: the element offset of its next input inside the plane (ALONG_Y: row index, wave-uniform; along x:
 // column index, per lane) and how it advances
 template <bool ALONG_Y>
@@ -169,6 +196,22 @@ PDWT_DEVICE void swt_stream_tile(const SwtStreamArgs& a, long long block) {
                 for (int i = 0; i < NC; ++i) acc[m][o].v[i] = zero;
         svec<NC> b0[R][P], b1[R][P];
         auto fetch = [&](svec<NC>(&b)[R][P]) {
+            if constexpr (!ALONG_Y && NC == 1 && R % 2 == 0) {
+                if (f == 1) {  // (uniform) R consecutive samples: wide loads, unless this lane's run crosses the periodic wrap
+                    if (pos.p + R <= pos.n) {
+#pragma unroll
+                        for (int k = 0; k < P; ++k) {
+                            real_t run[R];
+                            stream_ld_run<R>(src[k] + pos.p, run);
+#pragma unroll
+                            for (int u = 0; u < R; ++u) b[u][k].v[0] = run[u];
+                        }
+                        pos.p += R;
+                        if (pos.p >= pos.n) pos.p -= pos.n;
+                        return;
+                    }
+                }
+            }
 #pragma unroll
             for (int u = 0; u < R; ++u) {
                 const long long o = (long long)pos.p * pitch;
