@@ -323,6 +323,44 @@ def metric_name(config, desc, batch_per_gpu):
     return "Msamples/s, %s (%s)" % (desc, config)
 
 
+NORTH_STAR_FRAC = 0.70  # BASELINE.json: >= 70 % of the HBM roofline, 4096^2 fp32 db4 L4 forward + inverse, END TO END
+
+
+def target_record(e2e_frac, algorithmic_bytes_per_step, copy_floor_us):
+    """What the line is graded against, next to what it reached: the north-star fraction (end to end, not the dominant
+    kernel alone), the end-to-end fraction measured, and the fraction the step would reach if every one of its launches
+    were a flat copy of its own bytes (the bound of a one-launch-per-level schedule, measured in this run)."""
+    floor = None
+    if copy_floor_us and copy_floor_us > 0:
+        floor = algorithmic_bytes_per_step / (copy_floor_us * 1e-6) / 1e9 / HBM_PEAK_GBPS
+    return {"north_star_frac": NORTH_STAR_FRAC, "of": "end-to-end algorithmic bytes per step / step time / %.0f GB/s" % HBM_PEAK_GBPS,
+            "end_to_end_frac": e2e_frac, "launch_copy_floor_frac": floor, "met": bool(e2e_frac >= NORTH_STAR_FRAC)}
+
+
+def in_step_durations(kernels, step_us):
+    """The event pair around every launch of a step costs stream time (the in-step averages sum to more than the step):
+    spread the excess evenly over the launches and take it off -- `in_step_us` is what a launch takes INSIDE the pipelined
+    step (what rocprofv3 --kernel-trace shows), next to `isolated_us`, the same launch repeated back to back on its own."""
+    n = len(kernels)
+    total = sum(k["avg_us"] for k in kernels)
+    overhead = max(0.0, (total - step_us) / n) if n and step_us else 0.0
+    for k in kernels:
+        k["in_step_us"] = max(k["avg_us"] - overhead, 0.0)
+    return overhead
+
+
+def judged_duration(k):
+    """The duration a launch's roofline fraction is computed from: the isolated timing, unless that is more than 10 % shorter
+    than what the launch takes in the step (planes that fit the Infinity Cache only when the launch runs alone: cfg4's fused
+    SWT inverse, 35.8 us alone against 42.7 in the step)."""
+    iso, ins = k.get("isolated_us"), k.get("in_step_us")
+    if iso is None:
+        return ins if ins is not None else k["avg_us"], "in_step"
+    if ins is not None and iso < 0.9 * ins:
+        return ins, "in_step"
+    return iso, "isolated"
+
+
 def median(values):
     v = sorted(values)
     n = len(v)
@@ -527,7 +565,7 @@ def other_config(name, device, steps):
             plan.synchronize()
         regions = [timed_steps(step, plan.synchronize, steps) for _ in range(3)]
         step_s = median(regions)
-        kernels, roofline, step_names = kernel_profile(plan, step, cfg, name, 1, steps)
+        kernels, roofline, step_names = kernel_profile(plan, step, cfg, name, 1, steps, step_us=step_s * 1e6)
         thr_separate = any(n.startswith("soft_threshold") for n in step_names)
         bps = algorithmic_bytes_per_sample(cfg, threshold_separate=thr_separate)
         e2e_bytes = bps * Nr * Nc
@@ -535,9 +573,12 @@ def other_config(name, device, steps):
                "Msamples_s": Nr * Nc / step_s / 1e6, "algorithmic_bytes_per_sample": bps,
                "frac_of_hbm_peak": e2e_bytes / step_s / 1e9 / HBM_PEAK_GBPS,
                "dominant_kernel": roofline.get("kernel"), "dominant_kernel_us": roofline.get("avg_us"),
+               "dominant_kernel_us_basis": roofline.get("avg_us_basis"), "dominant_kernel_isolated_us": roofline.get("isolated_us"),
+               "dominant_kernel_in_step_us": roofline.get("in_step_us"),
                "dominant_kernel_frac_of_hbm_peak": roofline.get("frac"), "copy_ceiling_GBps": roofline.get("copy_ceiling_GBps"),
                "copy_floor_us_per_step": roofline.get("step_copy_floor_us"),
-               "kernels": [{"kernel": k["kernel"], "avg_us": k["avg_us"]} for k in kernels[:8]]}
+               "kernels": [{"kernel": k["kernel"], "avg_us": k["avg_us"], "in_step_us": k.get("in_step_us"),
+                            "isolated_us": k.get("isolated_us")} for k in kernels[:8]]}
         if roofline.get("step_copy_floor_us"):
             rec["copy_floor_over_step"] = roofline["step_copy_floor_us"] * 1e-6 / step_s
         return rec
@@ -545,7 +586,43 @@ def other_config(name, device, steps):
         plan.cleanup()
 
 
-def kernel_profile(plan, step, cfg, config_name, B, steps):
+LONG_FILTER_PLANS = (("db20", 2048, 2048, 5), ("db20", 4096, 4096, 3))  # what the reference itself benchmarks: haar and db20 (test/benchmark.py:20-38)
+
+
+def long_filters(device, steps=20):
+    """The long-filter plans of VERDICT round 5, driver-timed: forward and inverse of db20 on 2048^2 (five levels) and
+    4096^2 (three levels), pipelined, median of three regions of `steps` calls; which kernel family served every launch."""
+    from pypwt_amd import BatchedWavelets
+    recs = []
+    for wname, Nr, Nc, L in LONG_FILTER_PLANS:
+        plan = BatchedWavelets(1, Nr, Nc, wname, L, device=device)
+        try:
+            plan.fill_hash(20240 + 3, 255.0)
+
+            def both():
+                plan.forward()
+                plan.inverse()
+            for _ in range(5):
+                both()
+            plan.synchronize()
+            fwd = median([timed_steps(plan.forward, plan.synchronize, steps) for _ in range(3)])
+            fi = median([timed_steps(both, plan.synchronize, steps) for _ in range(3)])
+            plan.enable_kernel_timing(True)
+            plan.reset_kernel_times()
+            both()
+            fams = list(zip([n for n, _ in plan.kernel_times()], plan.kernel_families()))
+            plan.enable_kernel_timing(False)
+            bps = 16.0  # input read + coefficients written, coefficients read + image written
+            recs.append({"workload": "%dx%d fp32 %s L%d" % (Nr, Nc, wname, plan.levels), "forward_us": fwd * 1e6,
+                         "forward_inverse_us": fi * 1e6, "inverse_us": (fi - fwd) * 1e6,
+                         "frac_of_hbm_peak": bps * Nr * Nc / fi / 1e9 / HBM_PEAK_GBPS,
+                         "launches": ["%s:%s" % (n, f) if f else n for n, f in fams]})
+        finally:
+            plan.cleanup()
+    return recs
+
+
+def kernel_profile(plan, step, cfg, config_name, B, steps, step_us=None):
     """Per-launch shares of one step (HIP events on the plan's stream), the dominant kernel re-timed alone, its
     roofline and the copy ceiling measured beside it.  Returns (kernels, roofline, names of one step's launches)."""
     Nr, Nc, wname, L, swt, ndim, beta, desc = cfg
@@ -576,6 +653,7 @@ def kernel_profile(plan, step, cfg, config_name, B, steps):
         kernels.append({"kernel": label, "avg_us": avg_ms * 1e3, "algorithmic_bytes": abytes,
                         "GBps": abytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0})
     kernels.sort(key=lambda k: -k["avg_us"])
+    event_overhead_us = in_step_durations(kernels, step_us)
     # The per-launch events above cost ~2.5 us of stream time each (the in-step durations sum to more than the step)
     # and the first launch behind an event absorbs its latency, so they RANK launches of similar length unreliably
     # (round 3 named the second-longest kernel).  The three longest candidates are therefore timed again on their
@@ -588,12 +666,13 @@ def kernel_profile(plan, step, cfg, config_name, B, steps):
         if lvl is not None:
             k["isolated_us"] = plan.time_level(lvl[0], inverse=lvl[1], reps=max(steps, 20))
     plan.inverse()
-    dom = max(kernels[:3], key=lambda k: k.get("isolated_us", k["avg_us"]))
-    dom_us = dom.get("isolated_us", dom["avg_us"])
+    dom = max(kernels[:3], key=lambda k: judged_duration(k)[0])
+    dom_us, dom_basis = judged_duration(dom)
     dom_gbps = dom["algorithmic_bytes"] / (dom_us * 1e-6) / 1e9 if dom_us > 0 else 0.0
     roofline = {"bound": "hbm", "achieved": dom_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": dom_gbps / HBM_PEAK_GBPS, "traffic": None, "kernel": dom["kernel"],
-                "avg_us": dom_us, "avg_us_in_step_with_event_overhead": dom["avg_us"],
+                "avg_us": dom_us, "avg_us_basis": dom_basis, "isolated_us": dom.get("isolated_us"), "in_step_us": dom.get("in_step_us"),
+                "avg_us_in_step_with_event_overhead": dom["avg_us"], "event_overhead_us_per_launch": event_overhead_us,
                 "algorithmic_bytes_per_launch": dom["algorithmic_bytes"]}
     # The measured ceiling next to the spec peak: a plain 16-B grid-stride copy that moves the dominant launch's
     # bytes (half read, half written) out of this plan's own buffers, in this run, in the same cache state
@@ -842,7 +921,7 @@ def main():
     samples_per_step = total_images * Nr * Nc
     value = samples_per_step / step_s / 1e6
 
-    kernels, roofline, step_names = kernel_profile(plan, step, cfg, args.config, B, args.steps)
+    kernels, roofline, step_names = kernel_profile(plan, step, cfg, args.config, B, args.steps, step_us=step_s * 1e6)
     # the soft threshold costs bytes only when it ran as its own sweep (a `soft_threshold` launch in the step)
     thr_separate = any(n.startswith("soft_threshold") for n in step_names)
     bps = algorithmic_bytes_per_sample(cfg, threshold_separate=thr_separate)
@@ -879,6 +958,8 @@ def main():
 
         "roofline": roofline, "end_to_end": e2e, "kernels": kernels[:12],
     }
+    if args.config in ("cfg2", "cfg5"):  # the configurations the north star is stated on
+        out["target"] = target_record(e2e["frac_of_hbm_peak"], e2e_bytes, roofline.get("step_copy_floor_us"))
     if alone_s is not None:
         one = B * Nr * Nc / alone_s / 1e6
         out["scaling_reference"] = {"one_gpu_same_workload_Msamples_s": one, "one_gpu_same_workload_ms_per_step": alone_s * 1e3,
@@ -913,6 +994,10 @@ def main():
                     extra["configs"][other] = other_config(other, local_rank, 20)
                 except Exception as e:
                     extra["configs"][other] = {"error": repr(e)}
+            try:
+                extra["long_filters"] = long_filters(local_rank)
+            except Exception as e:
+                extra["long_filters"] = {"error": repr(e)}
             try:
                 extra["beyond_infinity_cache"] = beyond_mall(cfg, local_rank, args.steps)
             except Exception as e:

@@ -45,6 +45,7 @@ SOURCES = [
     "launch_dwt2_chain.hip",
     "launch_dwt2_wave.hip",
     "launch_dwt2_ring.hip",
+    "launch_dwt2_long.hip",
     "launch_dwt1.hip",
     "launch_dwt1_fused.hip",
     "launch_dwt1_reg.hip",

@@ -20,7 +20,7 @@ enum EwOp { EW_SOFT = 0, EW_HARD = 1, EW_LINF = 2, EW_SCALE = 3 };
 // third thread calling pdwt_set_tuning -- cannot change each other's kernel choice in mid-transform; with no active set
 // (direct calls of the launchers: tools, emulation) the process-wide values apply.
 struct Tuning {
-    int wave_min_log2, lds_max_log2, swt_split_fwd, swt_split_inv, dwt_split_fwd, dwt_split_inv, ring_min_log2;
+    int wave_min_log2, lds_max_log2, swt_split_fwd, swt_split_inv, dwt_split_fwd, dwt_split_inv, ring_min_log2, long_fwd, long_inv;
     int wave2, swt_fused, chain, reg1d;  // read by build_schedule: a clone rebuilds its launch lists from its source's values
 };
 Tuning current_tuning();                  // the process-wide values now
@@ -51,6 +51,12 @@ hipError_t try_launch_dwt2_inv_wave(const Inv2DArgs& a, int batch, hipStream_t s
 // forces the rows per wavefront
 hipError_t try_launch_dwt2_fwd_ring(const Fwd2DArgs& a, int batch, hipStream_t s, int cpl = 4, int seg_hint = 0);
 hipError_t try_launch_dwt2_inv_ring(const Inv2DArgs& a, int batch, hipStream_t s, int cpl = 4, int seg_hint = 0);
+// strip-streaming kernels for long filters (dwt2_long_kernels.hpp): even hlen 10-40, even sides, rows of whole 16-B groups; seg_hint > 0
+// forces the rows per segment
+hipError_t try_launch_dwt2_fwd_long(const Fwd2DArgs& a, int batch, hipStream_t s, int seg_hint = 0);
+hipError_t try_launch_dwt2_inv_long(const Inv2DArgs& a, int batch, hipStream_t s, int seg_hint = 0);
+int set_long_min_taps(int inverse, int taps);  // shortest filter on them (0: never; 100 + n: n taps at every size they take); returns the previous value
+int get_long_min_taps(int inverse);
 int set_ring_min_log2(int value);  // 2D DWT levels of at least 2^value samples with 12-20 taps run on them (63 = never; below the default: 10-20 taps, tests)
 int get_ring_min_log2();
 int set_wave_min_log2(int value);  // returns the previous threshold

@@ -161,6 +161,37 @@ static bool ring_kernels_for(long long samples, int hlen, int Nc, bool inverse) 
     return (hlen == 12 || hlen == 16) && Nc >= 1024;
 }
 
+// Strip-streaming kernels for long filters (dwt2_long_kernels.hpp, round 6).  A long filter is arithmetic-bound: the tiles
+// re-filter their halo (40 taps, 32 x 8 inverse tile: 1.75x the column arithmetic, 6.3x the staging) where a strip walks down
+// the level and filters every row once.  Inside plans (tools/long_ab.py, profiles/r06_long_ab.txt; three levels, forward /
+// inverse us, tiles -> strips):
+//     db20  4096^2        92 / 113 ->  71 /  73      4 images   349 / 469 -> 246 / 258     16 images  1254 / 2052 -> 954 / 930
+//     db16  4096^2        65 /  92 ->  57 /  64                 272 / 373 -> 203 / 227
+//     db13  4096^2        51 /  63 ->  53 /  56 (forced)        204 / 252 -> 185 / 201
+//     db10  4096^2        45 /  59 ->  49 /  51 (forced)        186 / 243 -> 162 / 184                 717 /  985 -> 639 / 720
+//     sym8  (16 taps)     41 /  45 ->  44 /  47 (forced)        155 / 157 -> 158 / 168: tiles and ring kernels stay
+//     db20  2048^2 L5     38 /  45 ->  53 /  56 with every level forced; level 1 of the inverse alone: 45 -> 40 (db13: 28 -> 30)
+// Rules: from 20 taps on (tuning keys "long_fwd" / "long_inv": the shortest filter; 0 = never; 100 + n = n taps at every size
+// the kernels take: tests); the inverse from 2^24 samples per launch and, from 30 taps, from 2^22; the forward from 2^25
+// samples (batches) and, from 30 taps, from 2^24.
+constexpr int kLongFwdDefault = 20, kLongInvDefault = 20;
+static std::atomic<int>& long_min_taps(bool inverse) {
+    static std::atomic<int> v[2] = {{kLongFwdDefault}, {kLongInvDefault}};
+    return v[inverse ? 1 : 0];
+}
+int set_long_min_taps(int inverse, int taps) { return long_min_taps(inverse != 0).exchange(taps < 0 ? 0 : taps); }
+int get_long_min_taps(int inverse) { return long_min_taps(inverse != 0).load(std::memory_order_relaxed); }
+static bool long_kernels_for(long long samples, int hlen, bool inverse) {
+    if (sizeof(real_t) != 4) return false;
+    const int m = g_active_tuning ? (inverse ? g_active_tuning->long_inv : g_active_tuning->long_fwd) : get_long_min_taps(inverse);
+    if (m <= 0) return false;
+    if (m >= 100) return hlen >= m - 100;  // forced: every size
+    if (hlen < m) return false;
+    const long long all = inverse ? (1LL << 24) : (1LL << 25);       // every length from m on
+    const long long longest = inverse ? (1LL << 22) : (1LL << 24);   // 30 taps and more
+    return samples >= all || (hlen >= 30 && samples >= longest);
+}
+
 static int eff_wave_min_log2() { return g_active_tuning ? g_active_tuning->wave_min_log2 : wave_min_log2().load(std::memory_order_relaxed); }
 static bool wave_kernels_for(long long samples) {
     const int m = eff_wave_min_log2();
@@ -217,6 +248,8 @@ Tuning current_tuning() {
     t.dwt_split_fwd = get_dwt_split_min(0);
     t.dwt_split_inv = get_dwt_split_min(1);
     t.ring_min_log2 = get_ring_min_log2();
+    t.long_fwd = get_long_min_taps(0);
+    t.long_inv = get_long_min_taps(1);
     t.wave2 = get_wave2_enabled();
     t.swt_fused = get_swt_fused_enabled();
     t.chain = get_chain_enabled();
@@ -225,6 +258,10 @@ Tuning current_tuning() {
 }
 
 hipError_t launch_dwt2_fwd(const Fwd2DArgs& a, int batch, hipStream_t s) {
+    if (long_kernels_for((long long)batch * a.Nr * a.Nc, a.hlen, false)) {
+        const hipError_t e = try_launch_dwt2_fwd_long(a, batch, s);
+        if (took(e, "long")) return e;
+    }
     if (ring_kernels_for((long long)batch * a.Nr * a.Nc, a.hlen, a.Nc, false)) {
         const hipError_t e = try_launch_dwt2_fwd_ring(a, batch, s);
         if (took(e, "ring")) return e;
@@ -265,6 +302,10 @@ hipError_t launch_dwt2_inv(const Inv2DArgs& a, int batch, hipStream_t s) {
     // 23.6 us) and loses slightly to the LDS tiles on a batch streamed from HBM (8 x 4096^2: 224-232 vs 219 us,
     // profiles/r02b_wbench_b8.txt): 2^26 samples and beyond go to the tiles
     const long long samples = (long long)batch * a.Nr * a.Nc;
+    if (long_kernels_for(samples, a.hlen, true)) {
+        const hipError_t e = try_launch_dwt2_inv_long(a, batch, s);
+        if (took(e, "long")) return e;
+    }
     if (ring_kernels_for(samples, a.hlen, a.Nc, true)) {
         const hipError_t e = try_launch_dwt2_inv_ring(a, batch, s);
         if (took(e, "ring")) return e;

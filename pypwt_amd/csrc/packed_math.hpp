@@ -51,6 +51,20 @@ static __device__ __forceinline__ v2f fma2_ty(v2f p, v2f t, v2f acc) {
     asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(p), "s"(t));
     return acc;
 }
+// the same with the tap pair in VECTOR registers (dwt2_long_kernels.hpp: 84 tap SGPRs beside the kernel's pointers and sizes
+// spill; a wavefront that may use 256 VGPRs keeps the table there instead)
+static __device__ __forceinline__ v2f fma2_bx_v(v2f p, v2f t, v2f acc) {
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(p), "v"(t));
+    return acc;
+}
+static __device__ __forceinline__ v2f fma2_by_v(v2f p, v2f t, v2f acc) {
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(p), "v"(t));
+    return acc;
+}
+static __device__ __forceinline__ v2f in_vgprs(v2f t) {  // a uniform value the compiler must hold in vector registers from here on
+    asm volatile("" : "+v"(t));
+    return t;
+}
 static __device__ __forceinline__ v2f fma2_s(v2f p, v2f t, v2f acc) {  // element-wise, the tap pair from SGPRs
     asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(p), "s"(t));
     return acc;
@@ -61,6 +75,9 @@ static PDWT_DEVICE v2f fma2_by(v2f p, v2f t, v2f acc) { return fma2(bc(p.y), t, 
 static PDWT_DEVICE v2f fma2_tx(v2f p, v2f t, v2f acc) { return fma2(p, bc(t.x), acc); }
 static PDWT_DEVICE v2f fma2_ty(v2f p, v2f t, v2f acc) { return fma2(p, bc(t.y), acc); }
 static PDWT_DEVICE v2f fma2_s(v2f p, v2f t, v2f acc) { return fma2(p, t, acc); }
+static PDWT_DEVICE v2f fma2_bx_v(v2f p, v2f t, v2f acc) { return fma2(bc(p.x), t, acc); }
+static PDWT_DEVICE v2f fma2_by_v(v2f p, v2f t, v2f acc) { return fma2(bc(p.y), t, acc); }
+static PDWT_DEVICE v2f in_vgprs(v2f t) { return t; }
 #endif
 
 // Reads 16 B from LDS as ONE ds_read_b128 (256 B/clk) even when only some components are used

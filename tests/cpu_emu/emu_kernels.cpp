@@ -22,6 +22,7 @@
 #include "../../pypwt_amd/csrc/dwt2_strip_kernels.hpp"
 #include "../../pypwt_amd/csrc/dwt2_wave_kernels.hpp"
 #include "../../pypwt_amd/csrc/dwt2_ring_kernels.hpp"
+#include "../../pypwt_amd/csrc/dwt2_long_kernels.hpp"
 #include "../../pypwt_amd/csrc/nonsep_kernels.hpp"
 #include "../../pypwt_amd/csrc/swt_kernels.hpp"
 #include "../../pypwt_amd/csrc/swt_split_kernels.hpp"
@@ -1213,4 +1214,91 @@ EMU_API int emu_dwt2_stream(int inverse, float* io, int batch, int Nr, int Nc, c
     else if (R == 2) { if (two) run_dwt_stream<2, 2>(inverse != 0, io, batch, Nr, Nc, fb, hlen, A, H, V, D, tmp.data()); else run_dwt_stream<1, 2>(inverse != 0, io, batch, Nr, Nc, fb, hlen, A, H, V, D, tmp.data()); }
     else return -1;
     return 0;
+}
+
+// ------------------------------------------------------------------ strip-streaming level kernels for long filters (dwt2_long_kernels.hpp)
+// shape: 0 = <64, 16, 256, KB 2 (inverse 4), M 4, XB 1> (a launch shape), 1 = <32, 8, 128, 2 (4), 2, 2>, 2 = <16, 4, 64, 4, 4, 1>,
+// 3 = <64, 16, 512, 4, 2, 2>
+template <int HLEN, int TXC, int TY, int NT, int KB, int M, int XB>
+static void run_fwd_long(FwdLongArgs a, int batch, int seg) {
+    using G = FwdLongGeom<HLEN, TXC, TY>;
+    a.strips = cdiv(a.Nc2, TXC);
+    a.seg = cdiv(seg < 1 ? a.Nr2 : seg, TY) * TY;
+    a.segs = cdiv(a.Nr2, a.seg);
+    std::vector<float> lds(G::LDS_REALS, NAN);
+    const int chunk = (a.strips * a.segs + 7) / 8;
+    for (int bz = 0; bz < batch; bz++)
+        for (int b = 0; b < 8 * chunk; b++) {
+            int strip, sg;
+            if (!xcd_tile(b, a.strips, a.segs, strip, sg)) continue;
+            std::fill(lds.begin(), lds.end(), NAN);  // a workgroup never reads what another one left
+            dwt2_fwd_long_wg<HLEN, TXC, TY, NT, KB, M, XB>(a, strip, sg, bz, lds.data());
+        }
+}
+
+// Nr, Nc even, Nc % 4 == 0, Nr >= 2 TY of the shape; seg = output rows per segment (rounded up to whole steps; < 1: one segment)
+EMU_API int emu_dwt2_fwd_long(const float* in, int batch, int Nr, int Nc, const float* lo, const float* hi, int hlen, int seg,
+                              int shape, float* A, float* H, float* V, float* D) {
+    if ((hlen & 1) || hlen < kLongMinHlen || hlen > kMaxTaps || (Nr & 1) || (Nc & 3)) return -1;
+    const int ty = shape == 1 ? 8 : (shape == 2 ? 4 : 16);
+    if (Nr < 2 * ty) return -2;
+    FwdLongArgs a;
+    a.in = in; a.A = A; a.H = H; a.V = V; a.D = D;
+    a.Nr = Nr; a.Nc = Nc; a.Nr2 = Nr / 2; a.Nc2 = Nc / 2;
+    a.in_bstride = (long long)Nr * Nc; a.out_bstride = (long long)a.Nr2 * a.Nc2;
+    interleave_bank(a.fb, lo, hi, hlen);
+    switch (hlen) {
+#define X(h) case h:                                                            \
+        if (shape == 0) run_fwd_long<h, 64, 16, 256, 2, 4, 1>(a, batch, seg);    \
+        else if (shape == 1) run_fwd_long<h, 32, 8, 128, 2, 2, 2>(a, batch, seg); \
+        else if (shape == 2) run_fwd_long<h, 16, 4, 64, 4, 4, 1>(a, batch, seg);  \
+        else run_fwd_long<h, 64, 16, 512, 4, 2, 2>(a, batch, seg);               \
+        return 0;
+        X(10) X(12) X(14) X(16) X(18) X(20) X(22) X(24) X(26) X(28) X(30) X(32) X(34) X(36) X(38) X(40)
+#undef X
+    }
+    return -1;
+}
+
+template <int HLEN, int TXC, int TY, int NT, int KB, int M, int XB>
+static void run_inv_long(InvLongArgs a, int batch, int seg, const float* lo, const float* hi) {
+    using G = InvLongGeom<HLEN, TXC, TY>;
+    a.strips = cdiv(a.Ncc, TXC);
+    a.seg = cdiv(seg < 1 ? a.Nrc : seg, TY) * TY;
+    a.segs = cdiv(a.Nrc, a.seg);
+    long_syn_tables<HLEN>(a, lo, hi);
+    std::vector<float> lds(G::LDS_REALS, NAN);
+    const int chunk = (a.strips * a.segs + 7) / 8;
+    for (int bz = 0; bz < batch; bz++)
+        for (int b = 0; b < 8 * chunk; b++) {
+            int strip, sg;
+            if (!xcd_tile(b, a.strips, a.segs, strip, sg)) continue;
+            std::fill(lds.begin(), lds.end(), NAN);
+            dwt2_inv_long_wg<HLEN, TXC, TY, NT, KB, M, XB>(a, strip, sg, bz, lds.data());
+        }
+}
+
+// Ncc % 4 == 0, Nc == 2 Ncc, Nr == 2 Nrc, Nrc >= TY of the shape; seg = coefficient rows per segment
+EMU_API int emu_dwt2_inv_long(const float* A, const float* H, const float* V, const float* D, int batch, int Nrc, int Ncc,
+                              int Nr, int Nc, const float* lo, const float* hi, int hlen, int seg, int shape, float* out) {
+    if ((hlen & 1) || hlen < kLongMinHlen || hlen > kMaxTaps || (Ncc & 3) || Nc != 2 * Ncc || Nr != 2 * Nrc) return -1;
+    const int ty = shape == 1 ? 8 : (shape == 2 ? 4 : 16);
+    if (Nrc < ty) return -2;
+    InvLongArgs a;
+    a.A = A; a.H = H; a.V = V; a.D = D; a.out = out;
+    a.Nrc = Nrc; a.Ncc = Ncc; a.Nr = Nr; a.Nc = Nc;
+    a.in_bstride = (long long)Nrc * Ncc; a.out_bstride = (long long)Nr * Nc;
+    std::vector<float> plo(kMaxTaps, 0.f), phi(kMaxTaps, 0.f);
+    for (int i = 0; i < hlen; i++) { plo[i] = lo[i]; phi[i] = hi[i]; }
+    switch (hlen) {
+#define X(h) case h:                                                            \
+        if (shape == 0) run_inv_long<h, 64, 16, 256, 4, 4, 1>(a, batch, seg, plo.data(), phi.data());    \
+        else if (shape == 1) run_inv_long<h, 32, 8, 128, 4, 2, 2>(a, batch, seg, plo.data(), phi.data()); \
+        else if (shape == 2) run_inv_long<h, 16, 4, 64, 4, 4, 1>(a, batch, seg, plo.data(), phi.data());  \
+        else run_inv_long<h, 64, 16, 512, 8, 2, 2>(a, batch, seg, plo.data(), phi.data());               \
+        return 0;
+        X(10) X(12) X(14) X(16) X(18) X(20) X(22) X(24) X(26) X(28) X(30) X(32) X(34) X(36) X(38) X(40)
+#undef X
+    }
+    return -1;
 }

@@ -6,7 +6,8 @@ CASES = [
     # ---- 2D DWT, level launches: LDS tiles / wave kernels / register ring / generic
     ("dwt2", "db4", (4096, 4096), 1, 1, "f32"),      # one 4096^2 level, 8 taps: tiles
     ("dwt2", "db4", (2048, 2048), 1, 1, "f32"),      # exactly 2^22 samples: wave kernels
-    ("dwt2", "db10", (2048, 2048), 1, 1, "f32"),     # long filter: tiles
+    ("dwt2", "db10", (2048, 2048), 1, 1, "f32"),     # long filter, 2^22 samples: tiles
+    ("dwt2", "db20", (4096, 4096), 1, 1, "f32"),     # 40 taps, 2^24 samples: strip-streaming kernels in both directions
     ("dwt2", "sym8", (2048, 4096), 1, 4, "f32"),     # 2^25 samples, 16 taps: register ring
     ("dwt2", "db6", (2048, 4096), 1, 4, "f32"),      # 12 taps: register ring
     ("dwt2", "db7", (2048, 4096), 1, 4, "f32"),      # 14 taps: stays on the tiles

@@ -160,3 +160,37 @@ def test_force_dist_runs_the_collective_code_with_one_rank():
     assert r.returncode == 0, r.stderr[-2000:]
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
     assert out["n_gpus"] == 1 and out["ms_per_step"] >= 0.9
+
+
+def test_target_and_in_step_rules_of_the_line():
+    """VERDICT round 5, task 2: the line says what it is graded against (0.70 END TO END, not the dominant kernel alone) and
+    does not price a launch by an isolated timing that its in-step duration contradicts."""
+    import bench
+    t = bench.target_record(0.47, 268435456.0, 52.5)
+    assert t["north_star_frac"] == 0.70 and t["met"] is False and abs(t["end_to_end_frac"] - 0.47) < 1e-12
+    assert abs(t["launch_copy_floor_frac"] - 268435456.0 / 52.5e-6 / 8.0e12) < 1e-9  # 0.64: the six-launch schedule's bound
+    assert bench.target_record(0.71, 1.0, None)["met"] is True and bench.target_record(0.71, 1.0, None)["launch_copy_floor_frac"] is None
+    # six launches whose event-timed averages sum to 15 us more than the 71.3-us step: 2.5 us of event overhead each
+    ks = [{"kernel": "k%d" % i, "avg_us": a} for i, a in enumerate([24.1, 24.6, 10.3, 11.2, 7.9, 8.2])]
+    ovh = bench.in_step_durations(ks, 71.3)
+    assert abs(ovh - 2.5) < 1e-9 and abs(ks[0]["in_step_us"] - 21.6) < 1e-9
+    assert abs(sum(k["in_step_us"] for k in ks) - 71.3) < 1e-9
+    # cfg4's fused inverse: 35.8 us alone, 42.7 in the step -> the in-step figure is the judged one; cfg2's level 1 keeps the isolated one
+    assert bench.judged_duration({"avg_us": 45.2, "in_step_us": 42.7, "isolated_us": 35.8}) == (42.7, "in_step")
+    assert bench.judged_duration({"avg_us": 24.1, "in_step_us": 21.6, "isolated_us": 21.63}) == (21.63, "isolated")
+    assert bench.judged_duration({"avg_us": 9.0, "in_step_us": 6.5}) == (6.5, "in_step")
+    assert [p[0] for p in bench.LONG_FILTER_PLANS] == ["db20", "db20"] and bench.LONG_FILTER_PLANS[1][1:] == (4096, 4096, 3)
+    src = open(bench.__file__).read()
+    assert 'out["target"] = target_record(' in src and 'extra["long_filters"] = long_filters(' in src
+
+
+def test_dry_run_eight_ranks_is_the_cfg5_shard():
+    """The first real SCALE run must not trip on plumbing: eight ranks (gloo, dry run), 128 images per GPU and step."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--dry-run"],
+                       capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["scaling"] == "weak"
+    assert out["config"]["config"] == "cfg5" and out["config"]["images_per_step"] == 1024 and out["config"]["shard_rank0"] == [0, 128]

@@ -1073,3 +1073,67 @@ def test_emu_dwt2_ring_batch_and_custom_filter():
         for b in range(B):
             ref = oracle.inverse([o[b] for o in outs], (nr, nc), "sym8", 1, ndim=2, filt=(16, lo, hi, lo, hi))
             assert np.abs(rec[b] - ref).max() <= 4 * _tol(ref)
+
+
+# ----------------------------------------------------------------------------- strip-streaming kernels for long filters
+# (dwt2_long_kernels.hpp: a workgroup walks down a strip of coefficient columns, the row-filtered history in a linear LDS
+# buffer whose last rows are carried to its top between steps, both passes register-blocked).  shape = template instance,
+# see tests/cpu_emu/emu_kernels.cpp; seg = rows per segment (0: one segment).
+LONG_WNAMES = ["db5", "db8", "db10", "db11", "db12", "db13", "db14", "db15", "db16", "db17", "db18", "db19", "db20", "sym20", "coif5",
+               "bior6.8"]
+LONG_SHAPES = [(64, 256, 0), (96, 128, 16), (48, 64, 5), (40, 72, 16), (32, 264, 8), (32, 24, 2), (200, 516, 32), (36, 24, 100)]
+
+
+@pytest.mark.parametrize("wname", LONG_WNAMES)
+def test_emu_dwt2_long_fwd(wname):
+    hlen, dlo, dhi, rlo, rhi = oracle.filters(wname)
+    assert 10 <= hlen <= 40 and hlen % 2 == 0
+    for si, (nr, nc, seg) in enumerate(LONG_SHAPES):
+        x = oracle.hash_input((nr, nc), 7100 + si)
+        ref = oracle.forward(x, wname, 1, ndim=2)
+        for shape in range(4):
+            outs = [np.full((nr // 2, nc // 2), np.nan, dtype=np.float32) for _ in range(4)]
+            rc = lib().emu_dwt2_fwd_long(P(x), 1, nr, nc, P(dlo), P(dhi), hlen, seg, shape, *[P(o) for o in outs])
+            assert rc == 0, (wname, nr, nc, shape)
+            for got, want in zip(outs, ref):
+                assert np.isfinite(got).all(), (wname, nr, nc, shape)
+                assert np.abs(got - want).max() <= _tol(want), (wname, nr, nc, seg, shape)
+
+
+@pytest.mark.parametrize("wname", LONG_WNAMES)
+def test_emu_dwt2_long_inv(wname):
+    hlen, dlo, dhi, rlo, rhi = oracle.filters(wname)
+    for si, (nr, nc, seg) in enumerate(LONG_SHAPES):
+        r2, c2 = nr // 2, nc // 2
+        if c2 % 4:
+            continue
+        bands = [oracle.hash_input((r2, c2), 7900 + 7 * si + b, 2.0) - 1.0 for b in range(4)]
+        ref = oracle.inverse(bands, (nr, nc), wname, 1, ndim=2)
+        for shape in range(4):
+            out = np.full((nr, nc), np.nan, dtype=np.float32)
+            rc = lib().emu_dwt2_inv_long(*[P(b) for b in bands], 1, r2, c2, nr, nc, P(rlo), P(rhi), hlen, seg, shape, P(out))
+            assert rc == 0, (wname, nr, nc, shape)
+            assert np.isfinite(out).all(), (wname, nr, nc, shape)
+            assert np.abs(out - ref).max() <= _tol(ref), (wname, nr, nc, seg, shape)
+
+
+def test_emu_dwt2_long_batch_custom_filter_and_declined_sizes():
+    rng = np.random.default_rng(12)
+    lo, hi = f32(rng.standard_normal(40)), f32(rng.standard_normal(40))
+    B, nr, nc = 2, 64, 136
+    x = oracle.hash_input((B, nr, nc), 94)
+    outs = [np.zeros((B, nr // 2, nc // 2), dtype=np.float32) for _ in range(4)]
+    assert lib().emu_dwt2_fwd_long(P(x), B, nr, nc, P(lo), P(hi), 40, 16, 0, *[P(o) for o in outs]) == 0
+    for b in range(B):
+        ref = oracle.forward(x[b], "db20", 1, ndim=2, filt=(40, lo, hi, lo, hi))
+        for got, want in zip(outs, ref):
+            assert np.abs(got[b] - want).max() <= _tol(want)
+    rec = np.zeros((B, nr, nc), dtype=np.float32)
+    assert lib().emu_dwt2_inv_long(*[P(o) for o in outs], B, nr // 2, nc // 2, nr, nc, P(lo), P(hi), 40, 16, 0, P(rec)) == 0
+    for b in range(B):
+        ref = oracle.inverse([o[b] for o in outs], (nr, nc), "db20", 1, ndim=2, filt=(40, lo, hi, lo, hi))
+        assert np.abs(rec[b] - ref).max() <= 4 * _tol(ref)
+    # sizes the kernels do not take (the launchers send them to the tiles): odd rows, rows that are not whole 16-B groups
+    assert lib().emu_dwt2_fwd_long(P(x), 1, 63, 136, P(lo), P(hi), 40, 0, 0, *[P(o) for o in outs]) < 0
+    assert lib().emu_dwt2_fwd_long(P(x), 1, 64, 134, P(lo), P(hi), 40, 0, 0, *[P(o) for o in outs]) < 0
+    assert lib().emu_dwt2_inv_long(*[P(o) for o in outs], 1, 32, 66, 64, 132, P(lo), P(hi), 40, 0, 0, P(rec)) < 0

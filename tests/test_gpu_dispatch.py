@@ -14,8 +14,9 @@ pytestmark = pytest.mark.gpu
 
 # every pair the default dispatch can reach, per library: launch name (the step kind) x the family that serves a LEVEL step
 REACHABLE = {
-    "f32": {("dwt2_fwd_level", "tile"), ("dwt2_fwd_level", "wave"), ("dwt2_fwd_level", "ring"), ("dwt2_fwd_level", "generic"),
-            ("dwt2_inv_level", "tile"), ("dwt2_inv_level", "wave"), ("dwt2_inv_level", "ring"), ("dwt2_inv_level", "generic"),
+    "f32": {("dwt2_fwd_level", "tile"), ("dwt2_fwd_level", "wave"), ("dwt2_fwd_level", "ring"), ("dwt2_fwd_level", "long"), ("dwt2_fwd_level", "generic"),
+            ("dwt2_inv_level", "tile"), ("dwt2_inv_level", "wave"), ("dwt2_inv_level", "ring"), ("dwt2_inv_level", "long"),
+            ("dwt2_inv_level", "generic"),
             ("dwt2_fwd_pyr2", ""), ("dwt2_inv_pyr2", ""), ("dwt2_fwd_pyr3", ""), ("dwt2_inv_pyr3", ""), ("dwt2_fwd_tail", ""),
             ("dwt2_inv_tail", ""), ("dwt2_fwd_strip2", ""),
             ("dwt1_fwd_level", ""), ("dwt1_inv_level", ""), ("dwt1_fwd_reg", ""), ("dwt1_inv_reg", ""), ("dwt1_fwd_fused", ""),
