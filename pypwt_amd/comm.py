@@ -181,7 +181,9 @@ class HostRing(object):
     """A ring of `size` ranks over TCP.  Every rank listens on a port the system picks, tells rank 0 (which listens on `port`, the
     only agreed one: MASTER_PORT + port_offset, or PDWT_RING_PORT) and gets every rank's port back; then it connects to the next
     rank and accepts its previous one.  Messages are host byte strings (TiledWavelets stages its halo rows through pdwt_copy).
-    For ranks that share one GPU (tests) or have no RCCL; hello line and job nonce as in the unique-id rendezvous."""
+    For ranks of ONE HOST that share a GPU (tests) or have no RCCL: every rank binds its listener to `addr` and looks for its
+    neighbour there, so `addr` must be an address of the machine all ranks run on (a rank on another node fails to bind with
+    EADDRNOTAVAIL -- several nodes need RCCL, `Communicator`).  Hello line and job nonce as in the unique-id rendezvous."""
 
     def __init__(self, rank, size, addr="127.0.0.1", port=29540, timeout=120.0):
         import threading
@@ -207,7 +209,8 @@ class HostRing(object):
                     conn, _ = srv.accept()
                     conn.settimeout(5.0)
                     try:
-                        parts = _recv_line(conn)[len(HELLO):].split()
+                        hello = _recv_line(conn)
+                        parts = hello[len(HELLO):].split() if hello.startswith(HELLO) else []
                         if len(parts) != 3 or parts[1] != nonce or int(parts[0]) in ports or not 0 < int(parts[0]) < self.size:
                             conn.close()
                             continue
@@ -243,7 +246,8 @@ class HostRing(object):
             while time.time() < deadline:
                 conn, _ = mine.accept()
                 conn.settimeout(timeout)
-                parts = _recv_line(conn)[len(HELLO):].split()
+                hello = _recv_line(conn)
+                parts = hello[len(HELLO):].split() if hello.startswith(HELLO) else []
                 if len(parts) == 2 and parts[1] == nonce and int(parts[0]) == (self.rank - 1) % self.size:
                     accepted["conn"] = conn
                     return

@@ -171,10 +171,13 @@ static bool ring_kernels_for(long long samples, int hlen, int Nc, bool inverse) 
 //     db10  4096^2        45 /  59 ->  49 /  51 (forced)        186 / 243 -> 162 / 184                 717 /  985 -> 639 / 720
 //     sym8  (16 taps)     41 /  45 ->  44 /  47 (forced)        155 / 157 -> 158 / 168: tiles and ring kernels stay
 //     db20  2048^2 L5     38 /  45 ->  53 /  56 with every level forced; level 1 of the inverse alone: 45 -> 40 (db13: 28 -> 30)
-// Rules: from 20 taps on (tuning keys "long_fwd" / "long_inv": the shortest filter; 0 = never; 100 + n = n taps at every size
-// the kernels take: tests); the inverse from 2^24 samples per launch and, from 30 taps, from 2^22; the forward from 2^25
-// samples (batches) and, from 30 taps, from 2^24.
-constexpr int kLongFwdDefault = 20, kLongInvDefault = 20;
+//     db9   (18 taps)     43 /  47 ->  45 /  49 (forced)        172 / 193 -> 159 / 176
+//     db14  4096^2        61 /  76 ->  56 /  57;  db15  62 / 68 -> 55 / 59;  db13 forward 51 -> 53: the forward of one image from 28 taps
+//     db20  2048^2 L5     38 /  45 ->  53 /  56 with every level forced; level 1 of the inverse alone: 45 -> 40 (db16 38 -> 35, db15 31 -> 32)
+// Rules (tuning keys "long_fwd" / "long_inv": the shortest filter, default 18; 0 = never; 100 + n = n taps at every size the
+// kernels take: tests): 18 taps from 2^26 samples per launch; 20 taps and more: the inverse from 2^24 samples, the forward
+// from 2^25; the forward of 28 taps and more from 2^24; the inverse of 32 taps and more from 2^22.
+constexpr int kLongFwdDefault = 18, kLongInvDefault = 18;
 static std::atomic<int>& long_min_taps(bool inverse) {
     static std::atomic<int> v[2] = {{kLongFwdDefault}, {kLongInvDefault}};
     return v[inverse ? 1 : 0];
@@ -187,9 +190,11 @@ static bool long_kernels_for(long long samples, int hlen, bool inverse) {
     if (m <= 0) return false;
     if (m >= 100) return hlen >= m - 100;  // forced: every size
     if (hlen < m) return false;
-    const long long all = inverse ? (1LL << 24) : (1LL << 25);       // every length from m on
-    const long long longest = inverse ? (1LL << 22) : (1LL << 24);   // 30 taps and more
-    return samples >= all || (hlen >= 30 && samples >= longest);
+    if (samples >= (1LL << 26)) return true;
+    if (hlen < 20) return false;
+    if (samples >= (inverse ? (1LL << 24) : (1LL << 25))) return true;
+    if (inverse) return hlen >= 32 && samples >= (1LL << 22);
+    return hlen >= 28 && samples >= (1LL << 24);
 }
 
 static int eff_wave_min_log2() { return g_active_tuning ? g_active_tuning->wave_min_log2 : wave_min_log2().load(std::memory_order_relaxed); }

@@ -87,6 +87,7 @@ static hipError_t run_inv(const Inv2DArgs& g, int batch, int seg_hint, hipStream
 constexpr int kRingMaxHlenInv = 16;
 
 hipError_t try_launch_dwt2_inv_ring(const Inv2DArgs& a, int batch, hipStream_t s, int cpl, int seg_hint) {
+    if (batch < 1 || batch > 65535) return hipErrorNotSupported;  // the batch is grid.y: the tiles take what does not fit
     if ((a.hlen & 1) || a.hlen < kRingMinHlen || a.hlen > kRingMaxHlenInv) return hipErrorNotSupported;
     if ((a.Ncc & 1) || a.Nc != 2 * a.Ncc || (a.in_bstride & 1) || (a.out_bstride & 3)) return hipErrorNotSupported;
     if (a.Nr > 2 * a.Nrc || a.Nr < 2 * a.Nrc - 1) return hipErrorNotSupported;
@@ -106,6 +107,7 @@ hipError_t try_launch_dwt2_inv_ring(const Inv2DArgs& a, int batch, hipStream_t s
 }
 
 hipError_t try_launch_dwt2_fwd_ring(const Fwd2DArgs& a, int batch, hipStream_t s, int cpl, int seg_hint) {
+    if (batch < 1 || batch > 65535) return hipErrorNotSupported;
     if ((a.hlen & 1) || a.hlen < kRingMinHlen || a.hlen > kRingMaxHlen) return hipErrorNotSupported;
     if ((a.Nc & 3) || (a.in_bstride & 3) || (a.out_bstride & 1) || a.Nc2 * 2 != a.Nc) return hipErrorNotSupported;
     if ((long long)a.Nc * (long long)sizeof(real_t) >= (1LL << 31)) return hipErrorNotSupported;  // 32-bit byte offsets inside a row

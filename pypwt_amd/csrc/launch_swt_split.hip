@@ -37,9 +37,17 @@ static hipError_t go_stream(const SwtStreamArgs& k, hipStream_t s) {
 // outputs per work item (A/B builds: -DPDWT_STREAM_R_...): analysis | synthesis, one column | a pair of columns per work item
 #ifndef PDWT_STREAM_R_A1
 #define PDWT_STREAM_R_A1 4
+#endif
+#ifndef PDWT_STREAM_R_A2
 #define PDWT_STREAM_R_A2 4
+#endif
+#ifndef PDWT_STREAM_R_S1
 #define PDWT_STREAM_R_S1 4
+#endif
+#ifndef PDWT_STREAM_R_S2
 #define PDWT_STREAM_R_S2 4
+#endif
+#ifndef PDWT_STREAM_NT_Y
 #define PDWT_STREAM_NT_Y 512
 #endif
 // pairs of columns (16-B accesses) where rows are even and the planes 16-B aligned; along x the dilation must be even too
@@ -199,9 +207,9 @@ bool swt2_split_supported(int hlen, int Nr, int Nc, int f, bool inverse, long lo
     if (stream_route32(hlen, Nr, Nc, f, inverse, samples, min_taps)) return true;
     // (narrow images keep this path too: measured, the tiled inverse is slower still there -- 4096 images of 64^2, db4 L2
     // forward+inverse 1006 us on this path against 1168 tiled, 8192 of 32^2 1047 against 2182)
-    if (Nr % f) {
-        min_taps = 10;  // rows the dilation does not divide: the alternative is three direct passes (one load per tap and output)
-    } else if (min_taps >= 100) {
+    // (rows the dilation does not divide used to come here from 10 taps on, when the alternative was three direct passes; since
+    // round 5 the LDS tiles take any row count, so such levels follow the ordinary thresholds -- and the caller's tuning value)
+    if (min_taps >= 100) {
         min_taps -= 100;  // forced: the same threshold at every size (tests)
     } else if (!inverse) {
         if (samples < (1LL << 21) && min_taps < 18) min_taps = 18;  // 14 and 16 taps: from 2 M samples (see above)

@@ -85,23 +85,24 @@ class DeviceArray(object):
 
 class Wavelets(object):
     """
-    Initializes the Wavelet transform from an image and given parameters.
+    A wavelet-transform plan bound to one image (or one batch of rows) on the GPU: the drop-in for pycudwt's class of the
+    same name (constructor signature, attributes and coefficient layout of src/pypwt.pyx:64-615).
 
-    img: 2D numpy.ndarray, float32
-        Input image
-    wname: string
-        Name of the wavelet
-    levels: int
-        Number of decomposition levels
-    do_separable: int
-        if not 0, perform a separable transform
-    do_cycle_spinning: int
-        if not 0, perform a random shift on the image
-        (useful for iterative algorithms)
-    do_swt: int
-        if not 0, perform a Stationary (non-decimated) wavelet transform
-    ndim: int
-        2 (default) or 1; a 2D array with ndim=1 is a batched 1D transform
+    Arguments, in the reference's order:
+
+    * ``img``      the data, float32: a 2D array (one image), a 1D array (one signal), or a 2D array with ``ndim=1``
+      (every row is a signal of its own).  A device array (``__cuda_array_interface__``, a torch tensor on the GPU,
+      a ``DeviceArray`` of another plan) is taken over without a trip through the host.
+    * ``wname``    one of the 72 built-in wavelet names ("haar", "db2" ... "db20", "sym2" ..., "coif1" ..., "bior1.3" ...,
+      "rbio1.3" ...); custom banks go in afterwards through ``set_wavelets_filters``.
+    * ``levels``   how many decomposition levels are wanted; clamped to what the image size allows, with the reference's
+      warning on stdout.
+    * ``do_separable``       nonzero (default): row and column passes; zero: the 2D non-separable kernels.
+    * ``do_cycle_spinning``  nonzero: every ``forward`` circularly shifts the image by a random offset that the matching
+      ``inverse`` undoes -- the usual trick against blocking artefacts in iterative shrinkage.
+    * ``do_swt``   nonzero: the undecimated (a-trous) transform, every band at full size.
+    * ``ndim``     2 or 1, see ``img``.
+    * ``copy``     accepted and ignored like the reference's (its copy branch is commented out, pypwt.pyx:121-142).
     """
 
     # storage / arithmetic type: float32 like the reference's Python class; the Wavelets64 subclass below

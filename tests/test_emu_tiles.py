@@ -1137,3 +1137,31 @@ def test_emu_dwt2_long_batch_custom_filter_and_declined_sizes():
     assert lib().emu_dwt2_fwd_long(P(x), 1, 63, 136, P(lo), P(hi), 40, 0, 0, *[P(o) for o in outs]) < 0
     assert lib().emu_dwt2_fwd_long(P(x), 1, 64, 134, P(lo), P(hi), 40, 0, 0, *[P(o) for o in outs]) < 0
     assert lib().emu_dwt2_inv_long(*[P(o) for o in outs], 1, 32, 66, 64, 132, P(lo), P(hi), 40, 0, 0, P(rec)) < 0
+
+
+def test_stream_kernels_nonfinite_footprint_is_bounded():
+    """the stream kernels multiply the (input, output) pairs outside the filter support by zero-padded taps
+    instead of skipping them (taps by wave-uniform index out of a padded table: no per-pair test in the chunk loop), so one
+    non-finite sample reaches up to R - 1 outputs beyond its support on each side of each filtered axis (0 * Inf = NaN).
+    Finite data is unaffected.  This pins the bound: the non-finite set contains the oracle's and stays inside its
+    (R - 1)-dilation; the tile, wave, ring and strip-streaming ("long") kernels reproduce the oracle's set exactly
+    (tests/test_gpu_long.py::test_long_nonfinite_footprint_matches_the_oracle)."""
+    hlen, dlo, dhi, rlo, rhi = oracle.filters("db10")
+    Nr, Nc = 64, 136
+    x = oracle.hash_input((Nr, Nc), 777)
+    x[30, 61] = np.inf
+    ref = oracle.forward(x, "db10", 1, ndim=2)
+    for R in (2, 4):
+        outs = [np.full((1, Nr // 2, Nc // 2), np.nan, dtype=np.float32) for _ in range(4)]
+        xin = x[None].copy()
+        assert lib().emu_dwt2_stream(0, P(xin), 1, Nr, Nc, P(dlo), P(dhi), hlen, R, *[P(o) for o in outs]) == 0
+        for got, want in zip(outs, ref):
+            bad, want_bad = ~np.isfinite(got[0]), ~np.isfinite(want)
+            assert (bad | ~want_bad).all(), "the oracle's non-finite outputs are non-finite here too"
+            reach = np.zeros_like(want_bad)
+            for dy in range(-(R - 1), R):
+                for dx in range(-(R - 1), R):
+                    reach |= np.roll(np.roll(want_bad, dy, axis=0), dx, axis=1)
+            assert not (bad & ~reach).any(), (R, int((bad & ~reach).sum()))
+            ok = ~reach
+            assert np.abs(got[0][ok] - want[ok]).max() <= _tol(want[np.isfinite(want)])

@@ -1,6 +1,6 @@
 """GPU parity of the strip-streaming level kernels for long filters (pypwt_amd/csrc/dwt2_long_kernels.hpp; reference:
 w_kern_forward_pass1/2 and w_kern_inverse_pass1/2, pdwt/src/separable.cu:91-176, 246-328, which take every hlen <= 40 and are
-what test/benchmark.py:20-38 times with db20).  By default they serve the large levels of filters of 20 taps and more; here
+what test/benchmark.py:20-38 times with db20).  By default they serve the large levels of filters of 18-20 taps and more; here
 pdwt_set_tuning("long_fwd" / "long_inv", 110) sends every eligible level (even hlen 10-40, even sides, rows of whole 16-B
 groups) through them, every level as its own launch, and the results are compared with the CPU oracle element by element.
 The default dispatch at full size is the last test."""
@@ -154,7 +154,7 @@ def test_long_full_size_default_dispatch_every_element():
     on the strips in both directions, the 2048^2 level in the inverse only, the 1024^2 level on the tiles; every element."""
     from pypwt_amd import _lib
     lib = _lib.load()
-    prev = (lib.pdwt_set_tuning(b"long_fwd", 20), lib.pdwt_set_tuning(b"long_inv", 20))
+    prev = (lib.pdwt_set_tuning(b"long_fwd", 18), lib.pdwt_set_tuning(b"long_inv", 18))
     os.environ.pop("PDWT_NO_PYRAMID", None)
     os.environ.pop("PDWT_NO_TAIL", None)
     try:

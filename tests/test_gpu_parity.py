@@ -313,6 +313,13 @@ def test_strip_paths_match_oracle(wname, monkeypatch):
     small inputs: coefficients and reconstruction must equal the oracle's and the per-level path's."""
     from pypwt_amd import BatchedWavelets, _lib
     was_lab = _lib.use_lab_kernels(True)  # the inverse strips are an experiment: libpypwt_amd_lab.so
+    try:  # a failing assert must not leave the measurement library selected for every later test
+        _strip_paths_case(wname, monkeypatch, BatchedWavelets)
+    finally:
+        _lib.use_lab_kernels(was_lab)
+
+
+def _strip_paths_case(wname, monkeypatch, BatchedWavelets):
     monkeypatch.setenv("PDWT_FORCE_STRIP", "1")
     B, shape, L = 3, (136, 272), 3
     x = oracle.hash_input((B,) + shape, 4242, scale=255.0)
@@ -335,7 +342,6 @@ def test_strip_paths_match_oracle(wname, monkeypatch):
             assert np.abs(got[k][b] - r).max() <= tol, (wname, b, k)
             assert np.abs(got[k][b] - w2.coeff(k)[b]).max() <= tol, (wname, b, k)
     w2.inverse()
-    _lib.use_lab_kernels(was_lab)
     assert np.abs(rec - x).max() <= 2e-3
     assert np.abs(rec - w2.image).max() <= 1e-3
 
