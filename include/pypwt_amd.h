@@ -122,6 +122,14 @@ int pdwt_proj_linf(pdwt_handle h, pdwt_real beta, int do_thresh_appcoeffs);
 int pdwt_circshift(pdwt_handle h, int sr, int sc, int inplace); /* wt.cu:364-366 */
 int pdwt_norm1(pdwt_handle h, pdwt_real* out);   /* wt.cu:396-416 */
 int pdwt_norm2sq(pdwt_handle h, pdwt_real* out); /* wt.cu:368-393 (1D bug at :387 not reproduced) */
+/* NEW (round 6): the same two sums WITHOUT the round trip.  The results -- {sum |c|, sum c^2} as two doubles -- are written
+ * to DEVICE memory on the plan's stream (d_out2, or the plan's own slot when NULL: pdwt_norms_slot) and nothing is
+ * synchronised; pdwt_norm1 / pdwt_norm2sq above stay blocking host getters like the reference's (wt.cu:368-416).
+ * pdwt_soft_threshold_norms_async = pdwt_soft_threshold followed by pdwt_norms_async in ONE sweep over the coefficients
+ * (the inner loop of iterative shrinkage, pdwt/README.md:6-7): same arguments and state rules as pdwt_soft_threshold. */
+int pdwt_norms_async(pdwt_handle h, double* d_out2);
+int pdwt_norms_slot(pdwt_handle h, double** d_ptr); /* device address of the plan's own result slot (valid while the plan lives) */
+int pdwt_soft_threshold_norms_async(pdwt_handle h, pdwt_real beta, int do_thresh_appcoeffs, int normalize, double* d_out2);
 /* dst += alpha * src ; returns 0, or the reference's codes -1..-4 / +1 (wt.cu:622-655) */
 int pdwt_add_wavelet(pdwt_handle dst, pdwt_handle src, pdwt_real alpha);
 

@@ -58,6 +58,9 @@ def signatures(real=C.c_float):
         "pdwt_circshift": (C.c_int, [handle_t, C.c_int, C.c_int, C.c_int]),
         "pdwt_norm1": (C.c_int, [handle_t, realp]),
         "pdwt_norm2sq": (C.c_int, [handle_t, realp]),
+        "pdwt_norms_async": (C.c_int, [handle_t, C.c_void_p]),
+        "pdwt_norms_slot": (C.c_int, [handle_t, C.POINTER(C.c_void_p)]),
+        "pdwt_soft_threshold_norms_async": (C.c_int, [handle_t, real, C.c_int, C.c_int, C.c_void_p]),
         "pdwt_add_wavelet": (C.c_int, [handle_t, handle_t, real]),
         "pdwt_get_image": (C.c_longlong, [handle_t, C.c_void_p]),
         "pdwt_get_coeff": (C.c_longlong, [handle_t, C.c_void_p, C.c_int]),

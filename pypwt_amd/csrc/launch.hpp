@@ -164,8 +164,13 @@ hipError_t launch_ew(int op, real_t* p, long long n, real_t b, hipStream_t s);
 hipError_t launch_group_soft(real_t* d0, real_t* d1, real_t* d2, real_t* ap, long long n, real_t beta, int nb,
                              hipStream_t s);
 hipError_t launch_axpy(real_t* dst, const real_t* src, long long n, real_t alpha, hipStream_t s);
-hipError_t launch_norms(const real_t* p, long long n, double* out2, hipStream_t s);  // out2: norms_scratch_doubles() doubles
+hipError_t launch_norms(const real_t* p, long long n, double* scratch, double* out, hipStream_t s);  // scratch: norms_scratch_doubles() doubles; out: 2 doubles (device)
 int norms_scratch_doubles();
+// soft threshold + norms of the result in one sweep (ops_kernels.hpp); several sweeps share the scratch, then one final launch
+hipError_t launch_soft_norms(real_t* p, long long n, long long split, real_t b_lo, real_t b_hi, bool keep_lo, bool store,
+                             double* scratch, int first_block, int max_blocks, int* blocks, hipStream_t s);
+hipError_t launch_norms_final(const double* scratch, int nblocks, double* out, hipStream_t s);
+int norms_max_blocks();
 hipError_t launch_circshift(const real_t* in, real_t* out, int batch, int Nr, int Nc, int sr, int sc, hipStream_t s);
 hipError_t launch_copy(const real_t* src, real_t* dst, long long n, hipStream_t s);  // 16-B grid-stride copy (n % 4 == 0)
 hipError_t launch_fill_hash(real_t* x, long long n, uint32_t seed, real_t scale, long long index_offset,

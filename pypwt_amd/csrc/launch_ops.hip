@@ -35,17 +35,41 @@ hipError_t launch_axpy(real_t* dst, const real_t* src, long long n, real_t alpha
     return hipGetLastError();
 }
 
-// out2: 2 + 2 * kNormsMaxBlocks doubles: [0], [1] = the results, the rest = per-block partial sums (scratch)
-hipError_t launch_norms(const real_t* p, long long n, double* out2, hipStream_t s) {
-    if (n <= 0) return hipMemsetAsync(out2, 0, 2 * sizeof(double), s);
+// scratch: 2 + 2 * kNormsMaxBlocks doubles ([0], [1]: a result slot of its own, the rest per-block partial sums); out: where the
+// two results go (device memory; may be scratch itself)
+hipError_t launch_norms(const real_t* p, long long n, double* scratch, double* out, hipStream_t s) {
+    if (n <= 0) return hipMemsetAsync(out, 0, 2 * sizeof(double), s);
     const long long n4 = n / 4;
     int grid = stream_grid(n4, 256);
     if (grid > kNormsMaxBlocks) grid = kNormsMaxBlocks;
-    hipLaunchKernelGGL(norms_partial_kernel, dim3(grid), dim3(256), 0, s, reinterpret_cast<const real4_t*>(p), n4, out2 + 2);
-    hipLaunchKernelGGL(norms_final_kernel, dim3(1), dim3(256), 0, s, out2 + 2, grid, out2);
+    hipLaunchKernelGGL(norms_partial_kernel, dim3(grid), dim3(256), 0, s, reinterpret_cast<const real4_t*>(p), n4, scratch + 2);
+    hipLaunchKernelGGL(norms_final_kernel, dim3(1), dim3(256), 0, s, scratch + 2, grid, out);
     return hipGetLastError();
 }
 int norms_scratch_doubles() { return 2 + 2 * kNormsMaxBlocks; }
+
+// one fused sweep of soft_norms_partial_kernel over n values from p; its partial sums go to scratch + 2 + 2 * first_block;
+// returns the blocks it used through *blocks (at most max_blocks)
+hipError_t launch_soft_norms(real_t* p, long long n, long long split, real_t b_lo, real_t b_hi, bool keep_lo, bool store,
+                             double* scratch, int first_block, int max_blocks, int* blocks, hipStream_t s) {
+    *blocks = 0;
+    if (n <= 0) return hipSuccess;
+    const long long n4 = n / 4;
+    int grid = stream_grid(n4, 256);
+    if (grid > max_blocks) grid = max_blocks;
+    if (grid < 1 || first_block + grid > kNormsMaxBlocks) return hipErrorInvalidValue;
+    double* part = scratch + 2 + 2 * first_block;
+    real4_t* p4 = reinterpret_cast<real4_t*>(p);
+    if (store) hipLaunchKernelGGL((soft_norms_partial_kernel<true>), dim3(grid), dim3(256), 0, s, p4, n4, split / 4, b_lo, b_hi, keep_lo ? 1 : 0, part);
+    else hipLaunchKernelGGL((soft_norms_partial_kernel<false>), dim3(grid), dim3(256), 0, s, p4, n4, split / 4, b_lo, b_hi, keep_lo ? 1 : 0, part);
+    *blocks = grid;
+    return hipGetLastError();
+}
+hipError_t launch_norms_final(const double* scratch, int nblocks, double* out, hipStream_t s) {
+    hipLaunchKernelGGL(norms_final_kernel, dim3(1), dim3(256), 0, s, scratch + 2, nblocks, out);
+    return hipGetLastError();
+}
+int norms_max_blocks() { return kNormsMaxBlocks; }
 
 hipError_t launch_circshift(const real_t* in, real_t* out, int batch, int Nr, int Nc, int sr, int sc,
                             hipStream_t s) {

@@ -112,6 +112,47 @@ __global__ void __launch_bounds__(256) norms_partial_kernel(const real4_t* __res
         partial[2 * blockIdx.x + 1] = part[1][0] + part[1][1] + part[1][2] + part[1][3];
     }
 }
+// The inner loop of iterative shrinkage -- soft_threshold, then norm1 of what is left (pdwt/README.md:6-7; wt.cu:308-315,
+// 396-416) -- as ONE sweep: x' = soft(x, beta) for every coefficient (beta = b_lo in the first split4 groups -- the
+// approximation band --, b_hi behind; keep_lo: the first part as it is), sum |x'| and sum x'^2 per block.  STORE = false is the
+// read-only form for plans whose inverse applies the threshold as it loads the details (2D SWT): the norms of the
+// thresholded coefficients without touching them.
+template <bool STORE>
+__global__ void __launch_bounds__(256) soft_norms_partial_kernel(real4_t* __restrict__ p, long long n4, long long split4, real_t b_lo,
+                                                                 real_t b_hi, int keep_lo, double* __restrict__ partial) {
+    double s1 = 0.0, s2 = 0.0;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        real4_t v = p[i];
+        const bool lo = i < split4;
+        if (!(lo && keep_lo)) {
+            const real_t b = lo ? b_lo : b_hi;
+            v.x = ew_apply<EW_SOFT>(v.x, b);
+            v.y = ew_apply<EW_SOFT>(v.y, b);
+            v.z = ew_apply<EW_SOFT>(v.z, b);
+            v.w = ew_apply<EW_SOFT>(v.w, b);
+            if (STORE) p[i] = v;
+        }
+        s1 += (double)fabs(v.x) + (double)fabs(v.y) + (double)fabs(v.z) + (double)fabs(v.w);
+        s2 += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        s1 += __shfl_down(s1, off, 64);
+        s2 += __shfl_down(s2, off, 64);
+    }
+    __shared__ double part[2][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+        part[0][wave] = s1;
+        part[1][wave] = s2;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        partial[2 * blockIdx.x] = part[0][0] + part[0][1] + part[0][2] + part[0][3];
+        partial[2 * blockIdx.x + 1] = part[1][0] + part[1][1] + part[1][2] + part[1][3];
+    }
+}
 // one block: out[0] = sum of partial[2 b], out[1] = sum of partial[2 b + 1], b < nblocks (fixed order: deterministic)
 __global__ void __launch_bounds__(256) norms_final_kernel(const double* __restrict__ partial, int nblocks, double* __restrict__ out) {
     double s1 = 0.0, s2 = 0.0;

@@ -58,6 +58,20 @@ def _device_array(obj, dtype):
     return int(iface["data"][0]), shape, order
 
 
+def _read_norms(lib, h, view):
+    """(sum |c|, sum c^2) out of a two-double device slot: a blocking device-to-host pdwt_copy on the plan's stream."""
+    if view is None:
+        ptr = C.c_void_p()
+        check(lib.pdwt_norms_slot(h, C.byref(ptr)), "pdwt_norms_slot", lib)
+        addr = ptr.value
+    else:
+        addr = int(view.__cuda_array_interface__["data"][0])
+    host = np.zeros(2, dtype=np.float64)
+    count = 16 // C.sizeof(lib.pdwt_real)  # pdwt_copy counts elements of pdwt_real
+    check(lib.pdwt_copy(h, host.ctypes.data_as(C.c_void_p), C.c_void_p(addr), count, 2), "pdwt_copy", lib)
+    return float(host[0]), float(host[1])
+
+
 class _Shape(object):
     def __init__(self, shape):
         self.shape = tuple(shape)
@@ -372,6 +386,36 @@ class Wavelets(object):
         self._check(self._lib.pdwt_norm2sq(self._h, C.byref(out)))
         return out.value
 
+    def _norms_slot(self, out):
+        if out is not None:
+            dev = _device_array(out, np.float64)
+            if dev is None or int(np.prod(dev[1])) < 2:
+                raise ValueError("norms: `out` must be a device array of two float64")
+            return C.c_void_p(dev[0]), out
+        ptr = C.c_void_p()
+        self._check(self._lib.pdwt_norms_slot(self._h, C.byref(ptr)))
+        return C.c_void_p(None), DeviceArray(self, ptr.value, (2,), np.float64, self._stream())
+
+    def norms_device(self, out=None):
+        """NEW: (sum |c|, sum c^2) of all the coefficients as two float64 ON THE DEVICE, enqueued on the plan's stream and not
+        waited for (norm1 / norm2sq above block and copy one float to the host each).  Returns a two-element device array:
+        ``out`` if given (any ``__cuda_array_interface__`` holder of two float64), else a view of the plan's own slot."""
+        arg, view = self._norms_slot(out)
+        self._check(self._lib.pdwt_norms_async(self._h, arg))
+        return view
+
+    def soft_threshold_norms(self, beta, do_threshold_appcoeffs=0, normalize=0, out=None):
+        """NEW: ``soft_threshold(beta, ...)`` and ``norms_device()`` of the result in ONE sweep over the coefficients (the inner
+        loop of iterative shrinkage: threshold, then the l1 norm of what is left); same arguments as ``soft_threshold``."""
+        arg, view = self._norms_slot(out)
+        self._check(self._lib.pdwt_soft_threshold_norms_async(self._h, float(beta), int(do_threshold_appcoeffs), int(normalize), arg))
+        return view
+
+    def read_norms(self, view=None):
+        """The two float64 a ``norms_device`` / ``soft_threshold_norms`` call left on the device, copied to the host (waits for
+        the plan's stream): (sum |c|, sum c^2)."""
+        return _read_norms(self._lib, self._h, view)
+
     def add_wavelet(self, W, alpha=1.0):
         """coefficients += alpha * W.coefficients"""
         rc = self._lib.pdwt_add_wavelet(self._h, W._h, float(alpha))
@@ -547,6 +591,17 @@ class BatchedWavelets(object):
 
     def soft_threshold(self, beta, do_threshold_appcoeffs=0, normalize=0):
         check(self._lib.pdwt_soft_threshold(self._h, float(beta), int(do_threshold_appcoeffs), int(normalize)))
+
+    def norms_device(self):
+        """(sum |c|, sum c^2) over the whole batch into the plan's device slot; not waited for (see Wavelets.norms_device)."""
+        check(self._lib.pdwt_norms_async(self._h, None))
+
+    def soft_threshold_norms(self, beta, do_threshold_appcoeffs=0, normalize=0):
+        """soft_threshold and the norms of the result in one sweep (see Wavelets.soft_threshold_norms)."""
+        check(self._lib.pdwt_soft_threshold_norms_async(self._h, float(beta), int(do_threshold_appcoeffs), int(normalize), None))
+
+    def read_norms(self):
+        return _read_norms(self._lib, self._h, None)
 
     def set_image(self, img):
         img = self._single._checkarray(np.asarray(img), (self.batch, self.Nr, self.Nc))

@@ -898,3 +898,53 @@ def test_bind_image_chains_two_plans_without_a_copy(W):
     assert lib.pdwt_bind_image(b._h, C.c_void_p(lib.pdwt_coeff_ptr(a._h, 0) + 4)) == _lib.ERR_ARG
     assert lib.pdwt_image_ptr(b._h) == lib.pdwt_coeff_ptr(a._h, 0)
     assert lib.pdwt_bind_image(b._h, None) == 0 and lib.pdwt_image_ptr(b._h) == own
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("do_app,normalize", [(0, 0), (1, 0), (0, 1), (1, 1)])
+def test_soft_threshold_norms_in_one_sweep(W, case, do_app, normalize):
+    """NEW (round 6): soft_threshold_norms = soft_threshold + the two norms of what is left, one sweep, results on the device.
+    The coefficients are the oracle's thresholded ones (bit for bit what soft_threshold leaves), the sums the oracle's; a 2D SWT
+    plan keeps its threshold deferred into the inverse (the sweep is read-only there) and still reports the thresholded norms."""
+    shape, nd, swt, wname, lv = case
+    beta = 7.5
+    w, x, bands = _mk(W, case)
+    view = w.soft_threshold_norms(beta, do_app, normalize)
+    got = w.read_norms(view)
+    ref = oracle.threshold(bands, shape, lv, "soft", beta, do_app, normalize, ndim=nd, do_swt=swt)
+    n1, n2 = oracle.norms(ref, shape, lv, ndim=nd, do_swt=swt)
+    assert abs(got[0] - n1) <= 1e-5 * max(n1, 1.0) and abs(got[1] - n2) <= 1e-5 * max(n2, 1.0), (got, n1, n2)
+    w2, _, _ = _mk(W, case)
+    w2.soft_threshold(beta, do_app, normalize)
+    for g, h, r in zip(flat_coeffs(w), flat_coeffs(w2), ref):
+        assert np.array_equal(g, h)
+        assert np.abs(g - r).max() <= 2e-6 * max(np.abs(r).max(), 1.0)
+    assert abs(w2.norm1() - got[0]) <= 1e-6 * max(got[0], 1.0) and abs(w2.norm2sq() - got[1]) <= 1e-6 * max(got[1], 1.0)
+    w.inverse()
+    w2.inverse()
+    assert np.array_equal(w.image, w2.image)
+
+
+def test_norms_device_and_caller_owned_slot(W):
+    """norms_device leaves (sum |c|, sum c^2) in device memory -- the plan's slot or two float64 the caller owns (here: another
+    plan's slot through its __cuda_array_interface__ view) -- and equals the blocking getters."""
+    x = oracle.hash_input((192, 160), 21)
+    w = W(x, "db3", 3)
+    w.forward()
+    v = w.norms_device()
+    assert v.shape == (2,) and v.dtype == np.float64
+    a = w.read_norms(v)
+    assert abs(a[0] - w.norm1()) <= 1e-6 * a[0] and abs(a[1] - w.norm2sq()) <= 1e-6 * a[1]
+    other = W(np.zeros((32, 32), dtype=np.float32), "haar", 1)
+    slot = other.norms_device()                  # a two-double device array that `w` does not own
+    w.soft_threshold(5.0)
+    out = w.norms_device(out=slot)
+    assert out is slot
+    w.synchronize()
+    b = other.read_norms(slot)
+    assert abs(b[0] - w.norm1()) <= 1e-6 * b[0] and b[0] < a[0]
+    with pytest.raises(ValueError):
+        w.norms_device(out=w.image_device)       # float32 view: not two float64
+    w.inverse()
+    with pytest.raises(Exception):
+        w.soft_threshold_norms(1.0)              # state machine: as soft_threshold after inverse()

@@ -33,6 +33,9 @@ for shape, wname, L, swt in (((4096, 4096), "db4", 4, 0), ((2048, 2048), "haar",
         ("soft_threshold(app)", lambda: (W.soft_threshold(1.0, 1), W.norm1()), 8 * ncoef + 4 * ncoef),
         ("shrink", lambda: W.shrink(0.5), 8 * ncoef),
         ("proj_linf", lambda: W.proj_linf(100.0), 8 * ncoef),
+        ("soft_threshold+norm1", lambda: (W.soft_threshold(1.0), W.norm1()), 8 * ndet + 4 * ncoef),
+        ("soft_threshold_norms", lambda: W.soft_threshold_norms(1.0), 8 * ndet + 4 * (ncoef - ndet)),   # one sweep, results stay on the device
+        ("norms_device", W.norms_device, 4 * ncoef),   # no round trip
         ("norm1", W.norm1, 4 * ncoef),
         ("norm2sq", W.norm2sq, 4 * ncoef),
         ("add_wavelet", lambda: W.add_wavelet(W2, 0.5), 12 * ncoef),
