@@ -127,10 +127,76 @@ def build_library(force=False, verbose=True, variant="f32"):
     return lib
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# the compiled Python binding: INTEGRATION.md's `cdef extern` block + pypwt_amd/_cy/wavelets_class.pyx.in -> _cy/_wavelets.*.so
+CY_DIR = os.path.join(HERE, "_cy")
+
+
+def cython_extern_block():
+    """The ```cython block of INTEGRATION.md section 2 that declares pypwt_amd.h (the document is the source); a source tree
+    without the document (an sdist) uses the copy build_cython() keeps beside the class."""
+    import re
+    doc = os.path.join(ROOT, "INTEGRATION.md")
+    keep = os.path.join(CY_DIR, "pdwt_decl.pxi")
+    if os.path.exists(doc):
+        txt = open(doc).read()
+        sec = txt[txt.index("## 2. The Cython declaration block"):txt.index("## 3. ")]
+        for b in re.findall(r"```cython\n(.*?)```", sec, flags=re.S):
+            if 'cdef extern from "pypwt_amd.h"' in b:
+                if not os.path.exists(keep) or open(keep).read() != b:
+                    with open(keep, "w") as f:
+                        f.write(b)
+                return b
+        raise RuntimeError("INTEGRATION.md: no `cdef extern from \"pypwt_amd.h\"` block in section 2")
+    return open(keep).read()
+
+
+def cython_module_path():
+    import sysconfig
+    return os.path.join(CY_DIR, "_wavelets" + sysconfig.get_config_var("EXT_SUFFIX"))
+
+
+def build_cython(force=False, verbose=True):
+    """Cythonize + compile + link pypwt_amd/_cy/_wavelets (needs cython and gcc; libpypwt_amd.so must exist).  Returns the
+    path, or None when cython is not installed (the package then binds through ctypes)."""
+    import sysconfig
+    try:
+        import Cython  # noqa: F401
+    except ImportError:
+        return None
+    so = cython_module_path()
+    cls = os.path.join(CY_DIR, "wavelets_class.pyx.in")
+    pyx = ("# cython: language_level=3\n# generated by pypwt_amd/build.py from INTEGRATION.md (section 2) + wavelets_class.pyx.in\n"
+           + cython_extern_block() + "\n" + open(cls).read())
+    gen = os.path.join(OBJ, "cy")
+    os.makedirs(gen, exist_ok=True)
+    src = os.path.join(gen, "_wavelets.pyx")
+    deps = [cls, os.path.join(ROOT, "include", "pypwt_amd.h"), LIB, __file__]
+    if (not force and os.path.exists(so) and os.path.exists(src) and open(src).read() == pyx
+            and all(os.path.getmtime(so) >= os.path.getmtime(d) for d in deps if os.path.exists(d))):
+        return so
+    with open(src, "w") as f:
+        f.write(pyx)
+    r = subprocess.run([sys.executable, "-m", "cython", "-3", "_wavelets.pyx", "-o", "_wavelets.c"], cwd=gen, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("cython failed:\n" + (r.stdout + r.stderr)[-4000:])
+    cmd = ["gcc", "-shared", "-fPIC", "-O2", "-Wall", "-Wno-unused-function", "-I", sysconfig.get_paths()["include"],
+           "-I", os.path.join(ROOT, "include"), "_wavelets.c", "-L", HERE, "-lpypwt_amd", "-Wl,-rpath,$ORIGIN/..", "-o", so + ".tmp"]
+    r = subprocess.run(cmd, cwd=gen, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("gcc failed on the Cython binding:\n" + r.stderr[-4000:])
+    os.replace(so + ".tmp", so)
+    if verbose:
+        print("built", so, "(%d KiB)" % (os.path.getsize(so) // 1024))
+    return so
+
+
 def build_all(force=False, verbose=True):
     """Both variants; their translation units share one pool of compiler processes."""
     with ThreadPoolExecutor(max_workers=3) as ex:
-        return list(ex.map(lambda v: build_library(force, verbose, v), ("f32", "f64", "lab")))
+        libs = list(ex.map(lambda v: build_library(force, verbose, v), ("f32", "f64", "lab")))
+    cy = build_cython(force, verbose)
+    return libs + ([cy] if cy else [])
 
 
 if __name__ == "__main__":
