@@ -6,6 +6,7 @@
 #include "dwt2_kernels.hpp"
 #include "launch.hpp"
 #include "launch_util.hpp"
+#include "tuning.hpp"
 
 namespace pdwt {
 
@@ -85,9 +86,9 @@ hipError_t launch_dwt2_inv_chain(real_t*, real_t* const*, real_t* const*, int, i
 // pdwt_set_tuning("wave_min_log2") override the threshold (log2 samples): tests and A/B measurements.
 // fp64 build: the alternative is the generic kernel, not a tuned LDS tile, so the wave kernels start at 2^16 samples
 #ifdef PDWT_DOUBLE
-constexpr int kWaveMinDefault = 16;
+constexpr int kWaveMinDefault = (int)tune::wave_min_log2_f64;
 #else
-constexpr int kWaveMinDefault = 22;
+constexpr int kWaveMinDefault = (int)tune::wave_min_log2;
 #endif
 static std::atomic<int>& wave_min_log2() {
     static std::atomic<int> v{lab_env("PDWT_NO_WAVE") ? 63 : (lab_env("PDWT_WAVE_MIN") ? atoi(lab_env("PDWT_WAVE_MIN")) : kWaveMinDefault)};
@@ -145,7 +146,7 @@ const Tuning* active_tuning() { return g_active_tuning; }
 //     (18 and 20 keep the tile's inverse, launch_dwt2_ring.hip); images of 512 columns lose 2x (two strips per image).
 // Default: levels of at least 2^25 samples, 12 or 16 taps, rows of at least 1024 columns.  Tuning key "ring_min_log2"
 // (63 = never; below the default: every level of 10-20 taps and any width of that size on -- tests and measurements).
-constexpr int kRingMinDefault = 25;
+constexpr int kRingMinDefault = (int)tune::ring_min_log2;
 static std::atomic<int>& ring_min_log2() {
     static std::atomic<int> v{kRingMinDefault};
     return v;
@@ -158,7 +159,7 @@ static bool ring_kernels_for(long long samples, int hlen, int Nc, bool inverse) 
     static const int dirs = lab_env("PDWT_RING_DIRS") ? atoi(lab_env("PDWT_RING_DIRS")) : 3;  // A/B measurements: bit 0 forward, bit 1 inverse
     if (!((dirs >> (inverse ? 1 : 0)) & 1)) return false;
     if (m < kRingMinDefault) return hlen >= 10 && hlen <= 20;  // forced: every length the kernels are built for, any width
-    return (hlen == 12 || hlen == 16) && Nc >= 1024;
+    return (hlen == 12 || hlen == 16) && Nc >= tune::ring_min_columns;
 }
 
 // Strip-streaming kernels for long filters (dwt2_long_kernels.hpp, round 6).  A long filter is arithmetic-bound: the tiles
@@ -177,7 +178,7 @@ static bool ring_kernels_for(long long samples, int hlen, int Nc, bool inverse) 
 // Rules (tuning keys "long_fwd" / "long_inv": the shortest filter, default 18; 0 = never; 100 + n = n taps at every size the
 // kernels take: tests): 18 taps from 2^26 samples per launch; 20 taps and more: the inverse from 2^24 samples, the forward
 // from 2^25; the forward of 28 taps and more from 2^24; the inverse of 32 taps and more from 2^22.
-constexpr int kLongFwdDefault = 18, kLongInvDefault = 18;
+constexpr int kLongFwdDefault = (int)tune::long_min_taps, kLongInvDefault = (int)tune::long_min_taps;
 static std::atomic<int>& long_min_taps(bool inverse) {
     static std::atomic<int> v[2] = {{kLongFwdDefault}, {kLongInvDefault}};
     return v[inverse ? 1 : 0];
@@ -190,11 +191,11 @@ static bool long_kernels_for(long long samples, int hlen, bool inverse) {
     if (m <= 0) return false;
     if (m >= 100) return hlen >= m - 100;  // forced: every size
     if (hlen < m) return false;
-    if (samples >= (1LL << 26)) return true;
-    if (hlen < 20) return false;
-    if (samples >= (inverse ? (1LL << 24) : (1LL << 25))) return true;
-    if (inverse) return hlen >= 32 && samples >= (1LL << 22);
-    return hlen >= 28 && samples >= (1LL << 24);
+    if (samples >= (1LL << tune::long_any_log2)) return true;
+    if (hlen < tune::long_taps20) return false;
+    if (samples >= (1LL << (inverse ? tune::long_inv_log2 : tune::long_fwd_log2))) return true;
+    if (inverse) return hlen >= tune::long_inv_mid_taps && samples >= (1LL << tune::long_inv_mid_log2);
+    return hlen >= tune::long_fwd_mid_taps && samples >= (1LL << tune::long_fwd_mid_log2);
 }
 
 static int eff_wave_min_log2() { return g_active_tuning ? g_active_tuning->wave_min_log2 : wave_min_log2().load(std::memory_order_relaxed); }
@@ -216,7 +217,7 @@ static bool wave_kernels_for(long long samples) {
 #ifdef PDWT_DOUBLE
 constexpr int kLdsMaxDefault = 0;   // no tuned LDS tiles in the fp64 build
 #else
-constexpr int kLdsMaxDefault = 25;
+constexpr int kLdsMaxDefault = (int)tune::lds_max_log2;
 #endif
 static std::atomic<int>& lds_max_log2() {
     static std::atomic<int> v{lab_env("PDWT_LDS_MAX") ? atoi(lab_env("PDWT_LDS_MAX")) : kLdsMaxDefault};
@@ -228,10 +229,10 @@ static bool lds_tiles_for(long long samples, int hlen, long long per_image = 0, 
     // ... and only above 2^22 samples: in the step the 2048^2 level of cfg2 is 0.3-0.4 us faster on the wave kernels
     // (10.6 / 11.6 against 11.0 / 11.9 us event-timed), the 4096^2 level 1.0 / 0.3 us faster on the tiles
     const int m = g_active_tuning ? g_active_tuning->lds_max_log2 : lds_max_log2().load(std::memory_order_relaxed);
-    if (m <= 0 || (hlen & 1) || samples <= (1LL << 22)) return false;
+    if (m <= 0 || (hlen & 1) || samples <= (1LL << tune::lds_tiles_above_log2)) return false;
     if (samples <= (1LL << m)) return true;
     // forward levels of smaller images, up to where the strips take over
-    return !inverse && m >= kLdsMaxDefault && kLdsMaxDefault > 0 && samples < (1LL << 26) && per_image < (1LL << 24);
+    return !inverse && m >= kLdsMaxDefault && kLdsMaxDefault > 0 && samples < (1LL << tune::lds_fwd_batch_log2) && per_image < (1LL << tune::lds_fwd_image_log2);
 }
 
 // A wavefront of the wave kernels owns a strip of 256 image columns: on a batch of NARROW images most of its lanes idle and
@@ -240,7 +241,7 @@ static bool lds_tiles_for(long long samples, int hlen, long long per_image = 0, 
 // tools/planprof.sh; the whole db4 L3 plan 155.7 -> see profiles/r04zc_small_batches.txt).  fp32 only (the fp64 library has
 // no tuned tile to fall back to); a threshold forced below its default -- tests -- still takes the wave kernels.
 static bool narrow_for_wave(int Nc) {
-    static const int min_nc = lab_env("PDWT_WAVE_MIN_NC") ? atoi(lab_env("PDWT_WAVE_MIN_NC")) : 512;  // two full strips; A/B measurements
+    static const int min_nc = lab_env("PDWT_WAVE_MIN_NC") ? atoi(lab_env("PDWT_WAVE_MIN_NC")) : (int)tune::wave_min_columns;  // two full strips; A/B measurements
     return sizeof(real_t) == 4 && Nc < min_nc && eff_wave_min_log2() >= kWaveMinDefault;
 }
 
@@ -322,7 +323,7 @@ hipError_t launch_dwt2_inv(const Inv2DArgs& a, int batch, hipStream_t s) {
 #ifdef PDWT_DOUBLE
     constexpr long long kInvWaveMax = 1LL << 62;  // no tuned LDS tile to hand a large batch to
 #else
-    constexpr long long kInvWaveMax = 1LL << 26;
+    constexpr long long kInvWaveMax = 1LL << tune::inv_wave_max_log2;
 #endif
     if (wave_kernels_for(samples) && samples < kInvWaveMax && !narrow_for_wave(a.Nc)) {
         const hipError_t e = try_launch_dwt2_inv_wave(a, batch, s);

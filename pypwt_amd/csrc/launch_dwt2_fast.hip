@@ -12,6 +12,7 @@
 #include "dwt2_fast_kernels.hpp"
 #include "launch.hpp"
 #include "launch_util.hpp"
+#include "tuning.hpp"
 
 namespace pdwt {
 
@@ -80,7 +81,7 @@ static hipError_t run_fwd_fast_tile(const Fwd2DArgs& g, int batch, hipStream_t s
 }
 
 // levels whose input is between 2^20 and 2^22 samples (one 2048^2 image): the single-round tile shapes
-static bool mid_size(long long samples) { return samples > (1LL << 20) && samples <= (1LL << 22); }
+static bool mid_size(long long samples) { return samples > (1LL << tune::tile_small_level_log2) && samples <= (1LL << tune::tile_mid_hi_log2); }
 
 template <int HLEN, int TX, int TY, int NT>
 static hipError_t run_inv_fast(const Inv2DArgs& g, int batch, hipStream_t s) {
@@ -169,7 +170,7 @@ hipError_t try_launch_dwt2_fwd_fast(const Fwd2DArgs& a, int batch, hipStream_t s
     //   * large levels of 18+ taps: 32 x 32 outputs with 512 threads (each thread one column pair of one output row):
     //     40 taps 4096^2 87.0 -> 56.9 us, 2048^2 28.9 -> 20.4; 26 taps 58.8 -> 38.6; 20 taps 39.9 -> 34.9;
     //   * 10-16 taps keep 64 x 16 / 512 (16 taps 4096^2: 31.4 against 32.8).
-    const bool small_level = (long long)batch * a.Nr * a.Nc < (1LL << 20);
+    const bool small_level = (long long)batch * a.Nr * a.Nc < (1LL << tune::tile_small_level_log2);
     switch (a.hlen) {
 #define X(h)                                                                \
     case h:                                                                 \
@@ -247,7 +248,7 @@ hipError_t try_launch_dwt2_inv_fast(const Inv2DArgs& a, int batch, hipStream_t s
     // 512 as before (18 taps 4096^2: 38.4 against 39.5-40.0); 26 and 30 taps 32 x 16 / 512 (76.0 -> 46.0, 30 taps 52.9
     // against 55.2); every other length 32 x 8 / 256 (20 taps 47.3 -> 44.0, 22: 47.8 -> 43.0, 24: 57.6 -> 52.1, 28: 65.3 ->
     // 60.6, 32: 97.3 -> 73.2, 36: 105.7 -> 73.8, 40: 131.7 -> 89.8, 2048^2 38.4 -> 29.2); profiles/r04p_tilesweep3.txt
-    const bool small_level = (long long)batch * a.Nr * a.Nc < (1LL << 20);
+    const bool small_level = (long long)batch * a.Nr * a.Nc < (1LL << tune::tile_small_level_log2);
     switch (a.hlen) {
 #define X(h)                                                                \
     case h:                                                                 \

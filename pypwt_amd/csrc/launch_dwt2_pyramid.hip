@@ -13,6 +13,7 @@
 
 #include "launch.hpp"
 #include "launch_util.hpp"
+#include "tuning.hpp"
 
 namespace pdwt {
 
@@ -69,7 +70,7 @@ static hipError_t run_inv_t(InvPyr2Args& a, int batch, hipStream_t s) {
 // threads; 512^2: 4.95 against 4.85 us -- profiles/r02y_kbench_tiles.txt)
 template <int HLEN>
 static hipError_t run_inv(InvPyr2Args& a, int batch, hipStream_t s) {
-    if ((long long)batch * a.N0r * a.N0c >= (1LL << 20)) return run_inv_t<HLEN, 64, 16, 512>(a, batch, s);
+    if ((long long)batch * a.N0r * a.N0c >= (1LL << tune::pyr2_inv_big_log2)) return run_inv_t<HLEN, 64, 16, 512>(a, batch, s);
     return run_inv_t<HLEN, 64, 8, 256>(a, batch, s);
 }
 

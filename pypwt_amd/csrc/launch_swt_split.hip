@@ -5,6 +5,7 @@
 
 #include "launch.hpp"
 #include "launch_util.hpp"
+#include "tuning.hpp"
 #include "swt_kernels_args.hpp"
 #include "swt_stream_kernels.hpp"
 #ifndef PDWT_DOUBLE
@@ -168,7 +169,7 @@ static inline v2f mk2h(real_t a, real_t b) {
 // the default is 14 taps from 2^21 samples, 18 below.  Tuning keys "swt_split_fwd" / "swt_split_inv" (environment
 // PDWT_SWT_SPLIT_FWD / _INV): the shortest filter that takes this path at full size, 0 = never, 100 + n = n taps at EVERY size.
 static std::atomic<int>& split_min(bool inverse) {
-    static std::atomic<int> fwd{env_int("PDWT_SWT_SPLIT_FWD", 14)}, inv{env_int("PDWT_SWT_SPLIT_INV", 10)};
+    static std::atomic<int> fwd{env_int("PDWT_SWT_SPLIT_FWD", (int)tune::swt_split_fwd_big_taps)}, inv{env_int("PDWT_SWT_SPLIT_INV", (int)tune::swt_split_inv_taps)};
     return inverse ? inv : fwd;
 }
 int set_swt_split_min(int inverse, int taps) { return split_min(inverse != 0).exchange(taps < 0 ? 0 : taps); }
@@ -212,7 +213,7 @@ bool swt2_split_supported(int hlen, int Nr, int Nc, int f, bool inverse, long lo
     if (min_taps >= 100) {
         min_taps -= 100;  // forced: the same threshold at every size (tests)
     } else if (!inverse) {
-        if (samples < (1LL << 21) && min_taps < 18) min_taps = 18;  // 14 and 16 taps: from 2 M samples (see above)
+        if (samples < (1LL << tune::swt_split_fwd_big_log2) && min_taps < tune::swt_split_fwd_taps) min_taps = (int)tune::swt_split_fwd_taps;  // 14 and 16 taps: from 2 M samples (see above)
     } else {
         // small launches: two launches of one round each cost more than they save until the filter is long -- inverse levels of
         // 256^2 / 512^2: 10 taps 13 | 17-18 us (tiled | split), 16 taps 16 | 21-22, 26 taps 33 | 26-27, 40 taps 31-44 | 22-35;
@@ -222,8 +223,8 @@ bool swt2_split_supported(int hlen, int Nr, int Nc, int f, bool inverse, long lo
         const bool eight_mid = hlen == 8 && f <= 2 && min_taps <= 10 && samples >= (3LL << 19);
         // (up to AND INCLUDING 2^20 samples since round 5: a 1024^2 image is exactly that, and its 12-16-tap inverse is 46-51 us on
         // the tiles against 66-73 on these kernels -- tools/swt_pitch_probe.py, profiles/r05k_swt_inv_at_2p20.txt)
-        if (samples <= (1LL << 20) && min_taps < 24) min_taps = 24;
-        else if (samples < (1LL << 22) && min_taps < 12 && !eight_mid) min_taps = 12;
+        if (samples <= (1LL << tune::swt_split_inv_small_log2) && min_taps < tune::swt_split_inv_small_taps) min_taps = (int)tune::swt_split_inv_small_taps;
+        else if (samples < (1LL << tune::swt_split_inv_mid_log2) && min_taps < tune::swt_split_inv_mid_taps && !eight_mid) min_taps = (int)tune::swt_split_inv_mid_taps;
         // 8 taps (db4, sym4, bior2.4 ...), dilation 1 and 2, from 2048^2 on: the tiled inverse issues one 16-B load per band and
         // tap at 4-B / 8-B alignment there (52-55 us per 2048^2 level against 33 at dilation 4, where the loads are aligned);
         // the two launches stage aligned quads through LDS: 35.6 / 33.4 us, 4096^2 190.8 / 199.2 -> 140.8 / 164.6

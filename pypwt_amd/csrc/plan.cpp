@@ -5,6 +5,7 @@
 // the reference member it replaces.  No CPU fallback exists: without a GPU every entry point
 // that touches data fails with PDWT_ERR_HIP.
 #include "plan.hpp"
+#include "tuning.hpp"
 
 #include <mutex>
 
@@ -463,11 +464,11 @@ void build_schedule(pdwt_plan* p) {
             // (2-tap filters: no rows carried between chunks, the strips are ahead from 2^25 samples on -- forward of 8 x 2048^2
             // 63 -> 56 us, 32 x 1024^2 60 -> 52, 3 x 4096^2 106 -> 88; longer filters lose there: db4 2 x 4096^2 78 -> 83)
             static const int strip_min = lab_env("PDWT_STRIP_MIN_LOG2") ? atoi(lab_env("PDWT_STRIP_MIN_LOG2")) : 0;  // A/B measurements
-            const int min_log2 = strip_min > 0 ? strip_min : (hlen == 2 && sizeof(real_t) == 4 ? 25 : 26);
+            const int min_log2 = strip_min > 0 ? strip_min : (int)(hlen == 2 && sizeof(real_t) == 4 ? tune::strip2_min_log2_haar : tune::strip2_min_log2);
             return force_strip || samples(l) >= (1LL << min_log2);
         };
         static const bool inv_pyr_l1 = lab_env("PDWT_INV_PYR_L1") != nullptr;  // A/B: the tile pyramid for levels 1+2 of any inverse
-        auto pyr_at = [&](int l, bool inverse) { return fusable && !no_pyr && pair_ok(l, inverse) && samples(l) <= (1LL << 20); };
+        auto pyr_at = [&](int l, bool inverse) { return fusable && !no_pyr && pair_ok(l, inverse) && samples(l) <= (1LL << tune::pyr2_max_log2); };
         // Three levels per launch where a small image (at most 2^19 samples, 2^20 over the batch) has three (or five, six, ...) levels
         // left: one launch fewer per direction -- 512^2 db2 L3: 15.6 -> 9.9 us per forward+inverse, 256^2 db4 L5: 26.8 ->
         // 18.4 us, 64 x 128^2 db4 L3: 27.0 -> 20.3 us; at 1024^2 the pairs are ahead (db4 L3: 18.6 against 20.4 us).  Four levels left stay two tile
@@ -489,8 +490,8 @@ void build_schedule(pdwt_plan* p) {
             // 6- and 8-tap plans with six or nine levels left too (with three left their pair + level stays ahead: 1024^2 db4 L3 18.6
             // against 20.4 us): 1024^2 L6 db3 29.7 -> 26.4, db4 31.7 -> 29.0; 2048^2 L7 47.5 -> 42.2, 47.7 -> 43.4
             const bool short_whole = (hlen <= 4 && left % 3 == 0) || (hlen <= 8 && left % 3 == 0 && left >= 6);
-            const long long per_image = short_whole ? (1LL << 20) : (hlen <= 8 ? (1LL << 19) : (1LL << 18));
-            return fusable && !no_pyr3 && left >= 3 && left != 4 && samples(l) <= (1LL << 20) &&
+            const long long per_image = 1LL << (short_whole ? tune::pyr3_image_short_log2 : (hlen <= 8 ? tune::pyr3_image_log2 : tune::pyr3_image_long_log2));
+            return fusable && !no_pyr3 && left >= 3 && left != 4 && samples(l) <= (1LL << tune::pyr3_max_log2) &&
                    (long long)p->lr[l - 1] * p->lc[l - 1] <= per_image && dwt2_pyr3_supported(hlen, p->lr[l - 1], p->lc[l - 1]);
         };
         // Two levels per WAVEFRONT (dwt2_fwd2_wave: A_l stays in registers, overlapping strips).  Correct and
@@ -522,7 +523,7 @@ void build_schedule(pdwt_plan* p) {
             // streams at a time instead of the whole batch's -- 2 / 4 x 2048^2 haar L3 forward 97.7 / 212.7 us level by level, 108.6 /
             // 217.9 fused over the batch, 92.0 / 194.0 fused image by image; L5, 4 images: 349 / 409 / 319 (tools/swt_batch_probe.py,
             // profiles/r05d_swt_batch_probe.txt).  4-tap pairs stay level by level there (db2: 101 against 115 us).
-            if (swt_bytes > (320LL << 20) && p->tune.swt_fused < 2 && !(inverse && sizeof(real_t) == 4) && !(hlen == 2 && sizeof(real_t) == 4))
+            if (swt_bytes > (tune::swt_fused_max_mib << 20) && p->tune.swt_fused < 2 && !(inverse && sizeof(real_t) == 4) && !(hlen == 2 && sizeof(real_t) == 4))
                 return 0;  // "swt_fused" = 2 forces both directions (tests)
             for (int K = (L - l + 1 < 3 ? L - l + 1 : 3); K >= 2; --K) {
                 const bool same_plane = K == 2 && l - 1 >= 1 && l + K - 1 <= L - 1;
@@ -581,9 +582,9 @@ void build_schedule(pdwt_plan* p) {
         // PDWT_NO_TAIL / PDWT_TAIL_WORK_LOG2 / PDWT_TAIL_MIN_K: A/B measurements.
         // (read per plan, not once per process: the parity tests widen the rule to reach every instantiation)
         const bool no_tail = getenv("PDWT_NO_TAIL") != nullptr;
-        const int tail_work_log2 = lab_env("PDWT_TAIL_WORK_LOG2") ? atoi(lab_env("PDWT_TAIL_WORK_LOG2")) : 14;
-        const int tail_min_k = lab_env("PDWT_TAIL_MIN_K") ? atoi(lab_env("PDWT_TAIL_MIN_K")) : 5;
-        const long long tail_batch = lab_env("PDWT_TAIL_BATCH") ? atoll(lab_env("PDWT_TAIL_BATCH")) : 4096;  // largest image taken in batch mode (0 = off)
+        const int tail_work_log2 = lab_env("PDWT_TAIL_WORK_LOG2") ? atoi(lab_env("PDWT_TAIL_WORK_LOG2")) : (int)tune::tail_work_log2;
+        const int tail_min_k = lab_env("PDWT_TAIL_MIN_K") ? atoi(lab_env("PDWT_TAIL_MIN_K")) : (int)tune::tail_min_levels;
+        const long long tail_batch = lab_env("PDWT_TAIL_BATCH") ? atoll(lab_env("PDWT_TAIL_BATCH")) : tune::tail_batch_image;  // largest image taken in batch mode (0 = off)
         auto tail_at = [&](int l) {
             const int K = L - l + 1;
             const long long per_image = (long long)p->lr[l - 1] * p->lc[l - 1];
@@ -604,13 +605,13 @@ void build_schedule(pdwt_plan* p) {
             const bool deep = per_image <= 4 * tail_batch && K >= 5 && per_image * hlen <= 16 * tail_batch;
             // (beyond 2^20 samples only: up to there the three-level tile pyramid takes such batches and is ahead -- 64 x 128^2 db4 L3
             // 20.9 us against 27.4, haar 9.5 against 17.5)
-            const bool few = per_image <= 4 * tail_batch && K >= 3 && p->batch <= 384 && per_image * hlen <= 32 * tail_batch &&
-                             samples(l) > (1LL << 20);
-            if (fusable && !no_tail && (tiny || deep || few) && samples(l) >= (1LL << 20)) {
+            const bool few = per_image <= 4 * tail_batch && K >= 3 && p->batch <= tune::tail_few_batch && per_image * hlen <= 32 * tail_batch &&
+                             samples(l) > (1LL << tune::tail_max_log2);
+            if (fusable && !no_tail && (tiny || deep || few) && samples(l) >= (1LL << tune::tail_max_log2)) {
                 const int Kb = dwt2_tail_max_levels(hlen, p->lr[l - 1], p->lc[l - 1], K);
                 if (Kb >= 1 && (tiny || (deep && Kb >= 5) || (few && Kb >= 3))) return Kb;
             }
-            if (!fusable || no_tail || samples(l) > (1LL << 20) || per_image * hlen > (1LL << tail_work_log2)) return 0;
+            if (!fusable || no_tail || samples(l) > (1LL << tune::tail_max_log2) || per_image * hlen > (1LL << tail_work_log2)) return 0;
             if (K < tail_min_k && !(K >= tail_min_k - 1 && per_image <= 1024)) return 0;
             return dwt2_tail_supported(hlen, p->lr[l - 1], p->lc[l - 1], K) ? K : 0;
         };
@@ -623,13 +624,13 @@ void build_schedule(pdwt_plan* p) {
             // four bands x hlen taps per output from global memory: db4 L2 1015 -> 739 us, but haar L3 458 -> 482; 32 x 32 and below
             // always: haar L3 16384 x 32^2 1176 -> 352, 65536 x 16^2 4520 -> 674, db4 L2 8192 x 32^2 1047 -> 202)
             const long long total = (long long)p->batch * per_image;
-            static const int few = lab_env("PDWT_SWT_TAIL_FEW") ? atoi(lab_env("PDWT_SWT_TAIL_FEW")) : 64;  // A/B measurements
+            static const int few = lab_env("PDWT_SWT_TAIL_FEW") ? atoi(lab_env("PDWT_SWT_TAIL_FEW")) : (int)tune::swt_tail_few;  // A/B measurements
             // ... and the latency regime: a FEW tiny images with two levels and more -- one launch instead of one per level
             // (32 x 32 and below: 16 x 32^2 haar L5 forward+inverse 47 -> 32 us, 8 x 16^2 db2 L2 30 -> 11; one workgroup of 256 threads is
             // too slow for a single 64 x 64 image: haar L6 50 -> 105 us)
             const bool latency = p->batch <= few && L >= 2 && per_image <= 1024;
             if (!latency && per_image > 1024 && hlen < 8) return false;
-            return swt && p->do_separable && !no_tail && tail_batch > 0 && per_image <= 4096 && per_image * hlen <= (1LL << 17) &&
+            return swt && p->do_separable && !no_tail && tail_batch > 0 && per_image <= tune::swt_tail_image && per_image * hlen <= (1LL << 17) &&
                    (total >= (1LL << 20) || latency) && swt2_tail_supported(hlen, p->info.Nr, p->info.Nc, L);
         };
         for (int dir = 0; dir < 2; dir++) {
@@ -665,15 +666,15 @@ void build_schedule(pdwt_plan* p) {
                 // profiles/r02y_bench_cfg3_batch.txt.  Bit 2 of the knob forces the forward too.)
                 // (The fp64 build has no LDS pyramid to prefer.)
                 bool reg_here = ((reg >> dir) & 1) && (dir == 1 || ((reg >> 2) & 1) || sizeof(real_t) == 8 ||
-                                                       (long long)p->batch * p->info.Nr * p->info.Nc <= (1LL << 25));
+                                                       (long long)p->batch * p->info.Nr * p->info.Nc <= (1LL << tune::reg1d_fwd_max_log2));
                 // Round 4 (tools/reg1d_rows.sh, profiles/r04v_reg1d_rows.txt): the register kernels' overlapping 1024-sample
                 // blocks and their launch per three levels only pay on LONG rows of a LARGE transform -- rows of 4096 samples
                 // lose a quarter of every row's blocks to the overlap (4096 x 4096 sym8 L5 forward+inverse 86.6 us against 83.6
                 // for the LDS pyramids, db4 79.6 against 70.6), and below ~2^23 samples one launch of the pyramid beats two
                 // (2^20 samples: db4 16.2 against 14.2 us, 256 rows of 4096: 18.0 against 13.8).  fp32 only (the fp64 build has
                 // no LDS pyramid); bit 3 of the "reg1d" knob lifts the limits (tests).
-                static const int min_log2 = lab_env("PDWT_REG1D_MIN_LOG2") ? atoi(lab_env("PDWT_REG1D_MIN_LOG2")) : 23;
-                static const int min_row = lab_env("PDWT_REG1D_MIN_ROW") ? atoi(lab_env("PDWT_REG1D_MIN_ROW")) : 16384;
+                static const int min_log2 = lab_env("PDWT_REG1D_MIN_LOG2") ? atoi(lab_env("PDWT_REG1D_MIN_LOG2")) : (int)tune::reg1d_min_log2;
+                static const int min_row = lab_env("PDWT_REG1D_MIN_ROW") ? atoi(lab_env("PDWT_REG1D_MIN_ROW")) : (int)tune::reg1d_min_row;
                 // Decided for the PLAN, not per launch: a register first stage followed by a pyramid on the remaining 2^21
                 // samples measured slower than either pure schedule (2^24 samples, db4 L5: 64.6 us against 54.5 / 60.3).
                 if (reg_here && sizeof(real_t) == 4 && !((reg >> 3) & 1)) {

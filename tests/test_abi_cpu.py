@@ -363,3 +363,28 @@ def test_host_ring_of_several_processes(size):
     for r, fp, fn, n, parts, root in res:
         assert fp == b"N%d" % ((r - 1) % size) and fn == b"P%d" % ((r + 1) % size) and n == 300002
         assert parts == [b"G%d" % k for k in range(size)] and root == b"ROOT"
+
+
+def test_dispatch_thresholds_are_a_table_with_provenance():
+    """the dispatch literals of build_schedule and the launchers are rows of csrc/tuning_gfx950.inc -- key,
+    value, evidence file, round -- read through tuning.hpp; every evidence file exists, no key twice, and the sources hold no
+    bare size threshold of their own where a row exists."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "tuning_table.py"), "--check"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import tuning_table
+    rows = tuning_table.rows()
+    assert len(rows) >= 40
+    keys = {k for _, k, _, _, _, _ in rows}
+    for src in ("plan.cpp", "launch_dwt2.hip", "launch_dwt2_fast.hip", "launch_swt_split.hip"):
+        txt = open(os.path.join(ROOT, "pypwt_amd", "csrc", src)).read()
+        assert '#include "tuning.hpp"' in txt, src
+        used = set(re.findall(r"\btune::(\w+)", txt))
+        assert used and used <= keys, (src, used - keys)
+    every = set()
+    for f in os.listdir(os.path.join(ROOT, "pypwt_amd", "csrc")):
+        if f.endswith((".cpp", ".hip")):
+            every |= set(re.findall(r"\btune::(\w+)", open(os.path.join(ROOT, "pypwt_amd", "csrc", f)).read()))
+    assert keys - every <= {"kRows", "kRowCount"} | set(), ("rows nothing reads", sorted(keys - every))

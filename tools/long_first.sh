@@ -1,7 +1,10 @@
 #!/bin/bash
 set -u
-OUT=gpurun_out/pkg1
+OUT=gpurun_out/tune1
 mkdir -p $OUT
-timeout 1200 python -m pytest tests/test_packaging.py tests/test_cython_shim.py -x -q -m gpu > $OUT/pytest.txt 2>&1; echo "pytest rc=$?"
-tail -5 $OUT/pytest.txt
-timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.txt 2>&1; echo "smoke rc=$?"; tail -3 $OUT/smoke.txt
+timeout 2400 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.txt 2>&1; echo "pytest gpu rc=$?"
+grep -E "passed|failed" $OUT/pytest_gpu.txt | tail -2
+timeout 900 python3 tools/retune.py > $OUT/retune.txt 2>&1; echo "retune rc=$?"
+cat $OUT/retune.txt
+timeout 1200 python3 tools/sched_scan.py > $OUT/sched_scan.txt 2>&1; echo "sched_scan rc=$?"
+grep -c "default loses" $OUT/sched_scan.txt; grep "default loses" $OUT/sched_scan.txt | head
