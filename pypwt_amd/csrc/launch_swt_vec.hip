@@ -91,6 +91,12 @@ hipError_t try_launch_swt2_vec(const Swt2DArgs& a, bool inverse, int batch, hipS
 #undef X
         }
     }
+    // Round quantisation (round 6; profiles/r06_sizes_cliff.txt, r06_swt_round_scan.txt, r06_dispatchprobe.txt): a level of 512 of
+    // these tiles is two per CU -- one wavefront of each on every SIMD -- and 17.9 us (1024^2, 14 taps); 520 tiles (1032 rows) put a
+    // third wavefront on the SIMDs of eight CUs and the level takes 22.6 us, the same as 768 tiles (24.6): a level lasts as long as its
+    // fullest SIMD.  Narrower tiles (64 or 32 columns: 2080 one-wavefront workgroups, 8-9 per CU) were built and measured: 22.2 us --
+    // the unit that fills up is the SIMD, not the CU, and 2080 wavefronts on 1024 SIMDs are 2-3 per SIMD like 520 x 4.  What would help
+    // is bands of unequal height (64 bands of 16-17 rows: exactly two wavefronts per SIMD again); not built.
     // fp64, more than 24 taps: a 128-column tile of doubles is 112-145 KB of LDS -- one workgroup of four wavefronts per CU.  64 x 16
     // tiles of 256 threads are 56 KB: two workgroups, eight wavefronts (round 5; forward + inverse, three levels: 26 taps 1024^2
     // 677 -> 333 us, 32 taps 547 -> 230, 40 taps 512^2 1003 -> 483 -- but 40 taps 2048^2 3288 -> 3934: images below 2^22 samples only;

@@ -1053,6 +1053,28 @@ def test_swt_any_width_and_any_row_count(wname):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("wname,shape,levels", [("db7", (1040, 1024), 2), ("sym8", (1024, 1100), 1), ("db3", (1080, 1080), 2), ("db12", (1200, 1040), 1),
+                                                ("db5", (688, 1152), 2)])
+def test_swt_at_sizes_just_past_a_power_of_two(wname, shape, levels):
+    """Round 6: the sizes where the tile grid spills past a whole number of rounds (1040 x 1024: 520 tiles
+    on 256 CUs; the inverse crosses to the two-launch kernels there) -- slower per sample than 1024^2 (profiles/r06_sizes_cliff.txt,
+    mechanism in launch_swt_vec.hip), and exactly as correct: every band against the oracle, the soft threshold folded into the
+    inverse, the reconstruction."""
+    from pypwt_amd import Wavelets
+    x = oracle.hash_input(shape, 6160)
+    w = Wavelets(x, wname, levels, do_swt=1)
+    w.forward()
+    ref = oracle.forward(x, wname, w.levels, do_swt=1)
+    for k, (g, r) in enumerate(zip(flat_coeffs(w), ref)):
+        assert np.abs(g - r).max() <= 2e-6 * (1 + w.levels) * max(float(np.abs(r).max()), 255.0), (wname, shape, k)
+    w.soft_threshold(7.5)
+    w.inverse()
+    thr = oracle.threshold(ref, shape, w.levels, "soft", 7.5, do_swt=1)
+    want = oracle.inverse(thr, shape, wname, w.levels, do_swt=1)
+    assert np.abs(w.image - want).max() <= 4e-6 * (1 + w.levels) * 255.0, (wname, shape)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("wname,shape,levels", [("haar", (1000, 1000), 3), ("db4", (1000, 1000), 3), ("sym8", (200, 72), 2), ("db2", (260, 264), 2),
                                                 ("db4", (500, 1000), 4), ("coif2", (96, 1192), 3)])
 def test_pyramid_on_rows_of_eight_but_not_sixteen(wname, shape, levels):
