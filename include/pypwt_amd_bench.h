@@ -67,7 +67,8 @@ long long pdwt_copy_capacity(pdwt_handle h); /* the largest `elems` pdwt_time_co
  *                    history in LDS, both passes register-blocked -- no halo is filtered twice).  Default 18 taps: 18 taps
  *                    from 2^26 samples per launch; from 20 taps the inverse from 2^24 and the forward from 2^25; the forward
  *                    of 28 taps and more from 2^24, the inverse of 32 taps and more from 2^22; 0 = never;
- *                    100 + n = n taps (10-40) at every size the kernels take (tests).  Part of the plan's snapshot.  fp32 only.
+ *                    100 + n = n taps (10-40) at every size the kernels take (tests).  Part of the plan's snapshot.  The fp64
+ *                    library: forward 18-36 taps from 2^24 samples (up to 32 taps from 2^22), inverse 18-26 taps from 2^22.
  *   "reg1d"          bit 0 / bit 1: the forward / inverse 1D DWT levels run three at a time in registers
  *                    (dwt1_reg_kernels.hpp) where the rows qualify (even hlen <= 20, rows of >= 2048 samples that
  *                    are multiples of 32); default 3; 0 = the workgroup-wide LDS pyramids (57.6 vs 69.5 us per

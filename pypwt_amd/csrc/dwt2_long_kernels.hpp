@@ -43,10 +43,16 @@ extern __device__ unsigned long long pdwt_long_prof[];
 #else
 #define PDWT_LONG_CLK(k) ((void)0)
 #endif
-// the items of a pass, tid + k NT: a fixed number of rounds, unrolled (the scheduler overlaps the tail of one item -- stores,
-// LDS writes -- with the first reads of the next)
+// the items of a pass, tid + k NT: a fixed number of rounds, unrolled in the fp32 library (the scheduler overlaps the tail of one
+// item -- stores, LDS writes -- with the first reads of the next); the fp64 library keeps the loop (twice the registers per value:
+// two items in flight spill)
+#ifdef PDWT_DOUBLE
+#define PDWT_LONG_ITEMS(it, tid, ITEMS, NT) \
+    _Pragma("unroll 1") for (int it = (tid), pdwt_k_ = 0; pdwt_k_ < ((ITEMS) + (NT) - 1) / (NT); ++pdwt_k_, it += (NT))
+#else
 #define PDWT_LONG_ITEMS(it, tid, ITEMS, NT) \
     _Pragma("unroll") for (int it = (tid), pdwt_k_ = 0; pdwt_k_ < ((ITEMS) + (NT) - 1) / (NT); ++pdwt_k_, it += (NT))
+#endif
 #if PDWT_LONG_DIAG & 16
 #define PDWT_LONG_SYNC() ((void)0)
 #else

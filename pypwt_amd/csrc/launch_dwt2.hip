@@ -186,11 +186,15 @@ static std::atomic<int>& long_min_taps(bool inverse) {
 int set_long_min_taps(int inverse, int taps) { return long_min_taps(inverse != 0).exchange(taps < 0 ? 0 : taps); }
 int get_long_min_taps(int inverse) { return long_min_taps(inverse != 0).load(std::memory_order_relaxed); }
 static bool long_kernels_for(long long samples, int hlen, bool inverse) {
-    if (sizeof(real_t) != 4) return false;
     const int m = g_active_tuning ? (inverse ? g_active_tuning->long_inv : g_active_tuning->long_fwd) : get_long_min_taps(inverse);
     if (m <= 0) return false;
     if (m >= 100) return hlen >= m - 100;  // forced: every size
     if (hlen < m) return false;
+    if (sizeof(real_t) == 8) {  // the fp64 library (profiles/r06_f64_long_ab.txt): the lengths whose tap tables fit the register file
+        if (inverse) return hlen <= tune::long_f64_inv_max_taps && samples >= (1LL << tune::long_f64_min_log2);
+        return (hlen <= tune::long_f64_fwd_max_taps && samples >= (1LL << tune::long_f64_fwd_log2)) ||
+               (hlen <= tune::long_f64_fwd_mid_max_taps && samples >= (1LL << tune::long_f64_min_log2));
+    }
     if (samples >= (1LL << tune::long_any_log2)) return true;
     if (hlen < tune::long_taps20) return false;
     if (samples >= (1LL << (inverse ? tune::long_inv_log2 : tune::long_fwd_log2))) return true;

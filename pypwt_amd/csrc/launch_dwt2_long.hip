@@ -1,40 +1,52 @@
 // launch_dwt2_long.hip -- launchers of the strip-streaming 2D DWT level kernels for long filters (dwt2_long_kernels.hpp).
 //
 // try_launch_* return hipErrorNotSupported when the level does not meet the kernels' preconditions; the caller then falls
-// back to the LDS tiles.  fp32 library only (the fp64 library's long filters run on the stream kernels).
+// back to the LDS tiles.
 //
 // Shapes (tools/longbench.hip on MI355X, profiles/r06_longbench_*.txt): a strip of 64 coefficient columns, 16 coefficient
 // rows per step, 256 threads; forward: 4 output columns per row item, 4 output rows per column item; inverse: 4 coefficient
 // columns per row item, 8 output row pairs per column item.  56-58 KB of LDS at 40 taps: two workgroups per CU, up to 256 VGPRs
 // each, which is what lets the tap tables live in vector registers.
+// The fp64 library: strips of 32 columns and 128 threads (an element is 8 bytes: 61-64 KB of LDS at 40 taps, two workgroups of two
+// wavefronts per CU -- one wavefront per SIMD with up to 512 registers, of which the tap tables take 160-168).
 #include "launch.hpp"
 #include "launch_util.hpp"
 
-#ifndef PDWT_DOUBLE
 #include "dwt2_long_kernels.hpp"
 
 namespace pdwt {
 
-static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+static v2f mk2_host(real_t x, real_t y) {
+    v2f r;
+    r.x = x;
+    r.y = y;
+    return r;
+}
 
-constexpr int kLongTXC = 64, kLongTY = 16, kLongNT = 256;
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & (4 * sizeof(real_t) - 1)) == 0; }  // a 4-element group
+
+constexpr bool kLongF64 = sizeof(real_t) == 8;
+constexpr int kLongTXC = kLongF64 ? 32 : 64, kLongTY = 16, kLongNT = kLongF64 ? 128 : 256, kLongMinB = kLongF64 ? 1 : 2;
 
 // Rows per segment: the walk of a workgroup re-filters the D history rows of its segment (hlen - 2 input rows forward,
 // hlen / 2 coefficient rows inverse), so long segments are cheaper -- but the chip wants two workgroups per CU (512): one
 // 4096^2 level is 32 strips x 16 segments of 128 rows, a batch of 16 images one segment per strip.
-static int long_seg(int rows, int strips, int batch, int hint) {
-    if (hint > 0) return cdiv(hint, kLongTY) * kLongTY;
+static int long_seg(int rows, int strips, int batch, int hint, int ty = kLongTY) {
+    if (hint > 0) return cdiv(hint, ty) * ty;
     const long long units = (long long)strips * (batch > 0 ? batch : 1);
     long long segs = cdivll(512, units);
     if (segs < 1) segs = 1;
     int seg = (int)cdivll(rows, segs);
-    seg = cdiv(seg, kLongTY) * kLongTY;
-    return seg < kLongTY ? kLongTY : seg;
+    seg = cdiv(seg, ty) * ty;
+    return seg < ty ? ty : seg;
 }
 
 template <int HLEN>
 static hipError_t run_fwd(const Fwd2DArgs& g, int batch, int seg_hint, hipStream_t s) {
-    constexpr int TXC = kLongTXC, TY = kLongTY, NT = kLongNT, KB = 4, M = 4, XB = 1, MINB = 2;
+    // fp64: smaller register blocks, and from 32 taps on steps of 8 output rows (half the staged groups in flight): 40 taps keep 68 B of
+    // scratch (16-row steps: 296 B and 608 us per 4096^2 L3 forward against 266 on the tiles)
+    constexpr int TXC = kLongTXC, TY = kLongF64 && HLEN >= 32 ? 8 : kLongTY, NT = kLongNT, KB = kLongF64 ? 2 : 4, M = kLongF64 ? 2 : 4, XB = 1,
+                  MINB = kLongMinB;
     using G = FwdLongGeom<HLEN, TXC, TY>;
     static std::atomic<bool> big[64] = {};
     constexpr size_t lds = (size_t)G::LDS_REALS * sizeof(real_t);
@@ -47,19 +59,16 @@ static hipError_t run_fwd(const Fwd2DArgs& g, int batch, int seg_hint, hipStream
     a.Nr = g.Nr; a.Nc = g.Nc; a.Nr2 = g.Nr2; a.Nc2 = g.Nc2;
     a.in_bstride = g.in_bstride; a.out_bstride = g.out_bstride;
     a.strips = cdiv(g.Nc2, TXC);
-    a.seg = long_seg(g.Nr2, a.strips, batch, seg_hint);
+    a.seg = long_seg(g.Nr2, a.strips, batch, seg_hint, TY);
     a.segs = cdiv(g.Nr2, a.seg);
-    for (int i = 0; i < kMaxTaps; i++) {
-        a.fb.t[i].x = g.fb.lo[i];
-        a.fb.t[i].y = g.fb.hi[i];
-    }
+    for (int i = 0; i < kMaxTaps; i++) a.fb.t[i] = mk2_host(g.fb.lo[i], g.fb.hi[i]);
     hipLaunchKernelGGL(kern, dim3(8 * cdiv(a.strips * a.segs, 8), batch), dim3(NT), lds, s, a);
     return hipGetLastError();
 }
 
 template <int HLEN>
 static hipError_t run_inv(const Inv2DArgs& g, int batch, int seg_hint, hipStream_t s) {
-    constexpr int TXC = kLongTXC, TY = kLongTY, NT = kLongNT, KB = 4, M = 8, XB = 1, MINB = 2;
+    constexpr int TXC = kLongTXC, TY = kLongTY, NT = kLongNT, KB = 4, M = 8, XB = 1, MINB = kLongMinB;
     using G = InvLongGeom<HLEN, TXC, TY>;
     static std::atomic<bool> big[64] = {};
     constexpr size_t lds = (size_t)G::LDS_REALS * sizeof(real_t);
@@ -111,9 +120,3 @@ hipError_t try_launch_dwt2_inv_long(const Inv2DArgs& a, int batch, hipStream_t s
 }
 
 }  // namespace pdwt
-#else
-namespace pdwt {
-hipError_t try_launch_dwt2_fwd_long(const Fwd2DArgs&, int, hipStream_t, int) { return hipErrorNotSupported; }
-hipError_t try_launch_dwt2_inv_long(const Inv2DArgs&, int, hipStream_t, int) { return hipErrorNotSupported; }
-}  // namespace pdwt
-#endif

@@ -77,7 +77,14 @@ static PDWT_DEVICE v2f fma2_ty(v2f p, v2f t, v2f acc) { return fma2(p, bc(t.y), 
 static PDWT_DEVICE v2f fma2_s(v2f p, v2f t, v2f acc) { return fma2(p, t, acc); }
 static PDWT_DEVICE v2f fma2_bx_v(v2f p, v2f t, v2f acc) { return fma2(bc(p.x), t, acc); }
 static PDWT_DEVICE v2f fma2_by_v(v2f p, v2f t, v2f acc) { return fma2(bc(p.y), t, acc); }
+#ifdef PDWT_CPU_EMU
 static PDWT_DEVICE v2f in_vgprs(v2f t) { return t; }
+#else
+static __device__ __forceinline__ v2f in_vgprs(v2f t) {  // fp64: a pair is four vector registers
+    asm volatile("" : "+v"(t));
+    return t;
+}
+#endif
 #endif
 
 // Reads 16 B from LDS as ONE ds_read_b128 (256 B/clk) even when only some components are used

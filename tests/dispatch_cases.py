@@ -51,6 +51,7 @@ CASES = [
     ("swt2", "db4", (256, 256), 2, 1, "f64"),        # 8 taps: tiles forward, stream kernels inverse
     ("swt2", "db2", (30, 44), 2, 1, "f64"),          # 4 taps, dilation does not divide the rows: tiles both ways
     ("dwt2", "db20", (1024, 1024), 1, 1, "f64"),     # 40 taps, 2^20 samples: the inverse as row + column launches of the stream kernels
+    ("dwt2", "db10", (2048, 2048), 1, 1, "f64"),     # 20 taps, 2^22 samples: the strip-streaming kernels in both directions
 ]
 
 

@@ -170,3 +170,33 @@ def test_long_full_size_default_dispatch_every_element():
         os.environ["PDWT_NO_TAIL"] = "1"
         lib.pdwt_set_tuning(b"long_fwd", prev[0])
         lib.pdwt_set_tuning(b"long_inv", prev[1])
+
+
+@pytest.mark.parametrize("wname,shape,levels", [("db9", (256, 264), 2), ("db10", (192, 512), 2), ("db13", (320, 256), 2), ("db16", (256, 136), 1),
+                                                ("db18", (128, 264), 1), ("db20", (136, 256), 1), ("sym20", (512, 128), 2)])
+def test_long_kernels_of_the_fp64_library(wname, shape, levels):
+    """The fp64 library (the reference's DOUBLEPRECISION build, pdwt/src/filters.h:16-30) runs the same kernels on strips of 32
+    columns (launch_dwt2_long.hip); forced on from 10 taps at every size and compared with the fp64 oracle at 1e-12: both
+    directions, every length class (step heights 16 and 8, both parities of hlen / 2)."""
+    from pypwt_amd import BatchedWavelets64, _lib
+    lib = _lib.load("f64")
+    prev = (lib.pdwt_set_tuning(b"long_fwd", 110), lib.pdwt_set_tuning(b"long_inv", 110))
+    try:
+        x = oracle.hash_input(shape, 888, scale=255.0).astype(np.float64)
+        x += 1e-9 * (np.arange(x.size) % 1009).reshape(x.shape)
+        plan = BatchedWavelets64(1, shape[0], shape[1], wname, levels, img=x[None])
+        plan.enable_kernel_timing(True)
+        plan.reset_kernel_times()
+        plan.forward()
+        ref = oracle.forward(x, wname, plan.levels, double="full")
+        for num, r in enumerate(ref):
+            g = plan.coeff_at(num, 0)
+            assert g.dtype == np.float64 and np.abs(g - r).max() <= 1e-12 * max(1.0, float(np.abs(r).max())), (wname, num)
+        plan.inverse()
+        fams = list(zip([n for n, _ in plan.kernel_times()], plan.kernel_families()))
+        assert ("dwt2_fwd_level", "long") in fams and ("dwt2_inv_level", "long") in fams, fams
+        want = oracle.inverse(ref, shape, wname, plan.levels, double="full")
+        assert np.abs(plan.image_at(0) - want).max() <= 1e-11 * 255, wname
+    finally:
+        lib.pdwt_set_tuning(b"long_fwd", prev[0])
+        lib.pdwt_set_tuning(b"long_inv", prev[1])

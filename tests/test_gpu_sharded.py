@@ -87,7 +87,13 @@ def test_bench_line_names_the_longest_kernel_and_carries_the_measured_ceiling():
     assert out["config"]["workload"].startswith("cfg2") and out["n_gpus"] == 1
     timed = [k for k in out["kernels"] if "isolated_us" in k]
     assert len(timed) >= 2
-    assert rf["avg_us"] == max(k["isolated_us"] for k in timed)  # the longest of the re-timed candidates
+    # the longest of the re-timed candidates -- each judged by its isolated timing unless that is more than 10 % shorter than what the
+    # launch takes inside the step (round 6: bench.judged_duration; cfg4's fused inverse is the case it exists for)
+    import bench
+    assert rf["avg_us"] == max(bench.judged_duration(k)[0] for k in timed)
+    assert rf["avg_us_basis"] in ("isolated", "in_step") and rf["isolated_us"] is not None and rf["in_step_us"] is not None
+    assert out["target"]["north_star_frac"] == 0.70 and out["target"]["met"] == (out["target"]["end_to_end_frac"] >= 0.70)
+    assert abs(out["target"]["end_to_end_frac"] - e2e["frac_of_hbm_peak"]) < 1e-12
     assert rf["kernel"] in ("dwt2_inv_level[L1]", "dwt2_fwd_level[L1]")
     assert 0.3 < rf["frac"] < 1.0 and abs(rf["frac"] - rf["achieved"] / 8000.0) < 1e-9
     assert rf["copy_ceiling_GBps"] > 3000 and rf["copy_ceiling_bytes"] == rf["algorithmic_bytes_per_launch"]
