@@ -704,7 +704,7 @@ def kernel_profile(plan, step, cfg, config_name, B, steps, step_us=None):
     # HBM bytes per launch of that kernel from the rocprofv3 PMC passes of this same command
     # (FETCH_SIZE x2 + WRITE_SIZE, collected separately; tools/prof.sh + tools/summarize_pmc.py).
     # Counters cannot be read from inside the process, so the committed measurement is quoted.
-    for tag in ("r05", "r04", "r03", "r02", "r01"):
+    for tag in ("r06", "r05", "r04", "r03", "r02", "r01"):
         tpath = os.path.join(ROOT, "profiles", "%s_traffic_%s.json" % (tag, config_name))
         if B == 1 and os.path.exists(tpath):
             try:

@@ -43,6 +43,10 @@ static int long_seg(int rows, int strips, int batch, int hint, int ty = kLongTY)
 
 template <int HLEN>
 static hipError_t run_fwd(const Fwd2DArgs& g, int batch, int seg_hint, hipStream_t s) {
+    // fp64, 40 taps: 160 tap registers + the staged rows in flight leave 68 B of scratch and no gain over the tiles
+    // (profiles/r06_f64_long_ab.txt: 269 against 263 us): not built, the library holds no kernel that spills
+    if constexpr (kLongF64 && HLEN > 38) return hipErrorNotSupported;
+    else {
     // fp64: smaller register blocks, and from 32 taps on steps of 8 output rows (half the staged groups in flight): 40 taps keep 68 B of
     // scratch (16-row steps: 296 B and 608 us per 4096^2 L3 forward against 266 on the tiles)
     constexpr int TXC = kLongTXC, TY = kLongF64 && HLEN >= 32 ? 8 : kLongTY, NT = kLongNT, KB = kLongF64 ? 2 : 4, M = kLongF64 ? 2 : 4, XB = 1,
@@ -64,6 +68,7 @@ static hipError_t run_fwd(const Fwd2DArgs& g, int batch, int seg_hint, hipStream
     for (int i = 0; i < kMaxTaps; i++) a.fb.t[i] = mk2_host(g.fb.lo[i], g.fb.hi[i]);
     hipLaunchKernelGGL(kern, dim3(8 * cdiv(a.strips * a.segs, 8), batch), dim3(NT), lds, s, a);
     return hipGetLastError();
+    }
 }
 
 template <int HLEN>

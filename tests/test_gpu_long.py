@@ -194,7 +194,8 @@ def test_long_kernels_of_the_fp64_library(wname, shape, levels):
             assert g.dtype == np.float64 and np.abs(g - r).max() <= 1e-12 * max(1.0, float(np.abs(r).max())), (wname, num)
         plan.inverse()
         fams = list(zip([n for n, _ in plan.kernel_times()], plan.kernel_families()))
-        assert ("dwt2_fwd_level", "long") in fams and ("dwt2_inv_level", "long") in fams, fams
+        hlen = oracle.filters(wname)[0]
+        assert (("dwt2_fwd_level", "long") in fams) == (hlen <= 38) and ("dwt2_inv_level", "long") in fams, fams  # (40 taps forward: not built in fp64)
         want = oracle.inverse(ref, shape, wname, plan.levels, double="full")
         assert np.abs(plan.image_at(0) - want).max() <= 1e-11 * 255, wname
     finally:
