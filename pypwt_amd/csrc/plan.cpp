@@ -523,7 +523,10 @@ void build_schedule(pdwt_plan* p) {
             // streams at a time instead of the whole batch's -- 2 / 4 x 2048^2 haar L3 forward 97.7 / 212.7 us level by level, 108.6 /
             // 217.9 fused over the batch, 92.0 / 194.0 fused image by image; L5, 4 images: 349 / 409 / 319 (tools/swt_batch_probe.py,
             // profiles/r05d_swt_batch_probe.txt).  4-tap pairs stay level by level there (db2: 101 against 115 us).
-            if (swt_bytes > (tune::swt_fused_max_mib << 20) && p->tune.swt_fused < 2 && !(inverse && sizeof(real_t) == 4) && !(hlen == 2 && sizeof(real_t) == 4))
+            // Round 6: on rows that are not whole 16-B groups the level kernels are the ones that lose (4095 x 4093 db2 L4 forward 434 us level
+            // by level, 327 fused; 16 x 1000 x 1002: 405 / 307; aligned sizes 296 / 323: profiles/r06_swt4_fwd_ab.txt)
+            const bool odd4 = hlen == 4 && sizeof(real_t) == 4 && tune::swt4_fwd_fused_odd && (p->info.Nc % 4) != 0;
+            if (swt_bytes > (tune::swt_fused_max_mib << 20) && p->tune.swt_fused < 2 && !(inverse && sizeof(real_t) == 4) && !(hlen == 2 && sizeof(real_t) == 4) && !odd4)
                 return 0;  // "swt_fused" = 2 forces both directions (tests)
             for (int K = (L - l + 1 < 3 ? L - l + 1 : 3); K >= 2; --K) {
                 const bool same_plane = K == 2 && l - 1 >= 1 && l + K - 1 <= L - 1;

@@ -38,6 +38,7 @@ struct Swt4Args {
     int strips, segs, seg_rows;  // seg_rows: phase rows a wavefront owns (multiple of 8)
     real_t beta[2];     // inverse: soft threshold of each level's details (0 = none)
     real_t lo[4], hi[4];
+    SwtWalk wk;         // swt_walk(Nr, Nc, f0, 4): planes of any size (swt2_fused_kernels.hpp)
 };
 
 template <int F0>
@@ -117,7 +118,7 @@ PDWT_DEVICE void swt4_fwd_level(const Swt4Args& a, WaveReg<real_t, 4>& ain, Wave
 }
 
 // step R of a group of 8 rows: walk row w = g0 + R is phase row i0 - 3 + w
-template <int F0, int R>
+template <int F0, bool GEN, int R>
 PDWT_DEVICE void swt4_fwd_step(const Swt4Args& a, Swt4FwdState<F0>& st, const real_t* in, int g0, int i0, int rows_phase, int py) {
     using G = Swt4Geom<F0>;
     const int w = g0 + R;
@@ -127,9 +128,9 @@ PDWT_DEVICE void swt4_fwd_step(const Swt4Args& a, Swt4FwdState<F0>& st, const re
         ww = ww < last ? ww : last;
         int p = i0 - G::Wf_before + ww;
         p = ((p % rows_phase) + rows_phase) % rows_phase;
-        const real_t* row = in + (long long)(py + F0 * p) * a.Nc;
+        const real_t* row = in + (long long)swt_walk_row<GEN, F0>(a.wk, a.Nr, py, p) * a.Nc;
         PDWT_WAVE_LANES(lane) {
-            const v4f q = wave_ld16(row, st.off.mine(lane)[0]);
+            const v4f q = swt_ld16<GEN>(row, st.off.mine(lane)[0]);
             real_t* v = st.ld.mine(lane) + 4 * ((R + G::NR - 1) % G::NR);
             v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
         }
@@ -143,7 +144,7 @@ PDWT_DEVICE void swt4_fwd_step(const Swt4Args& a, Swt4FwdState<F0>& st, const re
     }
     auto rowoff = [&](int rel) -> unsigned {  // owned row `rel` of the segment -> byte offset of that row in a plane
         const bool ow = rel >= 0 && rel < a.seg_rows && i0 + rel < rows_phase;
-        return ow ? kRealBytes * (unsigned)(py + F0 * (i0 + rel)) * (unsigned)a.Nc : kSwtRowDropped;
+        return ow ? kRealBytes * (unsigned)swt_walk_row<GEN, F0>(a.wk, a.Nr, py, i0 + rel) * (unsigned)a.Nc : kSwtRowDropped;
     };
     // level A: input row w (ring slot w mod 4) emits its row w - 2, i.e. owned row w - 2 - 3
     swt4_fwd_level<G::DA, 4, R % 4>(a, a0, st.ringA, a1, st.off, st.bH[0], st.bV[0], st.bD[0], rowoff(w - 5));
@@ -155,32 +156,33 @@ PDWT_DEVICE void swt4_fwd_step(const Swt4Args& a, Swt4FwdState<F0>& st, const re
     }
 }
 
-template <int F0, int R>
+template <int F0, bool GEN, int R>
 PDWT_DEVICE void swt4_fwd_group(const Swt4Args& a, Swt4FwdState<F0>& st, const real_t* in, int g0, int i0, int rows_phase, int py) {
     if constexpr (R < Swt4Geom<F0>::P) {
-        swt4_fwd_step<F0, R>(a, st, in, g0, i0, rows_phase, py);
-        swt4_fwd_group<F0, R + 1>(a, st, in, g0, i0, rows_phase, py);
+        swt4_fwd_step<F0, GEN, R>(a, st, in, g0, i0, rows_phase, py);
+        swt4_fwd_group<F0, GEN, R + 1>(a, st, in, g0, i0, rows_phase, py);
     }
 }
 
 // wavefront `w` of the launch: (image, phase, segment, strip)
-template <int F0>
+template <int F0, bool GEN = false>
 PDWT_DEVICE void swt4_fwd_fused(const Swt4Args& a, long long w) {
     using G = Swt4Geom<F0>;
     const int strip = (int)(w % a.strips);
     long long t = w / a.strips;
     const int seg = (int)(t % a.segs);
     t /= a.segs;
-    const int py = (int)(t % F0);
-    const long long img = t / F0;
-    const int rows_phase = a.Nr / F0;
+    const int phases = GEN ? a.wk.phases : F0;
+    const int py = (int)(t % phases);
+    const long long img = t / phases;
+    const int rows_phase = GEN ? a.wk.rows_phase : a.Nr / F0;
     const int i0 = seg * a.seg_rows;
     const long long boff = img * a.bstride;
     const real_t* in = a.in + boff;
     Swt4FwdState<F0> st;
     PDWT_WAVE_LANES(lane) {
-        const int x = strip * 4 * G::Vf + 4 * (lane - G::fwd_left);
-        // halo columns wrap periodically (Nc % 4 == 0: a group never straddles); lanes far right of the row end re-read
+        const int x = (GEN ? swt_strip_x0(a.wk, strip, 4 * G::Vf) : strip * 4 * G::Vf) + 4 * (lane - G::fwd_left);
+        // halo columns wrap periodically (a group never straddles: Nc % 4 == 0 or SwtWalk::pad); lanes far right of the row end re-read
         // the row's last group (nothing of theirs is used)
         int xl = x < 0 ? x + a.Nc : (x >= a.Nc ? x - a.Nc : x);
         if (x >= a.Nc + 4 * G::fwd_right) xl = a.Nc - 4;
@@ -199,9 +201,9 @@ PDWT_DEVICE void swt4_fwd_fused(const Swt4Args& a, long long w) {
     for (int p = 0; p < G::NR - 1; ++p) {
         int pr = i0 - G::Wf_before + p;
         pr = ((pr % rows_phase) + rows_phase) % rows_phase;
-        const real_t* row = in + (long long)(py + F0 * pr) * a.Nc;
+        const real_t* row = in + (long long)swt_walk_row<GEN, F0>(a.wk, a.Nr, py, pr) * a.Nc;
         PDWT_WAVE_LANES(lane) {
-            const v4f q = wave_ld16(row, st.off.mine(lane)[0]);
+            const v4f q = swt_ld16<GEN>(row, st.off.mine(lane)[0]);
             real_t* v = st.ld.mine(lane) + 4 * p;
             v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
         }
@@ -209,7 +211,7 @@ PDWT_DEVICE void swt4_fwd_fused(const Swt4Args& a, long long w) {
     PDWT_WAIT_VMEM();
     // seg_rows + 9 walk rows in groups of 8 (seg_rows is a multiple of 8: two extra groups cover the 9)
     const int ngroups = a.seg_rows / G::P + 2;
-    for (int g = 0; g < ngroups; ++g) swt4_fwd_group<F0, 0>(a, st, in, g * G::P, i0, rows_phase, py);
+    for (int g = 0; g < ngroups; ++g) swt4_fwd_group<F0, GEN, 0>(a, st, in, g * G::P, i0, rows_phase, py);
 }
 
 
@@ -232,21 +234,21 @@ struct Swt4InvState {
     RowBuf bo;
 };
 
-template <int F0, int NRI, int SLOT>
+template <int F0, int NRI, bool GEN, int SLOT>
 PDWT_DEVICE void swt4_inv_load(const Swt4Args& a, Swt4InvState<F0, NRI>& st, long long boff, int ww, int i0, int rows_phase, int py) {
     using G = Swt4Geom<F0>;
     int pB = i0 - G::Wi_before + ww, pA = pB - 2;
     pB = ((pB % rows_phase) + rows_phase) % rows_phase;
     pA = ((pA % rows_phase) + rows_phase) % rows_phase;
-    const unsigned roB = kRealBytes * (unsigned)(py + F0 * pB) * (unsigned)a.Nc;
+    const unsigned roB = kRealBytes * (unsigned)swt_walk_row<GEN, F0>(a.wk, a.Nr, py, pB) * (unsigned)a.Nc;
     const bool usedA = ww >= G::Wi_before;  // uniform
-    const unsigned roA = usedA ? kRealBytes * (unsigned)(py + F0 * pA) * (unsigned)a.Nc : roB;
+    const unsigned roA = usedA ? kRealBytes * (unsigned)swt_walk_row<GEN, F0>(a.wk, a.Nr, py, pA) * (unsigned)a.Nc : roB;
     const real_t* pl[7] = {a.in, a.H[1], a.V[1], a.D[1], usedA ? a.H[0] : a.in, usedA ? a.V[0] : a.in, usedA ? a.D[0] : a.in};
     PDWT_WAVE_LANES(lane) {
         real_t* base = st.ld.mine(lane) + 4 * 7 * SLOT;
 #pragma unroll
         for (int q = 0; q < 7; ++q) {
-            const v4f w4 = wave_ld16(pl[q] + boff, st.off.mine(lane)[0] + (q < 4 ? roB : roA));
+            const v4f w4 = swt_ld16<GEN>(pl[q] + boff, st.off.mine(lane)[0] + (q < 4 ? roB : roA));
             base[4 * q] = w4.x; base[4 * q + 1] = w4.y; base[4 * q + 2] = w4.z; base[4 * q + 3] = w4.w;
         }
     }
@@ -306,7 +308,7 @@ PDWT_DEVICE void swt4_inv_level(const Swt4Args& a, WaveReg<real_t, 4>& ain, Wave
     }
 }
 
-template <int F0, int NRI, int R>
+template <int F0, int NRI, bool GEN, int R>
 PDWT_DEVICE void swt4_inv_step(const Swt4Args& a, Swt4InvState<F0, NRI>& st, int g0, int i0, int rows_phase, int py, long long boff) {
     using G = Swt4Geom<F0>;
     const int w = g0 + R;
@@ -314,7 +316,7 @@ PDWT_DEVICE void swt4_inv_step(const Swt4Args& a, Swt4InvState<F0, NRI>& st, int
     {
         int ww = w + NRI - 1;
         ww = ww < last ? ww : last;
-        swt4_inv_load<F0, NRI, (R + NRI - 1) % NRI>(a, st, boff, ww, i0, rows_phase, py);
+        swt4_inv_load<F0, NRI, GEN, (R + NRI - 1) % NRI>(a, st, boff, ww, i0, rows_phase, py);
     }
     PDWT_ROW_FENCE();
     WaveReg<real_t, 4> cur, mid, res;
@@ -337,68 +339,69 @@ PDWT_DEVICE void swt4_inv_step(const Swt4Args& a, Swt4InvState<F0, NRI>& st, int
     swt4_inv_level<G::DA, 4, (R + 2) % 4>(a, mid, det, a.beta[0], st.ringA, res);
     const int rel = w - (G::Wi_before + 3);
     const bool ow = rel >= 0 && rel < a.seg_rows && i0 + rel < rows_phase;
-    const unsigned ro = ow ? kRealBytes * (unsigned)(py + F0 * (i0 + rel)) * (unsigned)a.Nc : kSwtRowDropped;
+    const unsigned ro = ow ? kRealBytes * (unsigned)swt_walk_row<GEN, F0>(a.wk, a.Nr, py, i0 + rel) * (unsigned)a.Nc : kSwtRowDropped;
     PDWT_WAVE_LANES(lane) {
         const real_t* v = res.mine(lane);
         row_st16(st.bo, st.off.mine(lane)[1] + ro, v[0], v[1], v[2], v[3]);
     }
 }
 
-template <int F0, int NRI, int R>
+template <int F0, int NRI, bool GEN, int R>
 PDWT_DEVICE void swt4_inv_group(const Swt4Args& a, Swt4InvState<F0, NRI>& st, int g0, int i0, int rows_phase, int py, long long boff) {
     if constexpr (R < Swt4Geom<F0>::P) {
-        swt4_inv_step<F0, NRI, R>(a, st, g0, i0, rows_phase, py, boff);
-        swt4_inv_group<F0, NRI, R + 1>(a, st, g0, i0, rows_phase, py, boff);
+        swt4_inv_step<F0, NRI, GEN, R>(a, st, g0, i0, rows_phase, py, boff);
+        swt4_inv_group<F0, NRI, GEN, R + 1>(a, st, g0, i0, rows_phase, py, boff);
     }
 }
 
-template <int F0, int NRI, int I>
+template <int F0, int NRI, bool GEN, int I>
 PDWT_DEVICE void swt4_inv_preload(const Swt4Args& a, Swt4InvState<F0, NRI>& st, long long boff, int i0, int rows_phase, int py) {
     if constexpr (I < NRI - 1) {
-        swt4_inv_load<F0, NRI, I>(a, st, boff, I, i0, rows_phase, py);
-        swt4_inv_preload<F0, NRI, I + 1>(a, st, boff, i0, rows_phase, py);
+        swt4_inv_load<F0, NRI, GEN, I>(a, st, boff, I, i0, rows_phase, py);
+        swt4_inv_preload<F0, NRI, GEN, I + 1>(a, st, boff, i0, rows_phase, py);
     }
 }
 
-template <int F0, int NRI>
+template <int F0, int NRI, bool GEN = false>
 PDWT_DEVICE void swt4_inv_fused(const Swt4Args& a, long long w) {
     using G = Swt4Geom<F0>;
     const int strip = (int)(w % a.strips);
     long long t = w / a.strips;
     const int seg = (int)(t % a.segs);
     t /= a.segs;
-    const int py = (int)(t % F0);
-    const long long img = t / F0;
-    const int rows_phase = a.Nr / F0;
+    const int phases = GEN ? a.wk.phases : F0;
+    const int py = (int)(t % phases);
+    const long long img = t / phases;
+    const int rows_phase = GEN ? a.wk.rows_phase : a.Nr / F0;
     const int i0 = seg * a.seg_rows;
     const long long boff = img * a.bstride;
     Swt4InvState<F0, NRI> st;
     PDWT_WAVE_LANES(lane) {
-        const int x = strip * 4 * G::Vi + 4 * (lane - G::inv_left);
+        const int x = (GEN ? swt_strip_x0(a.wk, strip, 4 * G::Vi) : strip * 4 * G::Vi) + 4 * (lane - G::inv_left);
         int xl = x < 0 ? x + a.Nc : (x >= a.Nc ? x - a.Nc : x);
         if (x >= a.Nc + 4 * G::inv_right) xl = a.Nc - 4;
         st.off.mine(lane)[0] = kRealBytes * (unsigned)xl;
         st.off.mine(lane)[1] = (lane >= G::inv_left && lane < G::inv_left + G::Vi && x < a.Nc) ? kRealBytes * (unsigned)x : kSwtLaneDropped;
     }
     st.bo = swt_plane(a.out, boff, a.Nr, a.Nc);
-    swt4_inv_preload<F0, NRI, 0>(a, st, boff, i0, rows_phase, py);
+    swt4_inv_preload<F0, NRI, GEN, 0>(a, st, boff, i0, rows_phase, py);
     PDWT_WAIT_VMEM();
     const int ngroups = a.seg_rows / G::P + 2;
-    for (int g = 0; g < ngroups; ++g) swt4_inv_group<F0, NRI, 0>(a, st, g * G::P, i0, rows_phase, py, boff);
+    for (int g = 0; g < ngroups; ++g) swt4_inv_group<F0, NRI, GEN, 0>(a, st, g * G::P, i0, rows_phase, py, boff);
 }
 
 #ifndef PDWT_CPU_EMU
-template <int F0, int NT>
+template <int F0, int NT, bool GEN>
 __global__ void __launch_bounds__(NT, 1) swt4_fwd_fused_kernel(const Swt4Args a, long long waves) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long long w = swt_fused_wave(blockIdx.x, NT / 64, wave, waves);
-    if (w < waves) swt4_fwd_fused<F0>(a, w);
+    if (w < waves) swt4_fwd_fused<F0, GEN>(a, w);
 }
-template <int F0, int NRI, int NT>
+template <int F0, int NRI, int NT, bool GEN>
 __global__ void __launch_bounds__(NT, 1) swt4_inv_fused_kernel(const Swt4Args a, long long waves) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long long w = swt_fused_wave(blockIdx.x, NT / 64, wave, waves);
-    if (w < waves) swt4_inv_fused<F0, NRI>(a, w);
+    if (w < waves) swt4_inv_fused<F0, NRI, GEN>(a, w);
 }
 #endif
 

@@ -44,6 +44,84 @@ namespace pdwt {
 
 constexpr int kSwtFusedMaxLevels = 3;
 
+// Planes of ANY size (round 6; the reference's kernels take any width and height: pdwt/src/separable.cu:409-493).  The
+// kernels below were written for rows of whole 16-B groups and row counts the first dilation f0 divides; the GEN
+// instantiations lift both conditions with the same walk:
+//   * columns: a lane still owns four consecutive columns, loaded and stored as 16 B at 4-B alignment.  No lane may straddle
+//     the row end (its last columns would come from the next row instead of the row start), so every strip but the first
+//     starts `pad` = (4 - Nc mod 4) mod 4 columns further left: the lanes then hold columns x with x = Nc (mod 4) up to the
+//     row end and 0, 4, 8 ... after it.  Strips 0 and 1 overlap by `pad` columns and store the same values there.
+//   * rows: the rows a wavefront walks, r, r + f0, r + 2 f0 ... (mod Nr), form gcd(f0, Nr) closed CHAINS of Nr / gcd rows
+//     instead of f0 phases of Nr / f0; inside a chain the group's dilations are 1, 2, 4 positions exactly as inside a
+//     phase, so only the map from position to row changes: (c + f0 i) mod Nr, by a multiplication with ceil(2^32 / Nr).
+struct SwtWalk {
+    int phases;       // chains of rows: gcd(f0, Nr) (= f0 when f0 divides Nr)
+    int rows_phase;   // rows of a chain: Nr / phases
+    unsigned magic;   // ceil(2^32 / Nr)
+    int pad;          // columns every strip but the first starts further left
+};
+
+static inline SwtWalk swt_walk(int Nr, int Nc, int f0, int cols_per_lane) {
+    int g = f0, r = Nr % f0;
+    while (r) { const int q = g % r; g = r; r = q; }
+    SwtWalk w;
+    w.phases = g;
+    w.rows_phase = Nr / g;
+    w.magic = (unsigned)(((1ULL << 32) + (unsigned)Nr - 1) / (unsigned)Nr);
+    w.pad = (cols_per_lane - Nc % cols_per_lane) % cols_per_lane;
+    return w;
+}
+static inline int swt_walk_strips(const SwtWalk& w, int Nc, int strip_cols) { return (Nc + w.pad + strip_cols - 1) / strip_cols; }
+static inline bool swt_walk_general(int Nr, int Nc, int f0) { return (Nc % 4) != 0 || (Nr % f0) != 0; }
+
+// row of position `idx` of chain `py`
+template <bool GEN, int F0>
+PDWT_DEVICE int swt_walk_row(const SwtWalk& wk, int Nr, int py, int idx) {
+    const int n = py + F0 * idx;
+    if constexpr (!GEN) {
+        return n;
+    } else {
+        // n < f0 (Nr + 1) <= 2^20: the estimate of n / Nr is exact or one too large
+        const int q = (int)(((unsigned long long)(unsigned)n * wk.magic) >> 32);
+        const int r = n - q * Nr;
+        return r < 0 ? r + Nr : r;
+    }
+}
+PDWT_DEVICE int swt_strip_x0(const SwtWalk& wk, int strip, int strip_cols) { return strip * strip_cols - (strip > 0 ? wk.pad : 0); }
+
+// 16-B / 8-B loads like wave_ld16 / wave_ld8 (dwt2_wave_kernels.hpp); GEN: at the alignment of one element
+#ifdef PDWT_CPU_EMU
+template <bool GEN> PDWT_DEVICE v4f swt_ld16(const real_t* base, unsigned byte_off) {
+    const real_t* p = reinterpret_cast<const real_t*>(reinterpret_cast<const char*>(base) + byte_off);
+    v4f r; r.x = p[0]; r.y = p[1]; r.z = p[2]; r.w = p[3];
+    return r;
+}
+template <bool GEN> PDWT_DEVICE v2f swt_ld8(const real_t* base, unsigned byte_off) {
+    const real_t* p = reinterpret_cast<const real_t*>(reinterpret_cast<const char*>(base) + byte_off);
+    return mk2(p[0], p[1]);
+}
+#else
+typedef real_t pdwt_v4u __attribute__((ext_vector_type(4), aligned(sizeof(real_t))));
+typedef real_t pdwt_v2u __attribute__((ext_vector_type(2), aligned(sizeof(real_t))));
+template <bool GEN> static __device__ __forceinline__ v4f swt_ld16(const real_t* base, unsigned byte_off) {
+    if constexpr (GEN) {
+        const pdwt_v4u v = *reinterpret_cast<const pdwt_v4u*>(reinterpret_cast<const char*>(base) + byte_off);
+        v4f r; r.x = v.x; r.y = v.y; r.z = v.z; r.w = v.w;
+        return r;
+    } else {
+        return wave_ld16(base, byte_off);
+    }
+}
+template <bool GEN> static __device__ __forceinline__ v2f swt_ld8(const real_t* base, unsigned byte_off) {
+    if constexpr (GEN) {
+        const pdwt_v2u v = *reinterpret_cast<const pdwt_v2u*>(reinterpret_cast<const char*>(base) + byte_off);
+        return mk2(v.x, v.y);
+    } else {
+        return wave_ld8(base, byte_off);
+    }
+}
+#endif
+
 
 struct SwtFusedArgs {
     const real_t* in;                    // forward: A_{l0-1}; inverse: A_{l0+K-1}
@@ -53,11 +131,12 @@ struct SwtFusedArgs {
     real_t* D[kSwtFusedMaxLevels];
     int Nr, Nc;
     long long bstride;                  // floats between the images of a batch
-    int strips;                         // ceil(Nc / (4 V))
-    int segs;                           // segments per phase: ceil(Nr / f0 / seg_rows)
+    int strips;                         // ceil((Nc + wk.pad) / (4 V))
+    int segs;                           // segments per phase: ceil(wk.rows_phase / seg_rows)
     int seg_rows;                       // phase rows a wavefront owns (multiple of 2^K)
     real_t beta[kSwtFusedMaxLevels];     // inverse: soft threshold of each level's details (0 = none)
     real_t lo[2], hi[2];                 // analysis (forward) / synthesis (inverse) taps
+    SwtWalk wk;                          // swt_walk(Nr, Nc, f0, columns per lane)
 };
 
 template <int K, int F0>
@@ -153,7 +232,7 @@ PDWT_DEVICE void swt_fwd_level(const SwtFusedArgs& a, WaveReg<real_t, 4>& ain, W
 }
 
 // step R of a group of P rows (R static): input row r = g0 + R of the walk
-template <int K, int F0, int R>
+template <int K, int F0, bool GEN, int R>
 PDWT_DEVICE void swt_fwd_step(const SwtFusedArgs& a, SwtFwdState<K, F0>& st, const real_t* in, int g0, int i0, int rows_phase,
                               int py, long long boff) {
     using G = SwtFusedGeom<K, F0>;
@@ -165,9 +244,9 @@ PDWT_DEVICE void swt_fwd_step(const SwtFusedArgs& a, SwtFwdState<K, F0>& st, con
         int rr = r + G::NR - 1;
         rr = rr < a.seg_rows + G::W ? rr : a.seg_rows + G::W - 1;
         rr = (i0 + rr) % rows_phase;
-        const real_t* row = in + (long long)(py + F0 * rr) * a.Nc;
+        const real_t* row = in + (long long)swt_walk_row<GEN, F0>(a.wk, a.Nr, py, rr) * a.Nc;
         PDWT_WAVE_LANES(lane) {
-            const v4f w = wave_ld16(row, st.off.mine(lane)[0]);
+            const v4f w = swt_ld16<GEN>(row, st.off.mine(lane)[0]);
             real_t* v = st.ld.mine(lane) + 4 * ((R + G::NR - 1) % G::NR);
             v[0] = w.x; v[1] = w.y; v[2] = w.z; v[3] = w.w;
         }
@@ -183,7 +262,7 @@ PDWT_DEVICE void swt_fwd_step(const SwtFusedArgs& a, SwtFwdState<K, F0>& st, con
     // row in a plane, or kSwtRowDropped for a row another wavefront owns
     auto rowoff = [&](int rel) -> unsigned {
         const bool ow = rel >= 0 && rel < a.seg_rows && i0 + rel < rows_phase;
-        return ow ? kRealBytes * (unsigned)(py + F0 * (i0 + rel)) * (unsigned)a.Nc : kSwtRowDropped;
+        return ow ? kRealBytes * (unsigned)swt_walk_row<GEN, F0>(a.wk, a.Nr, py, i0 + rel) * (unsigned)a.Nc : kSwtRowDropped;
     };
     {
         const unsigned ro = rowoff(r - 1);
@@ -205,33 +284,34 @@ PDWT_DEVICE void swt_fwd_step(const SwtFusedArgs& a, SwtFwdState<K, F0>& st, con
     }
 }
 
-template <int K, int F0, int R>
+template <int K, int F0, bool GEN, int R>
 PDWT_DEVICE void swt_fwd_group(const SwtFusedArgs& a, SwtFwdState<K, F0>& st, const real_t* in, int g0, int i0, int rows_phase,
                                int py, long long boff) {
     if constexpr (R < SwtFusedGeom<K, F0>::P) {
-        swt_fwd_step<K, F0, R>(a, st, in, g0, i0, rows_phase, py, boff);
-        swt_fwd_group<K, F0, R + 1>(a, st, in, g0, i0, rows_phase, py, boff);
+        swt_fwd_step<K, F0, GEN, R>(a, st, in, g0, i0, rows_phase, py, boff);
+        swt_fwd_group<K, F0, GEN, R + 1>(a, st, in, g0, i0, rows_phase, py, boff);
     }
 }
 
 // wavefront `w` of the launch: (image, phase, segment, strip)
-template <int K, int F0>
+template <int K, int F0, bool GEN = false>
 PDWT_DEVICE void swt2_fwd_fused(const SwtFusedArgs& a, long long w) {
     using G = SwtFusedGeom<K, F0>;
     const int strip = (int)(w % a.strips);
     long long t = w / a.strips;
     const int seg = (int)(t % a.segs);
     t /= a.segs;
-    const int py = (int)(t % F0);
-    const long long img = t / F0;
-    const int rows_phase = a.Nr / F0;
+    const int phases = GEN ? a.wk.phases : F0;
+    const int py = (int)(t % phases);
+    const long long img = t / phases;
+    const int rows_phase = GEN ? a.wk.rows_phase : a.Nr / F0;
     const int i0 = seg * a.seg_rows;
     const long long boff = img * a.bstride;
     const real_t* in = a.in + boff;
     SwtFwdState<K, F0> st;
     PDWT_WAVE_LANES(lane) {
-        const int x = strip * 4 * G::V + 4 * lane;
-        // columns past the row end wrap (Nc % 4 == 0, strips * 4 V < 2 Nc) as far as a valid lane's window reaches;
+        const int x = (GEN ? swt_strip_x0(a.wk, strip, 4 * G::V) : strip * 4 * G::V) + 4 * lane;
+        // columns past the row end wrap (no lane straddles it: Nc % 4 == 0 or SwtWalk::pad; strips * 4 V < 2 Nc) as far as a valid lane's window reaches;
         // further right nothing is used: those lanes re-read the row's last group (a cache hit, no extra traffic)
         int xl = x >= a.Nc ? x - a.Nc : x;
         if (x >= a.Nc + G::halo_cols + 3) xl = a.Nc - 4;
@@ -248,9 +328,9 @@ PDWT_DEVICE void swt2_fwd_fused(const SwtFusedArgs& a, long long w) {
     // rows 0 .. NR-2 of the walk in flight before the first step
 #pragma unroll
     for (int p = 0; p < G::NR - 1; ++p) {
-        const real_t* row = in + (long long)(py + F0 * ((i0 + p) % rows_phase)) * a.Nc;
+        const real_t* row = in + (long long)swt_walk_row<GEN, F0>(a.wk, a.Nr, py, (i0 + p) % rows_phase) * a.Nc;
         PDWT_WAVE_LANES(lane) {
-            const v4f v4 = wave_ld16(row, st.off.mine(lane)[0]);
+            const v4f v4 = swt_ld16<GEN>(row, st.off.mine(lane)[0]);
             real_t* v = st.ld.mine(lane) + 4 * p;
             v[0] = v4.x; v[1] = v4.y; v[2] = v4.z; v[3] = v4.w;
         }
@@ -258,7 +338,7 @@ PDWT_DEVICE void swt2_fwd_fused(const SwtFusedArgs& a, long long w) {
     PDWT_WAIT_VMEM();  // the loop header must not inherit pending loads (see dwt1_inv_reg)
     // seg_rows + W input rows, in groups of P (seg_rows is a multiple of P: one extra group covers the W <= P - 1 rows)
     const int ngroups = a.seg_rows / G::P + 1;
-    for (int g = 0; g < ngroups; ++g) swt_fwd_group<K, F0, 0>(a, st, in, g * G::P, i0, rows_phase, py, boff);
+    for (int g = 0; g < ngroups; ++g) swt_fwd_group<K, F0, GEN, 0>(a, st, in, g * G::P, i0, rows_phase, py, boff);
 }
 
 // ---------------------------------------------------------------------------------------------- inverse
@@ -322,7 +402,7 @@ struct SwtInvState {
 // redirected (a uniform pointer select: no branch around a load, the vmcnt bookkeeping stays exact) to the approximation
 // plane's row, which the same step loads anyway: they hit in cache instead of fetching 30 rows per segment nobody reads.
 // The values they deliver are finite and only reach ring slots that are overwritten before the first owned row.
-template <int K, int F0, int NRI, int C, int SLOT>
+template <int K, int F0, int NRI, int C, bool GEN, int SLOT>
 PDWT_DEVICE void swt_inv_load(const SwtFusedArgs& a, SwtInvState<K, F0, NRI, C>& st, long long boff, unsigned ro, int wrow) {
     constexpr int NP = 1 + 3 * K;
     using G = SwtFusedGeom<K, F0>;
@@ -332,10 +412,10 @@ PDWT_DEVICE void swt_inv_load(const SwtFusedArgs& a, SwtInvState<K, F0, NRI, C>&
         auto put = [&](int p, const real_t* plane) {
             real_t* v = base + C * p;
             if constexpr (C == 4) {
-                const v4f w = wave_ld16(plane + boff, o);
+                const v4f w = swt_ld16<GEN>(plane + boff, o);
                 v[0] = w.x; v[1] = w.y; v[2] = w.z; v[3] = w.w;
             } else {
-                const v2f w = wave_ld8(plane + boff, o);
+                const v2f w = swt_ld8<GEN>(plane + boff, o);
                 v[0] = w.x; v[1] = w.y;
             }
         };
@@ -395,7 +475,7 @@ PDWT_DEVICE void swt_inv_level(const SwtFusedArgs& a, WaveReg<real_t, C>& ain, W
     }
 }
 
-template <int K, int F0, int NRI, int C, int R>
+template <int K, int F0, int NRI, int C, bool GEN, int R>
 PDWT_DEVICE void swt_inv_step(const SwtFusedArgs& a, SwtInvState<K, F0, NRI, C>& st, int g0, int i0, int rows_phase, int py, long long boff) {
     using G = SwtFusedGeom<K, F0>;
     using S = SwtInvState<K, F0, NRI, C>;
@@ -407,7 +487,7 @@ PDWT_DEVICE void swt_inv_step(const SwtFusedArgs& a, SwtInvState<K, F0, NRI, C>&
         const int wrow = rr;
         rr = i0 - G::W + rr;
         rr = ((rr % rows_phase) + rows_phase) % rows_phase;
-        swt_inv_load<K, F0, NRI, C, (R + S::NRI - 1) % S::NRI>(a, st, boff, kRealBytes * (unsigned)(py + F0 * rr) * (unsigned)a.Nc, wrow);
+        swt_inv_load<K, F0, NRI, C, GEN, (R + S::NRI - 1) % S::NRI>(a, st, boff, kRealBytes * (unsigned)swt_walk_row<GEN, F0>(a.wk, a.Nr, py, rr) * (unsigned)a.Nc, wrow);
     }
     PDWT_ROW_FENCE();
     WaveReg<real_t, C> cur, nxt;
@@ -445,7 +525,7 @@ PDWT_DEVICE void swt_inv_step(const SwtFusedArgs& a, SwtInvState<K, F0, NRI, C>&
     swt_inv_level<G::dist(0), 2, R % 2, C>(a, cur, det, a.beta[0], st.ring1, nxt);
     const int rel = r - G::W;  // output row relative to the segment
     const bool ow = rel >= 0 && rel < a.seg_rows && i0 + rel < rows_phase;
-    const unsigned ro = ow ? kRealBytes * (unsigned)(py + F0 * (i0 + rel)) * (unsigned)a.Nc : kSwtRowDropped;
+    const unsigned ro = ow ? kRealBytes * (unsigned)swt_walk_row<GEN, F0>(a.wk, a.Nr, py, i0 + rel) * (unsigned)a.Nc : kSwtRowDropped;
     PDWT_WAVE_LANES(lane) {
         const real_t* v = nxt.mine(lane);
         if constexpr (C == 4) row_st16(st.bo, st.off.mine(lane)[1] + ro, v[0], v[1], v[2], v[3]);
@@ -453,25 +533,25 @@ PDWT_DEVICE void swt_inv_step(const SwtFusedArgs& a, SwtInvState<K, F0, NRI, C>&
     }
 }
 
-template <int K, int F0, int NRI, int C, int R>
+template <int K, int F0, int NRI, int C, bool GEN, int R>
 PDWT_DEVICE void swt_inv_group(const SwtFusedArgs& a, SwtInvState<K, F0, NRI, C>& st, int g0, int i0, int rows_phase, int py, long long boff) {
     if constexpr (R < SwtFusedGeom<K, F0>::P) {
-        swt_inv_step<K, F0, NRI, C, R>(a, st, g0, i0, rows_phase, py, boff);
-        swt_inv_group<K, F0, NRI, C, R + 1>(a, st, g0, i0, rows_phase, py, boff);
+        swt_inv_step<K, F0, NRI, C, GEN, R>(a, st, g0, i0, rows_phase, py, boff);
+        swt_inv_group<K, F0, NRI, C, GEN, R + 1>(a, st, g0, i0, rows_phase, py, boff);
     }
 }
 
 // rows 0 .. NRI-2 of the walk into slots 0 .. NRI-2
-template <int K, int F0, int NRI, int C, int I, class RowBytes>
+template <int K, int F0, int NRI, int C, bool GEN, int I, class RowBytes>
 PDWT_DEVICE void swt_inv_preload(const SwtFusedArgs& a, SwtInvState<K, F0, NRI, C>& st, long long boff, const RowBytes& rowbytes) {
     if constexpr (I < NRI - 1) {
-        swt_inv_load<K, F0, NRI, C, I>(a, st, boff, rowbytes(I), I);
-        swt_inv_preload<K, F0, NRI, C, I + 1>(a, st, boff, rowbytes);
+        swt_inv_load<K, F0, NRI, C, GEN, I>(a, st, boff, rowbytes(I), I);
+        swt_inv_preload<K, F0, NRI, C, GEN, I + 1>(a, st, boff, rowbytes);
     }
 }
 
-// a.strips = ceil(Nc / (C V)) with V of SwtInvGeom<K, F0, C>
-template <int K, int F0, int NRI, int C>
+// a.strips = ceil((Nc + wk.pad) / (C V)) with V of SwtInvGeom<K, F0, C>
+template <int K, int F0, int NRI, int C, bool GEN = false>
 PDWT_DEVICE void swt2_inv_fused(const SwtFusedArgs& a, long long w) {
     using G = SwtFusedGeom<K, F0>;
     using GI = SwtInvGeom<K, F0, C>;
@@ -479,15 +559,16 @@ PDWT_DEVICE void swt2_inv_fused(const SwtFusedArgs& a, long long w) {
     long long t = w / a.strips;
     const int seg = (int)(t % a.segs);
     t /= a.segs;
-    const int py = (int)(t % F0);
-    const long long img = t / F0;
-    const int rows_phase = a.Nr / F0;
+    const int phases = GEN ? a.wk.phases : F0;
+    const int py = (int)(t % phases);
+    const long long img = t / phases;
+    const int rows_phase = GEN ? a.wk.rows_phase : a.Nr / F0;
     const int i0 = seg * a.seg_rows;
     const long long boff = img * a.bstride;
     SwtInvState<K, F0, NRI, C> st;
     PDWT_WAVE_LANES(lane) {
         // the first halo_lanes lanes lack their left neighbours: lane halo_lanes owns column strip * C V
-        const int x = strip * C * GI::V + C * (lane - GI::halo_lanes);
+        const int x = (GEN ? swt_strip_x0(a.wk, strip, C * GI::V) : strip * C * GI::V) + C * (lane - GI::halo_lanes);
         // left of the row start: wrapped (the halo of the first columns); at or past the row end: nothing is used
         const int xl = x < 0 ? x + a.Nc : (x >= a.Nc ? a.Nc - C : x);
         st.off.mine(lane)[0] = kRealBytes * (unsigned)xl;
@@ -496,13 +577,15 @@ PDWT_DEVICE void swt2_inv_fused(const SwtFusedArgs& a, long long w) {
     st.bo = swt_plane(a.out, boff, a.Nr, a.Nc);
     // rows 0 .. NRI-2 of the walk (phase rows i0 - W ...) in flight before the first step
     {
-        auto rowbytes = [&](int i) { return kRealBytes * (unsigned)(py + F0 * (((i0 - G::W + i) % rows_phase + rows_phase) % rows_phase)) * (unsigned)a.Nc; };
-        swt_inv_preload<K, F0, NRI, C, 0>(a, st, boff, rowbytes);
+        auto rowbytes = [&](int i) {
+            return kRealBytes * (unsigned)swt_walk_row<GEN, F0>(a.wk, a.Nr, py, ((i0 - G::W + i) % rows_phase + rows_phase) % rows_phase) * (unsigned)a.Nc;
+        };
+        swt_inv_preload<K, F0, NRI, C, GEN, 0>(a, st, boff, rowbytes);
     }
     PDWT_WAIT_VMEM();
     // W warm-up rows + seg_rows rows, in groups of P
     const int ngroups = a.seg_rows / G::P + 1;
-    for (int g = 0; g < ngroups; ++g) swt_inv_group<K, F0, NRI, C, 0>(a, st, g * G::P, i0, rows_phase, py, boff);
+    for (int g = 0; g < ngroups; ++g) swt_inv_group<K, F0, NRI, C, GEN, 0>(a, st, g * G::P, i0, rows_phase, py, boff);
 }
 
 #ifndef PDWT_CPU_EMU
@@ -517,17 +600,17 @@ PDWT_DEVICE long long swt_fused_wave(unsigned block, int waves_per_block, int wa
     return (block >> 3) < chunk && b < blocks ? b * waves_per_block + wave : waves;
 }
 
-template <int K, int F0, int NT>
+template <int K, int F0, int NT, bool GEN>
 __global__ void __launch_bounds__(NT, 1) swt2_fwd_fused_kernel(const SwtFusedArgs a, long long waves) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long long w = swt_fused_wave(blockIdx.x, NT / 64, wave, waves);
-    if (w < waves) swt2_fwd_fused<K, F0>(a, w);
+    if (w < waves) swt2_fwd_fused<K, F0, GEN>(a, w);
 }
-template <int K, int F0, int NRI, int C, int NT>
+template <int K, int F0, int NRI, int C, int NT, bool GEN>
 __global__ void __launch_bounds__(NT, 1) swt2_inv_fused_kernel(const SwtFusedArgs a, long long waves) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long long w = swt_fused_wave(blockIdx.x, NT / 64, wave, waves);
-    if (w < waves) swt2_inv_fused<K, F0, NRI, C>(a, w);
+    if (w < waves) swt2_inv_fused<K, F0, NRI, C, GEN>(a, w);
 }
 #endif
 

@@ -876,21 +876,25 @@ EMU_API int emu_dwt1_inv_reg(const float* app, const float* det, int rows, int N
 // ------------------------------------------------------------------ 2D SWT, 2-tap filters, two or three levels per launch
 template <int K, int F0>
 static void run_swt_fused(SwtFusedArgs& a, int batch, bool inverse, int cpl) {
-    if (inverse) a.strips = cpl == 2 ? (a.Nc + 2 * SwtInvGeom<K, F0, 2>::V - 1) / (2 * SwtInvGeom<K, F0, 2>::V)
-                                     : (a.Nc + 4 * SwtInvGeom<K, F0, 4>::V - 1) / (4 * SwtInvGeom<K, F0, 4>::V);
-    else a.strips = (a.Nc + 4 * SwtFusedGeom<K, F0>::V - 1) / (4 * SwtFusedGeom<K, F0>::V);
-    const long long waves = (long long)batch * F0 * a.segs * a.strips;
+    // sizes the aligned instantiations cannot take run the GEN ones (SwtWalk); `cpl` + 8 forces them on every size
+    const bool gen = swt_walk_general(a.Nr, a.Nc, F0) || cpl >= 8;
+    cpl &= 7;
+    a.wk = swt_walk(a.Nr, a.Nc, F0, inverse ? cpl : 4);
+    if (inverse) a.strips = cpl == 2 ? swt_walk_strips(a.wk, a.Nc, 2 * SwtInvGeom<K, F0, 2>::V) : swt_walk_strips(a.wk, a.Nc, 4 * SwtInvGeom<K, F0, 4>::V);
+    else a.strips = swt_walk_strips(a.wk, a.Nc, 4 * SwtFusedGeom<K, F0>::V);
+    a.segs = (a.wk.rows_phase + a.seg_rows - 1) / a.seg_rows;
+    const long long waves = (long long)batch * a.wk.phases * a.segs * a.strips;
     for (long long w = 0; w < waves; w++) {
-        if (!inverse) swt2_fwd_fused<K, F0>(a, w);
-        else if (cpl == 2) swt2_inv_fused<K, F0, 4, 2>(a, w);
-        else swt2_inv_fused<K, F0, 4, 4>(a, w);
+        if (!inverse) { if (gen) swt2_fwd_fused<K, F0, true>(a, w); else swt2_fwd_fused<K, F0, false>(a, w); }
+        else if (cpl == 2) { if (gen) swt2_inv_fused<K, F0, 4, 2, true>(a, w); else swt2_inv_fused<K, F0, 4, 2, false>(a, w); }
+        else { if (gen) swt2_inv_fused<K, F0, 4, 4, true>(a, w); else swt2_inv_fused<K, F0, 4, 4, false>(a, w); }
     }
 }
 
 // planes: forward  in -> det (K x [H, V, D] planes, level l0 first) and out;  inverse  in (A) + det -> out
 EMU_API int emu_swt2_fused(const float* in, float* det, float* out, int batch, int Nr, int Nc, int K, int f0, int seg_rows,
                            const float* lo, const float* hi, const float* beta, int inverse, int cpl) {
-    if (K < 2 || K > 3 || (f0 != 1 && f0 != 8) || (Nc % 4) || Nc < 256 || (Nr % f0) || seg_rows % (1 << K)) return -2;
+    if (K < 2 || K > 3 || (f0 != 1 && f0 != 8) || Nc < 256 || Nr / f0 < (1 << K) || seg_rows % (1 << K)) return -2;
     SwtFusedArgs a;
     const long long plane = (long long)Nr * Nc;
     a.in = in; a.out = out; a.Nr = Nr; a.Nc = Nc; a.bstride = plane;
@@ -914,20 +918,23 @@ EMU_API int emu_swt2_fused(const float* in, float* det, float* out, int batch, i
 
 // ---- 4-tap fused SWT pairs (swt2_fused4_kernels.hpp): planes as in emu_swt2_fused with K = 2
 template <int F0>
-static void run_swt4(Swt4Args& a, int batch, bool inverse) {
+static void run_swt4(Swt4Args& a, int batch, bool inverse, bool gen) {
     using G = Swt4Geom<F0>;
     const int V = inverse ? G::Vi : G::Vf;
-    a.strips = (a.Nc + 4 * V - 1) / (4 * V);
-    const long long waves = (long long)batch * F0 * a.segs * a.strips;
+    a.wk = swt_walk(a.Nr, a.Nc, F0, 4);
+    a.strips = swt_walk_strips(a.wk, a.Nc, 4 * V);
+    a.segs = (a.wk.rows_phase + a.seg_rows - 1) / a.seg_rows;
+    const long long waves = (long long)batch * a.wk.phases * a.segs * a.strips;
     for (long long w = 0; w < waves; w++) {
-        if (!inverse) swt4_fwd_fused<F0>(a, w);
-        else swt4_inv_fused<F0, 4>(a, w);
+        if (!inverse) { if (gen) swt4_fwd_fused<F0, true>(a, w); else swt4_fwd_fused<F0, false>(a, w); }
+        else { if (gen) swt4_inv_fused<F0, 4, true>(a, w); else swt4_inv_fused<F0, 4, false>(a, w); }
     }
 }
 
 EMU_API int emu_swt4_fused(const float* in, float* det, float* out, int batch, int Nr, int Nc, int f0, int seg_rows,
                            const float* lo, const float* hi, const float* beta, int inverse) {
-    if ((f0 != 1 && f0 != 4) || (Nc % 4) || Nc < 64 || (Nr % f0) || seg_rows % 8) return -2;
+    const bool gen = swt_walk_general(Nr, Nc, f0) || (inverse & 2);  // inverse + 2: the GEN instantiations on every size
+    if ((f0 != 1 && f0 != 4) || Nc < (gen ? 256 : 64) || Nr / f0 < 8 || seg_rows % 8) return -2;
     Swt4Args a;
     const long long plane = (long long)Nr * Nc;
     a.in = in; a.out = out; a.Nr = Nr; a.Nc = Nc; a.bstride = plane;
@@ -940,8 +947,8 @@ EMU_API int emu_swt4_fused(const float* in, float* det, float* out, int batch, i
     for (int j = 0; j < 4; j++) { a.lo[j] = lo[j]; a.hi[j] = hi[j]; }
     a.seg_rows = seg_rows;
     a.segs = (Nr / f0 + seg_rows - 1) / seg_rows;
-    if (f0 == 1) run_swt4<1>(a, batch, inverse != 0);
-    else run_swt4<4>(a, batch, inverse != 0);
+    if (f0 == 1) run_swt4<1>(a, batch, (inverse & 1) != 0, gen);
+    else run_swt4<4>(a, batch, (inverse & 1) != 0, gen);
     return 0;
 }
 

@@ -31,6 +31,8 @@ CASES = [
     # ---- 2D SWT
     ("swt2", "haar", (2048, 2048), 5, 1, "f32"),     # fused groups of levels
     ("swt2", "db2", (1024, 1024), 4, 1, "f32"),      # 4-tap fused pairs
+    ("swt2", "haar", (1001, 1002), 5, 1, "f32"),     # ... on rows that are not whole 16-B groups / row counts the dilation does not divide
+    ("swt2", "db2", (514, 1023), 4, 1, "f32"),
     ("swt2", "db4", (512, 512), 3, 1, "f32"),        # level launches
     ("swt2", "db10", (2048, 2048), 2, 1, "f32"),     # row + column launches (split)
     ("swt2", "sym8", (1024, 1024), 2, 1, "f32"),
@@ -50,6 +52,7 @@ CASES = [
     ("swt2", "db10", (512, 512), 2, 1, "f64"),      # 20 taps: row + column launches of the stream kernels, both directions
     ("swt2", "db4", (256, 256), 2, 1, "f64"),        # 8 taps: tiles forward, stream kernels inverse
     ("swt2", "db2", (30, 44), 2, 1, "f64"),          # 4 taps, dilation does not divide the rows: tiles both ways
+    ("swt2", "haar", (301, 515), 3, 1, "f64"),       # fused groups on any size
     ("dwt2", "db20", (1024, 1024), 1, 1, "f64"),     # 40 taps, 2^20 samples: the inverse as row + column launches of the stream kernels
     ("dwt2", "db10", (2048, 2048), 1, 1, "f64"),     # 20 taps, 2^22 samples: the strip-streaming kernels in both directions
 ]

@@ -766,6 +766,105 @@ def test_emu_swt2_fused_forward_and_inverse():
                 assert np.abs(rec[b] - want).max() <= 4e-6 * (1 + K), (si, "inverse", beta is not None, cpl)
 
 
+def _swt_group_inverse_ref(aK, d, wname, l0, K):
+    """Levels l0+K-1 .. l0 of an SWT undone one by one on a plane of ANY size: the oracle's one-level synthesis at an
+    arbitrary level (oracle_nonsep_inv_level with outer-product banks, pinned to the separable inverse in
+    tests/test_oracle_golden.py).  d = [H, V, D of level l0, ... of level l0+K-1]."""
+    hlen, dlo, dhi, rlo, rhi = oracle.filters(wname)
+    F = [np.outer(rlo, rlo).ravel(), np.outer(rhi, rlo).ravel(), np.outer(rlo, rhi).ravel(), np.outer(rhi, rhi).ravel()]
+    a = aK
+    for k in range(K - 1, -1, -1):
+        a = oracle.nonsep_inverse_level([a, d[3 * k], d[3 * k + 1], d[3 * k + 2]], a.shape, *F, hlen, do_swt=1, level=l0 + k)
+    return a
+
+
+def _swt_any_size_cases(l0_deep):
+    # (batch, Nr, Nc, l0, K, seg_rows): widths of every residue mod 4 (a lane may never straddle the row end), the row end
+    # inside a strip's halo lanes (4 V + 1 ... 4 V + 5 columns), row counts the first dilation does not divide (one chain of
+    # all rows, or gcd chains), aligned sizes through the same instantiations (forced), a batch whose planes start unaligned
+    cases = [(1, 24, 257, 1, 3, 8), (1, 33, 258, 1, 2, 8), (2, 19, 259, 1, 3, 8), (1, 16, 501, 1, 3, 8), (1, 17, 250 + 249, 1, 2, 4),
+             (1, 40, 256, 1, 3, 16), (1, 21, 747, 1, 2, 8)]
+    cases += [(1, 67, 262, l0_deep, 2, 8), (1, 100, 257, l0_deep, 2, 8), (2, 36, 259, l0_deep, 2, 8), (1, 64, 256, l0_deep, 2, 8)]
+    return cases
+
+
+def test_emu_swt2_fused_any_size():
+    """The GEN instantiations of swt2_fwd_fused / swt2_inv_fused (SwtWalk: 16-B accesses at 4-B alignment, strips moved so that
+    no lane straddles the row end, chains of rows instead of phases) against the oracle on sizes the aligned kernels refuse"""
+    hlen, dlo, dhi, rlo, rhi = oracle.filters("haar")
+    for si, (B, Nr, Nc, l0, K, seg) in enumerate(_swt_any_size_cases(4) + [(1, 70, 301, 4, 3, 8)]):
+        L = l0 + K - 1
+        f0 = 1 << (l0 - 1)
+        x = oracle.hash_input((B, Nr, Nc), 9150 + si)
+        refs = [oracle.forward(x[b], "haar", L, do_swt=1) for b in range(B)]
+        prev = [oracle.forward(x[b], "haar", l0 - 1, do_swt=1)[0] if l0 > 1 else x[b] for b in range(B)]
+        ain = np.stack(prev).astype(np.float32)
+        det = np.full((3 * K, B, Nr, Nc), np.nan, dtype=np.float32)
+        out = np.full((B, Nr, Nc), np.nan, dtype=np.float32)
+        assert lib().emu_swt2_fused(P(ain), P(det), P(out), B, Nr, Nc, K, f0, seg, P(dlo), P(dhi), None, 0, 8 + 4) == 0
+        for b in range(B):
+            assert np.isfinite(out[b]).all(), (si, "A")
+            assert np.abs(out[b] - refs[b][0]).max() <= _tol(refs[b][0]) * (1 + K), (si, "A")
+            for k in range(K):
+                for j in range(3):
+                    want = refs[b][1 + 3 * (l0 - 1 + k) + j]
+                    got = det[3 * k + j, b]
+                    assert np.isfinite(got).all(), (si, k, j)
+                    assert np.abs(got - want).max() <= _tol(want) * (1 + K), (si, k, j)
+        for beta, cpl in ((None, 4), (np.array([0.3, 0.2, 0.1], dtype=np.float32), 4), (None, 2)):
+            aK = (oracle.hash_input((B, Nr, Nc), 9250 + si, 2.0) - 1.0).astype(np.float32)
+            dets = (oracle.hash_input((3 * K, B, Nr, Nc), 9350 + si, 2.0) - 1.0).astype(np.float32)
+            rec = np.full((B, Nr, Nc), np.nan, dtype=np.float32)
+            assert lib().emu_swt2_fused(P(aK), P(dets), P(rec), B, Nr, Nc, K, f0, seg, P(rlo), P(rhi),
+                                        P(beta) if beta is not None else None, 1, 8 + cpl) == 0
+            for b in range(B):
+                d = dets[:, b]
+                if beta is not None:
+                    d = np.stack([d[3 * k + j] - np.clip(d[3 * k + j], -beta[k], beta[k]) for k in range(K) for j in range(3)])
+                want = _swt_group_inverse_ref(aK[b], d, "haar", l0, K)
+                assert np.isfinite(rec[b]).all(), (si, "inverse")
+                assert np.abs(rec[b] - want).max() <= 4e-6 * (1 + K), (si, "inverse", beta is not None, cpl)
+
+
+@pytest.mark.parametrize("wname", ["db2", "sym2"])
+def test_emu_swt4_fused_any_size(wname):
+    """The GEN instantiations of the 4-tap pairs (halo lanes on both sides of a strip) on any size"""
+    hlen, dlo, dhi, rlo, rhi = oracle.filters(wname)
+    for si, (B, Nr, Nc, l0, K, seg) in enumerate(_swt_any_size_cases(3)):
+        L = l0 + 1
+        f0 = 1 << (l0 - 1)
+        x = oracle.hash_input((B, Nr, Nc), 9550 + si)
+        refs = [oracle.forward(x[b], wname, L, do_swt=1) for b in range(B)]
+        prev = [oracle.forward(x[b], wname, l0 - 1, do_swt=1)[0] if l0 > 1 else x[b] for b in range(B)]
+        ain = np.stack(prev).astype(np.float32)
+        det = np.full((6, B, Nr, Nc), np.nan, dtype=np.float32)
+        out = np.full((B, Nr, Nc), np.nan, dtype=np.float32)
+        seg = (seg + 7) // 8 * 8
+        assert lib().emu_swt4_fused(P(ain), P(det), P(out), B, Nr, Nc, f0, seg, P(dlo), P(dhi), None, 0 + 2) == 0
+        for b in range(B):
+            assert np.isfinite(out[b]).all(), (si, "A")
+            assert np.abs(out[b] - refs[b][0]).max() <= _tol(refs[b][0]) * 3, (si, "A")
+            for k in range(2):
+                for j in range(3):
+                    want = refs[b][1 + 3 * (l0 - 1 + k) + j]
+                    got = det[3 * k + j, b]
+                    assert np.isfinite(got).all(), (si, k, j)
+                    assert np.abs(got - want).max() <= _tol(want) * 3, (wname, si, k, j)
+        for beta in (None, np.array([0.3, 0.2], dtype=np.float32)):
+            aK = (oracle.hash_input((B, Nr, Nc), 9650 + si, 2.0) - 1.0).astype(np.float32)
+            dets = (oracle.hash_input((6, B, Nr, Nc), 9750 + si, 2.0) - 1.0).astype(np.float32)
+            rec = np.full((B, Nr, Nc), np.nan, dtype=np.float32)
+            assert lib().emu_swt4_fused(P(aK), P(dets), P(rec), B, Nr, Nc, f0, seg, P(rlo), P(rhi),
+                                        P(beta) if beta is not None else None, 1 + 2) == 0
+            for b in range(B):
+                d = dets[:, b]
+                if beta is not None:
+                    d = np.stack([d[3 * k + j] - np.clip(d[3 * k + j], -beta[k], beta[k]) for k in range(2) for j in range(3)])
+                want = _swt_group_inverse_ref(aK[b], d, wname, l0, 2)
+                assert np.isfinite(rec[b]).all(), (si, "inverse")
+                assert np.abs(rec[b] - want).max() <= 4e-6 * 3 * max(1.0, float(np.abs(want).max())), (wname, si, "inverse", beta is not None)
+
+
 # ----------------------------------------------------------------------------- 4-tap fused SWT pairs
 def _swt4_cases():
     # (batch, Nr, Nc, l0, seg_rows): whole and ragged strips, partial last segments, phase rows (l0 = 3 -> f0 = 4)

@@ -1142,3 +1142,48 @@ def test_swt1_on_single_rows_that_are_not_whole_quads(wname, shape, levels):
     thr = oracle.threshold(ref, x.shape, w.levels, "soft", 5.0, do_swt=1, ndim=1)
     want = oracle.inverse(thr, x.shape, wname, w.levels, ndim=1, do_swt=1)
     assert np.abs(w.image.reshape(want.shape) - want).max() <= 4e-6 * (1 + w.levels) * 255.0, (wname, shape)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("wname,levels", [("haar", 5), ("db2", 4), ("sym2", 3), ("haar", 3)])
+def test_fused_swt_groups_on_any_size(wname, levels):
+    """Round 6 (missing 5): the 2- and 4-tap SWT groups -- three / two levels per launch in registers -- on planes
+    of ANY size (swt2_fused_kernels.hpp, SwtWalk: 16-B accesses at 4-B alignment, strips moved so that no lane straddles the row
+    end, chains of rows where the group's first dilation does not divide the row count).  The reference's kernels take any width
+    and height (pdwt/src/separable.cu:409-493, 553-672).  Every band against the oracle, the soft threshold folded into the
+    inverse, the reconstruction; and that the groups are what ran."""
+    from pypwt_amd import BatchedWavelets, Wavelets
+    for si, shape in enumerate([(2047, 2047), (1002, 1002), (301, 523), (1001, 258), (77, 1022), (512, 1026)]):
+        x = oracle.hash_input(shape, 7170 + si)
+        w = Wavelets(x, wname, levels, do_swt=1)
+        w.forward()
+        ref = oracle.forward(x, wname, w.levels, do_swt=1)
+        for k, (g, r) in enumerate(zip(flat_coeffs(w), ref)):
+            assert g.shape == r.shape
+            assert np.abs(g - r).max() <= 2e-6 * (1 + w.levels) * max(float(np.abs(r).max()), 255.0), (wname, shape, k)
+        w.soft_threshold(7.5)
+        w.inverse()
+        thr = oracle.threshold(ref, shape, w.levels, "soft", 7.5, do_swt=1)
+        want = oracle.inverse(thr, shape, wname, w.levels, do_swt=1)
+        assert np.abs(w.image - want).max() <= 4e-6 * (1 + w.levels) * 255.0, (wname, shape)
+        bw = BatchedWavelets(1, shape[0], shape[1], wname, levels, do_swt=1)
+        bw.set_image(x[None])
+        bw.enable_kernel_timing(True)
+        bw.reset_kernel_times()
+        bw.forward()
+        bw.inverse()
+        names = [n for n, _ in bw.kernel_times()]
+        assert "swt2_fwd_fused" in names and "swt2_inv_fused" in names, (wname, shape, names)
+    # a batch of images whose planes do not start on 16 B
+    B, shape = 3, (129, 259)
+    x = oracle.hash_input((B,) + shape, 7199)
+    bw = BatchedWavelets(B, shape[0], shape[1], wname, levels, do_swt=1)
+    bw.set_image(x)
+    bw.forward()
+    for b in range(B):
+        ref = oracle.forward(x[b], wname, bw.levels, do_swt=1)
+        for k, r in enumerate(ref):
+            assert np.abs(bw.coeff_at(k, b) - r).max() <= 2e-6 * (1 + bw.levels) * max(float(np.abs(r).max()), 255.0), (wname, b, k)
+    bw.inverse()
+    for b in range(B):
+        assert np.abs(bw.image_at(b) - x[b]).max() <= reconstruction_tol(x[b], wname, bw.levels, do_swt=1), (wname, b)
