@@ -53,10 +53,20 @@ extern __device__ unsigned long long pdwt_long_prof[];
 #define PDWT_LONG_ITEMS(it, tid, ITEMS, NT) \
     _Pragma("unroll") for (int it = (tid), pdwt_k_ = 0; pdwt_k_ < ((ITEMS) + (NT) - 1) / (NT); ++pdwt_k_, it += (NT))
 #endif
+// The barriers of these kernels order LDS accesses only (nothing a workgroup's threads exchange goes through global memory):
+// a release / acquire pair on the LOCAL address space around s_barrier.  __syncthreads() also waits for every outstanding global
+// access of the wavefront (s_waitcnt vmcnt(0)): the step's stores and the next step's prefetched rows.
 #if PDWT_LONG_DIAG & 16
 #define PDWT_LONG_SYNC() ((void)0)
-#else
+#elif defined(PDWT_CPU_EMU)
 #define PDWT_LONG_SYNC() PDWT_SYNC()
+#else
+#define PDWT_LONG_SYNC()                                                    \
+    do {                                                                    \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");     \
+        __builtin_amdgcn_s_barrier();                                       \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");     \
+    } while (0)
 #endif
 
 struct FwdLongArgs {

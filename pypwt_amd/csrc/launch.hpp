@@ -20,7 +20,7 @@ enum EwOp { EW_SOFT = 0, EW_HARD = 1, EW_LINF = 2, EW_SCALE = 3 };
 // third thread calling pdwt_set_tuning -- cannot change each other's kernel choice in mid-transform; with no active set
 // (direct calls of the launchers: tools, emulation) the process-wide values apply.
 struct Tuning {
-    int wave_min_log2, lds_max_log2, swt_split_fwd, swt_split_inv, dwt_split_fwd, dwt_split_inv, ring_min_log2, long_fwd, long_inv;
+    int wave_min_log2, lds_max_log2, swt_split_fwd, swt_split_inv, dwt_split_fwd, dwt_split_inv, ring_min_log2, long_fwd, long_inv, swt_colstream;
     int wave2, swt_fused, chain, reg1d;  // read by build_schedule: a clone rebuilds its launch lists from its source's values
 };
 Tuning current_tuning();                  // the process-wide values now
@@ -57,6 +57,8 @@ hipError_t try_launch_dwt2_fwd_long(const Fwd2DArgs& a, int batch, hipStream_t s
 hipError_t try_launch_dwt2_inv_long(const Inv2DArgs& a, int batch, hipStream_t s, int seg_hint = 0);
 int set_long_min_taps(int inverse, int taps);  // shortest filter on them (0: never; 100 + n: n taps at every size they take); returns the previous value
 int get_long_min_taps(int inverse);
+int set_swt_colstream_min(int taps);  // column pass of the two-launch SWT levels streamed through an LDS history (swt_colstream_kernels.hpp) from `taps` taps; 0: never
+int get_swt_colstream_min();
 int set_ring_min_log2(int value);  // 2D DWT levels of at least 2^value samples with 12-20 taps run on them (63 = never; below the default: 10-20 taps, tests)
 int get_ring_min_log2();
 int set_wave_min_log2(int value);  // returns the previous threshold

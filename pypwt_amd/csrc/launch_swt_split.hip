@@ -10,6 +10,7 @@
 #include "swt_stream_kernels.hpp"
 #ifndef PDWT_DOUBLE
 #include "swt_split_kernels.hpp"
+#include "swt_colstream_kernels.hpp"
 #endif
 
 namespace pdwt {
@@ -18,6 +19,14 @@ static int env_int(const char* name, int dflt) {
     const char* e = lab_env(name);
     return e ? atoi(e) : dflt;
 }
+
+// shortest filter whose column pass runs on the strip kernels of swt_colstream_kernels.hpp (fp32 library; tuning key "swt_colstream")
+static std::atomic<int>& colstream_min() {
+    static std::atomic<int> v{(int)tune::swt_colstream_taps};
+    return v;
+}
+int set_swt_colstream_min(int taps) { return colstream_min().exchange(taps < 0 ? 0 : taps); }
+int get_swt_colstream_min() { return colstream_min().load(std::memory_order_relaxed); }
 
 // ---- the any-length stream kernels (swt_stream_kernels.hpp, round 5): both libraries ----------------------------------------------
 static void stream_taps(SwtStreamArgs& k, const FilterBank& fb, int hlen) {
@@ -237,6 +246,51 @@ bool swt2_split_supported(int hlen, int Nr, int Nc, int f, bool inverse, long lo
     return true;
 }
 
+// ---- the column pass streamed down strips with the filter's history in LDS (swt_colstream_kernels.hpp)
+
+template <int HLEN, bool INV>
+static hipError_t run_colstream(const SwtSplitArgs& c, hipStream_t s) {
+    if constexpr (HLEN < 10) {
+        return hipErrorNotSupported;
+    } else {
+        // Rules (tools/swt_colstream_ab.py, profiles/r06_swt_colstream.txt): the inverse gains at every size and dilation (2048^2: 7-25 %,
+        // 4096^2: 25-45 %); the forward only where the register kernels' shared rows fall out of L1 / L2 -- from 2^23 samples per launch
+        // (4096^2: 7-36 %; 2048^2: +-5 %).  Tuning key "swt_colstream": shortest filter, 0 = never, 100 + n = n taps, both directions, every size.
+        const Tuning* at = active_tuning();
+        int min_taps = at ? at->swt_colstream : get_swt_colstream_min();
+        const bool forced = min_taps >= 100;
+        if (forced) min_taps -= 100;
+        if (min_taps <= 0 || HLEN < min_taps) return hipErrorNotSupported;
+        if (!INV && !forced && (long long)c.batch * c.Nr * c.Nc < (1LL << tune::swt_colstream_fwd_log2)) return hipErrorNotSupported;
+        constexpr int TXC = 64, TY = 32, NT = 256, M = 8, MINB = 2;
+        using G = SwtColStreamGeom<HLEN, INV, TXC, TY>;
+        SwtColStreamArgs a;
+        for (int k = 0; k < 4; ++k) { a.in[k] = c.in[k]; a.out[k] = c.out[k]; }
+        a.Nr = c.Nr; a.Nc = c.Nc; a.f = c.f;
+        a.in_bstride = c.in_bstride; a.out_bstride = c.out_bstride;
+        a.soft_beta = c.soft_beta;
+        a.t = c.t;
+        a.wk = swt_walk(c.Nr, c.Nc, c.f, 4);
+        // 32-bit byte offsets inside a plane (buffer stores), chains the staging plan can advance with one conditional wrap
+        if ((c.Nc & 3) || a.wk.rows_phase < TY || c.batch > 65535 || (long long)c.Nr * c.Nc * 2 * (long long)sizeof(real_t) >= (1LL << 32)) return hipErrorNotSupported;
+        a.strips = cdiv(c.Nc, TXC);
+        // two workgroups per CU: segments as long as 512 workgroups allow (a segment re-loads hlen - 1 rows, it filters none twice)
+        const long long units = (long long)a.strips * a.wk.phases * c.batch;
+        static const int target = lab_env("PDWT_COLSTREAM_WGS") ? atoi(lab_env("PDWT_COLSTREAM_WGS")) : 512;  // A/B measurements
+        int segs = (int)cdivll(target, units);
+        if (segs < 1) segs = 1;
+        a.seg = cdiv(cdiv(a.wk.rows_phase, segs), TY) * TY;
+        a.segs = cdiv(a.wk.rows_phase, a.seg);
+        static std::atomic<bool> big[64] = {};
+        constexpr size_t lds = (size_t)G::LDS_REALS * sizeof(real_t);
+        auto kern = swt_colstream_kernel<HLEN, INV, TXC, TY, NT, M, MINB>;
+        hipError_t e = allow_big_lds(kern, lds, big);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3(8 * cdiv(a.strips * a.segs * a.wk.phases, 8), c.batch), dim3(NT), lds, s, a);
+        return hipGetLastError();
+    }
+}
+
 template <int NT, typename K>
 static hipError_t go(K kernel, const SwtSplitArgs& a, long long waves, hipStream_t s, size_t lds_bytes = 0) {
     hipLaunchKernelGGL(kernel, dim3((unsigned)cdivll(waves, NT / 64)), dim3(NT), lds_bytes, s, a);
@@ -271,12 +325,16 @@ static hipError_t run_split(const Swt2DArgs& a, real_t* tmp, bool inverse, int b
         SwtSplitArgs c = k;
         c.in[0] = tmp; c.in[1] = tmp + plane; c.in_bstride = 2 * plane;
         c.out[0] = a.A; c.out[1] = a.H; c.out[2] = a.V; c.out[3] = a.D; c.out_bstride = a.bstride;
+        e = run_colstream<HLEN, false>(c, s);
+        if (e != hipErrorNotSupported) { note_family("colstream"); return e; }
         return go<NTC>(swt_col_fwd_kernel<HLEN, RC, NTC>, c, col_items, s);
     }
     SwtSplitArgs c = k;  // A, H, V, D -> interleaved (L', H') (scratch: two planes per image)
     c.in[0] = a.A; c.in[1] = a.H; c.in[2] = a.V; c.in[3] = a.D; c.in_bstride = a.bstride;
     c.out[0] = tmp; c.out_bstride = 2 * plane;
-    e = go<NTC>(swt_col_inv_kernel<HLEN, RC, NTC>, c, col_items, s);
+    e = run_colstream<HLEN, true>(c, s);
+    if (e != hipErrorNotSupported) note_family("colstream");
+    else e = go<NTC>(swt_col_inv_kernel<HLEN, RC, NTC>, c, col_items, s);
     if (e != hipSuccess) return e;
     SwtSplitArgs r = k;
     r.in[0] = tmp; r.in_bstride = 2 * plane;

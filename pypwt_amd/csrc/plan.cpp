@@ -2064,6 +2064,7 @@ int pdwt_set_tuning(const char* key, int value) {
     if (key && !strcmp(key, "ring_min_log2")) return set_ring_min_log2(value);
     if (key && !strcmp(key, "long_fwd")) return set_long_min_taps(0, value);
     if (key && !strcmp(key, "long_inv")) return set_long_min_taps(1, value);
+    if (key && !strcmp(key, "swt_colstream")) return set_swt_colstream_min(value);
     if (key && !strcmp(key, "wave2")) return set_wave2_enabled(value);
     if (key && !strcmp(key, "reg1d")) return set_reg1d_enabled(value);
     if (key && !strcmp(key, "swt_fused")) return set_swt_fused_enabled(value);

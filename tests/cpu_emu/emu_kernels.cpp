@@ -26,6 +26,7 @@
 #include "../../pypwt_amd/csrc/nonsep_kernels.hpp"
 #include "../../pypwt_amd/csrc/swt_kernels.hpp"
 #include "../../pypwt_amd/csrc/swt_split_kernels.hpp"
+#include "../../pypwt_amd/csrc/swt_colstream_kernels.hpp"
 #include "../../pypwt_amd/csrc/swt_stream_kernels.hpp"
 #include "../../pypwt_amd/csrc/dwt2_stream_kernels.hpp"
 #include "../../pypwt_amd/csrc/dwt2_split_kernels.hpp"
@@ -952,6 +953,37 @@ EMU_API int emu_swt4_fused(const float* in, float* det, float* out, int batch, i
     return 0;
 }
 
+// the column pass streamed down strips (swt_colstream_kernels.hpp) on the arguments of the register column kernels
+static int g_colstream_runs = 0;
+EMU_API int emu_colstream_runs() { return g_colstream_runs; }  // launches that took the strip kernels so far
+template <int HLEN, bool INV>
+static bool run_swt_colstream(const SwtSplitArgs& c) {
+    if constexpr (HLEN < 10) {
+        return false;
+    } else {
+        constexpr int TXC = 64, TY = 32, NT = 256, M = 8;
+        using G = SwtColStreamGeom<HLEN, INV, TXC, TY>;
+        SwtColStreamArgs a;
+        for (int k = 0; k < 4; ++k) { a.in[k] = c.in[k]; a.out[k] = c.out[k]; }
+        a.Nr = c.Nr; a.Nc = c.Nc; a.f = c.f; a.in_bstride = c.in_bstride; a.out_bstride = c.out_bstride;
+        a.soft_beta = c.soft_beta; a.t = c.t;
+        a.wk = swt_walk(c.Nr, c.Nc, c.f, 4);
+        if ((c.Nc & 3) || a.wk.rows_phase < TY) return false;
+        a.strips = (c.Nc + TXC - 1) / TXC;
+        const char* e = getenv("EMU_COLSTREAM_SEG");  // rows of a chain per segment (default: two segments)
+        int seg = e ? atoi(e) : (a.wk.rows_phase + 1) / 2;
+        a.seg = (seg + TY - 1) / TY * TY;
+        a.segs = (a.wk.rows_phase + a.seg - 1) / a.seg;
+        std::vector<float> smem(G::LDS_REALS, NAN);
+        ++g_colstream_runs;
+        for (int bz = 0; bz < c.batch; ++bz)
+            for (int py = 0; py < a.wk.phases; ++py)
+                for (int sg = 0; sg < a.segs; ++sg)
+                    for (int st = 0; st < a.strips; ++st) swt_colstream_wg<HLEN, INV, TXC, TY, NT, M>(a, st, py, sg, bz, smem.data());
+        return true;
+    }
+}
+
 // ---- one a-trous level as a row pass + a column pass through scratch (swt_split_kernels.hpp); planes as in emu_swt2
 template <int HLEN>
 static void run_swt_split(const Swt2DArgs& a, int batch, bool inverse, float* tmp) {
@@ -966,6 +998,7 @@ static void run_swt_split(const Swt2DArgs& a, int batch, bool inverse, float* tm
     const long long row_lds = split_row_lds_waves(batch, a.Nr, a.Nc);
     std::vector<float> smem(16384, NAN);  // one workgroup's LDS
     const bool direct = getenv("EMU_SPLIT_DIRECT") != nullptr;  // dilation 4 through the kernel of the dilations >= 8 (quads f apart, no LDS)
+    const bool colstream = getenv("EMU_SPLIT_COLSTREAM") != nullptr;  // the column passes through swt_colstream_kernels.hpp
     auto blocks = [](long long waves) { return (waves + NT / 64 - 1) / (NT / 64); };
     if (!inverse) {
         SwtSplitArgs r = k;
@@ -977,12 +1010,14 @@ static void run_swt_split(const Swt2DArgs& a, int batch, bool inverse, float* tm
         SwtSplitArgs c = k;
         c.in[0] = tmp; c.in[1] = tmp + plane; c.in_bstride = 2 * plane;
         c.out[0] = a.A; c.out[1] = a.H; c.out[2] = a.V; c.out[3] = a.D; c.out_bstride = a.bstride;
+        if (colstream && run_swt_colstream<HLEN, false>(c)) return;
         for (long long b = 0; b < blocks(col_items); ++b) swt_col_fwd_tile<HLEN, R, NT>(c, b);
         return;
     }
     SwtSplitArgs c = k;
     c.in[0] = a.A; c.in[1] = a.H; c.in[2] = a.V; c.in[3] = a.D; c.in_bstride = a.bstride; c.out[0] = tmp; c.out_bstride = 2 * plane;
-    for (long long b = 0; b < blocks(col_items); ++b) swt_col_inv_tile<HLEN, R, NT>(c, b);
+    if (!(colstream && run_swt_colstream<HLEN, true>(c)))
+        for (long long b = 0; b < blocks(col_items); ++b) swt_col_inv_tile<HLEN, R, NT>(c, b);
     SwtSplitArgs r = k;
     r.in[0] = tmp; r.in_bstride = 2 * plane; r.out[0] = a.out; r.out_bstride = a.bstride;
     if (f == 1) for (long long b = 0; b < blocks(row_lds); ++b) swt_row_inv_lds_tile<HLEN, 1, 1, NT>(r, b, smem.data());

@@ -966,6 +966,54 @@ def test_emu_swt_split_row_and_column_launches(wname, direct, monkeypatch):
                 assert np.abs(rec[b] - want).max() <= _tol(want), (wname, shape, level, "inverse", beta)
 
 
+@pytest.mark.parametrize("seg", [0, 32])
+@pytest.mark.parametrize("wname", ["db5", "sym8", "db10", "db13", "db20"])
+def test_emu_swt_column_pass_streamed_through_an_lds_history(wname, seg, monkeypatch):
+    """swt_colstream_kernels.hpp (the column pass of the two-launch level walking down strips of 64 columns, the filter's history
+    in LDS, 8 output rows per work item) in place of the register column kernels, vs the oracle's per-pass functions: dilations
+    1 ... 8, row counts the dilation does not divide (chains of rows), ragged last strips and steps, one and several segments
+    per chain, batches, the pending soft threshold of the inverse"""
+    import ctypes as C
+    monkeypatch.setenv("EMU_SPLIT_COLSTREAM", "1")
+    if seg:
+        monkeypatch.setenv("EMU_COLSTREAM_SEG", str(seg))
+    else:
+        monkeypatch.delenv("EMU_COLSTREAM_SEG", raising=False)
+    hlen, dlo, dhi, rlo, rhi = oracle.filters(wname)
+    lib_o = oracle.load()
+    cases = [((64, 64), 1, 1), ((97, 136), 1, 2), ((130, 72), 2, 1), ((135, 200), 2, 1), ((160, 260), 3, 1), ((75, 68), 3, 1), ((264, 64), 4, 1)]
+    for si, (shape, level, B) in enumerate(cases):
+        x = np.stack([oracle.hash_input(shape, 4700 + 10 * si + b) for b in range(B)]).astype(np.float32)
+        outs = [np.full((B,) + shape, np.nan, dtype=np.float32) for _ in range(4)]
+        xin = x.copy()
+        before = lib().emu_colstream_runs()
+        assert lib().emu_swt2_split(0, P(xin), B, shape[0], shape[1], level, P(dlo), P(dhi), hlen, C.c_float(0.0),
+                                    *[P(o) for o in outs]) == 0
+        assert lib().emu_colstream_runs() == before + 1, (wname, shape, level)
+        bands = [(oracle.hash_input((B,) + shape, 4800 + si * 4 + k, 2.0) - 1.0).astype(np.float32) for k in range(4)]
+        for beta in (0.0, 0.25):
+            rec = np.full((B,) + shape, np.nan, dtype=np.float32)
+            assert lib().emu_swt2_split(1, P(rec), B, shape[0], shape[1], level, P(rlo), P(rhi), hlen, C.c_float(beta),
+                                        *[P(b) for b in bands]) == 0
+            for b in range(B):
+                t1 = np.zeros(shape, np.float32); t2 = np.zeros(shape, np.float32)
+                if beta == 0.0:
+                    ref = [np.zeros(shape, np.float32) for _ in range(4)]
+                    lib_o.oracle_swt_analysis_rows(P(x[b]), shape[0], shape[1], P(dlo), P(dhi), hlen, level, P(t1), P(t2))
+                    lib_o.oracle_swt_analysis_cols(P(t1), shape[0], shape[1], P(dlo), P(dhi), hlen, level, P(ref[0]), P(ref[1]))
+                    lib_o.oracle_swt_analysis_cols(P(t2), shape[0], shape[1], P(dlo), P(dhi), hlen, level, P(ref[2]), P(ref[3]))
+                    for k in range(4):
+                        assert np.isfinite(outs[k][b]).all(), (wname, shape, level, k)
+                        assert np.abs(outs[k][b] - ref[k]).max() <= _tol(ref[k]), (wname, shape, level, k)
+                d = [np.ascontiguousarray(bands[0][b])] + [np.ascontiguousarray(bands[k][b] - np.clip(bands[k][b], -beta, beta)) for k in (1, 2, 3)]
+                lib_o.oracle_swt_synthesis_cols(P(d[0]), P(d[1]), shape[0], shape[1], P(rlo), P(rhi), hlen, level, P(t1))
+                lib_o.oracle_swt_synthesis_cols(P(d[2]), P(d[3]), shape[0], shape[1], P(rlo), P(rhi), hlen, level, P(t2))
+                want = np.zeros(shape, np.float32)
+                lib_o.oracle_swt_synthesis_rows(P(t1), P(t2), shape[0], shape[1], P(rlo), P(rhi), hlen, level, P(want))
+                assert np.isfinite(rec[b]).all(), (wname, shape, level, "inverse")
+                assert np.abs(rec[b] - want).max() <= _tol(want), (wname, shape, level, "inverse", beta)
+
+
 @pytest.mark.parametrize("R", [2, 4, 8])
 @pytest.mark.parametrize("wname", ["haar", "db2", "db5", "sym8", "db10", "db13", "db20"])
 def test_emu_swt_stream_kernels(wname, R):
