@@ -764,7 +764,6 @@ int fwd_level_2d(pdwt_plan* p, int l, bool run) {
     } else {
         const int f = 1 << (l - 1);
         const int Nr = p->info.Nr, Nc = p->info.Nc;
-        bool split = swt2_split_supported(hlen, Nr, Nc, f, false, (long long)B * Nr * Nc) && ensure_tmp(p, 2LL * Nr * Nc * B) == PDWT_OK;
         Swt2DArgs a;
         a.in = src; a.A = dstA; a.H = H; a.V = V; a.D = D; a.out = nullptr;
         a.Nr = Nr; a.Nc = Nc; a.f = f;
@@ -772,6 +771,12 @@ int fwd_level_2d(pdwt_plan* p, int l, bool run) {
         a.hlen = hlen;
         a.soft_beta = 0.f;
         a.fb = p->dec;
+        if (swt2_fwd_stream_takes(a, B)) {  // row and column pass in one launch, streamed down strips (swt_fwdstream_kernels.hpp)
+            Stamp st(p, "swt2_fwd_stream");
+            if (run) HIP_TRY(try_launch_swt2_fwd_stream(a, B, p->stream));
+            return PDWT_OK;
+        }
+        bool split = swt2_split_supported(hlen, Nr, Nc, f, false, (long long)B * Nr * Nc) && ensure_tmp(p, 2LL * Nr * Nc * B) == PDWT_OK;
         if (split) {
             // the launcher reads the (process-wide, atomic) threshold again and checks alignments the predicate does not:
             // hipErrorNotSupported is a DECLINE (another thread may have moved the knob in between), not a failure
@@ -2065,6 +2070,7 @@ int pdwt_set_tuning(const char* key, int value) {
     if (key && !strcmp(key, "long_fwd")) return set_long_min_taps(0, value);
     if (key && !strcmp(key, "long_inv")) return set_long_min_taps(1, value);
     if (key && !strcmp(key, "swt_colstream")) return set_swt_colstream_min(value);
+    if (key && !strcmp(key, "swt_fwdstream")) return set_swt_fwdstream_min(value);
     if (key && !strcmp(key, "wave2")) return set_wave2_enabled(value);
     if (key && !strcmp(key, "reg1d")) return set_reg1d_enabled(value);
     if (key && !strcmp(key, "swt_fused")) return set_swt_fused_enabled(value);

@@ -27,6 +27,7 @@
 #include "../../pypwt_amd/csrc/swt_kernels.hpp"
 #include "../../pypwt_amd/csrc/swt_split_kernels.hpp"
 #include "../../pypwt_amd/csrc/swt_colstream_kernels.hpp"
+#include "../../pypwt_amd/csrc/swt_fwdstream_kernels.hpp"
 #include "../../pypwt_amd/csrc/swt_stream_kernels.hpp"
 #include "../../pypwt_amd/csrc/dwt2_stream_kernels.hpp"
 #include "../../pypwt_amd/csrc/dwt2_split_kernels.hpp"
@@ -982,6 +983,42 @@ static bool run_swt_colstream(const SwtSplitArgs& c) {
                     for (int st = 0; st < a.strips; ++st) swt_colstream_wg<HLEN, INV, TXC, TY, NT, M>(a, st, py, sg, bz, smem.data());
         return true;
     }
+}
+
+// ---- one forward a-trous level in ONE launch, row and column pass streamed down strips (swt_fwdstream_kernels.hpp)
+template <int HLEN, int F>
+static int run_swt_fwdstream(const float* in, float* A, float* H, float* V, float* D, int batch, int Nr, int Nc, const float* lo, const float* hi, int seg_rows) {
+    constexpr int TXC = 64, TY = F == 8 ? 16 : 32, NT = 256, KB = F == 8 ? 4 : 8, M = F == 8 ? 4 : 8;
+    using G = SwtFwdStreamGeom<HLEN, F, TXC, TY>;
+    SwtFwdStreamArgs a;
+    a.in = in; a.A = A; a.H = H; a.V = V; a.D = D; a.Nr = Nr; a.Nc = Nc; a.bstride = (long long)Nr * Nc;
+    a.wk = swt_walk(Nr, Nc, F, 4);
+    if ((Nc & 3) || a.wk.rows_phase < TY) return -2;
+    for (int j = 0; j < HLEN; ++j) a.t.t[j] = mk2(lo[HLEN - 1 - j], hi[HLEN - 1 - j]);
+    a.strips = (Nc + TXC - 1) / TXC;
+    const int seg = seg_rows > 0 ? seg_rows : (a.wk.rows_phase + 1) / 2;
+    a.seg = (seg + TY - 1) / TY * TY;
+    a.segs = (a.wk.rows_phase + a.seg - 1) / a.seg;
+    std::vector<float> smem(G::LDS_REALS, NAN);
+    for (int bz = 0; bz < batch; ++bz)
+        for (int py = 0; py < a.wk.phases; ++py)
+            for (int sg = 0; sg < a.segs; ++sg)
+                for (int st = 0; st < a.strips; ++st) {
+                    std::fill(smem.begin(), smem.end(), NAN);
+                    swt_fwdstream_wg<HLEN, F, TXC, TY, NT, KB, M>(a, st, py, sg, bz, smem.data());
+                }
+    return 0;
+}
+
+EMU_API int emu_swt2_fwdstream(const float* in, int batch, int Nr, int Nc, int level, const float* lo, const float* hi, int hlen,
+                               int seg_rows, float* A, float* H, float* V, float* D) {
+    const int f = 1 << (level - 1);
+#define Y(h, ff) if (hlen == h && f == ff) return run_swt_fwdstream<h, ff>(in, A, H, V, D, batch, Nr, Nc, lo, hi, seg_rows);
+#define X(h) Y(h, 1) Y(h, 2) Y(h, 4) Y(h, 8)
+    X(6) X(8) X(10) X(12) X(16) X(20) X(26) X(40)
+#undef X
+#undef Y
+    return -1;
 }
 
 // ---- one a-trous level as a row pass + a column pass through scratch (swt_split_kernels.hpp); planes as in emu_swt2

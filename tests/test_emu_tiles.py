@@ -1014,6 +1014,34 @@ def test_emu_swt_column_pass_streamed_through_an_lds_history(wname, seg, monkeyp
                 assert np.abs(rec[b] - want).max() <= _tol(want), (wname, shape, level, "inverse", beta)
 
 
+@pytest.mark.parametrize("seg", [0, 32])
+@pytest.mark.parametrize("wname", ["db3", "db4", "db5", "sym8", "db10", "db13", "db20"])
+def test_emu_swt_forward_level_in_one_launch(wname, seg):
+    """swt_fwdstream_kernels.hpp (row pass and column pass of a forward a-trous level streamed down strips of 64 columns: the
+    dilation's column phases de-interleaved in LDS, the row-filtered rows never leave it) vs the oracle's SWT: dilations 1 ... 8,
+    row counts the dilation does not divide, ragged last strips and steps, one and several segments per chain, batches"""
+    hlen, dlo, dhi, rlo, rhi = oracle.filters(wname)
+    cases = [((64, 64), 1, 1), ((97, 136), 1, 2), ((130, 72), 2, 1), ((135, 200), 2, 1), ((160, 260), 3, 1), ((150, 68), 3, 1), ((264, 64), 4, 1),
+             ((160, 132), 4, 1)]
+    for si, (shape, level, B) in enumerate(cases):
+        if level > oracle.max_level(min(shape), hlen) + 1 and hlen > 20:
+            pass  # (the a-trous level itself is defined for any size: the oracle's per-pass functions are the reference)
+        x = np.stack([oracle.hash_input(shape, 5100 + 10 * si + b) for b in range(B)]).astype(np.float32)
+        outs = [np.full((B,) + shape, np.nan, dtype=np.float32) for _ in range(4)]
+        rc = lib().emu_swt2_fwdstream(P(x), B, shape[0], shape[1], level, P(dlo), P(dhi), hlen, seg, *[P(o) for o in outs])
+        assert rc == 0, (wname, shape, level, rc)
+        lib_o = oracle.load()
+        for b in range(B):
+            t1 = np.zeros(shape, np.float32); t2 = np.zeros(shape, np.float32)
+            ref = [np.zeros(shape, np.float32) for _ in range(4)]
+            lib_o.oracle_swt_analysis_rows(P(x[b]), shape[0], shape[1], P(dlo), P(dhi), hlen, level, P(t1), P(t2))
+            lib_o.oracle_swt_analysis_cols(P(t1), shape[0], shape[1], P(dlo), P(dhi), hlen, level, P(ref[0]), P(ref[1]))
+            lib_o.oracle_swt_analysis_cols(P(t2), shape[0], shape[1], P(dlo), P(dhi), hlen, level, P(ref[2]), P(ref[3]))
+            for k in range(4):
+                assert np.isfinite(outs[k][b]).all(), (wname, shape, level, k)
+                assert np.abs(outs[k][b] - ref[k]).max() <= _tol(ref[k]), (wname, shape, level, k)
+
+
 @pytest.mark.parametrize("R", [2, 4, 8])
 @pytest.mark.parametrize("wname", ["haar", "db2", "db5", "sym8", "db10", "db13", "db20"])
 def test_emu_swt_stream_kernels(wname, R):

@@ -16,7 +16,9 @@ pytestmark = pytest.mark.gpu
 def forced():
     from pypwt_amd import _lib
     lib = _lib.load()
-    prev = [(k, lib.pdwt_set_tuning(k, v)) for k, v in ((b"swt_colstream", 110), (b"swt_split_fwd", 104), (b"swt_split_inv", 104))]
+    # ("swt_fwdstream" = 0: the one-launch forward levels of swt_fwdstream_kernels.hpp -- tests/test_gpu_fwdstream.py -- would take
+    # the forward of dilations 1-8 otherwise)
+    prev = [(k, lib.pdwt_set_tuning(k, v)) for k, v in ((b"swt_colstream", 110), (b"swt_split_fwd", 104), (b"swt_split_inv", 104), (b"swt_fwdstream", 0))]
     assert min(v for _, v in prev) >= 0
     yield
     for k, v in prev:
@@ -98,12 +100,13 @@ def test_colstream_batches_vs_oracle():
 
 def test_colstream_default_dispatch_at_full_size():
     """What the plans launch by themselves: db20 on 2048^2, five levels (the reference benchmark's largest case) -- the inverse's column
-    passes on the strips, the forward's on the register kernels; sym8 on 4096^2: both.  Every element against the oracle."""
+    passes on the strips, the forward's levels 1-4 in one launch each (swt_fwdstream_kernels.hpp) and level 5 (dilation 16) as two
+    launches with the column pass in registers; db7 on 2048 x 4096: level 5's column pass on the strips.  Every element against the oracle."""
     from pypwt_amd import Wavelets, _lib
     lib = _lib.load()
-    prev = [(k, lib.pdwt_set_tuning(k, v)) for k, v in ((b"swt_colstream", 10), (b"swt_split_fwd", 14), (b"swt_split_inv", 10))]
+    prev = [(k, lib.pdwt_set_tuning(k, v)) for k, v in ((b"swt_colstream", 10), (b"swt_split_fwd", 14), (b"swt_split_inv", 10), (b"swt_fwdstream", 6))]
     try:
-        for wname, shape, levels, fwd_family in (("db20", (2048, 2048), 5, "packed"), ("sym8", (4096, 4096), 2, "colstream")):
+        for wname, shape, levels, fwd_family in (("db20", (2048, 2048), 5, "packed"), ("db7", (2048, 4096), 5, "colstream")):
             x = oracle.hash_input(shape, 4242)
             w = Wavelets(x, wname, levels, do_swt=1)
             w.forward()
@@ -113,6 +116,7 @@ def test_colstream_default_dispatch_at_full_size():
             w.inverse()
             assert np.abs(w.image - x).max() < 7e-4 * 255, wname
             fams = _families(x, wname, levels)
+            assert [n for n, f in fams if n.startswith("swt2_fwd")] == ["swt2_fwd_stream"] * 4 + ["swt2_fwd_split"], fams
             assert {f for n, f in fams if n == "swt2_fwd_split"} == {fwd_family}, fams
             assert {f for n, f in fams if n == "swt2_inv_split"} == {"colstream"}, fams
     finally:

@@ -158,6 +158,16 @@ def run(budget=None, max_cases=None, seed=1):
                 done[kind] = done.get(kind, 0) + check(1, (int(rng.integers(1, 40)), int(rng.integers(130, 5000))), str(rng.choice(longn)), int(rng.integers(1, 4)), 1, rng, kind, ndim=1)
             else:
                 done[kind] = done.get(kind, 0) + check(int(rng.choice([1, 1, 2, 3])), (r, c), str(rng.choice(longn)), int(rng.integers(1, 4)), 1, rng, kind)
+        elif kind == "swt-r6":        # round 6: one-launch forward levels (6-40 taps, dilations 1-8), column pass on strips, fused 2-/4-tap groups on any size
+            r, c = int(rng.integers(32, 900)), int(rng.integers(64, 1300))
+            if rng.integers(0, 2) == 0:
+                c = (c + 3) // 4 * 4      # rows of whole 16-B groups: the strip kernels
+            if rng.integers(0, 6) == 0:
+                r, c = int(rng.choice([256, 512, 1024, 2048])), int(rng.choice([256, 512, 1024, 2048]))
+            B = int(rng.choice([1, 1, 1, 2, 3, 7]))
+            if B * r * c > (1 << 22):
+                B = 1
+            done[kind] = done.get(kind, 0) + check(B, (r, c), str(rng.choice(names)), int(rng.choice([1, 2, 3, 4, 5, 99])), 1, rng, kind)
         elif kind == "real-sizes":    # camera / video / scan formats and their neighbours: rows of 8 but not 16 samples (forward pair pyramid only,
             # three levels per launch for the inverse), levels that turn odd on the way down, DWT and SWT
             base = [(480, 640), (600, 800), (720, 1280), (768, 1024), (1000, 1000), (1080, 1920), (1200, 1600), (1500, 2000), (520, 1000), (904, 1000), (1000, 1048)]
