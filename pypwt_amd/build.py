@@ -54,6 +54,7 @@ SOURCES = [
     "launch_swt_fused.hip",
     "launch_swt_split.hip",
     "launch_swt_fwdstream.hip",
+    "launch_swt_invstream.hip",
     "launch_dwt2_split.hip",
     "launch_ops.hip",
     "launch_nonsep.hip",

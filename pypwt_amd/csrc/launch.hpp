@@ -20,7 +20,7 @@ enum EwOp { EW_SOFT = 0, EW_HARD = 1, EW_LINF = 2, EW_SCALE = 3 };
 // third thread calling pdwt_set_tuning -- cannot change each other's kernel choice in mid-transform; with no active set
 // (direct calls of the launchers: tools, emulation) the process-wide values apply.
 struct Tuning {
-    int wave_min_log2, lds_max_log2, swt_split_fwd, swt_split_inv, dwt_split_fwd, dwt_split_inv, ring_min_log2, long_fwd, long_inv, swt_colstream, swt_fwdstream;
+    int wave_min_log2, lds_max_log2, swt_split_fwd, swt_split_inv, dwt_split_fwd, dwt_split_inv, ring_min_log2, long_fwd, long_inv, swt_colstream, swt_fwdstream, swt_invstream;
     int wave2, swt_fused, chain, reg1d;  // read by build_schedule: a clone rebuilds its launch lists from its source's values
 };
 Tuning current_tuning();                  // the process-wide values now
@@ -61,6 +61,8 @@ int set_swt_colstream_min(int taps);  // column pass of the two-launch SWT level
 int get_swt_colstream_min();
 int set_swt_fwdstream_min(int taps);  // forward SWT levels in one launch (swt_fwdstream_kernels.hpp) from `taps` taps; 0: never; 100 + n: n taps at every size
 int get_swt_fwdstream_min();
+int set_swt_invstream_min(int taps);  // ... inverse SWT levels in one launch (swt_invstream_kernels.hpp)
+int get_swt_invstream_min();
 int set_ring_min_log2(int value);  // 2D DWT levels of at least 2^value samples with 12-20 taps run on them (63 = never; below the default: 10-20 taps, tests)
 int get_ring_min_log2();
 int set_wave_min_log2(int value);  // returns the previous threshold
@@ -144,6 +146,8 @@ hipError_t launch_swt2_fwd(const Swt2DArgs& a, int batch, hipStream_t s);
 hipError_t launch_swt2_inv(const Swt2DArgs& a, int batch, hipStream_t s);
 bool swt2_fwd_stream_takes(const Swt2DArgs& a, int batch);  // the one-launch forward level of swt_fwdstream_kernels.hpp would take this level
 hipError_t try_launch_swt2_fwd_stream(const Swt2DArgs& a, int batch, hipStream_t s);  // hipErrorNotSupported: declined
+bool swt2_inv_stream_takes(const Swt2DArgs& a, int batch);
+hipError_t try_launch_swt2_inv_stream(const Swt2DArgs& a, int batch, hipStream_t s);
 // one a-trous level as a row launch + a column launch through scratch (2 Nr Nc batch elements): swt_split_kernels.hpp
 bool swt2_split_supported(int hlen, int Nr, int Nc, int f, bool inverse, long long samples_per_launch);
 int set_swt_split_min(int inverse, int taps);  // shortest filter on the split path (0: never); returns the previous value

@@ -262,6 +262,7 @@ Tuning current_tuning() {
     t.long_inv = get_long_min_taps(1);
     t.swt_colstream = get_swt_colstream_min();
     t.swt_fwdstream = get_swt_fwdstream_min();
+    t.swt_invstream = get_swt_invstream_min();
     t.wave2 = get_wave2_enabled();
     t.swt_fused = get_swt_fused_enabled();
     t.chain = get_chain_enabled();

@@ -1,0 +1,108 @@
+// launch_swt_invstream.hip -- launcher of the one-launch inverse a-trous level (swt_invstream_kernels.hpp); a translation unit of its
+// own: the filter lengths x dilations compile beside the other launchers.
+#include <atomic>
+#include <cstdint>
+#include <cstdlib>
+
+#include "launch.hpp"
+#include "launch_util.hpp"
+#include "tuning.hpp"
+#include "swt_kernels_args.hpp"
+#ifndef PDWT_DOUBLE
+#include "swt_invstream_kernels.hpp"
+#endif
+
+namespace pdwt {
+
+// shortest filter on these kernels (tuning key "swt_invstream"; 0 = never, 100 + n = n taps at every size they take)
+static std::atomic<int>& invstream_min() {
+    static std::atomic<int> v{(int)tune::swt_invstream_taps};
+    return v;
+}
+int set_swt_invstream_min(int taps) { return invstream_min().exchange(taps < 0 ? 0 : taps); }
+int get_swt_invstream_min() { return invstream_min().load(std::memory_order_relaxed); }
+
+#ifdef PDWT_DOUBLE
+bool swt2_inv_stream_takes(const Swt2DArgs&, int) { return false; }
+hipError_t try_launch_swt2_inv_stream(const Swt2DArgs&, int, hipStream_t) { return hipErrorNotSupported; }
+#else
+static inline v2f mk2h(real_t a, real_t b) {
+    v2f r;
+    r.x = a;
+    r.y = b;
+    return r;
+}
+
+template <int HLEN, int F>
+static hipError_t run(const Swt2DArgs& g, int batch, hipStream_t s) {
+    // the staged rows are pairs (8 B per sample): dilations 4 and 8 walk in steps of 16 rows (two workgroups per CU)
+    {
+    constexpr bool kShort = F >= 4 || (F == 2 && HLEN > 36);
+    constexpr int TXC = 64, TY = kShort ? 16 : 32, NT = 256, KB = kShort ? 4 : 8, M = kShort ? 4 : 8, MINB = 2;
+    using G = SwtInvStreamGeom<HLEN, F, TXC, TY>;
+    SwtInvStreamArgs a;
+    a.A = g.A; a.H = g.H; a.V = g.V; a.D = g.D; a.out = g.out;
+    a.Nr = g.Nr; a.Nc = g.Nc; a.bstride = g.bstride;
+    a.soft_beta = g.soft_beta;
+    a.wk = swt_walk(g.Nr, g.Nc, F, 4);
+    if (a.wk.rows_phase < TY) return hipErrorNotSupported;
+    for (int j = 0; j < HLEN; ++j) a.t.t[j] = mk2h(g.fb.lo[HLEN - 1 - j], g.fb.hi[HLEN - 1 - j]);
+    a.strips = cdiv(g.Nc, TXC);
+    // Segments as in launch_swt_fwdstream.hip: 512 workgroups per launch for long filters, 1024 up to 12 taps
+    const long long units = (long long)a.strips * a.wk.phases * batch;
+    static const int forced_target = lab_env("PDWT_INVSTREAM_WGS") ? atoi(lab_env("PDWT_INVSTREAM_WGS")) : 0;  // A/B measurements
+    const int target = forced_target > 0 ? forced_target : (HLEN <= tune::swt_invstream_short_taps ? 1024 : 512);
+    int segs = (int)cdivll(target, units);
+    if (segs < 1) segs = 1;
+    a.seg = cdiv(cdiv(a.wk.rows_phase, segs), TY) * TY;
+    a.segs = cdiv(a.wk.rows_phase, a.seg);
+    static std::atomic<bool> big[64] = {};
+    constexpr size_t lds = (size_t)G::LDS_REALS * sizeof(real_t);
+    auto kern = swt_invstream_kernel<HLEN, F, TXC, TY, NT, KB, M, MINB>;
+    hipError_t e = allow_big_lds(kern, lds, big);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(8 * cdiv(a.strips * a.segs * a.wk.phases, 8), batch), dim3(NT), lds, s, a);
+    return hipGetLastError();
+    }
+}
+
+// Built for 6-20 taps: beyond, the two launches with the column pass on the strips (swt_colstream_kernels.hpp) are as fast or faster
+// (2048^2 per level: db10 0.90-0.92x at dilations 1-4 but 1.18x at dilation 8; db20 1.07-1.18x; 4096^2 db20 1.03-1.28x: profiles/r06_swt_invstream.txt)
+// -- the row synthesis here is the 80-FMA pass and runs out of 8-B LDS reads, and the loads of four planes in flight beside 80 tap registers spill
+#ifndef PDWT_INVSTREAM_HLENS
+#define PDWT_INVSTREAM_HLENS(X) X(6) X(8) X(10) X(12) X(14) X(16) X(18) X(20)
+#endif
+
+bool swt2_inv_stream_takes(const Swt2DArgs& a, int batch) {
+    const Tuning* at = active_tuning();
+    int min_taps = at ? at->swt_invstream : get_swt_invstream_min();
+    const bool forced = min_taps >= 100;
+    if (forced) min_taps -= 100;
+    if (min_taps <= 0 || a.hlen < min_taps || a.hlen < 6 || (a.hlen & 1) || a.hlen > kMaxTaps) return false;
+    if (a.f != 1 && a.f != 2 && a.f != 4 && a.f != 8) return false;
+    if ((a.Nc & 3) || (a.bstride & 3) || batch < 1 || batch > 65535) return false;
+    if ((long long)a.Nr * a.Nc * (long long)sizeof(real_t) >= (1LL << 32)) return false;  // 32-bit byte offsets inside a plane
+    if (a.hlen > tune::swt_invstream_max_taps || (a.f == 8 && a.hlen > tune::swt_invstream_f8_max_taps && !forced)) return false;
+    if (swt_walk(a.Nr, a.Nc, a.f, 4).rows_phase < (a.f >= 4 ? 16 : 32)) return false;     // chains of at least one step
+    auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    if (!al16(a.out) || !al16(a.A) || !al16(a.H) || !al16(a.V) || !al16(a.D)) return false;
+    return forced || (long long)batch * a.Nr * a.Nc >= (1LL << tune::swt_invstream_log2);
+}
+
+hipError_t try_launch_swt2_inv_stream(const Swt2DArgs& a, int batch, hipStream_t s) {
+    if (!swt2_inv_stream_takes(a, batch)) return hipErrorNotSupported;
+    switch (a.hlen) {
+#define X(h)                                            \
+    case h:                                             \
+        if (a.f == 1) return run<h, 1>(a, batch, s);    \
+        if (a.f == 2) return run<h, 2>(a, batch, s);    \
+        if (a.f == 4) return run<h, 4>(a, batch, s);    \
+        return run<h, 8>(a, batch, s);
+        PDWT_INVSTREAM_HLENS(X)
+#undef X
+    }
+    return hipErrorNotSupported;
+}
+#endif
+
+}  // namespace pdwt

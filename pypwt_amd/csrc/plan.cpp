@@ -855,7 +855,6 @@ int inv_level_2d(pdwt_plan* p, int l, bool run) {
     } else {
         const int f = 1 << (l - 1);
         const int Nr = p->info.Nr, Nc = p->info.Nc;
-        bool split = swt2_split_supported(hlen, Nr, Nc, f, true, (long long)B * Nr * Nc) && ensure_tmp(p, 2LL * Nr * Nc * B) == PDWT_OK;
         Swt2DArgs a;
         a.in = nullptr;
         a.A = const_cast<real_t*>(cur); a.H = const_cast<real_t*>(H);
@@ -867,6 +866,12 @@ int inv_level_2d(pdwt_plan* p, int l, bool run) {
         a.soft_beta = 0.f;
         if (p->pend_soft) a.soft_beta = pending_beta_of_level(p, l);
         a.fb = p->rec;
+        if (swt2_inv_stream_takes(a, B)) {  // row and column synthesis in one launch, streamed down strips (swt_invstream_kernels.hpp)
+            Stamp st(p, p->pend_soft ? "swt2_inv_stream+soft" : "swt2_inv_stream");
+            if (run) HIP_TRY(try_launch_swt2_inv_stream(a, B, p->stream));
+            return PDWT_OK;
+        }
+        bool split = swt2_split_supported(hlen, Nr, Nc, f, true, (long long)B * Nr * Nc) && ensure_tmp(p, 2LL * Nr * Nc * B) == PDWT_OK;
         if (split) {  // a decline (hipErrorNotSupported) falls through to the other kernels, see fwd_level_2d
             Stamp st(p, p->pend_soft ? "swt2_inv_split+soft" : "swt2_inv_split");
             const hipError_t e = run ? launch_swt2_split(a, p->tmp, true, B, p->stream) : hipSuccess;
@@ -2071,6 +2076,7 @@ int pdwt_set_tuning(const char* key, int value) {
     if (key && !strcmp(key, "long_inv")) return set_long_min_taps(1, value);
     if (key && !strcmp(key, "swt_colstream")) return set_swt_colstream_min(value);
     if (key && !strcmp(key, "swt_fwdstream")) return set_swt_fwdstream_min(value);
+    if (key && !strcmp(key, "swt_invstream")) return set_swt_invstream_min(value);
     if (key && !strcmp(key, "wave2")) return set_wave2_enabled(value);
     if (key && !strcmp(key, "reg1d")) return set_reg1d_enabled(value);
     if (key && !strcmp(key, "swt_fused")) return set_swt_fused_enabled(value);

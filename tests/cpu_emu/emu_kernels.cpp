@@ -28,6 +28,7 @@
 #include "../../pypwt_amd/csrc/swt_split_kernels.hpp"
 #include "../../pypwt_amd/csrc/swt_colstream_kernels.hpp"
 #include "../../pypwt_amd/csrc/swt_fwdstream_kernels.hpp"
+#include "../../pypwt_amd/csrc/swt_invstream_kernels.hpp"
 #include "../../pypwt_amd/csrc/swt_stream_kernels.hpp"
 #include "../../pypwt_amd/csrc/dwt2_stream_kernels.hpp"
 #include "../../pypwt_amd/csrc/dwt2_split_kernels.hpp"
@@ -1016,6 +1017,44 @@ EMU_API int emu_swt2_fwdstream(const float* in, int batch, int Nr, int Nc, int l
 #define Y(h, ff) if (hlen == h && f == ff) return run_swt_fwdstream<h, ff>(in, A, H, V, D, batch, Nr, Nc, lo, hi, seg_rows);
 #define X(h) Y(h, 1) Y(h, 2) Y(h, 4) Y(h, 8)
     X(6) X(8) X(10) X(12) X(16) X(20) X(26) X(40)
+#undef X
+#undef Y
+    return -1;
+}
+
+// ---- one inverse a-trous level in ONE launch (swt_invstream_kernels.hpp)
+template <int HLEN, int F>
+static int run_swt_invstream(const float* A, const float* H, const float* V, const float* D, float* out, int batch, int Nr, int Nc, const float* lo,
+                             const float* hi, float beta, int seg_rows) {
+    constexpr bool kShort = F >= 4 || (F == 2 && HLEN > 36);  // launch_swt_invstream.hip
+    constexpr int TXC = 64, TY = kShort ? 16 : 32, NT = 256, KB = kShort ? 4 : 8, M = kShort ? 4 : 8;
+    using G = SwtInvStreamGeom<HLEN, F, TXC, TY>;
+    SwtInvStreamArgs a;
+    a.A = A; a.H = H; a.V = V; a.D = D; a.out = out; a.Nr = Nr; a.Nc = Nc; a.bstride = (long long)Nr * Nc; a.soft_beta = beta;
+    a.wk = swt_walk(Nr, Nc, F, 4);
+    if ((Nc & 3) || a.wk.rows_phase < TY) return -2;
+    for (int j = 0; j < HLEN; ++j) a.t.t[j] = mk2(lo[HLEN - 1 - j], hi[HLEN - 1 - j]);
+    a.strips = (Nc + TXC - 1) / TXC;
+    const int seg = seg_rows > 0 ? seg_rows : (a.wk.rows_phase + 1) / 2;
+    a.seg = (seg + TY - 1) / TY * TY;
+    a.segs = (a.wk.rows_phase + a.seg - 1) / a.seg;
+    std::vector<float> smem(G::LDS_REALS, NAN);
+    for (int bz = 0; bz < batch; ++bz)
+        for (int py = 0; py < a.wk.phases; ++py)
+            for (int sg = 0; sg < a.segs; ++sg)
+                for (int st = 0; st < a.strips; ++st) {
+                    std::fill(smem.begin(), smem.end(), NAN);
+                    swt_invstream_wg<HLEN, F, TXC, TY, NT, KB, M>(a, st, py, sg, bz, smem.data());
+                }
+    return 0;
+}
+
+EMU_API int emu_swt2_invstream(const float* A, const float* H, const float* V, const float* D, int batch, int Nr, int Nc, int level, const float* lo,
+                               const float* hi, int hlen, float beta, int seg_rows, float* out) {
+    const int f = 1 << (level - 1);
+#define Y(h, ff) if (hlen == h && f == ff) return run_swt_invstream<h, ff>(A, H, V, D, out, batch, Nr, Nc, lo, hi, beta, seg_rows);
+#define X(h) Y(h, 1) Y(h, 2) Y(h, 4) Y(h, 8)
+    X(6) X(8) X(10) X(12) X(16) X(18) X(20)  // (the product builds 6-20 taps)
 #undef X
 #undef Y
     return -1;

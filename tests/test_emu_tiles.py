@@ -1042,6 +1042,34 @@ def test_emu_swt_forward_level_in_one_launch(wname, seg):
                 assert np.abs(outs[k][b] - ref[k]).max() <= _tol(ref[k]), (wname, shape, level, k)
 
 
+@pytest.mark.parametrize("seg", [0, 32])
+@pytest.mark.parametrize("wname", ["db3", "db4", "db5", "db6", "sym8", "coif3", "db10"])
+def test_emu_swt_inverse_level_in_one_launch(wname, seg):
+    """swt_invstream_kernels.hpp (row synthesis, then column synthesis, of an inverse a-trous level streamed down strips; the (P, Q)
+    halves never leave LDS) vs the oracle's per-pass functions (column synthesis first: the passes commute, fp32 rounding differs):
+    dilations 1 ... 8, row counts the dilation does not divide, ragged last strips and steps, segments, batches, the soft threshold"""
+    import ctypes as C
+    hlen, dlo, dhi, rlo, rhi = oracle.filters(wname)
+    lib_o = oracle.load()
+    cases = [((64, 64), 1, 1), ((97, 136), 1, 2), ((130, 72), 2, 1), ((135, 200), 2, 1), ((160, 260), 3, 1), ((150, 68), 3, 1), ((264, 64), 4, 1),
+             ((160, 132), 4, 1)]
+    for si, (shape, level, B) in enumerate(cases):
+        bands = [(oracle.hash_input((B,) + shape, 5300 + si * 4 + k, 2.0) - 1.0).astype(np.float32) for k in range(4)]
+        for beta in (0.0, 0.25):
+            rec = np.full((B,) + shape, np.nan, dtype=np.float32)
+            rc = lib().emu_swt2_invstream(*[P(b) for b in bands], B, shape[0], shape[1], level, P(rlo), P(rhi), hlen, C.c_float(beta), seg, P(rec))
+            assert rc == 0, (wname, shape, level, rc)
+            for b in range(B):
+                t1 = np.zeros(shape, np.float32); t2 = np.zeros(shape, np.float32)
+                d = [np.ascontiguousarray(bands[0][b])] + [np.ascontiguousarray(bands[k][b] - np.clip(bands[k][b], -beta, beta)) for k in (1, 2, 3)]
+                lib_o.oracle_swt_synthesis_cols(P(d[0]), P(d[1]), shape[0], shape[1], P(rlo), P(rhi), hlen, level, P(t1))
+                lib_o.oracle_swt_synthesis_cols(P(d[2]), P(d[3]), shape[0], shape[1], P(rlo), P(rhi), hlen, level, P(t2))
+                want = np.zeros(shape, np.float32)
+                lib_o.oracle_swt_synthesis_rows(P(t1), P(t2), shape[0], shape[1], P(rlo), P(rhi), hlen, level, P(want))
+                assert np.isfinite(rec[b]).all(), (wname, shape, level, "inverse")
+                assert np.abs(rec[b] - want).max() <= _tol(want), (wname, shape, level, "inverse", beta)
+
+
 @pytest.mark.parametrize("R", [2, 4, 8])
 @pytest.mark.parametrize("wname", ["haar", "db2", "db5", "sym8", "db10", "db13", "db20"])
 def test_emu_swt_stream_kernels(wname, R):

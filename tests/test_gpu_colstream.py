@@ -16,9 +16,10 @@ pytestmark = pytest.mark.gpu
 def forced():
     from pypwt_amd import _lib
     lib = _lib.load()
-    # ("swt_fwdstream" = 0: the one-launch forward levels of swt_fwdstream_kernels.hpp -- tests/test_gpu_fwdstream.py -- would take
-    # the forward of dilations 1-8 otherwise)
-    prev = [(k, lib.pdwt_set_tuning(k, v)) for k, v in ((b"swt_colstream", 110), (b"swt_split_fwd", 104), (b"swt_split_inv", 104), (b"swt_fwdstream", 0))]
+    # ("swt_fwdstream" / "swt_invstream" = 0: the one-launch levels of swt_fwdstream_kernels.hpp / swt_invstream_kernels.hpp --
+    # tests/test_gpu_fwdstream.py, test_gpu_invstream.py -- would take dilations 1-8 otherwise)
+    prev = [(k, lib.pdwt_set_tuning(k, v)) for k, v in ((b"swt_colstream", 110), (b"swt_split_fwd", 104), (b"swt_split_inv", 104), (b"swt_fwdstream", 0),
+                                                           (b"swt_invstream", 0))]
     assert min(v for _, v in prev) >= 0
     yield
     for k, v in prev:
@@ -104,7 +105,7 @@ def test_colstream_default_dispatch_at_full_size():
     launches with the column pass in registers; db7 on 2048 x 4096: level 5's column pass on the strips.  Every element against the oracle."""
     from pypwt_amd import Wavelets, _lib
     lib = _lib.load()
-    prev = [(k, lib.pdwt_set_tuning(k, v)) for k, v in ((b"swt_colstream", 10), (b"swt_split_fwd", 14), (b"swt_split_inv", 10), (b"swt_fwdstream", 6))]
+    prev = [(k, lib.pdwt_set_tuning(k, v)) for k, v in ((b"swt_colstream", 10), (b"swt_split_fwd", 14), (b"swt_split_inv", 10), (b"swt_fwdstream", 6), (b"swt_invstream", 6))]
     try:
         for wname, shape, levels, fwd_family in (("db20", (2048, 2048), 5, "packed"), ("db7", (2048, 4096), 5, "colstream")):
             x = oracle.hash_input(shape, 4242)

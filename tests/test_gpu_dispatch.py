@@ -21,9 +21,9 @@ REACHABLE = {
             ("dwt2_inv_tail", ""), ("dwt2_fwd_strip2", ""),
             ("dwt1_fwd_level", ""), ("dwt1_inv_level", ""), ("dwt1_fwd_reg", ""), ("dwt1_inv_reg", ""), ("dwt1_fwd_fused", ""),
             ("dwt1_inv_fused", ""),
-            ("swt2_fwd_level", ""), ("swt2_inv_level", ""), ("swt2_fwd_split", "packed"), ("swt2_inv_split", "packed"),
+            ("swt2_fwd_level", ""), ("swt2_inv_level", ""), ("swt2_fwd_split", "packed"),
             ("swt2_fwd_split", "stream"), ("swt2_inv_split", "stream"), ("swt2_fwd_split", "colstream"), ("swt2_inv_split", "colstream"),
-            ("swt2_fwd_fused", ""), ("swt2_fwd_stream", ""),
+            ("swt2_fwd_fused", ""), ("swt2_fwd_stream", ""), ("swt2_inv_stream", ""),
             ("swt2_inv_fused", ""), ("swt2_fwd_fused", "anysize"), ("swt2_inv_fused", "anysize"), ("swt2_fwd_tail", ""), ("swt2_inv_tail", ""), ("swt1_fwd_level", ""), ("swt1_inv_level", "")},
     "f64": {("dwt2_fwd_level", "tile"), ("dwt2_fwd_level", "wave"), ("dwt2_inv_level", "tile"), ("dwt2_inv_level", "wave"),
             ("dwt2_fwd_level", "long"), ("dwt2_inv_level", "long"),

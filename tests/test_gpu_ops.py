@@ -829,11 +829,13 @@ def test_plan_keeps_the_tuning_it_was_created_with():
     lib = _lib.load()
     x = oracle.hash_input((128, 192), 911, scale=255.0)
     prev = lib.pdwt_set_tuning(b"swt_split_fwd", 110)
+    prev_stream = lib.pdwt_set_tuning(b"swt_fwdstream", 0)  # (round 6: the one-launch forward levels would serve both plans)
     try:
         A = BatchedWavelets(1, 128, 192, "db6", 2, do_swt=1, img=x[None])
         lib.pdwt_set_tuning(b"swt_split_fwd", 0)
         B = BatchedWavelets(1, 128, 192, "db6", 2, do_swt=1, img=x[None])
         lib.pdwt_set_tuning(b"swt_split_fwd", 130)  # neither plan's value
+        lib.pdwt_set_tuning(b"swt_fwdstream", 6)    # ... nor this one's
         names = {}
 
         def run(tag, plan):
@@ -854,6 +856,7 @@ def test_plan_keeps_the_tuning_it_was_created_with():
                 assert np.abs(plan.coeff(k)[0] - r).max() <= 2e-5 * max(float(np.abs(r).max()), 255.0)
     finally:
         lib.pdwt_set_tuning(b"swt_split_fwd", prev)
+        lib.pdwt_set_tuning(b"swt_fwdstream", prev_stream)
 
 
 @pytest.mark.gpu

@@ -399,11 +399,12 @@ def swt_split_off():
     from pypwt_amd import _lib
     lib = _lib.load()
     prev = lib.pdwt_set_tuning(b"swt_split_fwd", 0), lib.pdwt_set_tuning(b"swt_split_inv", 0)
-    prev_stream = lib.pdwt_set_tuning(b"swt_fwdstream", 0)  # (... and, since round 6, the one-launch forward levels from 6 taps)
+    prev_stream = lib.pdwt_set_tuning(b"swt_fwdstream", 0), lib.pdwt_set_tuning(b"swt_invstream", 0)  # (... and, since round 6, the one-launch levels from 6 taps)
     yield
     lib.pdwt_set_tuning(b"swt_split_fwd", prev[0])
     lib.pdwt_set_tuning(b"swt_split_inv", prev[1])
-    lib.pdwt_set_tuning(b"swt_fwdstream", prev_stream)
+    lib.pdwt_set_tuning(b"swt_fwdstream", prev_stream[0])
+    lib.pdwt_set_tuning(b"swt_invstream", prev_stream[1])
 
 
 @pytest.mark.gpu
@@ -442,7 +443,7 @@ def test_swt_two_launch_levels(wname, shape, levels, batch):
     from pypwt_amd import BatchedWavelets, _lib
     lib = _lib.load()
     prev = lib.pdwt_set_tuning(b"swt_split_fwd", 110), lib.pdwt_set_tuning(b"swt_split_inv", 110)  # 10 taps, at every size
-    prev_stream = lib.pdwt_set_tuning(b"swt_fwdstream", 0)  # (round 6: the one-launch forward levels would take dilations 1-8 otherwise)
+    prev_stream = lib.pdwt_set_tuning(b"swt_fwdstream", 0), lib.pdwt_set_tuning(b"swt_invstream", 0)  # (round 6: the one-launch levels would take dilations 1-8 otherwise)
     try:
         x = np.stack([oracle.hash_input(shape, 140 + b, scale=255.0) for b in range(batch)])
         bw = BatchedWavelets(batch, shape[0], shape[1], wname, levels, do_swt=1, img=x)
@@ -471,7 +472,8 @@ def test_swt_two_launch_levels(wname, shape, levels, batch):
     finally:
         lib.pdwt_set_tuning(b"swt_split_fwd", prev[0])
         lib.pdwt_set_tuning(b"swt_split_inv", prev[1])
-        lib.pdwt_set_tuning(b"swt_fwdstream", prev_stream)
+        lib.pdwt_set_tuning(b"swt_fwdstream", prev_stream[0])
+        lib.pdwt_set_tuning(b"swt_invstream", prev_stream[1])
 
 
 @pytest.mark.gpu
