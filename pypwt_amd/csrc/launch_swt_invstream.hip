@@ -48,19 +48,18 @@ static hipError_t run(const Swt2DArgs& g, int batch, hipStream_t s) {
     if (a.wk.rows_phase < TY) return hipErrorNotSupported;
     for (int j = 0; j < HLEN; ++j) a.t.t[j] = mk2h(g.fb.lo[HLEN - 1 - j], g.fb.hi[HLEN - 1 - j]);
     a.strips = cdiv(g.Nc, TXC);
-    // Segments as in launch_swt_fwdstream.hip: 512 workgroups per launch for long filters, 1024 up to 12 taps
+    // Segments as in launch_swt_fwdstream.hip (strip_walk_seg)
     const long long units = (long long)a.strips * a.wk.phases * batch;
-    static const int forced_target = lab_env("PDWT_INVSTREAM_WGS") ? atoi(lab_env("PDWT_INVSTREAM_WGS")) : 0;  // A/B measurements
-    const int target = forced_target > 0 ? forced_target : (HLEN <= tune::swt_invstream_short_taps ? 1024 : 512);
-    int segs = (int)cdivll(target, units);
-    if (segs < 1) segs = 1;
-    a.seg = cdiv(cdiv(a.wk.rows_phase, segs), TY) * TY;
-    a.segs = cdiv(a.wk.rows_phase, a.seg);
     static std::atomic<bool> big[64] = {};
     constexpr size_t lds = (size_t)G::LDS_REALS * sizeof(real_t);
     auto kern = swt_invstream_kernel<HLEN, F, TXC, TY, NT, KB, M, MINB>;
     hipError_t e = allow_big_lds(kern, lds, big);
     if (e != hipSuccess) return e;
+    static std::atomic<int> slots_cache{0};
+    static const int forced_slots = lab_env("PDWT_STRIP_SLOTS") ? atoi(lab_env("PDWT_STRIP_SLOTS")) : 0;  // A/B measurements
+    const int slots = forced_slots > 0 ? forced_slots : resident_slots(kern, NT, lds, &slots_cache);
+    a.seg = strip_walk_seg(a.wk.rows_phase, units, TY, G::W, slots);
+    a.segs = cdiv(a.wk.rows_phase, a.seg);
     hipLaunchKernelGGL(kern, dim3(8 * cdiv(a.strips * a.segs * a.wk.phases, 8), batch), dim3(NT), lds, s, a);
     return hipGetLastError();
     }

@@ -274,18 +274,17 @@ static hipError_t run_colstream(const SwtSplitArgs& c, hipStream_t s) {
         // 32-bit byte offsets inside a plane (buffer stores), chains the staging plan can advance with one conditional wrap
         if ((c.Nc & 3) || a.wk.rows_phase < TY || c.batch > 65535 || (long long)c.Nr * c.Nc * 2 * (long long)sizeof(real_t) >= (1LL << 32)) return hipErrorNotSupported;
         a.strips = cdiv(c.Nc, TXC);
-        // two workgroups per CU: segments as long as 512 workgroups allow (a segment re-loads hlen - 1 rows, it filters none twice)
+        // segments as long as one round of resident workgroups allows (strip_walk_seg; a segment re-loads hlen - 1 rows, it filters none twice)
         const long long units = (long long)a.strips * a.wk.phases * c.batch;
-        static const int target = lab_env("PDWT_COLSTREAM_WGS") ? atoi(lab_env("PDWT_COLSTREAM_WGS")) : 512;  // A/B measurements
-        int segs = (int)cdivll(target, units);
-        if (segs < 1) segs = 1;
-        a.seg = cdiv(cdiv(a.wk.rows_phase, segs), TY) * TY;
-        a.segs = cdiv(a.wk.rows_phase, a.seg);
         static std::atomic<bool> big[64] = {};
         constexpr size_t lds = (size_t)G::LDS_REALS * sizeof(real_t);
         auto kern = swt_colstream_kernel<HLEN, INV, TXC, TY, NT, M, MINB>;
         hipError_t e = allow_big_lds(kern, lds, big);
         if (e != hipSuccess) return e;
+        static std::atomic<int> slots_cache{0};
+        static const int forced_slots = lab_env("PDWT_STRIP_SLOTS") ? atoi(lab_env("PDWT_STRIP_SLOTS")) : 0;  // A/B measurements
+        a.seg = strip_walk_seg(a.wk.rows_phase, units, TY, 1, forced_slots > 0 ? forced_slots : resident_slots(kern, NT, lds, &slots_cache));
+        a.segs = cdiv(a.wk.rows_phase, a.seg);
         hipLaunchKernelGGL(kern, dim3(8 * cdiv(a.strips * a.segs * a.wk.phases, 8), c.batch), dim3(NT), lds, s, a);
         return hipGetLastError();
     }
