@@ -31,14 +31,11 @@ constexpr int kLongTXC = kLongF64 ? 32 : 64, kLongTY = 16, kLongNT = kLongF64 ? 
 // Rows per segment: the walk of a workgroup re-filters the D history rows of its segment (hlen - 2 input rows forward,
 // hlen / 2 coefficient rows inverse), so long segments are cheaper -- but the chip wants two workgroups per CU (512): one
 // 4096^2 level is 32 strips x 16 segments of 128 rows, a batch of 16 images one segment per strip.
-static int long_seg(int rows, int strips, int batch, int hint, int ty = kLongTY) {
+// (strip_walk_seg, launch_util.hpp: the whole number of steps with the fewest rounds of 512 resident workgroups x steps per workgroup; the first
+// version rounded ceil(rows / segments) up to whole steps, which halves the workgroups just past a power of two)
+static int long_seg(int rows, int strips, int batch, int hint, int ty, int warm) {
     if (hint > 0) return cdiv(hint, ty) * ty;
-    const long long units = (long long)strips * (batch > 0 ? batch : 1);
-    long long segs = cdivll(512, units);
-    if (segs < 1) segs = 1;
-    int seg = (int)cdivll(rows, segs);
-    seg = cdiv(seg, ty) * ty;
-    return seg < ty ? ty : seg;
+    return strip_walk_seg(rows, (long long)strips * (batch > 0 ? batch : 1), ty, warm, 512);
 }
 
 template <int HLEN>
@@ -63,7 +60,7 @@ static hipError_t run_fwd(const Fwd2DArgs& g, int batch, int seg_hint, hipStream
     a.Nr = g.Nr; a.Nc = g.Nc; a.Nr2 = g.Nr2; a.Nc2 = g.Nc2;
     a.in_bstride = g.in_bstride; a.out_bstride = g.out_bstride;
     a.strips = cdiv(g.Nc2, TXC);
-    a.seg = long_seg(g.Nr2, a.strips, batch, seg_hint, TY);
+    a.seg = long_seg(g.Nr2, a.strips, batch, seg_hint, TY, G::W);
     a.segs = cdiv(g.Nr2, a.seg);
     for (int i = 0; i < kMaxTaps; i++) a.fb.t[i] = mk2_host(g.fb.lo[i], g.fb.hi[i]);
     hipLaunchKernelGGL(kern, dim3(8 * cdiv(a.strips * a.segs, 8), batch), dim3(NT), lds, s, a);
@@ -86,7 +83,7 @@ static hipError_t run_inv(const Inv2DArgs& g, int batch, int seg_hint, hipStream
     a.Nrc = g.Nrc; a.Ncc = g.Ncc; a.Nr = g.Nr; a.Nc = g.Nc;
     a.in_bstride = g.in_bstride; a.out_bstride = g.out_bstride;
     a.strips = cdiv(g.Ncc, TXC);
-    a.seg = long_seg(g.Nrc, a.strips, batch, seg_hint);
+    a.seg = long_seg(g.Nrc, a.strips, batch, seg_hint, TY, G::W);
     a.segs = cdiv(g.Nrc, a.seg);
     long_syn_tables<HLEN>(a, g.fb.lo, g.fb.hi);
     hipLaunchKernelGGL(kern, dim3(8 * cdiv(a.strips * a.segs, 8), batch), dim3(NT), lds, s, a);

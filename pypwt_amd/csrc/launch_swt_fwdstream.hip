@@ -36,7 +36,8 @@ static inline v2f mk2h(real_t a, real_t b) {
 template <int HLEN, int F>
 static hipError_t run(const Swt2DArgs& g, int batch, hipStream_t s) {
     // dilation 8: 47-sample phases of 8 columns each -- steps of 16 rows keep the staged rows + the history at 53 KB (two workgroups per CU)
-    constexpr int TXC = 64, TY = F == 8 ? 16 : 32, NT = 256, KB = F == 8 ? 4 : 8, M = F == 8 ? 4 : 8, MINB = 2;
+    // (dilation 16: phases of 4 columns: the staged row is 64 + 15 (hlen - 1) columns wide for 64 outputs)
+    constexpr int TXC = 64, TY = F >= 8 ? 16 : 32, NT = 256, KB = F >= 8 ? 4 : 8, M = F >= 8 ? 4 : 8, MINB = 2;
     using G = SwtFwdStreamGeom<HLEN, F, TXC, TY>;
     SwtFwdStreamArgs a;
     a.in = g.in; a.A = g.A; a.H = g.H; a.V = g.V; a.D = g.D;
@@ -74,10 +75,10 @@ bool swt2_fwd_stream_takes(const Swt2DArgs& a, int batch) {
     const bool forced = min_taps >= 100;
     if (forced) min_taps -= 100;
     if (min_taps <= 0 || a.hlen < min_taps || a.hlen < 6 || (a.hlen & 1) || a.hlen > kMaxTaps) return false;
-    if (a.f != 1 && a.f != 2 && a.f != 4 && a.f != 8) return false;
+    if (a.f != 1 && a.f != 2 && a.f != 4 && a.f != 8 && a.f != 16) return false;
     if ((a.Nc & 3) || (a.bstride & 3) || batch < 1 || batch > 65535) return false;
     if ((long long)a.Nr * a.Nc * (long long)sizeof(real_t) >= (1LL << 32)) return false;  // 32-bit byte offsets inside a plane
-    if (swt_walk(a.Nr, a.Nc, a.f, 4).rows_phase < (a.f == 8 ? 16 : 32)) return false;     // chains of at least one step
+    if (swt_walk(a.Nr, a.Nc, a.f, 4).rows_phase < (a.f >= 8 ? 16 : 32)) return false;     // chains of at least one step
     auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     if (!al16(a.in) || !al16(a.A) || !al16(a.H) || !al16(a.V) || !al16(a.D)) return false;
     return forced || (long long)batch * a.Nr * a.Nc >= (1LL << tune::swt_fwdstream_log2);
@@ -91,7 +92,8 @@ hipError_t try_launch_swt2_fwd_stream(const Swt2DArgs& a, int batch, hipStream_t
         if (a.f == 1) return run<h, 1>(a, batch, s);    \
         if (a.f == 2) return run<h, 2>(a, batch, s);    \
         if (a.f == 4) return run<h, 4>(a, batch, s);    \
-        return run<h, 8>(a, batch, s);
+        if (a.f == 8) return run<h, 8>(a, batch, s);    \
+        return run<h, 16>(a, batch, s);
         PDWT_FWDSTREAM_HLENS(X)
 #undef X
     }

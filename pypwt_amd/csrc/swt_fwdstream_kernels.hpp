@@ -18,7 +18,7 @@
 //   column  swt_colstream_kernels.hpp's forward pass: M output rows of a column, M + hlen - 1 buffer rows slide past them.
 // Nothing is filtered twice along y except the D warm-up rows in front of a segment (row pass only); the x halo is only loaded.
 // Index convention of swt_split_kernels.hpp: out[i] = sum_j in[i + (j - c) f] t[j], c = hlen / 2 - 1, t[j] = (lo, hi)[hlen - 1 - j].
-// Preconditions (the launcher checks them): even hlen 6-40, f = F in {1, 2, 4, 8}, Nc % 4 == 0, 16-B aligned planes, chains of at
+// Preconditions (the launcher checks them): even hlen 6-40, f = F in {1, 2, 4, 8, 16}, Nc % 4 == 0, 16-B aligned planes, chains of at
 // least TY rows, planes below 4 GiB.
 #pragma once
 
@@ -38,7 +38,7 @@ struct SwtFwdStreamArgs {
 
 template <int HLEN, int F, int TXC, int TY>
 struct SwtFwdStreamGeom {
-    static_assert(F == 1 || F == 2 || F == 4 || F == 8, "dilations whose phases tile a strip");
+    static_assert(F == 1 || F == 2 || F == 4 || F == 8 || F == 16, "dilations whose phases tile a strip");
     static constexpr int C = HLEN / 2 - 1;
     static constexpr int D = HLEN - 1;                           // rows of history an output row needs
     static constexpr int W = (D + TY - 1) / TY;                  // warm-up steps: staging and row pass only
@@ -58,7 +58,7 @@ template <int HLEN, int F, int TXC, int TY, int NT, int KB, int M>
 PDWT_DEVICE void swt_fwdstream_wg(const SwtFwdStreamArgs& a, int strip, int py, int seg, int bz, real_t* smem) {
     using G = SwtFwdStreamGeom<HLEN, F, TXC, TY>;
     constexpr int C = G::C, D = G::D, W = G::W, PADL = G::PADL, NQ = G::NQ, PWA = G::PWA, RXA = G::RXA, XS = G::XS;
-    static_assert(TXC % (F * KB) == 0 && KB % 4 == 0, "row-pass items tile the phases in whole 16-B groups");
+    static_assert(TXC % (F * KB) == 0 && (KB % 4 == 0 || TXC == F * KB), "row-pass items tile the phases in whole 16-B groups");
     static_assert((TY / M) * TXC == NT && TXC % 64 == 0 && NT % 64 == 0, "one column-pass item per thread, one block of M rows per wavefront");
     constexpr int TOTAL = TY * NQ, TRIPS = (TOTAL + NT - 1) / NT;
     constexpr int CARRY = D * TXC / 2, CTRIPS = (CARRY + NT - 1) / NT;  // 16-B groups of the D carried rows of (lo, hi) pairs

@@ -989,7 +989,7 @@ static bool run_swt_colstream(const SwtSplitArgs& c) {
 // ---- one forward a-trous level in ONE launch, row and column pass streamed down strips (swt_fwdstream_kernels.hpp)
 template <int HLEN, int F>
 static int run_swt_fwdstream(const float* in, float* A, float* H, float* V, float* D, int batch, int Nr, int Nc, const float* lo, const float* hi, int seg_rows) {
-    constexpr int TXC = 64, TY = F == 8 ? 16 : 32, NT = 256, KB = F == 8 ? 4 : 8, M = F == 8 ? 4 : 8;
+    constexpr int TXC = 64, TY = F >= 8 ? 16 : 32, NT = 256, KB = F >= 8 ? 4 : 8, M = F >= 8 ? 4 : 8;
     using G = SwtFwdStreamGeom<HLEN, F, TXC, TY>;
     SwtFwdStreamArgs a;
     a.in = in; a.A = A; a.H = H; a.V = V; a.D = D; a.Nr = Nr; a.Nc = Nc; a.bstride = (long long)Nr * Nc;
@@ -1015,7 +1015,7 @@ EMU_API int emu_swt2_fwdstream(const float* in, int batch, int Nr, int Nc, int l
                                int seg_rows, float* A, float* H, float* V, float* D) {
     const int f = 1 << (level - 1);
 #define Y(h, ff) if (hlen == h && f == ff) return run_swt_fwdstream<h, ff>(in, A, H, V, D, batch, Nr, Nc, lo, hi, seg_rows);
-#define X(h) Y(h, 1) Y(h, 2) Y(h, 4) Y(h, 8)
+#define X(h) Y(h, 1) Y(h, 2) Y(h, 4) Y(h, 8) Y(h, 16)
     X(6) X(8) X(10) X(12) X(16) X(20) X(26) X(40)
 #undef X
 #undef Y

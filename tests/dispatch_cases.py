@@ -36,8 +36,8 @@ CASES = [
     ("swt2", "db4", (512, 512), 3, 1, "f32"),        # level launches
     ("swt2", "db10", (2048, 2048), 2, 1, "f32"),     # row + column launches (split)
     ("swt2", "sym8", (1024, 1024), 2, 1, "f32"),
-    ("swt2", "db7", (2048, 4096), 5, 1, "f32"),      # level 5 (dilation 16) of 2^23 samples: the two-launch forward with its column pass on the strips (the inverse's at every size)
-    ("swt2", "db10", (1024, 2048), 5, 1, "f32"),     # ... of 2^21 samples: in registers
+    ("swt2", "db7", (2048, 4096), 6, 1, "f32"),      # level 6 (dilation 32) of 2^23 samples: the two-launch forward with its column pass on the strips (the inverse's at every size)
+    ("swt2", "db7", (1024, 2048), 6, 1, "f32"),      # ... of 2^21 samples: in registers
     ("swt2", "haar", (32, 32), 3, 2000, "f32"),      # tiny images: one workgroup each
     ("swt2", "db3", (30, 44), 2, 1, "f32"),          # dilation does not divide the rows
     ("swt2", "db10", (250, 1022), 2, 1, "f32"),      # rows that are not whole quads, 20 taps: the any-length stream kernels

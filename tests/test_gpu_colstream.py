@@ -101,13 +101,13 @@ def test_colstream_batches_vs_oracle():
 
 def test_colstream_default_dispatch_at_full_size():
     """What the plans launch by themselves: db20 on 2048^2, five levels (the reference benchmark's largest case) -- the inverse's column
-    passes on the strips, the forward's levels 1-4 in one launch each (swt_fwdstream_kernels.hpp) and level 5 (dilation 16) as two
-    launches with the column pass in registers; db7 on 2048 x 4096: level 5's column pass on the strips.  Every element against the oracle."""
+    passes on the strips, the forward's levels in one launch each (swt_fwdstream_kernels.hpp); db7 on 2048 x 4096, six levels: level 6
+    (dilation 32) as two launches with the column pass on the strips.  Every element against the oracle."""
     from pypwt_amd import Wavelets, _lib
     lib = _lib.load()
     prev = [(k, lib.pdwt_set_tuning(k, v)) for k, v in ((b"swt_colstream", 10), (b"swt_split_fwd", 14), (b"swt_split_inv", 10), (b"swt_fwdstream", 6), (b"swt_invstream", 6))]
     try:
-        for wname, shape, levels, fwd_family in (("db20", (2048, 2048), 5, "packed"), ("db7", (2048, 4096), 5, "colstream")):
+        for wname, shape, levels, fwd_family in (("db20", (2048, 2048), 5, None), ("db7", (2048, 4096), 6, "colstream")):
             x = oracle.hash_input(shape, 4242)
             w = Wavelets(x, wname, levels, do_swt=1)
             w.forward()
@@ -117,8 +117,8 @@ def test_colstream_default_dispatch_at_full_size():
             w.inverse()
             assert np.abs(w.image - x).max() < 7e-4 * 255, wname
             fams = _families(x, wname, levels)
-            assert [n for n, f in fams if n.startswith("swt2_fwd")] == ["swt2_fwd_stream"] * 4 + ["swt2_fwd_split"], fams
-            assert {f for n, f in fams if n == "swt2_fwd_split"} == {fwd_family}, fams
+            assert [n for n, f in fams if n.startswith("swt2_fwd")] == ["swt2_fwd_stream"] * 5 + ["swt2_fwd_split"] * (levels - 5), fams
+            assert {f for n, f in fams if n == "swt2_fwd_split"} == ({fwd_family} if fwd_family else set()), fams
             assert {f for n, f in fams if n == "swt2_inv_split"} == {"colstream"}, fams
     finally:
         for k, v in prev:

@@ -1,7 +1,7 @@
 """GPU parity of the one-launch forward SWT levels (pypwt_amd/csrc/swt_fwdstream_kernels.hpp: row pass and column pass of an a-trous
 level streamed down column strips, the row-filtered rows never leave LDS; reference: w_kern_forward_swt_pass1 / _pass2,
 pdwt/src/separable.cu:409-493, which take every hlen <= 40 and any size, and which test/benchmark.py:24-38 times with haar and db20).
-By default they serve filters of 6 taps and more at dilations 1-8 from 2^18 samples per launch; here
+By default they serve filters of 6 taps and more at dilations 1-16 from 2^14 samples per launch; here
 pdwt_set_tuning("swt_fwdstream", 106) sends every eligible level through them, compared with the CPU oracle element by element."""
 import numpy as np
 import pytest
@@ -60,9 +60,9 @@ def test_fwdstream_levels_vs_oracle(wname):
 
 
 def test_fwdstream_declines_what_it_cannot_take():
-    """Rows that are not whole 16-B groups, chains shorter than one step, dilation 16: the other kernels; results stay right."""
+    """Rows that are not whole 16-B groups, chains shorter than one step, dilation 32: the other kernels; results stay right."""
     from pypwt_amd import Wavelets
-    for shape, levels, expect in (((128, 130), 1, [False]), ((48, 256), 2, [True, False]), ((1024, 256), 5, [True, True, True, True, False])):
+    for shape, levels, expect in (((128, 130), 1, [False]), ((48, 256), 2, [True, False]), ((2048, 512), 6, [True, True, True, True, True, False])):
         x = oracle.hash_input(shape, 78)
         w = Wavelets(x, "db4", levels, do_swt=1)
         w.forward()
