@@ -622,6 +622,46 @@ def long_filters(device, steps=20):
     return recs
 
 
+SWT_FILTER_PLANS = (("db4", 2048, 2048, 4), ("sym8", 1080, 1920, 3), ("db20", 2048, 2048, 5))
+
+
+def swt_filters(device, steps=20):
+    """Round 6: the undecimated transform with filters of 6 taps and more, driver-timed -- the denoising step of the reference's
+    documentation (doc/denoising.rst:85-141: forward, soft threshold, inverse) on db4 2048^2 L4 and sym8 1080 x 1920 L3, and the
+    reference benchmark's own largest case (test/benchmark.py:24-38: swt2 db20 2048^2 at the maximum level, forward); pipelined,
+    median of three regions of `steps` calls; the launch list says which kernels served every level.  Algorithmic bytes: 20 B per
+    sample and level in each direction (one plane in, four out / four in, one out)."""
+    from pypwt_amd import BatchedWavelets
+    recs = []
+    for wname, Nr, Nc, L in SWT_FILTER_PLANS:
+        plan = BatchedWavelets(1, Nr, Nc, wname, L, do_swt=1, device=device)
+        try:
+            plan.fill_hash(20240 + 4, 255.0)
+
+            def denoise():
+                plan.forward()
+                plan.soft_threshold(3.0)
+                plan.inverse()
+            for _ in range(5):
+                denoise()
+            plan.synchronize()
+            fwd = median([timed_steps(plan.forward, plan.synchronize, steps) for _ in range(3)])
+            step = median([timed_steps(denoise, plan.synchronize, steps) for _ in range(3)])
+            plan.enable_kernel_timing(True)
+            plan.reset_kernel_times()
+            denoise()
+            fams = list(zip([n for n, _ in plan.kernel_times()], plan.kernel_families()))
+            plan.enable_kernel_timing(False)
+            recs.append({"workload": "swt2 %dx%d fp32 %s L%d" % (Nr, Nc, wname, plan.levels), "forward_us": fwd * 1e6,
+                         "forward_threshold_inverse_us": step * 1e6,
+                         "forward_frac_of_hbm_peak": 20.0 * plan.levels * Nr * Nc / fwd / 1e9 / HBM_PEAK_GBPS,
+                         "step_frac_of_hbm_peak": 40.0 * plan.levels * Nr * Nc / step / 1e9 / HBM_PEAK_GBPS,
+                         "launches": ["%s:%s" % (n, f) if f else n for n, f in fams]})
+        finally:
+            plan.cleanup()
+    return recs
+
+
 def kernel_profile(plan, step, cfg, config_name, B, steps, step_us=None):
     """Per-launch shares of one step (HIP events on the plan's stream), the dominant kernel re-timed alone, its
     roofline and the copy ceiling measured beside it.  Returns (kernels, roofline, names of one step's launches)."""
@@ -998,6 +1038,10 @@ def main():
                 extra["long_filters"] = long_filters(local_rank)
             except Exception as e:
                 extra["long_filters"] = {"error": repr(e)}
+            try:
+                extra["swt_filters"] = swt_filters(local_rank)
+            except Exception as e:
+                extra["swt_filters"] = {"error": repr(e)}
             try:
                 extra["beyond_infinity_cache"] = beyond_mall(cfg, local_rank, args.steps)
             except Exception as e:

@@ -88,6 +88,14 @@ long long pdwt_copy_capacity(pdwt_handle h); /* the largest `elems` pdwt_time_co
  *                    forward level, 16 taps 93 -> 40 us per inverse level); the inverse of images below 1024^2 / 2048^2 starts at 24 / 12 taps
  *                    (two one-round launches cost more than they save there); 0 = never; 100 + n = n taps at every size (tests).
  *                    Part of the plan's snapshot.
+ *   "swt_fwdstream" / "swt_invstream"   (round 6) the shortest (even) filter whose 2D SWT levels run in ONE launch each, row and
+ *                    column pass streamed down column strips (swt_fwdstream_kernels.hpp: 6-40 taps, dilations 1-16;
+ *                    swt_invstream_kernels.hpp: 6-20 taps, dilations 1-8; rows of whole 16-B groups, from 2^14 samples per
+ *                    launch): default 6; 0 = never (the levels then run on the tiles / the two launches above); 100 + n = n
+ *                    taps at every size they take (tests).  Part of the plan's snapshot.
+ *   "swt_colstream"  (round 6) the shortest (even) filter whose two-launch SWT levels run their COLUMN pass as a strip walk with the
+ *                    filter's history in LDS (swt_colstream_kernels.hpp) instead of the register kernels: default 10 (the inverse
+ *                    at every size, the forward from 2^23 samples per launch); 0 = never; 100 + n = n taps, both directions, every size.
  *   "dwt_split_fwd" / "dwt_split_inv"   the shortest (even) filter whose DECIMATED 2D levels run as a register-blocked row
  *                    launch + column launch through scratch (dwt2_split_kernels.hpp; rows and columns even, columns a
  *                    multiple of 8) instead of one LDS-tiled launch.  Default 0 (never): measured no faster than LDS tiles

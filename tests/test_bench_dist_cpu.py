@@ -182,6 +182,7 @@ def test_target_and_in_step_rules_of_the_line():
     assert [p[0] for p in bench.LONG_FILTER_PLANS] == ["db20", "db20"] and bench.LONG_FILTER_PLANS[1][1:] == (4096, 4096, 3)
     src = open(bench.__file__).read()
     assert 'out["target"] = target_record(' in src and 'extra["long_filters"] = long_filters(' in src
+    assert 'extra["swt_filters"] = swt_filters(' in src  # round 6: the SWT denoising step and the reference benchmark's db20 case
 
 
 def test_dry_run_eight_ranks_is_the_cfg5_shard():

@@ -9,7 +9,7 @@ for f in bench_default bench_cfg1 bench_cfg3 bench_cfg4 bench_cfg5_shard bench_c
     [ -s "$S/$f.json" ] && cp "$S/$f.json" "profiles/${TAG}_$f.json"
 done
 for f in rocprofv3_summary_cfg2 rocprofv3_summary_cfg3 rocprofv3_summary_cfg4 rocprofv3_summary_db20_4096_L3_b1 rocprofv3_summary_db20_4096_L3_b4 \
-         long_ab f64_long_ab opsbench cliffs_long sizes_cliff refbench; do
+         long_ab f64_long_ab opsbench cliffs_long sizes_cliff refbench swt_round6_ab swt_any_ab rocprofv3_summary_swt_db4_2048_L4 rocprofv3_summary_swt_db20_2048_L5; do
     [ -s "$S/$f.txt" ] && cp "$S/$f.txt" "profiles/${TAG}_$f.txt"
 done
 [ -s "$S/dispatch_table.md" ] && cp "$S/dispatch_table.md" "profiles/${TAG}_dispatch_table.md"
