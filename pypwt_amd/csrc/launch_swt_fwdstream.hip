@@ -8,9 +8,7 @@
 #include "launch_util.hpp"
 #include "tuning.hpp"
 #include "swt_kernels_args.hpp"
-#ifndef PDWT_DOUBLE
 #include "swt_fwdstream_kernels.hpp"
-#endif
 
 namespace pdwt {
 
@@ -22,10 +20,11 @@ static std::atomic<int>& fwdstream_min() {
 int set_swt_fwdstream_min(int taps) { return fwdstream_min().exchange(taps < 0 ? 0 : taps); }
 int get_swt_fwdstream_min() { return fwdstream_min().load(std::memory_order_relaxed); }
 
-#ifdef PDWT_DOUBLE
-bool swt2_fwd_stream_takes(const Swt2DArgs&, int) { return false; }
-hipError_t try_launch_swt2_fwd_stream(const Swt2DArgs&, int, hipStream_t) { return hipErrorNotSupported; }
-#else
+// The fp64 library (the reference's DOUBLEPRECISION build, pdwt/src/filters.h:16-30) runs the same kernels for 6-20 taps at dilations 1-8:
+// steps of 16 rows (an element is 8 bytes: 36 KB of history + 11-20 KB of staged rows at 20 taps), the 40 tap registers of fp32's 40 taps
+constexpr bool kF64 = sizeof(real_t) == 8;
+constexpr int kFwdStreamMaxTaps = kF64 ? 20 : kMaxTaps, kFwdStreamMaxF = kF64 ? 8 : 16;
+
 static inline v2f mk2h(real_t a, real_t b) {
     v2f r;
     r.x = a;
@@ -37,7 +36,10 @@ template <int HLEN, int F>
 static hipError_t run(const Swt2DArgs& g, int batch, hipStream_t s) {
     // dilation 8: 47-sample phases of 8 columns each -- steps of 16 rows keep the staged rows + the history at 53 KB (two workgroups per CU)
     // (dilation 16: phases of 4 columns: the staged row is 64 + 15 (hlen - 1) columns wide for 64 outputs)
-    constexpr int TXC = 64, TY = F >= 8 ? 16 : 32, NT = 256, KB = F >= 8 ? 4 : 8, M = F >= 8 ? 4 : 8, MINB = 2;
+    if constexpr (HLEN > kFwdStreamMaxTaps || F > kFwdStreamMaxF || (kF64 && F == 8 && HLEN > 18)) return hipErrorNotSupported;  // (fp64, 20 taps, dilation 8: 44 B of scratch)
+    else {
+    constexpr bool kShort = F >= 8 || kF64;
+    constexpr int TXC = 64, TY = kShort ? 16 : 32, NT = 256, KB = kShort ? 4 : 8, M = kShort ? 4 : 8, MINB = 2;
     using G = SwtFwdStreamGeom<HLEN, F, TXC, TY>;
     SwtFwdStreamArgs a;
     a.in = g.in; a.A = g.A; a.H = g.H; a.V = g.V; a.D = g.D;
@@ -63,6 +65,7 @@ static hipError_t run(const Swt2DArgs& g, int batch, hipStream_t s) {
     a.segs = cdiv(a.wk.rows_phase, a.seg);
     hipLaunchKernelGGL(kern, dim3(8 * cdiv(a.strips * a.segs * a.wk.phases, 8), batch), dim3(NT), lds, s, a);
     return hipGetLastError();
+    }
 }
 
 #ifndef PDWT_FWDSTREAM_HLENS
@@ -74,12 +77,12 @@ bool swt2_fwd_stream_takes(const Swt2DArgs& a, int batch) {
     int min_taps = at ? at->swt_fwdstream : get_swt_fwdstream_min();
     const bool forced = min_taps >= 100;
     if (forced) min_taps -= 100;
-    if (min_taps <= 0 || a.hlen < min_taps || a.hlen < 6 || (a.hlen & 1) || a.hlen > kMaxTaps) return false;
-    if (a.f != 1 && a.f != 2 && a.f != 4 && a.f != 8 && a.f != 16) return false;
+    if (min_taps <= 0 || a.hlen < min_taps || a.hlen < 6 || (a.hlen & 1) || a.hlen > kFwdStreamMaxTaps) return false;
+    if ((a.f != 1 && a.f != 2 && a.f != 4 && a.f != 8 && a.f != 16) || a.f > kFwdStreamMaxF || (kF64 && a.f == 8 && a.hlen > 18)) return false;
     if ((a.Nc & 3) || (a.bstride & 3) || batch < 1 || batch > 65535) return false;
     if ((long long)a.Nr * a.Nc * (long long)sizeof(real_t) >= (1LL << 32)) return false;  // 32-bit byte offsets inside a plane
-    if (swt_walk(a.Nr, a.Nc, a.f, 4).rows_phase < (a.f >= 8 ? 16 : 32)) return false;     // chains of at least one step
-    auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    if (swt_walk(a.Nr, a.Nc, a.f, 4).rows_phase < (a.f >= 8 || kF64 ? 16 : 32)) return false;     // chains of at least one step
+    auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & (4 * sizeof(real_t) - 1)) == 0; };  // a 4-element group
     if (!al16(a.in) || !al16(a.A) || !al16(a.H) || !al16(a.V) || !al16(a.D)) return false;
     return forced || (long long)batch * a.Nr * a.Nc >= (1LL << tune::swt_fwdstream_log2);
 }
@@ -99,6 +102,6 @@ hipError_t try_launch_swt2_fwd_stream(const Swt2DArgs& a, int batch, hipStream_t
     }
     return hipErrorNotSupported;
 }
-#endif
+
 
 }  // namespace pdwt

@@ -8,9 +8,7 @@
 #include "launch_util.hpp"
 #include "tuning.hpp"
 #include "swt_kernels_args.hpp"
-#ifndef PDWT_DOUBLE
 #include "swt_invstream_kernels.hpp"
-#endif
 
 namespace pdwt {
 
@@ -22,10 +20,10 @@ static std::atomic<int>& invstream_min() {
 int set_swt_invstream_min(int taps) { return invstream_min().exchange(taps < 0 ? 0 : taps); }
 int get_swt_invstream_min() { return invstream_min().load(std::memory_order_relaxed); }
 
-#ifdef PDWT_DOUBLE
-bool swt2_inv_stream_takes(const Swt2DArgs&, int) { return false; }
-hipError_t try_launch_swt2_inv_stream(const Swt2DArgs&, int, hipStream_t) { return hipErrorNotSupported; }
-#else
+// The fp64 library runs the same kernels for 6-16 taps at dilations 1-4, in steps of 16 rows (launch_swt_fwdstream.hip)
+constexpr bool kF64 = sizeof(real_t) == 8;
+constexpr int kInvStreamMaxTaps = kF64 ? 16 : 20, kInvStreamMaxF = kF64 ? 4 : 8;
+
 static inline v2f mk2h(real_t a, real_t b) {
     v2f r;
     r.x = a;
@@ -36,8 +34,9 @@ static inline v2f mk2h(real_t a, real_t b) {
 template <int HLEN, int F>
 static hipError_t run(const Swt2DArgs& g, int batch, hipStream_t s) {
     // the staged rows are pairs (8 B per sample): dilations 4 and 8 walk in steps of 16 rows (two workgroups per CU)
-    {
-    constexpr bool kShort = F >= 4 || (F == 2 && HLEN > 36);
+    if constexpr (HLEN > kInvStreamMaxTaps || F > kInvStreamMaxF) return hipErrorNotSupported;
+    else {
+    constexpr bool kShort = F >= 4 || (F == 2 && HLEN > 36) || kF64;
     constexpr int TXC = 64, TY = kShort ? 16 : 32, NT = 256, KB = kShort ? 4 : 8, M = kShort ? 4 : 8, MINB = 2;
     using G = SwtInvStreamGeom<HLEN, F, TXC, TY>;
     SwtInvStreamArgs a;
@@ -81,9 +80,9 @@ bool swt2_inv_stream_takes(const Swt2DArgs& a, int batch) {
     if (a.f != 1 && a.f != 2 && a.f != 4 && a.f != 8) return false;
     if ((a.Nc & 3) || (a.bstride & 3) || batch < 1 || batch > 65535) return false;
     if ((long long)a.Nr * a.Nc * (long long)sizeof(real_t) >= (1LL << 32)) return false;  // 32-bit byte offsets inside a plane
-    if (a.hlen > tune::swt_invstream_max_taps || (a.f == 8 && a.hlen > tune::swt_invstream_f8_max_taps && !forced)) return false;
-    if (swt_walk(a.Nr, a.Nc, a.f, 4).rows_phase < (a.f >= 4 ? 16 : 32)) return false;     // chains of at least one step
-    auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    if (a.hlen > kInvStreamMaxTaps || a.f > kInvStreamMaxF || a.hlen > tune::swt_invstream_max_taps || (a.f == 8 && a.hlen > tune::swt_invstream_f8_max_taps && !forced)) return false;
+    if (swt_walk(a.Nr, a.Nc, a.f, 4).rows_phase < (a.f >= 4 || kF64 ? 16 : 32)) return false;     // chains of at least one step
+    auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & (4 * sizeof(real_t) - 1)) == 0; };  // a 4-element group
     if (!al16(a.out) || !al16(a.A) || !al16(a.H) || !al16(a.V) || !al16(a.D)) return false;
     return forced || (long long)batch * a.Nr * a.Nc >= (1LL << tune::swt_invstream_log2);
 }
@@ -102,6 +101,6 @@ hipError_t try_launch_swt2_inv_stream(const Swt2DArgs& a, int batch, hipStream_t
     }
     return hipErrorNotSupported;
 }
-#endif
+
 
 }  // namespace pdwt

@@ -51,8 +51,9 @@ CASES = [
     ("dwt2", "db2", (256, 256), 3, 1, "f64"),
     ("dwt1", "sym8", (1, 1 << 20), 5, 1, "f64"),
     ("swt2", "haar", (512, 512), 3, 1, "f64"),
-    ("swt2", "db10", (512, 512), 2, 1, "f64"),      # 20 taps: row + column launches of the stream kernels, both directions
-    ("swt2", "db4", (256, 256), 2, 1, "f64"),        # 8 taps: tiles forward, stream kernels inverse
+    ("swt2", "db13", (512, 512), 2, 1, "f64"),      # 26 taps: row + column launches of the stream kernels, both directions
+    ("swt2", "db10", (512, 512), 2, 1, "f64"),      # 20 taps: the forward in one launch per level (round 6), the inverse on the stream kernels
+    ("swt2", "db4", (256, 256), 2, 1, "f64"),        # 8 taps: one launch per level both ways
     ("swt2", "db2", (30, 44), 2, 1, "f64"),          # 4 taps, dilation does not divide the rows: tiles both ways
     ("swt2", "haar", (301, 515), 3, 1, "f64"),       # fused groups on any size
     ("dwt2", "db20", (1024, 1024), 1, 1, "f64"),     # 40 taps, 2^20 samples: the inverse as row + column launches of the stream kernels

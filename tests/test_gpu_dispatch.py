@@ -29,7 +29,7 @@ REACHABLE = {
             ("dwt2_fwd_level", "long"), ("dwt2_inv_level", "long"),
             ("dwt2_fwd_pyr3", ""), ("dwt2_inv_pyr3", ""), ("dwt1_fwd_reg", ""), ("dwt1_inv_reg", ""),
             ("swt2_fwd_level", ""), ("swt2_inv_level", ""), ("swt2_fwd_fused", ""), ("swt2_inv_fused", ""),
-            ("swt2_fwd_fused", "anysize"), ("swt2_inv_fused", "anysize"),
+            ("swt2_fwd_fused", "anysize"), ("swt2_inv_fused", "anysize"), ("swt2_fwd_stream", ""), ("swt2_inv_stream", ""),
             ("swt2_fwd_split", "stream"), ("swt2_inv_split", "stream"), ("dwt2_inv_split", "")},
 }
 

@@ -125,3 +125,37 @@ def test_fwdstream_default_dispatch_at_full_size():
             assert _names(x, wname, 4) == ["swt2_fwd_stream"] * 4
     finally:
         lib.pdwt_set_tuning(b"swt_fwdstream", prev)
+
+
+@pytest.mark.parametrize("wname,shape,levels", [("db3", (256, 264), 3), ("db4", (192, 512), 3), ("db5", (130, 256), 2), ("sym8", (256, 136), 2),
+                                                ("coif3", (128, 264), 1), ("db10", (136, 256), 2)])
+def test_one_launch_levels_of_the_fp64_library(wname, shape, levels):
+    """The fp64 library (the reference's DOUBLEPRECISION build, pdwt/src/filters.h:16-30) runs the same kernels for 6-20 taps (forward) and
+    6-16 taps (inverse) at dilations 1-4 in steps of 16 rows; forced on at every size and compared with the fp64 oracle at 1e-12."""
+    from pypwt_amd import BatchedWavelets64, _lib
+    lib = _lib.load("f64")
+    prev = lib.pdwt_set_tuning(b"swt_fwdstream", 106), lib.pdwt_set_tuning(b"swt_invstream", 106)
+    try:
+        x = oracle.hash_input(shape, 889, scale=255.0).astype(np.float64)
+        x += 1e-9 * (np.arange(x.size) % 1009).reshape(x.shape)
+        plan = BatchedWavelets64(1, shape[0], shape[1], wname, levels, do_swt=1, img=x[None])
+        assert plan.levels == levels
+        plan.enable_kernel_timing(True)
+        plan.reset_kernel_times()
+        plan.forward()
+        ref = oracle.forward(x, wname, levels, do_swt=1, double="full")
+        for num, r in enumerate(ref):
+            g = plan.coeff_at(num, 0)
+            assert g.dtype == np.float64 and np.abs(g - r).max() <= 1e-12 * max(1.0, float(np.abs(r).max())), (wname, num)
+        plan.soft_threshold(4.0)
+        plan.inverse()
+        names = [n for n, _ in plan.kernel_times()]
+        hlen = oracle.filters(wname)[0]
+        assert names[:levels] == ["swt2_fwd_stream"] * levels, names
+        assert ("swt2_inv_stream+soft" in names) == (hlen <= 16), names
+        thr = [r if i == 0 else r - np.clip(r, -4.0, 4.0) for i, r in enumerate(ref)]  # x - clamp(x, -beta, beta), as the kernels compute it
+        want = oracle.inverse(thr, shape, wname, levels, do_swt=1, double="full")
+        assert np.abs(plan.image_at(0) - want).max() <= 1e-11 * 255, wname
+    finally:
+        lib.pdwt_set_tuning(b"swt_fwdstream", prev[0])
+        lib.pdwt_set_tuning(b"swt_invstream", prev[1])

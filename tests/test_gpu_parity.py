@@ -629,6 +629,7 @@ def test_fp64_stream_levels_forced_for_every_filter(wname, shape, levels, ndim, 
     from pypwt_amd import _lib
     lib = _lib.load("f64")
     prev = lib.pdwt_set_tuning(b"swt_split_fwd", 102), lib.pdwt_set_tuning(b"swt_split_inv", 102)
+    prev_one = lib.pdwt_set_tuning(b"swt_fwdstream", 0), lib.pdwt_set_tuning(b"swt_invstream", 0)  # (round 6: the one-launch levels would take 6-20 taps otherwise)
     try:
         x = oracle.hash_input((batch,) + shape, 4242, scale=255.0).astype(np.float64)
         x += 1e-9 * (np.arange(x.size) % 997).reshape(x.shape)
@@ -670,6 +671,8 @@ def test_fp64_stream_levels_forced_for_every_filter(wname, shape, levels, ndim, 
     finally:
         lib.pdwt_set_tuning(b"swt_split_fwd", prev[0])
         lib.pdwt_set_tuning(b"swt_split_inv", prev[1])
+        lib.pdwt_set_tuning(b"swt_fwdstream", prev_one[0])
+        lib.pdwt_set_tuning(b"swt_invstream", prev_one[1])
 
 
 @pytest.mark.gpu

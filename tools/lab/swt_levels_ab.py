@@ -2,12 +2,14 @@
 """Per-launch times of 2D SWT plans under two settings of one tuning key:  swt_levels_ab.py key v0 v1 [lab] [fwd]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-from pypwt_amd import BatchedWavelets, _lib
-args = [a for a in sys.argv[1:] if a not in ("lab", "fwd")]
+from pypwt_amd import BatchedWavelets, BatchedWavelets64, _lib
+args = [a for a in sys.argv[1:] if a not in ("lab", "fwd", "f64")]
 key, v0, v1 = args[0].encode(), int(args[1]), int(args[2])
 if "lab" in sys.argv[1:]:
     _lib.use_lab_kernels(True)
-lib = _lib.load("lab" if "lab" in sys.argv[1:] else "f32")
+lib = _lib.load("lab" if "lab" in sys.argv[1:] else ("f64" if "f64" in sys.argv[1:] else "f32"))
+if "f64" in sys.argv[1:]:
+    BatchedWavelets = BatchedWavelets64
 CASES = (("db3", 1, (2048, 2048), 4), ("db4", 1, (2048, 2048), 4), ("db5", 1, (2048, 2048), 4), ("sym8", 1, (2048, 2048), 4), ("db10", 1, (2048, 2048), 4), ("db20", 1, (2048, 2048), 5),
          ("db4", 1, (1024, 1024), 4), ("sym8", 1, (1024, 1024), 4), ("db20", 1, (1024, 1024), 4), ("db4", 1, (4096, 4096), 3), ("sym8", 1, (4096, 4096), 3), ("db20", 1, (4096, 4096), 3),
          ("db4", 4, (1024, 1024), 3), ("db4", 1, (1080, 1920), 3), ("db4", 1, (512, 512), 3))
