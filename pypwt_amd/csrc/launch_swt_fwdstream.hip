@@ -36,7 +36,7 @@ template <int HLEN, int F>
 static hipError_t run(const Swt2DArgs& g, int batch, hipStream_t s) {
     // dilation 8: 47-sample phases of 8 columns each -- steps of 16 rows keep the staged rows + the history at 53 KB (two workgroups per CU)
     // (dilation 16: phases of 4 columns: the staged row is 64 + 15 (hlen - 1) columns wide for 64 outputs)
-    if constexpr (HLEN > kFwdStreamMaxTaps || F > kFwdStreamMaxF || (kF64 && F == 8 && HLEN > 18)) return hipErrorNotSupported;  // (fp64, 20 taps, dilation 8: 44 B of scratch)
+    if constexpr (HLEN > kFwdStreamMaxTaps || F > kFwdStreamMaxF || (kF64 && F >= 4 && HLEN > 18)) return hipErrorNotSupported;  // (fp64, 20 taps, dilations 4 and 8: 12-44 B of scratch)
     else {
     constexpr bool kShort = F >= 8 || kF64;
     constexpr int TXC = 64, TY = kShort ? 16 : 32, NT = 256, KB = kShort ? 4 : 8, M = kShort ? 4 : 8, MINB = 2;
@@ -78,12 +78,12 @@ bool swt2_fwd_stream_takes(const Swt2DArgs& a, int batch) {
     const bool forced = min_taps >= 100;
     if (forced) min_taps -= 100;
     if (min_taps <= 0 || a.hlen < min_taps || a.hlen < 6 || (a.hlen & 1) || a.hlen > kFwdStreamMaxTaps) return false;
-    if ((a.f != 1 && a.f != 2 && a.f != 4 && a.f != 8 && a.f != 16) || a.f > kFwdStreamMaxF || (kF64 && a.f == 8 && a.hlen > 18)) return false;
-    if ((a.Nc & 3) || (a.bstride & 3) || batch < 1 || batch > 65535) return false;
+    if ((a.f != 1 && a.f != 2 && a.f != 4 && a.f != 8 && a.f != 16) || a.f > kFwdStreamMaxF || (kF64 && a.f >= 4 && a.hlen > 18)) return false;
+    if (batch < 1 || batch > 65535) return false;
+    // rows that are not whole 16-B groups: the staged window of a strip may cross the row end once (swt_stage_pad)
+    if ((a.Nc & 3) && a.Nc < 64 + (a.hlen - 1) * a.f + 4) return false;
     if ((long long)a.Nr * a.Nc * (long long)sizeof(real_t) >= (1LL << 32)) return false;  // 32-bit byte offsets inside a plane
     if (swt_walk(a.Nr, a.Nc, a.f, 4).rows_phase < (a.f >= 8 || kF64 ? 16 : 32)) return false;     // chains of at least one step
-    auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & (4 * sizeof(real_t) - 1)) == 0; };  // a 4-element group
-    if (!al16(a.in) || !al16(a.A) || !al16(a.H) || !al16(a.V) || !al16(a.D)) return false;
     return forced || (long long)batch * a.Nr * a.Nc >= (1LL << tune::swt_fwdstream_log2);
 }
 

@@ -78,12 +78,12 @@ bool swt2_inv_stream_takes(const Swt2DArgs& a, int batch) {
     if (forced) min_taps -= 100;
     if (min_taps <= 0 || a.hlen < min_taps || a.hlen < 6 || (a.hlen & 1) || a.hlen > kMaxTaps) return false;
     if (a.f != 1 && a.f != 2 && a.f != 4 && a.f != 8) return false;
-    if ((a.Nc & 3) || (a.bstride & 3) || batch < 1 || batch > 65535) return false;
+    if (batch < 1 || batch > 65535) return false;
+    // rows that are not whole 16-B groups: the staged window of a strip may cross the row end once (swt_stage_pad)
+    if ((a.Nc & 3) && a.Nc < 64 + (a.hlen - 1) * a.f + 4) return false;
     if ((long long)a.Nr * a.Nc * (long long)sizeof(real_t) >= (1LL << 32)) return false;  // 32-bit byte offsets inside a plane
     if (a.hlen > kInvStreamMaxTaps || a.f > kInvStreamMaxF || a.hlen > tune::swt_invstream_max_taps || (a.f == 8 && a.hlen > tune::swt_invstream_f8_max_taps && !forced)) return false;
     if (swt_walk(a.Nr, a.Nc, a.f, 4).rows_phase < (a.f >= 4 || kF64 ? 16 : 32)) return false;     // chains of at least one step
-    auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & (4 * sizeof(real_t) - 1)) == 0; };  // a 4-element group
-    if (!al16(a.out) || !al16(a.A) || !al16(a.H) || !al16(a.V) || !al16(a.D)) return false;
     return forced || (long long)batch * a.Nr * a.Nc >= (1LL << tune::swt_invstream_log2);
 }
 

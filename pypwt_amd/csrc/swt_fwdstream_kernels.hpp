@@ -18,8 +18,8 @@
 //   column  swt_colstream_kernels.hpp's forward pass: M output rows of a column, M + hlen - 1 buffer rows slide past them.
 // Nothing is filtered twice along y except the D warm-up rows in front of a segment (row pass only); the x halo is only loaded.
 // Index convention of swt_split_kernels.hpp: out[i] = sum_j in[i + (j - c) f] t[j], c = hlen / 2 - 1, t[j] = (lo, hi)[hlen - 1 - j].
-// Preconditions (the launcher checks them): even hlen 6-40, f = F in {1, 2, 4, 8, 16}, Nc % 4 == 0, 16-B aligned planes, chains of at
-// least TY rows, planes below 4 GiB.
+// Preconditions (the launcher checks them): even hlen 6-40, f = F in {1, 2, 4, 8, 16}, chains of at least TY rows, planes below 4 GiB;
+// any width (rows that are not whole 16-B groups: at least TXC + (hlen - 1) f + 4 columns, see swt_stage_pad).
 #pragma once
 
 #include "swt_colstream_kernels.hpp"
@@ -36,6 +36,16 @@ struct SwtFwdStreamArgs {
     FilterBankI t;         // t[j] = (lo[hlen - 1 - j], hi[hlen - 1 - j]) of the analysis bank
 };
 
+// The 16-B groups a strip stages start `pad` samples in front of its first column x0 (which may be negative: the periodic halo).  Rows
+// of whole groups (Nc % 4 == 0): the groups are aligned, pad = x0 mod 4.  Any other width: the groups are loaded at 4-B alignment, and
+// none may straddle the row end -- where the staged window [x0, x0 + xs) runs past the END of the row the groups are laid out from
+// there backwards (pad = (x0 - Nc) mod 4), where it starts before column 0 from 0 (the same formula as the aligned case); a window
+// that does both needs Nc % 4 == 0 (the launcher declines narrower images of other widths).
+PDWT_DEVICE int swt_stage_pad(int x0, int xs, int Nc) {
+    const bool right_only = x0 >= 0 && x0 + xs > Nc;
+    return true_mod(right_only ? x0 - Nc : x0, 4);
+}
+
 template <int HLEN, int F, int TXC, int TY>
 struct SwtFwdStreamGeom {
     static_assert(F == 1 || F == 2 || F == 4 || F == 8 || F == 16, "dilations whose phases tile a strip");
@@ -45,8 +55,7 @@ struct SwtFwdStreamGeom {
     static constexpr int SKIP = W * TY - D;                      // rows of step 0 nobody needs
     static constexpr int BR = D + TY;                            // rows of the (lo, hi) buffer
     static constexpr int XS = TXC + (HLEN - 1) * F;              // staged columns of a row: column k0 - C F onwards
-    static constexpr int PADL = (4 - (C * F) % 4) % 4;           // samples between the aligned load origin and column k0 - C F
-    static constexpr int NQ = (PADL + XS + 3) / 4;               // 16-B groups loaded per row
+    static constexpr int NQ = (3 + XS + 3) / 4;                  // 16-B groups loaded per row (up to 3 samples in front of column k0 - C F)
     static constexpr int PW = TXC / F + HLEN - 1;                // samples of one phase
     static constexpr int PWA = ((PW + 3) & ~3) + 4;              // ... padded: whole 16-B groups, phases start in different banks
     static constexpr int RXA = F * PWA;                          // staged samples per row
@@ -57,7 +66,7 @@ struct SwtFwdStreamGeom {
 template <int HLEN, int F, int TXC, int TY, int NT, int KB, int M>
 PDWT_DEVICE void swt_fwdstream_wg(const SwtFwdStreamArgs& a, int strip, int py, int seg, int bz, real_t* smem) {
     using G = SwtFwdStreamGeom<HLEN, F, TXC, TY>;
-    constexpr int C = G::C, D = G::D, W = G::W, PADL = G::PADL, NQ = G::NQ, PWA = G::PWA, RXA = G::RXA, XS = G::XS;
+    constexpr int C = G::C, D = G::D, W = G::W, NQ = G::NQ, PWA = G::PWA, RXA = G::RXA, XS = G::XS;
     static_assert(TXC % (F * KB) == 0 && (KB % 4 == 0 || TXC == F * KB), "row-pass items tile the phases in whole 16-B groups");
     static_assert((TY / M) * TXC == NT && TXC % 64 == 0 && NT % 64 == 0, "one column-pass item per thread, one block of M rows per wavefront");
     constexpr int TOTAL = TY * NQ, TRIPS = (TOTAL + NT - 1) / NT;
@@ -72,7 +81,8 @@ PDWT_DEVICE void swt_fwdstream_wg(const SwtFwdStreamArgs& a, int strip, int py, 
     if (nm <= 0) return;
     const int T = W + (nm + TY - 1) / TY;
     const int pbase = i0 - C + D - W * TY;   // chain position of the first row of step 0
-    const int xa = k0 - C * F - PADL;        // multiple of 4 (k0 is a multiple of 64)
+    const int padl = swt_stage_pad(k0 - C * F, XS, a.Nc);
+    const int xa = k0 - C * F - padl;        // the origin of the row's 16-B groups
     const long long boff = (long long)bz * a.bstride;
     const real_t* PDWT_RESTRICT in = a.in + boff;
     const LanePlane pA = lane_plane(a.A + boff), pH = lane_plane(a.H + boff), pV = lane_plane(a.V + boff), pD = lane_plane(a.D + boff);
@@ -92,8 +102,8 @@ PDWT_DEVICE void swt_fwdstream_wg(const SwtFwdStreamArgs& a, int strip, int py, 
             const int r = idx / NQ;
             const int g = idx - r * NQ;
             pl[4 * q + 0] = r * RXA;
-            pl[4 * q + 1] = 4 * g - PADL;
-            pl[4 * q + 2] = wrap_periodic(xa + 4 * g, a.Nc);  // Nc % 4 == 0: a group never straddles the row end
+            pl[4 * q + 1] = 4 * g - padl;
+            pl[4 * q + 2] = wrap_periodic(xa + 4 * g, a.Nc);  // a group never straddles the row end (swt_stage_pad)
             pl[4 * q + 3] = true_mod(pbase + r, rows_phase);
         }
     };
@@ -103,7 +113,7 @@ PDWT_DEVICE void swt_fwdstream_wg(const SwtFwdStreamArgs& a, int strip, int py, 
 #pragma unroll
         for (int q = 0; q < TRIPS; ++q) {
             const int pos = pl[4 * q + 3];
-            p[q] = *reinterpret_cast<const v4f*>(in + (long long)swt_walk_row<true, 1>(a.wk, a.Nr, py, pos * F) * a.Nc + pl[4 * q + 2]);
+            p[q] = swt_ld16<true>(in, kRealBytes * (unsigned)(swt_walk_row<true, 1>(a.wk, a.Nr, py, pos * F) * a.Nc + pl[4 * q + 2]));
             const int np = pos + TY;
             pl[4 * q + 3] = np >= rows_phase ? np - rows_phase : np;  // rows_phase >= TY
         }

@@ -19,8 +19,8 @@
 // dilation, as in the forward.  Packed arithmetic: a pair (A, V) / (H, D) / (P, Q) times the tap pair (rlo, rhi) element by
 // element, the two halves added at the end -- 80 packed FMAs per sample in the row pass, 40 in the column pass.
 // Index convention of swt_split_kernels.hpp: out[i] = 1/2 sum_j in[i + (j - c) f] t[j], c = hlen / 2, t[j] = (rlo, rhi)[hlen - 1 - j].
-// Preconditions (the launcher checks them): even hlen 6-40, f = F in {1, 2, 4, 8}, Nc % 4 == 0, 16-B aligned planes, chains of at
-// least TY rows, planes below 4 GiB.
+// Preconditions (the launcher checks them): even hlen 6-40, f = F in {1, 2, 4, 8}, chains of at least TY rows, planes below 4 GiB; any
+// width (swt_stage_pad in swt_fwdstream_kernels.hpp).
 #pragma once
 
 #include "swt_fwdstream_kernels.hpp"
@@ -47,8 +47,7 @@ struct SwtInvStreamGeom {
     static constexpr int SKIP = W * TY - D;
     static constexpr int BR = D + TY;
     static constexpr int XS = GF::XS;
-    static constexpr int PADL = (4 - (C * F) % 4) % 4;
-    static constexpr int NQ = (PADL + XS + 3) / 4;
+    static constexpr int NQ = (3 + XS + 3) / 4;
     static constexpr int PWA = GF::PWA;                          // pairs of one phase, padded
     static constexpr int RXA = F * PWA;                          // staged pairs per row
     static constexpr int LDS_REALS = 2 * TY * RXA + 2 * BR * TXC;
@@ -57,7 +56,7 @@ struct SwtInvStreamGeom {
 template <int HLEN, int F, int TXC, int TY, int NT, int KB, int M>
 PDWT_DEVICE void swt_invstream_wg(const SwtInvStreamArgs& a, int strip, int py, int seg, int bz, real_t* smem) {
     using G = SwtInvStreamGeom<HLEN, F, TXC, TY>;
-    constexpr int C = G::C, D = G::D, W = G::W, PADL = G::PADL, NQ = G::NQ, PWA = G::PWA, RXA = G::RXA, XS = G::XS;
+    constexpr int C = G::C, D = G::D, W = G::W, NQ = G::NQ, PWA = G::PWA, RXA = G::RXA, XS = G::XS;
     static_assert(TXC % (F * KB) == 0, "row-pass items tile the phases");
     static_assert((TY / M) * TXC == NT && TXC % 64 == 0 && NT % 64 == 0, "one column-pass item per thread, one block of M rows per wavefront");
     constexpr int TOTAL = TY * NQ, TRIPS = (TOTAL + NT - 1) / NT;
@@ -72,7 +71,8 @@ PDWT_DEVICE void swt_invstream_wg(const SwtInvStreamArgs& a, int strip, int py, 
     if (nm <= 0) return;
     const int T = W + (nm + TY - 1) / TY;
     const int pbase = i0 - C + D - W * TY;
-    const int xa = k0 - C * F - PADL;
+    const int padl = swt_stage_pad(k0 - C * F, XS, a.Nc);
+    const int xa = k0 - C * F - padl;
     const long long boff = (long long)bz * a.bstride;
     const real_t* PDWT_RESTRICT pA = a.A + boff;
     const real_t* PDWT_RESTRICT pH = a.H + boff;
@@ -114,8 +114,8 @@ PDWT_DEVICE void swt_invstream_wg(const SwtInvStreamArgs& a, int strip, int py, 
             const int pos = pl[2 * q + 1];
             const int o = swt_walk_row<true, 1>(a.wk, a.Nr, py, pos * F) * a.Nc + pl[2 * q];
             so[q] = o;
-            p[2 * q] = *reinterpret_cast<const v4f*>(pA + o);
-            p[2 * q + 1] = *reinterpret_cast<const v4f*>(pV + o);
+            p[2 * q] = swt_ld16<true>(pA, kRealBytes * (unsigned)o);
+            p[2 * q + 1] = swt_ld16<true>(pV, kRealBytes * (unsigned)o);
             const int np = pos + TY;
             pl[2 * q + 1] = np >= rows_phase ? np - rows_phase : np;
         }
@@ -125,8 +125,8 @@ PDWT_DEVICE void swt_invstream_wg(const SwtInvStreamArgs& a, int strip, int py, 
         v4f* p = PDWT_MINE(pre, tid);
 #pragma unroll
         for (int q = 0; q < TRIPS; ++q) {
-            p[2 * q] = *reinterpret_cast<const v4f*>(pH + so[q]);
-            p[2 * q + 1] = *reinterpret_cast<const v4f*>(pD + so[q]);
+            p[2 * q] = swt_ld16<true>(pH, kRealBytes * (unsigned)so[q]);
+            p[2 * q + 1] = swt_ld16<true>(pD, kRealBytes * (unsigned)so[q]);
         }
     };
     // the loaded quads of two planes -> (first, second) pairs, phase u mod F, index u / F; `first_soft`: the first plane is a detail band
@@ -138,7 +138,7 @@ PDWT_DEVICE void swt_invstream_wg(const SwtInvStreamArgs& a, int strip, int py, 
             idx = idx < TOTAL ? idx : TOTAL - 1;
             const int r = idx / NQ;
             v2f* row = sIn + r * RXA;
-            const int u0 = 4 * (idx - r * NQ) - PADL;
+            const int u0 = 4 * (idx - r * NQ) - padl;
             real_t x[4] = {p[2 * q].x, p[2 * q].y, p[2 * q].z, p[2 * q].w};
             real_t y[4] = {p[2 * q + 1].x, p[2 * q + 1].y, p[2 * q + 1].z, p[2 * q + 1].w};
             if (soft) {

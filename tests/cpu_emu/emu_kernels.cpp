@@ -994,7 +994,7 @@ static int run_swt_fwdstream(const float* in, float* A, float* H, float* V, floa
     SwtFwdStreamArgs a;
     a.in = in; a.A = A; a.H = H; a.V = V; a.D = D; a.Nr = Nr; a.Nc = Nc; a.bstride = (long long)Nr * Nc;
     a.wk = swt_walk(Nr, Nc, F, 4);
-    if ((Nc & 3) || a.wk.rows_phase < TY) return -2;
+    if (((Nc & 3) && Nc < TXC + (HLEN - 1) * F + 4) || a.wk.rows_phase < TY) return -2;
     for (int j = 0; j < HLEN; ++j) a.t.t[j] = mk2(lo[HLEN - 1 - j], hi[HLEN - 1 - j]);
     a.strips = (Nc + TXC - 1) / TXC;
     const int seg = seg_rows > 0 ? seg_rows : (a.wk.rows_phase + 1) / 2;
@@ -1032,7 +1032,7 @@ static int run_swt_invstream(const float* A, const float* H, const float* V, con
     SwtInvStreamArgs a;
     a.A = A; a.H = H; a.V = V; a.D = D; a.out = out; a.Nr = Nr; a.Nc = Nc; a.bstride = (long long)Nr * Nc; a.soft_beta = beta;
     a.wk = swt_walk(Nr, Nc, F, 4);
-    if ((Nc & 3) || a.wk.rows_phase < TY) return -2;
+    if (((Nc & 3) && Nc < TXC + (HLEN - 1) * F + 4) || a.wk.rows_phase < TY) return -2;
     for (int j = 0; j < HLEN; ++j) a.t.t[j] = mk2(lo[HLEN - 1 - j], hi[HLEN - 1 - j]);
     a.strips = (Nc + TXC - 1) / TXC;
     const int seg = seg_rows > 0 ? seg_rows : (a.wk.rows_phase + 1) / 2;

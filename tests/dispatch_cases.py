@@ -40,7 +40,8 @@ CASES = [
     ("swt2", "db7", (1024, 2048), 6, 1, "f32"),      # ... of 2^21 samples: in registers
     ("swt2", "haar", (32, 32), 3, 2000, "f32"),      # tiny images: one workgroup each
     ("swt2", "db3", (30, 44), 2, 1, "f32"),          # dilation does not divide the rows
-    ("swt2", "db10", (250, 1022), 2, 1, "f32"),      # rows that are not whole quads, 20 taps: the any-length stream kernels
+    ("swt2", "db10", (250, 1022), 2, 1, "f32"),      # rows that are not whole quads, 20 taps: one launch per level since round 6 (any width)
+    ("swt2", "db10", (250, 78), 1, 1, "f32"),        # ... narrower than one staged window: the any-length stream kernels
     ("swt2", "db20", (256, 256), 2, 1, "f32"),       # small image, 40 taps: stream kernels (two columns per lane)
     # ---- 1D SWT
     ("swt1", "db4", (4096, 4096), 3, 1, "f32"),
