@@ -58,22 +58,29 @@ struct SwtFwdStreamGeom {
     static constexpr int NQ = (3 + XS + 3) / 4;                  // 16-B groups loaded per row (up to 3 samples in front of column k0 - C F)
     static constexpr int PW = TXC / F + HLEN - 1;                // samples of one phase
     static constexpr int PWA = ((PW + 3) & ~3) + 4;              // ... padded: whole 16-B groups, phases start in different banks
-    static constexpr int RXA = F * PWA;                          // staged samples per row
-    static constexpr int LDS_REALS = TY * RXA + 2 * BR * TXC;
+    // LDS banks (64 of 4 B).  The row pass has the lanes of a wavefront on consecutive ROWS: a 16-B read of 16 lanes is conflict-free
+    // when the row pitch is 4 words mod 64, and so are their 8-B writes into the buffer when ITS pitch is 2 words mod 64 (rocprofv3,
+    // 8 taps, lanes on consecutive blocks of one row: 1.7 M conflict cycles per 2048^2 level forward, 7.8 M inverse = half its time)
+    // From 30 taps on the first layout stays -- lanes on consecutive blocks of a row, dense pitches: the conflicts are a small share of a
+    // 40-tap pass and the padded layout measured 4 % SLOWER there (db20 512^2 L3 forward 32.7 -> 34.4 us; 6-20 taps: 7-12 % faster)
+    static constexpr bool ROWS_FAST = HLEN < 30;
+    static constexpr int RXA = ROWS_FAST ? (F * PWA + 59) / 64 * 64 + 4 : F * PWA;  // staged samples per row
+    static constexpr int BP = ROWS_FAST ? TXC + 1 : TXC;                            // (lo, hi) pairs per buffer row
+    static constexpr int LDS_REALS = TY * RXA + 2 * (BR * BP + 1);
 };
 
 //   KB outputs of one phase per row-pass item;  M output rows per column-pass item
 template <int HLEN, int F, int TXC, int TY, int NT, int KB, int M>
 PDWT_DEVICE void swt_fwdstream_wg(const SwtFwdStreamArgs& a, int strip, int py, int seg, int bz, real_t* smem) {
     using G = SwtFwdStreamGeom<HLEN, F, TXC, TY>;
-    constexpr int C = G::C, D = G::D, W = G::W, NQ = G::NQ, PWA = G::PWA, RXA = G::RXA, XS = G::XS;
+    constexpr int C = G::C, D = G::D, W = G::W, NQ = G::NQ, PWA = G::PWA, RXA = G::RXA, XS = G::XS, BP = G::BP;
     static_assert(TXC % (F * KB) == 0 && (KB % 4 == 0 || TXC == F * KB), "row-pass items tile the phases in whole 16-B groups");
     static_assert((TY / M) * TXC == NT && TXC % 64 == 0 && NT % 64 == 0, "one column-pass item per thread, one block of M rows per wavefront");
     constexpr int TOTAL = TY * NQ, TRIPS = (TOTAL + NT - 1) / NT;
-    constexpr int CARRY = D * TXC / 2, CTRIPS = (CARRY + NT - 1) / NT;  // 16-B groups of the D carried rows of (lo, hi) pairs
+    constexpr int CARRY = (D * BP + 1) / 2, CTRIPS = (CARRY + NT - 1) / NT;  // 16-B groups of the D carried rows of (lo, hi) pairs
 
     real_t* sIn = smem;                                      // TY x RXA: the step's input rows, phases de-interleaved
-    v2f* buf = reinterpret_cast<v2f*>(smem + TY * RXA);     // BR x TXC (lo, hi) pairs
+    v2f* buf = reinterpret_cast<v2f*>(smem + TY * RXA);     // BR x BP (lo, hi) pairs
 
     const int rows_phase = a.wk.rows_phase;
     const int k0 = strip * TXC, i0 = seg * a.seg;
@@ -140,7 +147,7 @@ PDWT_DEVICE void swt_fwdstream_wg(const SwtFwdStreamArgs& a, int strip, int py, 
         for (int q = 0; q < CTRIPS; ++q) {
             int idx = tid + q * NT;
             idx = idx < CARRY ? idx : CARRY - 1;
-            c[q] = lds_load16(buf + TY * TXC + 2 * idx);
+            c[q] = lds_load16(buf + TY * BP + 2 * idx);
         }
     };
     auto carry_write = [&](int tid) {  // ... to rows [0, D)
@@ -149,7 +156,8 @@ PDWT_DEVICE void swt_fwdstream_wg(const SwtFwdStreamArgs& a, int strip, int py, 
         for (int q = 0; q < CTRIPS; ++q) {
             int idx = tid + q * NT;
             idx = idx < CARRY ? idx : CARRY - 1;
-            *reinterpret_cast<v4f*>(buf + 2 * idx) = c[q];
+            if (((D * BP) & 1) && idx == CARRY - 1) buf[2 * idx] = mk2(c[q].x, c[q].y);  // an odd number of pairs: the last group is half a group (its other half is row D, which this step writes)
+            else *reinterpret_cast<v4f*>(buf + 2 * idx) = c[q];
         }
     };
 
@@ -160,11 +168,23 @@ PDWT_DEVICE void swt_fwdstream_wg(const SwtFwdStreamArgs& a, int strip, int py, 
         constexpr int NQW = (KB - 1 + HLEN + 3) / 4;  // 16-B groups of a window
         constexpr int GB = 3, NG = (NQW + GB - 1) / GB;
         PDWT_LONG_ITEMS(it, tid, ITEMS, NT) {
-            const int r = it / (F * NB);
-            const int rem = it - r * (F * NB);
-            const int ph = rem / NB;
-            const int b = rem - ph * NB;
-            if (it >= ITEMS || r < first_row) continue;
+            // the rows are the fastest index (the pitches of SwtFwdStreamGeom); step 0 filters rows first_row .. TY - 1 only: its
+            // items are numbered over those rows, so that whole wavefronts drop out instead of most lanes of every wavefront
+            int r, ph, b;
+            if constexpr (G::ROWS_FAST) {
+                const int nrows = first_row ? TY - first_row : TY;
+                const int rem = first_row ? it / nrows : it / TY;
+                r = first_row + it - rem * nrows;
+                ph = rem / NB;
+                b = rem - ph * NB;
+                if (it >= nrows * F * NB) continue;
+            } else {
+                r = it / (F * NB);
+                const int rem = it - r * (F * NB);
+                ph = rem / NB;
+                b = rem - ph * NB;
+                if (it >= ITEMS || r < first_row) continue;
+            }
             const real_t* p4 = sIn + r * RXA + ph * PWA + KB * b;
             v2f acc[KB];
 #pragma unroll
@@ -200,7 +220,7 @@ PDWT_DEVICE void swt_fwdstream_wg(const SwtFwdStreamArgs& a, int strip, int py, 
                     }
                 }
             }
-            v2f* dst = buf + (D + r) * TXC + ph + F * KB * b;
+            v2f* dst = buf + (D + r) * BP + ph + F * KB * b;
 #pragma unroll
             for (int kk = 0; kk < KB; ++kk) dst[F * kk] = acc[kk];
         }
@@ -212,7 +232,7 @@ PDWT_DEVICE void swt_fwdstream_wg(const SwtFwdStreamArgs& a, int strip, int py, 
         constexpr int GB = 6, NG = (NWIN + GB - 1) / GB;
         const int ch = wave_uniform(tid / TXC);
         const int x = tid - (tid / TXC) * TXC;
-        const v2f* base = buf + ch * M * TXC + x;
+        const v2f* base = buf + ch * M * BP + x;
         v2f accAH[M], accVD[M];
 #pragma unroll
         for (int mm = 0; mm < M; ++mm) accAH[mm] = accVD[mm] = mk2(real_t(0), real_t(0));
@@ -220,7 +240,7 @@ PDWT_DEVICE void swt_fwdstream_wg(const SwtFwdStreamArgs& a, int strip, int py, 
         auto load_group = [&](int g) {
 #pragma unroll
             for (int e = 0; e < GB; ++e)
-                if (g * GB + e < NWIN) w[g & 1][e] = base[(g * GB + e) * TXC];
+                if (g * GB + e < NWIN) w[g & 1][e] = base[(g * GB + e) * BP];
         };
         load_group(0);
 #pragma unroll

@@ -49,21 +49,22 @@ struct SwtInvStreamGeom {
     static constexpr int XS = GF::XS;
     static constexpr int NQ = (3 + XS + 3) / 4;
     static constexpr int PWA = GF::PWA;                          // pairs of one phase, padded
-    static constexpr int RXA = F * PWA;                          // staged pairs per row
-    static constexpr int LDS_REALS = 2 * TY * RXA + 2 * BR * TXC;
+    static constexpr int RXA = (F * PWA + 30) / 32 * 32 + 1;     // staged pairs per row: a pitch of 2 words mod 64 (8-B reads of lanes on consecutive rows)
+    static constexpr int BP = GF::BP;                            // (P, Q) pairs per buffer row
+    static constexpr int LDS_REALS = 2 * TY * RXA + 2 * (BR * BP + 1);
 };
 
 template <int HLEN, int F, int TXC, int TY, int NT, int KB, int M>
 PDWT_DEVICE void swt_invstream_wg(const SwtInvStreamArgs& a, int strip, int py, int seg, int bz, real_t* smem) {
     using G = SwtInvStreamGeom<HLEN, F, TXC, TY>;
-    constexpr int C = G::C, D = G::D, W = G::W, NQ = G::NQ, PWA = G::PWA, RXA = G::RXA, XS = G::XS;
+    constexpr int C = G::C, D = G::D, W = G::W, NQ = G::NQ, PWA = G::PWA, RXA = G::RXA, XS = G::XS, BP = G::BP;
     static_assert(TXC % (F * KB) == 0, "row-pass items tile the phases");
     static_assert((TY / M) * TXC == NT && TXC % 64 == 0 && NT % 64 == 0, "one column-pass item per thread, one block of M rows per wavefront");
     constexpr int TOTAL = TY * NQ, TRIPS = (TOTAL + NT - 1) / NT;
-    constexpr int CARRY = D * TXC / 2, CTRIPS = (CARRY + NT - 1) / NT;
+    constexpr int CARRY = (D * BP + 1) / 2, CTRIPS = (CARRY + NT - 1) / NT;
 
     v2f* sIn = reinterpret_cast<v2f*>(smem);                    // TY x RXA pairs: (A, V), then (H, D), phases de-interleaved
-    v2f* buf = reinterpret_cast<v2f*>(smem + 2 * TY * RXA);    // BR x TXC (P, Q) pairs
+    v2f* buf = reinterpret_cast<v2f*>(smem + 2 * TY * RXA);    // BR x BP (P, Q) pairs
 
     const int rows_phase = a.wk.rows_phase;
     const int k0 = strip * TXC, i0 = seg * a.seg;
@@ -161,7 +162,7 @@ PDWT_DEVICE void swt_invstream_wg(const SwtInvStreamArgs& a, int strip, int py, 
         for (int q = 0; q < CTRIPS; ++q) {
             int idx = tid + q * NT;
             idx = idx < CARRY ? idx : CARRY - 1;
-            c[q] = lds_load16(buf + TY * TXC + 2 * idx);
+            c[q] = lds_load16(buf + TY * BP + 2 * idx);
         }
     };
     auto carry_write = [&](int tid) {
@@ -170,7 +171,8 @@ PDWT_DEVICE void swt_invstream_wg(const SwtInvStreamArgs& a, int strip, int py, 
         for (int q = 0; q < CTRIPS; ++q) {
             int idx = tid + q * NT;
             idx = idx < CARRY ? idx : CARRY - 1;
-            *reinterpret_cast<v4f*>(buf + 2 * idx) = c[q];
+            if (((D * BP) & 1) && idx == CARRY - 1) buf[2 * idx] = mk2(c[q].x, c[q].y);  // an odd number of pairs: the last group is half a group (its other half is row D, which this step writes)
+            else *reinterpret_cast<v4f*>(buf + 2 * idx) = c[q];
         }
     };
 
@@ -181,11 +183,13 @@ PDWT_DEVICE void swt_invstream_wg(const SwtInvStreamArgs& a, int strip, int py, 
         constexpr int NWIN = KB - 1 + HLEN;
         constexpr int GB = 4, NG = (NWIN + GB - 1) / GB;
         PDWT_LONG_ITEMS(it, tid, ITEMS, NT) {
-            const int r = it / (F * NB);
-            const int rem = it - r * (F * NB);
+            // (the rows are the fastest index, step 0 numbers its items over the rows it filters: swt_fwdstream_kernels.hpp)
+            const int nrows = first_row ? TY - first_row : TY;
+            const int rem = first_row ? it / nrows : it / TY;
+            const int r = first_row + it - rem * nrows;
             const int ph = rem / NB;
             const int b = rem - ph * NB;
-            if (it >= ITEMS || r < first_row) continue;
+            if (it >= nrows * F * NB) continue;
             const v2f* p2 = sIn + r * RXA + ph * PWA + KB * b;
             v2f acc[KB];
 #pragma unroll
@@ -212,7 +216,7 @@ PDWT_DEVICE void swt_invstream_wg(const SwtInvStreamArgs& a, int strip, int py, 
                     }
                 }
             }
-            real_t* dst = reinterpret_cast<real_t*>(buf + (D + r) * TXC + ph + F * KB * b) + second;
+            real_t* dst = reinterpret_cast<real_t*>(buf + (D + r) * BP + ph + F * KB * b) + second;
 #pragma unroll
             for (int kk = 0; kk < KB; ++kk) dst[2 * F * kk] = half * (acc[kk].x + acc[kk].y);
         }
@@ -224,7 +228,7 @@ PDWT_DEVICE void swt_invstream_wg(const SwtInvStreamArgs& a, int strip, int py, 
         constexpr int GB = 6, NG = (NWIN + GB - 1) / GB;
         const int ch = wave_uniform(tid / TXC);
         const int x = tid - (tid / TXC) * TXC;
-        const v2f* base = buf + ch * M * TXC + x;
+        const v2f* base = buf + ch * M * BP + x;
         v2f acc[M];
 #pragma unroll
         for (int mm = 0; mm < M; ++mm) acc[mm] = mk2(real_t(0), real_t(0));
@@ -232,7 +236,7 @@ PDWT_DEVICE void swt_invstream_wg(const SwtInvStreamArgs& a, int strip, int py, 
         auto load_group = [&](int g) {
 #pragma unroll
             for (int e = 0; e < GB; ++e)
-                if (g * GB + e < NWIN) w[g & 1][e] = base[(g * GB + e) * TXC];
+                if (g * GB + e < NWIN) w[g & 1][e] = base[(g * GB + e) * BP];
         };
         load_group(0);
 #pragma unroll
