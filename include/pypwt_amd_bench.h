@@ -90,7 +90,7 @@ long long pdwt_copy_capacity(pdwt_handle h); /* the largest `elems` pdwt_time_co
  *                    Part of the plan's snapshot.
  *   "swt_fwdstream" / "swt_invstream"   (round 6) the shortest (even) filter whose 2D SWT levels run in ONE launch each, row and
  *                    column pass streamed down column strips (swt_fwdstream_kernels.hpp: 6-40 taps, dilations 1-16;
- *                    swt_invstream_kernels.hpp: 6-20 taps, dilations 1-8; rows of whole 16-B groups, from 2^14 samples per
+ *                    swt_invstream_kernels.hpp: 6-28 taps, dilations 1-8; rows of whole 16-B groups, from 2^14 samples per
  *                    launch): default 6; 0 = never (the levels then run on the tiles / the two launches above); 100 + n = n
  *                    taps at every size they take (tests).  Part of the plan's snapshot.
  *   "swt_colstream"  (round 6) the shortest (even) filter whose two-launch SWT levels run their COLUMN pass as a strip walk with the

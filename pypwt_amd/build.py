@@ -117,7 +117,8 @@ def build_library(force=False, verbose=True, variant="f32"):
         return lib
     if force:
         for f in os.listdir(objdir):
-            os.remove(os.path.join(objdir, f))
+            if os.path.isfile(os.path.join(objdir, f)):  # (build/obj/cy is the Cython binding's directory)
+                os.remove(os.path.join(objdir, f))
     with ThreadPoolExecutor(max_workers=min(max(2, (os.cpu_count() or 4) // 2), len(srcs))) as ex:
         objs = list(ex.map(_compile, [(s, objdir, extra) for s in srcs]))
     cmd = [hipcc(), "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", lib] + objs

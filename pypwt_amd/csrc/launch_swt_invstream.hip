@@ -22,7 +22,7 @@ int get_swt_invstream_min() { return invstream_min().load(std::memory_order_rela
 
 // The fp64 library runs the same kernels for 6-16 taps at dilations 1-4, in steps of 16 rows (launch_swt_fwdstream.hip)
 constexpr bool kF64 = sizeof(real_t) == 8;
-constexpr int kInvStreamMaxTaps = kF64 ? 16 : 20, kInvStreamMaxF = kF64 ? 4 : 8;
+constexpr int kInvStreamMaxTaps = kF64 ? 16 : 28, kInvStreamMaxF = kF64 ? 4 : 8;
 
 static inline v2f mk2h(real_t a, real_t b) {
     v2f r;
@@ -64,11 +64,12 @@ static hipError_t run(const Swt2DArgs& g, int batch, hipStream_t s) {
     }
 }
 
-// Built for 6-20 taps: beyond, the two launches with the column pass on the strips (swt_colstream_kernels.hpp) are as fast or faster
-// (2048^2 per level: db10 0.90-0.92x at dilations 1-4 but 1.18x at dilation 8; db20 1.07-1.18x; 4096^2 db20 1.03-1.28x: profiles/r06_swt_invstream.txt)
-// -- the row synthesis here is the 80-FMA pass and runs out of 8-B LDS reads, and the loads of four planes in flight beside 80 tap registers spill
+// Built for 6-28 taps.  With the first LDS layout the two launches won from 22 taps on (and at dilation 8 from 18); with the lanes on consecutive rows and
+// conflict-free pitches (swt_fwdstream_kernels.hpp) one launch wins up to 28 taps -- 2048^2 per level db11 39-49 -> 34-45 us, db13 / db14 41-52 -> 35-50,
+// 1024^2 db11 21 -> 15-17, 4096^2 db13 153 -> 120 -- and loses from 32 (db16 45-56 -> 50-65): profiles/r06_swt_invstream.txt.  The row synthesis here is
+// the 80-FMA pass, fed by 8-B LDS reads, and the loads of four planes in flight beside the tap registers spill at 40 taps
 #ifndef PDWT_INVSTREAM_HLENS
-#define PDWT_INVSTREAM_HLENS(X) X(6) X(8) X(10) X(12) X(14) X(16) X(18) X(20)
+#define PDWT_INVSTREAM_HLENS(X) X(6) X(8) X(10) X(12) X(14) X(16) X(18) X(20) X(22) X(24) X(26) X(28)
 #endif
 
 bool swt2_inv_stream_takes(const Swt2DArgs& a, int batch) {
@@ -82,7 +83,7 @@ bool swt2_inv_stream_takes(const Swt2DArgs& a, int batch) {
     // rows that are not whole 16-B groups: the staged window of a strip may cross the row end once (swt_stage_pad)
     if ((a.Nc & 3) && a.Nc < 64 + (a.hlen - 1) * a.f + 4) return false;
     if ((long long)a.Nr * a.Nc * (long long)sizeof(real_t) >= (1LL << 32)) return false;  // 32-bit byte offsets inside a plane
-    if (a.hlen > kInvStreamMaxTaps || a.f > kInvStreamMaxF || a.hlen > tune::swt_invstream_max_taps || (a.f == 8 && a.hlen > tune::swt_invstream_f8_max_taps && !forced)) return false;
+    if (a.hlen > kInvStreamMaxTaps || a.f > kInvStreamMaxF || (a.hlen > tune::swt_invstream_max_taps && !forced) || (a.f == 8 && a.hlen > tune::swt_invstream_f8_max_taps && !forced)) return false;
     if (swt_walk(a.Nr, a.Nc, a.f, 4).rows_phase < (a.f >= 4 || kF64 ? 16 : 32)) return false;     // chains of at least one step
     return forced || (long long)batch * a.Nr * a.Nc >= (1LL << tune::swt_invstream_log2);
 }

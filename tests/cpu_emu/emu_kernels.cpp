@@ -1054,7 +1054,7 @@ EMU_API int emu_swt2_invstream(const float* A, const float* H, const float* V, c
     const int f = 1 << (level - 1);
 #define Y(h, ff) if (hlen == h && f == ff) return run_swt_invstream<h, ff>(A, H, V, D, out, batch, Nr, Nc, lo, hi, beta, seg_rows);
 #define X(h) Y(h, 1) Y(h, 2) Y(h, 4) Y(h, 8)
-    X(6) X(8) X(10) X(12) X(16) X(18) X(20)  // (the product builds 6-20 taps)
+    X(6) X(8) X(10) X(12) X(16) X(18) X(20) X(26)  // (the product builds 6-28 taps)
 #undef X
 #undef Y
     return -1;

@@ -1045,7 +1045,7 @@ def test_emu_swt_forward_level_in_one_launch(wname, seg):
 
 
 @pytest.mark.parametrize("seg", [0, 32])
-@pytest.mark.parametrize("wname", ["db3", "db4", "db5", "db6", "sym8", "coif3", "db10"])
+@pytest.mark.parametrize("wname", ["db3", "db4", "db5", "db6", "sym8", "coif3", "db10", "db13"])
 def test_emu_swt_inverse_level_in_one_launch(wname, seg):
     """swt_invstream_kernels.hpp (row synthesis, then column synthesis, of an inverse a-trous level streamed down strips; the (P, Q)
     halves never leave LDS) vs the oracle's per-pass functions (column synthesis first: the passes commute, fp32 rounding differs):
