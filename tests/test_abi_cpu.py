@@ -388,3 +388,7 @@ def test_dispatch_thresholds_are_a_table_with_provenance():
         if f.endswith((".cpp", ".hip")):
             every |= set(re.findall(r"\btune::(\w+)", open(os.path.join(ROOT, "pypwt_amd", "csrc", f)).read()))
     assert keys - every <= {"kRows", "kRowCount"} | set(), ("rows nothing reads", sorted(keys - every))
+    # the table as text (docs/TUNING.md) is the generator's output for THIS tuning_gfx950.inc
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "tuning_table.py")], capture_output=True, text=True).stdout
+    doc = open(os.path.join(ROOT, "docs", "TUNING.md")).read()
+    assert out.strip() and out.strip() in doc, "docs/TUNING.md is stale: regenerate its table with tools/tuning_table.py"
