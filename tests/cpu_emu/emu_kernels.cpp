@@ -29,6 +29,7 @@
 #include "../../pypwt_amd/csrc/swt_colstream_kernels.hpp"
 #include "../../pypwt_amd/csrc/swt_fwdstream_kernels.hpp"
 #include "../../pypwt_amd/csrc/swt_invstream_kernels.hpp"
+#include "../../pypwt_amd/csrc/strip_walk.hpp"
 #include "../../pypwt_amd/csrc/swt_stream_kernels.hpp"
 #include "../../pypwt_amd/csrc/dwt2_stream_kernels.hpp"
 #include "../../pypwt_amd/csrc/dwt2_split_kernels.hpp"
@@ -984,6 +985,18 @@ static bool run_swt_colstream(const SwtSplitArgs& c) {
                     for (int st = 0; st < a.strips; ++st) swt_colstream_wg<HLEN, INV, TXC, TY, NT, M>(a, st, py, sg, bz, smem.data());
         return true;
     }
+}
+
+// ---- host-side geometry of the strip walks and of the any-size fused groups (pure functions)
+EMU_API int emu_strip_walk_seg(int rows, long long units, int ty, int warm, int slots) { return strip_walk_seg(rows, units, ty, warm, slots); }
+EMU_API int emu_swt_stage_pad(int x0, int xs, int Nc) { return swt_stage_pad(x0, xs, Nc); }
+EMU_API void emu_swt_walk(int Nr, int Nc, int f0, int cols_per_lane, int* out4) {
+    const SwtWalk w = swt_walk(Nr, Nc, f0, cols_per_lane);
+    out4[0] = w.phases; out4[1] = w.rows_phase; out4[2] = (int)w.magic; out4[3] = w.pad;
+}
+EMU_API int emu_swt_walk_row(int Nr, int Nc, int f0, int py, int idx) {
+    const SwtWalk w = swt_walk(Nr, Nc, f0, 4);
+    return swt_walk_row<true, 1>(w, Nr, py, idx * f0);
 }
 
 // ---- one forward a-trous level in ONE launch, row and column pass streamed down strips (swt_fwdstream_kernels.hpp)

@@ -1014,6 +1014,45 @@ def test_emu_swt_column_pass_streamed_through_an_lds_history(wname, seg, monkeyp
                 assert np.abs(rec[b] - want).max() <= _tol(want), (wname, shape, level, "inverse", beta)
 
 
+def test_strip_walk_geometry_host_functions():
+    """The pure host functions behind the round's strip walks: strip_walk_seg (segment length from the resident workgroups: whole steps,
+    never the halving just past a power of two that its first version had), swt_walk / swt_walk_row (chains of rows: every row exactly
+    once, the multiply-high row map equals the modulo), swt_stage_pad (no staged 16-B group straddles the row end, for every width)."""
+    import ctypes as C
+    L = lib()
+    L.emu_strip_walk_seg.argtypes = [C.c_int, C.c_longlong, C.c_int, C.c_int, C.c_int]
+    for rows, units, ty, warm, slots in [(1024, 16, 32, 1, 768), (1040, 16, 32, 1, 768), (2048, 32, 32, 2, 512), (2048, 32, 32, 1, 1024), (130, 4, 16, 3, 512), (33, 1, 32, 1, 512),
+                                         (1080, 30, 32, 1, 768), (4096, 64, 32, 2, 512)]:
+        seg = L.emu_strip_walk_seg(rows, units, ty, warm, slots)
+        assert seg % ty == 0 and ty <= seg <= (rows + ty - 1) // ty * ty, (rows, units, seg)
+    assert L.emu_strip_walk_seg(1024, 16, 32, 1, 768) == L.emu_strip_walk_seg(1040, 16, 32, 1, 768) == 32   # 512 / 528 workgroups in one round of 768
+    assert L.emu_strip_walk_seg(2048, 32, 32, 2, 512) == 128                                                # 40 taps: two workgroups per CU, 512 per launch
+    assert L.emu_strip_walk_seg(2048, 32, 32, 1, 1024) == 64                                                # short filters: four per CU
+    out = (C.c_int * 4)()
+    for Nr, Nc, f0 in [(2047, 2047, 8), (1002, 1000, 8), (1000, 1001, 4), (96, 2047, 4), (2048, 2048, 8), (135, 200, 2), (77, 1022, 8), (3001, 4001, 16)]:
+        L.emu_swt_walk(Nr, Nc, f0, 4, out)
+        phases, rows_phase, magic, pad = out[0], out[1], out[2] & 0xffffffff, out[3]
+        assert phases == np.gcd(f0, Nr) and phases * rows_phase == Nr and (Nc + pad) % 4 == 0 and 0 <= pad < 4
+        seen = np.zeros(Nr, dtype=np.int32)
+        for py in range(phases):
+            for idx in range(rows_phase):
+                r = L.emu_swt_walk_row(Nr, Nc, f0, py, idx)
+                assert r == (py + f0 * idx) % Nr
+                seen[r] += 1
+        assert (seen == 1).all(), (Nr, f0)
+    for Nc in list(range(150, 420)) + [1001, 1022, 2047]:
+        for x0, xs in [(-7, 71), (-19, 103), (Nc - 90, 103), (Nc - 64 - 3, 79), (64 - 38, 142), (-304, 688 if Nc > 700 else 100)]:
+            if (xs + 4 > Nc and Nc % 4) or (x0 < 0 and not (x0 > -Nc and x0 + xs > 0)):
+                continue  # (a strip's window is shorter than the row and, where it starts left of column 0, reaches across it)
+            pad = L.emu_swt_stage_pad(x0, xs, Nc)
+            assert 0 <= pad < 4
+            xa = x0 - pad
+            for g in range((pad + xs + 3) // 4):
+                q = xa + 4 * g                     # a group covers columns q .. q + 3 of the periodic row
+                lo, hi = q % Nc, (q + 3) % Nc
+                assert hi == lo + 3 or q + 3 < x0 or q >= x0 + xs, (Nc, x0, xs, pad, g)  # inside the needed window no group wraps
+
+
 @pytest.mark.parametrize("seg", [0, 32])
 @pytest.mark.parametrize("wname", ["db3", "db4", "db5", "sym8", "db10", "db13", "db20"])
 def test_emu_swt_forward_level_in_one_launch(wname, seg):
