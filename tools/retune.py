@@ -27,6 +27,9 @@ SWEEPS = {
     "wave_min_log2": (("wave_min_log2",), (21, 23), ("db4:2048x2048:4:1", "db4:1448x1448:3:1", "db4:4096x4096:4:1")),
     "swt_split_fwd_big_taps": (("swt_split_fwd",), (12, 16, 18), ("swt:db6:2048x2048:3:1", "swt:db7:2048x2048:3:1", "swt:sym8:2048x2048:3:1", "swt:sym8:1080x1920:3:1")),
     "swt_split_inv_taps": (("swt_split_inv",), (8, 12), ("swt:db4:2048x2048:3:1", "swt:db5:2048x2048:3:1", "swt:db6:2048x2048:3:1")),
+    "swt_fwdstream_taps": (("swt_fwdstream",), (0,), ("swt:db3:1024x1024:3:1", "swt:db4:2048x2048:3:1", "swt:sym8:1080x1920:3:1", "swt:db20:2048x2048:3:1")),
+    "swt_invstream_taps": (("swt_invstream",), (0,), ("swt:db3:1024x1024:3:1", "swt:db4:2048x2048:3:1", "swt:sym8:1080x1920:3:1", "swt:db13:2048x2048:3:1")),
+    "swt_colstream_taps": (("swt_colstream",), (0,), ("swt:db16:2048x2048:3:1", "swt:db20:2048x2048:3:1")),
 }
 
 
